@@ -1,0 +1,310 @@
+"""TEST INFRASTRUCTURE -- generate `tests/golden/*.npz` from the *reference itself*.
+
+Runs only in the build container (needs `/root/reference`); resolves the reference at run
+time through `oracle/ref_shells.py` and copies none of it.  For every fixture it
+  1. runs the reference's own Python (CPU, fp32) on seeded inputs / name-seeded weights,
+  2. asserts `oracle/s2f_oracle.py` reproduces it (bit-exact forward, fp32 round-off backward),
+  3. stores inputs + the reference's outputs as data.
+
+    python -m oracle.gen_golden            # rewrites tests/golden/
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import ref_shells as rs
+from oracle import s2f_oracle as so
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _close(a, b, rel, what):
+    d = (a - b).abs().max().item()
+    s = max(a.abs().max().item(), 1e-30)
+    assert d <= rel * s, f"{what}: maxdiff {d} vs scale {s}"
+    return d / s
+
+
+# --------------------------------------------------------------------------- a1/a2 neuron KATs
+def gen_lif(R):
+    Q = lambda: R.neuron.Q_IFNode(surrogate_function=R.surrogate.Quant())
+    out = {}
+    # (1) four stateful steps on the SURVEY vector, no reset in between
+    x = torch.tensor([0.3, 0.5, 1.5, 2.5, 8.6, 9.7, -0.7, 3.49])
+    n = Q()
+    counts = []
+    for _ in range(4):
+        counts.append(_np(n(x) * 8))
+    out["kat_x"] = _np(x); out["kat_counts"] = np.stack(counts); out["kat_v_final"] = _np(n.v)
+    # (2) round-half-to-even
+    xh = torch.tensor([0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 8.5, -0.5, 8.0, 0.0, -0.0, 8.0000001, 7.9999995])
+    out["half_x"] = _np(xh); out["half_counts"] = _np(Q()(xh) * 8)
+    # (3) two stateful steps with gradient through the membrane
+    xg = torch.tensor([0.3, 0.6, 4.2, 8.5, -1.0], requires_grad=True)
+    n = Q()
+    (n(xg).sum() + n(xg).sum()).backward()
+    out["grad2_x"] = _np(xg); out["grad2_gx"] = _np(xg.grad)
+    # (4) random T-step sequence with BPTT through the membrane chain, weights on every output and on v_T
+    g = torch.Generator().manual_seed(11)
+    T, N = 5, 4096
+    xs = (torch.randn(T, N, generator=g) * 3.0 + 1.0).requires_grad_(True)
+    v0 = (torch.randn(N, generator=g)).requires_grad_(True)
+    wy = torch.randn(T, N, generator=g)
+    wv = torch.randn(N, generator=g)
+    n = Q()
+    n.v = v0
+    ys = torch.stack([n(xs[t]) for t in range(T)])
+    ((ys * wy).sum() + (n.v * wv).sum()).backward()
+    out.update(seq_x=_np(xs), seq_v0=_np(v0), seq_wy=_np(wy), seq_wv=_np(wv), seq_y=_np(ys), seq_vT=_np(n.v),
+               seq_gx=_np(xs.grad), seq_gv0=_np(v0.grad))
+    # oracle check (numpy + torch restatements)
+    c, vT = so.lif_seq_numpy(_np(xs), _np(v0))
+    assert np.array_equal(c.astype(np.float32) / 8, out["seq_y"]) and np.array_equal(vT, out["seq_vT"])
+    c, vT = so.lif_seq_numpy(np.stack([_np(x)] * 4))
+    assert np.array_equal(c, out["kat_counts"].astype(np.uint8)) and np.array_equal(vT, out["kat_v_final"])
+    xs2 = torch.tensor(out["seq_x"], requires_grad=True); v02 = torch.tensor(out["seq_v0"], requires_grad=True)
+    v = v02; ys2 = []
+    for t in range(T):
+        y, v, _ = so.lif_step(xs2[t], v)
+        ys2.append(y)
+    ((torch.stack(ys2) * wy).sum() + (v * wv).sum()).backward()
+    assert torch.equal(xs2.grad, xs.grad) and torch.equal(v02.grad, v0.grad)
+    np.savez_compressed(os.path.join(OUT, "lif_kat.npz"), **out)
+    print("lif_kat ok")
+
+
+# --------------------------------------------------------------------------- a9 DCNv3 core
+def gen_dcn_core(R):
+    """Input distributions follow the reference's own (un-runnable) check script
+    ops_dcnv3/test.py:19-38: input = rand*0.01, offset = rand*10, mask softmax-normalised, seed 3."""
+    out = {}
+    cases = [  # N, H, W, G, Cg, K, stride, pad, dil, offset_scale
+        ("a", 2, 8, 8, 4, 16, 3, 1, 1, 1, 2.0),
+        ("b", 1, 7, 5, 2, 8, 3, 1, 1, 1, 1.0),      # odd sizes, the hot-path geometry (stride 1, pad 1)
+        ("c", 2, 9, 6, 3, 5, 3, 2, 1, 1, 1.7),      # stride 2
+        ("d", 1, 10, 10, 2, 4, 3, 1, 2, 2, 1.3),    # dilation 2
+    ]
+    torch.manual_seed(3)
+    for tag, N, H, W, G, Cg, K, s, p, d, osc in cases:
+        Ho = (H + 2 * p - (d * (K - 1) + 1)) // s + 1
+        Wo = (W + 2 * p - (d * (K - 1) + 1)) // s + 1
+        x = (torch.rand(N, H, W, G * Cg) * 0.01).requires_grad_(True)
+        off = (torch.rand(N, Ho, Wo, G * K * K * 2) * 10 - 3).requires_grad_(True)
+        m = torch.rand(N, Ho, Wo, G, K * K) + 1e-5
+        m = (m / m.sum(-1, keepdim=True)).reshape(N, Ho, Wo, G * K * K).requires_grad_(True)
+        y = R.dcn_fn.dcnv3_core_pytorch(x, off, m, K, K, s, s, p, p, d, d, G, Cg, osc)
+        gy = torch.randn(y.shape)
+        y.backward(gy)
+        x2, o2, m2 = (t.detach().clone().requires_grad_(True) for t in (x, off, m))
+        y2 = so.dcnv3_core(x2, o2, m2, G, Cg, K, s, p, d, osc)
+        y2.backward(gy)
+        # the reference builds its grid in normalised fp32 coordinates -> not bit-identical
+        _close(y, y2, 2e-4, f"dcn {tag} y"); _close(x.grad, x2.grad, 2e-4, f"dcn {tag} gx")
+        _close(off.grad, o2.grad, 2e-3, f"dcn {tag} goff"); _close(m.grad, m2.grad, 2e-4, f"dcn {tag} gm")
+        out.update({f"{tag}_geom": np.array([N, H, W, G, Cg, K, s, p, d], dtype=np.int64),
+                    f"{tag}_offset_scale": np.float32(osc), f"{tag}_x": _np(x), f"{tag}_offset": _np(off),
+                    f"{tag}_mask": _np(m), f"{tag}_y": _np(y), f"{tag}_gy": _np(gy), f"{tag}_gx": _np(x.grad),
+                    f"{tag}_goffset": _np(off.grad), f"{tag}_gmask": _np(m.grad)})
+    np.savez_compressed(os.path.join(OUT, "dcnv3_core.npz"), **out)
+    print("dcnv3_core ok")
+
+
+# --------------------------------------------------------------------------- model-level fixtures
+def _load_ref(cfg, training):
+    bb, hd = rs.build_reference_model(cfg)
+    st = so.make_params(cfg)
+    bb.load_state_dict({k[len("backbone."):]: v.detach().clone() for k, v in st.items() if k.startswith("backbone.")})
+    hd.load_state_dict({k[len("decode_head."):]: v.detach().clone() for k, v in st.items()
+                        if k.startswith("decode_head.")})
+    bb.train(training); hd.train(training)
+    return bb, hd, st
+
+
+def _ref_named(bb, hd):
+    yield from (("backbone." + n, m) for n, m in bb.named_modules())
+    yield from (("decode_head." + n, m) for n, m in hd.named_modules())
+
+
+def gen_e2e(R, cfg_name="C1_64"):
+    cfg = so.CONFIGS[cfg_name]
+    bb, hd, st = _load_ref(cfg, True)
+    fr, taps = {}, {}
+    lif_names = []
+    want_taps = ("backbone.block3.0.attn.attn_spike", "decode_head.pixel_decoder.encoder.layers.0.dcn.mask_spike",
+                 "decode_head.transformer_decoder.layers.1.cross_attn.attn.attn_spike", "decode_head.mask_embed_spike")
+    for n, m in _ref_named(bb, hd):
+        if isinstance(m, R.neuron.Q_IFNode):
+            lif_names.append(n)
+
+            def hook(mod, i, o, n=n):
+                fr[n] = float((o.detach() * 8).mean())
+                if n in want_taps:
+                    taps[n] = _np(o * 8).astype(np.uint8)
+            m.register_forward_hook(hook)
+    img = so.synthetic_image(cfg)
+    metas = [rs.Meta(cfg.H, cfg.W)] * cfg.B
+    R.functional.reset_net(bb); R.functional.reset_net(hd)
+    feats = bb(img)
+    cls, masks = hd(feats, metas)
+    so.headline_loss(cls, masks).backward()
+    rg = {"backbone." + k: p.grad for k, p in bb.named_parameters()}
+    rg.update({"decode_head." + k: p.grad for k, p in hd.named_parameters()})
+
+    net = so.OracleNet(st, cfg, True)
+    otaps = {}
+    net.tap = lambda n, y: otaps.__setitem__(n, y) if n in want_taps else None
+    ocls, omasks = net.forward(img)
+    so.headline_loss(ocls, omasks).backward()
+    assert torch.equal(cls, ocls) and torch.equal(masks, omasks), "oracle forward is not bit-exact vs reference"
+    assert set(fr) == set(net.firing) and all(fr[k] == net.firing[k] for k in fr)
+    for n in want_taps:
+        assert np.array_equal(taps[n], _np(otaps[n] * 8).astype(np.uint8)), n
+    gscale = max(g.abs().max().item() for g in rg.values() if g is not None)
+    worst = 0.0
+    for k, g in rg.items():
+        if g is None:
+            assert st[k].grad is None
+            continue
+        d = (g - st[k].grad).abs().max().item()
+        # parameters whose true gradient is zero (biases feeding a train-mode BN) hold only cancellation
+        # noise of order 1e-6 * gscale, hence the absolute term
+        worst = max(worst, d / (g.abs().max().item() + 5e-3 * gscale))
+    assert worst < 2e-3, worst
+    # updated BN running statistics (train mode mutates them)
+    rstats = {"backbone." + k: v for k, v in bb.state_dict().items() if "running_" in k}
+    rstats.update({"decode_head." + k: v for k, v in hd.state_dict().items() if "running_" in k})
+    for k, v in rstats.items():
+        # bit-equal except downstream of the DCN core, whose grid arithmetic is not bit-identical
+        assert torch.allclose(v, st[k], rtol=1e-5, atol=1e-6), k
+
+    # `encoder_in_proj_spike` is constructed but never called (pixel_decoder.py:396 vs :435): it is in
+    # named_modules() but produces no firing entry -- keep both lists
+    lif_names_all = list(lif_names)
+    lif_names = [n for n in lif_names if n in fr]
+    keys = [k for k, g in rg.items() if g is not None]
+    sel = ["backbone.downsample1_1.encode_conv.weight", "backbone.block3.0.attn.q_conv.0.body.0.weight",
+           "backbone.block4.1.mlp.fc2_conv.weight", "decode_head.pixel_decoder.encoder.layers.0.dcn.offset.0.weight",
+           "decode_head.pixel_decoder.encoder.layers.1.gamma2", "decode_head.pixel_decoder.mask_feature.weight",
+           "decode_head.transformer_decoder.layers.0.cross_attn.attn.k_conv.0.weight",
+           "decode_head.mask_embed.fc1.weight", "decode_head.query_feat.weight", "decode_head.w"]
+    out = dict(
+        cfg_name=np.array(cfg_name), img=_np(img), cls=_np(cls), masks=_np(masks),
+        feat_x4=_np(feats[3]), feat_absmean=np.array([float(f.abs().mean()) for f in feats], dtype=np.float64),
+        lif_names=np.array(lif_names), lif_names_all=np.array(lif_names_all),
+        firing=np.array([fr[n] for n in lif_names], dtype=np.float64),
+        grad_keys=np.array(keys), grad_absmax=np.array([rg[k].abs().max().item() for k in keys], dtype=np.float64),
+        grad_sum=np.array([rg[k].double().sum().item() for k in keys], dtype=np.float64),
+        sel_keys=np.array(sel), stat_keys=np.array(sorted(rstats)),
+        stat_sum=np.array([rstats[k].double().sum().item() for k in sorted(rstats)], dtype=np.float64))
+    for i, k in enumerate(sel):
+        out[f"sel_grad_{i}"] = _np(rg[k])
+    for n in want_taps:
+        out["tap__" + n] = taps[n]
+    np.savez_compressed(os.path.join(OUT, f"e2e_{cfg_name}.npz"), **out)
+    print(f"e2e_{cfg_name} ok: {len(lif_names)} neurons, worst grad rel {worst:.2e}, grad scale {gscale:.3g}")
+
+
+def gen_stateful(R, cfg_name="C1_64"):
+    """cal_firing_num.py semantics (tools/cal_firing_num.py:203-225): eval mode, successive images, NO reset
+    between them -> membranes carry over.  Three images; firing table per call and the accumulated table."""
+    cfg = so.CONFIGS[cfg_name]
+    bb, hd, st = _load_ref(cfg, False)
+    lif_names, fr = [], {}
+    for n, m in _ref_named(bb, hd):
+        if isinstance(m, R.neuron.Q_IFNode):
+            lif_names.append(n)
+            m.register_forward_hook(lambda mod, i, o, n=n: fr.__setitem__(n, float((o.detach() * 8).mean())))
+    net = so.OracleNet({k: v.detach() for k, v in st.items()}, cfg, False)
+    metas = [rs.Meta(cfg.H, cfg.W)] * cfg.B
+    R.functional.reset_net(bb); R.functional.reset_net(hd)
+    tables, imgs = [], []
+    with torch.no_grad():
+        for i in range(3):
+            img = so.synthetic_image(cfg, seed=100 + i)
+            cls, masks = hd(bb(img), metas)
+            ocls, omasks = net.forward(img)
+            assert torch.equal(cls, ocls) and torch.equal(masks, omasks), f"stateful call {i}"
+            assert all(fr[k] == net.firing[k] for k in fr)
+            if i == 0:
+                lif_names = [n for n in lif_names if n in fr]
+            tables.append([fr[n] for n in lif_names]); imgs.append(_np(img))
+    np.savez_compressed(os.path.join(OUT, f"stateful_{cfg_name}.npz"), cfg_name=np.array(cfg_name),
+                        seeds=np.array([100, 101, 102]), lif_names=np.array(lif_names),
+                        firing=np.array(tables, dtype=np.float64), cls_last=_np(cls), masks_last=_np(masks))
+    print(f"stateful_{cfg_name} ok")
+
+
+def gen_blocks(R):
+    """Per-block fixtures (a5 attention, a6 RepConv, a9 DCNv3 module + encoder layer, a10 decoder layer):
+    reference sub-modules of the C1_64 model run stand-alone on seeded inputs; outputs and input-gradients stored."""
+    cfg = so.CONFIGS["C1_64"]
+    bb, hd, st = _load_ref(cfg, True)
+    net = so.OracleNet(st, cfg, True)
+    g = torch.Generator().manual_seed(5)
+    T, B = cfg.T, cfg.B
+    out = {}
+
+    def run(tag, ref_fn, orc_fn, *xs):
+        R.functional.reset_net(bb); R.functional.reset_net(hd); net.reset()
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        xo = [x.clone().requires_grad_(True) for x in xs]
+        yr = ref_fn(*xr); yo = orc_fn(*xo)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy); yo.backward(gy)
+        fwd = _close(yr, yo, 1e-5, tag + " y")
+        for i, (a, b) in enumerate(zip(xr, xo)):
+            _close(a.grad, b.grad, 2e-3, f"{tag} gx{i}")
+            out[f"{tag}_x{i}"] = _np(xs[i]); out[f"{tag}_gx{i}"] = _np(a.grad)
+        out[f"{tag}_y"] = _np(yr); out[f"{tag}_gy"] = _np(gy)
+        print(f"  block {tag}: fwd rel {fwd:.1e}")
+
+    C3 = cfg.embed_dim[2]
+    x = torch.randn(T, B, C3, 4, 4, generator=g) * 2
+    run("attn", bb.block3[1].attn, lambda a: net._attn("backbone.block3.1.attn", a), x)
+    run("repconv", lambda a: bb.block3[2].attn.q_conv(a), lambda a: net._repconv_bn("backbone.block3.2.attn.q_conv", a),
+        torch.randint(0, 9, (T * B, C3, 4, 4), generator=g).float() / 8)
+    run("block3", bb.block3[3], lambda a: net._block("backbone.block3.3", a), x)
+    Fc = cfg.feat_channels
+    q = torch.randn(T, B, 6, 5, Fc, generator=g) * 2
+    L = hd.pixel_decoder.encoder.layers[0]
+    run("dcn", L.dcn, lambda a: net._dcn("decode_head.pixel_decoder.encoder.layers.0.dcn", a), q)
+    run("enc_layer", hd.pixel_decoder.encoder.layers[1],
+        lambda a: net._enc_layer("decode_head.pixel_decoder.encoder.layers.1", a), q)
+    D = hd.transformer_decoder.layers[0]
+    nq, nk = cfg.num_queries, 30
+    qq = torch.randn(T, B, nq, Fc, generator=g) * 2
+    kk = torch.randn(T, B, nk, Fc, generator=g) * 2
+    qp = torch.randn(B, nq, Fc, generator=g); kp = torch.randn(B, nk, Fc, generator=g)
+    run("dec_layer", lambda a, b: D(query=a, key=b, value=b, query_pos=qp, key_pos=kp),
+        lambda a, b: net._dec_layer("decode_head.transformer_decoder.layers.0", a, b, qp, kp), qq, kk)
+    out["dec_layer_qpos"] = _np(qp); out["dec_layer_kpos"] = _np(kp)
+    pe = R.pe.SinePositionalEncoding(num_feats=cfg.num_feats, normalize=True)(torch.zeros(2, 6, 5, dtype=torch.bool))
+    assert torch.equal(pe, so.sine_pos_embed(2, 6, 5, cfg.num_feats))
+    out["pos_embed_2x6x5"] = _np(pe)
+    np.savez_compressed(os.path.join(OUT, "blocks_C1_64.npz"), **out)
+    print("blocks ok")
+
+
+def main():
+    if not rs.available():
+        sys.exit("reference tree not mounted; fixtures can only be regenerated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    R = rs.load()
+    gen_lif(R)
+    gen_dcn_core(R)
+    gen_blocks(R)
+    gen_e2e(R)
+    gen_stateful(R)
+    for f in sorted(os.listdir(OUT)):
+        print(f"{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
