@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+backward images/sec of the Spike2Former hot path on N MI355X (one process per GPU).
+
+A "step" is one pass of the hot path over one synthetic batch: reset every membrane (what
+ResetModelHook does before each iteration) -> forward (Meta-SpikeFormer backbone + MaskFormer head) -> scalar loss
+`cls.mean() + masks.mean()` -> backward -> (N > 1) one RCCL all-reduce of the flat gradient buffer.  Optimiser excluded.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events on the LIF kernels")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload):
+    """The oracle (a port of the reference's PyTorch CPU path, pinned against it on golden vectors) timed on this box's
+    host cores: ONE fwd+bwd step at the workload's shapes with B=1 -- a bounded sample of the same workload."""
+    import torch
+
+    from oracle import s2f_oracle as so        # cpu_baseline leg only
+    import dataclasses
+    cfg = dataclasses.replace(so.CONFIGS[workload], B=1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = so.make_params(cfg)
+    net = so.OracleNet(st, cfg, training=True)
+    img = so.synthetic_image(cfg)
+    t0 = time.perf_counter()
+    net.reset()
+    cls, masks = net.forward(img)
+    so.headline_loss(cls, masks).backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(cfg.B / dt, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 un-warmed fwd+bwd step, B=1, {cfg.H}x{cfg.W}, T={cfg.T}, fp32, oracle/s2f_oracle.py "
+                      f"(torch {torch.__version__} CPU kernels), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import spike2former_amd as s2f
+    from spike2former_amd import ops
+    from spike2former_amd.dist import FlatGradAllReduce, broadcast_params, init_process_group
+    from spike2former_amd.init_utils import seeded_init
+
+    rank, world, local = init_process_group()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True          # let MIOpen pick its fastest solver for the library convolutions
+
+    w = s2f.WORKLOADS[args.workload]
+    B = w["B"]                                      # per-GPU batch: weak scaling (BASELINE.json configs[1]: batch=2 on 1 GPU)
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg(args.workload))).to(dev).train()
+    broadcast_params(model)
+    s2f.set_keep_membrane(model, False)             # a reset precedes every step -> the membrane is never read back
+    red = FlatGradAllReduce(model.parameters(), world)
+    img = torch.randn(B, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+
+    def step():
+        s2f.reset_net(model)
+        red.zero()
+        cls, masks = model(img)
+        s2f.headline_loss(cls, masks).backward()
+        red.reduce()
+        red.wait()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "fwd+bwd images/sec, 512x512 T=4 ADE20K-150" if args.workload == "C2" else f"fwd+bwd images/sec ({args.workload})",
+            "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']} Meta-SpikeFormer "
+                                   f"{w['embed_dim']} + MaskFormer head, per-GPU batch {B}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"},
+        }
+        if events:
+            # per-launch HIP events recorded on the launch stream inside the timed region (ops.KERNEL_EVENTS)
+            agg = {}
+            for name, nbytes, e0, e1 in events:
+                a = agg.setdefault(name, [0, 0.0, 0])
+                a[0] += nbytes; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            for name, key in (("lif_fwd", "roofline"), ("lif_bwd", "roofline_lif_bwd")):
+                if name in agg:
+                    nbytes, secs, launches = agg[name]
+                    gbs = nbytes / secs / 1e9
+                    out[key] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
+                                "algorithmic_bytes_per_launch": nbytes // launches}
+            out["lif_time_frac"] = round(sum(a[1] for a in agg.values()) / dt, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            del model, red
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+/*
+ * s2f.h -- C ABI of libs2f_hip.so: the MI355X (gfx950) kernels of the Spike2Former hot path.
+ *
+ * Conventions (every entry point):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross this boundary.
+ *   - all pointers are DEVICE pointers owned by the caller; nothing is allocated or freed inside;
+ *     `?` in a comment marks a nullable pointer.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are asynchronous.
+ *   - return value: S2F_OK (0) or a negative S2F_E* code; `s2f_last_error()` gives the text.
+ *   - re-entrant, no global state apart from the thread-local error string.
+ *
+ * The reference (BICLab/Spike2Former) has no FFI on its live path -- everything is ATen ops called from
+ * Python.  The in-tree precedents this ABI follows are the (dormant) pybind pair
+ * `dcnv3_forward/backward` (ops_dcnv3/src/vision.cpp:14-17, argument list src/dcnv3.h:20-59) and the cupy
+ * raw-pointer launch convention (Qtrick_architecture/clock_driven/cu_kernel_opt.py:53-71).  Each function
+ * below names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ */
+#ifndef S2F_H
+#define S2F_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2F_OK 0
+#define S2F_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported geometry) */
+#define S2F_EALIGN (-2)   /* pointer not aligned as required */
+#define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
+
+#define S2F_ABI_VERSION 1
+
+int s2f_version(void);
+const char* s2f_last_error(void);
+
+/* Number of uint64 words of the in-range bitmask for n elements: 4 words per 256-element tile.
+ * Tile i covers elements [256 i, 256 i + 256); word j (0..3) bit l (0..63) belongs to element 256 i + 4 l + j
+ * (lane l of a wavefront holds 4 consecutive elements; word j is the wave ballot of component j). */
+int64_t s2f_lif_mask_words(int64_t n);
+
+/* ---- a1/a2: Q_IFNode.forward + quant STE ------------------------------------------------------------
+ * Replaces BaseNode.forward (Qtrick_architecture/clock_driven/neuron.py:166-197; charge :459-460, soft reset
+ * :133-153) with `quant` (surrogate.py:522-538) as surrogate:
+ *     h = v_in + x ; s = rint(clamp(h, 0, D)) (round-half-even) ; v_out = h - s*vth ; y = s / D
+ *     mask bit = (0 <= h <= D)                          (what the STE backward needs instead of fp32 h)
+ * v_in? NULL == membrane freshly reset (python float 0.).  v_out? NULL == membrane not kept.
+ * mask? NULL == no backward wanted.  count_u8? NULL == integer counts not wanted.
+ * stats? : uint64[2], atomically accumulated {sum of counts s, number of non-zero s} (cal_firing_num.py:138-160
+ *          accumulates mean(y*D) = stats[0]/n; firing_utils non-zero rate = stats[1]/n).
+ * x, y, v_* need 16-byte alignment when n >= 4. */
+int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
+                uint64_t* stats, int64_t n, float vth, int D, void* stream);
+
+/* STE backward of one step:  gx = gv_out + (gy / D - gv_out * vth) * m   (gv_out? NULL == 0; dL/dv_in == gx). */
+int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth, int D,
+                void* stream);
+
+/* ---- T successive stateful calls on one neuron, membrane carried in registers -----------------------
+ * Same arithmetic as T calls of s2f_lif_fwd with v chained (what tools/cal_firing_num.py:203-225 does across
+ * images; structural precedent: the dormant cupy kernel IFNode_fptt_softReset, neuron_kernel.py:19-119).
+ * x_seq, y_seq: [T, n]; mask: [T, s2f_lif_mask_words(n)]; v0? / vT? : [n]. stats?: uint64[2*T]. */
+int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq, float* vT, uint64_t* mask, uint64_t* stats,
+                    int T, int64_t n, float vth, int D, void* stream);
+/* BPTT: g_h[t] = g_h[t+1] + (gy[t]/D - g_h[t+1]*vth) * m[t], g_h[T] := gvT (NULL == 0); gx_seq[t] = g_h[t]; gv0? = g_h[0]. */
+int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask, float* gx_seq, float* gv0, int T,
+                    int64_t n, float vth, int D, void* stream);
+
+/* ---- a5 / a10: spike-driven (softmax-free) attention core --------------------------------------------
+ * Replaces  kv = k^T @ v ; o = (q @ kv) * scale ; o.transpose(3,4).reshape(T,B,C,N)
+ * (MS_Attention_RepConv_qkv_id, mmseg/models/backbones/sdtv2.py:308-339) and the decoder's
+ * (q k^T / sqrt(C)) v  ((Cross)MultiHeadAttentionBlock, mmcv_spike/transformer.py:253-274, :334-355 -- no softmax,
+ * so the same bilinear form) on spikes laid out channel-major [TB, C, N] (channel c = head*d + j), i.e. directly on
+ * the *_spike outputs without the reference's permute/contiguous copies.  d = C / heads <= 64.
+ * q, o: [TB, C, Nq]; k, v: [TB, C, Nk]; kv_save: [TB, heads, d, d] (kept for backward).
+ * With spike inputs (multiples of 1/D) every partial sum is an exactly representable fp32 while it stays below
+ * 2^24 ulps -- the result is then independent of summation order and equals the reference's bit for bit. */
+int s2f_sdsa_fwd(const float* q, const float* k, const float* v, float* o, float* kv_save, int TB, int heads, int d,
+                 int Nq, int Nk, float scale, void* stream);
+/* gq = scale * go kv^T ; gkv = scale * q^T go ; gk = v gkv^T ; gv = k gkv.   gkv_ws: [TB, heads, d, d] scratch. */
+int s2f_sdsa_bwd(const float* q, const float* k, const float* v, const float* kv_save, const float* go, float* gq,
+                 float* gk, float* gv, float* gkv_ws, int TB, int heads, int d, int Nq, int Nk, float scale,
+                 void* stream);
+/* The two building blocks (exported for tests and for callers that fuse differently):
+ *   kv[tb,h][i][j]    = alpha * sum_n k[tb, h*d+i, n] * v[tb, h*d+j, n]
+ *   y[tb, h*d+j, n]   = alpha * sum_i x[tb, h*d+i, n] * m[tb,h][i][j]      (transpose_m != 0: m[j][i]) */
+int s2f_sdsa_kv(const float* k, const float* v, float* kv, int TB, int heads, int d, int N, float alpha, void* stream);
+int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, int heads, int d, int N, float alpha,
+                   int transpose_m, void* stream);
+
+/* ---- a9: DCNv3 core ---------------------------------------------------------------------------------
+ * Replaces dcnv3_core_pytorch (ops_dcnv3/functions/dcnv3_func.py:147-189; = the dormant CUDA op
+ * dcnv3_forward/backward, ops_dcnv3/src/dcnv3.h:20-59, same geometry tuple).  Layouts:
+ *   input [N, H, W, G*Cg]; offset [N, Ho, Wo, G*K*K*2] ((x, y) per tap, tap k = i_w*Kh + j_h);
+ *   mask [N, Ho, Wo, G*K*K]; output [N, Ho, Wo, G*Cg].   Bilinear, zero outside the zero-padded input. */
+int s2f_dcnv3_fwd(const float* input, const float* offset, const float* mask, float* output, int N, int H, int W,
+                  int G, int Cg, int Kh, int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                  float offset_scale, void* stream);
+/* grad_input must be zero-filled by the caller (atomic scatter-add into it). */
+int s2f_dcnv3_bwd(const float* input, const float* offset, const float* mask, const float* grad_output,
+                  float* grad_input, float* grad_offset, float* grad_mask, int N, int H, int W, int G, int Cg, int Kh,
+                  int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float offset_scale,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2F_H */

@@ -1,0 +1,53 @@
+"""ctypes binding of libs2f_hip.so (the C ABI declared in include/s2f.h).
+
+There is deliberately no fallback: if the shared library is missing or an entry point is absent the import
+fails loudly, and every op raises when handed a non-CUDA tensor.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs2f_hip.so")
+
+_p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/s2f.h one to one (tests/test_abi.py parses the header and checks).
+SIGNATURES = {
+    "s2f_version": (_i, []),
+    "s2f_last_error": (ctypes.c_char_p, []),
+    "s2f_lif_mask_words": (_i64, [_i64]),
+    "s2f_lif_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _i, _p]),
+    "s2f_lif_bwd": (_i, [_p, _p, _p, _p, _i64, _f, _i, _p]),
+    "s2f_lif_seq_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i64, _f, _i, _p]),
+    "s2f_lif_seq_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i64, _f, _i, _p]),
+    "s2f_sdsa_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "s2f_sdsa_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _f, _p]),
+    "s2f_sdsa_kv": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "s2f_sdsa_apply": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "s2f_dcnv3_fwd": (_i, [_p] * 4 + [_i] * 13 + [_f, _p]),
+    "s2f_dcnv3_bwd": (_i, [_p] * 7 + [_i] * 13 + [_f, _p]),
+}
+
+
+class S2FError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C spike2former_amd/csrc`). spike2former_amd has no CPU / PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise S2FError(f"{what} failed (rc={rc}): {lib.s2f_last_error().decode()}")

@@ -1,0 +1,290 @@
+"""Meta-SpikeFormer (SDT-v2) backbone on the MI355X kernels.
+
+Mirrors the registry surface of the reference backbone -- class names, constructor kwargs and state_dict keys of
+mmseg/models/backbones/sdtv2.py:48-655 -- so reference configs and checkpoints load unchanged.  Every Q_IFNode, and
+the softmax-free attention core, run in libs2f_hip.so; dense/depthwise convolutions and train-mode BatchNorm go
+through ATen (MIOpen / rocBLAS) as plain library calls.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .neuron import Q_IFNode, Quant
+from .registry import MODELS
+
+
+def _lif():
+    return Q_IFNode(surrogate_function=Quant())
+
+
+class BNAndPadLayer(nn.Module):
+    """BatchNorm2d, then a 1-pixel border filled with BN(0) computed from the *running* statistics
+    (sdtv2.py:48-89) -- also in training, where the interior is normalised with batch statistics."""
+
+    def __init__(self, pad_pixels, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(num_features, eps, momentum, affine, track_running_stats)
+        self.pad_pixels = pad_pixels
+
+    def forward(self, x):
+        out = self.bn(x)
+        p = self.pad_pixels
+        if p > 0:
+            bn = self.bn
+            std = torch.sqrt(bn.running_var + bn.eps)
+            if bn.affine:
+                pad = bn.bias.detach() - bn.running_mean * bn.weight.detach() / std
+            else:
+                pad = -bn.running_mean / std
+            N, C, H, W = out.shape
+            full = pad.view(1, C, 1, 1).expand(N, C, H + 2 * p, W + 2 * p).clone()
+            full[:, :, p:-p, p:-p] = out
+            out = full
+        return out
+
+    weight = property(lambda self: self.bn.weight)
+    bias = property(lambda self: self.bn.bias)
+    running_mean = property(lambda self: self.bn.running_mean)
+    running_var = property(lambda self: self.bn.running_var)
+    eps = property(lambda self: self.bn.eps)
+
+
+class RepConv(nn.Module):
+    """conv1x1 -> BNAndPad -> depthwise 3x3 (no padding) -> conv1x1 -> BN  (sdtv2.py:112-132); not re-parameterised
+    at train time, as in the reference."""
+
+    def __init__(self, in_channel, out_channel, bias=False):
+        super().__init__()
+        conv1x1 = nn.Conv2d(in_channel, in_channel, 1, 1, 0, bias=False, groups=1)
+        bn = BNAndPadLayer(pad_pixels=1, num_features=in_channel)
+        conv3x3 = nn.Sequential(
+            nn.Conv2d(in_channel, in_channel, 3, 1, 0, groups=in_channel, bias=False),
+            nn.Conv2d(in_channel, out_channel, 1, 1, 0, groups=1, bias=False),
+            nn.BatchNorm2d(out_channel))
+        self.body = nn.Sequential(conv1x1, bn, conv3x3)
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class SepConv(nn.Module):
+    """LIF -> pw 1x1 (C->2C) -> BN -> LIF -> dw 7x7 -> pw 1x1 (2C->C) -> BN   (sdtv2.py:135-180)."""
+
+    def __init__(self, dim, expansion_ratio=2, act2_layer=nn.Identity, bias=False, kernel_size=7, padding=3, T=None):
+        super().__init__()
+        med = int(expansion_ratio * dim)
+        self.spike1 = _lif()
+        self.pwconv1 = nn.Conv2d(dim, med, kernel_size=1, stride=1, bias=bias)
+        self.bn1 = nn.BatchNorm2d(med)
+        self.spike2 = _lif()
+        self.dwconv = nn.Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias)
+        self.pwconv2 = nn.Conv2d(med, dim, kernel_size=1, stride=1, bias=bias)
+        self.bn2 = nn.BatchNorm2d(dim)
+
+    def forward(self, x):
+        T, B, C, H, W = x.shape
+        x = self.spike1(x)
+        x = self.bn1(self.pwconv1(x.flatten(0, 1)))
+        x = self.spike2(x)
+        x = self.dwconv(x)
+        return self.bn2(self.pwconv2(x)).reshape(T, B, C, H, W)
+
+
+class MS_ConvBlock(nn.Module):
+    """x += SepConv(x);  x += BN(conv3x3(LIF(BN(conv3x3(LIF(x))))))   (sdtv2.py:183-219)."""
+
+    def __init__(self, dim, mlp_ratio=4.0, T=4):
+        super().__init__()
+        self.T = T
+        self.Conv = SepConv(dim=dim)
+        self.mlp_ratio = mlp_ratio
+        self.spike1 = _lif()
+        self.conv1 = nn.Conv2d(dim, dim * mlp_ratio, kernel_size=3, padding=1, groups=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(dim * mlp_ratio)
+        self.spike2 = _lif()
+        self.conv2 = nn.Conv2d(dim * mlp_ratio, dim, kernel_size=3, padding=1, groups=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(dim)
+
+    def forward(self, x):
+        T, B, C, H, W = x.shape
+        x = self.Conv(x) + x
+        feat = x
+        x = self.spike1(x)
+        x = self.bn1(self.conv1(x.flatten(0, 1)))
+        x = self.spike2(x)
+        x = self.bn2(self.conv2(x)).reshape(T, B, C, H, W)
+        return feat + x
+
+
+class MS_MLP(nn.Module):
+    """LIF -> Conv1d(C->4C) -> BN1d -> LIF -> Conv1d(4C->C) -> BN1d on [T,B,C,N]   (sdtv2.py:222-255)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.0, layer=0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1_conv = nn.Conv1d(in_features, hidden_features, kernel_size=1, stride=1)
+        self.fc1_bn = nn.BatchNorm1d(hidden_features)
+        self.fc1_spike = _lif()
+        self.fc2_conv = nn.Conv1d(hidden_features, out_features, kernel_size=1, stride=1)
+        self.fc2_bn = nn.BatchNorm1d(out_features)
+        self.fc2_spike = _lif()
+        self.c_hidden = hidden_features
+        self.c_output = out_features
+
+    def forward(self, x):
+        T, B, C, H, W = x.shape
+        x = self.fc1_spike(x.flatten(3))
+        x = self.fc1_bn(self.fc1_conv(x.flatten(0, 1)))
+        x = self.fc2_spike(x)
+        return self.fc2_bn(self.fc2_conv(x)).reshape(T, B, C, H, W)
+
+
+class MS_Attention_RepConv_qkv_id(nn.Module):
+    """Spike-driven self-attention (sdtv2.py:258-344): q,k,v = LIF(BN(RepConv(LIF(x)))); o = scale * q (k^T v);
+    proj(LIF(o)).  The core runs as ops.sdsa directly on the channel-major spikes (no head permutes)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, sr_ratio=1,
+                 T=None):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim = dim
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.head_spike = _lif()
+        self.q_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
+        self.k_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
+        self.v_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
+        self.q_spike = _lif()
+        self.k_spike = _lif()
+        self.v_spike = _lif()
+        self.attn_spike = _lif()
+        self.proj_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
+
+    def forward(self, x):
+        T, B, C, H, W = x.shape
+        N = H * W
+        x = self.head_spike(x).flatten(0, 1)
+        q = self.q_spike(self.q_conv(x)).view(T * B, C, N)
+        k = self.k_spike(self.k_conv(x)).view(T * B, C, N)
+        v = self.v_spike(self.v_conv(x)).view(T * B, C, N)
+        o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
+        o = self.attn_spike(o).view(T * B, C, H, W)
+        return self.proj_conv(o).reshape(T, B, C, H, W)
+
+
+class MS_Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, norm_layer=nn.LayerNorm, sr_ratio=1, T=None):
+        super().__init__()
+        if drop_path > 0.0:
+            raise NotImplementedError("drop_path > 0 is not used by any Spike2Former config")
+        self.attn = MS_Attention_RepConv_qkv_id(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                                attn_drop=attn_drop, proj_drop=drop, sr_ratio=sr_ratio)
+        self.drop_path = nn.Identity()
+        self.mlp = MS_MLP(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
+
+    def forward(self, x):
+        x = x + self.attn(x)
+        return x + self.mlp(x)
+
+
+class MS_DownSampling(nn.Module):
+    """[LIF ->] conv(k, s) -> BN   (sdtv2.py:386-421)."""
+
+    def __init__(self, in_channels=2, embed_dims=256, kernel_size=3, stride=2, padding=1, first_layer=True, T=None):
+        super().__init__()
+        self.encode_conv = nn.Conv2d(in_channels, embed_dims, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.encode_bn = nn.BatchNorm2d(embed_dims)
+        self.first_layer = first_layer
+        if not first_layer:
+            self.encode_spike = _lif()
+
+    def forward(self, x):
+        T, B = x.shape[:2]
+        if hasattr(self, "encode_spike"):
+            x = self.encode_spike(x)
+        x = self.encode_bn(self.encode_conv(x.flatten(0, 1)))
+        return x.reshape(T, B, *x.shape[1:])
+
+
+@MODELS.register_module()
+class Spiking_vit_MetaFormer(nn.Module):
+    """Registry type 'Spiking_vit_MetaFormer' (sdtv2.py:424-655).  forward(img [B,3,H,W]) -> 4 maps [T,B,C_i,H_i,W_i]
+    at strides 2, 4, 8, 16 for decode_mode='Qsnn'.  Block counts 6 and 2 are fixed as in the reference (:536,565)."""
+
+    def __init__(self, img_size_h=128, img_size_w=128, patch_size=16, in_channels=2, num_classes=11,
+                 embed_dim=(64, 128, 256), num_heads=(1, 2, 4), mlp_ratios=(4, 4, 4), qkv_bias=False, qk_scale=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, norm_layer=nn.LayerNorm, depths=(6, 8, 6),
+                 sr_ratios=(8, 4, 2), T=1, decode_mode="snn", init_cfg=None,
+                 norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, pretrained=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+        self.num_classes = num_classes
+        self.depths = depths
+        self.T = T
+        self.decode_mode = decode_mode
+        self.freeze_bn_ = norm_eval          # accepted but unused, as in the reference (:448,457)
+        self.norm_cfg = norm_cfg
+        if drop_path_rate != 0.0:
+            raise NotImplementedError("drop_path_rate != 0 is not used by any Spike2Former config")
+        e = list(embed_dim)
+        blk = dict(num_heads=num_heads, mlp_ratio=mlp_ratios, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                   attn_drop=attn_drop_rate, drop_path=0.0, norm_layer=norm_layer, sr_ratio=sr_ratios)
+        self.downsample1_1 = MS_DownSampling(in_channels, e[0] // 2, kernel_size=7, stride=2, padding=3,
+                                             first_layer=True)
+        self.ConvBlock1_1 = nn.ModuleList([MS_ConvBlock(dim=e[0] // 2, mlp_ratio=mlp_ratios)])
+        self.downsample1_2 = MS_DownSampling(e[0] // 2, e[0], kernel_size=3, stride=2, padding=1, first_layer=False)
+        self.ConvBlock1_2 = nn.ModuleList([MS_ConvBlock(dim=e[0], mlp_ratio=mlp_ratios)])
+        self.downsample2 = MS_DownSampling(e[0], e[1], kernel_size=3, stride=2, padding=1, first_layer=False)
+        self.ConvBlock2_1 = nn.ModuleList([MS_ConvBlock(dim=e[1], mlp_ratio=mlp_ratios)])
+        self.ConvBlock2_2 = nn.ModuleList([MS_ConvBlock(dim=e[1], mlp_ratio=mlp_ratios)])
+        self.downsample3 = MS_DownSampling(e[1], e[2], kernel_size=3, stride=2, padding=1, first_layer=False)
+        self.block3 = nn.ModuleList([MS_Block(dim=e[2], **blk) for _ in range(6)])
+        self.downsample4 = MS_DownSampling(e[2], e[3], kernel_size=3, stride=1, padding=1, first_layer=False)
+        self.block4 = nn.ModuleList([MS_Block(dim=e[3], **blk) for _ in range(2)])
+
+    def init_weights(self):
+        """Load `init_cfg['checkpoint']`, stripping a leading 'backbone.' from the keys, strict=False (:577-612)."""
+        if self.init_cfg is None:
+            return
+        assert "checkpoint" in self.init_cfg, f"Only support specify `Pretrained` in `init_cfg` in {type(self).__name__}"
+        ckpt = torch.load(self.init_cfg["checkpoint"], map_location="cpu")
+        sd = ckpt.get("state_dict", ckpt.get("model", ckpt))
+        sd = OrderedDict((k[9:] if k.startswith("backbone.") else k, v) for k, v in sd.items())
+        return self.load_state_dict(sd, strict=False)
+
+    def forward_features(self, x):
+        x = x.unsqueeze(0).repeat(self.T, 1, 1, 1, 1)
+        x = self.downsample1_1(x)
+        for b in self.ConvBlock1_1:
+            x = b(x)
+        x1 = x
+        x = self.downsample1_2(x)
+        for b in self.ConvBlock1_2:
+            x = b(x)
+        x2 = x
+        x = self.downsample2(x)
+        for b in self.ConvBlock2_1:
+            x = b(x)
+        for b in self.ConvBlock2_2:
+            x = b(x)
+        x3 = x
+        x = self.downsample3(x)
+        for b in self.block3:
+            x = b(x)
+        x = self.downsample4(x)
+        for b in self.block4:
+            x = b(x)
+        x4 = x
+        if self.decode_mode == "snn":
+            return [t.mean(0, keepdim=True) for t in (x1, x2, x3, x4)]
+        if self.decode_mode == "Qsnn":
+            return [x1, x2, x3, x4]
+        return [t.flatten(0, 1) for t in (x1, x2, x3, x4)]
+
+    def forward(self, x):
+        return self.forward_features(x)

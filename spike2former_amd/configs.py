@@ -1,0 +1,42 @@
+"""The BASELINE.json workloads as model configs, in the reference's own config vocabulary
+(configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:23-131)."""
+from .registry import ConfigDict
+
+WORKLOADS = {
+    # name: H, W, T, per-GPU batch, classes, embed_dim, feat_channels, queries, pd layers/ffn, dec layers/ffn, group, num_feats
+    "C1": dict(H=128, W=128, T=1, B=1, K=20, embed_dim=[16, 32, 64, 72], Fc=64, Q=10, pd=(2, 256), dec=(2, 512), G=8, nf=32),
+    "C1_64": dict(H=64, W=64, T=2, B=2, K=20, embed_dim=[16, 32, 64, 72], Fc=64, Q=10, pd=(2, 256), dec=(2, 512), G=8, nf=32),
+    "C2": dict(H=512, W=512, T=4, B=2, K=150, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 1024), dec=(6, 2048), G=32, nf=128),
+    "C3": dict(H=512, W=1024, T=4, B=2, K=19, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 2048), dec=(6, 2048), G=32, nf=128),
+    "C4": dict(H=512, W=512, T=8, B=2, K=150, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 1024), dec=(6, 2048), G=32, nf=128),
+}
+
+
+def model_cfg(name):
+    w = WORKLOADS[name]
+    e, Fc = w["embed_dim"], w["Fc"]
+    norm_cfg = dict(type="SyncBN", requires_grad=True)       # accepted and ignored, as in the reference
+    return ConfigDict(
+        type="EncoderDecoder",
+        backbone=dict(type="Spiking_vit_MetaFormer", img_size_h=w["H"], img_size_w=w["W"], patch_size=16, embed_dim=e,
+                      num_heads=8, mlp_ratios=4, in_channels=3, num_classes=w["K"], qkv_bias=False, depths=8,
+                      sr_ratios=1, T=w["T"], norm_eval=True, norm_cfg=norm_cfg, decode_mode="Qsnn"),
+        decode_head=dict(
+            type="MaskFormerHead", in_channels=[e[0] // 2, e[0], e[1], e[3]], feat_channels=Fc, in_index=[0, 1, 2, 3],
+            num_classes=w["K"], out_channels=Fc, num_queries=w["Q"], T=w["T"],
+            pixel_decoder=dict(
+                type="mmdet.DCNTransformerEncoderPixelDecoder", norm_cfg=norm_cfg, T=w["T"],
+                encoder=dict(num_layers=w["pd"][0], layer_cfg=dict(
+                    self_attn_cfg=dict(embed_dims=Fc, num_heads=8, batch_first=True, dw_kernel_size=5, group=w["G"]),
+                    ffn_cfg=dict(embed_dims=Fc, feedforward_channels=w["pd"][1], num_fcs=2))),
+                positional_encoding=dict(num_feats=w["nf"], normalize=True)),
+            enforce_decoder_input_project=False,
+            positional_encoding=dict(num_feats=w["nf"], normalize=True),
+            transformer_decoder=dict(
+                return_intermediate=True, num_layers=w["dec"][0],
+                layer_cfg=dict(
+                    self_attn_cfg=dict(embed_dims=Fc, num_heads=8, attn_type="SA", batch_first=True),
+                    cross_attn_cfg=dict(embed_dims=Fc, num_heads=8, attn_type="CA", batch_first=True),
+                    ffn_cfg=dict(embed_dims=Fc, feedforward_channels=w["dec"][1], num_fcs=2, add_identity=True)),
+                init_cfg=None)),
+        train_cfg=dict(), test_cfg=dict(mode="whole"))

@@ -1,0 +1,228 @@
+// DCNv3 core (deformable sampling + modulation) for gfx950.
+//
+// Reference semantics: dcnv3_core_pytorch, mmdet/models/layers/transformer/ops_dcnv3/functions/dcnv3_func.py:147-189
+// (grid_sample(bilinear, zeros, align_corners=False) on the zero-padded input); the dormant CUDA op of the same
+// function is ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh:216-275 (forward) / :278-839 (backward).  Pixel-coordinate
+// form of the sampling position, in zero-PADDED input coordinates:
+//     px = wo*sw + c0w + (i_w - (Kw-1)/2) * dw * s + off_x * s        c0w = (dw*(Kw-1))/2,  s = offset_scale
+//     py = ho*sh + c0h + (j_h - (Kh-1)/2) * dh * s + off_y * s        tap k = i_w*Kh + j_h
+//
+// Gather-bound (HBM/L2).  One thread owns one (n, ho, wo, g): it reads its 2*K offsets and K mask values once and
+// loops over the Cg channels of the group in 16-byte pieces (NHWC: a group's channels are contiguous), so the
+// backward needs NO cross-thread reduction for grad_offset / grad_mask (the reference CUDA op spreads a group over
+// Cg threads and reduces through shared memory, .cuh:907-1039).  Consecutive threads are consecutive groups of one
+// pixel: a wavefront reads 64*Cg contiguous floats per corner when the offsets agree.
+#include "s2f_common.h"
+
+namespace {
+
+struct Geom {
+  int N, H, W, G, Cg, Kh, Kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
+  float osc;
+};
+
+struct Tap {
+  int x0, y0;          // top-left corner in UNPADDED input coordinates
+  float lx, ly;        // fractional parts
+  bool vx0, vx1, vy0, vy1;
+};
+
+__device__ __forceinline__ Tap make_tap(const Geom& g, int ho, int wo, int iw, int jh, float offx, float offy) {
+  // same operation order as the oracle (padded coordinates, left to right), then shift the integer corner
+  const float c0w = (float)((g.dw * (g.Kw - 1)) / 2), c0h = (float)((g.dh * (g.Kh - 1)) / 2);
+  const float px = ((float)(wo * g.sw) + c0w + (float)(iw - (g.Kw - 1) / 2) * (float)g.dw * g.osc) + offx * g.osc;
+  const float py = ((float)(ho * g.sh) + c0h + (float)(jh - (g.Kh - 1) / 2) * (float)g.dh * g.osc) + offy * g.osc;
+  const float fx = floorf(px), fy = floorf(py);
+  Tap t;
+  t.lx = px - fx;
+  t.ly = py - fy;
+  // clamp before the int conversion so that wild offsets cannot overflow; anything outside is invalid anyway
+  const float cx = fminf(fmaxf(fx, -4.0f), (float)(g.W + 2 * g.pw + 4));
+  const float cy = fminf(fmaxf(fy, -4.0f), (float)(g.H + 2 * g.ph + 4));
+  t.x0 = (int)cx - g.pw;
+  t.y0 = (int)cy - g.ph;
+  t.vx0 = t.x0 >= 0 && t.x0 < g.W;
+  t.vx1 = t.x0 + 1 >= 0 && t.x0 + 1 < g.W;
+  t.vy0 = t.y0 >= 0 && t.y0 < g.H;
+  t.vy1 = t.y0 + 1 >= 0 && t.y0 + 1 < g.H;
+  return t;
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+  float4 v;
+  __device__ __forceinline__ static Vec ld(const float* p) { Vec r; r.v = *reinterpret_cast<const float4*>(p); return r; }
+  __device__ __forceinline__ static Vec zero() { Vec r; r.v = make_float4(0, 0, 0, 0); return r; }
+  __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+  __device__ __forceinline__ void set(int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else if (i == 2) v.z = f; else v.w = f; }
+  __device__ __forceinline__ void st(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+};
+template <>
+struct Vec<1> {
+  float v;
+  __device__ __forceinline__ static Vec ld(const float* p) { Vec r; r.v = *p; return r; }
+  __device__ __forceinline__ static Vec zero() { Vec r; r.v = 0.f; return r; }
+  __device__ __forceinline__ float get(int) const { return v; }
+  __device__ __forceinline__ void set(int, float f) { v = f; }
+  __device__ __forceinline__ void st(float* p) const { *p = v; }
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void dcn_fwd_kernel(const float* __restrict__ in, const float* __restrict__ off,
+                                                      const float* __restrict__ msk, float* __restrict__ out, Geom g) {
+  const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+  const int P = g.Kh * g.Kw;
+  const int C = g.G * g.Cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx % g.G);
+    int64_t r = idx / g.G;
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int n = (int)(r / g.Ho);
+    const int64_t pix = ((int64_t)n * g.Ho + ho) * g.Wo + wo;
+    const float* offp = off + (pix * g.G + gi) * P * 2;
+    const float* mp = msk + (pix * g.G + gi) * P;
+    const float* inb = in + (int64_t)n * g.H * g.W * C + gi * g.Cg;
+    float* outp = out + pix * C + gi * g.Cg;
+    for (int c = 0; c < g.Cg; c += V) {
+      Vec<V> acc = Vec<V>::zero();
+      for (int k = 0; k < P; ++k) {
+        const int iw = k / g.Kh, jh = k % g.Kh;
+        const Tap t = make_tap(g, ho, wo, iw, jh, offp[2 * k], offp[2 * k + 1]);
+        const float m = mp[k];
+        const float w00 = (1.f - t.ly) * (1.f - t.lx), w01 = (1.f - t.ly) * t.lx, w10 = t.ly * (1.f - t.lx),
+                    w11 = t.ly * t.lx;
+        const float* p00 = inb + ((int64_t)t.y0 * g.W + t.x0) * C + c;
+        Vec<V> v00 = (t.vy0 && t.vx0) ? Vec<V>::ld(p00) : Vec<V>::zero();
+        Vec<V> v01 = (t.vy0 && t.vx1) ? Vec<V>::ld(p00 + C) : Vec<V>::zero();
+        Vec<V> v10 = (t.vy1 && t.vx0) ? Vec<V>::ld(p00 + (int64_t)g.W * C) : Vec<V>::zero();
+        Vec<V> v11 = (t.vy1 && t.vx1) ? Vec<V>::ld(p00 + (int64_t)g.W * C + C) : Vec<V>::zero();
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          float s = v00.get(i) * (w00 * m) + v01.get(i) * (w01 * m) + v10.get(i) * (w10 * m) + v11.get(i) * (w11 * m);
+          acc.set(i, acc.get(i) + s);
+        }
+      }
+      acc.st(outp + c);
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void dcn_bwd_kernel(const float* __restrict__ in, const float* __restrict__ off,
+                                                      const float* __restrict__ msk, const float* __restrict__ gout,
+                                                      float* __restrict__ gin, float* __restrict__ goff,
+                                                      float* __restrict__ gmsk, Geom g) {
+  const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+  const int P = g.Kh * g.Kw;
+  const int C = g.G * g.Cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx % g.G);
+    int64_t r = idx / g.G;
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int n = (int)(r / g.Ho);
+    const int64_t pix = ((int64_t)n * g.Ho + ho) * g.Wo + wo;
+    const float* offp = off + (pix * g.G + gi) * P * 2;
+    const float* mp = msk + (pix * g.G + gi) * P;
+    const int64_t img = (int64_t)n * g.H * g.W * C + gi * g.Cg;
+    const float* gop = gout + pix * C + gi * g.Cg;
+    for (int k = 0; k < P; ++k) {
+      const int iw = k / g.Kh, jh = k % g.Kh;
+      const Tap t = make_tap(g, ho, wo, iw, jh, offp[2 * k], offp[2 * k + 1]);
+      const float m = mp[k];
+      const float w00 = (1.f - t.ly) * (1.f - t.lx), w01 = (1.f - t.ly) * t.lx, w10 = t.ly * (1.f - t.lx),
+                  w11 = t.ly * t.lx;
+      const int64_t o00 = img + ((int64_t)t.y0 * g.W + t.x0) * C;
+      const bool b00 = t.vy0 && t.vx0, b01 = t.vy0 && t.vx1, b10 = t.vy1 && t.vx0, b11 = t.vy1 && t.vx1;
+      float am = 0.f, ax = 0.f, ay = 0.f;
+      for (int c = 0; c < g.Cg; c += V) {
+        const Vec<V> go = Vec<V>::ld(gop + c);
+        const Vec<V> v00 = b00 ? Vec<V>::ld(in + o00 + c) : Vec<V>::zero();
+        const Vec<V> v01 = b01 ? Vec<V>::ld(in + o00 + C + c) : Vec<V>::zero();
+        const Vec<V> v10 = b10 ? Vec<V>::ld(in + o00 + (int64_t)g.W * C + c) : Vec<V>::zero();
+        const Vec<V> v11 = b11 ? Vec<V>::ld(in + o00 + (int64_t)g.W * C + C + c) : Vec<V>::zero();
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float gv = go.get(i);
+          const float a = v00.get(i), b = v01.get(i), cc = v10.get(i), d = v11.get(i);
+          am += gv * (a * w00 + b * w01 + cc * w10 + d * w11);
+          ax += gv * ((1.f - t.ly) * (b - a) + t.ly * (d - cc));
+          ay += gv * ((1.f - t.lx) * (cc - a) + t.lx * (d - b));
+          const float gm = gv * m;
+          if (b00) atomicAdd(gin + o00 + c + i, gm * w00);
+          if (b01) atomicAdd(gin + o00 + C + c + i, gm * w01);
+          if (b10) atomicAdd(gin + o00 + (int64_t)g.W * C + c + i, gm * w10);
+          if (b11) atomicAdd(gin + o00 + (int64_t)g.W * C + C + c + i, gm * w11);
+        }
+      }
+      gmsk[(pix * g.G + gi) * P + k] = am;
+      goff[((pix * g.G + gi) * P + k) * 2] = ax * m * g.osc;
+      goff[((pix * g.G + gi) * P + k) * 2 + 1] = ay * m * g.osc;
+    }
+  }
+}
+
+int make_geom(Geom& g, int N, int H, int W, int G, int Cg, int Kh, int Kw, int sh, int sw, int ph, int pw, int dh, int dw,
+              float osc, const char* who) {
+  S2F_REQUIRE(N > 0 && H > 0 && W > 0 && G > 0 && Cg > 0 && Kh > 0 && Kw > 0 && sh > 0 && sw > 0 && ph >= 0 &&
+                  pw >= 0 && dh > 0 && dw > 0,
+              S2F_EINVAL, "%s: bad geometry", who);
+  g = Geom{N, H, W, G, Cg, Kh, Kw, sh, sw, ph, pw, dh, dw, 0, 0, osc};
+  g.Ho = (H + 2 * ph - (dh * (Kh - 1) + 1)) / sh + 1;
+  g.Wo = (W + 2 * pw - (dw * (Kw - 1) + 1)) / sw + 1;
+  S2F_REQUIRE(g.Ho > 0 && g.Wo > 0, S2F_EINVAL, "%s: empty output", who);
+  return S2F_OK;
+}
+
+inline int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int s2f_dcnv3_fwd(const float* input, const float* offset, const float* mask, float* output, int N, int H,
+                             int W, int G, int Cg, int Kh, int Kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                             int dil_h, int dil_w, float offset_scale, void* stream) {
+  S2F_REQUIRE(input && offset && mask && output, S2F_EINVAL, "s2f_dcnv3_fwd: null pointer");
+  Geom g;
+  int rc = make_geom(g, N, H, W, G, Cg, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, offset_scale,
+                     "s2f_dcnv3_fwd");
+  if (rc != S2F_OK) return rc;
+  const int64_t total = (int64_t)N * g.Ho * g.Wo * G;
+  const bool vec = (Cg % 4 == 0) && s2f_aligned16(input) && s2f_aligned16(output);
+  if (vec)
+    hipLaunchKernelGGL(dcn_fwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
+                       output, g);
+  else
+    hipLaunchKernelGGL(dcn_fwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
+                       output, g);
+  return s2f_check_launch("s2f_dcnv3_fwd");
+}
+
+extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const float* mask, const float* grad_output,
+                             float* grad_input, float* grad_offset, float* grad_mask, int N, int H, int W, int G, int Cg,
+                             int Kh, int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                             float offset_scale, void* stream) {
+  S2F_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, S2F_EINVAL,
+              "s2f_dcnv3_bwd: null pointer");
+  Geom g;
+  int rc = make_geom(g, N, H, W, G, Cg, Kh, Kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, offset_scale,
+                     "s2f_dcnv3_bwd");
+  if (rc != S2F_OK) return rc;
+  const int64_t total = (int64_t)N * g.Ho * g.Wo * G;
+  const bool vec = (Cg % 4 == 0) && s2f_aligned16(input) && s2f_aligned16(grad_output);
+  if (vec)
+    hipLaunchKernelGGL(dcn_bwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
+                       grad_output, grad_input, grad_offset, grad_mask, g);
+  else
+    hipLaunchKernelGGL(dcn_bwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
+                       grad_output, grad_input, grad_offset, grad_mask, g);
+  return s2f_check_launch("s2f_dcnv3_bwd");
+}

@@ -1,0 +1,328 @@
+// Quantised integrate-and-fire neuron (Q_IFNode + quant STE) for gfx950.
+//
+// Reference semantics: Qtrick_architecture/clock_driven/neuron.py:166-197 (forward), :459-460 (charge), :133-153
+// (soft reset); surrogate.py:522-538 (round(clamp(.,0,D)) forward, in-range straight-through backward).
+//
+// HBM-bound elementwise kernels.  One wavefront owns a 256-element tile (lane l holds elements 4l..4l+3 as one
+// 16-byte access, 1 KiB per wave instruction); the in-range bit of component j is collected with a wave ballot, so
+// the backward pass reads 1 bit/element instead of the fp32 membrane the reference saves.  Firing statistics
+// (sum of counts, number of non-zero counts) are reduced per wave with popcount / DPP adds, one atomic pair per block.
+#include <stdarg.h>
+
+#include "s2f_common.h"
+
+static thread_local char g_err[512] = "";
+void s2f_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* s2f_last_error(void) { return g_err; }
+extern "C" int s2f_version(void) { return S2F_ABI_VERSION; }
+extern "C" int64_t s2f_lif_mask_words(int64_t n) { return ((n + 255) >> 8) * 4; }
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / S2F_WAVE;
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct Tile4 {
+  float a[4];
+};
+
+__device__ __forceinline__ Tile4 load4(const float* p, int64_t base, int64_t n, float fill) {
+  Tile4 t;
+  if (base + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(p + base);
+    t.a[0] = v.x; t.a[1] = v.y; t.a[2] = v.z; t.a[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.a[j] = (base + j < n) ? p[base + j] : fill;
+  }
+  return t;
+}
+
+__device__ __forceinline__ void store4(float* p, int64_t base, int64_t n, const Tile4& t) {
+  if (base + 3 < n) {
+    *reinterpret_cast<float4*>(p + base) = make_float4(t.a[0], t.a[1], t.a[2], t.a[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (base + j < n) p[base + j] = t.a[j];
+  }
+}
+
+__device__ __forceinline__ void write_mask(uint64_t* mask, int64_t tile, int lane, const bool inr[4]) {
+  // wave ballot of each component; word j bit l <-> element 256*tile + 4*l + j
+  uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+  if (mask != nullptr && lane < 4) {
+    uint64_t w = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    mask[tile * 4 + lane] = w;
+  }
+}
+
+// ------------------------------------------------------------------ single step
+template <bool HAS_V>
+__global__ __launch_bounds__(kBlock) void lif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v_in,
+                                                         float* __restrict__ y, float* __restrict__ v_out,
+                                                         uint64_t* __restrict__ mask, uint8_t* __restrict__ cnt,
+                                                         unsigned long long* __restrict__ stats, int64_t n, float vth,
+                                                         float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  uint32_t csum = 0, cnz = 0;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    Tile4 xv = load4(x, base, n, -1.0f);
+    Tile4 vv;
+    if (HAS_V) vv = load4(v_in, base, n, 0.0f);
+    Tile4 yv, vo;
+    bool inr[4];
+    uint32_t c4 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float h = HAS_V ? (vv.a[j] + xv.a[j]) : xv.a[j];
+      float s;
+      s2f_lif_update(h, Df, 1.0f, vth, s, yv.a[j], vo.a[j], inr[j]);
+      yv.a[j] = s / Df;
+      inr[j] = inr[j] && (base + j < n);
+      uint32_t si = (uint32_t)s;
+      if (base + j < n) {
+        csum += si;
+        cnz += (si != 0);
+      }
+      c4 |= si << (8 * j);
+    }
+    store4(y, base, n, yv);
+    if (v_out != nullptr) store4(v_out, base, n, vo);
+    if (cnt != nullptr) {
+      if (base + 3 < n) {
+        *reinterpret_cast<uint32_t*>(cnt + base) = c4;
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (base + j < n) cnt[base + j] = (uint8_t)(c4 >> (8 * j));
+      }
+    }
+    write_mask(mask, tile, lane, inr);
+  }
+  if (stats != nullptr) {
+    csum = wave_sum_u32(csum);
+    cnz = wave_sum_u32(cnz);
+    __shared__ uint32_t red[2 * kWavesPerBlock];
+    if (lane == 0) {
+      red[(threadIdx.x >> 6) * 2] = csum;
+      red[(threadIdx.x >> 6) * 2 + 1] = cnz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long a = 0, b = 0;
+      for (int w = 0; w < kWavesPerBlock; ++w) {
+        a += red[2 * w];
+        b += red[2 * w + 1];
+      }
+      if (a) atomicAdd(&stats[0], a);
+      if (b) atomicAdd(&stats[1], b);
+    }
+  }
+}
+
+template <bool HAS_GV>
+__global__ __launch_bounds__(kBlock) void lif_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gv,
+                                                         const uint64_t* __restrict__ mask, float* __restrict__ gx,
+                                                         int64_t n, float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    Tile4 g = load4(gy, base, n, 0.0f);
+    Tile4 gvv;
+    if (HAS_GV) gvv = load4(gv, base, n, 0.0f);
+    Tile4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool m = (mask[tile * 4 + j] >> lane) & 1ull;
+      // autograd of  y = s/D ; v' = h - s*vth  with ds/dh = m:  dL/dh = gv + (gy/D - gv*vth) * m
+      const float through = g.a[j] / Df;
+      if (HAS_GV)
+        o.a[j] = m ? (gvv.a[j] + (through - gvv.a[j] * vth)) : gvv.a[j];
+      else
+        o.a[j] = m ? through : 0.0f;
+    }
+    store4(gx, base, n, o);
+  }
+}
+
+// ------------------------------------------------------------------ T chained steps, membrane in registers
+template <bool HAS_V0>
+__global__ __launch_bounds__(kBlock) void lif_seq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v0,
+                                                             float* __restrict__ y, float* __restrict__ vT,
+                                                             uint64_t* __restrict__ mask,
+                                                             unsigned long long* __restrict__ stats, int T, int64_t n,
+                                                             float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  const int64_t mwords = ntiles * 4;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    Tile4 v;
+    if (HAS_V0) {
+      v = load4(v0, base, n, 0.0f);
+    } else {
+      v.a[0] = v.a[1] = v.a[2] = v.a[3] = 0.0f;
+    }
+    Tile4 xn = load4(x, base, n, -1.0f);
+    for (int t = 0; t < T; ++t) {
+      Tile4 xv = xn;
+      if (t + 1 < T) xn = load4(x + (int64_t)(t + 1) * n, base, n, -1.0f);  // prefetch next step
+      Tile4 yv;
+      bool inr[4];
+      uint32_t csum = 0, cnz = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // first step after a reset: the reference computes 0. + x == x; adding the 0.0f register is identical
+        float h = v.a[j] + xv.a[j];
+        float s, yy;
+        s2f_lif_update(h, Df, 1.0f, vth, s, yy, v.a[j], inr[j]);
+        yv.a[j] = s / Df;
+        inr[j] = inr[j] && (base + j < n);
+        if (base + j < n) {
+          csum += (uint32_t)s;
+          cnz += ((uint32_t)s != 0);
+        }
+      }
+      store4(y + (int64_t)t * n, base, n, yv);
+      write_mask(mask == nullptr ? nullptr : mask + (int64_t)t * mwords, tile, lane, inr);
+      if (stats != nullptr) {
+        csum = wave_sum_u32(csum);
+        cnz = wave_sum_u32(cnz);
+        if (lane == 0) {
+          if (csum) atomicAdd(&stats[2 * t], (unsigned long long)csum);
+          if (cnz) atomicAdd(&stats[2 * t + 1], (unsigned long long)cnz);
+        }
+      }
+    }
+    if (vT != nullptr) store4(vT, base, n, v);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void lif_seq_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gvT,
+                                                             const uint64_t* __restrict__ mask,
+                                                             float* __restrict__ gx, float* __restrict__ gv0, int T,
+                                                             int64_t n, float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  const int64_t mwords = ntiles * 4;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    Tile4 gh;
+    if (gvT != nullptr) {
+      gh = load4(gvT, base, n, 0.0f);
+    } else {
+      gh.a[0] = gh.a[1] = gh.a[2] = gh.a[3] = 0.0f;
+    }
+    for (int t = T - 1; t >= 0; --t) {
+      Tile4 g = load4(gy + (int64_t)t * n, base, n, 0.0f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool m = (mask[(int64_t)t * mwords + tile * 4 + j] >> lane) & 1ull;
+        gh.a[j] = m ? (gh.a[j] + (g.a[j] / Df - gh.a[j] * vth)) : gh.a[j];
+      }
+      store4(gx + (int64_t)t * n, base, n, gh);
+    }
+    if (gv0 != nullptr) store4(gv0, base, n, gh);
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t tiles = (n + 255) >> 8;
+  int64_t blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
+                           uint64_t* stats, int64_t n, float vth, int D, void* stream) {
+  S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_lif_fwd: null x/y");
+  S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_fwd: bad n=%lld or D=%d", (long long)n, D);
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y) && s2f_aligned16(v_in) && s2f_aligned16(v_out), S2F_EALIGN,
+              "s2f_lif_fwd: x/y/v must be 16-byte aligned");
+  S2F_REQUIRE(count_u8 == nullptr || (reinterpret_cast<uintptr_t>(count_u8) & 3u) == 0, S2F_EALIGN,
+              "s2f_lif_fwd: count_u8 must be 4-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  auto* st = reinterpret_cast<unsigned long long*>(stats);
+  if (v_in != nullptr)
+    hipLaunchKernelGGL(lif_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
+                       st, n, vth, (float)D);
+  else
+    hipLaunchKernelGGL(lif_fwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
+                       st, n, vth, (float)D);
+  return s2f_check_launch("s2f_lif_fwd");
+}
+
+extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth,
+                           int D, void* stream) {
+  S2F_REQUIRE(gy && mask && gx, S2F_EINVAL, "s2f_lif_bwd: null gy/mask/gx");
+  S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_bwd: bad n or D");
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(s2f_aligned16(gy) && s2f_aligned16(gx) && s2f_aligned16(gv_out), S2F_EALIGN,
+              "s2f_lif_bwd: gy/gx/gv must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (gv_out != nullptr)
+    hipLaunchKernelGGL(lif_bwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
+                       (float)D);
+  else
+    hipLaunchKernelGGL(lif_bwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
+                       (float)D);
+  return s2f_check_launch("s2f_lif_bwd");
+}
+
+extern "C" int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq, float* vT, uint64_t* mask,
+                               uint64_t* stats, int T, int64_t n, float vth, int D, void* stream) {
+  S2F_REQUIRE(x_seq && y_seq, S2F_EINVAL, "s2f_lif_seq_fwd: null x/y");
+  S2F_REQUIRE(T >= 1 && n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_seq_fwd: bad T/n/D");
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(T == 1 || (n % 4) == 0, S2F_EINVAL, "s2f_lif_seq_fwd: n must be a multiple of 4 when T > 1");
+  S2F_REQUIRE(s2f_aligned16(x_seq) && s2f_aligned16(y_seq) && s2f_aligned16(v0) && s2f_aligned16(vT), S2F_EALIGN,
+              "s2f_lif_seq_fwd: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  auto* st = reinterpret_cast<unsigned long long*>(stats);
+  if (v0 != nullptr)
+    hipLaunchKernelGGL(lif_seq_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, x_seq, v0, y_seq, vT, mask, st,
+                       T, n, vth, (float)D);
+  else
+    hipLaunchKernelGGL(lif_seq_fwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, x_seq, v0, y_seq, vT, mask, st,
+                       T, n, vth, (float)D);
+  return s2f_check_launch("s2f_lif_seq_fwd");
+}
+
+extern "C" int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask, float* gx_seq, float* gv0,
+                               int T, int64_t n, float vth, int D, void* stream) {
+  S2F_REQUIRE(gy_seq && mask && gx_seq, S2F_EINVAL, "s2f_lif_seq_bwd: null gy/mask/gx");
+  S2F_REQUIRE(T >= 1 && n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_seq_bwd: bad T/n/D");
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(T == 1 || (n % 4) == 0, S2F_EINVAL, "s2f_lif_seq_bwd: n must be a multiple of 4 when T > 1");
+  S2F_REQUIRE(s2f_aligned16(gy_seq) && s2f_aligned16(gx_seq) && s2f_aligned16(gvT) && s2f_aligned16(gv0), S2F_EALIGN,
+              "s2f_lif_seq_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(lif_seq_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, gy_seq, gvT, mask,
+                     gx_seq, gv0, T, n, vth, (float)D);
+  return s2f_check_launch("s2f_lif_seq_bwd");
+}

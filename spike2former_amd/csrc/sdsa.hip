@@ -1,0 +1,187 @@
+// Spike-driven (softmax-free) attention core for gfx950:  kv = k^T v  (d x d per head),  o = (q kv) * scale.
+//
+// Reference semantics: MS_Attention_RepConv_qkv_id.forward, mmseg/models/backbones/sdtv2.py:308-339 (backbone), and
+// the decoder's (Cross)MultiHeadAttentionBlock, mmcv_spike/transformer.py:253-274 / :334-355, whose
+// (q k^T / sqrt(C)) v has no softmax and is therefore the same bilinear form.  All operands stay in the
+// channel-major layout [TB, C, N] the surrounding 1x1 convolutions produce (channel c = head*d + j); none of the
+// reference's permute/contiguous copies exist here.
+//
+// Two building blocks, both reused by the backward pass:
+//   outer :  M[tb,h][i][j] (+)= alpha * sum_n A[tb, h*d+i, n] * B[tb, h*d+j, n]
+//   apply :  Y[tb, h*d+j, n]   = alpha * sum_i X[tb, h*d+i, n] * M[tb,h][i][j]      (TRANS: M[j][i])
+// Spike operands are multiples of 1/D, so every product and every partial sum is exactly representable in fp32
+// while it stays below 2^24 ulps: the result is independent of summation order (atomics included) and identical to
+// the reference's fp32 matmuls.  The tests assert that bound instead of a tolerance.
+#include "s2f_common.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int kDMax = 64;   // head dim limit (block3: 32, block4: 45, decoder: 32)
+constexpr int kNT = 64;     // columns staged per step
+
+// grid (TB*heads, nsplit); block 256.  LDS: two [d][kNT+1] tiles.
+__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                    float* __restrict__ M, int heads, int d, int N, float alpha) {
+  __shared__ float sa[kDMax][kNT + 1];
+  __shared__ float sb[kDMax][kNT + 1];
+  const int bh = blockIdx.x;
+  const int tb = bh / heads, h = bh % heads;
+  const int C = heads * d;
+  const float* a = A + ((int64_t)tb * C + h * d) * N;
+  const float* b = B + ((int64_t)tb * C + h * d) * N;
+  const int nsplit = gridDim.y;
+  const int chunk = ((N + nsplit - 1) / nsplit + kNT - 1) / kNT * kNT;
+  const int n_begin = blockIdx.y * chunk;
+  const int n_end = min(N, n_begin + chunk);
+  // each thread owns a 2x2 micro-tile per pass over (i, j)
+  const int dt = (d + 1) / 2;          // micro-tiles per side
+  const int ntile = dt * dt;
+  float acc[4][4];                      // up to 4 micro-tiles per thread (d <= 64 -> 1024 micro-tiles / 256 threads)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
+  for (int n0 = n_begin; n0 < n_end; n0 += kNT) {
+    for (int e = threadIdx.x; e < d * kNT; e += 256) {
+      const int r = e / kNT, c = e % kNT;
+      const bool ok = n0 + c < n_end;
+      sa[r][c] = ok ? a[(int64_t)r * N + n0 + c] : 0.f;
+      sb[r][c] = ok ? b[(int64_t)r * N + n0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = threadIdx.x + u * 256;
+      if (t < ntile) {
+        const int i0 = (t / dt) * 2, j0 = (t % dt) * 2;
+        const int i1 = min(i0 + 1, d - 1), j1 = min(j0 + 1, d - 1);
+        for (int c = 0; c < kNT; ++c) {
+          const float a0 = sa[i0][c], a1 = sa[i1][c], b0 = sb[j0][c], b1 = sb[j1][c];
+          acc[u][0] += a0 * b0; acc[u][1] += a0 * b1; acc[u][2] += a1 * b0; acc[u][3] += a1 * b1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* m = M + (int64_t)bh * d * d;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int t = threadIdx.x + u * 256;
+    if (t < ntile) {
+      const int i0 = (t / dt) * 2, j0 = (t % dt) * 2;
+      const bool hi = i0 + 1 < d, hj = j0 + 1 < d;
+      if (nsplit == 1) {
+        m[i0 * d + j0] = acc[u][0] * alpha;
+        if (hj) m[i0 * d + j0 + 1] = acc[u][1] * alpha;
+        if (hi) m[(i0 + 1) * d + j0] = acc[u][2] * alpha;
+        if (hi && hj) m[(i0 + 1) * d + j0 + 1] = acc[u][3] * alpha;
+      } else {
+        atomicAdd(&m[i0 * d + j0], acc[u][0] * alpha);
+        if (hj) atomicAdd(&m[i0 * d + j0 + 1], acc[u][1] * alpha);
+        if (hi) atomicAdd(&m[(i0 + 1) * d + j0], acc[u][2] * alpha);
+        if (hi && hj) atomicAdd(&m[(i0 + 1) * d + j0 + 1], acc[u][3] * alpha);
+      }
+    }
+  }
+}
+
+// grid (TB*heads, ceil(N/256)); block 256: thread = one column n, d accumulators in registers, M broadcast from LDS.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X, const float* __restrict__ M,
+                                                    float* __restrict__ Y, int heads, int d, int N, float alpha) {
+  __shared__ float sm[kDMax * kDMax];
+  const int bh = blockIdx.x;
+  const int tb = bh / heads, h = bh % heads;
+  const int C = heads * d;
+  const float* m = M + (int64_t)bh * d * d;
+  for (int e = threadIdx.x; e < d * d; e += 256) {
+    const int i = e / d, j = e % d;
+    sm[i * d + j] = TRANS ? m[j * d + i] : m[i * d + j];
+  }
+  __syncthreads();
+  const int n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* x = X + ((int64_t)tb * C + h * d) * N + n;
+  float* y = Y + ((int64_t)tb * C + h * d) * N + n;
+  float acc[kDMax];
+#pragma unroll
+  for (int j = 0; j < kDMax; ++j) acc[j] = 0.f;
+  for (int i = 0; i < d; ++i) {
+    const float xv = x[(int64_t)i * N];
+    const float* row = sm + i * d;
+#pragma unroll
+    for (int j = 0; j < kDMax; ++j)
+      if (j < d) acc[j] += xv * row[j];
+  }
+#pragma unroll
+  for (int j = 0; j < kDMax; ++j)
+    if (j < d) y[(int64_t)j * N] = acc[j] * alpha;
+}
+
+int pick_split(int TBh, int N) {
+  int ns = 1;
+  while (TBh * ns < 512 && (N / (ns * 2)) >= 256) ns *= 2;
+  return ns;
+}
+
+int check(const char* who, int TB, int heads, int d, int N) {
+  S2F_REQUIRE(TB > 0 && heads > 0 && N > 0 && d > 0 && d <= kDMax, S2F_EINVAL, "%s: need 0 < d <= %d, got TB=%d heads=%d d=%d N=%d",
+              who, kDMax, TB, heads, d, N);
+  return S2F_OK;
+}
+
+}  // namespace
+
+extern "C" int s2f_sdsa_kv(const float* k, const float* v, float* kv, int TB, int heads, int d, int N, float alpha,
+                           void* stream) {
+  S2F_REQUIRE(k && v && kv, S2F_EINVAL, "s2f_sdsa_kv: null pointer");
+  int rc = check("s2f_sdsa_kv", TB, heads, d, N);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = pick_split(TB * heads, N);
+  if (ns > 1) {
+    if (hipMemsetAsync(kv, 0, sizeof(float) * (size_t)TB * heads * d * d, s) != hipSuccess)
+      return s2f_check_launch("s2f_sdsa_kv memset");
+  }
+  hipLaunchKernelGGL(outer_kernel, dim3(TB * heads, ns), dim3(256), 0, s, k, v, kv, heads, d, N, alpha);
+  return s2f_check_launch("s2f_sdsa_kv");
+}
+
+extern "C" int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, int heads, int d, int N, float alpha,
+                              int transpose_m, void* stream) {
+  S2F_REQUIRE(x && m && y, S2F_EINVAL, "s2f_sdsa_apply: null pointer");
+  int rc = check("s2f_sdsa_apply", TB, heads, d, N);
+  if (rc) return rc;
+  dim3 grid(TB * heads, (N + 255) / 256);
+  if (transpose_m)
+    hipLaunchKernelGGL(apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, m, y, heads, d, N, alpha);
+  else
+    hipLaunchKernelGGL(apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, m, y, heads, d, N, alpha);
+  return s2f_check_launch("s2f_sdsa_apply");
+}
+
+extern "C" int s2f_sdsa_fwd(const float* q, const float* k, const float* v, float* o, float* kv_save, int TB, int heads,
+                            int d, int Nq, int Nk, float scale, void* stream) {
+  S2F_REQUIRE(q && k && v && o && kv_save, S2F_EINVAL, "s2f_sdsa_fwd: null pointer");
+  int rc = s2f_sdsa_kv(k, v, kv_save, TB, heads, d, Nk, 1.0f, stream);
+  if (rc) return rc;
+  return s2f_sdsa_apply(q, kv_save, o, TB, heads, d, Nq, scale, 0, stream);
+}
+
+extern "C" int s2f_sdsa_bwd(const float* q, const float* k, const float* v, const float* kv_save, const float* go,
+                            float* gq, float* gk, float* gv, float* gkv_ws, int TB, int heads, int d, int Nq, int Nk,
+                            float scale, void* stream) {
+  S2F_REQUIRE(q && k && v && kv_save && go && gq && gk && gv && gkv_ws, S2F_EINVAL, "s2f_sdsa_bwd: null pointer");
+  // gq[i][n] = scale * sum_j go[j][n] kv[i][j]
+  int rc = s2f_sdsa_apply(go, kv_save, gq, TB, heads, d, Nq, scale, 1, stream);
+  if (rc) return rc;
+  // gkv[i][j] = scale * sum_n q[i][n] go[j][n]
+  rc = s2f_sdsa_kv(q, go, gkv_ws, TB, heads, d, Nq, scale, stream);
+  if (rc) return rc;
+  // gk[i][n] = sum_j v[j][n] gkv[i][j] ;  gv[j][n] = sum_i k[i][n] gkv[i][j]
+  rc = s2f_sdsa_apply(v, gkv_ws, gk, TB, heads, d, Nk, 1.0f, 1, stream);
+  if (rc) return rc;
+  return s2f_sdsa_apply(k, gkv_ws, gv, TB, heads, d, Nk, 1.0f, 0, stream);
+}

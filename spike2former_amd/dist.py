@@ -1,0 +1,78 @@
+"""Data parallelism: one process per GPU, the image batch sharded across ranks, parameters replicated, and ONE
+all-reduce of a flat fp32 gradient buffer per step over RCCL/xGMI (the reference wraps the model in
+MMDistributedDataParallel, tools/train.py:40-44, configs/_base_/default_runtime.py:5).  BatchNorm statistics stay
+per-GPU, as in the reference (plain nn.BatchNorm, SyncBN ignored -- SURVEY 2.3)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, 0
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatGradAllReduce:
+    """All parameter gradients live as views into one contiguous fp32 buffer (137 MB at C2); `reduce()` issues a single
+    all-reduce(SUM) on a side stream and divides by the world size.  The gradient hooks only count arrivals, so the
+    collective starts the moment the last gradient of the backward pass lands and overlaps whatever follows."""
+
+    def __init__(self, params, world_size=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.work = None
+
+    def zero(self):
+        self.flat.zero_()
+
+    def reduce(self, async_op=True):
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+                self.flat.div_(self.world)
+        else:
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
+            self.flat.div_(self.world)
+
+    def wait(self):
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.work = None
+
+
+def broadcast_params(module, src=0):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def shard_batch(global_batch, rank, world):
+    """Even split of the image batch (C3: 16 -> 2 per GPU; C5: 8 -> 1 per GPU)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, per

@@ -1,0 +1,357 @@
+"""Spiking layers of the MaskFormer head on the MI355X kernels: SepConv_Spike / MLP (mmcv_spike/SNN_core.py:11-123),
+DCNv3 module (ops_dcnv3/modules/dcnv3.py:96-233), pixel-decoder MS_MLP and decoder attention / FFN
+(mmcv_spike/transformer.py:196-361, 505-638, 710-831), encoder / decoder layers (detr_layers.py:19-60, 112-185,
+263-339, 417-559) and the sine positional encoding (positional_encoding.py:59-98).  Class names, kwargs and state_dict
+keys follow the reference; the bug-compatible `reshape`-instead-of-permute quirks are reproduced and flagged."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .neuron import Q_IFNode, Quant
+from .registry import ConfigDict
+
+
+def _lif():
+    return Q_IFNode(surrogate_function=Quant())
+
+
+class SepConv_Spike(nn.Module):
+    """NHWC in/out: LIF -> pw(C->rC)+BN -> LIF -> dw kxk+BN -> LIF -> pw(rC->C)+BN   (SNN_core.py:11-63)."""
+
+    def __init__(self, dim, expansion_ratio=2, T=4, act2_layer=nn.Identity, bias=False, kernel_size=7, padding=3):
+        super().__init__()
+        med = int(expansion_ratio * dim)
+        self.T = T
+        self.expansion_ratio = expansion_ratio
+        self.spike1 = _lif()
+        self.pwconv1 = nn.Sequential(nn.Conv2d(dim, med, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(med))
+        self.spike2 = _lif()
+        self.dwconv = nn.Sequential(
+            nn.Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias), nn.BatchNorm2d(med))
+        self.spike3 = _lif()
+        self.pwconv2 = nn.Sequential(nn.Conv2d(med, dim, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(dim))
+
+    def forward(self, x):
+        T, B, H, W, C = x.shape
+        x = self.spike1(x.permute(0, 1, 4, 2, 3).contiguous()).flatten(0, 1)
+        x = self.spike2(self.pwconv1(x))
+        x = self.spike3(self.dwconv(x))
+        x = self.pwconv2(x).reshape(T, B, C, H, W)
+        return x.permute(0, 1, 3, 4, 2).contiguous()
+
+
+class MLP(nn.Module):
+    """Mask-embedding MLP: fc1 -> 4*LIF -> fc2 -> 4*LIF -> fc_out   (SNN_core.py:95-123)."""
+
+    def __init__(self, in_dim, out_dim, layer, quant_const=4, T=4):
+        super().__init__()
+        self.T = T
+        self.fc1 = nn.Linear(in_dim, in_dim, bias=False)
+        self.spike1 = _lif()
+        self.fc2 = nn.Linear(in_dim, in_dim, bias=False)
+        self.spike2 = _lif()
+        self.fc_out = nn.Linear(in_dim, out_dim)
+        self.quant_const = quant_const
+        nn.init.constant_(self.fc_out.bias, 0)
+        nn.init.trunc_normal_(self.fc_out.weight, std=0.02)
+
+    def forward(self, x):
+        x = self.spike1(self.fc1(x)) * self.quant_const
+        x = self.spike2(self.fc2(x)) * self.quant_const
+        return self.fc_out(x)
+
+
+class DCNv3_pytorch(nn.Module):
+    """DCNv3 module of the pixel decoder (dcnv3.py:96-233); registry-visible name kept.  The sampling core is the HIP
+    kernel `s2f_dcnv3_fwd/bwd`, not grid_sample."""
+
+    def __init__(self, channels=64, kernel_size=3, dw_kernel_size=None, stride=1, pad=1, dilation=1, group=4,
+                 offset_scale=1.0, expension_ratio=4, T=4, act_layer="GELU", norm_layer="LN",
+                 center_feature_scale=False):
+        super().__init__()
+        if channels % group != 0:
+            raise ValueError(f"channels must be divisible by group, but got {channels} and {group}")
+        if center_feature_scale:
+            raise NotImplementedError("center_feature_scale is False in every Spike2Former config")
+        dw_kernel_size = dw_kernel_size if dw_kernel_size is not None else kernel_size
+        self.offset_scale = offset_scale
+        self.channels = channels
+        self.kernel_size = kernel_size
+        self.dw_kernel_size = dw_kernel_size
+        self.stride = stride
+        self.dilation = dilation
+        self.pad = pad
+        self.group = group
+        self.group_channels = channels // group
+        self.center_feature_scale = center_feature_scale
+        self.T = T
+        self.dw_spike = _lif()
+        self.offset_spike = _lif()
+        self.mask_spike = _lif()
+        kk = kernel_size * kernel_size
+        self.dw_conv = nn.Sequential(
+            nn.Conv2d(channels, channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
+                      groups=channels, bias=False), nn.BatchNorm2d(channels))
+        self.offset = nn.Sequential(nn.Conv2d(channels, group * kk * 2, kernel_size=1, stride=1),
+                                    nn.BatchNorm2d(group * kk * 2))
+        self.mask = nn.Sequential(nn.Conv2d(channels, group * kk, kernel_size=1, stride=1), nn.BatchNorm2d(group * kk))
+        self.input_proj = SepConv_Spike(dim=channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
+                                        expansion_ratio=expension_ratio)
+        self.output_proj = SepConv_Spike(dim=channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
+                                         expansion_ratio=expension_ratio)
+        for m in (self.offset[0], self.mask[0]):           # zero init as in the reference (:192-196)
+            nn.init.constant_(m.weight, 0.0)
+            nn.init.constant_(m.bias, 0.0)
+
+    def forward(self, inp):
+        T, N, H, W, C = inp.shape
+        x = self.input_proj(inp)
+        x1 = self.dw_spike(inp.permute(0, 1, 4, 2, 3).contiguous()).flatten(0, 1)
+        x1 = self.offset_spike(self.dw_conv(x1))
+        # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
+        offset = self.offset(x1).reshape(T * N, H, W, -1)
+        mask = self.mask_spike(self.mask(x1).reshape(T * N, H, W, -1))
+        k = self.kernel_size
+        y = ops.dcnv3_core(x.flatten(0, 1), offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
+                           self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale)
+        return self.output_proj(y.reshape(T, N, H, W, C))
+
+
+class MS_MLP(nn.Module):
+    """Pixel-decoder FFN on NHWC input (mmcv_spike/transformer.py:787-831)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=2048, num_fcs=2, act_cfg=None, ffn_drop=0.0, T=4,
+                 dropout_layer=None, add_identity=True, init_cfg=None, layer_scale_init_value=0.0):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.feedforward_channels = feedforward_channels
+        self.num_fcs = num_fcs
+        self.T = T
+        self.fc1_spike = _lif()
+        self.fc1_conv = nn.Conv1d(embed_dims, feedforward_channels, kernel_size=1, stride=1)
+        self.fc1_bn = nn.BatchNorm1d(feedforward_channels)
+        self.fc2_spike = _lif()
+        self.fc2_conv = nn.Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
+        self.fc2_bn = nn.BatchNorm1d(embed_dims)
+
+    def forward(self, x):
+        T, B, H, W, C = x.shape
+        x = self.fc1_spike(x.permute(0, 1, 4, 2, 3).contiguous().flatten(3)).flatten(0, 1)
+        x = self.fc2_spike(self.fc1_bn(self.fc1_conv(x)))
+        # bug-compatible: [T*B, C, N] reinterpreted as [T, B, H, W, C] (:829)
+        return self.fc2_bn(self.fc2_conv(x)).reshape(T, B, H, W, C)
+
+
+class DCNDetrTransformerEncoderLayer(nn.Module):
+    """q += g1*SepConv(q); q += g2*DCN(q); q += g3*MLP(q) on NHWC [T,B,H,W,C]   (detr_layers.py:263-339)."""
+
+    def __init__(self, self_attn_cfg=None, ffn_cfg=None, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        self.self_attn_cfg = ConfigDict(self_attn_cfg or dict(embed_dims=256, num_heads=8, dropout=0.0))
+        if "batch_first" not in self.self_attn_cfg:
+            self.self_attn_cfg["batch_first"] = True
+        else:
+            assert self.self_attn_cfg["batch_first"] is True
+        self.ffn_cfg = ConfigDict(ffn_cfg or dict(embed_dims=256, feedforward_channels=1024, num_fcs=2))
+        self.layer_scale = 1e-6
+        self.embed_dims = self.self_attn_cfg.embed_dims
+        self.Conv = SepConv_Spike(dim=self.embed_dims, kernel_size=3, padding=1, expansion_ratio=2)
+        self.dcn = DCNv3_pytorch(channels=self.embed_dims, kernel_size=3, stride=1, pad=1, dilation=1,
+                                 group=self.self_attn_cfg.group, offset_scale=1.0, expension_ratio=2, act_layer="GELU",
+                                 norm_layer="BN", dw_kernel_size=self.self_attn_cfg.dw_kernel_size,
+                                 center_feature_scale=False)
+        self.ffn = MS_MLP(**self.ffn_cfg)
+        self.gamma1 = nn.Parameter(self.layer_scale * torch.ones(self.embed_dims))
+        self.gamma2 = nn.Parameter(self.layer_scale * torch.ones(self.embed_dims))
+        self.gamma3 = nn.Parameter(self.layer_scale * torch.ones(self.embed_dims))
+
+    def forward(self, query):
+        query = query + self.gamma1 * self.Conv(query)
+        query = query + self.gamma2 * self.dcn(query)
+        return query + self.gamma3 * self.ffn(query)
+
+
+class DCNDetrTransformerEncoder(nn.Module):
+    def __init__(self, num_layers, layer_cfg, init_cfg=None):
+        super().__init__()
+        self.num_layers = num_layers
+        self.layer_cfg = ConfigDict(layer_cfg)
+        self.layers = nn.ModuleList([DCNDetrTransformerEncoderLayer(**self.layer_cfg) for _ in range(num_layers)])
+        self.embed_dims = self.layers[0].embed_dims
+
+    def forward(self, query):
+        for layer in self.layers:
+            query = layer(query)
+        return query
+
+
+class MultiHeadAttentionBlock(nn.Module):
+    """Decoder attention block (identical code for SA and CA in the reference, transformer.py:196-361):
+    q,k,v = LIF(BN1d(Conv1d(LIF(.)))); out = BN1d(Conv1d(LIF( (q k^T / sqrt(C)) v ))).  No softmax, so the core is
+    evaluated as q (k^T v) / sqrt(C) by ops.sdsa on channel-major spikes -- exact for spike operands."""
+
+    def __init__(self, embed_dims, num_heads=8, attn_drop=0.0, dropout=0.0, proj_drop=0.0, batch_first=True,
+                 dropout_layer=None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.embed_dim = embed_dims
+        self.scale = (embed_dims // num_heads) ** -0.5
+
+        def proj():
+            return nn.Sequential(nn.Conv1d(embed_dims, embed_dims, kernel_size=1, stride=1), nn.BatchNorm1d(embed_dims))
+
+        self.q_conv_spike = _lif(); self.q_conv = proj()
+        self.k_conv_spike = _lif(); self.k_conv = proj()
+        self.v_conv_spike = _lif(); self.v_conv = proj()
+        self.q_spike = _lif()
+        self.k_spike = _lif()
+        self.v_spike = _lif()
+        self.attn_spike = _lif()
+        self.out_conv = proj()
+
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
+        if attn_mask is not None:
+            raise NotImplementedError("attn_mask is always None on the MaskFormerHead path (maskformer_head.py:554-564)")
+        t, b, nq, dim = query.shape
+        nk = key.shape[2]
+
+        def proj(spike_in, conv, spike_out, x):                 # x [t,b,L,dim] -> channel-major spikes [t*b, dim, L]
+            x = spike_in(x).permute(0, 1, 3, 2).flatten(0, 1)
+            return spike_out(conv(x))
+
+        q = proj(self.q_conv_spike, self.q_conv, self.q_spike, query)
+        k = proj(self.k_conv_spike, self.k_conv, self.k_spike, key)
+        v = proj(self.v_conv_spike, self.v_conv, self.v_spike, value)
+        o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5))      # embed_dim**0.5, not head dim
+        o = self.out_conv(self.attn_spike(o))
+        return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
+
+
+CrossMultiHeadAttentionBlock = MultiHeadAttentionBlock
+
+
+class MultiheadAttention(nn.Module):
+    """Wrapper adding the positional encodings (transformer.py:505-638); returns the block output WITHOUT identity."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0, attn_type="SA", dropout_layer=None,
+                 init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.num_heads = num_heads
+        self.batch_first = batch_first
+        if attn_type in ("LinearCA", "LinearSA"):
+            raise NotImplementedError(f"attn_type={attn_type} is not used by any Spike2Former config")
+        self.attn = MultiHeadAttentionBlock(embed_dims, num_heads, attn_drop, **kwargs)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        if query_pos is not None:
+            query = query + query_pos
+        if key_pos is not None:
+            key = key + key_pos
+        return self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask)[0]
+
+
+class MSDA_FFN(nn.Module):
+    """Decoder FFN (transformer.py:710-784); both `reshape`s are reinterpretations, not transposes (:777,:781)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=2048, num_fcs=2, act_cfg=None, ffn_drop=0.0, T=4,
+                 dropout_layer=None, add_identity=True, init_cfg=None, layer_scale_init_value=0.0):
+        super().__init__()
+        assert num_fcs >= 2
+        self.embed_dims = embed_dims
+        self.feedforward_channels = feedforward_channels
+        self.num_fcs = num_fcs
+        self.T = T
+        self.fc1_spike = _lif()
+        self.fc1 = nn.Conv1d(embed_dims, feedforward_channels, kernel_size=1, stride=1)
+        self.bn1 = nn.BatchNorm1d(feedforward_channels)
+        self.fc2_spike = _lif()
+        self.fc2 = nn.Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
+        self.bn2 = nn.BatchNorm1d(embed_dims)
+
+    def forward(self, x, identity=None):
+        t, bs, N, C = x.shape
+        a = self.fc1_spike(x).reshape(t * bs, C, N)
+        a = self.fc2_spike(self.bn1(self.fc1(a)))
+        return self.bn2(self.fc2(a)).reshape(t, bs, N, C)
+
+
+class DetrTransformerDecoderLayer(nn.Module):
+    """query += CA(query, memory); query += SA(query); query += FFN(query)   (detr_layers.py:417-559)."""
+
+    def __init__(self, self_attn_cfg=None, cross_attn_cfg=None, ffn_cfg=None, T=4, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        self.self_attn_cfg = ConfigDict(self_attn_cfg or dict(embed_dims=256, num_heads=8, batch_first=True))
+        self.cross_attn_cfg = ConfigDict(cross_attn_cfg or dict(embed_dims=256, num_heads=8, batch_first=True))
+        for c in (self.self_attn_cfg, self.cross_attn_cfg):
+            if "batch_first" not in c:
+                c["batch_first"] = True
+            else:
+                assert c["batch_first"] is True
+        self.ffn_cfg = ConfigDict(ffn_cfg or dict(embed_dims=256, feedforward_channels=1024, num_fcs=2))
+        self.self_attn = MultiheadAttention(**self.self_attn_cfg)
+        self.cross_attn = MultiheadAttention(**self.cross_attn_cfg)
+        self.embed_dims = self.self_attn.embed_dims
+        self.ffn = MSDA_FFN(**self.ffn_cfg)
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, self_attn_mask=None,
+                cross_attn_mask=None, key_padding_mask=None, **kwargs):
+        query = query + self.cross_attn(query=query, key=key, value=value, query_pos=query_pos, key_pos=key_pos,
+                                        attn_mask=cross_attn_mask, key_padding_mask=key_padding_mask)
+        query = query + self.self_attn(query=query, key=query, value=query, query_pos=query_pos, key_pos=query_pos,
+                                       attn_mask=self_attn_mask)
+        return query + self.ffn(query)
+
+
+class DetrTransformerDecoder(nn.Module):
+    def __init__(self, num_layers, layer_cfg, post_norm_cfg=None, return_intermediate=True, init_cfg=None):
+        super().__init__()
+        self.layer_cfg = ConfigDict(layer_cfg)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.layers = nn.ModuleList([DetrTransformerDecoderLayer(**self.layer_cfg) for _ in range(num_layers)])
+        self.embed_dims = self.layers[0].embed_dims
+
+    def forward(self, query, key, value, query_pos, key_pos, key_padding_mask=None, **kwargs):
+        inter = []
+        for layer in self.layers:
+            query = layer(query, key=key, value=value, query_pos=query_pos, key_pos=key_pos,
+                          key_padding_mask=key_padding_mask, **kwargs)
+            if self.return_intermediate:
+                inter.append(query)
+        return torch.stack(inter) if self.return_intermediate else query.unsqueeze(0)
+
+
+class SinePositionalEncoding(nn.Module):
+    """positional_encoding.py:59-98 (normalised sine/cosine embedding of the cumulative valid-pixel count)."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6, offset=0.0,
+                 init_cfg=None):
+        super().__init__()
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+
+    def forward(self, mask):
+        not_mask = 1 - mask.to(torch.int)
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+        dim_t = torch.arange(self.num_feats, dtype=torch.float32, device=mask.device)
+        dim_t = self.temperature ** (2 * (dim_t // 2) / self.num_feats)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        B, H, W = mask.size()
+        pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).view(B, H, W, -1)
+        pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).view(B, H, W, -1)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)

@@ -1,0 +1,129 @@
+"""MaskFormer head with the SDME mask-embedding block, registry type 'MaskFormerHead'.
+
+One class covers the reference's two layers: mmdet `MaskFormerHead.forward`
+(mmdet/models/dense_heads/maskformer_head.py:31-160, 498-586) and the mmseg wrapper's `predict` / constructor
+(mmseg/models/decode_heads/maskformer_head.py:22-51, 138-180).  The Hungarian-matched loss (`loss_by_feat`) is SURVEY
+section 8 row f1 ("next") and is not part of this hot path; `loss()` raises.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .head_layers import MLP, DetrTransformerDecoder, SinePositionalEncoding
+from .neuron import Q_IFNode, Quant
+from .registry import MODELS, ConfigDict
+
+
+def _lif():
+    return Q_IFNode(surrogate_function=Quant())
+
+
+@MODELS.register_module()
+class MaskFormerHead(nn.Module):
+    def __init__(self, in_channels, feat_channels, out_channels, num_classes=None, num_things_classes=80,
+                 num_stuff_classes=53, num_queries=100, T=4, pixel_decoder=None, enforce_decoder_input_project=False,
+                 transformer_decoder=None, positional_encoding=dict(num_feats=128, normalize=True), loss_cls=None,
+                 loss_mask=None, loss_dice=None, train_cfg=None, test_cfg=None, init_cfg=None, align_corners=False,
+                 ignore_index=255, in_index=None, **kwargs):
+        super().__init__()
+        if num_classes is None:
+            num_classes = num_things_classes + num_stuff_classes
+        self.num_things_classes = num_things_classes
+        self.num_stuff_classes = num_stuff_classes
+        self.num_classes = num_classes
+        self.num_queries = num_queries
+        transformer_decoder = ConfigDict(transformer_decoder)
+        self.num_transformer_decoder_layers = transformer_decoder.num_layers
+        self.num_transformer_feat_level = 3
+        self.T = T
+        self.alpha = 4
+        self.Identity = nn.Identity()
+        pixel_decoder = ConfigDict(pixel_decoder)
+        pixel_decoder.update(in_channels=in_channels, feat_channels=feat_channels, out_channels=out_channels)
+        self.pixel_decoder = MODELS.build(pixel_decoder)
+        self.transformer_decoder = DetrTransformerDecoder(**transformer_decoder)
+        self.decoder_embed_dims = self.transformer_decoder.embed_dims
+        self.decoder_input_projs = nn.ModuleList()
+        for _ in range(self.num_transformer_feat_level):
+            if self.decoder_embed_dims != feat_channels or enforce_decoder_input_project:
+                self.decoder_input_projs.append(nn.Conv2d(feat_channels, self.decoder_embed_dims, kernel_size=1))
+            else:
+                self.decoder_input_projs.append(nn.Identity())
+        self.decoder_pe = SinePositionalEncoding(**positional_encoding)
+        self.query_embed = nn.Embedding(num_queries, out_channels)
+        self.query_feat = nn.Embedding(num_queries, out_channels)
+        self.level_embed = nn.Embedding(self.num_transformer_feat_level, feat_channels)
+        self.decoder_post_norm = nn.Sigmoid()
+        self.decoder_out_spike = _lif()
+        self.cls_embed = nn.Linear(feat_channels, num_classes + 1)
+        self.mask_embed_spike = _lif()
+        self.mask_embed = MLP(in_dim=feat_channels, out_dim=out_channels, layer=3, T=T, quant_const=self.alpha)
+        self.w = nn.Parameter(torch.ones(1))
+        self.shortcut_conv_spike = _lif()
+        self.shortcut_conv = nn.Sequential(nn.Conv1d(num_queries, num_queries, kernel_size=1, stride=1, bias=False),
+                                           nn.BatchNorm1d(num_queries))
+        self.test_cfg, self.train_cfg = test_cfg, train_cfg
+        self.align_corners = align_corners
+        self.out_channels = num_classes
+        self.ignore_index = ignore_index
+        self._pe_cache = {}
+
+    def init_weights(self):
+        pass
+
+    def _pos(self, bs, h, w, device):
+        key = (bs, h, w, str(device))
+        if key not in self._pe_cache:        # all-valid mask -> data independent
+            m = torch.zeros((bs, h, w), dtype=torch.bool, device=device)
+            self._pe_cache[key] = self.decoder_pe(m).flatten(2).permute(0, 2, 1).contiguous()
+        return self._pe_cache[key]
+
+    def forward(self, x, batch_data_samples=None):
+        """x: the 4 backbone maps.  -> all_cls_scores [L+1,B,Q,K+1], all_mask_preds [L+1,B,Q,H/2,W/2]."""
+        mask_features, memory, msm = self.pixel_decoder(x, None)
+        t, bs = memory.shape[:2]
+        query_feat = self.query_feat.weight.unsqueeze(0).repeat((t, bs, 1, 1))
+        query_embed = self.query_embed.weight.unsqueeze(0).repeat(bs, 1, 1)
+        dec_in, dec_pos = [], []
+        for i in range(self.num_transformer_feat_level):
+            d = self.decoder_input_projs[i](msm[i])
+            d = d.flatten(3).permute(0, 1, 3, 2) + self.level_embed.weight[i].view(1, 1, -1)
+            dec_in.append(d)
+            dec_pos.append(self._pos(bs, msm[i].shape[-2], msm[i].shape[-1], d.device))
+        out_dec = [query_feat]
+        for i in range(self.num_transformer_decoder_layers):
+            lv = i % self.num_transformer_feat_level
+            query_feat = self.transformer_decoder.layers[i](
+                query=query_feat, key=dec_in[lv], value=dec_in[lv], query_pos=query_embed, key_pos=dec_pos[lv],
+                cross_attn_mask=None, key_padding_mask=None)
+            out_dec.append(query_feat)
+        out_dec = torch.stack(out_dec)
+        ln, t, bs, nq, C = out_dec.shape
+        # ---- SDME block (maskformer_head.py:568-582)
+        z = self.decoder_post_norm(out_dec)
+        a = self.alpha * self.decoder_out_spike(z)
+        all_cls_scores = self.cls_embed(a).mean(1)
+        sc = self.shortcut_conv((self.alpha * self.shortcut_conv_spike(z)).reshape(ln * t * bs, nq, C))
+        e = self.mask_embed(a) + self.w * sc.view(ln, t, bs, nq, C)
+        e = self.alpha * self.mask_embed_spike(e)
+        # einsum('ltbqc,tbchw->ltbqhw').mean(t) with the mean folded into the contraction: the reference's
+        # [L+1,T,B,Q,H,W] intermediate (734 MB / image at 512^2, T=4) is never materialised.
+        Hm, Wm = mask_features.shape[-2:]
+        mf = mask_features.flatten(3)                                    # [t, b, C, HW]
+        acc = None
+        for ti in range(t):
+            et = e[:, ti].permute(1, 0, 2, 3).reshape(bs, ln * nq, C)   # [b, L*Q, C]
+            acc = torch.bmm(et, mf[ti]) if acc is None else torch.baddbmm(acc, et, mf[ti])
+        all_mask_preds = (acc / t).view(bs, ln, nq, Hm, Wm).permute(1, 0, 2, 3, 4)
+        return all_cls_scores, all_mask_preds
+
+    def predict(self, x, batch_img_metas, test_cfg=None):
+        """mmseg MaskFormerHead.predict (decode_heads/maskformer_head.py:138-180) -> seg logits [B,K,H,W]."""
+        cls, masks = self(x, None)
+        img_shape = batch_img_metas[0].get("batch_input_shape", batch_img_metas[0]["img_shape"])
+        mp = F.interpolate(masks[-1], size=tuple(img_shape), mode="bilinear", align_corners=False)
+        cls_score = F.softmax(cls[-1], dim=-1)[..., :-1]
+        return torch.einsum("bqc,bqhw->bchw", cls_score, mp.sigmoid())
+
+    def loss(self, x, batch_data_samples, train_cfg=None):
+        raise NotImplementedError("Hungarian-matched MaskFormer loss is SURVEY section 8 row f1 (next), not this path")

@@ -1,0 +1,76 @@
+"""Host-side mirror of `Q_IFNode` / `Quant` / `reset_net` (Qtrick_architecture/clock_driven/neuron.py:395-550,
+surrogate.py:644-701, functional.py:9-33, base.py:25-161).  The arithmetic runs in libs2f_hip.so (ops.lif)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Quant(nn.Module):
+    """Surrogate marker object (`Q_IFNode(surrogate_function=Quant())`): forward round(clamp(.,0,D)), straight-through
+    backward inside [0, D] (surrogate.py:522-538).  Carries only the level count."""
+
+    def __init__(self, alpha=4.0, spiking=True, D=8):
+        super().__init__()
+        self.alpha, self.spiking, self.D = alpha, spiking, D
+
+
+class Q_IFNode(nn.Module):
+    """Quantised integrate-and-fire node: h = v + x; s = rint(clamp(h,0,D)); v <- h - s*vth; returns s/D.
+
+    `v` is a non-parameter memory that is NOT in the state_dict (base.py:25-69): python float 0. after `reset()`,
+    afterwards a tensor shaped like the input, carried to the next call.
+    `keep_membrane=False` skips writing `v` -- output-identical whenever `reset()` precedes every forward (what
+    ResetModelHook guarantees during training, resetmodel_hook.py:17-37); it saves 4 B/element of HBM traffic.
+    """
+
+    def __init__(self, v_threshold=1.0, v_reset=0.0, surrogate_function=None, detach_reset=False,
+                 cupy_fp32_inference=False):
+        super().__init__()
+        assert isinstance(v_threshold, float) and isinstance(detach_reset, bool)
+        if detach_reset:
+            raise NotImplementedError("detach_reset=True is not instantiated anywhere on the Spike2Former path")
+        self.v_threshold = v_threshold
+        self.v_reset = v_reset
+        self.detach_reset = detach_reset
+        self.surrogate_function = surrogate_function if surrogate_function is not None else Quant()
+        self.D = getattr(self.surrogate_function, "D", 8)
+        self.v = 0.0
+        self.keep_membrane = True
+        self.stats = None          # int64[2] device tensor {sum of counts, non-zero counts} when firing is recorded
+        self.stats_elems = 0
+
+    def reset(self):
+        self.v = 0.0
+
+    def extra_repr(self):
+        return f"v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}, D={self.D}"
+
+    def _apply(self, fn, *a, **k):
+        if isinstance(self.v, torch.Tensor):
+            self.v = fn(self.v)
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x):
+        v_in = None if isinstance(self.v, float) else self.v
+        if self.stats is not None:
+            self.stats_elems += x.numel()
+        y, v_out = ops.lif(x, v_in, self.D, self.v_threshold, self.keep_membrane, self.stats)
+        if self.keep_membrane:
+            self.v = v_out
+        else:
+            self.v = 0.0
+        return y
+
+
+def reset_net(net: nn.Module):
+    """functional.reset_net (functional.py:9-33): call `reset()` on every module that has one."""
+    for m in net.modules():
+        if hasattr(m, "reset"):
+            m.reset()
+
+
+def set_keep_membrane(net: nn.Module, keep: bool):
+    for m in net.modules():
+        if isinstance(m, Q_IFNode):
+            m.keep_membrane = keep

@@ -1,0 +1,190 @@
+"""torch.autograd wrappers around the C ABI.  Torch is plumbing here: it owns device memory and the stream; all
+arithmetic of these ops happens in libs2f_hip.so.  Every op raises on non-CUDA input -- there is no fallback."""
+import torch
+
+from ._lib import check, lib
+
+
+# When set to a list, every neuron-kernel launch is bracketed by two HIP events on the launch stream and
+# (name, algorithmic_bytes, start, end) is appended -- bench.py's live roofline measurement.  Algorithmic bytes are
+# SURVEY section 8d's per-element figures: forward 8 B (read x, write y), backward 12 B (read gy, read x, write gx).
+KERNEL_EVENTS = None
+
+
+def _ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"spike2former_amd ops compute in fp32; got {t.dtype}")
+
+
+def mask_words(n):
+    return ((n + 255) >> 8) * 4
+
+
+# ------------------------------------------------------------------------------------------------ LIF
+class _LIF(torch.autograd.Function):
+    """One Q_IFNode call (neuron.py:166-197 + surrogate.py:522-538).  Saves 1 bit/element for backward."""
+
+    @staticmethod
+    def forward(ctx, x, v_in, D, vth, keep_v, stats):
+        _need_cuda(x, v_in)
+        x = x.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        n = x.numel()
+        y = torch.empty_like(x)
+        v_out = torch.empty_like(x) if keep_v else None
+        need_grad = x.requires_grad or (v_in is not None and v_in.requires_grad)
+        mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
+        e0 = _ev() if KERNEL_EVENTS is not None else None
+        check(lib.s2f_lif_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), 0, _ptr(stats), n, vth, D,
+                              _stream()), "s2f_lif_fwd")
+        if e0 is not None:
+            KERNEL_EVENTS.append(("lif_fwd", 8 * n, e0, _ev()))
+        ctx.save_for_backward(mask)
+        ctx.D, ctx.vth, ctx.has_v = D, vth, v_in is not None
+        if v_out is None:
+            v_out = x.new_empty(0)
+            ctx.mark_non_differentiable(v_out)
+        return y, v_out
+
+    @staticmethod
+    def backward(ctx, gy, gv):
+        (mask,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gv is not None and gv.numel() != gy.numel():
+            gv = None
+        if gv is not None:
+            gv = gv.contiguous()
+        gx = torch.empty_like(gy)
+        e0 = _ev() if KERNEL_EVENTS is not None else None
+        check(lib.s2f_lif_bwd(_ptr(gy), _ptr(gv), _ptr(mask), _ptr(gx), gy.numel(), ctx.vth, ctx.D, _stream()),
+              "s2f_lif_bwd")
+        if e0 is not None:
+            KERNEL_EVENTS.append(("lif_bwd", 12 * gy.numel(), e0, _ev()))
+        return gx, (gx if ctx.has_v else None), None, None, None, None
+
+
+def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None):
+    """-> (y, v_out or None)"""
+    y, v = _LIF.apply(x, v_in, D, vth, keep_v, stats)
+    return y, (v if keep_v else None)
+
+
+class _LIFSeq(torch.autograd.Function):
+    """T chained stateful calls on one neuron, membrane in registers (cal_firing_num.py:203-225 across images)."""
+
+    @staticmethod
+    def forward(ctx, x_seq, v0, D, vth, stats):
+        _need_cuda(x_seq, v0)
+        x_seq = x_seq.contiguous()
+        T = x_seq.shape[0]
+        n = x_seq[0].numel()
+        y = torch.empty_like(x_seq)
+        vT = torch.empty_like(x_seq[0])
+        mask = torch.empty(T * mask_words(n), dtype=torch.int64, device=x_seq.device)
+        check(lib.s2f_lif_seq_fwd(_ptr(x_seq), _ptr(None if v0 is None else v0.contiguous()), _ptr(y), _ptr(vT),
+                                  _ptr(mask), _ptr(stats), T, n, vth, D, _stream()), "s2f_lif_seq_fwd")
+        ctx.save_for_backward(mask)
+        ctx.D, ctx.vth, ctx.has_v0, ctx.T, ctx.n = D, vth, v0 is not None, T, n
+        return y, vT
+
+    @staticmethod
+    def backward(ctx, gy, gvT):
+        (mask,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        gv0 = torch.empty_like(gy[0]) if ctx.has_v0 else None
+        check(lib.s2f_lif_seq_bwd(_ptr(gy), _ptr(None if gvT is None else gvT.contiguous()), _ptr(mask), _ptr(gx),
+                                  _ptr(gv0), ctx.T, ctx.n, ctx.vth, ctx.D, _stream()), "s2f_lif_seq_bwd")
+        return gx, gv0, None, None, None
+
+
+def lif_seq(x_seq, v0=None, D=8, vth=1.0, stats=None):
+    return _LIFSeq.apply(x_seq, v0, D, vth, stats)
+
+
+# ------------------------------------------------------------------------------------------------ attention core
+class _SDSA(torch.autograd.Function):
+    """o = scale * q (k^T v) on channel-major spikes [TB, C, N] (sdtv2.py:335-339; transformer.py:253-274)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        _need_cuda(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        TB, C, Nq = q.shape
+        Nk = k.shape[2]
+        d = C // heads
+        o = torch.empty_like(q)
+        kv = torch.empty(TB, heads, d, d, dtype=torch.float32, device=q.device)
+        check(lib.s2f_sdsa_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(kv), TB, heads, d, Nq, Nk, scale, _stream()),
+              "s2f_sdsa_fwd")
+        ctx.save_for_backward(q, k, v, kv)
+        ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, kv = ctx.saved_tensors
+        go = go.contiguous()
+        TB, C, Nq = q.shape
+        Nk = k.shape[2]
+        d = C // ctx.heads
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty_like(kv)
+        check(lib.s2f_sdsa_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv), _ptr(go), _ptr(gq), _ptr(gk), _ptr(gv), _ptr(ws),
+                               TB, ctx.heads, d, Nq, Nk, ctx.scale, _stream()), "s2f_sdsa_bwd")
+        return gq, gk, gv, None, None
+
+
+def sdsa(q, k, v, heads, scale):
+    return _SDSA.apply(q, k, v, heads, scale)
+
+
+# ------------------------------------------------------------------------------------------------ DCNv3 core
+class _DCNv3(torch.autograd.Function):
+    """dcnv3_core_pytorch (ops_dcnv3/functions/dcnv3_func.py:147-189), NHWC in/out."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, offset_scale):
+        _need_cuda(x, offset, mask)
+        x, offset, mask = x.contiguous(), offset.contiguous(), mask.contiguous()
+        N, H, W, _ = x.shape
+        Ho, Wo = offset.shape[1], offset.shape[2]
+        out = torch.empty(N, Ho, Wo, G * Cg, dtype=torch.float32, device=x.device)
+        geo = (N, H, W, G, Cg, kh, kw, sh, sw, ph, pw, dh, dw)
+        check(lib.s2f_dcnv3_fwd(_ptr(x), _ptr(offset), _ptr(mask), _ptr(out), *geo, offset_scale, _stream()),
+              "s2f_dcnv3_fwd")
+        ctx.save_for_backward(x, offset, mask)
+        ctx.geo, ctx.osc = geo, offset_scale
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, offset, mask = ctx.saved_tensors
+        go = go.contiguous()
+        gx = torch.zeros_like(x)
+        goff, gm = torch.empty_like(offset), torch.empty_like(mask)
+        check(lib.s2f_dcnv3_bwd(_ptr(x), _ptr(offset), _ptr(mask), _ptr(go), _ptr(gx), _ptr(goff), _ptr(gm), *ctx.geo,
+                                ctx.osc, _stream()), "s2f_dcnv3_bwd")
+        return (gx, goff, gm) + (None,) * 11
+
+
+def dcnv3_core(x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, offset_scale):
+    return _DCNv3.apply(x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, float(offset_scale))

@@ -1,0 +1,83 @@
+"""DCN pixel decoder, registry type 'mmdet.DCNTransformerEncoderPixelDecoder'
+(mmdet/models/layers/pixel_decoder.py:316-472; the base-class neuron it inherits and uses is :80)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .head_layers import DCNDetrTransformerEncoder, SinePositionalEncoding
+from .neuron import Q_IFNode, Quant
+from .registry import MODELS
+
+
+def _lif():
+    return Q_IFNode(surrogate_function=Quant())
+
+
+@MODELS.register_module()
+class DCNTransformerEncoderPixelDecoder(nn.Module):
+    """forward(feats[4] of [T,B,C_i,H_i,W_i]) -> (mask_feature [T,B,C,H/2,W/2], memory [T,B,C,H/16,W/16], [y16,y8,y4]).
+
+    Module registration order follows the reference (base `PixelDecoder.__init__` first, then the overrides), so that
+    `named_modules()` -- and with it the firing table of cal_firing_num.py -- lists neurons in the same order.
+    `encoder_in_proj_spike` is constructed but never called, as in the reference (:396 vs :435).
+    """
+
+    def __init__(self, in_channels, feat_channels, out_channels, T=4, norm_cfg=None, act_cfg=None, encoder=None,
+                 positional_encoding=dict(num_feats=128, normalize=True), init_cfg=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.feat_channels = feat_channels
+        self.num_inputs = len(in_channels)
+        self.use_bias = norm_cfg is None
+        self.T = T
+        # names in the order the reference's base class registers them (pixel_decoder.py:57-87)
+        self.lateral_convs = nn.ModuleList()
+        self.lateral_convs_spike = nn.ModuleList()
+        self.output_convs = nn.ModuleList()
+        self.output_convs_spike = nn.ModuleList()
+        for i in range(self.num_inputs - 1):
+            self.lateral_convs.append(nn.Sequential(nn.Conv2d(in_channels[i], feat_channels, kernel_size=1, stride=1),
+                                                    nn.BatchNorm2d(feat_channels)))
+            self.lateral_convs_spike.append(_lif())
+            self.output_convs.append(nn.Sequential(
+                nn.Conv2d(feat_channels, feat_channels, kernel_size=3, padding=1, groups=feat_channels, bias=False),
+                nn.BatchNorm2d(feat_channels)))
+            self.output_convs_spike.append(_lif())
+        self.last_feat_conv_spike = _lif()
+        self.last_feat_conv = None
+        self.mask_feature_spike = _lif()
+        self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1, stride=1)
+        self.encoder = DCNDetrTransformerEncoder(**encoder)
+        self.encoder_embed_dims = self.encoder.embed_dims
+        assert self.encoder_embed_dims == feat_channels, (
+            f"embed_dims({feat_channels}) of tranformer encoder must equal to feat_channels({self.encoder_embed_dims})")
+        self.positional_encoding = SinePositionalEncoding(**positional_encoding)
+        self.encoder_in_proj_spike = _lif()
+        self.encoder_in_proj = nn.Sequential(nn.Conv2d(in_channels[-1], feat_channels, kernel_size=1, stride=1),
+                                             nn.BatchNorm2d(feat_channels))
+        self.encoder_out_proj_spike = _lif()
+        self.encoder_out_proj = nn.Sequential(nn.Conv2d(feat_channels, feat_channels, kernel_size=1, stride=1),
+                                              nn.BatchNorm2d(feat_channels))
+
+    def init_weights(self):
+        pass
+
+    def forward(self, feats, batch_img_metas=None):
+        x4 = feats[-1]
+        t, bs, c, h, w = x4.shape
+        E = self.encoder_embed_dims
+        y = self.last_feat_conv_spike(x4)
+        y = self.encoder_in_proj(y.flatten(0, 1)).reshape(t, bs, E, h, w)
+        memory = self.encoder(query=y.permute(0, 1, 3, 4, 2))
+        memory = memory.permute(0, 1, 4, 2, 3).contiguous()
+        memory = self.encoder_out_proj_spike(memory)
+        y = self.encoder_out_proj(memory.flatten(0, 1))
+        out = [y.reshape(t, bs, E, h, w)]
+        for i in range(self.num_inputs - 2, -1, -1):
+            x = self.lateral_convs_spike[i](feats[i])
+            cur = self.lateral_convs[i](x.flatten(0, 1))
+            y = cur + F.interpolate(y, size=cur.shape[-2:], mode="bilinear", align_corners=False)
+            y = self.output_convs[i](self.output_convs_spike[i](y))
+            out.append(y.reshape(t, bs, *y.shape[1:]))
+        y = self.mask_feature_spike(y)
+        mf = self.mask_feature(y)
+        return mf.reshape(t, bs, *mf.shape[1:]), memory, out[:3]

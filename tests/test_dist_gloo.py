@@ -1,0 +1,51 @@
+"""CPU, world_size 2, gloo: the N>1 path -- batch sharding plus ONE all-reduce of the flat gradient buffer."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from spike2former_amd.dist import FlatGradAllReduce, broadcast_params, init_process_group, shard_batch
+    r, w, _ = init_process_group("gloo")
+    torch.manual_seed(100 + rank)                        # deliberately different init per rank
+    lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    broadcast_params(lin, 0)
+    red = FlatGradAllReduce(lin.parameters(), world)
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(8, 6, generator=g)               # the global batch, identical on every rank
+    start, per = shard_batch(8, r, w)
+    red.zero()
+    lin(data[start:start + per]).square().mean().backward()
+    local = red.flat.clone()
+    red.reduce(); red.wait()
+    gathered = [torch.zeros_like(local) for _ in range(w)]
+    dist.all_gather(gathered, local)
+    want = torch.stack(gathered).mean(0)
+    ok = torch.allclose(red.flat, want, atol=1e-7) and all(
+        p.grad.data_ptr() >= red.flat.data_ptr() for p in lin.parameters())
+    p0 = torch.cat([p.detach().flatten() for p in lin.parameters()])
+    ps = [torch.zeros_like(p0) for _ in range(w)]
+    dist.all_gather(ps, p0)
+    ok = ok and torch.equal(ps[0], ps[1])
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_grad_allreduce_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}

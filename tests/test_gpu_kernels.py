@@ -1,0 +1,235 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI (spike2former_amd.ops -> libs2f_hip.so), against
+the oracle and the committed golden vectors.  Bit-exact for the neuron and the spike attention core; stated fp
+tolerances for DCNv3."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.requires_grad_(True) if grad else t
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spike2former_amd import ops
+    return ops
+
+
+@pytest.fixture(scope="module")
+def so():
+    from oracle import s2f_oracle
+    return s2f_oracle
+
+
+def unpack_mask(words, n):
+    """Inverse of the wave-ballot layout documented in include/s2f.h."""
+    w = words.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    tiles = w.shape[0]
+    out = np.zeros(tiles * 256, dtype=bool)
+    lanes = np.arange(64, dtype=np.uint64)
+    for j in range(4):
+        bits = (w[:, j][:, None] >> lanes[None, :]) & np.uint64(1)
+        out.reshape(tiles, 64, 4)[:, :, j] = bits.astype(bool)
+    return out[:n]
+
+
+# ----------------------------------------------------------------------------------------------- neuron
+def test_lif_known_answers(ops, golden):
+    g = golden("lif_kat.npz")
+    x = T(g["kat_x"])
+    v = None
+    for t in range(4):
+        y, v = ops.lif(x, v)
+        assert np.array_equal((y * 8).cpu().numpy(), g["kat_counts"][t])
+    assert np.array_equal(v.cpu().numpy(), g["kat_v_final"])
+    y, _ = ops.lif(T(g["half_x"]))
+    assert np.array_equal((y * 8).cpu().numpy(), g["half_counts"])       # round-half-to-even, clamp edges
+    x = T(g["grad2_x"], grad=True)
+    y1, v = ops.lif(x)
+    y2, v = ops.lif(x, v)
+    (y1.sum() + y2.sum()).backward()
+    assert np.array_equal(x.grad.cpu().numpy(), g["grad2_gx"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 1000, 4099, 1 << 20])
+def test_lif_vs_c_oracle_ragged_sizes(ops, n):
+    from oracle import lif_ref
+    from spike2former_amd._lib import lib
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 4 + 2).astype(np.float32)
+    x[: n // 7] = np.round(x[: n // 7] * 2) / 2          # plenty of exact .5 ties
+    v0 = rng.standard_normal(n).astype(np.float32)
+    if n == 0:
+        y, v = ops.lif(torch.zeros(0, device="cuda"))
+        assert y.numel() == 0
+        return
+    ry, rv, rc, rin = lif_ref.seq_fwd(x[None], v0)
+    xt, vt = T(x, grad=True), T(v0, grad=True)
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    y, v = ops.lif(xt, vt, stats=stats)
+    assert np.array_equal(y.detach().cpu().numpy(), ry[0]) and np.array_equal(v.detach().cpu().numpy(), rv)
+    assert stats.tolist() == [int(rc.sum()), int((rc != 0).sum())]
+    gy, gv = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    (y * T(gy)).sum().backward(retain_graph=True)
+    rgx, _ = lif_ref.seq_bwd(gy[None], rin)
+    assert np.array_equal(xt.grad.cpu().numpy(), rgx[0]) and np.array_equal(vt.grad.cpu().numpy(), rgx[0])
+    xt.grad = None; vt.grad = None
+    ((y * T(gy)).sum() + (v * T(gv)).sum()).backward()
+    rgx, _ = lif_ref.seq_bwd(gy[None], rin, gv)
+    assert np.array_equal(xt.grad.cpu().numpy(), rgx[0])
+    # the packed in-range mask and the optional u8 counts, straight through the C ABI
+    yy = torch.empty(n, device="cuda"); cnt = torch.empty(n, dtype=torch.uint8, device="cuda")
+    mask = torch.zeros(int(lib.s2f_lif_mask_words(n)), dtype=torch.int64, device="cuda")
+    assert lib.s2f_lif_fwd(xt.data_ptr(), vt.data_ptr(), yy.data_ptr(), None, mask.data_ptr(), cnt.data_ptr(), None, n,
+                           1.0, 8, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(unpack_mask(mask, n), rin[0].astype(bool)) and np.array_equal(cnt.cpu().numpy(), rc[0])
+
+
+def test_lif_four_levels_stateless(ops):
+    """The D=4 stateless variant of the E-SpikeFormer backbone (mmseg/models/utils/Qtrick.py:4-38)."""
+    x = torch.linspace(-1, 6, 2001, device="cuda")
+    y, _ = ops.lif(x, None, D=4, keep_v=False)
+    assert torch.equal(y, torch.round(torch.clamp(x, 0, 4)) / 4)
+
+
+def test_lif_seq_matches_chained_calls_and_golden(ops, golden):
+    g = golden("lif_kat.npz")
+    xs, v0 = T(g["seq_x"], grad=True), T(g["seq_v0"], grad=True)
+    stats = torch.zeros(2 * xs.shape[0], dtype=torch.int64, device="cuda")
+    y, vT = ops.lif_seq(xs, v0, stats=stats)
+    assert np.array_equal(y.detach().cpu().numpy(), g["seq_y"]) and np.array_equal(vT.detach().cpu().numpy(), g["seq_vT"])
+    ((y * T(g["seq_wy"])).sum() + (vT * T(g["seq_wv"])).sum()).backward()
+    assert np.array_equal(xs.grad.cpu().numpy(), g["seq_gx"]) and np.array_equal(v0.grad.cpu().numpy(), g["seq_gv0"])
+    assert stats.view(-1, 2)[:, 0].tolist() == (g["seq_y"] * 8).sum(1).astype(np.int64).tolist()
+    # fused-over-T == T single-step launches
+    v, ys = T(g["seq_v0"]), []
+    for t in range(xs.shape[0]):
+        yt, v = ops.lif(xs.detach()[t], v)
+        ys.append(yt)
+    assert torch.equal(torch.stack(ys), y.detach()) and torch.equal(v, vT.detach())
+    y2, _ = ops.lif_seq(T(np.stack([g["kat_x"]] * 4)))                       # no initial membrane
+    assert np.array_equal((y2 * 8).cpu().numpy(), g["kat_counts"])
+
+
+def test_lif_full_size_properties(ops):
+    """BASELINE full size (the largest single neuron call at C2, [4,2,256,256,256] = 134 M elements): properties that
+    do not need the oracle -- output on the 9-point grid, y + v' == x exactly, idempotence of the stateless map."""
+    n = 4 * 2 * 256 * 256 * 256
+    x = torch.randn(n, device="cuda") * 3 + 1
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    y, v = ops.lif(x, None, stats=stats)
+    c = y * 8
+    assert torch.equal(c, torch.round(c)) and float(c.min()) == 0 and float(c.max()) == 8
+    assert torch.equal(x - c, v)
+    assert int(stats[0]) == int(c.double().sum()) and int(stats[1]) == int((c != 0).sum())
+    y2, _ = ops.lif(c, None, keep_v=False)
+    assert torch.equal(y2, y)
+
+
+# ----------------------------------------------------------------------------------------------- attention core
+@pytest.mark.parametrize("TB,heads,d,Nq,Nk", [(4, 8, 32, 1024, 1024), (2, 8, 45, 256, 256), (3, 8, 8, 10, 30),
+                                               (2, 8, 32, 100, 4096), (1, 1, 64, 7, 513)])
+def test_sdsa_exact_for_spikes(ops, TB, heads, d, Nq, Nk):
+    """With spike operands all partial sums are exact in fp32 (< 2^24 ulp), so the kernel must equal the reference's
+    (q k^T) v association bit for bit -- the bound is asserted, not assumed."""
+    g = torch.Generator().manual_seed(TB * 1000 + d)
+    C = heads * d
+
+    def spikes(n):
+        return torch.clamp(torch.round(torch.randn(TB, C, n, generator=g) + 0.6), 0, 8) / 8
+    q, k, v = spikes(Nq), spikes(Nk), spikes(Nk)
+    scale = d ** -0.5
+
+    def heads_view(t):
+        return t.view(TB, heads, d, -1).transpose(2, 3)                        # [TB, h, N, d]
+    kv = heads_view(k).transpose(-2, -1).double() @ heads_view(v).double()
+    o64 = heads_view(q).double() @ kv
+    assert float(kv.abs().max()) * 64 < 2 ** 24 and float(o64.abs().max()) * 512 < 2 ** 24
+    ref = ((heads_view(q) @ (heads_view(k).transpose(-2, -1) @ heads_view(v))) * scale)   # sdtv2.py:335-336, fp32
+    ref_dec = (heads_view(q) @ heads_view(k).transpose(-2, -1)) / 16.0 @ heads_view(v)    # transformer.py:262-272
+    ref = ref.transpose(2, 3).reshape(TB, C, Nq)
+    ref_dec = ref_dec.transpose(2, 3).reshape(TB, C, Nq)
+    out = ops.sdsa(q.cuda(), k.cuda(), v.cuda(), heads, scale)
+    assert torch.equal(out.cpu(), ref)
+    out = ops.sdsa(q.cuda(), k.cuda(), v.cuda(), heads, 1.0 / 16.0)
+    assert torch.equal(out.cpu(), ref_dec)
+
+
+def test_sdsa_backward(ops):
+    TB, heads, d, Nq, Nk = 2, 8, 32, 100, 300
+    g = torch.Generator().manual_seed(1)
+    C = heads * d
+    q, k, v = (torch.randn(TB, C, n, generator=g).double().requires_grad_(True) for n in (Nq, Nk, Nk))
+    go = torch.randn(TB, C, Nq, generator=g).double()
+
+    def hv(t):
+        return t.view(TB, heads, d, -1).transpose(2, 3)
+    o = (hv(q) @ (hv(k).transpose(-2, -1) @ hv(v)) * 0.37).transpose(2, 3).reshape(TB, C, Nq)
+    o.backward(go)
+    qc, kc, vc = (t.detach().float().cuda().requires_grad_(True) for t in (q, k, v))
+    oc = ops.sdsa(qc, kc, vc, heads, 0.37)
+    oc.backward(go.float().cuda())
+    for a, b, name in ((oc, o, "o"), (qc.grad, q.grad, "gq"), (kc.grad, k.grad, "gk"), (vc.grad, v.grad, "gv")):
+        err = (a.detach().cpu().double() - b.detach()).abs().max().item()
+        assert err <= 2e-5 * b.abs().max().item(), name          # fp32 accumulation over <= 300 terms
+
+
+# ----------------------------------------------------------------------------------------------- DCNv3
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_dcnv3_vs_reference_vectors(ops, golden, tag):
+    """Tolerances of test_oracle_golden.py::test_dcnv3_core_vs_reference (the reference's grid arithmetic is not
+    bit-reproducible by a pixel-coordinate kernel)."""
+    g = golden("dcnv3_core.npz")
+    N, H, W, G, Cg, K, s, p, d = (int(v) for v in g[f"{tag}_geom"])
+    x, off, m = (T(g[f"{tag}_{k}"], grad=True) for k in ("x", "offset", "mask"))
+    y = ops.dcnv3_core(x, off, m, K, K, s, s, p, p, d, d, G, Cg, float(g[f"{tag}_offset_scale"]))
+    y.backward(T(g[f"{tag}_gy"]))
+
+    def close(a, key, rel):
+        b = g[f"{tag}_{key}"]
+        return np.abs(a.detach().cpu().numpy() - b).max() <= rel * np.abs(b).max()
+    assert close(y, "y", 2e-4) and close(x.grad, "gx", 2e-4) and close(m.grad, "gmask", 2e-4)
+    assert close(off.grad, "goffset", 2e-3)
+
+
+def test_dcnv3_vs_oracle_hot_path_geometry(ops, so):
+    """C2 geometry per (t,b): 32x32, G=32, Cg=8, K=3, spikes as mask -- against the oracle's gather restatement."""
+    g = torch.Generator().manual_seed(2)
+    N, H, W, G, Cg = 2, 32, 32, 32, 8
+    x = torch.randn(N, H, W, G * Cg, generator=g)
+    off = torch.randn(N, H, W, G * 18, generator=g) * 2
+    m = torch.clamp(torch.round(torch.randn(N, H, W, G * 9, generator=g) + 1), 0, 8) / 8
+    gy = torch.randn(N, H, W, G * Cg, generator=g)
+    xo, oo, mo = (t.clone().requires_grad_(True) for t in (x, off, m))
+    so.dcnv3_core(xo, oo, mo, G, Cg).backward(gy)
+    xc, oc, mc = (t.cuda().requires_grad_(True) for t in (x, off, m))
+    y = ops.dcnv3_core(xc, oc, mc, 3, 3, 1, 1, 1, 1, 1, 1, G, Cg, 1.0)
+    y.backward(gy.cuda())
+    yo = so.dcnv3_core(x, off, m, G, Cg)
+    for a, b, tol, name in ((y, yo, 1e-5, "y"), (xc.grad, xo.grad, 1e-5, "gx"), (mc.grad, mo.grad, 1e-5, "gm"),
+                            (oc.grad, oo.grad, 1e-4, "goff")):
+        assert (a.detach().cpu() - b).abs().max().item() <= tol * b.abs().max().item(), name
+
+
+def test_dcnv3_zero_offset_is_a_modulated_3x3_average(ops):
+    """Size-independent property: zero offsets + constant mask 1 turn DCNv3 into a 3x3 box filter with zero padding."""
+    N, H, W, G, Cg = 8, 32, 32, 32, 8
+    x = torch.randn(N, H, W, G * Cg, device="cuda")
+    y = ops.dcnv3_core(x, torch.zeros(N, H, W, G * 18, device="cuda"), torch.ones(N, H, W, G * 9, device="cuda"),
+                       3, 3, 1, 1, 1, 1, 1, 1, G, Cg, 1.0)
+    ref = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1, count_include_pad=True) * 9
+    assert torch.allclose(y, ref.permute(0, 2, 3, 1), atol=1e-5, rtol=1e-5)
+
+
+def test_errors_are_raised_not_swallowed(ops):
+    from spike2former_amd._lib import S2FError
+    with pytest.raises(S2FError, match="head dim|d <="):
+        ops.sdsa(torch.zeros(1, 130, 4, device="cuda"), torch.zeros(1, 130, 4, device="cuda"),
+                 torch.zeros(1, 130, 4, device="cuda"), 2, 1.0)
+    with pytest.raises(RuntimeError, match="fp32"):
+        ops.lif(torch.zeros(8, device="cuda", dtype=torch.float16))

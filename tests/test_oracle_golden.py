@@ -1,0 +1,160 @@
+"""CPU: the oracle (oracle/s2f_oracle.py + oracle/lif_ref.c) against the vectors captured from the reference itself
+(tests/golden/*.npz, written by oracle/gen_golden.py in the build container).  No reference needed to run."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lif_ref
+from oracle import s2f_oracle as so
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_lif_kats_python_and_c(golden):
+    g = golden("lif_kat.npz")
+    # the captured counts, verbatim
+    assert g["kat_counts"].astype(int).tolist() == [[0, 0, 2, 2, 8, 8, 0, 3], [1, 1, 1, 3, 8, 8, 0, 4],
+                                                    [0, 0, 2, 2, 8, 8, 0, 3], [0, 1, 1, 3, 8, 8, 0, 4]]
+    x4 = np.stack([g["kat_x"]] * 4)
+    for impl in (lambda x, v: so.lif_seq_numpy(x, v), lambda x, v: lif_ref.seq_fwd(x, v)[2:0:-1]):
+        c, vT = impl(x4, None)
+        assert np.array_equal(np.asarray(c), g["kat_counts"].astype(np.uint8))
+        assert np.array_equal(np.asarray(vT), g["kat_v_final"])
+    # round-half-to-even and the clamp edges
+    c, _ = so.lif_seq_numpy(g["half_x"][None])
+    assert np.array_equal(c[0], g["half_counts"].astype(np.uint8))
+    assert np.array_equal(lif_ref.seq_fwd(g["half_x"][None])[2][0], g["half_counts"].astype(np.uint8))
+    assert g["half_counts"][:9].astype(int).tolist() == [0, 2, 2, 4, 4, 6, 6, 8, 8]
+
+
+def test_lif_gradient_kats(golden):
+    g = golden("lif_kat.npz")
+    x = T(g["grad2_x"]).requires_grad_(True)
+    y1, v, _ = so.lif_step(x, None)
+    y2, v, _ = so.lif_step(x, v)
+    (y1.sum() + y2.sum()).backward()
+    assert torch.equal(x.grad, T(g["grad2_gx"]))
+    assert g["grad2_gx"].tolist() == [0.25, 0.25, 0.25, 0.0, 0.0]
+    # BPTT over 5 steps with a membrane gradient: torch restatement and C restatement, both bit-exact
+    xs = T(g["seq_x"]).requires_grad_(True); v0 = T(g["seq_v0"]).requires_grad_(True)
+    v, ys = v0, []
+    for t in range(xs.shape[0]):
+        y, v, _ = so.lif_step(xs[t], v)
+        ys.append(y)
+    ((torch.stack(ys) * T(g["seq_wy"])).sum() + (v * T(g["seq_wv"])).sum()).backward()
+    assert torch.equal(torch.stack(ys).detach(), T(g["seq_y"])) and torch.equal(v.detach(), T(g["seq_vT"]))
+    assert torch.equal(xs.grad, T(g["seq_gx"])) and torch.equal(v0.grad, T(g["seq_gv0"]))
+    y, vT, c, inr = lif_ref.seq_fwd(g["seq_x"], g["seq_v0"])
+    assert np.array_equal(y, g["seq_y"]) and np.array_equal(vT, g["seq_vT"])
+    gx, gv0 = lif_ref.seq_bwd(g["seq_wy"], inr, g["seq_wv"])
+    assert np.array_equal(gx, g["seq_gx"]) and np.array_equal(gv0, g["seq_gv0"])
+
+
+def test_lif_empty_and_ragged():
+    c, v = so.lif_seq_numpy(np.zeros((3, 0), np.float32))
+    assert c.shape == (3, 0) and v.shape == (0,)
+    y, vT, c, inr = lif_ref.seq_fwd(np.full((1, 7), 2.5, np.float32))
+    assert c.tolist() == [[2] * 7]
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_dcnv3_core_vs_reference(golden, tag):
+    """Tolerances: the reference builds its sampling grid in normalised fp32 coordinates, so a pixel-coordinate
+    restatement is not bit-identical (use rtol 1e-4; the reference's own CUDA check used 1e-2/1e-3)."""
+    g = golden("dcnv3_core.npz")
+    N, H, W, G, Cg, K, s, p, d = (int(v) for v in g[f"{tag}_geom"])
+    x, off, m = (T(g[f"{tag}_{k}"]).requires_grad_(True) for k in ("x", "offset", "mask"))
+    y = so.dcnv3_core(x, off, m, G, Cg, K, s, p, d, float(g[f"{tag}_offset_scale"]))
+    y.backward(T(g[f"{tag}_gy"]))
+
+    def close(a, b, rel):
+        return (a - b).abs().max().item() <= rel * b.abs().max().item()
+    assert close(y.detach(), T(g[f"{tag}_y"]), 2e-4)
+    assert close(x.grad, T(g[f"{tag}_gx"]), 2e-4)
+    assert close(off.grad, T(g[f"{tag}_goffset"]), 2e-3)
+    assert close(m.grad, T(g[f"{tag}_gmask"]), 2e-4)
+
+
+def test_param_tree_matches_reference_state_dict(golden):
+    g = golden("e2e_C1_64.npz")
+    shapes = so.param_shapes(so.CONFIGS["C1_64"])
+    assert set(g["grad_keys"]) <= set(shapes)
+    assert len(shapes) == 1216            # 823-key backbone / 1037-key head layout of SURVEY Appendix A, shrunken widths
+    c2 = so.param_shapes(so.CONFIGS["C2"])
+    n = sum(int(np.prod(s)) for k, s in c2.items() if "running_" not in k and "num_batches" not in k)
+    assert n == 34_361_112                # 14.75 M backbone + 19.61 M head
+
+
+def test_end_to_end_vs_reference(golden):
+    g = golden("e2e_C1_64.npz")
+    cfg = so.CONFIGS["C1_64"]
+    st = so.make_params(cfg)
+    net = so.OracleNet(st, cfg, training=True)
+    img = T(g["img"])
+    assert torch.equal(img, so.synthetic_image(cfg))
+    taps = {}
+    net.tap = lambda n, y: taps.__setitem__(n, y)
+    cls, masks = net.forward(img)
+    so.headline_loss(cls, masks).backward()
+    assert torch.equal(cls.detach(), T(g["cls"])) and torch.equal(masks.detach(), T(g["masks"]))   # bit-exact forward
+    names = list(g["lif_names"])
+    assert set(names) == set(net.firing) and len(names) == 150
+    assert np.array_equal(np.array([net.firing[n] for n in names]), g["firing"])
+    for k in g.files:
+        if k.startswith("tap__"):
+            assert np.array_equal((taps[k[5:]].detach() * 8).numpy().astype(np.uint8), g[k]), k
+    gscale = g["grad_absmax"].max()
+    for k, amax in zip(g["grad_keys"], g["grad_absmax"]):
+        mine = st[str(k)].grad.abs().max().item()
+        assert abs(mine - amax) <= 2e-3 * amax + 5e-6 * gscale, k
+    for i, k in enumerate(g["sel_keys"]):
+        ref = T(g[f"sel_grad_{i}"])
+        assert (st[str(k)].grad - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 5e-6 * gscale, k
+    for k, ssum in zip(g["stat_keys"], g["stat_sum"]):     # train-mode BN updated its running statistics
+        assert abs(st[str(k)].double().sum().item() - ssum) <= 1e-5 * max(1.0, abs(ssum)), k
+
+
+def test_stateful_firing_vs_reference(golden):
+    """cal_firing_num.py semantics: eval mode, three images, no reset in between (membranes carry over)."""
+    g = golden("stateful_C1_64.npz")
+    cfg = so.CONFIGS["C1_64"]
+    st = so.make_params(cfg, requires_grad=False)
+    net = so.OracleNet(st, cfg, training=False)
+    names = list(g["lif_names"])
+    with torch.no_grad():
+        for i, seed in enumerate(g["seeds"]):
+            cls, masks = net.forward(so.synthetic_image(cfg, seed=int(seed)))
+            assert np.array_equal(np.array([net.firing[n] for n in names]), g["firing"][i]), f"call {i}"
+    assert torch.equal(cls, T(g["cls_last"])) and torch.equal(masks, T(g["masks_last"]))
+    assert not np.array_equal(g["firing"][0], g["firing"][1])     # the state really matters
+
+
+def test_blocks_vs_reference(golden):
+    g = golden("blocks_C1_64.npz")
+    cfg = so.CONFIGS["C1_64"]
+    st = so.make_params(cfg)
+    net = so.OracleNet(st, cfg, training=True)
+    qp, kp = T(g["dec_layer_qpos"]), T(g["dec_layer_kpos"])
+    cases = {
+        "attn": lambda a: net._attn("backbone.block3.1.attn", a),
+        "repconv": lambda a: net._repconv_bn("backbone.block3.2.attn.q_conv", a),
+        "block3": lambda a: net._block("backbone.block3.3", a),
+        "dcn": lambda a: net._dcn("decode_head.pixel_decoder.encoder.layers.0.dcn", a),
+        "enc_layer": lambda a: net._enc_layer("decode_head.pixel_decoder.encoder.layers.1", a),
+        "dec_layer": lambda a, b: net._dec_layer("decode_head.transformer_decoder.layers.0", a, b, qp, kp),
+    }
+    for tag, fn in cases.items():
+        # gen_golden ran the blocks in this order on ONE reference model whose train-mode BN running statistics are
+        # mutated by each run; only RepConv's pad value reads them, and each block here is touched once -> same state.
+        net.reset()
+        xs = [T(g[f"{tag}_x{i}"]).requires_grad_(True) for i in range(2) if f"{tag}_x{i}" in g.files]
+        y = fn(*xs)
+        y.backward(T(g[f"{tag}_gy"]))
+        ref = T(g[f"{tag}_y"])
+        assert (y.detach() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), tag
+        for i, x in enumerate(xs):
+            r = T(g[f"{tag}_gx{i}"])
+            assert (x.grad - r).abs().max().item() <= 2e-3 * r.abs().max().item(), (tag, i)
+    assert torch.equal(so.sine_pos_embed(2, 6, 5, cfg.num_feats), T(g["pos_embed_2x6x5"]))
