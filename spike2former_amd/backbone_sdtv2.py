@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .conv import Conv1d, Conv2d
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -58,11 +59,11 @@ class RepConv(nn.Module):
 
     def __init__(self, in_channel, out_channel, bias=False):
         super().__init__()
-        conv1x1 = nn.Conv2d(in_channel, in_channel, 1, 1, 0, bias=False, groups=1)
+        conv1x1 = Conv2d(in_channel, in_channel, 1, 1, 0, bias=False, groups=1)
         bn = BNAndPadLayer(pad_pixels=1, num_features=in_channel)
         conv3x3 = nn.Sequential(
-            nn.Conv2d(in_channel, in_channel, 3, 1, 0, groups=in_channel, bias=False),
-            nn.Conv2d(in_channel, out_channel, 1, 1, 0, groups=1, bias=False),
+            Conv2d(in_channel, in_channel, 3, 1, 0, groups=in_channel, bias=False),
+            Conv2d(in_channel, out_channel, 1, 1, 0, groups=1, bias=False),
             nn.BatchNorm2d(out_channel))
         self.body = nn.Sequential(conv1x1, bn, conv3x3)
 
@@ -77,11 +78,11 @@ class SepConv(nn.Module):
         super().__init__()
         med = int(expansion_ratio * dim)
         self.spike1 = _lif()
-        self.pwconv1 = nn.Conv2d(dim, med, kernel_size=1, stride=1, bias=bias)
+        self.pwconv1 = Conv2d(dim, med, kernel_size=1, stride=1, bias=bias)
         self.bn1 = nn.BatchNorm2d(med)
         self.spike2 = _lif()
-        self.dwconv = nn.Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias)
-        self.pwconv2 = nn.Conv2d(med, dim, kernel_size=1, stride=1, bias=bias)
+        self.dwconv = Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias)
+        self.pwconv2 = Conv2d(med, dim, kernel_size=1, stride=1, bias=bias)
         self.bn2 = nn.BatchNorm2d(dim)
 
     def forward(self, x):
@@ -102,10 +103,10 @@ class MS_ConvBlock(nn.Module):
         self.Conv = SepConv(dim=dim)
         self.mlp_ratio = mlp_ratio
         self.spike1 = _lif()
-        self.conv1 = nn.Conv2d(dim, dim * mlp_ratio, kernel_size=3, padding=1, groups=1, bias=False)
+        self.conv1 = Conv2d(dim, dim * mlp_ratio, kernel_size=3, padding=1, groups=1, bias=False)
         self.bn1 = nn.BatchNorm2d(dim * mlp_ratio)
         self.spike2 = _lif()
-        self.conv2 = nn.Conv2d(dim * mlp_ratio, dim, kernel_size=3, padding=1, groups=1, bias=False)
+        self.conv2 = Conv2d(dim * mlp_ratio, dim, kernel_size=3, padding=1, groups=1, bias=False)
         self.bn2 = nn.BatchNorm2d(dim)
 
     def forward(self, x):
@@ -126,10 +127,10 @@ class MS_MLP(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1_conv = nn.Conv1d(in_features, hidden_features, kernel_size=1, stride=1)
+        self.fc1_conv = Conv1d(in_features, hidden_features, kernel_size=1, stride=1)
         self.fc1_bn = nn.BatchNorm1d(hidden_features)
         self.fc1_spike = _lif()
-        self.fc2_conv = nn.Conv1d(hidden_features, out_features, kernel_size=1, stride=1)
+        self.fc2_conv = Conv1d(hidden_features, out_features, kernel_size=1, stride=1)
         self.fc2_bn = nn.BatchNorm1d(out_features)
         self.fc2_spike = _lif()
         self.c_hidden = hidden_features
@@ -197,7 +198,7 @@ class MS_DownSampling(nn.Module):
 
     def __init__(self, in_channels=2, embed_dims=256, kernel_size=3, stride=2, padding=1, first_layer=True, T=None):
         super().__init__()
-        self.encode_conv = nn.Conv2d(in_channels, embed_dims, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.encode_conv = Conv2d(in_channels, embed_dims, kernel_size=kernel_size, stride=stride, padding=padding)
         self.encode_bn = nn.BatchNorm2d(embed_dims)
         self.first_layer = first_layer
         if not first_layer:

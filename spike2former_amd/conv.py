@@ -1,0 +1,51 @@
+"""Convolution plumbing without MIOpen.
+
+This image ships no gfx950 MIOpen find-db / kernel cache, so every MIOpen convolution JIT-compiles (and, in benchmark
+mode, exhaustively searches) its kernels on a fresh box: the first C2 step took > 15 minutes.  The path therefore never
+touches MIOpen (`torch.backends.cudnn.enabled = False`, set when the package is imported):
+
+  * 1x1 Conv2d / Conv1d(k=1) (the bulk of the path's FLOPs: q/k/v, MLP, pixel-decoder and decoder projections) are
+    plain GEMMs  Y[n] = W @ X[n]  on the channel-major activations -> rocBLAS (prebuilt gfx950 kernels);
+  * dense kxk convolutions (stem 7x7, MS_ConvBlock 3x3, downsampling 3x3/s2) are lowered to im2col + the same GEMM;
+  * depthwise convolutions and train-mode BatchNorm use ATen's native HIP kernels.
+
+The classes subclass nn.Conv2d / nn.Conv1d, so parameter names and shapes -- the checkpoint ABI -- are unchanged.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+torch.backends.cudnn.enabled = False        # = MIOpen on ROCm; see module docstring
+
+
+def _gemm_nc(weight2d, x3, bias):
+    """x3 [N, K, L], weight2d [M, K] -> [N, M, L]."""
+    y = torch.matmul(weight2d, x3)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1)
+    return y
+
+
+class Conv2d(nn.Conv2d):
+    def forward(self, x):
+        if x.device.type != "cuda":
+            raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+        if self.groups != 1:
+            return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        N, C, H, W = x.shape
+        M = self.out_channels
+        kh, kw = self.kernel_size
+        if kh == 1 and kw == 1 and self.stride == (1, 1) and self.padding == (0, 0):
+            return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), self.bias).view(N, M, H, W)
+        Ho = (H + 2 * self.padding[0] - self.dilation[0] * (kh - 1) - 1) // self.stride[0] + 1
+        Wo = (W + 2 * self.padding[1] - self.dilation[1] * (kw - 1) - 1) // self.stride[1] + 1
+        cols = F.unfold(x, (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]
+        return _gemm_nc(self.weight.view(M, -1), cols, self.bias).view(N, M, Ho, Wo)
+
+
+class Conv1d(nn.Conv1d):
+    def forward(self, x):
+        if x.device.type != "cuda":
+            raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+        assert self.kernel_size == (1,) and self.stride == (1,) and self.groups == 1, "only k=1 Conv1d is on the path"
+        return _gemm_nc(self.weight.view(self.out_channels, -1), x, self.bias)

@@ -260,9 +260,9 @@ inline int grid_for(int64_t n) {
 
 extern "C" int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
                            uint64_t* stats, int64_t n, float vth, int D, void* stream) {
+  if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_lif_fwd: null x/y");
   S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_fwd: bad n=%lld or D=%d", (long long)n, D);
-  if (n == 0) return S2F_OK;
   S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y) && s2f_aligned16(v_in) && s2f_aligned16(v_out), S2F_EALIGN,
               "s2f_lif_fwd: x/y/v must be 16-byte aligned");
   S2F_REQUIRE(count_u8 == nullptr || (reinterpret_cast<uintptr_t>(count_u8) & 3u) == 0, S2F_EALIGN,
@@ -280,9 +280,9 @@ extern "C" int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v
 
 extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth,
                            int D, void* stream) {
+  if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(gy && mask && gx, S2F_EINVAL, "s2f_lif_bwd: null gy/mask/gx");
   S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_bwd: bad n or D");
-  if (n == 0) return S2F_OK;
   S2F_REQUIRE(s2f_aligned16(gy) && s2f_aligned16(gx) && s2f_aligned16(gv_out), S2F_EALIGN,
               "s2f_lif_bwd: gy/gx/gv must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -297,9 +297,9 @@ extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t*
 
 extern "C" int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq, float* vT, uint64_t* mask,
                                uint64_t* stats, int T, int64_t n, float vth, int D, void* stream) {
+  if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(x_seq && y_seq, S2F_EINVAL, "s2f_lif_seq_fwd: null x/y");
   S2F_REQUIRE(T >= 1 && n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_seq_fwd: bad T/n/D");
-  if (n == 0) return S2F_OK;
   S2F_REQUIRE(T == 1 || (n % 4) == 0, S2F_EINVAL, "s2f_lif_seq_fwd: n must be a multiple of 4 when T > 1");
   S2F_REQUIRE(s2f_aligned16(x_seq) && s2f_aligned16(y_seq) && s2f_aligned16(v0) && s2f_aligned16(vT), S2F_EALIGN,
               "s2f_lif_seq_fwd: pointers must be 16-byte aligned");
@@ -316,9 +316,9 @@ extern "C" int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq
 
 extern "C" int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask, float* gx_seq, float* gv0,
                                int T, int64_t n, float vth, int D, void* stream) {
+  if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(gy_seq && mask && gx_seq, S2F_EINVAL, "s2f_lif_seq_bwd: null gy/mask/gx");
   S2F_REQUIRE(T >= 1 && n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_seq_bwd: bad T/n/D");
-  if (n == 0) return S2F_OK;
   S2F_REQUIRE(T == 1 || (n % 4) == 0, S2F_EINVAL, "s2f_lif_seq_bwd: n must be a multiple of 4 when T > 1");
   S2F_REQUIRE(s2f_aligned16(gy_seq) && s2f_aligned16(gx_seq) && s2f_aligned16(gvT) && s2f_aligned16(gv0), S2F_EALIGN,
               "s2f_lif_seq_bwd: pointers must be 16-byte aligned");

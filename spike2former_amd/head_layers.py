@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .conv import Conv1d, Conv2d
 from .neuron import Q_IFNode, Quant
 from .registry import ConfigDict
 
@@ -26,12 +27,12 @@ class SepConv_Spike(nn.Module):
         self.T = T
         self.expansion_ratio = expansion_ratio
         self.spike1 = _lif()
-        self.pwconv1 = nn.Sequential(nn.Conv2d(dim, med, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(med))
+        self.pwconv1 = nn.Sequential(Conv2d(dim, med, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(med))
         self.spike2 = _lif()
         self.dwconv = nn.Sequential(
-            nn.Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias), nn.BatchNorm2d(med))
+            Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias), nn.BatchNorm2d(med))
         self.spike3 = _lif()
-        self.pwconv2 = nn.Sequential(nn.Conv2d(med, dim, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(dim))
+        self.pwconv2 = nn.Sequential(Conv2d(med, dim, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(dim))
 
     def forward(self, x):
         T, B, H, W, C = x.shape
@@ -92,11 +93,11 @@ class DCNv3_pytorch(nn.Module):
         self.mask_spike = _lif()
         kk = kernel_size * kernel_size
         self.dw_conv = nn.Sequential(
-            nn.Conv2d(channels, channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
+            Conv2d(channels, channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
                       groups=channels, bias=False), nn.BatchNorm2d(channels))
-        self.offset = nn.Sequential(nn.Conv2d(channels, group * kk * 2, kernel_size=1, stride=1),
+        self.offset = nn.Sequential(Conv2d(channels, group * kk * 2, kernel_size=1, stride=1),
                                     nn.BatchNorm2d(group * kk * 2))
-        self.mask = nn.Sequential(nn.Conv2d(channels, group * kk, kernel_size=1, stride=1), nn.BatchNorm2d(group * kk))
+        self.mask = nn.Sequential(Conv2d(channels, group * kk, kernel_size=1, stride=1), nn.BatchNorm2d(group * kk))
         self.input_proj = SepConv_Spike(dim=channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
                                         expansion_ratio=expension_ratio)
         self.output_proj = SepConv_Spike(dim=channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
@@ -130,10 +131,10 @@ class MS_MLP(nn.Module):
         self.num_fcs = num_fcs
         self.T = T
         self.fc1_spike = _lif()
-        self.fc1_conv = nn.Conv1d(embed_dims, feedforward_channels, kernel_size=1, stride=1)
+        self.fc1_conv = Conv1d(embed_dims, feedforward_channels, kernel_size=1, stride=1)
         self.fc1_bn = nn.BatchNorm1d(feedforward_channels)
         self.fc2_spike = _lif()
-        self.fc2_conv = nn.Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
+        self.fc2_conv = Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
         self.fc2_bn = nn.BatchNorm1d(embed_dims)
 
     def forward(self, x):
@@ -200,7 +201,7 @@ class MultiHeadAttentionBlock(nn.Module):
         self.scale = (embed_dims // num_heads) ** -0.5
 
         def proj():
-            return nn.Sequential(nn.Conv1d(embed_dims, embed_dims, kernel_size=1, stride=1), nn.BatchNorm1d(embed_dims))
+            return nn.Sequential(Conv1d(embed_dims, embed_dims, kernel_size=1, stride=1), nn.BatchNorm1d(embed_dims))
 
         self.q_conv_spike = _lif(); self.q_conv = proj()
         self.k_conv_spike = _lif(); self.k_conv = proj()
@@ -272,10 +273,10 @@ class MSDA_FFN(nn.Module):
         self.num_fcs = num_fcs
         self.T = T
         self.fc1_spike = _lif()
-        self.fc1 = nn.Conv1d(embed_dims, feedforward_channels, kernel_size=1, stride=1)
+        self.fc1 = Conv1d(embed_dims, feedforward_channels, kernel_size=1, stride=1)
         self.bn1 = nn.BatchNorm1d(feedforward_channels)
         self.fc2_spike = _lif()
-        self.fc2 = nn.Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
+        self.fc2 = Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
         self.bn2 = nn.BatchNorm1d(embed_dims)
 
     def forward(self, x, identity=None):

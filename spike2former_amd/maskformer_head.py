@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .head_layers import MLP, DetrTransformerDecoder, SinePositionalEncoding
+from .conv import Conv1d, Conv2d
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS, ConfigDict
 
@@ -46,7 +47,7 @@ class MaskFormerHead(nn.Module):
         self.decoder_input_projs = nn.ModuleList()
         for _ in range(self.num_transformer_feat_level):
             if self.decoder_embed_dims != feat_channels or enforce_decoder_input_project:
-                self.decoder_input_projs.append(nn.Conv2d(feat_channels, self.decoder_embed_dims, kernel_size=1))
+                self.decoder_input_projs.append(Conv2d(feat_channels, self.decoder_embed_dims, kernel_size=1))
             else:
                 self.decoder_input_projs.append(nn.Identity())
         self.decoder_pe = SinePositionalEncoding(**positional_encoding)
@@ -60,7 +61,7 @@ class MaskFormerHead(nn.Module):
         self.mask_embed = MLP(in_dim=feat_channels, out_dim=out_channels, layer=3, T=T, quant_const=self.alpha)
         self.w = nn.Parameter(torch.ones(1))
         self.shortcut_conv_spike = _lif()
-        self.shortcut_conv = nn.Sequential(nn.Conv1d(num_queries, num_queries, kernel_size=1, stride=1, bias=False),
+        self.shortcut_conv = nn.Sequential(Conv1d(num_queries, num_queries, kernel_size=1, stride=1, bias=False),
                                            nn.BatchNorm1d(num_queries))
         self.test_cfg, self.train_cfg = test_cfg, train_cfg
         self.align_corners = align_corners

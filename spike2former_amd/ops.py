@@ -50,7 +50,7 @@ class _LIF(torch.autograd.Function):
         n = x.numel()
         y = torch.empty_like(x)
         v_out = torch.empty_like(x) if keep_v else None
-        need_grad = x.requires_grad or (v_in is not None and v_in.requires_grad)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
         e0 = _ev() if KERNEL_EVENTS is not None else None
         check(lib.s2f_lif_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), 0, _ptr(stats), n, vth, D,

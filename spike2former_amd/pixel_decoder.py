@@ -4,6 +4,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .head_layers import DCNDetrTransformerEncoder, SinePositionalEncoding
+from .conv import Conv1d, Conv2d
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -35,27 +36,27 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         self.output_convs = nn.ModuleList()
         self.output_convs_spike = nn.ModuleList()
         for i in range(self.num_inputs - 1):
-            self.lateral_convs.append(nn.Sequential(nn.Conv2d(in_channels[i], feat_channels, kernel_size=1, stride=1),
+            self.lateral_convs.append(nn.Sequential(Conv2d(in_channels[i], feat_channels, kernel_size=1, stride=1),
                                                     nn.BatchNorm2d(feat_channels)))
             self.lateral_convs_spike.append(_lif())
             self.output_convs.append(nn.Sequential(
-                nn.Conv2d(feat_channels, feat_channels, kernel_size=3, padding=1, groups=feat_channels, bias=False),
+                Conv2d(feat_channels, feat_channels, kernel_size=3, padding=1, groups=feat_channels, bias=False),
                 nn.BatchNorm2d(feat_channels)))
             self.output_convs_spike.append(_lif())
         self.last_feat_conv_spike = _lif()
         self.last_feat_conv = None
         self.mask_feature_spike = _lif()
-        self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1, stride=1)
+        self.mask_feature = Conv2d(feat_channels, out_channels, kernel_size=1, stride=1)
         self.encoder = DCNDetrTransformerEncoder(**encoder)
         self.encoder_embed_dims = self.encoder.embed_dims
         assert self.encoder_embed_dims == feat_channels, (
             f"embed_dims({feat_channels}) of tranformer encoder must equal to feat_channels({self.encoder_embed_dims})")
         self.positional_encoding = SinePositionalEncoding(**positional_encoding)
         self.encoder_in_proj_spike = _lif()
-        self.encoder_in_proj = nn.Sequential(nn.Conv2d(in_channels[-1], feat_channels, kernel_size=1, stride=1),
+        self.encoder_in_proj = nn.Sequential(Conv2d(in_channels[-1], feat_channels, kernel_size=1, stride=1),
                                              nn.BatchNorm2d(feat_channels))
         self.encoder_out_proj_spike = _lif()
-        self.encoder_out_proj = nn.Sequential(nn.Conv2d(feat_channels, feat_channels, kernel_size=1, stride=1),
+        self.encoder_out_proj = nn.Sequential(Conv2d(feat_channels, feat_channels, kernel_size=1, stride=1),
                                               nn.BatchNorm2d(feat_channels))
 
     def init_weights(self):

@@ -46,6 +46,9 @@ def test_end_to_end_train_step_vs_reference(env, golden):
     # spike maps: only isolated one-level flips allowed
     for n, mine in spikes.items():
         ref = g["tap__" + n]
+        if "transformer_decoder" in n:      # product keeps decoder spikes channel-major [TB, C, L]; reference [T,B,L,C]
+            mine = mine.reshape(ref.shape[0], ref.shape[1], ref.shape[3], ref.shape[2]).transpose(0, 1, 3, 2)
+        mine = mine.reshape(ref.shape)
         diff = mine.astype(int) - ref.astype(int)
         assert np.abs(diff).max() <= 1 and (diff != 0).mean() <= 2e-3, (n, (diff != 0).mean())
     # firing table (a14): same neurons, same order as the reference's hook table, same rates
