@@ -20,7 +20,9 @@ torch.backends.cudnn.enabled = False        # = MIOpen on ROCm; see module docst
 
 def _gemm_nc(weight2d, x3, bias):
     """x3 [N, K, L], weight2d [M, K] -> [N, M, L]."""
-    y = torch.matmul(weight2d, x3)
+    # bmm with the weight broadcast through a zero batch stride: rocBLAS strided-batched GEMM, no operand copies
+    # (torch.matmul would fold the batch into the rows of a transposed -- i.e. copied -- activation matrix)
+    y = torch.bmm(weight2d.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
     if bias is not None:
         y = y + bias.view(1, -1, 1)
     return y

@@ -167,6 +167,74 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(const float* __restrict__ 
   }
 }
 
+
+// Backward with the whole (n, group) slice resident in LDS: one workgroup owns grad_input[n, :, :, g*Cg:(g+1)*Cg]
+// (H*W*Cg floats, 32 KiB at the C2 geometry), so the scatter-add runs on LDS atomics and the slice is written back
+// with plain stores -- no global atomics, no pre-zeroed grad_input.  The input slice and the grad_output slice are
+// staged in LDS as well, so every bilinear corner is an LDS read.  Work item = (output pixel, tap).
+__global__ __launch_bounds__(256) void dcn_bwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ off,
+                                                          const float* __restrict__ msk, const float* __restrict__ gout,
+                                                          float* __restrict__ gin, float* __restrict__ goff,
+                                                          float* __restrict__ gmsk, Geom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x / g.G, gi = blockIdx.x % g.G;
+  const int Cg = g.Cg, C = g.G * g.Cg, P = g.Kh * g.Kw;
+  const int npix_in = g.H * g.W, npix_out = g.Ho * g.Wo;
+  float* s_in = smem;                       // [H*W][Cg]
+  float* s_gin = s_in + npix_in * Cg;       // [H*W][Cg]
+  float* s_go = s_gin + npix_in * Cg;       // [Ho*Wo][Cg]
+  const float* inb = in + (int64_t)n * npix_in * C + gi * Cg;
+  const float* gob = gout + (int64_t)n * npix_out * C + gi * Cg;
+  for (int e = threadIdx.x; e < npix_in * Cg; e += 256) {
+    const int p = e / Cg, c = e % Cg;
+    s_in[e] = inb[(int64_t)p * C + c];
+    s_gin[e] = 0.f;
+  }
+  for (int e = threadIdx.x; e < npix_out * Cg; e += 256) {
+    const int p = e / Cg, c = e % Cg;
+    s_go[e] = gob[(int64_t)p * C + c];
+  }
+  __syncthreads();
+  const int items = npix_out * P;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int pix = it / P, k = it % P;
+    const int ho = pix / g.Wo, wo = pix % g.Wo;
+    const int64_t gpix = (int64_t)n * npix_out + pix;
+    const int64_t ob = (gpix * g.G + gi) * P + k;
+    const float offx = off[ob * 2], offy = off[ob * 2 + 1];
+    const float m = msk[ob];
+    const Tap t = make_tap(g, ho, wo, k / g.Kh, k % g.Kh, offx, offy);
+    const float w00 = (1.f - t.ly) * (1.f - t.lx), w01 = (1.f - t.ly) * t.lx, w10 = t.ly * (1.f - t.lx),
+                w11 = t.ly * t.lx;
+    const bool b00 = t.vy0 && t.vx0, b01 = t.vy0 && t.vx1, b10 = t.vy1 && t.vx0, b11 = t.vy1 && t.vx1;
+    const int o00 = (t.y0 * g.W + t.x0) * Cg;
+    const int o01 = o00 + Cg, o10 = o00 + g.W * Cg, o11 = o10 + Cg;
+    float am = 0.f, ax = 0.f, ay = 0.f;
+    for (int c = 0; c < Cg; ++c) {
+      const float gv = s_go[pix * Cg + c];
+      const float a = b00 ? s_in[o00 + c] : 0.f, b = b01 ? s_in[o01 + c] : 0.f;
+      const float cc = b10 ? s_in[o10 + c] : 0.f, d = b11 ? s_in[o11 + c] : 0.f;
+      am += gv * (a * w00 + b * w01 + cc * w10 + d * w11);
+      ax += gv * ((1.f - t.ly) * (b - a) + t.ly * (d - cc));
+      ay += gv * ((1.f - t.lx) * (cc - a) + t.lx * (d - b));
+      const float gm = gv * m;
+      if (b00) atomicAdd(&s_gin[o00 + c], gm * w00);
+      if (b01) atomicAdd(&s_gin[o01 + c], gm * w01);
+      if (b10) atomicAdd(&s_gin[o10 + c], gm * w10);
+      if (b11) atomicAdd(&s_gin[o11 + c], gm * w11);
+    }
+    gmsk[ob] = am;
+    goff[ob * 2] = ax * m * g.osc;
+    goff[ob * 2 + 1] = ay * m * g.osc;
+  }
+  __syncthreads();
+  float* ginb = gin + (int64_t)n * npix_in * C + gi * Cg;
+  for (int e = threadIdx.x; e < npix_in * Cg; e += 256) {
+    const int p = e / Cg, c = e % Cg;
+    ginb[(int64_t)p * C + c] = s_gin[e];
+  }
+}
+
 int make_geom(Geom& g, int N, int H, int W, int G, int Cg, int Kh, int Kw, int sh, int sw, int ph, int pw, int dh, int dw,
               float osc, const char* who) {
   S2F_REQUIRE(N > 0 && H > 0 && W > 0 && G > 0 && Cg > 0 && Kh > 0 && Kw > 0 && sh > 0 && sw > 0 && ph >= 0 &&
@@ -217,6 +285,21 @@ extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const floa
                      "s2f_dcnv3_bwd");
   if (rc != S2F_OK) return rc;
   const int64_t total = (int64_t)N * g.Ho * g.Wo * G;
+  const size_t lds = sizeof(float) * ((size_t)2 * H * W + (size_t)g.Ho * g.Wo) * Cg;
+  if (lds <= 160 * 1024) {
+    // (n, group) slice fits in the CU's 160 KiB LDS: atomic-free path, overwrites grad_input completely
+    if (lds > 64 * 1024) {
+      static bool raised = false;
+      if (!raised) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        raised = true;
+      }
+    }
+    hipLaunchKernelGGL(dcn_bwd_lds_kernel, dim3(N * G), dim3(256), lds, (hipStream_t)stream, input, offset, mask,
+                       grad_output, grad_input, grad_offset, grad_mask, g);
+    return s2f_check_launch("s2f_dcnv3_bwd");
+  }
   const bool vec = (Cg % 4 == 0) && s2f_aligned16(input) && s2f_aligned16(grad_output);
   if (vec)
     hipLaunchKernelGGL(dcn_bwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,

@@ -87,37 +87,79 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ A,
   }
 }
 
-// grid (TB*heads, ceil(N/256)); block 256: thread = one column n, d accumulators in registers, M broadcast from LDS.
-template <bool TRANS>
+// grid (TB*heads, ceil(N/256)); block 256 = 4 waves.  Lane l of every wave owns columns n0+4l .. n0+4l+3 (one 16-byte
+// load per row of X); wave w owns output rows j in [w*JC, (w+1)*JC).  M is staged in LDS zero-padded to 4*JC columns,
+// and read as broadcast 16-byte rows: one ds_read_b128 feeds 16 FMAs.
+template <bool TRANS, int JC>
 __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X, const float* __restrict__ M,
                                                     float* __restrict__ Y, int heads, int d, int N, float alpha) {
-  __shared__ float sm[kDMax * kDMax];
+  constexpr int LD = 4 * JC;
+  __shared__ __attribute__((aligned(16))) float sm[kDMax * LD];
   const int bh = blockIdx.x;
   const int tb = bh / heads, h = bh % heads;
   const int C = heads * d;
   const float* m = M + (int64_t)bh * d * d;
-  for (int e = threadIdx.x; e < d * d; e += 256) {
-    const int i = e / d, j = e % d;
-    sm[i * d + j] = TRANS ? m[j * d + i] : m[i * d + j];
+  for (int e = threadIdx.x; e < d * LD; e += 256) {
+    const int i = e / LD, j = e % LD;
+    sm[e] = j < d ? (TRANS ? m[j * d + i] : m[i * d + j]) : 0.f;
   }
   __syncthreads();
-  const int n = blockIdx.y * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y * 256 + lane * 4;
   if (n >= N) return;
   const float* x = X + ((int64_t)tb * C + h * d) * N + n;
   float* y = Y + ((int64_t)tb * C + h * d) * N + n;
-  float acc[kDMax];
+  const bool vec = (n + 3 < N) && ((N & 3) == 0);
+  float acc[JC][4];
 #pragma unroll
-  for (int j = 0; j < kDMax; ++j) acc[j] = 0.f;
+  for (int j = 0; j < JC; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
   for (int i = 0; i < d; ++i) {
-    const float xv = x[(int64_t)i * N];
-    const float* row = sm + i * d;
+    float xv[4];
+    if (vec) {
+      const float4 t = *reinterpret_cast<const float4*>(x + (int64_t)i * N);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < kDMax; ++j)
-      if (j < d) acc[j] += xv * row[j];
+      for (int c = 0; c < 4; ++c) xv[c] = (n + c < N) ? x[(int64_t)i * N + c] : 0.f;
+    }
+    const float* row = sm + i * LD + wave * JC;
+#pragma unroll
+    for (int j4 = 0; j4 < JC; j4 += 4) {
+      const float4 mv = *reinterpret_cast<const float4*>(row + j4);
+      const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j4 + jj][c] += xv[c] * mm[jj];
+    }
   }
 #pragma unroll
-  for (int j = 0; j < kDMax; ++j)
-    if (j < d) y[(int64_t)j * N] = acc[j] * alpha;
+  for (int j = 0; j < JC; ++j) {
+    const int jg = wave * JC + j;
+    if (jg < d) {
+      if (vec) {
+        *reinterpret_cast<float4*>(y + (int64_t)jg * N) =
+            make_float4(acc[j][0] * alpha, acc[j][1] * alpha, acc[j][2] * alpha, acc[j][3] * alpha);
+      } else {
+        for (int c = 0; c < 4; ++c)
+          if (n + c < N) y[(int64_t)jg * N + c] = acc[j][c] * alpha;
+      }
+    }
+  }
+}
+
+template <bool TRANS>
+void launch_apply(const float* x, const float* m, float* y, int TB, int heads, int d, int N, float alpha, hipStream_t s) {
+  dim3 grid(TB * heads, (N + 255) / 256);
+  const int jc = ((d + 3) / 4 + 3) / 4 * 4;     // rows per wave, rounded up to a multiple of 4
+  if (jc <= 4)
+    hipLaunchKernelGGL((apply_kernel<TRANS, 4>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+  else if (jc <= 8)
+    hipLaunchKernelGGL((apply_kernel<TRANS, 8>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+  else if (jc <= 12)
+    hipLaunchKernelGGL((apply_kernel<TRANS, 12>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+  else
+    hipLaunchKernelGGL((apply_kernel<TRANS, 16>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
 }
 
 int pick_split(int TBh, int N) {
@@ -154,11 +196,11 @@ extern "C" int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, 
   S2F_REQUIRE(x && m && y, S2F_EINVAL, "s2f_sdsa_apply: null pointer");
   int rc = check("s2f_sdsa_apply", TB, heads, d, N);
   if (rc) return rc;
-  dim3 grid(TB * heads, (N + 255) / 256);
+  S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y), S2F_EALIGN, "s2f_sdsa_apply: x/y must be 16-byte aligned");
   if (transpose_m)
-    hipLaunchKernelGGL(apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, m, y, heads, d, N, alpha);
+    launch_apply<true>(x, m, y, TB, heads, d, N, alpha, (hipStream_t)stream);
   else
-    hipLaunchKernelGGL(apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, m, y, heads, d, N, alpha);
+    launch_apply<false>(x, m, y, TB, heads, d, N, alpha, (hipStream_t)stream);
   return s2f_check_launch("s2f_sdsa_apply");
 }
 
