@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .conv import Conv1d, Conv2d
+from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -31,7 +32,7 @@ class BNAndPadLayer(nn.Module):
         self.pad_pixels = pad_pixels
 
     def forward(self, x):
-        out = self.bn(x)
+        out, _ = bn_act(x, None, self.bn)
         p = self.pad_pixels
         if p > 0:
             bn = self.bn
@@ -67,8 +68,15 @@ class RepConv(nn.Module):
             nn.BatchNorm2d(out_channel))
         self.body = nn.Sequential(conv1x1, bn, conv3x3)
 
-    def forward(self, x):
-        return self.body(x)
+    def forward(self, x, outer_bn=None, lif=None, residual=None):
+        """conv1x1 -> BN+pad -> dw3x3 -> conv1x1 -> BN [-> outer BN [+ residual] [-> neuron]].
+        Returns (pre-activation or None, spikes or None) when `outer_bn` is given, else the tensor."""
+        x = self.body[1](self.body[0](x))
+        x = self.body[2][1](self.body[2][0](x))
+        if outer_bn is None:
+            return bn_act(x, None, self.body[2][2])[0]
+        x, _ = bn_act(x, None, self.body[2][2])
+        return bn_act(x, None, outer_bn, residual=residual, lif=lif)
 
 
 class SepConv(nn.Module):
@@ -85,13 +93,14 @@ class SepConv(nn.Module):
         self.pwconv2 = Conv2d(med, dim, kernel_size=1, stride=1, bias=bias)
         self.bn2 = nn.BatchNorm2d(dim)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """Returns SepConv(x) [+ residual] (the residual add is fused into the last BatchNorm kernel)."""
         T, B, C, H, W = x.shape
-        x = self.spike1(x)
-        x = self.bn1(self.pwconv1(x.flatten(0, 1)))
-        x = self.spike2(x)
-        x = self.dwconv(x)
-        return self.bn2(self.pwconv2(x)).reshape(T, B, C, H, W)
+        s = self.spike1(x)
+        _, s = bn_act(self.pwconv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
+        z = self.pwconv2(self.dwconv(s))
+        u, _ = bn_act(z, None, self.bn2, residual=None if residual is None else residual.flatten(0, 1))
+        return u.reshape(T, B, C, H, W)
 
 
 class MS_ConvBlock(nn.Module):
@@ -111,13 +120,11 @@ class MS_ConvBlock(nn.Module):
 
     def forward(self, x):
         T, B, C, H, W = x.shape
-        x = self.Conv(x) + x
-        feat = x
-        x = self.spike1(x)
-        x = self.bn1(self.conv1(x.flatten(0, 1)))
-        x = self.spike2(x)
-        x = self.bn2(self.conv2(x)).reshape(T, B, C, H, W)
-        return feat + x
+        feat = self.Conv(x, residual=x)                                  # x + SepConv(x)
+        s = self.spike1(feat)
+        _, s = bn_act(self.conv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
+        u, _ = bn_act(self.conv2(s), None, self.bn2, residual=feat.flatten(0, 1))   # feat + BN(conv2(.))
+        return u.reshape(T, B, C, H, W)
 
 
 class MS_MLP(nn.Module):
@@ -136,12 +143,13 @@ class MS_MLP(nn.Module):
         self.c_hidden = hidden_features
         self.c_output = out_features
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         T, B, C, H, W = x.shape
-        x = self.fc1_spike(x.flatten(3))
-        x = self.fc1_bn(self.fc1_conv(x.flatten(0, 1)))
-        x = self.fc2_spike(x)
-        return self.fc2_bn(self.fc2_conv(x)).reshape(T, B, C, H, W)
+        s = self.fc1_spike(x.flatten(3)).flatten(0, 1)
+        _, s = bn_act(self.fc1_conv.forward_nobias(s), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
+        res = None if residual is None else residual.reshape(T * B, C, H * W)
+        u, _ = bn_act(self.fc2_conv.forward_nobias(s), self.fc2_conv.bias, self.fc2_bn, residual=res)
+        return u.reshape(T, B, C, H, W)
 
 
 class MS_Attention_RepConv_qkv_id(nn.Module):
@@ -165,16 +173,17 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         self.attn_spike = _lif()
         self.proj_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         T, B, C, H, W = x.shape
         N = H * W
-        x = self.head_spike(x).flatten(0, 1)
-        q = self.q_spike(self.q_conv(x)).view(T * B, C, N)
-        k = self.k_spike(self.k_conv(x)).view(T * B, C, N)
-        v = self.v_spike(self.v_conv(x)).view(T * B, C, N)
+        s = self.head_spike(x).flatten(0, 1)
+        q = self.q_conv[0](s, outer_bn=self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N)
+        k = self.k_conv[0](s, outer_bn=self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N)
+        v = self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)
         o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
         o = self.attn_spike(o).view(T * B, C, H, W)
-        return self.proj_conv(o).reshape(T, B, C, H, W)
+        res = None if residual is None else residual.flatten(0, 1)
+        return self.proj_conv[0](o, outer_bn=self.proj_conv[1], residual=res)[0].reshape(T, B, C, H, W)
 
 
 class MS_Block(nn.Module):
@@ -189,8 +198,8 @@ class MS_Block(nn.Module):
         self.mlp = MS_MLP(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
 
     def forward(self, x):
-        x = x + self.attn(x)
-        return x + self.mlp(x)
+        x = self.attn(x, residual=x)          # x + attn(x), residual fused into the last BatchNorm kernel
+        return self.mlp(x, residual=x)        # x + mlp(x)
 
 
 class MS_DownSampling(nn.Module):
@@ -208,7 +217,7 @@ class MS_DownSampling(nn.Module):
         T, B = x.shape[:2]
         if hasattr(self, "encode_spike"):
             x = self.encode_spike(x)
-        x = self.encode_bn(self.encode_conv(x.flatten(0, 1)))
+        x, _ = bn_act(self.encode_conv.forward_nobias(x.flatten(0, 1)), self.encode_conv.bias, self.encode_bn)
         return x.reshape(T, B, *x.shape[1:])
 
 

@@ -30,24 +30,37 @@ def _gemm_nc(weight2d, x3, bias):
 
 class Conv2d(nn.Conv2d):
     def forward(self, x):
+        return self._conv(x, self.bias)
+
+    def forward_nobias(self, x):
+        """The convolution without its bias (the fused BatchNorm kernels add the bias on the fly)."""
+        return self._conv(x, None)
+
+    def _conv(self, x, bias):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         if self.groups != 1:
-            return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            return F.conv2d(x, self.weight, bias, self.stride, self.padding, self.dilation, self.groups)
         N, C, H, W = x.shape
         M = self.out_channels
         kh, kw = self.kernel_size
         if kh == 1 and kw == 1 and self.stride == (1, 1) and self.padding == (0, 0):
-            return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), self.bias).view(N, M, H, W)
+            return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias).view(N, M, H, W)
         Ho = (H + 2 * self.padding[0] - self.dilation[0] * (kh - 1) - 1) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - self.dilation[1] * (kw - 1) - 1) // self.stride[1] + 1
         cols = F.unfold(x, (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]
-        return _gemm_nc(self.weight.view(M, -1), cols, self.bias).view(N, M, Ho, Wo)
+        return _gemm_nc(self.weight.view(M, -1), cols, bias).view(N, M, Ho, Wo)
 
 
 class Conv1d(nn.Conv1d):
     def forward(self, x):
+        return self._conv(x, self.bias)
+
+    def forward_nobias(self, x):
+        return self._conv(x, None)
+
+    def _conv(self, x, bias):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         assert self.kernel_size == (1,) and self.stride == (1,) and self.groups == 1, "only k=1 Conv1d is on the path"
-        return _gemm_nc(self.weight.view(self.out_channels, -1), x, self.bias)
+        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias)

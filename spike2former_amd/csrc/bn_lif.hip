@@ -1,0 +1,378 @@
+// BatchNorm (train or eval) fused with the conv bias, the residual add and the following Q_IFNode, for gfx950.
+//
+// Reference chain (e.g. MS_ConvBlock / SepConv / MS_MLP, mmseg/models/backbones/sdtv2.py:167-255; Sequential(conv, BN)
+// + Q_IFNode everywhere in the head):   t = conv(x) + b ;  u = BN(t) [+ residual] ;  y = Q_IFNode(u)
+// which the reference runs as ~12 elementwise ATen kernels forward and as many backward.  Here:
+//   forward :  bn_stats  (1 read of z)  ->  bn_finalize (C threads: mean, rstd, running-stat update)
+//              bn_apply  (1 read of z [+ residual], writes u and/or the spikes y + 1-bit in-range mask)
+//   backward:  bn_bwd_reduce (per-channel sum(gu), sum(gu * xhat)) -> bn_bwd_apply (writes gz [, g_residual])
+//              with  gu = g_u + LIF-STE(g_y)  formed on the fly from the bit mask.
+// All kernels are HBM-bound streams over [N, C, L] (channel-major, L contiguous): lane l of a wave owns 4 consecutive
+// elements (one 16-byte access; L % 4 == 0 keeps them inside one channel row), the in-range bits are wave ballots as in
+// lif.hip.  Per-channel parameters are 2-3 floats per lane served from L1/L2.
+#include "s2f_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / S2F_WAVE;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ void block_atomic_add2(double a, double b, double* dst) {
+  __shared__ double red[2 * kWaves];
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[2 * w] = a;
+    red[2 * w + 1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+    for (int i = 0; i < kWaves; ++i) {
+      sa += red[2 * i];
+      sb += red[2 * i + 1];
+    }
+    atomicAdd(dst, sa);
+    atomicAdd(dst + 1, sb);
+  }
+}
+
+// grid (C, S): block (c, s) reduces rows n*C + c, columns [s*slice, (s+1)*slice).
+__global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                          double* __restrict__ sums, int N, int C, int L, int slice) {
+  const int c = blockIdx.x;
+  const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
+  const float b = bias ? bias[c] : 0.0f;
+  double s = 0.0, q = 0.0;
+  const bool vec = (L & 3) == 0;
+  for (int n = 0; n < N; ++n) {
+    const float* row = z + ((int64_t)n * C + c) * L;
+    float ps = 0.f, pq = 0.f;       // fp32 partials over <= slice/256*4 elements, folded into fp64 per row
+    if (vec) {
+      for (int l = l0 + threadIdx.x * 4; l < l1; l += kBlock * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + l);
+        const float a0 = v.x + b, a1 = v.y + b, a2 = v.z + b, a3 = v.w + b;
+        ps += (a0 + a1) + (a2 + a3);
+        pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    } else {
+      for (int l = l0 + threadIdx.x; l < l1; l += kBlock) {
+        const float a = row[l] + b;
+        ps += a;
+        pq += a * a;
+      }
+    }
+    s += (double)ps;
+    q += (double)pq;
+  }
+  block_atomic_add2(s, q, sums + 2 * c);
+}
+
+// One thread per channel.  train: mean/var from the fp64 sums, running statistics updated in place with the unbiased
+// variance (torch.nn.BatchNorm semantics, momentum m).  eval: mean/var = running statistics.
+// stat[c] = mean, stat[C + c] = rstd = 1/sqrt(var + eps).
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stat,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches, int C, double count, float momentum, float eps,
+                                   int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    const double m = sums[2 * c] / count;
+    double v = sums[2 * c + 1] / count - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m;
+    var = (float)v;
+    if (running_mean != nullptr) {
+      const float unbiased = count > 1 ? (float)(v * (count / (count - 1.0))) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (c == 0 && num_batches != nullptr) *num_batches += 1;
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  stat[c] = mean;
+  stat[C + c] = 1.0f / sqrtf(var + eps);
+}
+
+struct Tile4 {
+  float a[4];
+};
+__device__ __forceinline__ Tile4 ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  Tile4 t; t.a[0] = v.x; t.a[1] = v.y; t.a[2] = v.z; t.a[3] = v.w;
+  return t;
+}
+__device__ __forceinline__ void st4(float* p, const Tile4& t) {
+  *reinterpret_cast<float4*>(p) = make_float4(t.a[0], t.a[1], t.a[2], t.a[3]);
+}
+
+// u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
+template <bool LIF, bool HAS_V>
+__global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                          const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ res,
+                                                          float* __restrict__ u_out, const float* __restrict__ v_in,
+                                                          float* __restrict__ y, float* __restrict__ v_out,
+                                                          uint64_t* __restrict__ mask,
+                                                          unsigned long long* __restrict__ stats, int64_t total, int C,
+                                                          int L, float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+  const int64_t ntiles = (total + 255) >> 8;
+  uint32_t csum = 0, cnz = 0;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    const bool ok = base < total;                       // total % 4 == 0 -> whole float4 valid or not
+    bool inr[4] = {false, false, false, false};
+    if (ok) {
+      const int c = (int)((base / L) % C);
+      const float b = bias ? bias[c] : 0.f;
+      const float mean = stat[c], rstd = stat[C + c], g = gamma[c], be = beta[c];
+      const Tile4 zv = ld4(z + base);
+      Tile4 rv, vv, uo, yo, vo;
+      if (res) rv = ld4(res + base);
+      if (LIF && HAS_V) vv = ld4(v_in + base);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = ((zv.a[j] + b) - mean) * rstd * g + be;
+        if (res) u += rv.a[j];
+        uo.a[j] = u;
+        if (LIF) {
+          const float h = HAS_V ? (vv.a[j] + u) : u;
+          float s, yy;
+          s2f_lif_update(h, Df, 1.0f, vth, s, yy, vo.a[j], inr[j]);
+          yo.a[j] = s / Df;
+          csum += (uint32_t)s;
+          cnz += ((uint32_t)s != 0);
+        }
+      }
+      if (u_out) st4(u_out + base, uo);
+      if (LIF) {
+        st4(y + base, yo);
+        if (v_out) st4(v_out + base, vo);
+      }
+    }
+    if (LIF) {
+      const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+      if (mask != nullptr && lane < 4) mask[tile * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    }
+  }
+  if (LIF && stats != nullptr) {
+    for (int o = 32; o > 0; o >>= 1) {
+      csum += __shfl_xor(csum, o, 64);
+      cnz += __shfl_xor(cnz, o, 64);
+    }
+    if (lane == 0) {
+      if (csum) atomicAdd(&stats[0], (unsigned long long)csum);
+      if (cnz) atomicAdd(&stats[1], (unsigned long long)cnz);
+    }
+  }
+}
+
+// gu = g_u + LIF-STE(g_y, g_v)   (any of the three may be absent)
+__device__ __forceinline__ float form_gu(bool has_gu, float gu, bool has_gy, float gy, bool has_gv, float gv, bool m,
+                                         float vth, float Df) {
+  float r = has_gu ? gu : 0.f;
+  if (has_gy || has_gv) {
+    const float gvv = has_gv ? gv : 0.f;
+    const float through = has_gy ? gy / Df : 0.f;
+    const float lif = has_gv ? (m ? (gvv + (through - gvv * vth)) : gvv) : (m ? through : 0.f);
+    r = has_gu ? r + lif : lif;
+  }
+  return r;
+}
+
+// grid (C, S) like bn_stats: sums[2c] = sum(gu), sums[2c+1] = sum(gu * xhat),  xhat = ((z + b) - mean) * rstd
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                               const float* __restrict__ stat,
+                                                               const float* __restrict__ g_u, const float* __restrict__ g_y,
+                                                               const float* __restrict__ g_v,
+                                                               const uint64_t* __restrict__ mask,
+                                                               double* __restrict__ sums, int N, int C, int L, int slice,
+                                                               float vth, float Df) {
+  const int c = blockIdx.x;
+  const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
+  const float b = bias ? bias[c] : 0.0f, mean = stat[c], rstd = stat[C + c];
+  double s = 0.0, q = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const int64_t rbase = ((int64_t)n * C + c) * L;
+    float ps = 0.f, pq = 0.f;
+    for (int l = l0 + threadIdx.x * 4; l < l1; l += kBlock * 4) {
+      const int64_t e = rbase + l;
+      const Tile4 zv = ld4(z + e);
+      Tile4 a, bb, cc;
+      if (g_u) a = ld4(g_u + e);
+      if (g_y) bb = ld4(g_y + e);
+      if (g_v) cc = ld4(g_v + e);
+      const int64_t tile = e >> 8;
+      const int ln = (int)((e & 255) >> 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool m = mask ? ((mask[tile * 4 + j] >> ln) & 1ull) : false;
+        const float gu = form_gu(g_u != nullptr, a.a[j], g_y != nullptr, bb.a[j], g_v != nullptr, cc.a[j], m, vth, Df);
+        const float xhat = ((zv.a[j] + b) - mean) * rstd;
+        ps += gu;
+        pq += gu * xhat;
+      }
+    }
+    s += (double)ps;
+    q += (double)pq;
+  }
+  block_atomic_add2(s, q, sums + 2 * c);
+}
+
+// train: gz = gamma * rstd * (gu - sum_gu/cnt - xhat * sum_gux/cnt) ;  eval: gz = gamma * rstd * gu ;  g_res = gu
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                              const float* __restrict__ stat,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ g_u, const float* __restrict__ g_y,
+                                                              const float* __restrict__ g_v,
+                                                              const uint64_t* __restrict__ mask,
+                                                              const double* __restrict__ sums, float* __restrict__ gz,
+                                                              float* __restrict__ g_res, int64_t total, int C, int L,
+                                                              double count, int training, float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+  const int64_t ntiles = (total + 255) >> 8;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    if (base >= total) continue;
+    const int c = (int)((base / L) % C);
+    const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
+    const float m1 = training ? (float)(sums[2 * c] / count) : 0.f;
+    const float m2 = training ? (float)(sums[2 * c + 1] / count) : 0.f;
+    const Tile4 zv = ld4(z + base);
+    Tile4 a, bb, cc, o, r;
+    if (g_u) a = ld4(g_u + base);
+    if (g_y) bb = ld4(g_y + base);
+    if (g_v) cc = ld4(g_v + base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool m = mask ? ((mask[tile * 4 + j] >> lane) & 1ull) : false;
+      const float gu = form_gu(g_u != nullptr, a.a[j], g_y != nullptr, bb.a[j], g_v != nullptr, cc.a[j], m, vth, Df);
+      const float xhat = ((zv.a[j] + b) - mean) * rstd;
+      o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
+      r.a[j] = gu;
+    }
+    st4(gz + base, o);
+    if (g_res) st4(g_res + base, r);
+  }
+}
+
+// dgamma[c] = sum(gu*xhat), dbeta[c] = sum(gu)  (fp64 sums -> fp32)
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)sums[2 * c];
+  dgamma[c] = (float)sums[2 * c + 1];
+}
+
+inline int pick_slices(int C, int L, int& slice) {
+  int S = 1;
+  while ((int64_t)C * S < 1024 && L / (S * 2) >= 2048) S *= 2;
+  slice = ((L + S - 1) / S + 3) / 4 * 4;
+  return S;
+}
+
+inline int grid_flat(int64_t total) {
+  int64_t tiles = (total + 255) >> 8;
+  int64_t blocks = (tiles + kWaves - 1) / kWaves;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
+  S2F_REQUIRE(N > 0 && C > 0 && L > 0, S2F_EINVAL, "%s: bad shape N=%lld C=%lld L=%lld", who, (long long)N, (long long)C,
+              (long long)L);
+  S2F_REQUIRE((L & 3) == 0, S2F_EINVAL, "%s: L=%lld must be a multiple of 4", who, (long long)L);
+  S2F_REQUIRE(N * C * L < (1ll << 40) && L < (1ll << 31) && C < (1 << 24) && N < (1ll << 31), S2F_EINVAL, "%s: shape too large", who);
+  return S2F_OK;
+}
+
+}  // namespace
+
+extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_ws, float* stat, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, int64_t N, int64_t C, int64_t L,
+                            float momentum, float eps, int training, void* stream) {
+  S2F_REQUIRE(stat && sums_ws, S2F_EINVAL, "s2f_bn_stats: null stat/workspace");
+  int rc = check_shape("s2f_bn_stats", N, C, L);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (training) {
+    S2F_REQUIRE(z && s2f_aligned16(z), S2F_EINVAL, "s2f_bn_stats: z null or misaligned");
+    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return s2f_check_launch("s2f_bn_stats memset");
+    int slice;
+    const int S = pick_slices((int)C, (int)L, slice);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, sums_ws, (int)N, (int)C,
+                       (int)L, slice);
+  } else {
+    S2F_REQUIRE(running_mean && running_var, S2F_EINVAL, "s2f_bn_stats: eval mode needs running statistics");
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, sums_ws, stat, running_mean,
+                     running_var, (long long*)num_batches_tracked, (int)C, (double)N * (double)L, momentum, eps, training);
+  return s2f_check_launch("s2f_bn_stats");
+}
+
+extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const float* stat, const float* gamma,
+                              const float* beta, const float* residual, float* u_out, const float* v_in, float* y,
+                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L, float vth,
+                              int D, void* stream) {
+  S2F_REQUIRE(z && stat && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
+  S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
+  int rc = check_shape("s2f_bn_act_fwd", N, C, L);
+  if (rc) return rc;
+  S2F_REQUIRE(s2f_aligned16(z) && s2f_aligned16(residual) && s2f_aligned16(u_out) && s2f_aligned16(v_in) &&
+                  s2f_aligned16(y) && s2f_aligned16(v_out),
+              S2F_EALIGN, "s2f_bn_act_fwd: tensors must be 16-byte aligned");
+  const int64_t total = N * C * L;
+  hipStream_t s = (hipStream_t)stream;
+  auto* st = reinterpret_cast<unsigned long long*>(stats);
+  const dim3 grid(grid_flat(total)), block(kBlock);
+  if (y == nullptr)
+    hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, z, conv_bias, stat, gamma, beta, residual,
+                       u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L, vth, (float)D);
+  else if (v_in == nullptr)
+    hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, z, conv_bias, stat, gamma, beta, residual,
+                       u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L, vth, (float)D);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, z, conv_bias, stat, gamma, beta, residual,
+                       u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L, vth, (float)D);
+  return s2f_check_launch("s2f_bn_act_fwd");
+}
+
+extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma,
+                              const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask,
+                              double* sums_ws, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
+                              int64_t C, int64_t L, int training, float vth, int D, void* stream) {
+  S2F_REQUIRE(z && stat && gamma && sums_ws && gz && dgamma && dbeta, S2F_EINVAL, "s2f_bn_act_bwd: null pointer");
+  S2F_REQUIRE(g_u || g_y || g_v, S2F_EINVAL, "s2f_bn_act_bwd: no incoming gradient");
+  S2F_REQUIRE(!(g_y || g_v) || mask, S2F_EINVAL, "s2f_bn_act_bwd: spike gradients need the in-range mask");
+  int rc = check_shape("s2f_bn_act_bwd", N, C, L);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = N * C * L;
+  if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return s2f_check_launch("s2f_bn_act_bwd memset");
+  int slice;
+  const int S = pick_slices((int)C, (int)L, slice);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,
+                     mask, sums_ws, (int)N, (int)C, (int)L, slice, vth, (float)D);
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, sums_ws, dgamma, dbeta,
+                     (int)C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 0, s, z, conv_bias, stat, gamma, g_u, g_y,
+                     g_v, mask, sums_ws, gz, g_residual, total, (int)C, (int)L, (double)N * (double)L, training, vth,
+                     (float)D);
+  return s2f_check_launch("s2f_bn_act_bwd");
+}

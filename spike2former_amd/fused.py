@@ -1,0 +1,38 @@
+"""Module-level glue for the fused BatchNorm(+bias)(+residual)(+Q_IFNode) op.  The nn.BatchNorm / Conv / Q_IFNode
+modules stay in the module tree as parameter and state holders (the checkpoint ABI); their arithmetic is done here."""
+import torch.nn.functional as F
+
+from . import ops
+from .neuron import Q_IFNode
+
+
+def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None):
+    """z: conv output WITHOUT its bias, [N, C, *].  Returns (u, y): u = BN(z + bias) [+ residual] (None unless wanted),
+    y = lif(u) (None without lif).  Shapes follow z."""
+    if want_pre is None:
+        want_pre = lif is None
+    shape = z.shape
+    N, C = shape[0], shape[1]
+    L = z.numel() // max(N * C, 1)
+    training = bn.training or (bn.running_mean is None)
+    if L % 4 != 0 or z.numel() == 0:
+        # odd row length: unfused ATen BatchNorm (native HIP kernels, MIOpen is disabled) + the stand-alone neuron kernel
+        t = z if conv_bias is None else z + conv_bias.view(1, -1, *([1] * (z.dim() - 2)))
+        u = F.batch_norm(t, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+        if residual is not None:
+            u = u + residual.reshape(shape)
+        return (u if want_pre else None), (lif(u) if lif is not None else None)
+    v_in = None
+    if lif is not None and not isinstance(lif.v, float):
+        v_in = lif.v
+    if lif is not None and lif.stats is not None:
+        lif.stats_elems += z.numel()
+    u, y, v_out = ops.bn_act(
+        z, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+        bn.num_batches_tracked if training else None, training, bn.momentum, bn.eps,
+        residual=residual, lif=lif is not None, want_pre=want_pre, v_in=v_in,
+        keep_v=(lif is not None and lif.keep_membrane), D=(lif.D if lif is not None else 8),
+        vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None))
+    if lif is not None:
+        lif.v = v_out if lif.keep_membrane else 0.0
+    return u, y

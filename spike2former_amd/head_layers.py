@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from . import ops
 from .conv import Conv1d, Conv2d
+from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import ConfigDict
 
@@ -37,10 +38,10 @@ class SepConv_Spike(nn.Module):
     def forward(self, x):
         T, B, H, W, C = x.shape
         x = self.spike1(x.permute(0, 1, 4, 2, 3).contiguous()).flatten(0, 1)
-        x = self.spike2(self.pwconv1(x))
-        x = self.spike3(self.dwconv(x))
-        x = self.pwconv2(x).reshape(T, B, C, H, W)
-        return x.permute(0, 1, 3, 4, 2).contiguous()
+        _, x = bn_act(self.pwconv1[0](x), None, self.pwconv1[1], lif=self.spike2)
+        _, x = bn_act(self.dwconv[0](x), None, self.dwconv[1], lif=self.spike3)
+        x, _ = bn_act(self.pwconv2[0](x), None, self.pwconv2[1])
+        return x.reshape(T, B, C, H, W).permute(0, 1, 3, 4, 2).contiguous()
 
 
 class MLP(nn.Module):
@@ -110,10 +111,11 @@ class DCNv3_pytorch(nn.Module):
         T, N, H, W, C = inp.shape
         x = self.input_proj(inp)
         x1 = self.dw_spike(inp.permute(0, 1, 4, 2, 3).contiguous()).flatten(0, 1)
-        x1 = self.offset_spike(self.dw_conv(x1))
+        _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
         # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
-        offset = self.offset(x1).reshape(T * N, H, W, -1)
-        mask = self.mask_spike(self.mask(x1).reshape(T * N, H, W, -1))
+        offset, _ = bn_act(self.offset[0].forward_nobias(x1), self.offset[0].bias, self.offset[1])
+        _, mask = bn_act(self.mask[0].forward_nobias(x1), self.mask[0].bias, self.mask[1], lif=self.mask_spike)
+        offset, mask = offset.reshape(T * N, H, W, -1), mask.reshape(T * N, H, W, -1)
         k = self.kernel_size
         y = ops.dcnv3_core(x.flatten(0, 1), offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
                            self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale)
@@ -140,9 +142,10 @@ class MS_MLP(nn.Module):
     def forward(self, x):
         T, B, H, W, C = x.shape
         x = self.fc1_spike(x.permute(0, 1, 4, 2, 3).contiguous().flatten(3)).flatten(0, 1)
-        x = self.fc2_spike(self.fc1_bn(self.fc1_conv(x)))
+        _, x = bn_act(self.fc1_conv.forward_nobias(x), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
+        x, _ = bn_act(self.fc2_conv.forward_nobias(x), self.fc2_conv.bias, self.fc2_bn)
         # bug-compatible: [T*B, C, N] reinterpreted as [T, B, H, W, C] (:829)
-        return self.fc2_bn(self.fc2_conv(x)).reshape(T, B, H, W, C)
+        return x.reshape(T, B, H, W, C)
 
 
 class DCNDetrTransformerEncoderLayer(nn.Module):
@@ -220,13 +223,14 @@ class MultiHeadAttentionBlock(nn.Module):
 
         def proj(spike_in, conv, spike_out, x):                 # x [t,b,L,dim] -> channel-major spikes [t*b, dim, L]
             x = spike_in(x).permute(0, 1, 3, 2).flatten(0, 1)
-            return spike_out(conv(x))
+            return bn_act(conv[0].forward_nobias(x), conv[0].bias, conv[1], lif=spike_out)[1]
 
         q = proj(self.q_conv_spike, self.q_conv, self.q_spike, query)
         k = proj(self.k_conv_spike, self.k_conv, self.k_spike, key)
         v = proj(self.v_conv_spike, self.v_conv, self.v_spike, value)
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5))      # embed_dim**0.5, not head dim
-        o = self.out_conv(self.attn_spike(o))
+        o = self.attn_spike(o)
+        o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
         return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
 
 
@@ -282,8 +286,9 @@ class MSDA_FFN(nn.Module):
     def forward(self, x, identity=None):
         t, bs, N, C = x.shape
         a = self.fc1_spike(x).reshape(t * bs, C, N)
-        a = self.fc2_spike(self.bn1(self.fc1(a)))
-        return self.bn2(self.fc2(a)).reshape(t, bs, N, C)
+        _, a = bn_act(self.fc1.forward_nobias(a), self.fc1.bias, self.bn1, lif=self.fc2_spike)
+        a, _ = bn_act(self.fc2.forward_nobias(a), self.fc2.bias, self.bn2)
+        return a.reshape(t, bs, N, C)
 
 
 class DetrTransformerDecoderLayer(nn.Module):

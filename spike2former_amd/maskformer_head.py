@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from .head_layers import MLP, DetrTransformerDecoder, SinePositionalEncoding
 from .conv import Conv1d, Conv2d
+from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS, ConfigDict
 
@@ -104,7 +105,8 @@ class MaskFormerHead(nn.Module):
         z = self.decoder_post_norm(out_dec)
         a = self.alpha * self.decoder_out_spike(z)
         all_cls_scores = self.cls_embed(a).mean(1)
-        sc = self.shortcut_conv((self.alpha * self.shortcut_conv_spike(z)).reshape(ln * t * bs, nq, C))
+        sc = (self.alpha * self.shortcut_conv_spike(z)).reshape(ln * t * bs, nq, C)
+        sc, _ = bn_act(self.shortcut_conv[0].forward_nobias(sc), None, self.shortcut_conv[1])
         e = self.mask_embed(a) + self.w * sc.view(ln, t, bs, nq, C)
         e = self.alpha * self.mask_embed_spike(e)
         # einsum('ltbqc,tbchw->ltbqhw').mean(t) with the mean folded into the contraction: the reference's

@@ -188,3 +188,87 @@ class _DCNv3(torch.autograd.Function):
 
 def dcnv3_core(x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, offset_scale):
     return _DCNv3.apply(x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, float(offset_scale))
+
+
+# ------------------------------------------------------------------------------------------------ BN (+bias, +residual, +LIF)
+class _BNAct(torch.autograd.Function):
+    """t = z + conv_bias ; u = BatchNorm(t) [+ residual] ; y = Q_IFNode(u)   in two streaming kernels forward
+    (statistics, apply) and two backward (reduce, apply).  Returns (u, y, v_out); unrequested ones are empty."""
+
+    @staticmethod
+    def forward(ctx, z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
+                eps, lif_on, want_pre, keep_v, D, vth, stats):
+        _need_cuda(z, conv_bias, gamma, beta, residual, v_in)
+        z = z.contiguous()
+        N, C = z.shape[0], z.shape[1]
+        L = z.numel() // (N * C)
+        dev = z.device
+        stat = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        s = _stream()
+        check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
+                               _ptr(nbt), N, C, L, momentum, eps, int(training), s), "s2f_bn_stats")
+        if residual is not None:
+            residual = residual.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        u = torch.empty_like(z) if want_pre else None
+        y = torch.empty_like(z) if lif_on else None
+        v_out = torch.empty_like(z) if (lif_on and keep_v) else None
+        need_grad = any(ctx.needs_input_grad[:5])
+        mask = torch.empty(mask_words(z.numel()), dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
+        n = z.numel()
+        e0 = _ev() if (KERNEL_EVENTS is not None) else None
+        check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u),
+                                 _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, vth, D, s),
+              "s2f_bn_act_fwd")
+        if e0 is not None:
+            # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
+            nb = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
+            KERNEL_EVENTS.append(("bn_lif_fwd" if lif_on else "bn_fwd", nb, e0, _ev()))
+        ctx.save_for_backward(z, conv_bias, gamma, stat, mask)
+        ctx.cfg = (N, C, L, bool(training), D, vth, residual is not None, conv_bias is not None)
+        ctx.set_materialize_grads(False)
+        outs = [t if t is not None else z.new_empty(0) for t in (u, y, v_out)]
+        ctx.mark_non_differentiable(*[o for o, t in zip(outs, (u, y, v_out)) if t is None])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_u, g_y, g_v):
+        z, conv_bias, gamma, stat, mask = ctx.saved_tensors
+        N, C, L, training, D, vth, has_res, has_bias = ctx.cfg
+
+        def prep(g):
+            return None if (g is None or g.numel() == 0) else g.contiguous()
+        g_u, g_y, g_v = prep(g_u), prep(g_y), prep(g_v)
+        if g_u is None and g_y is None and g_v is None:
+            return (None,) * 18
+        dev = z.device
+        gz = torch.empty_like(z)
+        g_res = torch.empty_like(z) if (has_res and ctx.needs_input_grad[4]) else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        e0 = _ev() if (KERNEL_EVENTS is not None) else None
+        check(lib.s2f_bn_act_bwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
+                                 _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
+                                 int(training), vth, D, _stream()), "s2f_bn_act_bwd")
+        if e0 is not None:
+            n = z.numel()
+            nb = 4 * n * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None))   # read z + grads, write gz [, g_res]
+            KERNEL_EVENTS.append(("bn_lif_bwd" if g_y is not None else "bn_bwd", nb, e0, _ev()))
+        g_bias = None
+        if has_bias:
+            # train-mode BN removes any per-channel constant: d/d(bias) == 0; eval mode: sum(gz) = gamma * rstd * dbeta
+            g_bias = torch.zeros_like(dbeta) if training else gamma * stat[C:] * dbeta
+        if ctx.needs_input_grad[5]:
+            raise RuntimeError("gradient w.r.t. the incoming membrane is not supported by the fused BN+LIF op")
+        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 13
+
+
+def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, residual=None,
+           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None):
+    """-> (u or None, y or None, v_out or None)"""
+    u, y, v = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
+                           eps, lif, want_pre, keep_v, D, vth, stats)
+    return (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)

@@ -5,6 +5,7 @@ import torch.nn.functional as F
 
 from .head_layers import DCNDetrTransformerEncoder, SinePositionalEncoding
 from .conv import Conv1d, Conv2d
+from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -66,18 +67,22 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         x4 = feats[-1]
         t, bs, c, h, w = x4.shape
         E = self.encoder_embed_dims
+        def conv_bn(seq, x, **kw):
+            return bn_act(seq[0].forward_nobias(x), seq[0].bias, seq[1], **kw)
+
         y = self.last_feat_conv_spike(x4)
-        y = self.encoder_in_proj(y.flatten(0, 1)).reshape(t, bs, E, h, w)
+        y = conv_bn(self.encoder_in_proj, y.flatten(0, 1))[0].reshape(t, bs, E, h, w)
         memory = self.encoder(query=y.permute(0, 1, 3, 4, 2))
         memory = memory.permute(0, 1, 4, 2, 3).contiguous()
         memory = self.encoder_out_proj_spike(memory)
-        y = self.encoder_out_proj(memory.flatten(0, 1))
+        y = conv_bn(self.encoder_out_proj, memory.flatten(0, 1))[0]
         out = [y.reshape(t, bs, E, h, w)]
         for i in range(self.num_inputs - 2, -1, -1):
-            x = self.lateral_convs_spike[i](feats[i])
-            cur = self.lateral_convs[i](x.flatten(0, 1))
-            y = cur + F.interpolate(y, size=cur.shape[-2:], mode="bilinear", align_corners=False)
-            y = self.output_convs[i](self.output_convs_spike[i](y))
+            x = self.lateral_convs_spike[i](feats[i]).flatten(0, 1)
+            up = F.interpolate(y, size=feats[i].shape[-2:], mode="bilinear", align_corners=False)
+            # cur + upsample(y), then the output neuron: residual add and neuron fused into the BatchNorm kernel
+            _, s = conv_bn(self.lateral_convs[i], x, residual=up, lif=self.output_convs_spike[i])
+            y = conv_bn(self.output_convs[i], s)[0]
             out.append(y.reshape(t, bs, *y.shape[1:]))
         y = self.mask_feature_spike(y)
         mf = self.mask_feature(y)

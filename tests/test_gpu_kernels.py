@@ -233,3 +233,79 @@ def test_errors_are_raised_not_swallowed(ops):
                  torch.zeros(1, 130, 4, device="cuda"), 2, 1.0)
     with pytest.raises(RuntimeError, match="fp32"):
         ops.lif(torch.zeros(8, device="cuda", dtype=torch.float16))
+
+
+# ----------------------------------------------------------------------------------------------- fused BN (+bias, +residual, +LIF)
+@pytest.mark.parametrize("N,C,L,training,res,lif", [(8, 32, 1024, True, False, True), (4, 20, 64, True, True, True),
+                                                     (2, 7, 36, True, True, False), (3, 16, 256, False, True, True),
+                                                     (8, 256, 4096, True, False, True)])
+def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
+    """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
+    Pre-activation: rtol 2e-5 (different but equally valid fp32 evaluation orders); spikes: at most 1e-4 of the
+    elements may differ, each by exactly one level; gradients: 1e-4 of their max."""
+    import torch.nn.functional as F
+
+    from spike2former_amd import ops
+    g = torch.Generator().manual_seed(N * 131 + C)
+    z = torch.randn(N, C, L, generator=g) * 2 + 0.5
+    b = torch.randn(C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3 + 0.5
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    r = torch.randn(N, C, L, generator=g) if res else None
+    gu_w, gy_w = torch.randn(N, C, L, generator=g), torch.randn(N, C, L, generator=g)
+    # oracle
+    zo, bo, go, beo = (t.clone().requires_grad_(True) for t in (z, b, gamma, beta))
+    ro = r.clone().requires_grad_(True) if res else None
+    rmo, rvo = rm.clone(), rv.clone()
+    u = F.batch_norm(zo + bo.view(1, -1, 1), rmo, rvo, go, beo, training, 0.1, 1e-5)
+    if res:
+        u = u + ro
+    loss = (u * gu_w).sum()
+    if lif:
+        y, _, _ = so.lif_step(u, None)
+        loss = loss + (y * gy_w).sum()
+    loss.backward()
+    # product
+    zc, bc, gc, bec = (t.clone().cuda().requires_grad_(True) for t in (z, b, gamma, beta))
+    rc = r.clone().cuda().requires_grad_(True) if res else None
+    rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    uu, yy, _ = ops.bn_act(zc, bc, gc, bec, rmc, rvc, nbt if training else None, training, 0.1, 1e-5, residual=rc,
+                           lif=lif, want_pre=True)
+    lossc = (uu * gu_w.cuda()).sum()
+    if lif:
+        lossc = lossc + (yy * gy_w.cuda()).sum()
+    lossc.backward()
+
+    def close(a, bb, tol):
+        return (a.detach().cpu() - bb.detach()).abs().max().item() <= tol * max(bb.abs().max().item(), 1e-6)
+    assert close(uu, u, 2e-5)
+    if lif:
+        d = (yy.detach().cpu() - y.detach()) * 8
+        assert d.abs().max().item() <= 1 and (d != 0).float().mean().item() <= 1e-4
+    if training:
+        assert close(rmc, rmo, 1e-5) and close(rvc, rvo, 1e-5) and int(nbt) == 1
+        assert bc.grad.abs().max().item() == 0.0          # train-mode BN removes the conv bias gradient exactly
+    else:
+        assert close(bc.grad, bo.grad, 1e-4)
+    flips = lif and (d != 0).any().item()
+    tol = 5e-3 if flips else 1e-4
+    assert close(zc.grad, zo.grad, tol) and close(gc.grad, go.grad, tol) and close(bec.grad, beo.grad, tol)
+    if res:
+        assert close(rc.grad, ro.grad, tol)
+
+
+def test_bn_act_stateful_lif_matches_unfused(ops):
+    """Fused BN+neuron with a carried membrane == BN-only kernel followed by the stand-alone neuron kernel, bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    N, C, L = 4, 24, 512
+    z = (torch.randn(N, C, L, generator=g) * 2).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    v = torch.randn(N, C, L, generator=g).cuda()
+    stats_a = torch.zeros(2, dtype=torch.int64, device="cuda"); stats_b = torch.zeros(2, dtype=torch.int64, device="cuda")
+    u, y, v_out = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=True, want_pre=True, v_in=v,
+                             keep_v=True, stats=stats_a)
+    u2, _, _ = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=False, want_pre=True)
+    y2, v2 = ops.lif(u2, v, stats=stats_b)
+    assert torch.equal(u, u2) and torch.equal(y, y2) and torch.equal(v_out, v2) and torch.equal(stats_a, stats_b)
