@@ -90,6 +90,19 @@ int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, co
                    float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
                    float vth, int D, void* stream);
 
+/* ---- depthwise KxK convolution (stride 1, dilation 1, K in {3,5,7}) on [N, C, H, W] -----------------------
+ * Replaces nn.Conv2d(groups=C) as used by SepConv.dwconv (mmseg/models/backbones/sdtv2.py:156-163), RepConv's un-padded
+ * 3x3 on the BNAndPadLayer output (sdtv2.py:48-89, 123-127), SepConv_Spike.dwconv (mmcv_spike/SNN_core.py:36-40),
+ * DCNv3_pytorch.dw_conv (ops_dcnv3/modules/dcnv3.py:161-169) and the pixel decoder's output_convs (pixel_decoder.py:374-378).
+ * w: [C, K, K].  Output size Ho = H + 2*pad - K + 1.  border?: per-channel value read inside the padding ring instead of
+ * zero (BNAndPadLayer's constant border, sdtv2.py:68-84) -- the padded tensor is never materialised. */
+int s2f_dwconv_fwd(const float* x, const float* w, const float* border, float* y, int N, int C, int H, int W, int K,
+                   int pad, void* stream);
+int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, int N, int C, int H, int W, int K, int pad,
+                         void* stream);
+int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, float* gw, int N, int C, int H, int W,
+                          int K, int pad, void* stream);
+
 /* ---- a5 / a10: spike-driven (softmax-free) attention core --------------------------------------------
  * Replaces  kv = k^T @ v ; o = (q @ kv) * scale ; o.transpose(3,4).reshape(T,B,C,N)
  * (MS_Attention_RepConv_qkv_id, mmseg/models/backbones/sdtv2.py:308-339) and the decoder's

@@ -31,21 +31,29 @@ class BNAndPadLayer(nn.Module):
         self.bn = nn.BatchNorm2d(num_features, eps, momentum, affine, track_running_stats)
         self.pad_pixels = pad_pixels
 
-    def forward(self, x):
-        out, _ = bn_act(x, None, self.bn)
+    def border_values(self):
+        """BN(0) from the running statistics, detached (sdtv2.py:68-78)."""
+        bn = self.bn
+        std = torch.sqrt(bn.running_var + bn.eps)
+        if bn.affine:
+            return bn.bias.detach() - bn.running_mean * bn.weight.detach() / std
+        return -bn.running_mean / std
+
+    def pad(self, out, border):
         p = self.pad_pixels
-        if p > 0:
-            bn = self.bn
-            std = torch.sqrt(bn.running_var + bn.eps)
-            if bn.affine:
-                pad = bn.bias.detach() - bn.running_mean * bn.weight.detach() / std
-            else:
-                pad = -bn.running_mean / std
-            N, C, H, W = out.shape
-            full = pad.view(1, C, 1, 1).expand(N, C, H + 2 * p, W + 2 * p).clone()
-            full[:, :, p:-p, p:-p] = out
-            out = full
-        return out
+        N, C, H, W = out.shape
+        full = border.view(1, C, 1, 1).expand(N, C, H + 2 * p, W + 2 * p).clone()
+        full[:, :, p:-p, p:-p] = out
+        return full
+
+    def forward(self, x, return_border=False):
+        out, _ = bn_act(x, None, self.bn)           # updates the running statistics first, as the reference does
+        if self.pad_pixels == 0:
+            return (out, None) if return_border else out
+        border = self.border_values()
+        if return_border:                            # RepConv feeds the border to the depthwise kernel directly
+            return out, border
+        return self.pad(out, border)
 
     weight = property(lambda self: self.bn.weight)
     bias = property(lambda self: self.bn.bias)
@@ -71,8 +79,11 @@ class RepConv(nn.Module):
     def forward(self, x, outer_bn=None, lif=None, residual=None):
         """conv1x1 -> BN+pad -> dw3x3 -> conv1x1 -> BN [-> outer BN [+ residual] [-> neuron]].
         Returns (pre-activation or None, spikes or None) when `outer_bn` is given, else the tensor."""
-        x = self.body[1](self.body[0](x))
-        x = self.body[2][1](self.body[2][0](x))
+        x, border = self.body[1](self.body[0](x), return_border=True)
+        # un-padded depthwise 3x3 over the constant-bordered map == pad-1 stencil reading `border` outside the plane
+        dw = self.body[2][0]
+        x = ops.dwconv(x, dw.weight, dw.kernel_size[0] // 2, border) if dw.kernel_size == (3, 3) else dw(self.body[1].pad(x, border))
+        x = self.body[2][1](x)
         if outer_bn is None:
             return bn_act(x, None, self.body[2][2])[0]
         x, _ = bn_act(x, None, self.body[2][2])

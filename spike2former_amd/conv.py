@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 torch.backends.cudnn.enabled = False        # = MIOpen on ROCm; see module docstring
 
 
@@ -29,17 +31,22 @@ def _gemm_nc(weight2d, x3, bias):
 
 
 class Conv2d(nn.Conv2d):
-    def forward(self, x):
-        return self._conv(x, self.bias)
+    def forward(self, x, border=None):
+        return self._conv(x, self.bias, border)
 
     def forward_nobias(self, x):
         """The convolution without its bias (the fused BatchNorm kernels add the bias on the fly)."""
         return self._conv(x, None)
 
-    def _conv(self, x, bias):
+    def _conv(self, x, bias, border=None):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         if self.groups != 1:
+            kh, kw = self.kernel_size
+            if (self.groups == self.in_channels == self.out_channels and kh == kw and kh in (3, 5, 7) and bias is None
+                    and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding[0] == self.padding[1]):
+                return ops.dwconv(x, self.weight, self.padding[0], border)      # hand-written depthwise stencil
+            assert border is None
             return F.conv2d(x, self.weight, bias, self.stride, self.padding, self.dilation, self.groups)
         N, C, H, W = x.shape
         M = self.out_channels

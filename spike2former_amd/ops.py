@@ -272,3 +272,45 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
     u, y, v = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
                            eps, lif, want_pre, keep_v, D, vth, stats)
     return (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
+
+
+# ------------------------------------------------------------------------------------------------ depthwise conv
+class _DWConv(torch.autograd.Function):
+    """Depthwise KxK, stride 1 (nn.Conv2d(groups=C)); `border` = per-channel constant padding value (detached)."""
+
+    @staticmethod
+    def forward(ctx, x, w, border, pad):
+        _need_cuda(x, w, border)
+        x, w = x.contiguous(), w.contiguous()
+        N, C, H, W = x.shape
+        K = w.shape[-1]
+        Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+        y = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=x.device)
+        if border is not None:
+            border = border.contiguous()
+        check(lib.s2f_dwconv_fwd(_ptr(x), _ptr(w), _ptr(border), _ptr(y), N, C, H, W, K, pad, _stream()),
+              "s2f_dwconv_fwd")
+        ctx.save_for_backward(x, w, border)
+        ctx.pad = pad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, border = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, H, W = x.shape
+        K = w.shape[-1]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(lib.s2f_dwconv_bwd_input(_ptr(gy), _ptr(w), _ptr(gx), N, C, H, W, K, ctx.pad, _stream()),
+                  "s2f_dwconv_bwd_input")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            check(lib.s2f_dwconv_bwd_weight(_ptr(x), _ptr(border), _ptr(gy), _ptr(gw), N, C, H, W, K, ctx.pad,
+                                            _stream()), "s2f_dwconv_bwd_weight")
+        return gx, gw, None, None
+
+
+def dwconv(x, w, pad, border=None):
+    return _DWConv.apply(x, w, border, pad)

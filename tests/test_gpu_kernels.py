@@ -309,3 +309,34 @@ def test_bn_act_stateful_lif_matches_unfused(ops):
     u2, _, _ = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=False, want_pre=True)
     y2, v2 = ops.lif(u2, v, stats=stats_b)
     assert torch.equal(u, u2) and torch.equal(y, y2) and torch.equal(v_out, v2) and torch.equal(stats_a, stats_b)
+
+
+# ----------------------------------------------------------------------------------------------- depthwise stencils
+@pytest.mark.parametrize("N,C,H,W,K,pad,border", [(2, 8, 32, 32, 3, 1, True), (2, 6, 37, 45, 7, 3, False),
+                                                   (1, 5, 4, 4, 5, 2, False), (3, 16, 64, 64, 5, 2, False),
+                                                   (2, 4, 9, 7, 3, 1, True), (1, 3, 70, 33, 7, 3, False),
+                                                   (2, 4, 10, 10, 3, 0, False)])
+def test_dwconv_vs_aten_cpu(ops, N, C, H, W, K, pad, border):
+    """fp32, K*K <= 49 terms per output: rtol 2e-6 forward / input gradient; the weight gradient sums N*H*W terms in a
+    different order than ATen: 2e-5.  `border` reproduces conv(pad-with-constant(x), padding=0) of BNAndPadLayer."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H * 7 + K)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, K, K, generator=g)
+    b = torch.randn(C, generator=g) if border else None
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if border:
+        full = b.view(1, C, 1, 1).expand(N, C, H + 2 * pad, W + 2 * pad).clone()
+        full[:, :, pad:-pad, pad:-pad] = xo
+        yo = F.conv2d(full, wo, None, 1, 0, 1, C)
+    else:
+        yo = F.conv2d(xo, wo, None, 1, pad, 1, C)
+    gy = torch.randn(yo.shape, generator=g)
+    yo.backward(gy)
+    xc, wc = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    yc = ops.dwconv(xc, wc, pad, None if b is None else b.cuda())
+    yc.backward(gy.cuda())
+
+    def close(a, bb, tol):
+        return (a.detach().cpu() - bb.detach()).abs().max().item() <= tol * bb.abs().max().item()
+    assert yc.shape == yo.shape and close(yc, yo, 2e-6) and close(xc.grad, xo.grad, 2e-6) and close(wc.grad, wo.grad, 2e-5)
