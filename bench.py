@@ -42,7 +42,8 @@ def cpu_baseline(workload):
     from oracle import s2f_oracle as so        # cpu_baseline leg only
     import dataclasses
     cfg = dataclasses.replace(so.CONFIGS[workload], B=1)
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    cores = logical // 2 if logical >= 16 else logical        # physical cores (SMT siblings do not help fp32 GEMM/conv)
     torch.set_num_threads(cores)
     st = so.make_params(cfg)
     net = so.OracleNet(st, cfg, training=True)
