@@ -88,6 +88,7 @@ def main():
         red.zero()
         cls, masks = model(img)
         s2f.headline_loss(cls, masks).backward()
+        red.gather()
         red.reduce()
         red.wait()
 

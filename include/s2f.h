@@ -71,22 +71,24 @@ int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask,
  * SepConv, MS_MLP: mmseg/models/backbones/sdtv2.py:167-255; every Sequential(conv, BN) + Q_IFNode of the head), which
  * runs as ~12 ATen elementwise kernels forward and as many backward.  z: [N, C, L] channel-major, L % 4 == 0.
  *
- * s2f_bn_stats:  training != 0: per-channel mean / biased variance of (z + conv_bias?) -> stat[0:C] = mean,
- *   stat[C:2C] = 1/sqrt(var + eps); running_mean?/running_var? updated in place with momentum and the unbiased variance,
- *   *num_batches_tracked? += 1 (torch.nn.BatchNorm semantics).  training == 0: stat from the running statistics.
- *   sums_ws: double[2C] scratch.
- * s2f_bn_act_fwd:  u = ((z + b) - mean) * rstd * gamma + beta [+ residual?] ; u_out? = u ;
+ * s2f_bn_stats (training only): per-channel sum / sum of squares of (z + conv_bias?) accumulated into sums_zeroed
+ *   (double[2C], MUST be zero on entry -- the host hands out slices of one arena cleared once per step).
+ * s2f_bn_act_fwd:  mean / rstd = 1/sqrt(var + eps) from `sums` (training) or from the running statistics (eval), written to
+ *   stat_out[0:C] / stat_out[C:2C]; training: running_mean?/running_var? updated in place with `momentum` and the unbiased
+ *   variance, *num_batches_tracked? += 1 (torch.nn.BatchNorm semantics).
+ *   u = ((z + b) - mean) * rstd * gamma + beta [+ residual?] ; u_out? = u ;
  *   if y != NULL:  the Q_IFNode update of s2f_lif_fwd on u (v_in?, v_out?, mask?, stats? as there).
  * s2f_bn_act_bwd:  gu = g_u? + STE(g_y?, g_v?, mask) ;  training: gz = gamma*rstd*(gu - mean(gu) - xhat*mean(gu*xhat)),
- *   eval: gz = gamma*rstd*gu ;  g_residual? = gu ;  dgamma = sum(gu*xhat) ; dbeta = sum(gu). */
-int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_ws, float* stat, float* running_mean,
-                 float* running_var, int64_t* num_batches_tracked, int64_t N, int64_t C, int64_t L, float momentum,
-                 float eps, int training, void* stream);
-int s2f_bn_act_fwd(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* beta,
+ *   eval: gz = gamma*rstd*gu ;  g_residual? = gu ;  dgamma = sum(gu*xhat) ; dbeta = sum(gu).  sums_zeroed as above. */
+int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
+                 void* stream);
+int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
                    const float* residual, float* u_out, const float* v_in, float* y, float* v_out, uint64_t* mask,
-                   uint64_t* stats, int64_t N, int64_t C, int64_t L, float vth, int D, void* stream);
+                   uint64_t* stats, int64_t N, int64_t C, int64_t L, float momentum, float eps, int training, float vth,
+                   int D, void* stream);
 int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
-                   const float* g_y, const float* g_v, const uint64_t* mask, double* sums_ws, float* gz,
+                   const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
                    float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
                    float vth, int D, void* stream);
 

@@ -74,34 +74,27 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
   block_atomic_add2(s, q, sums + 2 * c);
 }
 
-// One thread per channel.  train: mean/var from the fp64 sums, running statistics updated in place with the unbiased
-// variance (torch.nn.BatchNorm semantics, momentum m).  eval: mean/var = running statistics.
-// stat[c] = mean, stat[C + c] = rstd = 1/sqrt(var + eps).
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stat,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   long long* __restrict__ num_batches, int C, double count, float momentum, float eps,
-                                   int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float mean, var;
+// Per-channel statistics derived identically by every lane that needs them (deterministic: same inputs, same ops).
+// training: mean / biased variance from the fp64 sums of bn_stats_kernel; eval: the running statistics.
+struct ChanStat {
+  float mean, rstd, var;
+};
+__device__ __forceinline__ ChanStat chan_stat(const double* __restrict__ sums, const float* __restrict__ running_mean,
+                                              const float* __restrict__ running_var, int c, double count, float eps,
+                                              int training) {
+  ChanStat r;
   if (training) {
     const double m = sums[2 * c] / count;
     double v = sums[2 * c + 1] / count - m * m;
     if (v < 0) v = 0;
-    mean = (float)m;
-    var = (float)v;
-    if (running_mean != nullptr) {
-      const float unbiased = count > 1 ? (float)(v * (count / (count - 1.0))) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
-    if (c == 0 && num_batches != nullptr) *num_batches += 1;
+    r.mean = (float)m;
+    r.var = (float)v;
   } else {
-    mean = running_mean[c];
-    var = running_var[c];
+    r.mean = running_mean[c];
+    r.var = running_var[c];
   }
-  stat[c] = mean;
-  stat[C + c] = 1.0f / sqrtf(var + eps);
+  r.rstd = 1.0f / sqrtf(r.var + eps);
+  return r;
 }
 
 struct Tile4 {
@@ -119,13 +112,18 @@ __device__ __forceinline__ void st4(float* p, const Tile4& t) {
 // u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
 template <bool LIF, bool HAS_V>
 __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
-                                                          const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                          const double* __restrict__ sums, float* __restrict__ stat,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var,
+                                                          long long* __restrict__ num_batches,
+                                                          const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ res,
                                                           float* __restrict__ u_out, const float* __restrict__ v_in,
                                                           float* __restrict__ y, float* __restrict__ v_out,
                                                           uint64_t* __restrict__ mask,
                                                           unsigned long long* __restrict__ stats, int64_t total, int C,
-                                                          int L, float vth, float Df) {
+                                                          int L, double count, float momentum, float eps, int training,
+                                                          float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
@@ -138,7 +136,20 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
     if (ok) {
       const int c = (int)((base / L) % C);
       const float b = bias ? bias[c] : 0.f;
-      const float mean = stat[c], rstd = stat[C + c], g = gamma[c], be = beta[c];
+      const ChanStat cs = chan_stat(sums, running_mean, running_var, c, count, eps, training);
+      const float mean = cs.mean, rstd = cs.rstd, g = gamma[c], be = beta[c];
+      if (base == (int64_t)c * L) {
+        // the lane owning the first element of channel c (row n = 0) publishes the statistics for the backward pass
+        // and performs the running-statistics update (torch.nn.BatchNorm: momentum, unbiased variance)
+        stat[c] = mean;
+        stat[C + c] = rstd;
+        if (training && running_mean != nullptr) {
+          const float unbiased = count > 1 ? (float)((double)cs.var * (count / (count - 1.0))) : cs.var;
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+        if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
+      }
       const Tile4 zv = ld4(z + base);
       Tile4 rv, vv, uo, yo, vo;
       if (res) rv = ld4(res + base);
@@ -240,7 +251,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
                                                               const float* __restrict__ g_v,
                                                               const uint64_t* __restrict__ mask,
                                                               const double* __restrict__ sums, float* __restrict__ gz,
-                                                              float* __restrict__ g_res, int64_t total, int C, int L,
+                                                              float* __restrict__ g_res, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int64_t total, int C, int L,
                                                               double count, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -253,6 +265,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
     const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
     const float m1 = training ? (float)(sums[2 * c] / count) : 0.f;
     const float m2 = training ? (float)(sums[2 * c + 1] / count) : 0.f;
+    if (base == (int64_t)c * L) {          // dbeta = sum(gu), dgamma = sum(gu * xhat)
+      dbeta[c] = (float)sums[2 * c];
+      dgamma[c] = (float)sums[2 * c + 1];
+    }
     const Tile4 zv = ld4(z + base);
     Tile4 a, bb, cc, o, r;
     if (g_u) a = ld4(g_u + base);
@@ -269,15 +285,6 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
     st4(gz + base, o);
     if (g_res) st4(g_res + base, r);
   }
-}
-
-// dgamma[c] = sum(gu*xhat), dbeta[c] = sum(gu)  (fp64 sums -> fp32)
-__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  dbeta[c] = (float)sums[2 * c];
-  dgamma[c] = (float)sums[2 * c + 1];
 }
 
 inline int pick_slices(int C, int L, int& slice) {
@@ -304,33 +311,27 @@ int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
 
 }  // namespace
 
-extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_ws, float* stat, float* running_mean,
-                            float* running_var, int64_t* num_batches_tracked, int64_t N, int64_t C, int64_t L,
-                            float momentum, float eps, int training, void* stream) {
-  S2F_REQUIRE(stat && sums_ws, S2F_EINVAL, "s2f_bn_stats: null stat/workspace");
+extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
+                            void* stream) {
+  S2F_REQUIRE(z && sums_zeroed, S2F_EINVAL, "s2f_bn_stats: null z/workspace");
   int rc = check_shape("s2f_bn_stats", N, C, L);
   if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  if (training) {
-    S2F_REQUIRE(z && s2f_aligned16(z), S2F_EINVAL, "s2f_bn_stats: z null or misaligned");
-    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return s2f_check_launch("s2f_bn_stats memset");
-    int slice;
-    const int S = pick_slices((int)C, (int)L, slice);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, sums_ws, (int)N, (int)C,
-                       (int)L, slice);
-  } else {
-    S2F_REQUIRE(running_mean && running_var, S2F_EINVAL, "s2f_bn_stats: eval mode needs running statistics");
-  }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, sums_ws, stat, running_mean,
-                     running_var, (long long*)num_batches_tracked, (int)C, (double)N * (double)L, momentum, eps, training);
+  S2F_REQUIRE(s2f_aligned16(z), S2F_EALIGN, "s2f_bn_stats: z must be 16-byte aligned");
+  int slice;
+  const int S = pick_slices((int)C, (int)L, slice);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, (hipStream_t)stream, z, conv_bias,
+                     sums_zeroed, (int)N, (int)C, (int)L, slice);
   return s2f_check_launch("s2f_bn_stats");
 }
 
-extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const float* stat, const float* gamma,
+extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
                               const float* beta, const float* residual, float* u_out, const float* v_in, float* y,
-                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L, float vth,
-                              int D, void* stream) {
-  S2F_REQUIRE(z && stat && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
+                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
+                              float momentum, float eps, int training, float vth, int D, void* stream) {
+  S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
+  S2F_REQUIRE(training ? sums != nullptr : (running_mean && running_var), S2F_EINVAL,
+              "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
   int rc = check_shape("s2f_bn_act_fwd", N, C, L);
   if (rc) return rc;
@@ -340,39 +341,40 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const floa
   const int64_t total = N * C * L;
   hipStream_t s = (hipStream_t)stream;
   auto* st = reinterpret_cast<unsigned long long*>(stats);
+  auto* nbt = reinterpret_cast<long long*>(num_batches_tracked);
   const dim3 grid(grid_flat(total)), block(kBlock);
+  const double count = (double)N * (double)L;
+#define S2F_BN_APPLY(LIFV, HASV)                                                                                        \
+  hipLaunchKernelGGL((bn_apply_kernel<LIFV, HASV>), grid, block, 0, s, z, conv_bias, sums, stat_out, running_mean,      \
+                     running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L,   \
+                     count, momentum, eps, training, vth, (float)D)
   if (y == nullptr)
-    hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, s, z, conv_bias, stat, gamma, beta, residual,
-                       u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L, vth, (float)D);
+    S2F_BN_APPLY(false, false);
   else if (v_in == nullptr)
-    hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, s, z, conv_bias, stat, gamma, beta, residual,
-                       u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L, vth, (float)D);
+    S2F_BN_APPLY(true, false);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, s, z, conv_bias, stat, gamma, beta, residual,
-                       u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L, vth, (float)D);
+    S2F_BN_APPLY(true, true);
+#undef S2F_BN_APPLY
   return s2f_check_launch("s2f_bn_act_fwd");
 }
 
 extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma,
                               const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask,
-                              double* sums_ws, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
+                              double* sums_zeroed, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
                               int64_t C, int64_t L, int training, float vth, int D, void* stream) {
-  S2F_REQUIRE(z && stat && gamma && sums_ws && gz && dgamma && dbeta, S2F_EINVAL, "s2f_bn_act_bwd: null pointer");
+  S2F_REQUIRE(z && stat && gamma && sums_zeroed && gz && dgamma && dbeta, S2F_EINVAL, "s2f_bn_act_bwd: null pointer");
   S2F_REQUIRE(g_u || g_y || g_v, S2F_EINVAL, "s2f_bn_act_bwd: no incoming gradient");
   S2F_REQUIRE(!(g_y || g_v) || mask, S2F_EINVAL, "s2f_bn_act_bwd: spike gradients need the in-range mask");
   int rc = check_shape("s2f_bn_act_bwd", N, C, L);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = N * C * L;
-  if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return s2f_check_launch("s2f_bn_act_bwd memset");
   int slice;
   const int S = pick_slices((int)C, (int)L, slice);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,
-                     mask, sums_ws, (int)N, (int)C, (int)L, slice, vth, (float)D);
-  hipLaunchKernelGGL(bn_param_grads_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, sums_ws, dgamma, dbeta,
-                     (int)C);
+                     mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 0, s, z, conv_bias, stat, gamma, g_u, g_y,
-                     g_v, mask, sums_ws, gz, g_residual, total, (int)C, (int)L, (double)N * (double)L, training, vth,
-                     (float)D);
+                     g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L, (double)N * (double)L,
+                     training, vth, (float)D);
   return s2f_check_launch("s2f_bn_act_bwd");
 }

@@ -24,9 +24,13 @@ def init_process_group(backend=None):
 
 
 class FlatGradAllReduce:
-    """All parameter gradients live as views into one contiguous fp32 buffer (137 MB at C2); `reduce()` issues a single
-    all-reduce(SUM) on a side stream and divides by the world size.  The gradient hooks only count arrivals, so the
-    collective starts the moment the last gradient of the backward pass lands and overlaps whatever follows."""
+    """One contiguous fp32 buffer holds every parameter gradient (137 MB at C2).
+
+    `gather()` packs the gradients autograd produced into the buffer with a handful of batched-copy launches
+    (torch.cat into `out=`), `reduce()` issues a single all-reduce(SUM) on a side stream and divides by the world size,
+    `wait()` joins it.  Gradients are *assigned* by autograd (`p.grad` is None before backward) rather than accumulated
+    into pre-existing views: accumulating costs one tiny add kernel per parameter (1 021 launches, 4.7 ms per C2 step).
+    `views[i]` is parameter i's slice of the flat buffer (what an optimiser would consume)."""
 
     def __init__(self, params, world_size=None):
         self.params = [p for p in params if p.requires_grad]
@@ -34,15 +38,22 @@ class FlatGradAllReduce:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.work = None
 
     def zero(self):
-        self.flat.zero_()
+        """Before backward: drop the old gradients so that autograd assigns instead of accumulating."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """After backward: pack p.grad into the flat buffer (parameters without a gradient keep zeros)."""
+        pieces = [(p.grad if p.grad is not None else v).reshape(-1) for p, v in zip(self.params, self.views)]
+        torch.cat(pieces, out=self.flat)
 
     def reduce(self, async_op=True):
         if self.world == 1:

@@ -35,11 +35,12 @@ class GraphedStep:
             self.grad_buffer.zero()
         else:
             for p in self.model.parameters():
-                if p.grad is not None:
-                    p.grad.zero_()
+                p.grad = None
         out = self.model(self.static_in)
         loss = self.loss_fn(*out)
         loss.backward()
+        if self.grad_buffer is not None:
+            self.grad_buffer.gather()
         return loss.detach()
 
     def __call__(self, x=None):

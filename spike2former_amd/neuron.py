@@ -68,6 +68,9 @@ def reset_net(net: nn.Module):
     for m in net.modules():
         if hasattr(m, "reset"):
             m.reset()
+    p = next(net.parameters(), None)
+    if p is not None and p.is_cuda:
+        ops.begin_step(p.device)        # a reset opens a new step: rewind + clear the reduction-workspace arena
 
 
 def set_keep_membrane(net: nn.Module, keep: bool):

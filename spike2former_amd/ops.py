@@ -17,6 +17,35 @@ def _ev():
     return e
 
 
+# One zero-initialised fp64 arena serves every per-channel reduction workspace of a step (BatchNorm statistics, BatchNorm
+# backward sums): `begin_step()` clears the used prefix with ONE memset and rewinds the cursor; each op takes a slice.
+# Regions are transient (produced and consumed inside one op call), so reuse across steps only needs them zero again.
+# Without `begin_step()` (stand-alone use of an op) every request falls back to a fresh torch.zeros.
+_ARENA = {"buf": None, "pos": 0, "high": 0, "armed": False}
+_ARENA_DOUBLES = 1 << 20
+
+
+def begin_step(device=None):
+    a = _ARENA
+    if a["buf"] is None:
+        if device is None:
+            return
+        a["buf"] = torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=device)
+    elif a["high"] > 0:
+        a["buf"][:a["high"]].zero_()
+    a["pos"], a["armed"] = 0, True
+
+
+def _take_zeroed(n, device):
+    a = _ARENA
+    if a["armed"] and a["buf"] is not None and a["buf"].device == device and a["pos"] + n <= _ARENA_DOUBLES:
+        t = a["buf"][a["pos"]:a["pos"] + n]
+        a["pos"] += n
+        a["high"] = max(a["high"], a["pos"])
+        return t
+    return torch.zeros(n, dtype=torch.float64, device=device)
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -179,7 +208,10 @@ class _DCNv3(torch.autograd.Function):
     def backward(ctx, go):
         x, offset, mask = ctx.saved_tensors
         go = go.contiguous()
-        gx = torch.zeros_like(x)
+        N, H, W, G, Cg = ctx.geo[:5]
+        Ho, Wo = offset.shape[1], offset.shape[2]
+        lds_path = 4 * (2 * H * W + Ho * Wo) * Cg <= 160 * 1024      # same test as s2f_dcnv3_bwd: slice resident in LDS
+        gx = torch.empty_like(x) if lds_path else torch.zeros_like(x)
         goff, gm = torch.empty_like(offset), torch.empty_like(mask)
         check(lib.s2f_dcnv3_bwd(_ptr(x), _ptr(offset), _ptr(mask), _ptr(go), _ptr(gx), _ptr(goff), _ptr(gm), *ctx.geo,
                                 ctx.osc, _stream()), "s2f_dcnv3_bwd")
@@ -204,10 +236,11 @@ class _BNAct(torch.autograd.Function):
         L = z.numel() // (N * C)
         dev = z.device
         stat = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
         s = _stream()
-        check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
-                               _ptr(nbt), N, C, L, momentum, eps, int(training), s), "s2f_bn_stats")
+        ws = None
+        if training:
+            ws = _take_zeroed(2 * C, dev)
+            check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), N, C, L, s), "s2f_bn_stats")
         if residual is not None:
             residual = residual.contiguous()
         if v_in is not None:
@@ -219,8 +252,9 @@ class _BNAct(torch.autograd.Function):
         mask = torch.empty(mask_words(z.numel()), dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
         n = z.numel()
         e0 = _ev() if (KERNEL_EVENTS is not None) else None
-        check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u),
-                                 _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, vth, D, s),
+        check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
+                                 _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
+                                 _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D, s),
               "s2f_bn_act_fwd")
         if e0 is not None:
             # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
@@ -248,7 +282,7 @@ class _BNAct(torch.autograd.Function):
         g_res = torch.empty_like(z) if (has_res and ctx.needs_input_grad[4]) else None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = _take_zeroed(2 * C, dev)
         e0 = _ev() if (KERNEL_EVENTS is not None) else None
         check(lib.s2f_bn_act_bwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
                                  _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,

@@ -4,6 +4,7 @@ runner are out of scope."""
 import torch
 import torch.nn as nn
 
+from . import ops
 from .neuron import reset_net
 from .registry import HOOKS, MODELS, ConfigDict
 
@@ -33,6 +34,8 @@ class EncoderDecoder(nn.Module):
         return self.decode_head.predict(self.extract_feat(inputs), batch_img_metas, self.test_cfg)
 
     def forward(self, inputs, data_samples=None, mode="tensor"):
+        if inputs.is_cuda:
+            ops.begin_step(inputs.device)          # rewind + clear the per-step reduction-workspace arena
         if mode == "tensor":
             return self._forward(inputs, data_samples)
         if mode == "predict":

@@ -27,13 +27,16 @@ def _worker(rank, world, port, out):
     start, per = shard_batch(8, r, w)
     red.zero()
     lin(data[start:start + per]).square().mean().backward()
+    red.gather()
     local = red.flat.clone()
+    want_local = torch.cat([p.grad.reshape(-1) for p in lin.parameters()])
     red.reduce(); red.wait()
     gathered = [torch.zeros_like(local) for _ in range(w)]
     dist.all_gather(gathered, local)
     want = torch.stack(gathered).mean(0)
-    ok = torch.allclose(red.flat, want, atol=1e-7) and all(
-        p.grad.data_ptr() >= red.flat.data_ptr() for p in lin.parameters())
+    ok = torch.equal(local, want_local) and torch.allclose(red.flat, want, atol=1e-7) and all(
+        torch.equal(v, red.flat[o:o + v.numel()].view_as(v))
+        for v, o in zip(red.views, [0] + list(torch.tensor([v.numel() for v in red.views]).cumsum(0)[:-1])))
     p0 = torch.cat([p.detach().flatten() for p in lin.parameters()])
     ps = [torch.zeros_like(p0) for _ in range(w)]
     dist.all_gather(ps, p0)
