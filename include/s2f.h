@@ -105,6 +105,19 @@ int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, int N, int 
 int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, float* gw, int N, int C, int H, int W,
                           int K, int pad, void* stream);
 
+/* ---- spike GEMM on the bf16 matrix cores ---------------------------------------------------------------
+ * Y[b] (M x N) = W (M x K) @ X[b] (K x N) [+ bias[M]]   for b in [0, batch): the 1x1 Conv2d / Conv1d(k=1) / im2col'd kxk
+ * convolution of the path on channel-major activations [batch, K, N] whose input is a Q_IFNode output (q/k/v/proj RepConv
+ * 1x1, sdtv2.py:121-125, 304-306; MS_MLP / MS_ConvBlock / MS_DownSampling, sdtv2.py:197-204, 229-235, 399-405; the head's
+ * Conv1d / 1x1 Conv2d, mmcv_spike/transformer.py:213-236, 758-763, pixel_decoder.py:368-404, SNN_core.py:31-45).
+ * X must hold spikes -- multiples of 1/D with at most 8 significant bits (exact in bf16).  W is pre-split by
+ * s2f_split_bf16x3 into hi + mid + lo bf16 terms (24 mantissa bits); products are exact, accumulation is fp32:
+ * the accuracy of an fp32 GEMM on v_mfma_f32_32x32x16_bf16.  `terms` in {1,2,3} = number of weight terms used.
+ * w_split: [3][Mpad][Kpad] bf16, zero padded, Mpad % 64 == 0, Kpad % 32 == 0.  N % 4 == 0. */
+int s2f_split_bf16x3(const float* w, uint16_t* w_split, int M, int K, int Mpad, int Kpad, void* stream);
+int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int N,
+                       int K, int Mpad, int Kpad, int terms, void* stream);
+
 /* ---- a5 / a10: spike-driven (softmax-free) attention core --------------------------------------------
  * Replaces  kv = k^T @ v ; o = (q @ kv) * scale ; o.transpose(3,4).reshape(T,B,C,N)
  * (MS_Attention_RepConv_qkv_id, mmseg/models/backbones/sdtv2.py:308-339) and the decoder's

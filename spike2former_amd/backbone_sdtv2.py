@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .conv import Conv1d, Conv2d
+from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
@@ -75,6 +75,7 @@ class RepConv(nn.Module):
             Conv2d(in_channel, out_channel, 1, 1, 0, groups=1, bias=False),
             nn.BatchNorm2d(out_channel))
         self.body = nn.Sequential(conv1x1, bn, conv3x3)
+        spikes_in(conv1x1)                      # RepConv is always fed by a neuron (head_spike / attn_spike)
 
     def forward(self, x, outer_bn=None, lif=None, residual=None):
         """conv1x1 -> BN+pad -> dw3x3 -> conv1x1 -> BN [-> outer BN [+ residual] [-> neuron]].
@@ -103,6 +104,7 @@ class SepConv(nn.Module):
         self.dwconv = Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias)
         self.pwconv2 = Conv2d(med, dim, kernel_size=1, stride=1, bias=bias)
         self.bn2 = nn.BatchNorm2d(dim)
+        spikes_in(self.pwconv1)                 # pwconv2 reads the depthwise output (not spikes)
 
     def forward(self, x, residual=None):
         """Returns SepConv(x) [+ residual] (the residual add is fused into the last BatchNorm kernel)."""
@@ -128,6 +130,7 @@ class MS_ConvBlock(nn.Module):
         self.spike2 = _lif()
         self.conv2 = Conv2d(dim * mlp_ratio, dim, kernel_size=3, padding=1, groups=1, bias=False)
         self.bn2 = nn.BatchNorm2d(dim)
+        spikes_in(self.conv1, self.conv2)
 
     def forward(self, x):
         T, B, C, H, W = x.shape
@@ -153,6 +156,7 @@ class MS_MLP(nn.Module):
         self.fc2_spike = _lif()
         self.c_hidden = hidden_features
         self.c_output = out_features
+        spikes_in(self.fc1_conv, self.fc2_conv)
 
     def forward(self, x, residual=None):
         T, B, C, H, W = x.shape
@@ -223,6 +227,7 @@ class MS_DownSampling(nn.Module):
         self.first_layer = first_layer
         if not first_layer:
             self.encode_spike = _lif()
+            spikes_in(self.encode_conv)
 
     def forward(self, x):
         T, B = x.shape[:2]

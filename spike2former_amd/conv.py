@@ -20,8 +20,16 @@ from . import ops
 torch.backends.cudnn.enabled = False        # = MIOpen on ROCm; see module docstring
 
 
-def _gemm_nc(weight2d, x3, bias):
+def spikes_in(*convs):
+    """Mark convolutions whose input is produced by a Q_IFNode (exact in bf16 -> eligible for the spike GEMM)."""
+    for c in convs:
+        c.spike_input = True
+
+
+def _gemm_nc(weight2d, x3, bias, spike_input=False):
     """x3 [N, K, L], weight2d [M, K] -> [N, M, L]."""
+    if spike_input and ops.SPIKE_GEMM_ENABLED and x3.shape[2] % 4 == 0:
+        return ops.spike_gemm(x3, weight2d, bias)       # bf16 matrix cores, exact for spike activations
     # bmm with the weight broadcast through a zero batch stride: rocBLAS strided-batched GEMM, no operand copies
     # (torch.matmul would fold the batch into the rows of a transposed -- i.e. copied -- activation matrix)
     y = torch.bmm(weight2d.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
@@ -31,6 +39,8 @@ def _gemm_nc(weight2d, x3, bias):
 
 
 class Conv2d(nn.Conv2d):
+    spike_input = False       # set by the owning module when the input is a Q_IFNode output (multiples of 1/D)
+
     def forward(self, x, border=None):
         return self._conv(x, self.bias, border)
 
@@ -52,14 +62,16 @@ class Conv2d(nn.Conv2d):
         M = self.out_channels
         kh, kw = self.kernel_size
         if kh == 1 and kw == 1 and self.stride == (1, 1) and self.padding == (0, 0):
-            return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias).view(N, M, H, W)
+            return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias, self.spike_input).view(N, M, H, W)
         Ho = (H + 2 * self.padding[0] - self.dilation[0] * (kh - 1) - 1) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - self.dilation[1] * (kw - 1) - 1) // self.stride[1] + 1
         cols = F.unfold(x, (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]
-        return _gemm_nc(self.weight.view(M, -1), cols, bias).view(N, M, Ho, Wo)
+        return _gemm_nc(self.weight.view(M, -1), cols, bias, self.spike_input).view(N, M, Ho, Wo)
 
 
 class Conv1d(nn.Conv1d):
+    spike_input = False
+
     def forward(self, x):
         return self._conv(x, self.bias)
 
@@ -70,4 +82,4 @@ class Conv1d(nn.Conv1d):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         assert self.kernel_size == (1,) and self.stride == (1,) and self.groups == 1, "only k=1 Conv1d is on the path"
-        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias)
+        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias, self.spike_input)

@@ -1,0 +1,252 @@
+// Spike GEMM on the bf16 matrix cores (gfx950):  Y[b] (M x N) = W (M x K) @ X[b] (K x N) [+ bias],  fp32 in / fp32 out.
+//
+// This is the 1x1 Conv2d / Conv1d(k=1) / im2col'd kxk convolution of the path applied to SPIKES: X holds multiples of
+// 1/D (|x| <= 16, at most 8 significant bits), which bf16 represents exactly.  The fp32 weight is split once into three
+// bf16 terms  w = hi + mid + lo  (3 x 8 = 24 mantissa bits, i.e. all of fp32), so every MFMA product is exact and the only
+// rounding is the fp32 accumulation -- the accuracy of an fp32 GEMM at 3/16 of the fp32-MFMA cost (v_mfma_f32_32x32x16_bf16
+// runs 16x the rate of v_mfma_f32_32x32x2_f32).  `terms` = 1..3 selects how many weight terms are used.
+// Reference call sites: q/k/v/proj RepConv 1x1 (mmseg/models/backbones/sdtv2.py:121-125, 304-306), MS_MLP / MS_ConvBlock /
+// MS_DownSampling convolutions (sdtv2.py:197-204, 229-235, 399-405), every Conv1d / 1x1 Conv2d of the head
+// (mmcv_spike/transformer.py:213-236, 758-763; pixel_decoder.py:368-404; SNN_core.py:31-45).
+//
+// Tiling: block = WM x 2 wavefronts, each wavefront owns a 64 x 64 output tile as 2 x 2 MFMA tiles (64 accumulator
+// VGPRs); block tile (64*WM) x 128, K step 32.  X is read ONCE per block tile straight from its channel-major layout
+// ([K][N], N contiguous): each thread loads a 4(k) x 4(n) patch with four 16-byte loads, converts to bf16 and writes it
+// TRANSPOSED into LDS ([n][k], one ds_write_b64 per n), so that both MFMA operands are k-contiguous ds_read_b128
+// fragments.  LDS rows are padded to 80 bytes: the 16-lane service groups of ds_read_b128 then cover all 64 banks exactly
+// once (conflict-free).  The split weight is pre-padded to multiples of the tile, so the A path has no bounds checks.
+#include "s2f_common.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int BN = 128;
+constexpr int BK = 32;
+constexpr int LDR = 40;          // LDS row length in bf16 (32 + 8 pad = 80 bytes)
+
+__device__ __forceinline__ unsigned short f2bf(float f) {          // round-to-nearest-even fp32 -> bf16 (finite inputs)
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// w [M][K] fp32 -> out [3][Mpad][Kpad] bf16 (zero padded):  w = hi + mid + lo with |w - (hi+mid+lo)| <= 2^-24 |w|
+__global__ void split_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K, int Mpad,
+                                    int Kpad) {
+  const int64_t total = (int64_t)Mpad * Kpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / Kpad), k = (int)(i % Kpad);
+    unsigned short h = 0, md = 0, l = 0;
+    if (m < M && k < K) {
+      const float v = w[(int64_t)m * K + k];
+      h = f2bf(v);
+      const float r1 = v - bf2f(h);
+      md = f2bf(r1);
+      const float r2 = r1 - bf2f(md);
+      l = f2bf(r2);
+    }
+    out[i] = h;
+    out[total + i] = md;
+    out[2 * total + i] = l;
+  }
+}
+
+// global -> registers for the K step starting at kk (issued one step ahead of its use: the loads fly under the MFMAs)
+template <int WM, int TERMS>
+__device__ __forceinline__ void fetch_tile(u32x4 (&areg)[TERMS][2], f32x4 (&breg)[(256 + 128 * WM - 1) / (128 * WM)][4],
+                                           const unsigned short* __restrict__ Wsplit, const float* __restrict__ Xb,
+                                           int64_t term_stride, int m0, int n0, int kk, int tid, int K, int N, int Kpad) {
+  constexpr int T = 128 * WM;
+  constexpr int NP = (256 + T - 1) / T;
+#pragma unroll
+  for (int t = 0; t < TERMS; ++t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = tid + h * T;
+      areg[t][h] =
+          *reinterpret_cast<const u32x4*>(Wsplit + t * term_stride + (int64_t)(m0 + (c >> 2)) * Kpad + kk + (c & 3) * 8);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int p = tid + q * T;
+    const int kb = p / (BN / 4), nb = p % (BN / 4);
+    const int n = n0 + nb * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kk + kb * 4 + r;
+      breg[q][r] = (p < 256 && k < K && n < N) ? *reinterpret_cast<const f32x4*>(Xb + (int64_t)k * N + n)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+template <int WM, int TERMS>
+__global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned short* __restrict__ Wsplit,
+                                                              const float* __restrict__ X, const float* __restrict__ bias,
+                                                              float* __restrict__ Y, int M, int N, int K, int Mpad, int Kpad,
+                                                              int n_tiles, int m_tiles) {
+  constexpr int BM = 64 * WM;
+  constexpr int T = 128 * WM;
+  __shared__ __attribute__((aligned(16))) unsigned short As[TERMS][BM][LDR];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[BN][LDR];
+
+  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a contiguous range of
+  // tiles with the m-tiles of one n-tile adjacent, so that re-reads of an X tile hit that XCD's L2.
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const float* Xb = X + (int64_t)b * K * N;
+  float* Yb = Y + (int64_t)b * M * N;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t term_stride = (int64_t)Mpad * Kpad;
+  constexpr int NP = (256 + T - 1) / T;          // 4x4 patches of the X tile per thread (256 patches per K step)
+  u32x4 areg[TERMS][2];
+  f32x4 breg[NP][4];
+
+  fetch_tile<WM, TERMS>(areg, breg, Wsplit, Xb, term_stride, m0, n0, 0, tid, K, N, Kpad);
+  for (int k0 = 0; k0 < Kpad; k0 += BK) {
+    // registers -> LDS (A as is; X converted to bf16 and transposed to [n][k])
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = tid + h * T;
+        *reinterpret_cast<u32x4*>(&As[t][c >> 2][(c & 3) * 8]) = areg[t][h];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int p = tid + q * T;
+      if (p < 256) {
+        const int kb = p / (BN / 4), nb = p % (BN / 4);
+        u16x4 pk;
+        pk[0] = f2bf(breg[q][0].x); pk[1] = f2bf(breg[q][1].x); pk[2] = f2bf(breg[q][2].x); pk[3] = f2bf(breg[q][3].x);
+        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 0][kb * 4]) = pk;
+        pk[0] = f2bf(breg[q][0].y); pk[1] = f2bf(breg[q][1].y); pk[2] = f2bf(breg[q][2].y); pk[3] = f2bf(breg[q][3].y);
+        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 1][kb * 4]) = pk;
+        pk[0] = f2bf(breg[q][0].z); pk[1] = f2bf(breg[q][1].z); pk[2] = f2bf(breg[q][2].z); pk[3] = f2bf(breg[q][3].z);
+        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 2][kb * 4]) = pk;
+        pk[0] = f2bf(breg[q][0].w); pk[1] = f2bf(breg[q][1].w); pk[2] = f2bf(breg[q][2].w); pk[3] = f2bf(breg[q][3].w);
+        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 3][kb * 4]) = pk;
+      }
+    }
+    __syncthreads();
+    if (k0 + BK < Kpad) fetch_tile<WM, TERMS>(areg, breg, Wsplit, Xb, term_stride, m0, n0, k0 + BK, tid, K, N, Kpad);
+    // ---- MFMA: 2 k-slices x (2 x 2 tiles) x terms
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kof = ks * 16 + 8 * (lane >> 5);
+      bf16x8 bfrag[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * 64 + j * 32 + (lane & 31)][kof]);
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[row];
+          Yb[(int64_t)row * N + col] = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int s2f_split_bf16x3(const float* w, uint16_t* out, int M, int K, int Mpad, int Kpad, void* stream) {
+  S2F_REQUIRE(w && out, S2F_EINVAL, "s2f_split_bf16x3: null pointer");
+  S2F_REQUIRE(M > 0 && K > 0 && Mpad >= M && Kpad >= K && Mpad % 64 == 0 && Kpad % 32 == 0, S2F_EINVAL,
+              "s2f_split_bf16x3: need Mpad %% 64 == 0, Kpad %% 32 == 0 (M=%d K=%d Mpad=%d Kpad=%d)", M, K, Mpad, Kpad);
+  const int64_t total = (int64_t)Mpad * Kpad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, M, K, Mpad, Kpad);
+  return s2f_check_launch("s2f_split_bf16x3");
+}
+
+extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M,
+                                  int N, int K, int Mpad, int Kpad, int terms, void* stream) {
+  S2F_REQUIRE(w_split && X && Y, S2F_EINVAL, "s2f_spike_gemm_fwd: null pointer");
+  S2F_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL, "s2f_spike_gemm_fwd: bad sizes");
+  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "s2f_spike_gemm_fwd: N=%d must be a multiple of 4", N);
+  S2F_REQUIRE(Kpad >= K && Kpad % 32 == 0 && Mpad >= M && Mpad % 64 == 0, S2F_EINVAL, "s2f_spike_gemm_fwd: bad padding");
+  S2F_REQUIRE(s2f_aligned16(w_split) && s2f_aligned16(X) && s2f_aligned16(Y), S2F_EALIGN,
+              "s2f_spike_gemm_fwd: pointers must be 16-byte aligned");
+  S2F_REQUIRE(batch < 65536, S2F_EINVAL, "s2f_spike_gemm_fwd: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_tiles = (N + BN - 1) / BN;
+  // Tile choice: the widest block tile (fewest re-reads of X) that still gives every CU >= 2 workgroups; short-and-fat
+  // problems (few output tiles, long K) fall back to narrower tiles so the grid fills the 256 CUs.
+  int wm = 1;
+  for (int cand = 4; cand >= 1; cand >>= 1) {
+    if (Mpad % (64 * cand) != 0) continue;
+    if (cand > 1 && M <= 32 * cand) continue;                 // more than half of the tile rows would be padding
+    const int64_t blocks = (int64_t)n_tiles * (Mpad / (64 * cand)) * batch;
+    if (blocks >= 512 || cand == 1) {
+      wm = cand;
+      break;
+    }
+  }
+  const int m_tiles = Mpad / (64 * wm);
+  const dim3 grid(n_tiles * m_tiles, batch);
+#define S2F_LAUNCH(WMV, TV)                                                                                             \
+  hipLaunchKernelGGL((spike_gemm_kernel<WMV, TV>), grid, dim3(128 * WMV), 0, s, w_split, X, bias, Y, M, N, K, Mpad, Kpad, \
+                     n_tiles, m_tiles)
+#define S2F_LAUNCH_T(WMV)            \
+  if (terms == 3) S2F_LAUNCH(WMV, 3); \
+  else if (terms == 2) S2F_LAUNCH(WMV, 2); \
+  else S2F_LAUNCH(WMV, 1)
+  if (wm == 4) {
+    S2F_LAUNCH_T(4);
+  } else if (wm == 2) {
+    S2F_LAUNCH_T(2);
+  } else {
+    S2F_LAUNCH_T(1);
+  }
+#undef S2F_LAUNCH_T
+#undef S2F_LAUNCH
+  return s2f_check_launch("s2f_spike_gemm_fwd");
+}

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .conv import Conv1d, Conv2d
+from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import ConfigDict
@@ -34,6 +34,7 @@ class SepConv_Spike(nn.Module):
             Conv2d(med, med, kernel_size=kernel_size, padding=padding, groups=med, bias=bias), nn.BatchNorm2d(med))
         self.spike3 = _lif()
         self.pwconv2 = nn.Sequential(Conv2d(med, dim, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(dim))
+        spikes_in(self.pwconv1[0], self.pwconv2[0])       # both follow a neuron (spike1, spike3)
 
     def forward(self, x):
         T, B, H, W, C = x.shape
@@ -103,6 +104,7 @@ class DCNv3_pytorch(nn.Module):
                                         expansion_ratio=expension_ratio)
         self.output_proj = SepConv_Spike(dim=channels, kernel_size=dw_kernel_size, padding=(dw_kernel_size - 1) // 2,
                                          expansion_ratio=expension_ratio)
+        spikes_in(self.offset[0], self.mask[0])            # both read offset_spike's output
         for m in (self.offset[0], self.mask[0]):           # zero init as in the reference (:192-196)
             nn.init.constant_(m.weight, 0.0)
             nn.init.constant_(m.bias, 0.0)
@@ -138,6 +140,7 @@ class MS_MLP(nn.Module):
         self.fc2_spike = _lif()
         self.fc2_conv = Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
         self.fc2_bn = nn.BatchNorm1d(embed_dims)
+        spikes_in(self.fc1_conv, self.fc2_conv)
 
     def forward(self, x):
         T, B, H, W, C = x.shape
@@ -214,6 +217,7 @@ class MultiHeadAttentionBlock(nn.Module):
         self.v_spike = _lif()
         self.attn_spike = _lif()
         self.out_conv = proj()
+        spikes_in(self.q_conv[0], self.k_conv[0], self.v_conv[0], self.out_conv[0])
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
         if attn_mask is not None:
@@ -282,6 +286,7 @@ class MSDA_FFN(nn.Module):
         self.fc2_spike = _lif()
         self.fc2 = Conv1d(feedforward_channels, embed_dims, kernel_size=1, stride=1)
         self.bn2 = nn.BatchNorm1d(embed_dims)
+        spikes_in(self.fc1, self.fc2)
 
     def forward(self, x, identity=None):
         t, bs, N, C = x.shape

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .head_layers import MLP, DetrTransformerDecoder, SinePositionalEncoding
-from .conv import Conv1d, Conv2d
+from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS, ConfigDict
@@ -64,6 +64,7 @@ class MaskFormerHead(nn.Module):
         self.shortcut_conv_spike = _lif()
         self.shortcut_conv = nn.Sequential(Conv1d(num_queries, num_queries, kernel_size=1, stride=1, bias=False),
                                            nn.BatchNorm1d(num_queries))
+        spikes_in(self.shortcut_conv[0])                    # reads alpha * spikes = multiples of 1/2
         self.test_cfg, self.train_cfg = test_cfg, train_cfg
         self.align_corners = align_corners
         self.out_channels = num_classes

@@ -348,3 +348,63 @@ class _DWConv(torch.autograd.Function):
 
 def dwconv(x, w, pad, border=None):
     return _DWConv.apply(x, w, border, pad)
+
+
+# ------------------------------------------------------------------------------------------------ spike GEMM (bf16 MFMA)
+_SPLIT_CACHE = {}
+SPIKE_GEMM_TERMS = 3          # number of bf16 weight terms (3 == fp32-equivalent)
+SPIKE_GEMM_ENABLED = True
+SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
+
+
+def split_weight(w2d):
+    """fp32 [M, K] -> cached bf16 [3, Mpad, Kpad] (hi, mid, lo).  Re-split when the parameter is modified in place
+    (optimiser step, load_state_dict) -- tracked through the tensor version counter."""
+    key = w2d.data_ptr()
+    M, K = w2d.shape
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0] == w2d._version and hit[1].shape[1] >= M and hit[2] == (M, K):
+        return hit[1]
+    Mpad, Kpad = (M + 63) // 64 * 64, (K + 31) // 32 * 32
+    out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=w2d.device)
+    check(lib.s2f_split_bf16x3(_ptr(w2d.detach().contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
+    _SPLIT_CACHE[key] = (w2d._version, out, (M, K))
+    return out
+
+
+class _SpikeGemm(torch.autograd.Function):
+    """Y[b] = W @ X[b] (+ bias) with X spikes: forward on the bf16 matrix cores (W split hi+mid+lo), backward on rocBLAS."""
+
+    @staticmethod
+    def forward(ctx, x, w2d, bias):
+        _need_cuda(x, w2d, bias)
+        x = x.contiguous()
+        B, K, N = x.shape
+        M = w2d.shape[0]
+        if SPIKE_GEMM_CHECK:
+            assert torch.equal(x * 8, torch.round(x * 8)) and float(x.abs().max()) <= 16, "not a spike tensor"
+        ws = split_weight(w2d)
+        y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
+        check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, ws.shape[1], ws.shape[2],
+                                     SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
+        ctx.save_for_backward(x, w2d)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w2d = ctx.saved_tensors
+        gy = gy.contiguous()
+        B = x.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.bmm(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2))
+        return gx, gw, gb
+
+
+def spike_gemm(x, w2d, bias=None):
+    return _SpikeGemm.apply(x, w2d, bias)

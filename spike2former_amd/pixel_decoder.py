@@ -4,7 +4,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .head_layers import DCNDetrTransformerEncoder, SinePositionalEncoding
-from .conv import Conv1d, Conv2d
+from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
@@ -59,6 +59,7 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         self.encoder_out_proj_spike = _lif()
         self.encoder_out_proj = nn.Sequential(Conv2d(feat_channels, feat_channels, kernel_size=1, stride=1),
                                               nn.BatchNorm2d(feat_channels))
+        spikes_in(self.mask_feature, self.encoder_in_proj[0], self.encoder_out_proj[0], *[s[0] for s in self.lateral_convs])
 
     def init_weights(self):
         pass

@@ -340,3 +340,54 @@ def test_dwconv_vs_aten_cpu(ops, N, C, H, W, K, pad, border):
     def close(a, bb, tol):
         return (a.detach().cpu() - bb.detach()).abs().max().item() <= tol * bb.abs().max().item()
     assert yc.shape == yo.shape and close(yc, yo, 2e-6) and close(xc.grad, xo.grad, 2e-6) and close(wc.grad, wo.grad, 2e-5)
+
+
+# ----------------------------------------------------------------------------------------------- spike GEMM (bf16 MFMA)
+def test_mfma_fragment_layout_identity_check(ops):
+    """A = I with an ASYMMETRIC B catches row/column swaps in the MFMA operand / accumulator mapping."""
+    M = K = 64
+    N = 128
+    w = torch.eye(M, K, device="cuda")
+    x = (torch.arange(K * N, device="cuda").reshape(1, K, N) % 97).float() / 8          # spikes-like grid, asymmetric
+    y = ops.spike_gemm(x, w, None)
+    assert torch.equal(y, x)
+
+
+@pytest.mark.parametrize("B,M,K,N", [(2, 256, 256, 1024), (1, 32, 288, 4096), (3, 360, 360, 1024), (2, 151, 100, 100),
+                                     (1, 1024, 256, 256), (2, 64, 1152, 512), (1, 576, 256, 36)])
+def test_spike_gemm_matches_fp64(ops, B, M, K, N):
+    """Spike activations x three-term bf16 weights, fp32 accumulation: error vs an fp64 reference must be that of an fp32
+    GEMM (<= 2e-6 of sum|w||x|; measured fp32 rocBLAS on the same data is reported for comparison), ragged M/K/N included."""
+    g = torch.Generator().manual_seed(M + K)
+    w = torch.randn(M, K, generator=g) * K ** -0.5
+    x = torch.clamp(torch.round(torch.randn(B, K, N, generator=g) + 0.7), 0, 8) / 8
+    bias = torch.randn(M, generator=g)
+    ref = torch.matmul(w.double(), x.double()) + bias.double().view(1, -1, 1)
+    scale = torch.matmul(w.abs().double(), x.abs().double()).max().item()
+    wc, xc = w.cuda().requires_grad_(True), x.cuda().requires_grad_(True)
+    y = ops.spike_gemm(xc, wc, bias.cuda())
+    err = (y.detach().cpu().double() - ref).abs().max().item()
+    err32 = (torch.matmul(w.cuda(), x.cuda()).cpu().double() + bias.double().view(1, -1, 1) - ref).abs().max().item()
+    assert err <= 2e-6 * scale, (err, err32, scale)
+    # backward (rocBLAS fp32) is the plain GEMM adjoint
+    gy = torch.randn(B, M, N, generator=g)
+    y.backward(gy.cuda())
+    gx_ref = torch.matmul(w.t().double(), gy.double())
+    gw_ref = torch.einsum("bml,bkl->mk", gy.double(), x.double())
+    assert (xc.grad.cpu().double() - gx_ref).abs().max().item() <= 1e-5 * gx_ref.abs().max().item()
+    assert (wc.grad.cpu().double() - gw_ref).abs().max().item() <= 1e-5 * gw_ref.abs().max().item()
+
+
+def test_spike_gemm_terms_and_resplit(ops):
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(128, 256, generator=g).cuda()
+    x = (torch.randint(0, 9, (1, 256, 512), generator=g).float() / 8).cuda()
+    ref = torch.matmul(w.double(), x.double())
+    errs = []
+    for t in (1, 2, 3):
+        ops.SPIKE_GEMM_TERMS = t
+        errs.append((ops.spike_gemm(x, w).double() - ref).abs().max().item())
+    ops.SPIKE_GEMM_TERMS = 3
+    assert errs[0] > 100 * errs[1] and errs[1] > 3 * errs[2] and errs[2] < 3e-5     # 8 / 16 / 24 mantissa bits (x3 sits on the fp32 accumulation floor)
+    w.mul_(2.0)                                                                           # in-place update -> re-split
+    assert (ops.spike_gemm(x, w).double() - 2 * ref).abs().max().item() < 6e-5

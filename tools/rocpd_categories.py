@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-step GPU time by kernel category from a rocprofv3 rocpd database of `bench.py` (graph replays at the end).
+    python tools/rocpd_categories.py <results.db> <replays>   # replays = steps + warmup of the bench run"""
+import collections
+import sqlite3
+import sys
+
+
+def cat(name):
+    if name.startswith('Cijk'): return 'GEMM (rocBLAS/Tensile)'
+    if 'dcn_' in name: return 'dcn (ours)'
+    if 'dw_' in name: return 'dwconv (ours)'
+    if 'bn_' in name: return 'bn(+lif) fused (ours)'
+    if 'lif_' in name: return 'lif (ours)'
+    if 'apply_kernel' in name or 'outer_kernel' in name: return 'sdsa (ours)'
+    if 'depthwise' in name: return 'depthwise conv (ATen)'
+    if 'batch_norm' in name: return 'batch_norm (ATen)'
+    if 'im2col' in name or 'col2im' in name: return 'im2col/col2im (ATen)'
+    if 'upsample' in name: return 'upsample (ATen)'
+    if 'direct_copy' in name or 'copyBuffer' in name or 'CatArray' in name: return 'copies'
+    if 'CUDAFunctor_add' in name or 'CUDAFunctorOnSelf_add' in name: return 'add (ATen)'
+    if 'reduce_kernel' in name: return 'reduce (ATen)'
+    if 'fill' in name.lower(): return 'fill/memset'
+    return 'other elementwise (ATen)'
+
+
+def main():
+    c = sqlite3.connect(sys.argv[1])
+    replays = int(sys.argv[2])
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    # the last `replays` occurrences of the step are graph replays; one step has 6 dcn backward launches at C2 (pd layers)
+    marks = [i for i, r in enumerate(rows) if 'dcn_bwd' in r[0]]
+    per_step = len([1 for r in rows if 'dcn_fwd' in r[0]]) // max(len(marks) // 6, 1) or 6
+    first = marks[-6 * replays]
+    # step boundary: walk back from the first dcn_bwd of that replay to the preceding step's end is fuzzy; use whole replays
+    sel = rows[first:]
+    # approximate: measure categories over the last (replays-1) full steps between consecutive "first dcn_bwd of a step" marks
+    starts = [marks[-6 * k] for k in range(replays, 0, -1)]
+    sel = rows[starts[0]:starts[-1]]
+    nsteps = replays - 1
+    agg, cnt = collections.Counter(), collections.Counter()
+    for n, s, e in sel:
+        agg[cat(n)] += e - s
+        cnt[cat(n)] += 1
+    tot = sum(agg.values())
+    span = sel[-1][2] - sel[0][1]
+    print(f"# {nsteps} steps, {len(sel)//nsteps} launches/step, kernel time {tot/nsteps/1e6:.2f} ms/step, wall span {span/nsteps/1e6:.2f} ms/step")
+    for k, v in agg.most_common():
+        print(f"{k:30s} {v/nsteps/1e6:8.2f} ms/step {cnt[k]//nsteps:6d} launches/step {100*v/tot:5.1f}%")
+
+
+if __name__ == "__main__":
+    main()
