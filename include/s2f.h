@@ -118,6 +118,12 @@ int s2f_split_bf16x3(const float* w, uint16_t* w_split, int M, int K, int Mpad, 
 int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int N,
                        int K, int Mpad, int Kpad, int terms, void* stream);
 
+/* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
+ * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path
+ * (mmdet/models/layers/pixel_decoder.py:456-460).  w must be even (16-byte output stores). */
+int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream);
+int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream);
+
 /* ---- a5 / a10: spike-driven (softmax-free) attention core --------------------------------------------
  * Replaces  kv = k^T @ v ; o = (q @ kv) * scale ; o.transpose(3,4).reshape(T,B,C,N)
  * (MS_Attention_RepConv_qkv_id, mmseg/models/backbones/sdtv2.py:308-339) and the decoder's

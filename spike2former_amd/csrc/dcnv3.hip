@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(const float* __restrict__ 
 // (H*W*Cg floats, 32 KiB at the C2 geometry), so the scatter-add runs on LDS atomics and the slice is written back
 // with plain stores -- no global atomics, no pre-zeroed grad_input.  The input slice and the grad_output slice are
 // staged in LDS as well, so every bilinear corner is an LDS read.  Work item = (output pixel, tap).
-__global__ __launch_bounds__(256) void dcn_bwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ off,
+__global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ off,
                                                           const float* __restrict__ msk, const float* __restrict__ gout,
                                                           float* __restrict__ gin, float* __restrict__ goff,
                                                           float* __restrict__ gmsk, Geom g) {
@@ -185,18 +185,18 @@ __global__ __launch_bounds__(256) void dcn_bwd_lds_kernel(const float* __restric
   float* s_go = s_gin + npix_in * Cg;       // [Ho*Wo][Cg]
   const float* inb = in + (int64_t)n * npix_in * C + gi * Cg;
   const float* gob = gout + (int64_t)n * npix_out * C + gi * Cg;
-  for (int e = threadIdx.x; e < npix_in * Cg; e += 256) {
+  for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
     s_in[e] = inb[(int64_t)p * C + c];
     s_gin[e] = 0.f;
   }
-  for (int e = threadIdx.x; e < npix_out * Cg; e += 256) {
+  for (int e = threadIdx.x; e < npix_out * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
     s_go[e] = gob[(int64_t)p * C + c];
   }
   __syncthreads();
   const int items = npix_out * P;
-  for (int it = threadIdx.x; it < items; it += 256) {
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
     const int pix = it / P, k = it % P;
     const int ho = pix / g.Wo, wo = pix % g.Wo;
     const int64_t gpix = (int64_t)n * npix_out + pix;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_lds_kernel(const float* __restric
   }
   __syncthreads();
   float* ginb = gin + (int64_t)n * npix_in * C + gi * Cg;
-  for (int e = threadIdx.x; e < npix_in * Cg; e += 256) {
+  for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
     ginb[(int64_t)p * C + c] = s_gin[e];
   }
@@ -296,7 +296,8 @@ extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const floa
         raised = true;
       }
     }
-    hipLaunchKernelGGL(dcn_bwd_lds_kernel, dim3(N * G), dim3(256), lds, (hipStream_t)stream, input, offset, mask,
+    // 1024 threads = 16 wavefronts per CU: the per-item offset/mask loads are dependent global reads, hidden by occupancy
+    hipLaunchKernelGGL(dcn_bwd_lds_kernel, dim3(N * G), dim3(1024), lds, (hipStream_t)stream, input, offset, mask,
                        grad_output, grad_input, grad_offset, grad_mask, g);
     return s2f_check_launch("s2f_dcnv3_bwd");
   }

@@ -1,0 +1,117 @@
+// Exact-2x bilinear up-sampling (align_corners = False) of [N*C, h, w] planes and its adjoint, for gfx950.
+//
+// Reference call site: the FPN top-down path of the pixel decoder,
+//   y = cur_feat + F.interpolate(y, size=cur_feat.shape[-2:], mode='bilinear', align_corners=False)
+// (mmdet/models/layers/pixel_decoder.py:456-460); every level doubles the resolution (H/16 -> H/8 -> H/4 -> H/2).
+// ATen's generic kernel needs 0.80 ms for the largest level ([8,256,256,256]); this is a pure HBM stream:
+// with scale 2 the source index of output o is  o/2 - 0.25  clamped at 0, i.e. fixed weights
+//   out[2i]   = 0.25 * in[max(i-1,0)] + 0.75 * in[i]        out[2i+1] = 0.75 * in[i] + 0.25 * in[min(i+1,w-1)]
+// in each dimension.  One thread produces 4 consecutive outputs of a row (one 16-byte store) from a 2 x 4 input patch.
+#include "s2f_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// torch computes  lambda = src - floor(src) and  (1-lambda)*a + lambda*b ; reproduce that association exactly.
+__device__ __forceinline__ void taps(int o, int in_size, int& i0, int& i1, float& l1) {
+  float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void up2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes,
+                                                       int h, int w) {
+  const int W = 2 * w, H = 2 * h;
+  const int64_t quads_per_row = W / 4;
+  const int64_t total = planes * H * quads_per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % quads_per_row);
+    const int64_t r = idx / quads_per_row;
+    const int oy = (int)(r % H);
+    const int64_t p = r / H;
+    int y0, y1;
+    float ly;
+    taps(oy, h, y0, y1, ly);
+    const float* r0 = x + (p * h + y0) * w;
+    const float* r1 = x + (p * h + y1) * w;
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      float lx;
+      taps(q * 4 + j, w, x0, x1, lx);
+      const float top = (1.f - lx) * r0[x0] + lx * r0[x1];
+      const float bot = (1.f - lx) * r1[x0] + lx * r1[x1];
+      out[j] = (1.f - ly) * top + ly * bot;
+    }
+    *reinterpret_cast<float4*>(y + (p * H + oy) * W + q * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// adjoint: gx[i] gathers from the (at most) 4 outputs per dimension that read it
+__device__ __forceinline__ float wgt(int o, int i, int in_size) {     // d out[o] / d in[i] along one dimension
+  int i0, i1;
+  float l1;
+  taps(o, in_size, i0, i1, l1);
+  float r = 0.f;
+  if (i0 == i) r += 1.f - l1;
+  if (i1 == i) r += l1;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void up2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t planes,
+                                                       int h, int w) {
+  const int W = 2 * w, H = 2 * h;
+  const int64_t total = planes * h * w;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(idx % w);
+    const int64_t r = idx / w;
+    const int iy = (int)(r % h);
+    const int64_t p = r / h;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 2; ++dy) {
+      const int oy = 2 * iy + dy;
+      if (oy < 0 || oy >= H) continue;
+      const float wy = wgt(oy, iy, h);
+      if (wy == 0.f) continue;
+      const float* row = gy + (p * H + oy) * W;
+      float s = 0.f;
+#pragma unroll
+      for (int dx = -1; dx <= 2; ++dx) {
+        const int ox = 2 * ix + dx;
+        if (ox < 0 || ox >= W) continue;
+        s += wgt(ox, ix, w) * row[ox];
+      }
+      acc += wy * s;
+    }
+    gx[idx] = acc;
+  }
+}
+
+inline int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream) {
+  S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_upsample2x_fwd: null pointer");
+  S2F_REQUIRE(planes > 0 && h > 0 && w > 0 && (w % 2) == 0, S2F_EINVAL, "s2f_upsample2x_fwd: need even input width");
+  S2F_REQUIRE(s2f_aligned16(y), S2F_EALIGN, "s2f_upsample2x_fwd: output must be 16-byte aligned");
+  hipLaunchKernelGGL(up2x_fwd_kernel, dim3(grid_for(planes * 2 * h * (2 * w / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                     planes, h, w);
+  return s2f_check_launch("s2f_upsample2x_fwd");
+}
+
+extern "C" int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream) {
+  S2F_REQUIRE(gy && gx, S2F_EINVAL, "s2f_upsample2x_bwd: null pointer");
+  S2F_REQUIRE(planes > 0 && h > 0 && w > 0, S2F_EINVAL, "s2f_upsample2x_bwd: bad shape");
+  hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, (hipStream_t)stream, gy, gx, planes, h, w);
+  return s2f_check_launch("s2f_upsample2x_bwd");
+}

@@ -408,3 +408,32 @@ class _SpikeGemm(torch.autograd.Function):
 
 def spike_gemm(x, w2d, bias=None):
     return _SpikeGemm.apply(x, w2d, bias)
+
+
+# ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
+class _Up2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, C, h, w = x.shape
+        y = torch.empty(N, C, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+        check(lib.s2f_upsample2x_fwd(_ptr(x), _ptr(y), N * C, h, w, _stream()), "s2f_upsample2x_fwd")
+        ctx.shape = (N, C, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, h, w = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(N, C, h, w, dtype=torch.float32, device=gy.device)
+        check(lib.s2f_upsample2x_bwd(_ptr(gy), _ptr(gx), N * C, h, w, _stream()), "s2f_upsample2x_bwd")
+        return gx
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False); the exact-2x case runs the HIP kernel."""
+    h, w = x.shape[-2:]
+    if tuple(size) == (2 * h, 2 * w) and w % 2 == 0:
+        return _Up2x.apply(x)
+    return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)

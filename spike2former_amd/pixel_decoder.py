@@ -4,6 +4,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .head_layers import DCNDetrTransformerEncoder, SinePositionalEncoding
+from . import ops
 from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
 from .neuron import Q_IFNode, Quant
@@ -80,7 +81,7 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         out = [y.reshape(t, bs, E, h, w)]
         for i in range(self.num_inputs - 2, -1, -1):
             x = self.lateral_convs_spike[i](feats[i]).flatten(0, 1)
-            up = F.interpolate(y, size=feats[i].shape[-2:], mode="bilinear", align_corners=False)
+            up = ops.upsample_bilinear(y, feats[i].shape[-2:])
             # cur + upsample(y), then the output neuron: residual add and neuron fused into the BatchNorm kernel
             _, s = conv_bn(self.lateral_convs[i], x, residual=up, lif=self.output_convs_spike[i])
             y = conv_bn(self.output_convs[i], s)[0]

@@ -391,3 +391,22 @@ def test_spike_gemm_terms_and_resplit(ops):
     assert errs[0] > 100 * errs[1] and errs[1] > 3 * errs[2] and errs[2] < 3e-5     # 8 / 16 / 24 mantissa bits (x3 sits on the fp32 accumulation floor)
     w.mul_(2.0)                                                                           # in-place update -> re-split
     assert (ops.spike_gemm(x, w).double() - 2 * ref).abs().max().item() < 6e-5
+
+
+# ----------------------------------------------------------------------------------------------- 2x bilinear up-sampling
+@pytest.mark.parametrize("N,C,h,w", [(2, 3, 4, 4), (1, 5, 7, 6), (2, 16, 32, 32), (1, 2, 1, 2)])
+def test_upsample2x_matches_interpolate(ops, N, C, h, w):
+    """Against F.interpolate on CPU (forward and adjoint through autograd): 2e-6 of the max -- ATen's CPU kernel
+    associates the four weighted taps differently, so the last bit may differ."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(h * 10 + w)
+    x = torch.randn(N, C, h, w, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = F.interpolate(xo, size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
+    gy = torch.randn(yo.shape, generator=g)
+    yo.backward(gy)
+    xc = x.cuda().requires_grad_(True)
+    yc = ops.upsample_bilinear(xc, (2 * h, 2 * w))
+    yc.backward(gy.cuda())
+    assert (yc.detach().cpu() - yo.detach()).abs().max().item() <= 2e-6 * yo.abs().max().item()
+    assert (xc.grad.cpu() - xo.grad).abs().max().item() <= 2e-6 * xo.grad.abs().max().item()
