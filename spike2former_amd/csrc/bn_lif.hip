@@ -43,49 +43,55 @@ __device__ __forceinline__ void block_atomic_add2(double a, double b, double* ds
   }
 }
 
-// grid (C, S): block (c, s) reduces rows n*C + c, columns [s*slice, (s+1)*slice).
+// grid (C, S): block (c, s) reduces rows n*C + c, columns [s*slice, (s+1)*slice).  The (row, 16-byte column) items of the
+// block are flattened and walked 4 at a time with all loads issued before the first use (the per-row loop of a naive
+// version serialises N dependent HBM round trips per thread).
+constexpr int kUnroll = 4;
+
 __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                           double* __restrict__ sums, int N, int C, int L, int slice) {
   const int c = blockIdx.x;
   const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
   const float b = bias ? bias[c] : 0.0f;
-  double s = 0.0, q = 0.0;
-  const bool vec = (L & 3) == 0;
-  for (int n = 0; n < N; ++n) {
-    const float* row = z + ((int64_t)n * C + c) * L;
-    float ps = 0.f, pq = 0.f;       // fp32 partials over <= slice/256*4 elements, folded into fp64 per row
-    if (vec) {
-      for (int l = l0 + threadIdx.x * 4; l < l1; l += kBlock * 4) {
-        const float4 v = *reinterpret_cast<const float4*>(row + l);
-        const float a0 = v.x + b, a1 = v.y + b, a2 = v.z + b, a3 = v.w + b;
-        ps += (a0 + a1) + (a2 + a3);
-        pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-      }
-    } else {
-      for (int l = l0 + threadIdx.x; l < l1; l += kBlock) {
-        const float a = row[l] + b;
-        ps += a;
-        pq += a * a;
+  const int per_row = (l1 - l0) >> 2;                    // float4 items per row (slice and L are multiples of 4)
+  const int total = N * per_row;
+  float ps = 0.f, pq = 0.f;                              // fp32 partials over <= total/256 * 4 elements per thread
+  for (int it = threadIdx.x; it < total; it += kBlock * kUnroll) {
+    float4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int id = it + u * kBlock;
+      if (id < total) {
+        const int n = id / per_row, q = id - n * per_row;
+        v[u] = *reinterpret_cast<const float4*>(z + ((int64_t)n * C + c) * L + l0 + q * 4);
+      } else {
+        v[u] = make_float4(-b, -b, -b, -b);              // contributes exactly zero after the bias add
       }
     }
-    s += (double)ps;
-    q += (double)pq;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float a0 = v[u].x + b, a1 = v[u].y + b, a2 = v[u].z + b, a3 = v[u].w + b;
+      ps += (a0 + a1) + (a2 + a3);
+      pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
   }
-  block_atomic_add2(s, q, sums + 2 * c);
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
 }
 
 // Per-channel statistics derived identically by every lane that needs them (deterministic: same inputs, same ops).
-// training: mean / biased variance from the fp64 sums of bn_stats_kernel; eval: the running statistics.
+// training: mean / biased variance from the fp64 sums of bn_stats_kernel -- fp64 multiplies by the precomputed 1/count,
+// no fp64 division (a wave-level fp64 divide per tile made the streaming kernel VALU-bound: 3.7 vs 5.3 TB/s);
+// eval: the running statistics.
 struct ChanStat {
   float mean, rstd, var;
 };
 __device__ __forceinline__ ChanStat chan_stat(const double* __restrict__ sums, const float* __restrict__ running_mean,
-                                              const float* __restrict__ running_var, int c, double count, float eps,
+                                              const float* __restrict__ running_var, int c, double inv_count, float eps,
                                               int training) {
   ChanStat r;
   if (training) {
-    const double m = sums[2 * c] / count;
-    double v = sums[2 * c + 1] / count - m * m;
+    const double m = sums[2 * c] * inv_count;
+    double v = sums[2 * c + 1] * inv_count - m * m;
     if (v < 0) v = 0;
     r.mean = (float)m;
     r.var = (float)v;
@@ -95,6 +101,12 @@ __device__ __forceinline__ ChanStat chan_stat(const double* __restrict__ sums, c
   }
   r.rstd = 1.0f / sqrtf(r.var + eps);
   return r;
+}
+
+// channel of the element at flat index `base` in [N, C, L]; 32-bit division when the tensor has < 2^32 elements
+__device__ __forceinline__ int channel_of(int64_t base, int C, int L, bool small) {
+  if (small) return (int)(((uint32_t)base / (uint32_t)L) % (uint32_t)C);
+  return (int)((base / L) % C);
 }
 
 struct Tile4 {
@@ -122,31 +134,41 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
                                                           float* __restrict__ y, float* __restrict__ v_out,
                                                           uint64_t* __restrict__ mask,
                                                           unsigned long long* __restrict__ stats, int64_t total, int C,
-                                                          int L, double count, float momentum, float eps, int training,
-                                                          float vth, float Df) {
+                                                          int L, double inv_count, float unbias, float momentum,
+                                                          float eps, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
   const int64_t ntiles = (total + 255) >> 8;
   uint32_t csum = 0, cnz = 0;
+  // Prologue: every workgroup derives (mean, rstd) of ALL channels once into LDS (C/256 fp64 evaluations per thread);
+  // the streaming loop then reads two LDS floats per lane.  Doing the fp64 arithmetic per tile instead kept the kernel
+  // VALU-bound at 3.7 TB/s.
+  extern __shared__ __attribute__((aligned(16))) float sstat[];      // [3][C]: mean, rstd, var
+  for (int c = threadIdx.x; c < C; c += kBlock) {
+    const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+    sstat[c] = cs.mean;
+    sstat[C + c] = cs.rstd;
+    sstat[2 * C + c] = cs.var;
+  }
+  __syncthreads();
+  const bool small = (total >> 32) == 0;
   for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * 256 + lane * 4;
     const bool ok = base < total;                       // total % 4 == 0 -> whole float4 valid or not
     bool inr[4] = {false, false, false, false};
     if (ok) {
-      const int c = (int)((base / L) % C);
+      const int c = channel_of(base, C, L, small);
       const float b = bias ? bias[c] : 0.f;
-      const ChanStat cs = chan_stat(sums, running_mean, running_var, c, count, eps, training);
-      const float mean = cs.mean, rstd = cs.rstd, g = gamma[c], be = beta[c];
+      const float mean = sstat[c], rstd = sstat[C + c], g = gamma[c], be = beta[c];
       if (base == (int64_t)c * L) {
         // the lane owning the first element of channel c (row n = 0) publishes the statistics for the backward pass
         // and performs the running-statistics update (torch.nn.BatchNorm: momentum, unbiased variance)
         stat[c] = mean;
         stat[C + c] = rstd;
         if (training && running_mean != nullptr) {
-          const float unbiased = count > 1 ? (float)((double)cs.var * (count / (count - 1.0))) : cs.var;
           running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * (sstat[2 * C + c] * unbias);
         }
         if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
       }
@@ -215,32 +237,45 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __re
   const int c = blockIdx.x;
   const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
   const float b = bias ? bias[c] : 0.0f, mean = stat[c], rstd = stat[C + c];
-  double s = 0.0, q = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const int64_t rbase = ((int64_t)n * C + c) * L;
-    float ps = 0.f, pq = 0.f;
-    for (int l = l0 + threadIdx.x * 4; l < l1; l += kBlock * 4) {
-      const int64_t e = rbase + l;
-      const Tile4 zv = ld4(z + e);
-      Tile4 a, bb, cc;
-      if (g_u) a = ld4(g_u + e);
-      if (g_y) bb = ld4(g_y + e);
-      if (g_v) cc = ld4(g_v + e);
-      const int64_t tile = e >> 8;
-      const int ln = (int)((e & 255) >> 2);
+  const int per_row = (l1 - l0) >> 2;
+  const int total = N * per_row;
+  float ps = 0.f, pq = 0.f;
+  for (int it = threadIdx.x; it < total; it += kBlock * kUnroll) {
+    int64_t e[kUnroll];
+    bool ok[kUnroll];
+    Tile4 zv[kUnroll], a[kUnroll], bb[kUnroll], cc[kUnroll];
+    uint64_t mw[kUnroll][4];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {                 // issue every load of the group first
+      const int id = it + u * kBlock;
+      ok[u] = id < total;
+      const int n = ok[u] ? id / per_row : 0, q = ok[u] ? id - n * per_row : 0;
+      e[u] = ((int64_t)n * C + c) * L + l0 + q * 4;
+      zv[u] = ld4(z + e[u]);
+      if (g_u) a[u] = ld4(g_u + e[u]);
+      if (g_y) bb[u] = ld4(g_y + e[u]);
+      if (g_v) cc[u] = ld4(g_v + e[u]);
+      if (mask) {
+        const int64_t tile = e[u] >> 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mw[u][j] = mask[tile * 4 + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (!ok[u]) continue;
+      const int ln = (int)((e[u] & 255) >> 2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool m = mask ? ((mask[tile * 4 + j] >> ln) & 1ull) : false;
-        const float gu = form_gu(g_u != nullptr, a.a[j], g_y != nullptr, bb.a[j], g_v != nullptr, cc.a[j], m, vth, Df);
-        const float xhat = ((zv.a[j] + b) - mean) * rstd;
+        const bool m = mask ? ((mw[u][j] >> ln) & 1ull) : false;
+        const float gu = form_gu(g_u != nullptr, a[u].a[j], g_y != nullptr, bb[u].a[j], g_v != nullptr, cc[u].a[j], m, vth, Df);
+        const float xhat = ((zv[u].a[j] + b) - mean) * rstd;
         ps += gu;
         pq += gu * xhat;
       }
     }
-    s += (double)ps;
-    q += (double)pq;
   }
-  block_atomic_add2(s, q, sums + 2 * c);
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
 }
 
 // train: gz = gamma * rstd * (gu - sum_gu/cnt - xhat * sum_gux/cnt) ;  eval: gz = gamma * rstd * gu ;  g_res = gu
@@ -253,18 +288,24 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
                                                               const double* __restrict__ sums, float* __restrict__ gz,
                                                               float* __restrict__ g_res, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int64_t total, int C, int L,
-                                                              double count, int training, float vth, float Df) {
+                                                              double inv_count, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
   const int64_t ntiles = (total + 255) >> 8;
+  extern __shared__ __attribute__((aligned(16))) float sstat[];      // [2][C]: mean(gu), mean(gu * xhat)
+  for (int c = threadIdx.x; c < C; c += kBlock) {
+    sstat[c] = training ? (float)(sums[2 * c] * inv_count) : 0.f;
+    sstat[C + c] = training ? (float)(sums[2 * c + 1] * inv_count) : 0.f;
+  }
+  __syncthreads();
+  const bool small = (total >> 32) == 0;
   for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * 256 + lane * 4;
     if (base >= total) continue;
-    const int c = (int)((base / L) % C);
+    const int c = channel_of(base, C, L, small);
     const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
-    const float m1 = training ? (float)(sums[2 * c] / count) : 0.f;
-    const float m2 = training ? (float)(sums[2 * c + 1] / count) : 0.f;
+    const float m1 = sstat[c], m2 = sstat[C + c];
     if (base == (int64_t)c * L) {          // dbeta = sum(gu), dgamma = sum(gu * xhat)
       dbeta[c] = (float)sums[2 * c];
       dgamma[c] = (float)sums[2 * c + 1];
@@ -296,7 +337,7 @@ inline int pick_slices(int C, int L, int& slice) {
 
 inline int grid_flat(int64_t total) {
   int64_t tiles = (total + 255) >> 8;
-  int64_t blocks = (tiles + kWaves - 1) / kWaves;
+  int64_t blocks = (tiles + 4 * kWaves - 1) / (4 * kWaves);      // >= 4 tiles per wave amortise the per-block prologue
   if (blocks > 256 * 8) blocks = 256 * 8;
   return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -305,7 +346,8 @@ int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
   S2F_REQUIRE(N > 0 && C > 0 && L > 0, S2F_EINVAL, "%s: bad shape N=%lld C=%lld L=%lld", who, (long long)N, (long long)C,
               (long long)L);
   S2F_REQUIRE((L & 3) == 0, S2F_EINVAL, "%s: L=%lld must be a multiple of 4", who, (long long)L);
-  S2F_REQUIRE(N * C * L < (1ll << 40) && L < (1ll << 31) && C < (1 << 24) && N < (1ll << 31), S2F_EINVAL, "%s: shape too large", who);
+  S2F_REQUIRE(N * C * L < (1ll << 40) && L < (1ll << 31) && C <= 5120 && N < (1ll << 31), S2F_EINVAL,
+              "%s: shape too large (C <= 5120: per-channel statistics are staged in 60 KiB of LDS)", who);
   return S2F_OK;
 }
 
@@ -344,10 +386,12 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   auto* nbt = reinterpret_cast<long long*>(num_batches_tracked);
   const dim3 grid(grid_flat(total)), block(kBlock);
   const double count = (double)N * (double)L;
+  const double inv_count = 1.0 / count;
+  const float unbias = count > 1 ? (float)(count / (count - 1.0)) : 1.0f;
 #define S2F_BN_APPLY(LIFV, HASV)                                                                                        \
-  hipLaunchKernelGGL((bn_apply_kernel<LIFV, HASV>), grid, block, 0, s, z, conv_bias, sums, stat_out, running_mean,      \
+  hipLaunchKernelGGL((bn_apply_kernel<LIFV, HASV>), grid, block, 3 * C * sizeof(float), s, z, conv_bias, sums, stat_out, running_mean, \
                      running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L,   \
-                     count, momentum, eps, training, vth, (float)D)
+                     inv_count, unbias, momentum, eps, training, vth, (float)D)
   if (y == nullptr)
     S2F_BN_APPLY(false, false);
   else if (v_in == nullptr)
@@ -373,8 +417,8 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
   const int S = pick_slices((int)C, (int)L, slice);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,
                      mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 0, s, z, conv_bias, stat, gamma, g_u, g_y,
-                     g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L, (double)N * (double)L,
-                     training, vth, (float)D);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z, conv_bias, stat, gamma, g_u, g_y,
+                     g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L,
+                     1.0 / ((double)N * (double)L), training, vth, (float)D);
   return s2f_check_launch("s2f_bn_act_bwd");
 }
