@@ -339,6 +339,7 @@ class OracleNet:
         self.firing: "OrderedDict[str, float]" = OrderedDict()
         self.keep_membrane_graph = False
         self.tap = None      # optional callable(name, tensor) for intermediate captures
+        self.stages = None   # optional dict: stage name -> (input, output) of every backbone stage / encoder layer
 
     def reset(self):
         self.membranes.clear()
@@ -437,22 +438,29 @@ class OracleNet:
         x = x + self._attn(n + ".attn", x)
         return x + self._mlp(n + ".mlp", x)
 
+    def _stage(self, name, fn, x, *a):
+        y = fn(name, x, *a)
+        if self.stages is not None:
+            self.stages[name] = (x.detach(), y.detach())
+        return y
+
     def backbone(self, img):                             # Spiking_vit_MetaFormer.forward_features :614-651
         b = "backbone."
+        S = self._stage
         x = img.unsqueeze(0).repeat(self.cfg.T, 1, 1, 1, 1)
-        x = self._down(b + "downsample1_1", x, 7, 2, 3, True)
-        x = self._convblock(b + "ConvBlock1_1.0", x); x1 = x
-        x = self._down(b + "downsample1_2", x, 3, 2, 1, False)
-        x = self._convblock(b + "ConvBlock1_2.0", x); x2 = x
-        x = self._down(b + "downsample2", x, 3, 2, 1, False)
-        x = self._convblock(b + "ConvBlock2_1.0", x)
-        x = self._convblock(b + "ConvBlock2_2.0", x); x3 = x
-        x = self._down(b + "downsample3", x, 3, 2, 1, False)
+        x = S(b + "downsample1_1", self._down, x, 7, 2, 3, True)
+        x = S(b + "ConvBlock1_1.0", self._convblock, x); x1 = x
+        x = S(b + "downsample1_2", self._down, x, 3, 2, 1, False)
+        x = S(b + "ConvBlock1_2.0", self._convblock, x); x2 = x
+        x = S(b + "downsample2", self._down, x, 3, 2, 1, False)
+        x = S(b + "ConvBlock2_1.0", self._convblock, x)
+        x = S(b + "ConvBlock2_2.0", self._convblock, x); x3 = x
+        x = S(b + "downsample3", self._down, x, 3, 2, 1, False)
         for i in range(6):
-            x = self._block(b + f"block3.{i}", x)
-        x = self._down(b + "downsample4", x, 3, 1, 1, False)
+            x = S(b + f"block3.{i}", self._block, x)
+        x = S(b + "downsample4", self._down, x, 3, 1, 1, False)
         for i in range(2):
-            x = self._block(b + f"block4.{i}", x)
+            x = S(b + f"block4.{i}", self._block, x)
         return [x1, x2, x3, x]
 
     # ---- head blocks
@@ -507,7 +515,7 @@ class OracleNet:
         y = self.bn(n + ".encoder_in_proj.1", self.conv2d(n + ".encoder_in_proj.0", y.flatten(0, 1)))
         q = y.reshape(t, bs, Fc, h, w).permute(0, 1, 3, 4, 2)
         for i in range(self.cfg.pd_layers):
-            q = self._enc_layer(n + f".encoder.layers.{i}", q)
+            q = self._stage(n + f".encoder.layers.{i}", self._enc_layer, q)
         memory = q.permute(0, 1, 4, 2, 3).contiguous()
         memory = self.lif(n + ".encoder_out_proj_spike", memory)
         y = self.bn(n + ".encoder_out_proj.1", self.conv2d(n + ".encoder_out_proj.0", memory.flatten(0, 1)))
