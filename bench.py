@@ -147,7 +147,14 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"},
         }
         if events:
-            # per-launch HIP events recorded on the launch stream inside the timed region (ops.KERNEL_EVENTS)
+            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate runs, gfx950 corrections applied there); null when no such profile exists for a kernel
+            traffic = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+            except (OSError, KeyError, ValueError):
+                pass
             agg = {}
             for name, nbytes, e0, e1 in events:
                 a = agg.setdefault(name, [0, 0.0, 0])
@@ -158,7 +165,8 @@ def main():
                     nbytes, secs, launches = agg[name]
                     gbs = nbytes / secs / 1e9
                     out[key] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                "traffic": traffic.get(name) if args.workload == "C2" else None,
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
                                 "algorithmic_bytes_per_launch": nbytes // launches}
             out["neuron_kernels_ms_per_step"] = round(sum(a[1] for a in agg.values()) / 2 * 1e3, 3)
