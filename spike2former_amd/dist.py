@@ -15,8 +15,12 @@ def init_process_group(backend=None):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; S2F_DIST_BACKEND=gloo lets two ranks share one GPU when testing the N > 1 code path
+        backend = os.environ.get("S2F_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
+        torch.cuda.set_device(local)
+    elif torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -153,3 +153,16 @@ def test_predict_and_keep_membrane_equivalence(env):
             outs.append(model(img, mode="predict"))
     s2f.set_keep_membrane(model, True)
     assert outs[0].shape == (cfg.B, cfg.num_classes, cfg.H, cfg.W) and torch.equal(outs[0], outs[1])
+
+
+def test_cal_firing_num_tool(tmp_path):
+    """The firing tool's output contract (cal_firing_num.py:272-285): JSON {"t0": {name: rate}} + fr_rate.csv with one
+    column `T`, one row per called neuron in named_modules() order; state carried across images changes the table."""
+    from spike2former_amd.tools import cal_firing_num
+    res = cal_firing_num.main(["--workload", "C1_64", "--test-num", "3", "--out-dir", str(tmp_path)])
+    rows = open(tmp_path / "fr_rate.csv").read().strip().splitlines()
+    assert rows[0] == ",T" and len(rows) == 1 + 150 and len(res["t0"]) == 150
+    assert rows[1].split(",")[0] == "backbone.ConvBlock1_1.0.Conv.spike1"
+    assert all(0.0 <= v <= 8.0 for v in res["t0"].values())
+    res2 = cal_firing_num.main(["--workload", "C1_64", "--test-num", "3", "--out-dir", str(tmp_path), "--reset-between-images"])
+    assert max(abs(res["t0"][k] - res2["t0"][k]) for k in res["t0"]) > 1e-3
