@@ -75,10 +75,11 @@ class MaskFormerHead(nn.Module):
         pass
 
     def _pos(self, bs, h, w, device):
+        """Sine position embedding of an all-valid map, channel-major [bs, C, h*w] (data independent -> cached)."""
         key = (bs, h, w, str(device))
-        if key not in self._pe_cache:        # all-valid mask -> data independent
+        if key not in self._pe_cache:
             m = torch.zeros((bs, h, w), dtype=torch.bool, device=device)
-            self._pe_cache[key] = self.decoder_pe(m).flatten(2).permute(0, 2, 1).contiguous()
+            self._pe_cache[key] = self.decoder_pe(m).flatten(2).contiguous()
         return self._pe_cache[key]
 
     def forward(self, x, batch_data_samples=None):
@@ -87,18 +88,21 @@ class MaskFormerHead(nn.Module):
         t, bs = memory.shape[:2]
         query_feat = self.query_feat.weight.unsqueeze(0).repeat((t, bs, 1, 1))
         query_embed = self.query_embed.weight.unsqueeze(0).repeat(bs, 1, 1)
-        dec_in, dec_pos = [], []
+        # Keys / values stay in the channel-major layout the pixel decoder produced ([t, b, C, h*w]); the reference
+        # transposes them to token-major and back around every projection (maskformer_head.py:535-540).  key + key_pos
+        # depends only on the level, so it is formed once per level instead of once per decoder layer.
+        dec_in, dec_key = [], []
         for i in range(self.num_transformer_feat_level):
             d = self.decoder_input_projs[i](msm[i])
-            d = d.flatten(3).permute(0, 1, 3, 2) + self.level_embed.weight[i].view(1, 1, -1)
+            d = d.flatten(3) + self.level_embed.weight[i].view(1, 1, -1, 1)
             dec_in.append(d)
-            dec_pos.append(self._pos(bs, msm[i].shape[-2], msm[i].shape[-1], d.device))
+            dec_key.append(d + self._pos(bs, msm[i].shape[-2], msm[i].shape[-1], d.device))
         out_dec = [query_feat]
         for i in range(self.num_transformer_decoder_layers):
             lv = i % self.num_transformer_feat_level
             query_feat = self.transformer_decoder.layers[i](
-                query=query_feat, key=dec_in[lv], value=dec_in[lv], query_pos=query_embed, key_pos=dec_pos[lv],
-                cross_attn_mask=None, key_padding_mask=None)
+                query=query_feat, key=dec_key[lv], value=dec_in[lv], query_pos=query_embed, key_pos=None,
+                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True)
             out_dec.append(query_feat)
         out_dec = torch.stack(out_dec)
         ln, t, bs, nq, C = out_dec.shape
