@@ -117,6 +117,11 @@ int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, 
 int s2f_split_bf16x3(const float* w, uint16_t* w_split, int M, int K, int Mpad, int Kpad, void* stream);
 int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int N,
                        int K, int Mpad, int Kpad, int terms, void* stream);
+/* Weight gradient of the same convolution:  dW[m][k] = sum_b sum_l dY[b][m][l] * X[b][k][l]   (dY [batch, M, L],
+ * X [batch, K, L] spikes, dW [M, K] overwritten).  X is exact in bf16; dY is split on the fly into hi + mid + lo bf16
+ * terms: three MFMA passes, exact products, fp32 accumulation (split-K partial tiles are combined with fp32 atomics, so
+ * the result is reproducible to fp32 round-off, not bit for bit).  L % 4 == 0. */
+int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path

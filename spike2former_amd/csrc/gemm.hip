@@ -194,6 +194,113 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the spike GEMM:  dW[m][k] = sum_b sum_l dY[b][m][l] * X[b][k][l]      (dY: [B, M, L], X: [B, K, L])
+// Both operands are contraction-contiguous (L is the fast axis of the channel-major activations), so the MFMA fragments
+// are plain k-contiguous LDS rows -- no transposition.  X holds spikes (exact in bf16, one term); dY is a general fp32
+// gradient and is split on the fly into hi + mid + lo bf16 terms (24 mantissa bits) while it is staged: three MFMA passes
+// with exact products and fp32 accumulation, i.e. the accuracy of an fp32 GEMM.  The contraction is B*L long (524 288 at
+// the 256x256 maps) while the output is only M x K, so it is split over `splits` workgroups per output tile that add
+// their partial tiles into the zero-initialised dW with fp32 atomics.
+// Block = 4 wavefronts (2 x 2), output tile 128 x 128, contraction step 32, register prefetch of the next step.
+__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+  h = f2bf(v);
+  const float r1 = v - bf2f(h);
+  m = f2bf(r1);
+  l = f2bf(r1 - bf2f(m));
+}
+
+__global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                            float* __restrict__ dW, int B, int M, int K, int L,
+                                                            int steps_per_split, int k_tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][128][LDR];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[128][LDR];
+  const int tile = blockIdx.x;
+  const int m0 = (tile / k_tiles) * 128, k0 = (tile % k_tiles) * 128;
+  const int lsteps = (L + BK - 1) / BK;
+  const int total_steps = B * lsteps;
+  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_end = min(total_steps, s_begin + steps_per_split);
+  if (s_begin >= s_end) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[4], breg[4];
+  // chunk c = tid + h*256 (h = 0..3): row = c >> 3 (0..127), 16-byte column lq = c & 7 (4 floats each, 32 per row)
+  auto fetch = [&](int step, f32x4 (&a)[4], f32x4 (&bq)[4]) {
+    const int b = step / lsteps, l0 = (step - b * lsteps) * BK;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int c = tid + h * 256;
+      const int row = c >> 3, l = l0 + (c & 7) * 4;
+      const bool lok = l < L;                                       // L % 4 == 0: the whole float4 is valid or not
+      a[h] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + ((int64_t)b * K + k0 + row) * L + l)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(s_begin, areg, breg);
+  for (int step = s_begin; step < s_end; ++step) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int c = tid + h * 256;
+      const int row = c >> 3, col = (c & 7) * 4;
+      u16x4 ph, pm, pl, pb;
+      unsigned short x0, x1, x2;
+      split3(areg[h].x, x0, x1, x2); ph[0] = x0; pm[0] = x1; pl[0] = x2;
+      split3(areg[h].y, x0, x1, x2); ph[1] = x0; pm[1] = x1; pl[1] = x2;
+      split3(areg[h].z, x0, x1, x2); ph[2] = x0; pm[2] = x1; pl[2] = x2;
+      split3(areg[h].w, x0, x1, x2); ph[3] = x0; pm[3] = x1; pl[3] = x2;
+      *reinterpret_cast<u16x4*>(&As[0][row][col]) = ph;
+      *reinterpret_cast<u16x4*>(&As[1][row][col]) = pm;
+      *reinterpret_cast<u16x4*>(&As[2][row][col]) = pl;
+      pb[0] = f2bf(breg[h].x); pb[1] = f2bf(breg[h].y); pb[2] = f2bf(breg[h].z); pb[3] = f2bf(breg[h].w);
+      *reinterpret_cast<u16x4*>(&Bs[row][col]) = pb;
+    }
+    __syncthreads();
+    if (step + 1 < s_end) fetch(step + 1, areg, breg);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kof = ks * 16 + 8 * (lane >> 5);
+      bf16x8 bfrag[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * 64 + j * 32 + (lane & 31)][kof]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = k0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
+      }
+    }
+}
+
 }  // namespace
 
 extern "C" int s2f_split_bf16x3(const float* w, uint16_t* out, int M, int K, int Mpad, int Kpad, void* stream) {
@@ -249,4 +356,26 @@ extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const
 #undef S2F_LAUNCH_T
 #undef S2F_LAUNCH
   return s2f_check_launch("s2f_spike_gemm_fwd");
+}
+
+extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, void* stream) {
+  S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw: null pointer");
+  S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
+              "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
+  S2F_REQUIRE(s2f_aligned16(dY) && s2f_aligned16(X), S2F_EALIGN, "s2f_spike_gemm_dw: dY / X must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess) return s2f_check_launch("s2f_spike_gemm_dw memset");
+  const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
+  const int total_steps = batch * ((L + BK - 1) / BK);
+  // ~1024 workgroups in flight (4 per CU at 40 KiB of LDS each), at least 8 contraction steps per workgroup
+  int splits = 1024 / (m_tiles * k_tiles);
+  if (splits < 1) splits = 1;
+  if (splits > (total_steps + 7) / 8) splits = (total_steps + 7) / 8;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  const int steps_per_split = (total_steps + splits - 1) / splits;
+  splits = (total_steps + steps_per_split - 1) / steps_per_split;
+  hipLaunchKernelGGL(spike_gemm_dw_kernel, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K, L,
+                     steps_per_split, k_tiles);
+  return s2f_check_launch("s2f_spike_gemm_dw");
 }

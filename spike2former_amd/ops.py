@@ -354,6 +354,7 @@ def dwconv(x, w, pad, border=None):
 _SPLIT_CACHE = {}
 SPIKE_GEMM_TERMS = 3          # number of bf16 weight terms (3 == fp32-equivalent)
 SPIKE_GEMM_ENABLED = True
+SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
 
 
@@ -400,7 +401,12 @@ class _SpikeGemm(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.bmm(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
         if ctx.needs_input_grad[1]:
-            gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
+            if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 64:     # 128-row tiles: M <= 32 wastes 3/4 of the MFMAs
+                M, K = w2d.shape
+                gw = torch.empty(M, K, dtype=torch.float32, device=x.device)
+                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw), B, M, K, x.shape[2], _stream()), "s2f_spike_gemm_dw")
+            else:
+                gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2))
         return gx, gw, gb

@@ -410,3 +410,21 @@ def test_upsample2x_matches_interpolate(ops, N, C, h, w):
     yc.backward(gy.cuda())
     assert (yc.detach().cpu() - yo.detach()).abs().max().item() <= 2e-6 * yo.abs().max().item()
     assert (xc.grad.cpu() - xo.grad).abs().max().item() <= 2e-6 * xo.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("B,M,K,L", [(2, 256, 256, 1024), (1, 32, 288, 4096), (3, 360, 360, 100), (2, 151, 100, 36),
+                                     (8, 128, 64, 4096), (1, 576, 256, 1024)])
+def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
+    """dW = sum_b dY[b] X[b]^T on the bf16 matrix cores (dY split hi+mid+lo, X spikes): error vs fp64 <= 3e-6 of
+    sum|dY||X| -- fp32-GEMM class (split-K partials are combined with fp32 atomics)."""
+    from spike2former_amd._lib import lib
+    g = torch.Generator().manual_seed(M * 3 + L)
+    gy = torch.randn(B, M, L, generator=g) * torch.rand(B, M, 1, generator=g) * 10
+    x = torch.clamp(torch.round(torch.randn(B, K, L, generator=g) + 0.7), 0, 8) / 8
+    ref = torch.einsum("bml,bkl->mk", gy.double(), x.double())
+    scale = torch.einsum("bml,bkl->mk", gy.abs().double(), x.abs().double()).max().item()
+    gyc, xc = gy.cuda(), x.cuda()
+    out = torch.full((M, K), float("nan"), device="cuda")
+    assert lib.s2f_spike_gemm_dw(gyc.data_ptr(), xc.data_ptr(), out.data_ptr(), B, M, K, L, None) == 0
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 3e-6 * scale, (err, scale)
