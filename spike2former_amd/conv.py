@@ -63,6 +63,8 @@ class Conv2d(nn.Conv2d):
         kh, kw = self.kernel_size
         if kh == 1 and kw == 1 and self.stride == (1, 1) and self.padding == (0, 0):
             return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias, self.spike_input).view(N, M, H, W)
+        if (self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.dilation == (1, 1)):
+            return ops.conv_dense(x, self.weight, bias, self.stride[0], self.padding[0], self.spike_input)
         Ho = (H + 2 * self.padding[0] - self.dilation[0] * (kh - 1) - 1) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - self.dilation[1] * (kw - 1) - 1) // self.stride[1] + 1
         cols = F.unfold(x, (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]

@@ -443,3 +443,70 @@ def upsample_bilinear(x, size):
     if tuple(size) == (2 * h, 2 * w) and w % 2 == 0:
         return _Up2x.apply(x)
     return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+
+
+# ------------------------------------------------------------------------------------------------ dense k x k convolution
+class _ConvDense(torch.autograd.Function):
+    """Dense k x k Conv2d lowered to GEMMs (MIOpen is not usable on this image, see conv.py).
+
+    forward : cols = im2col(x) ; y = W2d @ cols                       (spike GEMM when x is a neuron output)
+    dW      : dY @ cols^T                                              (bf16-MFMA batch-reduce kernel for spike inputs)
+    dX      : the cheaper of two equivalent lowerings --
+                M >= C : dcols = W2d^T @ dY ; dX = col2im(dcols)       (the adjoint of im2col; C*k*k rows)
+                M <  C : dX = flip(W)^T (*) dY = W_t2d @ im2col(dY)     (transposed convolution; M*k*k rows)
+              the second form moves k*k*M instead of k*k*C rows through HBM and needs no col2im scatter; it applies to
+              stride 1 (MS_ConvBlock.conv2: 4C -> C, sdtv2.py:202-204)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, spike_input):
+        _need_cuda(x, weight, bias)
+        N, C, H, W = x.shape
+        M, _, kh, kw = weight.shape
+        Ho = (H + 2 * padding - kh) // stride + 1
+        Wo = (W + 2 * padding - kw) // stride + 1
+        cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
+        w2d = weight.view(M, -1)
+        use_mfma = spike_input and SPIKE_GEMM_ENABLED and cols.shape[2] % 4 == 0
+        if use_mfma:
+            ws = split_weight(w2d)
+            y = torch.empty(N, M, Ho * Wo, dtype=torch.float32, device=x.device)
+            check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, Ho * Wo, cols.shape[1],
+                                         ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
+        else:
+            y = torch.bmm(w2d.unsqueeze(0).expand(N, -1, -1), cols)
+            if bias is not None:
+                y = y + bias.view(1, -1, 1)
+        ctx.save_for_backward(cols, weight)
+        ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, use_mfma)
+        return y.view(N, M, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, gy):
+        cols, weight = ctx.saved_tensors
+        N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, has_bias, use_mfma = ctx.geo
+        gy = gy.contiguous().view(N, M, Ho * Wo)
+        w2d = weight.view(M, -1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
+                wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
+                gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)
+                gx = torch.bmm(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
+            else:
+                dcols = torch.bmm(w2d.t().unsqueeze(0).expand(N, -1, -1), gy)
+                gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
+        if ctx.needs_input_grad[1]:
+            K = w2d.shape[1]
+            if use_mfma and SPIKE_GEMM_DW and M >= 64:
+                gw = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw), N, M, K, Ho * Wo, _stream()), "s2f_spike_gemm_dw")
+            else:
+                gw = torch.bmm(gy, cols.transpose(1, 2)).sum(0)
+            gw = gw.view_as(weight)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2))
+        return gx, gw, gb, None, None, None
+
+
+def conv_dense(x, weight, bias, stride, padding, spike_input):
+    return _ConvDense.apply(x, weight, bias, stride, padding, spike_input)

@@ -428,3 +428,25 @@ def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
     assert lib.s2f_spike_gemm_dw(gyc.data_ptr(), xc.data_ptr(), out.data_ptr(), B, M, K, L, None) == 0
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 3e-6 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("N,C,M,H,W,k,s,p,spike", [(2, 16, 64, 12, 16, 3, 1, 1, True), (2, 64, 16, 12, 16, 3, 1, 1, True),
+                                                     (1, 8, 24, 9, 8, 3, 2, 1, True), (2, 3, 16, 16, 16, 7, 2, 3, False),
+                                                     (1, 128, 32, 8, 8, 3, 1, 1, True)])
+def test_conv_dense_vs_aten_cpu(ops, N, C, M, H, W, k, s, p, spike):
+    """The GEMM lowerings of the dense convolution (incl. the transposed-convolution form of dX used when M < C) against
+    F.conv2d on CPU: 2e-5 of the max for outputs and all three gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C * 7 + M)
+    x = (torch.randint(0, 9, (N, C, H, W), generator=g).float() / 8) if spike else torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(M, C, k, k, generator=g) * (C * k * k) ** -0.5
+    b = torch.randn(M, generator=g)
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yo = F.conv2d(xo, wo, bo, s, p)
+    gy = torch.randn(yo.shape, generator=g)
+    yo.backward(gy)
+    xc, wc, bc = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    yc = ops.conv_dense(xc, wc, bc, s, p, spike)
+    yc.backward(gy.cuda())
+    for a, r in ((yc, yo), (xc.grad, xo.grad), (wc.grad, wo.grad), (bc.grad, bo.grad)):
+        assert (a.detach().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.abs().max().item()

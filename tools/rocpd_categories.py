@@ -8,6 +8,9 @@ import sys
 
 def cat(name):
     if name.startswith('Cijk'): return 'GEMM (rocBLAS/Tensile)'
+    if 'spike_gemm_dw' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
+    if 'spike_gemm' in name or 'split_bf16' in name: return 'spike GEMM fwd, bf16 MFMA (ours)'
+    if 'up2x' in name: return 'upsample (ours)'
     if 'dcn_' in name: return 'dcn (ours)'
     if 'dw_' in name: return 'dwconv (ours)'
     if 'bn_' in name: return 'bn(+lif) fused (ours)'
