@@ -159,8 +159,9 @@ int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, int heads, 
 int s2f_dcnv3_fwd(const float* input, const float* offset, const float* mask, float* output, int N, int H, int W,
                   int G, int Cg, int Kh, int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                   float offset_scale, void* stream);
-/* grad_input must be zero-filled by the caller (the large-map fallback scatter-adds into it with global atomics; the
- * LDS-resident path used when 2*H*W*Cg + Ho*Wo*Cg floats fit in 160 KiB overwrites it). */
+/* All three gradients are fully overwritten (grad_input need not be zeroed).  When one (n, group) slice fits in the
+ * CU's LDS (12*H*W*Cg bytes + a staging chunk <= 160 KiB) the scatter-add into grad_input runs in LDS in 64-bit fixed
+ * point (order-independent, see csrc/dcnv3.hip); larger maps fall back to fp32 global atomics after a memset. */
 int s2f_dcnv3_bwd(const float* input, const float* offset, const float* mask, const float* grad_output,
                   float* grad_input, float* grad_offset, float* grad_mask, int N, int H, int W, int G, int Cg, int Kh,
                   int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float offset_scale,

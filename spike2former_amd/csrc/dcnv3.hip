@@ -169,69 +169,136 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(const float* __restrict__ 
 
 
 // Backward with the whole (n, group) slice resident in LDS: one workgroup owns grad_input[n, :, :, g*Cg:(g+1)*Cg]
-// (H*W*Cg floats, 32 KiB at the C2 geometry), so the scatter-add runs on LDS atomics and the slice is written back
-// with plain stores -- no global atomics, no pre-zeroed grad_input.  The input slice and the grad_output slice are
-// staged in LDS as well, so every bilinear corner is an LDS read.  Work item = (output pixel, tap).
+// (H*W*Cg values), so the scatter-add runs in LDS and the slice is written back with plain stores -- no global atomics,
+// no pre-zeroed grad_input.  The input slice is staged in LDS as well, so every bilinear corner is an LDS read.
+//
+// The scatter-add accumulates in 64-bit FIXED POINT with ds_add_u64.  Measured on MI355X (tools/probe_dcn.py, C2 geometry,
+// 75 M lane-adds per call): ds_add_f32 retires ~0.5 lane-adds per cycle per CU (260 us of a 420 us call, whatever the
+// address pattern), the integer LDS atomics run at full LDS rate (< 10 us).  Each workgroup scales its contributions by a
+// power of two chosen from its own max|grad_output| * max|mask| (bilinear weights are <= 1) so that the largest possible
+// sum of 4*K*Ho*Wo contributions still fits in 62 bits: every contribution is then rounded at <= 2^-(acc_bits) of that
+// bound -- finer than one fp32 ulp of any partial sum an fp32 atomic would have formed -- and the result no longer depends
+// on the order of the adds (the reference's CUDA op, dcnv3_im2col_cuda.cuh:278-839, uses fp32 atomicAdd in global memory).
+constexpr int kChunk = 256;   // output pixels whose offsets / mask / grad_output are staged in LDS at a time
+
 __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ off,
                                                           const float* __restrict__ msk, const float* __restrict__ gout,
                                                           float* __restrict__ gin, float* __restrict__ goff,
-                                                          float* __restrict__ gmsk, Geom g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+                                                          float* __restrict__ gmsk, Geom g, int acc_bits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float s_red[2][16];
   const int n = blockIdx.x / g.G, gi = blockIdx.x % g.G;
   const int Cg = g.Cg, C = g.G * g.Cg, P = g.Kh * g.Kw;
   const int npix_in = g.H * g.W, npix_out = g.Ho * g.Wo;
-  float* s_in = smem;                       // [H*W][Cg]
-  float* s_gin = s_in + npix_in * Cg;       // [H*W][Cg]
-  float* s_go = s_gin + npix_in * Cg;       // [Ho*Wo][Cg]
+  unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(smem_raw);      // [H*W][Cg] fixed-point grad_input
+  float* s_in = reinterpret_cast<float*>(s_acc + (size_t)npix_in * Cg);             // [H*W][Cg]
+  float* s_off = s_in + npix_in * Cg;       // [kChunk][P*2]
+  float* s_msk = s_off + kChunk * P * 2;    // [kChunk][P]
+  float* s_go = s_msk + kChunk * P;         // [kChunk][Cg]
   const float* inb = in + (int64_t)n * npix_in * C + gi * Cg;
   const float* gob = gout + (int64_t)n * npix_out * C + gi * Cg;
   for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
     s_in[e] = inb[(int64_t)p * C + c];
-    s_gin[e] = 0.f;
+    s_acc[e] = 0ull;
   }
-  for (int e = threadIdx.x; e < npix_out * Cg; e += blockDim.x) {
-    const int p = e / Cg, c = e % Cg;
-    s_go[e] = gob[(int64_t)p * C + c];
+  // scale of this slice: max|grad_output| * max|mask| bounds every contribution
+  float mg = 0.f, mm = 0.f;
+  for (int e = threadIdx.x; e < npix_out * Cg; e += blockDim.x) mg = fmaxf(mg, fabsf(gob[(int64_t)(e / Cg) * C + e % Cg]));
+  for (int e = threadIdx.x; e < npix_out * P; e += blockDim.x)
+    mm = fmaxf(mm, fabsf(msk[(((int64_t)n * npix_out + e / P) * g.G + gi) * P + e % P]));
+  for (int o = 32; o > 0; o >>= 1) {
+    mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+    mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_red[0][threadIdx.x >> 6] = mg;
+    s_red[1][threadIdx.x >> 6] = mm;
   }
   __syncthreads();
-  const int items = npix_out * P;
-  for (int it = threadIdx.x; it < items; it += blockDim.x) {
-    const int pix = it / P, k = it % P;
-    const int ho = pix / g.Wo, wo = pix % g.Wo;
-    const int64_t gpix = (int64_t)n * npix_out + pix;
-    const int64_t ob = (gpix * g.G + gi) * P + k;
-    const float offx = off[ob * 2], offy = off[ob * 2 + 1];
-    const float m = msk[ob];
-    const Tap t = make_tap(g, ho, wo, k / g.Kh, k % g.Kh, offx, offy);
-    const float w00 = (1.f - t.ly) * (1.f - t.lx), w01 = (1.f - t.ly) * t.lx, w10 = t.ly * (1.f - t.lx),
-                w11 = t.ly * t.lx;
-    const bool b00 = t.vy0 && t.vx0, b01 = t.vy0 && t.vx1, b10 = t.vy1 && t.vx0, b11 = t.vy1 && t.vx1;
-    const int o00 = (t.y0 * g.W + t.x0) * Cg;
-    const int o01 = o00 + Cg, o10 = o00 + g.W * Cg, o11 = o10 + Cg;
-    float am = 0.f, ax = 0.f, ay = 0.f;
-    for (int c = 0; c < Cg; ++c) {
-      const float gv = s_go[pix * Cg + c];
-      const float a = b00 ? s_in[o00 + c] : 0.f, b = b01 ? s_in[o01 + c] : 0.f;
-      const float cc = b10 ? s_in[o10 + c] : 0.f, d = b11 ? s_in[o11 + c] : 0.f;
-      am += gv * (a * w00 + b * w01 + cc * w10 + d * w11);
-      ax += gv * ((1.f - t.ly) * (b - a) + t.ly * (d - cc));
-      ay += gv * ((1.f - t.lx) * (cc - a) + t.lx * (d - b));
-      const float gm = gv * m;
-      if (b00) atomicAdd(&s_gin[o00 + c], gm * w00);
-      if (b01) atomicAdd(&s_gin[o01 + c], gm * w01);
-      if (b10) atomicAdd(&s_gin[o10 + c], gm * w10);
-      if (b11) atomicAdd(&s_gin[o11 + c], gm * w11);
+  mg = 0.f, mm = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+    mg = fmaxf(mg, s_red[0][w]);
+    mm = fmaxf(mm, s_red[1][w]);
+  }
+  // NaN/Inf gradients: fmaxf drops NaN; an infinite bound gives a negative shift and saturating conversions (garbage in,
+  // garbage out, but no undefined behaviour)
+  int ex = 0;
+  const float bound = mg * mm;
+  if (bound > 0.f) frexpf(fminf(bound, 3.0e38f), &ex);          // bound < 2^ex
+  const int shift = max(-126, min(126, acc_bits - ex));
+  const float scale = ldexpf(1.f, shift);
+  const double inv_scale = ldexp(1.0, -shift);
+
+  const bool lanes_per_channel = (Cg & (Cg - 1)) == 0 && Cg <= 64;
+  const int CL = lanes_per_channel ? Cg : 1;
+  const int cl = threadIdx.x % CL;
+  const int slots = blockDim.x / CL;
+  for (int p0 = 0; p0 < npix_out; p0 += kChunk) {
+    // The offsets / mask / grad_output of a pixel chunk are staged with one bulk load (every thread of the 16 waves
+    // issues its loads at once) instead of a dependent global round trip per item.
+    const int pc = min(kChunk, npix_out - p0);
+    for (int e = threadIdx.x; e < pc * P * 2; e += blockDim.x) {
+      const int pp = e / (P * 2), j = e % (P * 2);
+      s_off[e] = off[(((int64_t)n * npix_out + p0 + pp) * g.G + gi) * P * 2 + j];
     }
-    gmsk[ob] = am;
-    goff[ob * 2] = ax * m * g.osc;
-    goff[ob * 2 + 1] = ay * m * g.osc;
+    for (int e = threadIdx.x; e < pc * P; e += blockDim.x) {
+      const int pp = e / P, j = e % P;
+      s_msk[e] = msk[(((int64_t)n * npix_out + p0 + pp) * g.G + gi) * P + j];
+    }
+    for (int e = threadIdx.x; e < pc * Cg; e += blockDim.x) s_go[e] = gob[(int64_t)(p0 + e / Cg) * C + e % Cg];
+    __syncthreads();
+    // Work item = (tap, pixel of the chunk).  With Cg a power of two the Cg channels of an item sit on Cg adjacent lanes
+    // and a wavefront handles 64/Cg consecutive pixels of one tap; the per-item sums for grad_mask / grad_offset finish
+    // with a log2(Cg)-step lane shuffle (no cross-thread reduction through memory, cf. .cuh:907-1039).
+    const int items = pc * P;
+    for (int it0 = 0; it0 < items; it0 += slots) {
+      const int it = it0 + threadIdx.x / CL;
+      const bool live = it < items;
+      const int k = live ? it / pc : 0, pl = live ? it % pc : 0;
+      const int pix = p0 + pl;
+      const int ho = pix / g.Wo, wo = pix % g.Wo;
+      const float offx = s_off[(pl * P + k) * 2], offy = s_off[(pl * P + k) * 2 + 1];
+      const float m = s_msk[pl * P + k];
+      const Tap t = make_tap(g, ho, wo, k / g.Kh, k % g.Kh, offx, offy);
+      const float w00 = (1.f - t.ly) * (1.f - t.lx), w01 = (1.f - t.ly) * t.lx, w10 = t.ly * (1.f - t.lx),
+                  w11 = t.ly * t.lx;
+      const bool b00 = live && t.vy0 && t.vx0, b01 = live && t.vy0 && t.vx1, b10 = live && t.vy1 && t.vx0,
+                 b11 = live && t.vy1 && t.vx1;
+      const int o00 = (t.y0 * g.W + t.x0) * Cg;
+      const int o01 = o00 + Cg, o10 = o00 + g.W * Cg, o11 = o10 + Cg;
+      float am = 0.f, ax = 0.f, ay = 0.f;
+      for (int c = cl; c < Cg; c += CL) {
+        const float gv = live ? s_go[pl * Cg + c] : 0.f;
+        const float a = b00 ? s_in[o00 + c] : 0.f, b = b01 ? s_in[o01 + c] : 0.f;
+        const float cc = b10 ? s_in[o10 + c] : 0.f, d = b11 ? s_in[o11 + c] : 0.f;
+        am += gv * (a * w00 + b * w01 + cc * w10 + d * w11);
+        ax += gv * ((1.f - t.ly) * (b - a) + t.ly * (d - cc));
+        ay += gv * ((1.f - t.lx) * (cc - a) + t.lx * (d - b));
+        const float gm = gv * m * scale;
+        if (b00) atomicAdd(&s_acc[o00 + c], (unsigned long long)__float2ll_rn(gm * w00));
+        if (b01) atomicAdd(&s_acc[o01 + c], (unsigned long long)__float2ll_rn(gm * w01));
+        if (b10) atomicAdd(&s_acc[o10 + c], (unsigned long long)__float2ll_rn(gm * w10));
+        if (b11) atomicAdd(&s_acc[o11 + c], (unsigned long long)__float2ll_rn(gm * w11));
+      }
+      for (int o = CL >> 1; o > 0; o >>= 1) {          // CL divides 64: the group never straddles a wavefront
+        am += __shfl_xor(am, o, 64);
+        ax += __shfl_xor(ax, o, 64);
+        ay += __shfl_xor(ay, o, 64);
+      }
+      if (live && cl == 0) {
+        const int64_t ob = (((int64_t)n * npix_out + pix) * g.G + gi) * P + k;
+        gmsk[ob] = am;
+        goff[ob * 2] = ax * m * g.osc;
+        goff[ob * 2 + 1] = ay * m * g.osc;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   float* ginb = gin + (int64_t)n * npix_in * C + gi * Cg;
   for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
-    ginb[(int64_t)p * C + c] = s_gin[e];
+    ginb[(int64_t)p * C + c] = (float)((double)(long long)s_acc[e] * inv_scale);
   }
 }
 
@@ -285,22 +352,29 @@ extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const floa
                      "s2f_dcnv3_bwd");
   if (rc != S2F_OK) return rc;
   const int64_t total = (int64_t)N * g.Ho * g.Wo * G;
-  const size_t lds = sizeof(float) * ((size_t)2 * H * W + (size_t)g.Ho * g.Wo) * Cg;
-  if (lds <= 160 * 1024) {
-    // (n, group) slice fits in the CU's 160 KiB LDS: atomic-free path, overwrites grad_input completely
-    if (lds > 64 * 1024) {
-      static bool raised = false;
-      if (!raised) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        raised = true;
-      }
+  const size_t lds = (size_t)12 * H * W * Cg + sizeof(float) * (size_t)kChunk * (Kh * Kw * 3 + Cg);
+  constexpr size_t kMaxDynLds = 160 * 1024 - 256;          // the kernel also holds 128 B of static LDS
+  if (lds <= kMaxDynLds) {
+    // (n, group) slice fits in the CU's 160 KiB LDS: no global atomics
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bwd_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
+      S2F_REQUIRE(e == hipSuccess, S2F_ELAUNCH, "s2f_dcnv3_bwd: cannot raise the dynamic LDS limit: %s",
+                  hipGetErrorString(e));
+      raised = true;
     }
-    // 1024 threads = 16 wavefronts per CU: the per-item offset/mask loads are dependent global reads, hidden by occupancy
+    // accumulator bits so that 4*K*Ho*Wo contributions of magnitude < 2^acc_bits cannot overflow 62 bits
+    int count_bits = 0;
+    while (((int64_t)1 << count_bits) < (int64_t)4 * Kh * Kw * g.Ho * g.Wo) ++count_bits;
+    // 1024 threads = 16 wavefronts on the one CU that holds the slice
     hipLaunchKernelGGL(dcn_bwd_lds_kernel, dim3(N * G), dim3(1024), lds, (hipStream_t)stream, input, offset, mask,
-                       grad_output, grad_input, grad_offset, grad_mask, g);
+                       grad_output, grad_input, grad_offset, grad_mask, g, 62 - count_bits);
     return s2f_check_launch("s2f_dcnv3_bwd");
   }
+  // global-atomic path: grad_input is accumulated into, zero it first (stream-ordered, capturable)
+  if (hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)N * H * W * G * Cg, (hipStream_t)stream) != hipSuccess)
+    return s2f_check_launch("s2f_dcnv3_bwd");
   const bool vec = (Cg % 4 == 0) && s2f_aligned16(input) && s2f_aligned16(grad_output);
   if (vec)
     hipLaunchKernelGGL(dcn_bwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,

@@ -210,8 +210,7 @@ class _DCNv3(torch.autograd.Function):
         go = go.contiguous()
         N, H, W, G, Cg = ctx.geo[:5]
         Ho, Wo = offset.shape[1], offset.shape[2]
-        lds_path = 4 * (2 * H * W + Ho * Wo) * Cg <= 160 * 1024      # same test as s2f_dcnv3_bwd: slice resident in LDS
-        gx = torch.empty_like(x) if lds_path else torch.zeros_like(x)
+        gx = torch.empty_like(x)                      # s2f_dcnv3_bwd overwrites all three gradients
         goff, gm = torch.empty_like(offset), torch.empty_like(mask)
         check(lib.s2f_dcnv3_bwd(_ptr(x), _ptr(offset), _ptr(mask), _ptr(go), _ptr(gx), _ptr(goff), _ptr(gm), *ctx.geo,
                                 ctx.osc, _stream()), "s2f_dcnv3_bwd")

@@ -216,6 +216,52 @@ def test_dcnv3_vs_oracle_hot_path_geometry(ops, so):
         assert (a.detach().cpu() - b).abs().max().item() <= tol * b.abs().max().item(), name
 
 
+def test_dcnv3_backward_fixed_point_accumulator(ops):
+    """grad_input is accumulated in LDS in 64-bit fixed point scaled per (n, group) slice: the result must be (1) exactly
+    homogeneous under power-of-two scalings of grad_output over the whole fp32 range that gradients live in, (2) bit-wise
+    reproducible (order-independent, unlike an fp32 atomic), (3) independent of what grad_input's buffer held before, and
+    (4) equal to the large-map global-atomic path on a map that does not fit in LDS."""
+    from spike2former_amd._lib import lib
+    g = torch.Generator().manual_seed(5)
+    N, H, W, G, Cg = 2, 32, 32, 32, 8
+    x = torch.randn(N, H, W, G * Cg, generator=g).cuda()
+    off = (torch.randn(N, H, W, G * 18, generator=g) * 2).cuda()
+    m = torch.rand(N, H, W, G * 9, generator=g).cuda()
+    gy = torch.randn(N, H, W, G * Cg, generator=g).cuda()
+
+    def bwd(go, fill):
+        gx = torch.full_like(x, fill)
+        goff, gm = torch.empty_like(off), torch.empty_like(m)
+        rc = lib.s2f_dcnv3_bwd(x.data_ptr(), off.data_ptr(), m.data_ptr(), go.data_ptr(), gx.data_ptr(), goff.data_ptr(),
+                               gm.data_ptr(), N, H, W, G, Cg, 3, 3, 1, 1, 1, 1, 1, 1, 1.0, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return gx
+    base = bwd(gy, 0.0)
+    assert torch.equal(base, bwd(gy, 123.0))
+    for e in (-60, -30, 30, 60):
+        assert torch.equal(bwd(gy * 2.0 ** e, float("nan")) * 2.0 ** -e, base), e
+    assert torch.equal(bwd(torch.zeros_like(gy), 7.0), torch.zeros_like(x))
+    # one slice with a huge outlier: the other elements of that slice keep >= 2e-6 relative accuracy
+    go2 = gy.clone(); go2[0, 0, 0, 0] = 1.0e4
+    ref = bwd(gy, 0.0); out = bwd(go2, 0.0)
+    far = torch.ones_like(x, dtype=torch.bool); far[0, :4, :4, :Cg] = False
+    assert (out[far] - ref[far]).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # large map (64x64x32 channels per group = 1.5 MiB per slice): global-atomic path, same numbers as autograd of forward
+    N2, H2, G2, Cg2 = 1, 64, 2, 32
+    x2 = torch.randn(N2, H2, H2, G2 * Cg2, device="cuda", requires_grad=True)
+    o2 = (torch.randn(N2, H2, H2, G2 * 18, device="cuda")).requires_grad_(True)
+    m2 = torch.rand(N2, H2, H2, G2 * 9, device="cuda", requires_grad=True)
+    y2 = ops.dcnv3_core(x2, o2, m2, 3, 3, 1, 1, 1, 1, 1, 1, G2, Cg2, 1.0)
+    g2 = torch.randn_like(y2)
+    y2.backward(g2)
+    # linearity in x: <dcn(x'), g2> = <x', gx> for any x'
+    xp = torch.randn_like(x2)
+    lhs = (ops.dcnv3_core(xp, o2.detach(), m2.detach(), 3, 3, 1, 1, 1, 1, 1, 1, G2, Cg2, 1.0) * g2).double().sum()
+    rhs = (xp * x2.grad).double().sum()
+    assert abs(lhs.item() - rhs.item()) <= 1e-4 * (xp.abs() * x2.grad.abs()).double().sum().item()
+
+
 def test_dcnv3_zero_offset_is_a_modulated_3x3_average(ops):
     """Size-independent property: zero offsets + constant mask 1 turn DCNv3 into a 3x3 box filter with zero padding."""
     N, H, W, G, Cg = 8, 32, 32, 32, 8
