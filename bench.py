@@ -30,6 +30,7 @@ def parse():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP-event pass on the LIF kernels")
+    ap.add_argument("--dump-events", default=None, help="write (kernel, algorithmic bytes, us) of every timed launch here")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     return ap.parse_args()
 
@@ -155,6 +156,10 @@ def main():
                     traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
             except (OSError, KeyError, ValueError):
                 pass
+            if args.dump_events:
+                with open(args.dump_events, "w") as f:
+                    for name, nbytes, e0, e1 in events:
+                        f.write(f"{name} {nbytes} {e0.elapsed_time(e1) * 1e3:.2f}\n")
             agg = {}
             for name, nbytes, e0, e1 in events:
                 a = agg.setdefault(name, [0, 0.0, 0])

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from .head_layers import MLP, DetrTransformerDecoder, SinePositionalEncoding
 from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
+from . import ops
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS, ConfigDict
 
@@ -117,12 +118,9 @@ class MaskFormerHead(nn.Module):
         # einsum('ltbqc,tbchw->ltbqhw').mean(t) with the mean folded into the contraction: the reference's
         # [L+1,T,B,Q,H,W] intermediate (734 MB / image at 512^2, T=4) is never materialised.
         Hm, Wm = mask_features.shape[-2:]
-        mf = mask_features.flatten(3)                                    # [t, b, C, HW]
-        acc = None
-        for ti in range(t):
-            et = e[:, ti].permute(1, 0, 2, 3).reshape(bs, ln * nq, C)   # [b, L*Q, C]
-            acc = torch.bmm(et, mf[ti]) if acc is None else torch.baddbmm(acc, et, mf[ti])
-        all_mask_preds = (acc / t).view(bs, ln, nq, Hm, Wm).permute(1, 0, 2, 3, 4)
+        eq = e.permute(1, 2, 0, 3, 4).reshape(t, bs, ln * nq, C)        # [t, b, L*Q, C]: all L+1 predictions in one GEMM
+        acc = ops.mask_einsum(eq, mask_features.flatten(3), 1.0 / t)      # [b, L*Q, HW]
+        all_mask_preds = acc.view(bs, ln, nq, Hm, Wm).permute(1, 0, 2, 3, 4)
         return all_cls_scores, all_mask_preds
 
     def predict(self, x, batch_img_metas, test_cfg=None):

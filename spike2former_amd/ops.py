@@ -415,6 +415,51 @@ def spike_gemm(x, w2d, bias=None):
     return _SpikeGemm.apply(x, w2d, bias)
 
 
+# ------------------------------------------------------------------------------------------------ mask einsum (SDME)
+class _MaskEinsum(torch.autograd.Function):
+    """out[b] = scale * sum_t E[t, b] @ MF[t, b]   (E [T,B,Q,C], MF [T,B,C,HW] -> [B,Q,HW]).
+
+    = einsum('tbqc,tbchw->tbqhw').mean(t) of maskformer_head.py:582-583 with the mean folded into the contraction.  As a
+    Function the T partial products accumulate in the GEMM epilogue (baddbmm, in place) and the backward writes each
+    dMF[t] / dE[t] slice straight into its final buffer: autograd's select_backward would zero-fill and add T full-size
+    [T,B,C,HW] tensors (4 x 537 MB at C2)."""
+
+    @staticmethod
+    def forward(ctx, e, mf, scale):
+        _need_cuda(e, mf)
+        T, B, Q, C = e.shape
+        e = e.contiguous()
+        mf = mf.contiguous()
+        es = e * scale
+        out = torch.bmm(es[0], mf[0])
+        for t in range(1, T):
+            torch.baddbmm(out, es[t], mf[t], out=out)
+        ctx.save_for_backward(es, mf)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        es, mf = ctx.saved_tensors
+        g = g.contiguous()
+        T = es.shape[0]
+        ge = gmf = None
+        if ctx.needs_input_grad[0]:
+            ge = torch.empty_like(es)
+            for t in range(T):
+                torch.bmm(g, mf[t].transpose(1, 2), out=ge[t])
+            ge.mul_(ctx.scale)
+        if ctx.needs_input_grad[1]:
+            gmf = torch.empty_like(mf)
+            for t in range(T):
+                torch.bmm(es[t].transpose(1, 2), g, out=gmf[t])
+        return ge, gmf, None
+
+
+def mask_einsum(e, mf, scale):
+    return _MaskEinsum.apply(e, mf, float(scale))
+
+
 # ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
 class _Up2x(torch.autograd.Function):
     @staticmethod
