@@ -20,6 +20,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -128,8 +129,7 @@ def main():
         ops.KERNEL_EVENTS = []
         for _ in range(2):
             eager_step()
-        torch.cuda.synchronize()
-        events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        events = ops.drain_kernel_events()          # [(kernel, algorithmic bytes, MFMA flops, us)]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -158,23 +158,34 @@ def main():
                 pass
             if args.dump_events:
                 with open(args.dump_events, "w") as f:
-                    for name, nbytes, e0, e1 in events:
-                        f.write(f"{name} {nbytes} {e0.elapsed_time(e1) * 1e3:.2f}\n")
+                    for name, nbytes, flops, us in events:
+                        f.write(f"{name} {nbytes} {flops} {us:.2f}\n")
             agg = {}
-            for name, nbytes, e0, e1 in events:
-                a = agg.setdefault(name, [0, 0.0, 0])
-                a[0] += nbytes; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            for name, nbytes, flops, us in events:
+                a = agg.setdefault(name, [0, 0.0, 0, 0])
+                a[0] += nbytes; a[1] += us * 1e-6; a[2] += 1; a[3] += flops
             for name, key in (("bn_lif_fwd", "roofline"), ("bn_lif_bwd", "roofline_bn_lif_bwd"), ("lif_fwd", "roofline_lif_fwd"),
-                              ("lif_bwd", "roofline_lif_bwd"), ("bn_fwd", "roofline_bn_fwd"), ("bn_bwd", "roofline_bn_bwd")):
+                              ("lif_bwd", "roofline_lif_bwd"), ("bn_fwd", "roofline_bn_fwd"), ("bn_bwd", "roofline_bn_bwd"),
+                              ("bn_stats", "roofline_bn_stats")):
                 if name in agg:
-                    nbytes, secs, launches = agg[name]
+                    nbytes, secs, launches, _ = agg[name]
                     gbs = nbytes / secs / 1e9
                     out[key] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                 "traffic": traffic.get(name) if args.workload == "C2" else None,
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
                                 "algorithmic_bytes_per_launch": nbytes // launches}
-            out["neuron_kernels_ms_per_step"] = round(sum(a[1] for a in agg.values()) / 2 * 1e3, 3)
+            # the MFMA kernels: bf16 products actually issued (3 per fp32 multiply-add: W or dY split hi+mid+lo) against the
+            # dense bf16 MFMA peak; the K <= 256 shapes of the path are bound by streaming X / Y, see DESIGN.md section 4
+            for name, key in (("spike_gemm_fwd", "roofline_spike_gemm_fwd"), ("spike_gemm_dw", "roofline_spike_gemm_dw")):
+                if name in agg:
+                    nbytes, secs, launches, flops = agg[name]
+                    out[key] = {"kernel": name, "bound": "mfma", "achieved": round(flops / secs / 1e12, 1),
+                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
+                                "hbm_GBps_algorithmic": round(nbytes / secs / 1e9, 1)}
+            out["timed_kernels_ms_per_step"] = round(sum(a[1] for a in agg.values()) / 2 * 1e3, 3)
         if world == 1 and not args.no_cpu_baseline:
             del model, red
             torch.cuda.empty_cache()

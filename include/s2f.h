@@ -7,7 +7,7 @@
  *     `?` in a comment marks a nullable pointer.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are asynchronous.
  *   - return value: S2F_OK (0) or a negative S2F_E* code; `s2f_last_error()` gives the text.
- *   - re-entrant, no global state apart from the thread-local error string.
+ *   - re-entrant, no global state apart from the thread-local error string and the thread-local launch-timing arm.
  *
  * The reference (BICLab/Spike2Former) has no FFI on its live path -- everything is ATen ops called from
  * Python.  The in-tree precedents this ABI follows are the (dormant) pybind pair
@@ -29,10 +29,24 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 1
+#define S2F_ABI_VERSION 2
 
 int s2f_version(void);
 const char* s2f_last_error(void);
+
+/* ---- measurement: kernel-timestamp timing of one call ------------------------------------------------
+ * bench.py's roofline figures need the duration of individual launches.  Two hipEventRecord markers around a launch
+ * add ~4 us of command-processor time to a ~10 us kernel; instead the launch itself carries the events
+ * (hipExtLaunchKernelGGL start/stop events = the dispatch packet's own begin/end timestamps, what rocprofv3 reports).
+ *   s2f_event_create/destroy: a hipEvent_t as void*.
+ *   s2f_time_next_call(start, stop): arms THIS thread; the next s2f_lif_fwd / s2f_lif_bwd / s2f_bn_stats /
+ *       s2f_bn_act_fwd / s2f_bn_act_bwd / s2f_spike_gemm_fwd / s2f_spike_gemm_dw call stamps `start` with the begin of
+ *       its first kernel and `stop` with the end of its last one, then disarms.  Not valid during stream capture.
+ *   s2f_event_elapsed_us: stop - start in microseconds (both must have completed: synchronise first). */
+void* s2f_event_create(void);
+void s2f_event_destroy(void* event);
+int s2f_time_next_call(void* start_event, void* stop_event);
+int s2f_event_elapsed_us(void* start_event, void* stop_event, double* microseconds);
 
 /* Number of uint64 words of the in-range bitmask for n elements: 4 words per 256-element tile.
  * Tile i covers elements [256 i, 256 i + 256); word j (0..3) bit l (0..63) belongs to element 256 i + 4 l + j

@@ -15,6 +15,10 @@ _p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     "s2f_version": (_i, []),
     "s2f_last_error": (ctypes.c_char_p, []),
+    "s2f_event_create": (_p, []),
+    "s2f_event_destroy": (None, [_p]),
+    "s2f_time_next_call": (_i, [_p, _p]),
+    "s2f_event_elapsed_us": (_i, [_p, _p, ctypes.POINTER(ctypes.c_double)]),
     "s2f_lif_mask_words": (_i64, [_i64]),
     "s2f_lif_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _i, _p]),
     "s2f_lif_bwd": (_i, [_p, _p, _p, _p, _i64, _f, _i, _p]),

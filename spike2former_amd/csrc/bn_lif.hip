@@ -361,7 +361,7 @@ extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums
   S2F_REQUIRE(s2f_aligned16(z), S2F_EALIGN, "s2f_bn_stats: z must be 16-byte aligned");
   int slice;
   const int S = pick_slices((int)C, (int)L, slice);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, (hipStream_t)stream, z, conv_bias,
+  S2F_LAUNCH(true, true, bn_stats_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, (hipStream_t)stream, z, conv_bias,
                      sums_zeroed, (int)N, (int)C, (int)L, slice);
   return s2f_check_launch("s2f_bn_stats");
 }
@@ -389,7 +389,7 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   const double inv_count = 1.0 / count;
   const float unbias = count > 1 ? (float)(count / (count - 1.0)) : 1.0f;
 #define S2F_BN_APPLY(LIFV, HASV)                                                                                        \
-  hipLaunchKernelGGL((bn_apply_kernel<LIFV, HASV>), grid, block, 3 * C * sizeof(float), s, z, conv_bias, sums, stat_out, running_mean, \
+  S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV>), grid, block, 3 * C * sizeof(float), s, z, conv_bias, sums, stat_out, running_mean, \
                      running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L,   \
                      inv_count, unbias, momentum, eps, training, vth, (float)D)
   if (y == nullptr)
@@ -415,9 +415,9 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
   const int64_t total = N * C * L;
   int slice;
   const int S = pick_slices((int)C, (int)L, slice);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,
+  S2F_LAUNCH(true, false, bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,
                      mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z, conv_bias, stat, gamma, g_u, g_y,
+  S2F_LAUNCH(false, true, bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z, conv_bias, stat, gamma, g_u, g_y,
                      g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L,
                      1.0 / ((double)N * (double)L), training, vth, (float)D);
   return s2f_check_launch("s2f_bn_act_bwd");

@@ -24,6 +24,10 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -142,15 +146,16 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
       const int p = tid + q * T;
       if (p < 256) {
         const int kb = p / (BN / 4), nb = p % (BN / 4);
-        u16x4 pk;
-        pk[0] = f2bf(breg[q][0].x); pk[1] = f2bf(breg[q][1].x); pk[2] = f2bf(breg[q][2].x); pk[3] = f2bf(breg[q][3].x);
-        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 0][kb * 4]) = pk;
-        pk[0] = f2bf(breg[q][0].y); pk[1] = f2bf(breg[q][1].y); pk[2] = f2bf(breg[q][2].y); pk[3] = f2bf(breg[q][3].y);
-        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 1][kb * 4]) = pk;
-        pk[0] = f2bf(breg[q][0].z); pk[1] = f2bf(breg[q][1].z); pk[2] = f2bf(breg[q][2].z); pk[3] = f2bf(breg[q][3].z);
-        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 2][kb * 4]) = pk;
-        pk[0] = f2bf(breg[q][0].w); pk[1] = f2bf(breg[q][1].w); pk[2] = f2bf(breg[q][2].w); pk[3] = f2bf(breg[q][3].w);
-        *reinterpret_cast<u16x4*>(&Bs[nb * 4 + 3][kb * 4]) = pk;
+        // 16-byte k-chunk c of row n lives at chunk c ^ ((n >> 4) & 3): without the swizzle the 32 lanes of one
+        // ds_write_b64 (rows 4 nb + e, 320 bytes apart) fall on 4 bank groups -- an 8-way conflict that made up half of the
+        // kernel's LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.46); the fragment reads stay conflict-free.
+        const int kc = ((((kb >> 1) ^ (nb >> 2)) & 3) << 3) + ((kb & 1) << 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x2 lo = {breg[q][0][e], breg[q][1][e]}, hi = {breg[q][2][e], breg[q][3][e]};
+          *reinterpret_cast<bf16x4*>(&Bs[nb * 4 + e][kc]) = __builtin_shufflevector(
+              __builtin_convertvector(lo, bf16x2), __builtin_convertvector(hi, bf16x2), 0, 1, 2, 3);   // v_cvt_pk_bf16_f32
+        }
       }
     }
     __syncthreads();
@@ -161,8 +166,10 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
       const int kof = ks * 16 + 8 * (lane >> 5);
       bf16x8 bfrag[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * 64 + j * 32 + (lane & 31)][kof]);
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + (lane & 31);
+        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[row][(((kof >> 3) ^ (row >> 4)) & 3) << 3]);
+      }
 #pragma unroll
       for (int t = 0; t < TERMS; ++t) {
 #pragma unroll
@@ -203,11 +210,17 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
 // the 256x256 maps) while the output is only M x K, so it is split over `splits` workgroups per output tile that add
 // their partial tiles into the zero-initialised dW with fp32 atomics.
 // Block = 4 wavefronts (2 x 2), output tile 128 x 128, contraction step 32, register prefetch of the next step.
-__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-  h = f2bf(v);
-  const float r1 = v - bf2f(h);
-  m = f2bf(r1);
-  l = f2bf(r1 - bf2f(m));
+// (v0, v1) -> three packed bf16 pairs hi, mid, lo with v = hi + mid + lo to 24 bits; v_cvt_pk_bf16_f32 rounds to nearest
+// even, the residuals are exact fp32 subtractions.
+__device__ __forceinline__ unsigned int pack2(f32x2 v) {
+  bf16x2 b = __builtin_convertvector(v, bf16x2);
+  return *reinterpret_cast<unsigned int*>(&b);
+}
+__device__ __forceinline__ void split3x2(float v0, float v1, unsigned int& h, unsigned int& m, unsigned int& l) {
+  h = pack2(f32x2{v0, v1});
+  const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+  m = pack2(f32x2{r0, r1});
+  l = pack2(f32x2{r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u)});
 }
 
 __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
@@ -254,17 +267,14 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
     for (int h = 0; h < 4; ++h) {
       const int c = tid + h * 256;
       const int row = c >> 3, col = (c & 7) * 4;
-      u16x4 ph, pm, pl, pb;
-      unsigned short x0, x1, x2;
-      split3(areg[h].x, x0, x1, x2); ph[0] = x0; pm[0] = x1; pl[0] = x2;
-      split3(areg[h].y, x0, x1, x2); ph[1] = x0; pm[1] = x1; pl[1] = x2;
-      split3(areg[h].z, x0, x1, x2); ph[2] = x0; pm[2] = x1; pl[2] = x2;
-      split3(areg[h].w, x0, x1, x2); ph[3] = x0; pm[3] = x1; pl[3] = x2;
-      *reinterpret_cast<u16x4*>(&As[0][row][col]) = ph;
-      *reinterpret_cast<u16x4*>(&As[1][row][col]) = pm;
-      *reinterpret_cast<u16x4*>(&As[2][row][col]) = pl;
-      pb[0] = f2bf(breg[h].x); pb[1] = f2bf(breg[h].y); pb[2] = f2bf(breg[h].z); pb[3] = f2bf(breg[h].w);
-      *reinterpret_cast<u16x4*>(&Bs[row][col]) = pb;
+      unsigned int h0, m0_, l0_, h1, m1, l1;
+      split3x2(areg[h].x, areg[h].y, h0, m0_, l0_);
+      split3x2(areg[h].z, areg[h].w, h1, m1, l1);
+      *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
+      *reinterpret_cast<u32x2*>(&Bs[row][col]) =
+          u32x2{pack2(f32x2{breg[h].x, breg[h].y}), pack2(f32x2{breg[h].z, breg[h].w})};
     }
     __syncthreads();
     if (step + 1 < s_end) fetch(step + 1, areg, breg);
@@ -273,8 +283,10 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
       const int kof = ks * 16 + 8 * (lane >> 5);
       bf16x8 bfrag[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * 64 + j * 32 + (lane & 31)][kof]);
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + (lane & 31);
+        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[row][kof]);
+      }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
 #pragma unroll
@@ -339,22 +351,22 @@ extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const
   }
   const int m_tiles = Mpad / (64 * wm);
   const dim3 grid(n_tiles * m_tiles, batch);
-#define S2F_LAUNCH(WMV, TV)                                                                                             \
-  hipLaunchKernelGGL((spike_gemm_kernel<WMV, TV>), grid, dim3(128 * WMV), 0, s, w_split, X, bias, Y, M, N, K, Mpad, Kpad, \
-                     n_tiles, m_tiles)
-#define S2F_LAUNCH_T(WMV)            \
-  if (terms == 3) S2F_LAUNCH(WMV, 3); \
-  else if (terms == 2) S2F_LAUNCH(WMV, 2); \
-  else S2F_LAUNCH(WMV, 1)
+#define S2F_GEMM_GO(WMV, TV)                                                                                           \
+  S2F_LAUNCH(true, true, (spike_gemm_kernel<WMV, TV>), grid, dim3(128 * WMV), 0, s, w_split, X, bias, Y, M, N, K, Mpad,  \
+             Kpad, n_tiles, m_tiles)
+#define S2F_GEMM_T(WMV)                 \
+  if (terms == 3) S2F_GEMM_GO(WMV, 3);   \
+  else if (terms == 2) S2F_GEMM_GO(WMV, 2); \
+  else S2F_GEMM_GO(WMV, 1)
   if (wm == 4) {
-    S2F_LAUNCH_T(4);
+    S2F_GEMM_T(4);
   } else if (wm == 2) {
-    S2F_LAUNCH_T(2);
+    S2F_GEMM_T(2);
   } else {
-    S2F_LAUNCH_T(1);
+    S2F_GEMM_T(1);
   }
-#undef S2F_LAUNCH_T
-#undef S2F_LAUNCH
+#undef S2F_GEMM_T
+#undef S2F_GEMM_GO
   return s2f_check_launch("s2f_spike_gemm_fwd");
 }
 
@@ -375,7 +387,7 @@ extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int
   if (splits > 65535) splits = 65535;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
-  hipLaunchKernelGGL(spike_gemm_dw_kernel, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K, L,
+  S2F_LAUNCH(true, true, spike_gemm_dw_kernel, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K, L,
                      steps_per_split, k_tiles);
   return s2f_check_launch("s2f_spike_gemm_dw");
 }

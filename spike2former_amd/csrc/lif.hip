@@ -20,6 +20,33 @@ void s2f_set_error(const char* fmt, ...) {
 }
 extern "C" const char* s2f_last_error(void) { return g_err; }
 extern "C" int s2f_version(void) { return S2F_ABI_VERSION; }
+
+static thread_local S2fTiming g_timing = {nullptr, nullptr};
+S2fTiming* s2f_timing_tls() { return &g_timing; }
+extern "C" void* s2f_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) {
+    s2f_set_error("s2f_event_create: %s", hipGetErrorString(hipGetLastError()));
+    return nullptr;
+  }
+  return e;
+}
+extern "C" void s2f_event_destroy(void* event) {
+  if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+extern "C" int s2f_time_next_call(void* start_event, void* stop_event) {
+  g_timing.start = (hipEvent_t)start_event;
+  g_timing.stop = (hipEvent_t)stop_event;
+  return S2F_OK;
+}
+extern "C" int s2f_event_elapsed_us(void* start_event, void* stop_event, double* microseconds) {
+  S2F_REQUIRE(start_event && stop_event && microseconds, S2F_EINVAL, "s2f_event_elapsed_us: null argument");
+  float ms = 0.f;
+  hipError_t e = hipEventElapsedTime(&ms, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+  S2F_REQUIRE(e == hipSuccess, S2F_ELAUNCH, "s2f_event_elapsed_us: %s", hipGetErrorString(e));
+  *microseconds = (double)ms * 1e3;
+  return S2F_OK;
+}
 extern "C" int64_t s2f_lif_mask_words(int64_t n) { return ((n + 255) >> 8) * 4; }
 
 namespace {
@@ -270,10 +297,10 @@ extern "C" int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v
   hipStream_t s = (hipStream_t)stream;
   auto* st = reinterpret_cast<unsigned long long*>(stats);
   if (v_in != nullptr)
-    hipLaunchKernelGGL(lif_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
+    S2F_LAUNCH(true, true, lif_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
                        st, n, vth, (float)D);
   else
-    hipLaunchKernelGGL(lif_fwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
+    S2F_LAUNCH(true, true, lif_fwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
                        st, n, vth, (float)D);
   return s2f_check_launch("s2f_lif_fwd");
 }
@@ -287,10 +314,10 @@ extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t*
               "s2f_lif_bwd: gy/gx/gv must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   if (gv_out != nullptr)
-    hipLaunchKernelGGL(lif_bwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
+    S2F_LAUNCH(true, true, lif_bwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
                        (float)D);
   else
-    hipLaunchKernelGGL(lif_bwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
+    S2F_LAUNCH(true, true, lif_bwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
                        (float)D);
   return s2f_check_launch("s2f_lif_bwd");
 }

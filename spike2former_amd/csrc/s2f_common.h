@@ -1,6 +1,7 @@
 // Shared helpers for the libs2f_hip.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -30,6 +31,23 @@ static inline int s2f_check_launch(const char* what) {
   }
   return S2F_OK;
 }
+
+// Launch timing (include/s2f.h "measurement"): the armed events ride on the dispatch packets themselves.
+struct S2fTiming {
+  hipEvent_t start, stop;
+};
+S2fTiming* s2f_timing_tls();
+// FIRST / LAST: whether this launch is the first / last kernel of the C-ABI call
+#define S2F_LAUNCH(FIRST, LAST, kernel, grid, block, lds, stream, ...)                                 \
+  do {                                                                                                 \
+    S2fTiming* tm_ = s2f_timing_tls();                                                                 \
+    hipEvent_t ea_ = (FIRST) ? tm_->start : nullptr, eb_ = (LAST) ? tm_->stop : nullptr;               \
+    if (ea_ || eb_)                                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ea_, eb_, 0, __VA_ARGS__);               \
+    else                                                                                               \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                               \
+    if (LAST) tm_->start = tm_->stop = nullptr;                                                        \
+  } while (0)
 
 static inline bool s2f_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

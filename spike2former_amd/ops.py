@@ -5,16 +5,36 @@ import torch
 from ._lib import check, lib
 
 
-# When set to a list, every neuron-kernel launch is bracketed by two HIP events on the launch stream and
-# (name, algorithmic_bytes, start, end) is appended -- bench.py's live roofline measurement.  Algorithmic bytes are
-# SURVEY section 8d's per-element figures: forward 8 B (read x, write y), backward 12 B (read gy, read x, write gx).
+# When set to a list, the launches of the neuron / BatchNorm / spike-GEMM kernels are timed with the dispatch packets' own
+# begin / end timestamps (include/s2f.h "measurement": s2f_time_next_call) and (name, algorithmic_bytes, flops, start,
+# stop) is appended -- bench.py's live roofline measurement.  Algorithmic bytes are SURVEY section 8d's per-element
+# figures: LIF forward 8 B (read x, write y), backward 12 B (read gy, read x, write gx).  Eager launches only.
 KERNEL_EVENTS = None
 
 
-def _ev():
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
+def _time_next(name, nbytes, flops=0):
+    if KERNEL_EVENTS is not None:
+        e0, e1 = lib.s2f_event_create(), lib.s2f_event_create()
+        if not e0 or not e1:
+            raise RuntimeError("s2f_event_create failed: " + lib.s2f_last_error().decode())
+        lib.s2f_time_next_call(e0, e1)
+        KERNEL_EVENTS.append((name, int(nbytes), int(flops), e0, e1))
+
+
+def drain_kernel_events():
+    """-> [(name, algorithmic_bytes, flops, microseconds)] of the launches timed since KERNEL_EVENTS was set; synchronises,
+    frees the events and switches the timing off."""
+    global KERNEL_EVENTS
+    import ctypes
+    torch.cuda.synchronize()
+    out, us = [], ctypes.c_double()
+    for name, nbytes, flops, e0, e1 in (KERNEL_EVENTS or []):
+        check(lib.s2f_event_elapsed_us(e0, e1, ctypes.byref(us)), "s2f_event_elapsed_us")
+        out.append((name, nbytes, flops, us.value))
+        lib.s2f_event_destroy(e0)
+        lib.s2f_event_destroy(e1)
+    KERNEL_EVENTS = None
+    return out
 
 
 # One zero-initialised fp64 arena serves every per-channel reduction workspace of a step (BatchNorm statistics, BatchNorm
@@ -81,11 +101,9 @@ class _LIF(torch.autograd.Function):
         v_out = torch.empty_like(x) if keep_v else None
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
-        e0 = _ev() if KERNEL_EVENTS is not None else None
+        _time_next("lif_fwd", 8 * n)
         check(lib.s2f_lif_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), 0, _ptr(stats), n, vth, D,
                               _stream()), "s2f_lif_fwd")
-        if e0 is not None:
-            KERNEL_EVENTS.append(("lif_fwd", 8 * n, e0, _ev()))
         ctx.save_for_backward(mask)
         ctx.D, ctx.vth, ctx.has_v = D, vth, v_in is not None
         if v_out is None:
@@ -102,11 +120,9 @@ class _LIF(torch.autograd.Function):
         if gv is not None:
             gv = gv.contiguous()
         gx = torch.empty_like(gy)
-        e0 = _ev() if KERNEL_EVENTS is not None else None
+        _time_next("lif_bwd", 12 * gy.numel())
         check(lib.s2f_lif_bwd(_ptr(gy), _ptr(gv), _ptr(mask), _ptr(gx), gy.numel(), ctx.vth, ctx.D, _stream()),
               "s2f_lif_bwd")
-        if e0 is not None:
-            KERNEL_EVENTS.append(("lif_bwd", 12 * gy.numel(), e0, _ev()))
         return gx, (gx if ctx.has_v else None), None, None, None, None
 
 
@@ -239,6 +255,7 @@ class _BNAct(torch.autograd.Function):
         ws = None
         if training:
             ws = _take_zeroed(2 * C, dev)
+            _time_next("bn_stats", 4 * z.numel())
             check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), N, C, L, s), "s2f_bn_stats")
         if residual is not None:
             residual = residual.contiguous()
@@ -250,15 +267,12 @@ class _BNAct(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:5])
         mask = torch.empty(mask_words(z.numel()), dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
         n = z.numel()
-        e0 = _ev() if (KERNEL_EVENTS is not None) else None
+        # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
+        _time_next("bn_lif_fwd" if lif_on else "bn_fwd", 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on)))
         check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
                                  _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
                                  _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D, s),
               "s2f_bn_act_fwd")
-        if e0 is not None:
-            # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
-            nb = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
-            KERNEL_EVENTS.append(("bn_lif_fwd" if lif_on else "bn_fwd", nb, e0, _ev()))
         ctx.save_for_backward(z, conv_bias, gamma, stat, mask)
         ctx.cfg = (N, C, L, bool(training), D, vth, residual is not None, conv_bias is not None)
         ctx.set_materialize_grads(False)
@@ -282,14 +296,12 @@ class _BNAct(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = _take_zeroed(2 * C, dev)
-        e0 = _ev() if (KERNEL_EVENTS is not None) else None
+        # read z + incoming grads, write gz [, g_residual]
+        _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd",
+                   4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None)))
         check(lib.s2f_bn_act_bwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
                                  _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
                                  int(training), vth, D, _stream()), "s2f_bn_act_bwd")
-        if e0 is not None:
-            n = z.numel()
-            nb = 4 * n * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None))   # read z + grads, write gz [, g_res]
-            KERNEL_EVENTS.append(("bn_lif_bwd" if g_y is not None else "bn_bwd", nb, e0, _ev()))
         g_bias = None
         if has_bias:
             # train-mode BN removes any per-channel constant: d/d(bias) == 0; eval mode: sum(gz) = gamma * rstd * dbeta
@@ -385,6 +397,8 @@ class _SpikeGemm(torch.autograd.Function):
             assert torch.equal(x * 8, torch.round(x * 8)) and float(x.abs().max()) <= 16, "not a spike tensor"
         ws = split_weight(w2d)
         y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
+        # MFMA work actually issued: `terms` bf16 products per fp32 multiply-add
+        _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K * SPIKE_GEMM_TERMS)
         check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, ws.shape[1], ws.shape[2],
                                      SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
         ctx.save_for_backward(x, w2d)
@@ -403,6 +417,7 @@ class _SpikeGemm(torch.autograd.Function):
             if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 64:     # 128-row tiles: M <= 32 wastes 3/4 of the MFMAs
                 M, K = w2d.shape
                 gw = torch.empty(M, K, dtype=torch.float32, device=x.device)
+                _time_next("spike_gemm_dw", 4 * B * x.shape[2] * (K + M), 2 * B * M * x.shape[2] * K * 3)
                 check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw), B, M, K, x.shape[2], _stream()), "s2f_spike_gemm_dw")
             else:
                 gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
@@ -514,6 +529,7 @@ class _ConvDense(torch.autograd.Function):
         if use_mfma:
             ws = split_weight(w2d)
             y = torch.empty(N, M, Ho * Wo, dtype=torch.float32, device=x.device)
+            _time_next("spike_gemm_fwd", 4 * N * Ho * Wo * (cols.shape[1] + M), 2 * N * M * Ho * Wo * cols.shape[1] * SPIKE_GEMM_TERMS)
             check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, Ho * Wo, cols.shape[1],
                                          ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
         else:
@@ -543,6 +559,7 @@ class _ConvDense(torch.autograd.Function):
             K = w2d.shape[1]
             if use_mfma and SPIKE_GEMM_DW and M >= 64:
                 gw = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+                _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K * 3)
                 check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw), N, M, K, Ho * Wo, _stream()), "s2f_spike_gemm_dw")
             else:
                 gw = torch.bmm(gy, cols.transpose(1, 2)).sum(0)

@@ -13,7 +13,7 @@ def _declared():
     src = open(os.path.join(ROOT, "include", "s2f.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|int64_t|const char\s*\*)\s+(s2f_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t|void\s*\*?|const char\s*\*)\s*(s2f_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out
@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/s2f.h but not exported"
     lib.s2f_version.restype = ctypes.c_int
-    assert lib.s2f_version() == 1
+    assert lib.s2f_version() == 2
     lib.s2f_lif_mask_words.restype = ctypes.c_int64
     lib.s2f_lif_mask_words.argtypes = [ctypes.c_int64]
     assert [lib.s2f_lif_mask_words(n) for n in (0, 1, 256, 257, 1024)] == [0, 4, 4, 8, 16]
