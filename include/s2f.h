@@ -29,7 +29,8 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 2
+#define S2F_ABI_VERSION 4
+#define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
 const char* s2f_last_error(void);
@@ -60,8 +61,10 @@ int64_t s2f_lif_mask_words(int64_t n);
  *     mask bit = (0 <= h <= D)                          (what the STE backward needs instead of fp32 h)
  * v_in? NULL == membrane freshly reset (python float 0.).  v_out? NULL == membrane not kept.
  * mask? NULL == no backward wanted.  count_u8? NULL == integer counts not wanted.
- * stats? : uint64[2], atomically accumulated {sum of counts s, number of non-zero s} (cal_firing_num.py:138-160
- *          accumulates mean(y*D) = stats[0]/n; firing_utils non-zero rate = stats[1]/n).
+ * stats? : uint64[S2F_STAT_SLOTS][2], atomically accumulated {sum of counts s, number of non-zero s}; the caller sums the
+ *          slots (cal_firing_num.py:138-160 accumulates mean(y*D) = sum(stats[.][0])/n; firing_utils non-zero rate =
+ *          sum(stats[.][1])/n).  Workgroup b adds into slot b % S2F_STAT_SLOTS: with ONE pair of counters the 2 048
+ *          workgroups of a launch serialise on two L2 atomics (measured 52 us on a 5 us kernel).
  * x, y, v_* need 16-byte alignment when n >= 4. */
 int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
                 uint64_t* stats, int64_t n, float vth, int D, void* stream);
@@ -73,7 +76,7 @@ int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, floa
 /* ---- T successive stateful calls on one neuron, membrane carried in registers -----------------------
  * Same arithmetic as T calls of s2f_lif_fwd with v chained (what tools/cal_firing_num.py:203-225 does across
  * images; structural precedent: the dormant cupy kernel IFNode_fptt_softReset, neuron_kernel.py:19-119).
- * x_seq, y_seq: [T, n]; mask: [T, s2f_lif_mask_words(n)]; v0? / vT? : [n]. stats?: uint64[2*T]. */
+ * x_seq, y_seq: [T, n]; mask: [T, s2f_lif_mask_words(n)]; v0? / vT? : [n]. stats?: uint64[T][S2F_STAT_SLOTS][2]. */
 int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq, float* vT, uint64_t* mask, uint64_t* stats,
                     int T, int64_t n, float vth, int D, void* stream);
 /* BPTT: g_h[t] = g_h[t+1] + (gy[t]/D - g_h[t+1]*vth) * m[t], g_h[T] := gvT (NULL == 0); gx_seq[t] = g_h[t]; gv0? = g_h[0]. */
@@ -94,6 +97,10 @@ int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask,
  *   if y != NULL:  the Q_IFNode update of s2f_lif_fwd on u (v_in?, v_out?, mask?, stats? as there).
  * s2f_bn_act_bwd:  gu = g_u? + STE(g_y?, g_v?, mask) ;  training: gz = gamma*rstd*(gu - mean(gu) - xhat*mean(gu*xhat)),
  *   eval: gz = gamma*rstd*gu ;  g_residual? = gu ;  dgamma = sum(gu*xhat) ; dbeta = sum(gu).  sums_zeroed as above. */
+/* 1 when, in training mode, s2f_bn_act_fwd / s2f_bn_act_bwd compute the channel statistics of this shape themselves
+ * (one workgroup per channel holds the channel's N*L elements in registers: small maps with L % 256 == 0): the caller
+ * then skips s2f_bn_stats and may pass sums / sums_zeroed = NULL. */
+int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L);
 int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
                  void* stream);
 int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out, float* running_mean,

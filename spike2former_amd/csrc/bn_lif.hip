@@ -206,9 +206,23 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
       csum += __shfl_xor(csum, o, 64);
       cnz += __shfl_xor(cnz, o, 64);
     }
+    // one pair of atomics per workgroup (the prologue's LDS is free again after the streaming loop)
+    __syncthreads();
+    uint32_t* red = reinterpret_cast<uint32_t*>(sstat);
     if (lane == 0) {
-      if (csum) atomicAdd(&stats[0], (unsigned long long)csum);
-      if (cnz) atomicAdd(&stats[1], (unsigned long long)cnz);
+      red[(threadIdx.x >> 6) * 2] = csum;
+      red[(threadIdx.x >> 6) * 2 + 1] = cnz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long a = 0, b = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        a += red[2 * w];
+        b += red[2 * w + 1];
+      }
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (a) atomicAdd(&slot[0], a);
+      if (b) atomicAdd(&slot[1], b);
     }
   }
 }
@@ -328,6 +342,202 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-pass forms for small maps.  When one channel's N*L elements fit in the registers of one workgroup (4 waves x
+// 8 tiles x 256 elements = 8 192; L % 256 == 0 so that the 256-element mask tiles do not straddle channels) the workgroup of
+// channel c loads its slice ONCE, reduces the statistics through LDS and applies them from registers: z is read once instead
+// of twice and one launch replaces two.  At the 32x32 / 64x64 stages of the path the two-kernel form is launch-bound
+// (measured floors: bn_stats 4.3 us + bn_apply 5.5 us for <= 16 MB), which is where ~2/3 of the BatchNorm launches live.
+constexpr int kTpw = 8;                       // tiles per wave held in registers
+
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int nwaves) {
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();                            // red may still be read from a previous use
+  if (lane == 0) {
+    red[2 * w] = a;
+    red[2 * w + 1] = b;
+  }
+  __syncthreads();
+  a = 0, b = 0;
+  for (int i = 0; i < nwaves; ++i) {          // every thread forms the same sum in the same order
+    a += red[2 * i];
+    b += red[2 * i + 1];
+  }
+}
+
+template <bool LIF, bool HAS_V>
+__global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out, const float* __restrict__ v_in,
+    float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
+    int N, int C, int L, double inv_count, float unbias, float momentum, float eps, float vth, float Df) {
+  __shared__ double red[2 * kWaves];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int tpr = L >> 8, tiles = N * tpr;                  // tiles per row, tiles of this channel
+  const float b = bias ? bias[c] : 0.f;
+  Tile4 zv[kTpw];
+  int64_t base[kTpw];
+  bool ok[kTpw];
+#pragma unroll
+  for (int i = 0; i < kTpw; ++i) {                          // all loads in flight before the first use
+    const int t = w + i * nwaves;
+    ok[i] = t < tiles;
+    const int n = ok[i] ? t / tpr : 0, q = ok[i] ? t - n * tpr : 0;
+    base[i] = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
+    zv[i] = ld4(z + base[i]);
+  }
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kTpw; ++i) {
+    if (!ok[i]) continue;
+    const float a0 = zv[i].a[0] + b, a1 = zv[i].a[1] + b, a2 = zv[i].a[2] + b, a3 = zv[i].a[3] + b;
+    ps += (a0 + a1) + (a2 + a3);
+    pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  double s1 = (double)ps, s2 = (double)pq;
+  block_sum2(s1, s2, red, nwaves);
+  const double md = s1 * inv_count;
+  double vd = s2 * inv_count - md * md;
+  if (vd < 0) vd = 0;
+  const float mean = (float)md, var = (float)vd;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma[c], be = beta[c];
+  if (threadIdx.x == 0) {
+    stat[c] = mean;
+    stat[C + c] = rstd;
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var * unbias);
+    }
+    if (c == 0 && num_batches != nullptr) *num_batches += 1;
+  }
+  uint32_t csum = 0, cnz = 0;
+#pragma unroll
+  for (int i = 0; i < kTpw; ++i) {
+    bool inr[4] = {false, false, false, false};
+    if (ok[i]) {                                            // wave-uniform
+      Tile4 rv, vv, uo, yo, vo;
+      if (res) rv = ld4(res + base[i]);
+      if (LIF && HAS_V) vv = ld4(v_in + base[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = ((zv[i].a[j] + b) - mean) * rstd * g + be;
+        if (res) u += rv.a[j];
+        uo.a[j] = u;
+        if (LIF) {
+          const float h = HAS_V ? (vv.a[j] + u) : u;
+          float sp, yy;
+          s2f_lif_update(h, Df, 1.0f, vth, sp, yy, vo.a[j], inr[j]);
+          yo.a[j] = sp / Df;
+          csum += (uint32_t)sp;
+          cnz += ((uint32_t)sp != 0);
+        }
+      }
+      if (u_out) st4(u_out + base[i], uo);
+      if (LIF) {
+        st4(y + base[i], yo);
+        if (v_out) st4(v_out + base[i], vo);
+        const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+        const int64_t tile = base[i] >> 8;
+        if (mask != nullptr && lane < 4) mask[tile * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+      }
+    }
+  }
+  if (LIF && stats != nullptr) {
+    double a = (double)csum, bq = (double)cnz;              // < 2^53: exact
+    block_sum2(a, bq, red, nwaves);
+    if (threadIdx.x == 0) {
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (a > 0) atomicAdd(&slot[0], (unsigned long long)a);
+      if (bq > 0) atomicAdd(&slot[1], (unsigned long long)bq);
+    }
+  }
+}
+
+template <bool GU, bool GY, bool GV>
+__global__ __launch_bounds__(kBlock) void bn_fused_bwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
+    const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
+    const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df) {
+  __shared__ double red[2 * kWaves];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int tpr = L >> 8, tiles = N * tpr;
+  const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
+  // per tile: xhat (from z) and gu, both kept in registers for the second phase; the incoming gradients and the mask word
+  // of a tile are consumed as soon as they arrive (lane j < 4 loads word j, the others get it by a lane read)
+  Tile4 xh[kTpw], gu[kTpw];
+  int tix[kTpw];
+#pragma unroll
+  for (int i = 0; i < kTpw; ++i) {
+    const int t = w + i * nwaves;
+    tix[i] = t < tiles ? t : -1;
+    const int tt = t < tiles ? t : 0;
+    const int n = tt / tpr, q = tt - n * tpr;
+    const int64_t base = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
+    xh[i] = ld4(z + base);
+    if (GU) gu[i] = ld4(g_u + base);
+    Tile4 bb, cc;
+    uint64_t word = 0;
+    if (GY) bb = ld4(g_y + base);
+    if (GV) cc = ld4(g_v + base);
+    if (GY || GV) word = mask[(base >> 8) * 4 + (lane & 3)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool m = false;
+      if (GY || GV) {
+        const uint32_t lo = __shfl((uint32_t)word, j, 64), hi = __shfl((uint32_t)(word >> 32), j, 64);
+        m = ((lane < 32 ? lo >> lane : hi >> (lane - 32)) & 1u) != 0;
+      }
+      gu[i].a[j] = form_gu(GU, GU ? gu[i].a[j] : 0.f, GY, GY ? bb.a[j] : 0.f, GV, GV ? cc.a[j] : 0.f, m, vth, Df);
+      xh[i].a[j] = ((xh[i].a[j] + b) - mean) * rstd;
+    }
+  }
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kTpw; ++i) {
+    if (tix[i] < 0) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ps += gu[i].a[j];
+      pq += gu[i].a[j] * xh[i].a[j];
+    }
+  }
+  double s1 = (double)ps, s2 = (double)pq;
+  block_sum2(s1, s2, red, nwaves);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+  }
+  const float m1 = (float)(s1 * inv_count), m2 = (float)(s2 * inv_count);
+#pragma unroll
+  for (int i = 0; i < kTpw; ++i) {
+    if (tix[i] < 0) continue;
+    const int n = tix[i] / tpr, q = tix[i] - n * tpr;
+    const int64_t base = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
+    Tile4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.a[j] = (g * rstd) * ((gu[i].a[j] - m1) - xh[i].a[j] * m2);
+    st4(gz + base, o);
+    if (g_res) st4(g_res + base, gu[i]);
+  }
+}
+
+// single-pass eligibility: whole 256-element tiles per row, one channel's tiles fit kWaves x kTpw, and enough channels
+// to occupy the chip with one workgroup per channel
+inline bool single_pass_ok(int64_t N, int64_t C, int64_t L) {
+  if ((L & 255) != 0) return false;
+  const int64_t tiles = N * (L >> 8);
+  return tiles >= 4 && tiles <= kWaves * kTpw && C >= 64 && N * C * L < ((int64_t)1 << 31);
+}
+inline int single_pass_threads(int64_t N, int64_t L) {
+  const int tiles = (int)(N * (L >> 8));
+  return 64 * ((tiles + kTpw - 1) / kTpw);
+}
+
 inline int pick_slices(int C, int L, int& slice) {
   int S = 1;
   while ((int64_t)C * S < 1024 && L / (S * 2) >= 2048) S *= 2;
@@ -353,6 +563,8 @@ int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
 
 }  // namespace
 
+extern "C" int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L) { return single_pass_ok(N, C, L) ? 1 : 0; }
+
 extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
                             void* stream) {
   S2F_REQUIRE(z && sums_zeroed, S2F_EINVAL, "s2f_bn_stats: null z/workspace");
@@ -372,7 +584,8 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
                               float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
                               float momentum, float eps, int training, float vth, int D, void* stream) {
   S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
-  S2F_REQUIRE(training ? sums != nullptr : (running_mean && running_var), S2F_EINVAL,
+  const bool single = training && single_pass_ok(N, C, L);
+  S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
               "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
   int rc = check_shape("s2f_bn_act_fwd", N, C, L);
@@ -388,8 +601,23 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   const double count = (double)N * (double)L;
   const double inv_count = 1.0 / count;
   const float unbias = count > 1 ? (float)(count / (count - 1.0)) : 1.0f;
+  if (single) {
+    const dim3 fgrid((unsigned)C), fblock(single_pass_threads(N, L));
+#define S2F_BN_FUSED(LIFV, HASV)                                                                                         \
+  S2F_LAUNCH(true, true, (bn_fused_fwd_kernel<LIFV, HASV>), fgrid, fblock, 0, s, z, conv_bias, stat_out, running_mean,    \
+             running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C, (int)L, inv_count, \
+             unbias, momentum, eps, vth, (float)D)
+    if (y == nullptr)
+      S2F_BN_FUSED(false, false);
+    else if (v_in == nullptr)
+      S2F_BN_FUSED(true, false);
+    else
+      S2F_BN_FUSED(true, true);
+#undef S2F_BN_FUSED
+    return s2f_check_launch("s2f_bn_act_fwd");
+  }
 #define S2F_BN_APPLY(LIFV, HASV)                                                                                        \
-  S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV>), grid, block, 3 * C * sizeof(float), s, z, conv_bias, sums, stat_out, running_mean, \
+  S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV>), grid, block, 3 * C * sizeof(float) + 64, s, z, conv_bias, sums, stat_out, running_mean, \
                      running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L,   \
                      inv_count, unbias, momentum, eps, training, vth, (float)D)
   if (y == nullptr)
@@ -406,13 +634,33 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
                               const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask,
                               double* sums_zeroed, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
                               int64_t C, int64_t L, int training, float vth, int D, void* stream) {
-  S2F_REQUIRE(z && stat && gamma && sums_zeroed && gz && dgamma && dbeta, S2F_EINVAL, "s2f_bn_act_bwd: null pointer");
+  const bool single = training && single_pass_ok(N, C, L);
+  S2F_REQUIRE(z && stat && gamma && (single || sums_zeroed) && gz && dgamma && dbeta, S2F_EINVAL,
+              "s2f_bn_act_bwd: null pointer");
   S2F_REQUIRE(g_u || g_y || g_v, S2F_EINVAL, "s2f_bn_act_bwd: no incoming gradient");
   S2F_REQUIRE(!(g_y || g_v) || mask, S2F_EINVAL, "s2f_bn_act_bwd: spike gradients need the in-range mask");
   int rc = check_shape("s2f_bn_act_bwd", N, C, L);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = N * C * L;
+  if (single) {
+#define S2F_BN_FB(A, B, Cc)                                                                                               \
+  S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0, s, z,      \
+             conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L,          \
+             1.0 / ((double)N * (double)L), vth, (float)D)
+    const int combo = (g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0);
+    switch (combo) {
+      case 1: S2F_BN_FB(false, false, true); break;
+      case 2: S2F_BN_FB(false, true, false); break;
+      case 3: S2F_BN_FB(false, true, true); break;
+      case 4: S2F_BN_FB(true, false, false); break;
+      case 5: S2F_BN_FB(true, false, true); break;
+      case 6: S2F_BN_FB(true, true, false); break;
+      default: S2F_BN_FB(true, true, true); break;
+    }
+#undef S2F_BN_FB
+    return s2f_check_launch("s2f_bn_act_bwd");
+  }
   int slice;
   const int S = pick_slices((int)C, (int)L, slice);
   S2F_LAUNCH(true, false, bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,

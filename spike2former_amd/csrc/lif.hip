@@ -155,8 +155,9 @@ __global__ __launch_bounds__(kBlock) void lif_fwd_kernel(const float* __restrict
         a += red[2 * w];
         b += red[2 * w + 1];
       }
-      if (a) atomicAdd(&stats[0], a);
-      if (b) atomicAdd(&stats[1], b);
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (a) atomicAdd(&slot[0], a);
+      if (b) atomicAdd(&slot[1], b);
     }
   }
 }
@@ -235,8 +236,9 @@ __global__ __launch_bounds__(kBlock) void lif_seq_fwd_kernel(const float* __rest
         csum = wave_sum_u32(csum);
         cnz = wave_sum_u32(cnz);
         if (lane == 0) {
-          if (csum) atomicAdd(&stats[2 * t], (unsigned long long)csum);
-          if (cnz) atomicAdd(&stats[2 * t + 1], (unsigned long long)cnz);
+          unsigned long long* slot = stats + 2 * ((int64_t)t * S2F_STAT_SLOTS + blockIdx.x % S2F_STAT_SLOTS);
+          if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+          if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
         }
       }
     }

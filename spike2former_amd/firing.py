@@ -8,6 +8,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import ops
 from .neuron import Q_IFNode
 
 
@@ -22,7 +23,7 @@ class FiringRecorder:
     def __enter__(self):
         dev = next(self.model.parameters()).device
         for m in self.nodes.values():
-            m.stats = torch.zeros(2, dtype=torch.int64, device=dev)
+            m.stats = ops.new_stats(dev)
             m.stats_elems = 0
         return self
 
@@ -36,7 +37,7 @@ class FiringRecorder:
         names = [n for n, m in self.nodes.items() if m.stats_elems > 0]
         if not names:
             return
-        st = torch.stack([self.nodes[n].stats for n in names]).cpu()
+        st = torch.stack([ops.read_stats(self.nodes[n].stats) for n in names]).cpu()
         for i, n in enumerate(names):
             m = self.nodes[n]
             rate = float(st[i, 0]) / m.stats_elems * (self.quant / m.D)     # == mean(output * quant)

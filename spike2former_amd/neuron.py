@@ -37,7 +37,7 @@ class Q_IFNode(nn.Module):
         self.D = getattr(self.surrogate_function, "D", 8)
         self.v = 0.0
         self.keep_membrane = True
-        self.stats = None          # int64[2] device tensor {sum of counts, non-zero counts} when firing is recorded
+        self.stats = None          # ops.new_stats() counters {sum of counts, non-zero counts} when firing is recorded
         self.stats_elems = 0
 
     def reset(self):

@@ -82,6 +82,20 @@ def _need_cuda(*ts):
             raise RuntimeError(f"spike2former_amd ops compute in fp32; got {t.dtype}")
 
 
+STAT_SLOTS = 256         # include/s2f.h S2F_STAT_SLOTS
+
+
+def new_stats(device, T=None):
+    """Zeroed firing counters for one neuron (s2f.h `stats`): int64 [STAT_SLOTS, 2] (or [T, STAT_SLOTS, 2] for lif_seq)."""
+    shape = (STAT_SLOTS, 2) if T is None else (T, STAT_SLOTS, 2)
+    return torch.zeros(shape, dtype=torch.int64, device=device)
+
+
+def read_stats(stats):
+    """-> int64 [..., 2] = {sum of spike counts, number of non-zero counts}, summed over the contention slots."""
+    return stats.sum(-2)
+
+
 def mask_words(n):
     return ((n + 255) >> 8) * 4
 
@@ -253,7 +267,8 @@ class _BNAct(torch.autograd.Function):
         stat = torch.empty(2 * C, dtype=torch.float32, device=dev)
         s = _stream()
         ws = None
-        if training:
+        single = bool(training) and bool(lib.s2f_bn_single_pass(N, C, L))    # small map: statistics inside s2f_bn_act_fwd
+        if training and not single:
             ws = _take_zeroed(2 * C, dev)
             _time_next("bn_stats", 4 * z.numel())
             check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), N, C, L, s), "s2f_bn_stats")
@@ -295,7 +310,7 @@ class _BNAct(torch.autograd.Function):
         g_res = torch.empty_like(z) if (has_res and ctx.needs_input_grad[4]) else None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = _take_zeroed(2 * C, dev)
+        ws = None if (training and lib.s2f_bn_single_pass(N, C, L)) else _take_zeroed(2 * C, dev)
         # read z + incoming grads, write gz [, g_residual]
         _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd",
                    4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None)))

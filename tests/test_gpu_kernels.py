@@ -69,10 +69,10 @@ def test_lif_vs_c_oracle_ragged_sizes(ops, n):
         return
     ry, rv, rc, rin = lif_ref.seq_fwd(x[None], v0)
     xt, vt = T(x, grad=True), T(v0, grad=True)
-    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stats = ops.new_stats("cuda")
     y, v = ops.lif(xt, vt, stats=stats)
     assert np.array_equal(y.detach().cpu().numpy(), ry[0]) and np.array_equal(v.detach().cpu().numpy(), rv)
-    assert stats.tolist() == [int(rc.sum()), int((rc != 0).sum())]
+    assert ops.read_stats(stats).tolist() == [int(rc.sum()), int((rc != 0).sum())]
     gy, gv = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
     (y * T(gy)).sum().backward(retain_graph=True)
     rgx, _ = lif_ref.seq_bwd(gy[None], rin)
@@ -100,12 +100,12 @@ def test_lif_four_levels_stateless(ops):
 def test_lif_seq_matches_chained_calls_and_golden(ops, golden):
     g = golden("lif_kat.npz")
     xs, v0 = T(g["seq_x"], grad=True), T(g["seq_v0"], grad=True)
-    stats = torch.zeros(2 * xs.shape[0], dtype=torch.int64, device="cuda")
+    stats = ops.new_stats("cuda", T=xs.shape[0])
     y, vT = ops.lif_seq(xs, v0, stats=stats)
     assert np.array_equal(y.detach().cpu().numpy(), g["seq_y"]) and np.array_equal(vT.detach().cpu().numpy(), g["seq_vT"])
     ((y * T(g["seq_wy"])).sum() + (vT * T(g["seq_wv"])).sum()).backward()
     assert np.array_equal(xs.grad.cpu().numpy(), g["seq_gx"]) and np.array_equal(v0.grad.cpu().numpy(), g["seq_gv0"])
-    assert stats.view(-1, 2)[:, 0].tolist() == (g["seq_y"] * 8).sum(1).astype(np.int64).tolist()
+    assert ops.read_stats(stats)[:, 0].tolist() == (g["seq_y"] * 8).sum(1).astype(np.int64).tolist()
     # fused-over-T == T single-step launches
     v, ys = T(g["seq_v0"]), []
     for t in range(xs.shape[0]):
@@ -121,12 +121,13 @@ def test_lif_full_size_properties(ops):
     do not need the oracle -- output on the 9-point grid, y + v' == x exactly, idempotence of the stateless map."""
     n = 4 * 2 * 256 * 256 * 256
     x = torch.randn(n, device="cuda") * 3 + 1
-    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stats = ops.new_stats("cuda")
     y, v = ops.lif(x, None, stats=stats)
     c = y * 8
     assert torch.equal(c, torch.round(c)) and float(c.min()) == 0 and float(c.max()) == 8
     assert torch.equal(x - c, v)
-    assert int(stats[0]) == int(c.double().sum()) and int(stats[1]) == int((c != 0).sum())
+    st = ops.read_stats(stats)
+    assert int(st[0]) == int(c.double().sum()) and int(st[1]) == int((c != 0).sum())
     y2, _ = ops.lif(c, None, keep_v=False)
     assert torch.equal(y2, y)
 
@@ -284,7 +285,10 @@ def test_errors_are_raised_not_swallowed(ops):
 # ----------------------------------------------------------------------------------------------- fused BN (+bias, +residual, +LIF)
 @pytest.mark.parametrize("N,C,L,training,res,lif", [(8, 32, 1024, True, False, True), (4, 20, 64, True, True, True),
                                                      (2, 7, 36, True, True, False), (3, 16, 256, False, True, True),
-                                                     (8, 256, 4096, True, False, True)])
+                                                     (8, 256, 4096, True, False, True),
+                                                     # single-pass kernels (s2f_bn_single_pass): full / ragged wave counts
+                                                     (8, 256, 1024, True, False, True), (8, 64, 1024, True, True, True),
+                                                     (2, 128, 512, True, True, False), (3, 64, 768, True, False, True)])
 def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
     Pre-activation: rtol 2e-5 (different but equally valid fp32 evaluation orders); spikes: at most 1e-4 of the
@@ -316,8 +320,12 @@ def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
     rc = r.clone().cuda().requires_grad_(True) if res else None
     rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    fstats = ops.new_stats("cuda") if lif else None
     uu, yy, _ = ops.bn_act(zc, bc, gc, bec, rmc, rvc, nbt if training else None, training, 0.1, 1e-5, residual=rc,
-                           lif=lif, want_pre=True)
+                           lif=lif, want_pre=True, stats=fstats)
+    if lif:
+        cnt = torch.round(yy.detach() * 8).long()
+        assert ops.read_stats(fstats).tolist() == [int(cnt.sum()), int((cnt != 0).sum())]
     lossc = (uu * gu_w.cuda()).sum()
     if lif:
         lossc = lossc + (yy * gy_w.cuda()).sum()
@@ -349,12 +357,12 @@ def test_bn_act_stateful_lif_matches_unfused(ops):
     gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
     rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
     v = torch.randn(N, C, L, generator=g).cuda()
-    stats_a = torch.zeros(2, dtype=torch.int64, device="cuda"); stats_b = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stats_a = ops.new_stats("cuda"); stats_b = ops.new_stats("cuda")
     u, y, v_out = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=True, want_pre=True, v_in=v,
                              keep_v=True, stats=stats_a)
     u2, _, _ = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=False, want_pre=True)
     y2, v2 = ops.lif(u2, v, stats=stats_b)
-    assert torch.equal(u, u2) and torch.equal(y, y2) and torch.equal(v_out, v2) and torch.equal(stats_a, stats_b)
+    assert torch.equal(u, u2) and torch.equal(y, y2) and torch.equal(v_out, v2) and torch.equal(ops.read_stats(stats_a), ops.read_stats(stats_b))
 
 
 # ----------------------------------------------------------------------------------------------- depthwise stencils
