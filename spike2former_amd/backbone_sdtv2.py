@@ -77,7 +77,7 @@ class RepConv(nn.Module):
         self.body = nn.Sequential(conv1x1, bn, conv3x3)
         spikes_in(conv1x1)                      # RepConv is always fed by a neuron (head_spike / attn_spike)
 
-    def forward(self, x, outer_bn=None, lif=None, residual=None):
+    def forward(self, x, outer_bn=None, lif=None, residual=None, next_lif=None):
         """conv1x1 -> BN+pad -> dw3x3 -> conv1x1 -> BN [-> outer BN [+ residual] [-> neuron]].
         Returns (pre-activation or None, spikes or None) when `outer_bn` is given, else the tensor."""
         x, border = self.body[1](self.body[0](x), return_border=True)
@@ -88,7 +88,7 @@ class RepConv(nn.Module):
         if outer_bn is None:
             return bn_act(x, None, self.body[2][2])[0]
         x, _ = bn_act(x, None, self.body[2][2])
-        return bn_act(x, None, outer_bn, residual=residual, lif=lif)
+        return bn_act(x, None, outer_bn, residual=residual, lif=lif, next_lif=next_lif)
 
 
 class SepConv(nn.Module):
@@ -106,13 +106,14 @@ class SepConv(nn.Module):
         self.bn2 = nn.BatchNorm2d(dim)
         spikes_in(self.pwconv1)                 # pwconv2 reads the depthwise output (not spikes)
 
-    def forward(self, x, residual=None):
-        """Returns SepConv(x) [+ residual] (the residual add is fused into the last BatchNorm kernel)."""
+    def forward(self, x, residual=None, next_lif=None):
+        """Returns SepConv(x) [+ residual] (the residual add is fused into the last BatchNorm kernel; `next_lif`, the
+        neuron that reads the result next, is applied there as well -- fused.bn_act)."""
         T, B, C, H, W = x.shape
         s = self.spike1(x)
         _, s = bn_act(self.pwconv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
         z = self.pwconv2(self.dwconv(s))
-        u, _ = bn_act(z, None, self.bn2, residual=None if residual is None else residual.flatten(0, 1))
+        u, _ = bn_act(z, None, self.bn2, residual=None if residual is None else residual.flatten(0, 1), next_lif=next_lif)
         return u.reshape(T, B, C, H, W)
 
 
@@ -132,12 +133,16 @@ class MS_ConvBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(dim)
         spikes_in(self.conv1, self.conv2)
 
-    def forward(self, x):
+    @property
+    def first_lif(self):
+        return self.Conv.spike1
+
+    def forward(self, x, next_lif=None):
         T, B, C, H, W = x.shape
-        feat = self.Conv(x, residual=x)                                  # x + SepConv(x)
+        feat = self.Conv(x, residual=x, next_lif=self.spike1)            # x + SepConv(x)
         s = self.spike1(feat)
         _, s = bn_act(self.conv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
-        u, _ = bn_act(self.conv2(s), None, self.bn2, residual=feat.flatten(0, 1))   # feat + BN(conv2(.))
+        u, _ = bn_act(self.conv2(s), None, self.bn2, residual=feat.flatten(0, 1), next_lif=next_lif)   # feat + BN(conv2(.))
         return u.reshape(T, B, C, H, W)
 
 
@@ -158,12 +163,12 @@ class MS_MLP(nn.Module):
         self.c_output = out_features
         spikes_in(self.fc1_conv, self.fc2_conv)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
         s = self.fc1_spike(x.flatten(3)).flatten(0, 1)
         _, s = bn_act(self.fc1_conv.forward_nobias(s), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
         res = None if residual is None else residual.reshape(T * B, C, H * W)
-        u, _ = bn_act(self.fc2_conv.forward_nobias(s), self.fc2_conv.bias, self.fc2_bn, residual=res)
+        u, _ = bn_act(self.fc2_conv.forward_nobias(s), self.fc2_conv.bias, self.fc2_bn, residual=res, next_lif=next_lif)
         return u.reshape(T, B, C, H, W)
 
 
@@ -188,7 +193,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         self.attn_spike = _lif()
         self.proj_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
         N = H * W
         s = self.head_spike(x).flatten(0, 1)
@@ -198,7 +203,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
         o = self.attn_spike(o).view(T * B, C, H, W)
         res = None if residual is None else residual.flatten(0, 1)
-        return self.proj_conv[0](o, outer_bn=self.proj_conv[1], residual=res)[0].reshape(T, B, C, H, W)
+        return self.proj_conv[0](o, outer_bn=self.proj_conv[1], residual=res, next_lif=next_lif)[0].reshape(T, B, C, H, W)
 
 
 class MS_Block(nn.Module):
@@ -212,9 +217,13 @@ class MS_Block(nn.Module):
         self.drop_path = nn.Identity()
         self.mlp = MS_MLP(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
 
-    def forward(self, x):
-        x = self.attn(x, residual=x)          # x + attn(x), residual fused into the last BatchNorm kernel
-        return self.mlp(x, residual=x)        # x + mlp(x)
+    @property
+    def first_lif(self):
+        return self.attn.head_spike
+
+    def forward(self, x, next_lif=None):
+        x = self.attn(x, residual=x, next_lif=self.mlp.fc1_spike)   # x + attn(x), residual fused into the last BatchNorm kernel
+        return self.mlp(x, residual=x, next_lif=next_lif)           # x + mlp(x)
 
 
 class MS_DownSampling(nn.Module):
@@ -229,11 +238,16 @@ class MS_DownSampling(nn.Module):
             self.encode_spike = _lif()
             spikes_in(self.encode_conv)
 
-    def forward(self, x):
+    @property
+    def first_lif(self):
+        return getattr(self, "encode_spike", None)
+
+    def forward(self, x, next_lif=None):
         T, B = x.shape[:2]
         if hasattr(self, "encode_spike"):
             x = self.encode_spike(x)
-        x, _ = bn_act(self.encode_conv.forward_nobias(x.flatten(0, 1)), self.encode_conv.bias, self.encode_bn)
+        x, _ = bn_act(self.encode_conv.forward_nobias(x.flatten(0, 1)), self.encode_conv.bias, self.encode_bn,
+                      next_lif=next_lif)
         return x.reshape(T, B, *x.shape[1:])
 
 
@@ -285,27 +299,18 @@ class Spiking_vit_MetaFormer(nn.Module):
 
     def forward_features(self, x):
         x = x.unsqueeze(0).repeat(self.T, 1, 1, 1, 1)
-        x = self.downsample1_1(x)
-        for b in self.ConvBlock1_1:
-            x = b(x)
-        x1 = x
-        x = self.downsample1_2(x)
-        for b in self.ConvBlock1_2:
-            x = b(x)
-        x2 = x
-        x = self.downsample2(x)
-        for b in self.ConvBlock2_1:
-            x = b(x)
-        for b in self.ConvBlock2_2:
-            x = b(x)
-        x3 = x
-        x = self.downsample3(x)
-        for b in self.block3:
-            x = b(x)
-        x = self.downsample4(x)
-        for b in self.block4:
-            x = b(x)
-        x4 = x
+        # The stages as one chain: every module is told which neuron reads its output next, so that neuron's update runs
+        # inside the kernel that produces the output (fused.bn_act `next_lif`).  x1..x4 are taps of the same stream.
+        chain = [self.downsample1_1, *self.ConvBlock1_1, self.downsample1_2, *self.ConvBlock1_2, self.downsample2,
+                 *self.ConvBlock2_1, *self.ConvBlock2_2, self.downsample3, *self.block3, self.downsample4, *self.block4]
+        taps = {id(self.ConvBlock1_1[-1]): 0, id(self.ConvBlock1_2[-1]): 1, id(self.ConvBlock2_2[-1]): 2,
+                id(self.block4[-1]): 3}
+        outs = [None] * 4
+        for i, m in enumerate(chain):
+            x = m(x, next_lif=chain[i + 1].first_lif if i + 1 < len(chain) else None)
+            if id(m) in taps:
+                outs[taps[id(m)]] = x
+        x1, x2, x3, x4 = outs
         if self.decode_mode == "snn":
             return [t.mean(0, keepdim=True) for t in (x1, x2, x3, x4)]
         if self.decode_mode == "Qsnn":

@@ -6,9 +6,16 @@ from . import ops
 from .neuron import Q_IFNode
 
 
-def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None):
+def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
     """z: conv output WITHOUT its bias, [N, C, *].  Returns (u, y): u = BN(z + bias) [+ residual] (None unless wanted),
-    y = lif(u) (None without lif).  Shapes follow z."""
+    y = lif(u) (None without lif).  Shapes follow z.
+    next_lif: the neuron that the caller's consumer will apply to `u` next (the first Q_IFNode of the following block on
+    the residual stream).  Its update is done by this kernel as well and handed over with Q_IFNode.prefire: the reference's
+    separate neuron pass over u (one more read of u forward; a neuron backward + a gradient add backward) disappears."""
+    if next_lif is not None and lif is None:
+        u, y = bn_act(z, conv_bias, bn, residual=residual, lif=next_lif, want_pre=True)
+        next_lif.prefire(u, y)
+        return u, None
     if want_pre is None:
         want_pre = lif is None
     shape = z.shape

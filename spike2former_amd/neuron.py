@@ -39,9 +39,16 @@ class Q_IFNode(nn.Module):
         self.keep_membrane = True
         self.stats = None          # ops.new_stats() counters {sum of counts, non-zero counts} when firing is recorded
         self.stats_elems = 0
+        self._prefired = None      # (u, version, y): this call's output, already produced by the kernel that made u
 
     def reset(self):
         self.v = 0.0
+        self._prefired = None
+
+    def prefire(self, u, y):
+        """The producer of `u` (fused.bn_act with next_lif=self) has already applied this neuron to it -- same update, same
+        membrane / mask / firing counters as a call would have done; the next forward(u) just hands `y` out."""
+        self._prefired = (u, u._version, y)          # holding u keeps its address from being reused while pending
 
     def extra_repr(self):
         return f"v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}, D={self.D}"
@@ -52,6 +59,10 @@ class Q_IFNode(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def forward(self, x):
+        pf, self._prefired = self._prefired, None
+        if (pf is not None and pf[0].data_ptr() == x.data_ptr() and pf[0].numel() == x.numel() and x.is_contiguous()
+                and x._version == pf[1]):
+            return pf[2].view(x.shape)
         v_in = None if isinstance(self.v, float) else self.v
         if self.stats is not None:
             self.stats_elems += x.numel()
