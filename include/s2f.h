@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 4
+#define S2F_ABI_VERSION 5
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -91,8 +91,10 @@ int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask,
  * s2f_bn_stats (training only): per-channel sum / sum of squares of (z + conv_bias?) accumulated into sums_zeroed
  *   (double[2C], MUST be zero on entry -- the host hands out slices of one arena cleared once per step).
  * s2f_bn_act_fwd:  mean / rstd = 1/sqrt(var + eps) from `sums` (training) or from the running statistics (eval), written to
- *   stat_out[0:C] / stat_out[C:2C]; training: running_mean?/running_var? updated in place with `momentum` and the unbiased
- *   variance, *num_batches_tracked? += 1 (torch.nn.BatchNorm semantics).
+ *   stat_out[0:C] / stat_out[C:2C] (stat_out: float[3C]); training: running_mean?/running_var? updated in place with
+ *   `momentum` and the unbiased variance, *num_batches_tracked? += 1 (torch.nn.BatchNorm semantics).
+ *   stat_out[2C:3C] = beta - running_mean * gamma / sqrt(running_var + eps) with the UPDATED running statistics: the
+ *   border value "BN(0)" of BNAndPadLayer (sdtv2.py:68-78), which s2f_dwconv_fwd takes as `border`.
  *   u = ((z + b) - mean) * rstd * gamma + beta [+ residual?] ; u_out? = u ;
  *   if y != NULL:  the Q_IFNode update of s2f_lif_fwd on u (v_in?, v_out?, mask?, stats? as there).
  * s2f_bn_act_bwd:  gu = g_u? + STE(g_y?, g_v?, mask) ;  training: gz = gamma*rstd*(gu - mean(gu) - xhat*mean(gu*xhat)),
@@ -124,7 +126,7 @@ int s2f_dwconv_fwd(const float* x, const float* w, const float* border, float* y
 int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, int N, int C, int H, int W, int K, int pad,
                          void* stream);
 int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, float* gw, int N, int C, int H, int W,
-                          int K, int pad, void* stream);
+                          int K, int pad, int accumulate, void* stream);
 
 /* ---- spike GEMM on the bf16 matrix cores ---------------------------------------------------------------
  * Y[b] (M x N) = W (M x K) @ X[b] (K x N) [+ bias[M]]   for b in [0, batch): the 1x1 Conv2d / Conv1d(k=1) / im2col'd kxk
@@ -141,8 +143,10 @@ int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bia
 /* Weight gradient of the same convolution:  dW[m][k] = sum_b sum_l dY[b][m][l] * X[b][k][l]   (dY [batch, M, L],
  * X [batch, K, L] spikes, dW [M, K] overwritten).  X is exact in bf16; dY is split on the fly into hi + mid + lo bf16
  * terms: three MFMA passes, exact products, fp32 accumulation (split-K partial tiles are combined with fp32 atomics, so
- * the result is reproducible to fp32 round-off, not bit for bit).  L % 4 == 0. */
-int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, void* stream);
+ * the result is reproducible to fp32 round-off, not bit for bit).  L % 4 == 0.
+ * accumulate != 0: dW += ... (no clearing memset; for gradients summed straight into a pre-zeroed flat buffer). */
+int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
+                      void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path

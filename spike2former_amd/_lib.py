@@ -30,12 +30,12 @@ SIGNATURES = {
     "s2f_bn_act_bwd": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
     "s2f_dwconv_fwd": (_i, [_p] * 4 + [_i] * 6 + [_p]),
     "s2f_dwconv_bwd_input": (_i, [_p] * 3 + [_i] * 6 + [_p]),
-    "s2f_dwconv_bwd_weight": (_i, [_p] * 4 + [_i] * 6 + [_p]),
+    "s2f_dwconv_bwd_weight": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_split_bf16x3": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_fwd": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_upsample2x_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_upsample2x_bwd": (_i, [_p, _p, _i64, _i, _i, _p]),
-    "s2f_spike_gemm_dw": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "s2f_spike_gemm_dw": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "s2f_sdsa_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_kv": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),

@@ -47,10 +47,12 @@ class BNAndPadLayer(nn.Module):
         return full
 
     def forward(self, x, return_border=False):
-        out, _ = bn_act(x, None, self.bn)           # updates the running statistics first, as the reference does
+        # the kernel updates the running statistics first and derives the border from them, as the reference does
+        out, _, border = bn_act(x, None, self.bn, want_border=True)
         if self.pad_pixels == 0:
             return (out, None) if return_border else out
-        border = self.border_values()
+        if self.bn.running_mean is None or not self.bn.affine:
+            border = self.border_values()
         if return_border:                            # RepConv feeds the border to the depthwise kernel directly
             return out, border
         return self.pad(out, border)

@@ -166,10 +166,14 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
         // and performs the running-statistics update (torch.nn.BatchNorm: momentum, unbiased variance)
         stat[c] = mean;
         stat[C + c] = rstd;
+        float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
         if (training && running_mean != nullptr) {
-          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-          running_var[c] = (1.f - momentum) * running_var[c] + momentum * (sstat[2 * C + c] * unbias);
+          rm = (1.f - momentum) * rm + momentum * mean;
+          rv = (1.f - momentum) * rv + momentum * (sstat[2 * C + c] * unbias);
+          running_mean[c] = rm;
+          running_var[c] = rv;
         }
+        stat[2 * C + c] = be - rm * g / sqrtf(rv + eps);      // BN(0) from the (updated) running statistics
         if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
       }
       const Tile4 zv = ld4(z + base);
@@ -408,10 +412,14 @@ __global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
   if (threadIdx.x == 0) {
     stat[c] = mean;
     stat[C + c] = rstd;
+    float rm = 0.f, rv = 1.f;
     if (running_mean != nullptr) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var * unbias);
+      rm = (1.f - momentum) * running_mean[c] + momentum * mean;
+      rv = (1.f - momentum) * running_var[c] + momentum * (var * unbias);
+      running_mean[c] = rm;
+      running_var[c] = rv;
     }
+    stat[2 * C + c] = be - rm * g / sqrtf(rv + eps);          // BN(0) from the (updated) running statistics
     if (c == 0 && num_batches != nullptr) *num_batches += 1;
   }
   uint32_t csum = 0, cnz = 0;

@@ -175,13 +175,13 @@ extern "C" int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, 
 }
 
 extern "C" int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, float* gw, int N, int C, int H,
-                                     int W, int K, int pad, void* stream) {
+                                     int W, int K, int pad, int accumulate, void* stream) {
   S2F_REQUIRE(x && gy && gw, S2F_EINVAL, "s2f_dwconv_bwd_weight: null pointer");
   int Ho, Wo;
   int rc = check("s2f_dwconv_bwd_weight", N, C, H, W, K, pad, Ho, Wo);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C * K * K, s) != hipSuccess)
+  if (!accumulate && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C * K * K, s) != hipSuccess)
     return s2f_check_launch("s2f_dwconv_bwd_weight memset");
   const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
   const dim3 grid(tiles_x * tiles_y, N * C);

@@ -370,13 +370,15 @@ extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const
   return s2f_check_launch("s2f_spike_gemm_fwd");
 }
 
-extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, void* stream) {
+extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
+                                 void* stream) {
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw: null pointer");
   S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
               "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
   S2F_REQUIRE(s2f_aligned16(dY) && s2f_aligned16(X), S2F_EALIGN, "s2f_spike_gemm_dw: dY / X must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess) return s2f_check_launch("s2f_spike_gemm_dw memset");
+  if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess)
+    return s2f_check_launch("s2f_spike_gemm_dw memset");
   const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
   const int total_steps = batch * ((L + BK - 1) / BK);
   // ~1024 workgroups in flight (4 per CU at 40 KiB of LDS each), at least 8 contraction steps per workgroup

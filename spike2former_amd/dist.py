@@ -48,16 +48,67 @@ class FlatGradAllReduce:
             off += p.numel()
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.work = None
+        self.sinks = False
+        self._zero = None
+        self._n_dense = self._dense_elems = None
+
+    def install_sinks(self):
+        """Let the split-K weight-gradient kernels accumulate straight into this buffer (ops.GRAD_SINKS): `zero()` then
+        clears the whole buffer with ONE memset per step instead of one per weight-gradient launch (231 at C2)."""
+        from . import ops
+        ops.GRAD_SINKS = {p.data_ptr(): v for p, v in zip(self.params, self.views)}
+        self.sinks = True
 
     def zero(self):
         """Before backward: drop the old gradients so that autograd assigns instead of accumulating."""
         for p in self.params:
             p.grad = None
+        if self.sinks:
+            self.flat.zero_()
 
     def gather(self):
         """After backward: pack p.grad into the flat buffer (parameters without a gradient keep zeros)."""
-        pieces = [(p.grad if p.grad is not None else v).reshape(-1) for p, v in zip(self.params, self.views)]
-        torch.cat(pieces, out=self.flat)
+        # No gradient tensor: with sinks the parameter's slice already holds the sum (or the zeros of `zero()`) and is left
+        # alone -- the packing runs over the maximal runs of parameters that do have a tensor; without sinks it is a zero.
+        if not self.sinks:
+            if self._zero is None:
+                self._zero = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.flat.device)
+            pieces = [(p.grad if p.grad is not None else self._zero[:p.numel()]).reshape(-1) for p in self.params]
+            torch.cat(pieces, out=self.flat)
+            return
+        if self._n_dense is None:                  # not compacted yet: one batched copy per run of gradient tensors
+            run, start, off = [], 0, 0
+            for p in self.params:
+                if p.grad is not None:
+                    if not run:
+                        start = off
+                    run.append(p.grad.reshape(-1))
+                elif run:
+                    torch.cat(run, out=self.flat[start:off])
+                    run = []
+                off += p.numel()
+            if run:
+                torch.cat(run, out=self.flat[start:off])
+            return
+        dense = self.params[:self._n_dense]
+        if self._zero is None and any(p.grad is None for p in dense):
+            self._zero = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.flat.device)
+        pieces = [(p.grad if p.grad is not None else self._zero[:p.numel()]).reshape(-1) for p in dense]
+        torch.cat(pieces, out=self.flat[:self._dense_elems])
+
+    def compact(self):
+        """After one step with sinks: move the parameters whose gradient arrived through a sink (p.grad is None) behind the
+        others in the flat layout, so that packing stays ONE batched copy over the leading region."""
+        have = [p for p in self.params if p.grad is not None]
+        rest = [p for p in self.params if p.grad is None]
+        self.params = have + rest
+        self._n_dense, self._dense_elems = len(have), sum(p.numel() for p in have)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        if self.sinks:
+            self.install_sinks()
 
     def reduce(self, async_op=True):
         if self.world == 1:

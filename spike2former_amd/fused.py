@@ -1,14 +1,17 @@
 """Module-level glue for the fused BatchNorm(+bias)(+residual)(+Q_IFNode) op.  The nn.BatchNorm / Conv / Q_IFNode
 modules stay in the module tree as parameter and state holders (the checkpoint ABI); their arithmetic is done here."""
+import torch
 import torch.nn.functional as F
 
 from . import ops
 from .neuron import Q_IFNode
 
 
-def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
+def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None,
+           want_border=False):
     """z: conv output WITHOUT its bias, [N, C, *].  Returns (u, y): u = BN(z + bias) [+ residual] (None unless wanted),
-    y = lif(u) (None without lif).  Shapes follow z.
+    y = lif(u) (None without lif).  Shapes follow z.  want_border: also return BN(0) from the running statistics as
+    updated by this call (BNAndPadLayer's padding value, sdtv2.py:68-78) -- written by the same kernel.
     next_lif: the neuron that the caller's consumer will apply to `u` next (the first Q_IFNode of the following block on
     the residual stream).  Its update is done by this kernel as well and handed over with Q_IFNode.prefire: the reference's
     separate neuron pass over u (one more read of u forward; a neuron backward + a gradient add backward) disappears."""
@@ -28,18 +31,21 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         u = F.batch_norm(t, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
         if residual is not None:
             u = u + residual.reshape(shape)
-        return (u if want_pre else None), (lif(u) if lif is not None else None)
+        out = (u if want_pre else None), (lif(u) if lif is not None else None)
+        if want_border:
+            out += ((bn.bias.detach() - bn.running_mean * bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)),)
+        return out
     v_in = None
     if lif is not None and not isinstance(lif.v, float):
         v_in = lif.v
     if lif is not None and lif.stats is not None:
         lif.stats_elems += z.numel()
-    u, y, v_out = ops.bn_act(
+    u, y, v_out, border = ops.bn_act(
         z, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
         bn.num_batches_tracked if training else None, training, bn.momentum, bn.eps,
         residual=residual, lif=lif is not None, want_pre=want_pre, v_in=v_in,
         keep_v=(lif is not None and lif.keep_membrane), D=(lif.D if lif is not None else 8),
-        vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None))
+        vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None), want_border=True)
     if lif is not None:
         lif.v = v_out if lif.keep_membrane else 0.0
-    return u, y
+    return (u, y, border) if want_border else (u, y)

@@ -8,6 +8,7 @@ nothing and never synchronises, so it is capture-safe by construction (s2f_* use
 """
 import torch
 
+from . import ops
 from .neuron import reset_net
 
 
@@ -39,6 +40,7 @@ class GraphedStep:
         out = self.model(self.static_in)
         loss = self.loss_fn(*out)
         loss.backward()
+        ops.wgrad_join()                  # side-stream weight gradients (ops.WGRAD_STREAM) rejoin before packing
         if self.grad_buffer is not None:
             self.grad_buffer.gather()
         return loss.detach()

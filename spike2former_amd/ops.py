@@ -82,6 +82,42 @@ def _need_cuda(*ts):
             raise RuntimeError(f"spike2former_amd ops compute in fp32; got {t.dtype}")
 
 
+# Gradient sinks: {parameter data_ptr: fp32 view of a pre-zeroed flat gradient buffer}.  When a weight has a sink, the
+# split-K weight-gradient kernels add straight into it (no clearing memset per launch, no copy when the gradients are
+# packed) and autograd gets None for that weight.  Installed by dist.FlatGradAllReduce.install_sinks(); None = off.
+GRAD_SINKS = None
+
+
+# Weight gradients that go to a sink are off the critical path of the backward pass (nothing downstream reads them until
+# the gradients are packed): with a side stream set they are launched there, so the short weight-gradient GEMMs of the
+# 32x32 stages overlap the data-gradient chain instead of queueing in it.  wgrad_join() must precede any read of the sinks.
+# Measured at C2 inside the replayed hipGraph: 69.4 ms/step with the side stream vs 67.2 without -- OFF by default.
+WGRAD_STREAM = None
+_WGRAD_KEEP = []          # inputs of in-flight side-stream launches (kept alive until the join)
+
+
+def _wgrad_stream(sink, *inputs):
+    """-> (stream handle to launch on, context manager) for a weight-gradient launch into `sink`."""
+    if WGRAD_STREAM is None or sink is None:
+        return None
+    WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
+    _WGRAD_KEEP.append(inputs)
+    return WGRAD_STREAM
+
+
+def wgrad_join():
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+        _WGRAD_KEEP.clear()
+
+
+def _sink_for(w):
+    if GRAD_SINKS is None:
+        return None
+    v = GRAD_SINKS.get(w.data_ptr())
+    return v if (v is not None and v.numel() == w.numel()) else None
+
+
 STAT_SLOTS = 256         # include/s2f.h S2F_STAT_SLOTS
 
 
@@ -264,7 +300,7 @@ class _BNAct(torch.autograd.Function):
         N, C = z.shape[0], z.shape[1]
         L = z.numel() // (N * C)
         dev = z.device
-        stat = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        stat = torch.empty(3 * C, dtype=torch.float32, device=dev)      # mean, rstd, BN(0) border (s2f.h)
         s = _stream()
         ws = None
         single = bool(training) and bool(lib.s2f_bn_single_pass(N, C, L))    # small map: statistics inside s2f_bn_act_fwd
@@ -288,15 +324,17 @@ class _BNAct(torch.autograd.Function):
                                  _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
                                  _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D, s),
               "s2f_bn_act_fwd")
+        buf = stat
+        stat, border = buf[:2 * C], buf[2 * C:]
         ctx.save_for_backward(z, conv_bias, gamma, stat, mask)
         ctx.cfg = (N, C, L, bool(training), D, vth, residual is not None, conv_bias is not None)
         ctx.set_materialize_grads(False)
         outs = [t if t is not None else z.new_empty(0) for t in (u, y, v_out)]
-        ctx.mark_non_differentiable(*[o for o, t in zip(outs, (u, y, v_out)) if t is None])
-        return tuple(outs)
+        ctx.mark_non_differentiable(border, *[o for o, t in zip(outs, (u, y, v_out)) if t is None])
+        return tuple(outs) + (border,)
 
     @staticmethod
-    def backward(ctx, g_u, g_y, g_v):
+    def backward(ctx, g_u, g_y, g_v, g_border):
         z, conv_bias, gamma, stat, mask = ctx.saved_tensors
         N, C, L, training, D, vth, has_res, has_bias = ctx.cfg
 
@@ -319,19 +357,22 @@ class _BNAct(torch.autograd.Function):
                                  int(training), vth, D, _stream()), "s2f_bn_act_bwd")
         g_bias = None
         if has_bias:
-            # train-mode BN removes any per-channel constant: d/d(bias) == 0; eval mode: sum(gz) = gamma * rstd * dbeta
-            g_bias = torch.zeros_like(dbeta) if training else gamma * stat[C:] * dbeta
+            # train-mode BN removes any per-channel constant: d/d(bias) == 0 exactly -> no gradient tensor at all (None, a
+            # zero-fill launch per BatchNorm otherwise); eval mode: sum(gz) = gamma * rstd * dbeta
+            g_bias = None if training else gamma * stat[C:2 * C] * dbeta
         if ctx.needs_input_grad[5]:
             raise RuntimeError("gradient w.r.t. the incoming membrane is not supported by the fused BN+LIF op")
         return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 13
 
 
 def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, residual=None,
-           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None):
-    """-> (u or None, y or None, v_out or None)"""
-    u, y, v = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
-                           eps, lif, want_pre, keep_v, D, vth, stats)
-    return (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
+           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False):
+    """-> (u or None, y or None, v_out or None [, border]); border [C] = BN(0) from the updated running statistics
+    (BNAndPadLayer's padding value), produced by the same kernel."""
+    u, y, v, border = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
+                                   momentum, eps, lif, want_pre, keep_v, D, vth, stats)
+    out = (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
+    return out + (border,) if want_border else out
 
 
 # ------------------------------------------------------------------------------------------------ depthwise conv
@@ -366,9 +407,12 @@ class _DWConv(torch.autograd.Function):
             check(lib.s2f_dwconv_bwd_input(_ptr(gy), _ptr(w), _ptr(gx), N, C, H, W, K, ctx.pad, _stream()),
                   "s2f_dwconv_bwd_input")
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
-            check(lib.s2f_dwconv_bwd_weight(_ptr(x), _ptr(border), _ptr(gy), _ptr(gw), N, C, H, W, K, ctx.pad,
-                                            _stream()), "s2f_dwconv_bwd_weight")
+            sink = _sink_for(w)
+            gw = torch.empty_like(w) if sink is None else None
+            side = _wgrad_stream(sink, gy, x, border)
+            check(lib.s2f_dwconv_bwd_weight(_ptr(x), _ptr(border), _ptr(gy), _ptr(gw if sink is None else sink), N, C, H, W,
+                                            K, ctx.pad, int(sink is not None),
+                                            side.cuda_stream if side is not None else _stream()), "s2f_dwconv_bwd_weight")
         return gx, gw, None, None
 
 
@@ -431,9 +475,13 @@ class _SpikeGemm(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 64:     # 128-row tiles: M <= 32 wastes 3/4 of the MFMAs
                 M, K = w2d.shape
-                gw = torch.empty(M, K, dtype=torch.float32, device=x.device)
+                sink = _sink_for(w2d)
+                gw = torch.empty(M, K, dtype=torch.float32, device=x.device) if sink is None else None
                 _time_next("spike_gemm_dw", 4 * B * x.shape[2] * (K + M), 2 * B * M * x.shape[2] * K * 3)
-                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw), B, M, K, x.shape[2], _stream()), "s2f_spike_gemm_dw")
+                side = _wgrad_stream(sink, gy, x)
+                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, x.shape[2],
+                                            int(sink is not None), side.cuda_stream if side is not None else _stream()),
+                      "s2f_spike_gemm_dw")
             else:
                 gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -573,12 +621,16 @@ class _ConvDense(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             K = w2d.shape[1]
             if use_mfma and SPIKE_GEMM_DW and M >= 64:
-                gw = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+                sink = _sink_for(weight)
+                gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
                 _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K * 3)
-                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw), N, M, K, Ho * Wo, _stream()), "s2f_spike_gemm_dw")
+                side = _wgrad_stream(sink, gy, cols)
+                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                            int(sink is not None), side.cuda_stream if side is not None else _stream()),
+                      "s2f_spike_gemm_dw")
             else:
                 gw = torch.bmm(gy, cols.transpose(1, 2)).sum(0)
-            gw = gw.view_as(weight)
+            gw = gw.view_as(weight) if gw is not None else None
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2))
         return gx, gw, gb, None, None, None

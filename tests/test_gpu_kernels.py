@@ -321,8 +321,11 @@ def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
     rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")
     fstats = ops.new_stats("cuda") if lif else None
-    uu, yy, _ = ops.bn_act(zc, bc, gc, bec, rmc, rvc, nbt if training else None, training, 0.1, 1e-5, residual=rc,
-                           lif=lif, want_pre=True, stats=fstats)
+    uu, yy, _, border = ops.bn_act(zc, bc, gc, bec, rmc, rvc, nbt if training else None, training, 0.1, 1e-5, residual=rc,
+                                   lif=lif, want_pre=True, stats=fstats, want_border=True)
+    # BNAndPadLayer's padding value BN(0), from the running statistics AFTER this call's update (sdtv2.py:68-78)
+    bref = beta - rmo * gamma / torch.sqrt(rvo + 1e-5)
+    assert (border.cpu() - bref).abs().max().item() <= 1e-5 * max(bref.abs().max().item(), 1.0)
     if lif:
         cnt = torch.round(yy.detach() * 8).long()
         assert ops.read_stats(fstats).tolist() == [int(cnt.sum()), int((cnt != 0).sum())]
@@ -339,7 +342,7 @@ def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
         assert d.abs().max().item() <= 1 and (d != 0).float().mean().item() <= 1e-4
     if training:
         assert close(rmc, rmo, 1e-5) and close(rvc, rvo, 1e-5) and int(nbt) == 1
-        assert bc.grad.abs().max().item() == 0.0          # train-mode BN removes the conv bias gradient exactly
+        assert bc.grad is None or bc.grad.abs().max().item() == 0.0   # train-mode BN removes the conv bias gradient exactly
     else:
         assert close(bc.grad, bo.grad, 1e-4)
     flips = lif and (d != 0).any().item()
@@ -479,7 +482,7 @@ def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
     scale = torch.einsum("bml,bkl->mk", gy.abs().double(), x.abs().double()).max().item()
     gyc, xc = gy.cuda(), x.cuda()
     out = torch.full((M, K), float("nan"), device="cuda")
-    assert lib.s2f_spike_gemm_dw(gyc.data_ptr(), xc.data_ptr(), out.data_ptr(), B, M, K, L, None) == 0
+    assert lib.s2f_spike_gemm_dw(gyc.data_ptr(), xc.data_ptr(), out.data_ptr(), B, M, K, L, 0, None) == 0
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 3e-6 * scale, (err, scale)
 

@@ -42,3 +42,8 @@ for e in rows[:150]:
     if e.self_device_time_total < 50:
         break
     print(f"{e.self_device_time_total:9.0f} us {e.count:4d}x {e.key[:48]:48s} {str(e.input_shapes)[:150]}")
+print("== ATen ops only (library / glue), by op and input shape")
+for e in rows:
+    if e.self_device_time_total < 15 or not (e.key.startswith("aten::") or e.key.startswith("Mem")):
+        continue
+    print(f"{e.self_device_time_total:9.0f} us {e.count:4d}x {e.key[:28]:28s} {str(e.input_shapes)[:170]}")
