@@ -223,14 +223,23 @@ __device__ __forceinline__ void split3x2(float v0, float v1, unsigned int& h, un
   l = pack2(f32x2{r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u)});
 }
 
+// BKV = contraction elements per step (64 when the rows allow it: half the barriers per element).  Measured with one
+// workgroup per CU: 1.15 us per 32-wide step whether one or two steps are prefetched, i.e. NOT load latency -- the step is
+// issue-bound (operand split + LDS staging ~1000 VALU cycles, 24 MFMAs 768 cycles, LDS ~300, serial within a wave; they
+// only overlap across the two waves a SIMD holds).  LDS rows are BKV + 8 bf16 (80 / 144 bytes: odd multiples of 16 bytes,
+// conflict-free ds_read_b128 fragments).
+template <int BKV>
 __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                             float* __restrict__ dW, int B, int M, int K, int L,
                                                             int steps_per_split, int k_tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned short As[3][128][LDR];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[128][LDR];
+  constexpr int LD = BKV + 8;
+  constexpr int QPR = BKV / 4;                 // float4 chunks per row
+  constexpr int NH = 128 * QPR / 256;          // chunks per thread and operand
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][128][LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[128][LD];
   const int tile = blockIdx.x;
   const int m0 = (tile / k_tiles) * 128, k0 = (tile % k_tiles) * 128;
-  const int lsteps = (L + BK - 1) / BK;
+  const int lsteps = (L + BKV - 1) / BKV;
   const int total_steps = B * lsteps;
   const int s_begin = blockIdx.y * steps_per_split;
   const int s_end = min(total_steps, s_begin + steps_per_split);
@@ -246,14 +255,14 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 areg[4], breg[4];
-  // chunk c = tid + h*256 (h = 0..3): row = c >> 3 (0..127), 16-byte column lq = c & 7 (4 floats each, 32 per row)
-  auto fetch = [&](int step, f32x4 (&a)[4], f32x4 (&bq)[4]) {
-    const int b = step / lsteps, l0 = (step - b * lsteps) * BK;
+  f32x4 areg[NH], breg[NH];
+  // chunk c = tid + h*256: row = c / QPR (0..127), 16-byte column c % QPR (4 floats each)
+  auto fetch = [&](int step, f32x4 (&a)[NH], f32x4 (&bq)[NH]) {
+    const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int c = tid + h * 256;
-      const int row = c >> 3, l = l0 + (c & 7) * 4;
+      const int row = c / QPR, l = l0 + (c % QPR) * 4;
       const bool lok = l < L;                                       // L % 4 == 0: the whole float4 is valid or not
       a[h] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -264,9 +273,9 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
   fetch(s_begin, areg, breg);
   for (int step = s_begin; step < s_end; ++step) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int c = tid + h * 256;
-      const int row = c >> 3, col = (c & 7) * 4;
+      const int row = c / QPR, col = (c % QPR) * 4;
       unsigned int h0, m0_, l0_, h1, m1, l1;
       split3x2(areg[h].x, areg[h].y, h0, m0_, l0_);
       split3x2(areg[h].z, areg[h].w, h1, m1, l1);
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
     __syncthreads();
     if (step + 1 < s_end) fetch(step + 1, areg, breg);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BKV / 16; ++ks) {
       const int kof = ks * 16 + 8 * (lane >> 5);
       bf16x8 bfrag[2];
 #pragma unroll
@@ -380,16 +389,33 @@ extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int
   if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess)
     return s2f_check_launch("s2f_spike_gemm_dw memset");
   const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
-  const int total_steps = batch * ((L + BK - 1) / BK);
-  // ~1024 workgroups in flight (4 per CU at 40 KiB of LDS each), at least 8 contraction steps per workgroup
-  int splits = 1024 / (m_tiles * k_tiles);
-  if (splits < 1) splits = 1;
-  if (splits > (total_steps + 7) / 8) splits = (total_steps + 7) / 8;
-  if (splits < 1) splits = 1;
+  const int bkv = (L % 64 == 0 || L >= 512) ? 64 : 32;          // short ragged rows keep the 32-wide step
+  const int total_steps = batch * ((L + bkv - 1) / bkv);
+  // Split count from a two-term cost model fitted on MI355X (tools/probe: one split = one workgroup per output tile):
+  //   a workgroup spends ~2.3 us per 64-wide (1.2 us per 32-wide) contraction step, 512 workgroups run at a time;
+  //   every split adds its M x K partial tile into dW with fp32 atomics at ~1.7 TB/s (0.6 us per MB).
+  const int tiles = m_tiles * k_tiles;
+  const double t_step = bkv == 64 ? 2.3 : 1.2, t_mb = 0.6 * (double)M * K * 4.0 / 1e6;
+  int splits = 1;
+  double best = 1e30;
+  for (int cand = 1; cand <= total_steps && cand <= 65535; cand *= 2) {
+    const int steps = (total_steps + cand - 1) / cand;
+    const int64_t rounds = ((int64_t)tiles * cand + 511) / 512;
+    const double cost = (double)steps * t_step * (double)rounds + (double)cand * t_mb;
+    if (cost < best) {
+      best = cost;
+      splits = cand;
+    }
+  }
+  if (splits > total_steps) splits = total_steps;
   if (splits > 65535) splits = 65535;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
-  S2F_LAUNCH(true, true, spike_gemm_dw_kernel, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K, L,
-                     steps_per_split, k_tiles);
+  if (bkv == 64)
+    S2F_LAUNCH(true, true, spike_gemm_dw_kernel<64>, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K,
+               L, steps_per_split, k_tiles);
+  else
+    S2F_LAUNCH(true, true, spike_gemm_dw_kernel<32>, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K,
+               L, steps_per_split, k_tiles);
   return s2f_check_launch("s2f_spike_gemm_dw");
 }
