@@ -36,13 +36,20 @@ class SepConv_Spike(nn.Module):
         self.pwconv2 = nn.Sequential(Conv2d(med, dim, kernel_size=1, stride=1, bias=bias), nn.BatchNorm2d(dim))
         spikes_in(self.pwconv1[0], self.pwconv2[0])       # both follow a neuron (spike1, spike3)
 
-    def forward(self, x):
-        T, B, H, W, C = x.shape
-        x = self.spike1(x.permute(0, 1, 4, 2, 3).contiguous()).flatten(0, 1)
+    def forward_nchw(self, x, scale=None, residual=None, next_lif=None):
+        """Channel-major form: x, residual, result [T,B,C,H,W].  -> scale * SepConv(x) [+ residual]; the layer scale, the
+        residual add and the next neuron on the stream are folded into the last BatchNorm kernel (fused.bn_act)."""
+        T, B, C, H, W = x.shape
+        x = self.spike1(x).flatten(0, 1)
         _, x = bn_act(self.pwconv1[0](x), None, self.pwconv1[1], lif=self.spike2)
         _, x = bn_act(self.dwconv[0](x), None, self.dwconv[1], lif=self.spike3)
-        x, _ = bn_act(self.pwconv2[0](x), None, self.pwconv2[1])
-        return x.reshape(T, B, C, H, W).permute(0, 1, 3, 4, 2).contiguous()
+        x, _ = bn_act(self.pwconv2[0](x), None, self.pwconv2[1], scale=scale, next_lif=next_lif,
+                      residual=None if residual is None else residual.flatten(0, 1))
+        return x.reshape(T, B, C, H, W)
+
+    def forward(self, x):
+        """The reference's interface: NHWC in, NHWC out (SNN_core.py:46-63)."""
+        return self.forward_nchw(x.permute(0, 1, 4, 2, 3).contiguous()).permute(0, 1, 3, 4, 2).contiguous()
 
 
 class MLP(nn.Module):
@@ -109,19 +116,28 @@ class DCNv3_pytorch(nn.Module):
             nn.init.constant_(m.weight, 0.0)
             nn.init.constant_(m.bias, 0.0)
 
-    def forward(self, inp):
-        T, N, H, W, C = inp.shape
-        x = self.input_proj(inp)
-        x1 = self.dw_spike(inp.permute(0, 1, 4, 2, 3).contiguous()).flatten(0, 1)
+    def forward_nchw(self, inp, scale=None, residual=None, next_lif=None):
+        """Channel-major form: inp, residual, result [T,N,C,H,W].  Only the sampling core works on NHWC (its gather reads
+        the Cg channels of a group as one vector): one transposition in, one out, instead of the reference's permute pair
+        around every sub-module."""
+        T, N, C, H, W = inp.shape
+        x = self.input_proj.forward_nchw(inp)
+        x = x.permute(0, 1, 3, 4, 2).contiguous().flatten(0, 1)              # [T*N, H, W, C]
+        x1 = self.dw_spike(inp).flatten(0, 1)
         _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
         # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
         offset, _ = bn_act(self.offset[0].forward_nobias(x1), self.offset[0].bias, self.offset[1])
         _, mask = bn_act(self.mask[0].forward_nobias(x1), self.mask[0].bias, self.mask[1], lif=self.mask_spike)
         offset, mask = offset.reshape(T * N, H, W, -1), mask.reshape(T * N, H, W, -1)
         k = self.kernel_size
-        y = ops.dcnv3_core(x.flatten(0, 1), offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
+        y = ops.dcnv3_core(x, offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
                            self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale)
-        return self.output_proj(y.reshape(T, N, H, W, C))
+        y = y.view(T, N, H, W, C).permute(0, 1, 4, 2, 3).contiguous()
+        return self.output_proj.forward_nchw(y, scale=scale, residual=residual, next_lif=next_lif)
+
+    def forward(self, inp):
+        """The reference's interface: NHWC in, NHWC out (dcnv3.py:198-233)."""
+        return self.forward_nchw(inp.permute(0, 1, 4, 2, 3).contiguous()).permute(0, 1, 3, 4, 2).contiguous()
 
 
 class MS_MLP(nn.Module):
@@ -142,13 +158,18 @@ class MS_MLP(nn.Module):
         self.fc2_bn = nn.BatchNorm1d(embed_dims)
         spikes_in(self.fc1_conv, self.fc2_conv)
 
-    def forward(self, x):
-        T, B, H, W, C = x.shape
-        x = self.fc1_spike(x.permute(0, 1, 4, 2, 3).contiguous().flatten(3)).flatten(0, 1)
+    def forward_nchw(self, x):
+        """x [T,B,C,H,W] -> the FFN output as it lies in memory, [T*B, C, H*W] (the caller applies the reference's
+        reinterpretation of that buffer as [T,B,H,W,C], :829)."""
+        x = self.fc1_spike(x.flatten(3)).flatten(0, 1)
         _, x = bn_act(self.fc1_conv.forward_nobias(x), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
         x, _ = bn_act(self.fc2_conv.forward_nobias(x), self.fc2_conv.bias, self.fc2_bn)
+        return x
+
+    def forward(self, x):
+        T, B, H, W, C = x.shape
         # bug-compatible: [T*B, C, N] reinterpreted as [T, B, H, W, C] (:829)
-        return x.reshape(T, B, H, W, C)
+        return self.forward_nchw(x.permute(0, 1, 4, 2, 3).contiguous()).reshape(T, B, H, W, C)
 
 
 class DCNDetrTransformerEncoderLayer(nn.Module):
@@ -174,10 +195,21 @@ class DCNDetrTransformerEncoderLayer(nn.Module):
         self.gamma2 = nn.Parameter(self.layer_scale * torch.ones(self.embed_dims))
         self.gamma3 = nn.Parameter(self.layer_scale * torch.ones(self.embed_dims))
 
+    def forward_nchw(self, q, next_lif=None):
+        """The layer on the channel-major stream q [T,B,C,H,W] (value-identical to `forward` on q.permute(0,1,3,4,2)): the
+        reference permutes to NCHW and back around each of the six sub-modules; here the stream stays NCHW, every
+        `q + gamma * f(q)` is folded into f's last BatchNorm kernel, and only the DCN core and the FFN's memory
+        reinterpretation transpose anything."""
+        T, B, C, H, W = q.shape
+        q = self.Conv.forward_nchw(q, scale=self.gamma1, residual=q, next_lif=self.dcn.input_proj.spike1)
+        q = self.dcn.forward_nchw(q, scale=self.gamma2, residual=q, next_lif=self.ffn.fc1_spike)
+        m = self.ffn.forward_nchw(q)                                     # [T*B, C, H*W] in memory == [T,B,H,W,C] semantically
+        m = m.view(T, B, H * W, C).permute(0, 1, 3, 2).reshape(T, B, C, H, W)
+        return torch.addcmul(q, m, self.gamma3.view(1, 1, C, 1, 1))
+
     def forward(self, query):
-        query = query + self.gamma1 * self.Conv(query)
-        query = query + self.gamma2 * self.dcn(query)
-        return query + self.gamma3 * self.ffn(query)
+        """The reference's interface: NHWC in, NHWC out (detr_layers.py:331-337)."""
+        return self.forward_nchw(query.permute(0, 1, 4, 2, 3).contiguous()).permute(0, 1, 3, 4, 2).contiguous()
 
 
 class DCNDetrTransformerEncoder(nn.Module):
@@ -188,10 +220,14 @@ class DCNDetrTransformerEncoder(nn.Module):
         self.layers = nn.ModuleList([DCNDetrTransformerEncoderLayer(**self.layer_cfg) for _ in range(num_layers)])
         self.embed_dims = self.layers[0].embed_dims
 
-    def forward(self, query):
+    def forward_nchw(self, q):
         for layer in self.layers:
-            query = layer(query)
-        return query
+            q = layer.forward_nchw(q)
+        return q
+
+    def forward(self, query):
+        """NHWC in, NHWC out (the reference's interface); the layers run on the channel-major stream."""
+        return self.forward_nchw(query.permute(0, 1, 4, 2, 3).contiguous()).permute(0, 1, 3, 4, 2).contiguous()
 
 
 class MultiHeadAttentionBlock(nn.Module):

@@ -74,8 +74,7 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
 
         y = self.last_feat_conv_spike(x4)
         y = conv_bn(self.encoder_in_proj, y.flatten(0, 1))[0].reshape(t, bs, E, h, w)
-        memory = self.encoder(query=y.permute(0, 1, 3, 4, 2))
-        memory = memory.permute(0, 1, 4, 2, 3).contiguous()
+        memory = self.encoder.forward_nchw(y)          # == encoder(query=y.permute(0,1,3,4,2)).permute(0,1,4,2,3)
         memory = self.encoder_out_proj_spike(memory)
         y = conv_bn(self.encoder_out_proj, memory.flatten(0, 1))[0]
         out = [y.reshape(t, bs, E, h, w)]
