@@ -471,7 +471,12 @@ class _SpikeGemm(torch.autograd.Function):
         B = x.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.bmm(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
+            if gy.shape[2] <= 128 and w2d.shape[0] <= 512 and w2d.shape[1] <= 512:
+                # rocBLAS picks a 40 us kernel for the batched [256x256]^T @ [256x100] of the decoder (tools/probe_small_dx.py);
+                # the same product through einsum's folding takes 12 us
+                gx = torch.einsum("mk,bml->bkl", w2d, gy)
+            else:
+                gx = torch.bmm(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
         if ctx.needs_input_grad[1]:
             if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 64:     # 128-row tiles: M <= 32 wastes 3/4 of the MFMAs
                 M, K = w2d.shape
