@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 5
+#define S2F_ABI_VERSION 6
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -140,6 +140,20 @@ int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, 
 int s2f_split_bf16x3(const float* w, uint16_t* w_split, int M, int K, int Mpad, int Kpad, void* stream);
 int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int N,
                        int K, int Mpad, int Kpad, int terms, void* stream);
+/* General split GEMM on the same kernel structure:  Y[b] (M x N) = out_scale * A[b] (M x K) @ X[b] (K x N).
+ *   a_split: bf16 terms as written by s2f_split_bf16x3: term i of batch b starts at a_split + i*a_term_stride +
+ *     b*a_batch_stride (ELEMENTS; rows Kpad apart, Mpad readable rows per batch; a_batch_stride = 0 shares one A; several
+ *     batches may be row blocks of ONE split matrix); a_terms in {1, 3} = terms used (1: A exact in bf16, e.g. spikes).
+ *   X: fp32; row k of batch b lies at X + b*x_batch_stride + (k / k_inner)*x_outer_stride + (k % k_inner)*N (floats): a
+ *     contraction over the T slabs of a [T, B, C, HW] tensor is ONE launch with K = T*C, k_inner = C, x_outer_stride =
+ *     B*C*HW.  x_terms in {1, 3}: X is split in the kernel into that many bf16 terms.
+ *   (a_terms, x_terms) = (1,3) or (3,1): 3 MFMA passes, exact products; (3,3): 6 passes (terms i + j <= 2), 2^-24.
+ *   Mpad % 128 == 0, Kpad % 32 == 0, N % 4 == 0.  Call sites: the mask einsum 'ltbqc,tbchw->ltbqhw' + mean over t
+ *   (mmdet/models/dense_heads/maskformer_head.py:582-583) forward and its d(mask_features). */
+int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_term_stride, int a_terms, const float* X,
+                   int64_t x_batch_stride,
+                   int k_inner, int64_t x_outer_stride, int x_terms, float* Y, int64_t y_batch_stride, float out_scale,
+                   int batch, int M, int N, int K, int Mpad, int Kpad, void* stream);
 /* Weight gradient of the same convolution:  dW[m][k] = sum_b sum_l dY[b][m][l] * X[b][k][l]   (dY [batch, M, L],
  * X [batch, K, L] spikes, dW [M, K] overwritten).  X is exact in bf16; dY is split on the fly into hi + mid + lo bf16
  * terms: three MFMA passes, exact products, fp32 accumulation (split-K partial tiles are combined with fp32 atomics, so

@@ -63,6 +63,19 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ w, unsigned short*
   }
 }
 
+// (v0, v1) -> three packed bf16 pairs hi, mid, lo with v = hi + mid + lo to 24 bits; v_cvt_pk_bf16_f32 rounds to nearest
+// even, the residuals are exact fp32 subtractions.
+__device__ __forceinline__ unsigned int pack2(f32x2 v) {
+  bf16x2 b = __builtin_convertvector(v, bf16x2);
+  return *reinterpret_cast<unsigned int*>(&b);
+}
+__device__ __forceinline__ void split3x2(float v0, float v1, unsigned int& h, unsigned int& m, unsigned int& l) {
+  h = pack2(f32x2{v0, v1});
+  const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+  m = pack2(f32x2{r0, r1});
+  l = pack2(f32x2{r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u)});
+}
+
 // global -> registers for the K step starting at kk (issued one step ahead of its use: the loads fly under the MFMAs)
 template <int WM, int TERMS>
 __device__ __forceinline__ void fetch_tile(u32x4 (&areg)[TERMS][2], f32x4 (&breg)[(256 + 128 * WM - 1) / (128 * WM)][4],
@@ -202,6 +215,138 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// General form of the same kernel:  Y[b] (M x N) = out_scale * A[b] (M x K) @ X[b] (K x N)  with
+//   A : pre-split bf16 terms [AT][Mpad][Kpad] per batch (a_batch_stride elements apart; 0 = one A for all batches);
+//   X : fp32, row k of batch b at  X + b*x_batch_stride + (k / k_inner)*x_outer_stride + (k % k_inner)*N  (the two-level
+//       row index lets the T slabs of a [T, B, C, HW] tensor act as ONE contraction of length T*C), split IN THE KERNEL
+//       into BT bf16 terms while it is transposed into LDS.
+// The bf16 products of term a_i x b_j are issued for i + j < max(AT, BT): (3,1) / (1,3) = 3 MFMA passes (one operand exact
+// in bf16, e.g. spikes), (3,3) = 6 passes = two general fp32 operands to 2^-24.  Used for the mask einsum (SDME):
+// forward (1,3) with K = T*C, d(mask_features) (1,3); same tiling and LDS layout as spike_gemm_kernel.
+template <int WM, int AT, int BT>
+__global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned short* __restrict__ A, int64_t a_batch_stride,
+                                                              int64_t term_stride, const float* __restrict__ X,
+                                                              int64_t x_batch_stride,
+                                                              int k_inner, int64_t x_outer_stride, float* __restrict__ Y,
+                                                              int64_t y_batch_stride, float out_scale, int M, int N, int K,
+                                                              int Mpad, int Kpad, int n_tiles, int m_tiles) {
+  constexpr int BM = 64 * WM;
+  constexpr int T = 128 * WM;
+  constexpr int NP = (256 + T - 1) / T;
+  constexpr int MAXT = AT > BT ? AT : BT;
+  __shared__ __attribute__((aligned(16))) unsigned short As[AT][BM][LDR];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[BT][BN][LDR];
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const unsigned short* Ab = A + (int64_t)b * a_batch_stride;
+  const float* Xb = X + (int64_t)b * x_batch_stride;
+  float* Yb = Y + (int64_t)b * y_batch_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 areg[AT][2];
+  f32x4 breg[NP][4];
+  auto fetch = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = tid + h * T;
+        areg[t][h] = *reinterpret_cast<const u32x4*>(Ab + t * term_stride + (int64_t)(m0 + (c >> 2)) * Kpad + kk + (c & 3) * 8);
+      }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int p = tid + q * T;
+      const int kb = p / (BN / 4), nb = p % (BN / 4);
+      const int n = n0 + nb * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kk + kb * 4 + r;
+        const float* row = Xb + (int64_t)(k / k_inner) * x_outer_stride + (int64_t)(k % k_inner) * N;
+        breg[q][r] = (p < 256 && k < K && n < N) ? *reinterpret_cast<const f32x4*>(row + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < Kpad; k0 += BK) {
+#pragma unroll
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = tid + h * T;
+        *reinterpret_cast<u32x4*>(&As[t][c >> 2][(c & 3) * 8]) = areg[t][h];
+      }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int p = tid + q * T;
+      if (p < 256) {
+        const int kb = p / (BN / 4), nb = p % (BN / 4);
+        const int kc = ((((kb >> 1) ^ (nb >> 2)) & 3) << 3) + ((kb & 1) << 2);          // swizzle as in spike_gemm_kernel
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned int h0, m0_, l0_, h1, m1, l1;
+          split3x2(breg[q][0][e], breg[q][1][e], h0, m0_, l0_);
+          split3x2(breg[q][2][e], breg[q][3][e], h1, m1, l1);
+          *reinterpret_cast<u32x2*>(&Bs[0][nb * 4 + e][kc]) = u32x2{h0, h1};
+          if (BT > 1) *reinterpret_cast<u32x2*>(&Bs[BT > 1 ? 1 : 0][nb * 4 + e][kc]) = u32x2{m0_, m1};
+          if (BT > 2) *reinterpret_cast<u32x2*>(&Bs[BT > 2 ? 2 : 0][nb * 4 + e][kc]) = u32x2{l0_, l1};
+        }
+      }
+    }
+    __syncthreads();
+    if (k0 + BK < Kpad) fetch(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kof = ks * 16 + 8 * (lane >> 5);
+      bf16x8 bfrag[BT][2];
+#pragma unroll
+      for (int tb = 0; tb < BT; ++tb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = wn * 64 + j * 32 + (lane & 31);
+          bfrag[tb][j] = *reinterpret_cast<const bf16x8*>(&Bs[tb][row][(((kof >> 3) ^ (row >> 4)) & 3) << 3]);
+        }
+#pragma unroll
+      for (int ta = 0; ta < AT; ++ta)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[ta][wm * 64 + i * 32 + (lane & 31)][kof]);
+#pragma unroll
+          for (int tb = 0; tb < BT; ++tb)
+            if (ta + tb < MAXT)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[tb][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) Yb[(int64_t)row * N + col] = acc[i][j][r] * out_scale;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the spike GEMM:  dW[m][k] = sum_b sum_l dY[b][m][l] * X[b][k][l]      (dY: [B, M, L], X: [B, K, L])
 // Both operands are contraction-contiguous (L is the fast axis of the channel-major activations), so the MFMA fragments
 // are plain k-contiguous LDS rows -- no transposition.  X holds spikes (exact in bf16, one term); dY is a general fp32
@@ -210,19 +355,6 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
 // the 256x256 maps) while the output is only M x K, so it is split over `splits` workgroups per output tile that add
 // their partial tiles into the zero-initialised dW with fp32 atomics.
 // Block = 4 wavefronts (2 x 2), output tile 128 x 128, contraction step 32, register prefetch of the next step.
-// (v0, v1) -> three packed bf16 pairs hi, mid, lo with v = hi + mid + lo to 24 bits; v_cvt_pk_bf16_f32 rounds to nearest
-// even, the residuals are exact fp32 subtractions.
-__device__ __forceinline__ unsigned int pack2(f32x2 v) {
-  bf16x2 b = __builtin_convertvector(v, bf16x2);
-  return *reinterpret_cast<unsigned int*>(&b);
-}
-__device__ __forceinline__ void split3x2(float v0, float v1, unsigned int& h, unsigned int& m, unsigned int& l) {
-  h = pack2(f32x2{v0, v1});
-  const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
-  m = pack2(f32x2{r0, r1});
-  l = pack2(f32x2{r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u)});
-}
-
 // BKV = contraction elements per step (64 when the rows allow it: half the barriers per element).  Measured with one
 // workgroup per CU: 1.15 us per 32-wide step whether one or two steps are prefetched, i.e. NOT load latency -- the step is
 // issue-bound (operand split + LDS staging ~1000 VALU cycles, 24 MFMAs 768 cycles, LDS ~300, serial within a wave; they
@@ -377,6 +509,37 @@ extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const
 #undef S2F_GEMM_T
 #undef S2F_GEMM_GO
   return s2f_check_launch("s2f_spike_gemm_fwd");
+}
+
+extern "C" int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_term_stride, int a_terms,
+                              const float* X, int64_t x_batch_stride, int k_inner, int64_t x_outer_stride, int x_terms, float* Y,
+                              int64_t y_batch_stride, float out_scale, int batch, int M, int N, int K, int Mpad, int Kpad,
+                              void* stream) {
+  S2F_REQUIRE(a_split && X && Y, S2F_EINVAL, "s2f_split_gemm: null pointer");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N > 0 && K > 0 && k_inner > 0, S2F_EINVAL, "s2f_split_gemm: bad sizes");
+  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "s2f_split_gemm: N=%d must be a multiple of 4", N);
+  S2F_REQUIRE(Kpad >= K && Kpad % 32 == 0 && Mpad >= M && Mpad % 128 == 0, S2F_EINVAL,
+              "s2f_split_gemm: need Kpad %% 32 == 0 and Mpad %% 128 == 0");
+  S2F_REQUIRE((a_terms == 1 && x_terms == 3) || (a_terms == 3 && x_terms == 3) || (a_terms == 3 && x_terms == 1), S2F_EINVAL,
+              "s2f_split_gemm: (a_terms, x_terms) must be (1,3), (3,1) or (3,3)");
+  S2F_REQUIRE(s2f_aligned16(a_split) && s2f_aligned16(X) && s2f_aligned16(Y) && (x_batch_stride & 3) == 0 &&
+                  (x_outer_stride & 3) == 0 && (a_batch_stride & 7) == 0 && (a_term_stride & 7) == 0,
+              S2F_EALIGN, "s2f_split_gemm: pointers / strides must keep 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_tiles = (N + BN - 1) / BN, m_tiles = Mpad / 128;
+  const dim3 grid(n_tiles * m_tiles, batch);
+#define S2F_SG(AT, BT)                                                                                                  \
+  S2F_LAUNCH(true, true, (split_gemm_kernel<2, AT, BT>), grid, dim3(256), 0, s, a_split, a_batch_stride, a_term_stride, X, \
+             x_batch_stride,                                                                                              \
+             k_inner, x_outer_stride, Y, y_batch_stride, out_scale, M, N, K, Mpad, Kpad, n_tiles, m_tiles)
+  if (a_terms == 1)
+    S2F_SG(1, 3);
+  else if (x_terms == 1)
+    S2F_SG(3, 1);
+  else
+    S2F_SG(3, 3);
+#undef S2F_SG
+  return s2f_check_launch("s2f_split_gemm");
 }
 
 extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,

@@ -119,7 +119,8 @@ class MaskFormerHead(nn.Module):
         # [L+1,T,B,Q,H,W] intermediate (734 MB / image at 512^2, T=4) is never materialised.
         Hm, Wm = mask_features.shape[-2:]
         eq = e.permute(1, 2, 0, 3, 4).reshape(t, bs, ln * nq, C)        # [t, b, L*Q, C]: all L+1 predictions in one GEMM
-        acc = ops.mask_einsum(eq, mask_features.flatten(3), 1.0 / t)      # [b, L*Q, HW]
+        # e = alpha * spikes with alpha = 4: multiples of 1/2 <= 4, exact in bf16 -> the matrix-core path of ops.mask_einsum
+        acc = ops.mask_einsum(eq, mask_features.flatten(3), 1.0 / t, e_exact=float(self.alpha) == 4.0)      # [b, L*Q, HW]
         all_mask_preds = acc.view(bs, ln, nq, Hm, Wm).permute(1, 0, 2, 3, 4)
         return all_cls_scores, all_mask_preds
 

@@ -499,48 +499,83 @@ def spike_gemm(x, w2d, bias=None):
 
 
 # ------------------------------------------------------------------------------------------------ mask einsum (SDME)
+def _split_rows(mat, slack_rows):
+    """fp32 [R, K] -> bf16 terms [3, Rpad, Kpad] (s2f_split_bf16x3), Rpad >= R + slack_rows (zero rows: a row-block view of
+    the matrix may over-read that many rows past its end)."""
+    R, K = mat.shape
+    Rpad, Kpad = (R + slack_rows + 63) // 64 * 64, (K + 31) // 32 * 32
+    out = torch.empty(3, Rpad, Kpad, dtype=torch.int16, device=mat.device)
+    check(lib.s2f_split_bf16x3(_ptr(mat), _ptr(out), R, K, Rpad, Kpad, _stream()), "s2f_split_bf16x3")
+    return out, Rpad, Kpad
+
+
 class _MaskEinsum(torch.autograd.Function):
     """out[b] = scale * sum_t E[t, b] @ MF[t, b]   (E [T,B,Q,C], MF [T,B,C,HW] -> [B,Q,HW]).
 
-    = einsum('tbqc,tbchw->tbqhw').mean(t) of maskformer_head.py:582-583 with the mean folded into the contraction.  As a
-    Function the T partial products accumulate in the GEMM epilogue (baddbmm, in place) and the backward writes each
+    = einsum('tbqc,tbchw->tbqhw').mean(t) of maskformer_head.py:582-583 with the mean folded into the contraction.
+    `e_exact`: E is exactly representable in bf16 (the head passes alpha * spikes = multiples of 1/2): forward and
+    d(mask_features) then run on the bf16 matrix cores with MF / the incoming gradient split hi+mid+lo in the kernel
+    (s2f_split_gemm, 3 passes, exact products, fp32 accumulation) -- the forward as ONE GEMM of K = T*C, no partial-sum
+    traffic.  dE (two general fp32 operands, K = HW) and the non-exact case stay on rocBLAS fp32.  The backward writes each
     dMF[t] / dE[t] slice straight into its final buffer: autograd's select_backward would zero-fill and add T full-size
     [T,B,C,HW] tensors (4 x 537 MB at C2)."""
 
     @staticmethod
-    def forward(ctx, e, mf, scale):
+    def forward(ctx, e, mf, scale, e_exact):
         _need_cuda(e, mf)
         T, B, Q, C = e.shape
+        HW = mf.shape[-1]
         e = e.contiguous()
         mf = mf.contiguous()
-        es = e * scale
-        out = torch.bmm(es[0], mf[0])
-        for t in range(1, T):
-            torch.baddbmm(out, es[t], mf[t], out=out)
-        ctx.save_for_backward(es, mf)
-        ctx.scale = scale
+        mfma = bool(e_exact) and HW % 4 == 0 and SPIKE_GEMM_ENABLED
+        if SPIKE_GEMM_CHECK and mfma:
+            assert torch.equal(e, e.bfloat16().float()), "mask_einsum: E is not exact in bf16"
+        if mfma:
+            acat = e.permute(1, 2, 0, 3).reshape(B * Q, T * C)                  # row (b, q), column (t, c)
+            a_split, Rpad, Kpad = _split_rows(acat, 128)
+            out = torch.empty(B, Q, HW, dtype=torch.float32, device=e.device)
+            check(lib.s2f_split_gemm(_ptr(a_split), Q * Kpad, Rpad * Kpad, 1, _ptr(mf), C * HW, C, B * C * HW, 3, _ptr(out),
+                                     Q * HW, scale, B, Q, HW, T * C, (Q + 127) // 128 * 128, Kpad, _stream()),
+                  "s2f_split_gemm")
+        else:
+            es = e * scale
+            out = torch.bmm(es[0], mf[0])
+            for t in range(1, T):
+                torch.baddbmm(out, es[t], mf[t], out=out)
+        ctx.save_for_backward(e, mf)
+        ctx.scale, ctx.mfma = scale, mfma
         return out
 
     @staticmethod
     def backward(ctx, g):
-        es, mf = ctx.saved_tensors
+        e, mf = ctx.saved_tensors
         g = g.contiguous()
-        T = es.shape[0]
+        T, B, Q, C = e.shape
+        HW = mf.shape[-1]
         ge = gmf = None
         if ctx.needs_input_grad[0]:
-            ge = torch.empty_like(es)
+            ge = torch.empty_like(e)
             for t in range(T):
                 torch.bmm(g, mf[t].transpose(1, 2), out=ge[t])
             ge.mul_(ctx.scale)
         if ctx.needs_input_grad[1]:
             gmf = torch.empty_like(mf)
-            for t in range(T):
-                torch.bmm(es[t].transpose(1, 2), g, out=gmf[t])
-        return ge, gmf, None
+            if ctx.mfma:
+                et = e.permute(0, 1, 3, 2).reshape(T * B * C, Q)               # row (t, b, c), column q
+                a_split, Rpad, Kpad = _split_rows(et, 128)
+                for t in range(T):
+                    check(lib.s2f_split_gemm(_ptr(a_split) + 2 * t * B * C * Kpad, C * Kpad, Rpad * Kpad, 1, _ptr(g), Q * HW, Q,
+                                             0, 3, _ptr(gmf[t]), C * HW, ctx.scale, B, C, HW, Q, (C + 127) // 128 * 128, Kpad,
+                                             _stream()), "s2f_split_gemm")
+            else:
+                es = e * ctx.scale
+                for t in range(T):
+                    torch.bmm(es[t].transpose(1, 2), g, out=gmf[t])
+        return ge, gmf, None, None
 
 
-def mask_einsum(e, mf, scale):
-    return _MaskEinsum.apply(e, mf, float(scale))
+def mask_einsum(e, mf, scale, e_exact=False):
+    return _MaskEinsum.apply(e, mf, float(scale), bool(e_exact))
 
 
 # ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling

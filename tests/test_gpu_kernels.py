@@ -368,6 +368,34 @@ def test_bn_act_stateful_lif_matches_unfused(ops):
     assert torch.equal(u, u2) and torch.equal(y, y2) and torch.equal(v_out, v2) and torch.equal(ops.read_stats(stats_a), ops.read_stats(stats_b))
 
 
+def test_mask_einsum_matrix_core_path_vs_fp64(ops):
+    """out[b] = scale * sum_t E[t,b] @ MF[t,b] (maskformer_head.py:582-583 with the t-mean folded in) and its gradients.
+    With E exact in bf16 (alpha * spikes) the forward and d(MF) run as split GEMMs on the matrix cores: exact products,
+    fp32 accumulation -> same error class as an fp32 GEMM (<= 2e-6 * sum|e||mf|); ragged Q / HW exercise the padding."""
+    g = torch.Generator().manual_seed(11)
+    for (T, B, Q, C, HW) in ((4, 2, 100, 64, 1024), (3, 1, 37, 40, 260)):
+        e = (torch.randint(0, 9, (T, B, Q, C), generator=g).float() / 2).cuda().requires_grad_(True)     # multiples of 1/2
+        mf = torch.randn(T, B, C, HW, generator=g).cuda().requires_grad_(True)
+        go = torch.randn(B, Q, HW, generator=g).cuda()
+        out = ops.mask_einsum(e, mf, 1.0 / T, e_exact=True)
+        out.backward(go)
+        e64, mf64 = e.detach().double(), mf.detach().double()
+        ref = torch.einsum("tbqc,tbcn->bqn", e64, mf64) / T
+        bound = torch.einsum("tbqc,tbcn->bqn", e64.abs(), mf64.abs()) / T
+        assert ((out.detach().double() - ref).abs() <= 2e-6 * bound + 1e-12).all()
+        gmf_ref = torch.einsum("tbqc,bqn->tbcn", e64, go.double()) / T
+        gmf_bound = torch.einsum("tbqc,bqn->tbcn", e64.abs(), go.double().abs()) / T
+        assert ((mf.grad.double() - gmf_ref).abs() <= 2e-6 * gmf_bound + 1e-12).all()
+        ge_ref = torch.einsum("bqn,tbcn->tbqc", go.double(), mf64) / T
+        assert (e.grad.double() - ge_ref).abs().max().item() <= 1e-4 * ge_ref.abs().max().item()
+        # library path (E not flagged exact) gives the same numbers to fp32 round-off
+        e2, mf2 = e.detach().clone().requires_grad_(True), mf.detach().clone().requires_grad_(True)
+        out2 = ops.mask_einsum(e2, mf2, 1.0 / T)
+        out2.backward(go)
+        assert (out2 - out).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        assert (mf2.grad - mf.grad).abs().max().item() <= 1e-4 * gmf_ref.abs().max().item()
+
+
 # ----------------------------------------------------------------------------------------------- depthwise stencils
 @pytest.mark.parametrize("N,C,H,W,K,pad,border", [(2, 8, 32, 32, 3, 1, True), (2, 6, 37, 45, 7, 3, False),
                                                    (1, 5, 4, 4, 5, 2, False), (3, 16, 64, 64, 5, 2, False),
