@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 6
+#define S2F_ABI_VERSION 7
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -158,8 +158,10 @@ int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_te
  * X [batch, K, L] spikes, dW [M, K] overwritten).  X is exact in bf16; dY is split on the fly into hi + mid + lo bf16
  * terms: three MFMA passes, exact products, fp32 accumulation (split-K partial tiles are combined with fp32 atomics, so
  * the result is reproducible to fp32 round-off, not bit for bit).  L % 4 == 0.
- * accumulate != 0: dW += ... (no clearing memset; for gradients summed straight into a pre-zeroed flat buffer). */
-int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
+ * accumulate != 0: dW += ... (no clearing memset; for gradients summed straight into a pre-zeroed flat buffer).
+ * x_terms: 1 = X exact in bf16 (spikes), 3 passes; 3 = X a general fp32 tensor, split like dY: 6 passes (terms i + j <= 2)
+ *   -- the "both operands contraction-contiguous" GEMM of two general tensors, e.g. dE = g @ MF^T of the mask einsum. */
+int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate, int x_terms,
                       void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------

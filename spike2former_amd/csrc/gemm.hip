@@ -360,7 +360,7 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
 // issue-bound (operand split + LDS staging ~1000 VALU cycles, 24 MFMAs 768 cycles, LDS ~300, serial within a wave; they
 // only overlap across the two waves a SIMD holds).  LDS rows are BKV + 8 bf16 (80 / 144 bytes: odd multiples of 16 bytes,
 // conflict-free ds_read_b128 fragments).
-template <int BKV>
+template <int BKV, int XT>
 __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                             float* __restrict__ dW, int B, int M, int K, int L,
                                                             int steps_per_split, int k_tiles) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
   constexpr int QPR = BKV / 4;                 // float4 chunks per row
   constexpr int NH = 128 * QPR / 256;          // chunks per thread and operand
   __shared__ __attribute__((aligned(16))) unsigned short As[3][128][LD];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[128][LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[XT][128][LD];      // XT = 1: X exact in bf16 (spikes); 3: general
   const int tile = blockIdx.x;
   const int m0 = (tile / k_tiles) * 128, k0 = (tile % k_tiles) * 128;
   const int lsteps = (L + BKV - 1) / BKV;
@@ -414,28 +414,39 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
       *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
       *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
       *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
-      *reinterpret_cast<u32x2*>(&Bs[row][col]) =
-          u32x2{pack2(f32x2{breg[h].x, breg[h].y}), pack2(f32x2{breg[h].z, breg[h].w})};
+      if (XT == 1) {
+        *reinterpret_cast<u32x2*>(&Bs[0][row][col]) =
+            u32x2{pack2(f32x2{breg[h].x, breg[h].y}), pack2(f32x2{breg[h].z, breg[h].w})};
+      } else {
+        unsigned int bh0, bm0, bl0, bh1, bm1, bl1;
+        split3x2(breg[h].x, breg[h].y, bh0, bm0, bl0);
+        split3x2(breg[h].z, breg[h].w, bh1, bm1, bl1);
+        *reinterpret_cast<u32x2*>(&Bs[0][row][col]) = u32x2{bh0, bh1};
+        *reinterpret_cast<u32x2*>(&Bs[XT > 1 ? 1 : 0][row][col]) = u32x2{bm0, bm1};
+        *reinterpret_cast<u32x2*>(&Bs[XT > 2 ? 2 : 0][row][col]) = u32x2{bl0, bl1};
+      }
     }
     __syncthreads();
     if (step + 1 < s_end) fetch(step + 1, areg, breg);
 #pragma unroll
     for (int ks = 0; ks < BKV / 16; ++ks) {
       const int kof = ks * 16 + 8 * (lane >> 5);
-      bf16x8 bfrag[2];
+      bf16x8 bfrag[XT][2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wn * 64 + j * 32 + (lane & 31);
-        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[row][kof]);
-      }
+      for (int tb = 0; tb < XT; ++tb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfrag[tb][j] = *reinterpret_cast<const bf16x8*>(&Bs[tb][wn * 64 + j * 32 + (lane & 31)][kof]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+          for (int tb = 0; tb < XT; ++tb)
+            if (t + tb < 3)              // terms hi*hi .. up to 2^-16 * 2^-8: 3 products with an exact X, 6 with a general one
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[tb][j], acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -543,7 +554,7 @@ extern "C" int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, i
 }
 
 extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
-                                 void* stream) {
+                                 int x_terms, void* stream) {
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw: null pointer");
   S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
               "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
@@ -552,13 +563,15 @@ extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int
   if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess)
     return s2f_check_launch("s2f_spike_gemm_dw memset");
   const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
-  const int bkv = (L % 64 == 0 || L >= 512) ? 64 : 32;          // short ragged rows keep the 32-wide step
+  S2F_REQUIRE(x_terms == 1 || x_terms == 3, S2F_EINVAL, "s2f_spike_gemm_dw: x_terms must be 1 (X exact in bf16) or 3");
+  // short ragged rows keep the 32-wide step; so does the general-X form (six LDS operand tiles)
+  const int bkv = (x_terms == 1 && (L % 64 == 0 || L >= 512)) ? 64 : 32;
   const int total_steps = batch * ((L + bkv - 1) / bkv);
   // Split count from a two-term cost model fitted on MI355X (tools/probe: one split = one workgroup per output tile):
   //   a workgroup spends ~2.3 us per 64-wide (1.2 us per 32-wide) contraction step, 512 workgroups run at a time;
   //   every split adds its M x K partial tile into dW with fp32 atomics at ~1.7 TB/s (0.6 us per MB).
   const int tiles = m_tiles * k_tiles;
-  const double t_step = bkv == 64 ? 2.3 : 1.2, t_mb = 0.6 * (double)M * K * 4.0 / 1e6;
+  const double t_step = (bkv == 64 ? 2.3 : 1.2) * (x_terms == 3 ? 1.8 : 1.0), t_mb = 0.6 * (double)M * K * 4.0 / 1e6;
   int splits = 1;
   double best = 1e30;
   for (int cand = 1; cand <= total_steps && cand <= 65535; cand *= 2) {
@@ -574,11 +587,15 @@ extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int
   if (splits > 65535) splits = 65535;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
-  if (bkv == 64)
-    S2F_LAUNCH(true, true, spike_gemm_dw_kernel<64>, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K,
-               L, steps_per_split, k_tiles);
+#define S2F_DW_GO(BKV, XTV)                                                                                              \
+  S2F_LAUNCH(true, true, (spike_gemm_dw_kernel<BKV, XTV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, \
+             M, K, L, steps_per_split, k_tiles)
+  if (x_terms == 3)
+    S2F_DW_GO(32, 3);
+  else if (bkv == 64)
+    S2F_DW_GO(64, 1);
   else
-    S2F_LAUNCH(true, true, spike_gemm_dw_kernel<32>, dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, M, K,
-               L, steps_per_split, k_tiles);
+    S2F_DW_GO(32, 1);
+#undef S2F_DW_GO
   return s2f_check_launch("s2f_spike_gemm_dw");
 }

@@ -424,6 +424,7 @@ def dwconv(x, w, pad, border=None):
 _SPLIT_CACHE = {}
 SPIKE_GEMM_TERMS = 3          # number of bf16 weight terms (3 == fp32-equivalent)
 SPIKE_GEMM_ENABLED = True
+MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pass split GEMM) instead of rocBLAS fp32
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
 
@@ -485,7 +486,7 @@ class _SpikeGemm(torch.autograd.Function):
                 _time_next("spike_gemm_dw", 4 * B * x.shape[2] * (K + M), 2 * B * M * x.shape[2] * K * 3)
                 side = _wgrad_stream(sink, gy, x)
                 check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, x.shape[2],
-                                            int(sink is not None), side.cuda_stream if side is not None else _stream()),
+                                            int(sink is not None), 1, side.cuda_stream if side is not None else _stream()),
                       "s2f_spike_gemm_dw")
             else:
                 gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
@@ -554,9 +555,18 @@ class _MaskEinsum(torch.autograd.Function):
         HW = mf.shape[-1]
         ge = gmf = None
         if ctx.needs_input_grad[0]:
-            ge = torch.empty_like(e)
-            for t in range(T):
-                torch.bmm(g, mf[t].transpose(1, 2), out=ge[t])
+            if ctx.mfma and MASK_EINSUM_DE_MFMA:
+                # dE[t, b] = g[b] (Q x HW) @ MF[t, b]^T: both operands contraction-contiguous fp32 -> the weight-gradient
+                # kernel with both sides split hi+mid+lo (6 passes), split-K over HW with fp32 atomics
+                ge = torch.zeros_like(e)
+                for t in range(T):
+                    for b in range(B):
+                        check(lib.s2f_spike_gemm_dw(_ptr(g[b]), _ptr(mf[t, b]), _ptr(ge[t, b]), 1, Q, C, HW, 1, 3, _stream()),
+                              "s2f_spike_gemm_dw")
+            else:
+                ge = torch.empty_like(e)
+                for t in range(T):
+                    torch.bmm(g, mf[t].transpose(1, 2), out=ge[t])
             ge.mul_(ctx.scale)
         if ctx.needs_input_grad[1]:
             gmf = torch.empty_like(mf)
@@ -666,7 +676,7 @@ class _ConvDense(torch.autograd.Function):
                 _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K * 3)
                 side = _wgrad_stream(sink, gy, cols)
                 check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
-                                            int(sink is not None), side.cuda_stream if side is not None else _stream()),
+                                            int(sink is not None), 1, side.cuda_stream if side is not None else _stream()),
                       "s2f_spike_gemm_dw")
             else:
                 gw = torch.bmm(gy, cols.transpose(1, 2)).sum(0)

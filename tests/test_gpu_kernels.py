@@ -387,7 +387,8 @@ def test_mask_einsum_matrix_core_path_vs_fp64(ops):
         gmf_bound = torch.einsum("tbqc,bqn->tbcn", e64.abs(), go.double().abs()) / T
         assert ((mf.grad.double() - gmf_ref).abs() <= 2e-6 * gmf_bound + 1e-12).all()
         ge_ref = torch.einsum("bqn,tbcn->tbqc", go.double(), mf64) / T
-        assert (e.grad.double() - ge_ref).abs().max().item() <= 1e-4 * ge_ref.abs().max().item()
+        ge_bound = torch.einsum("bqn,tbcn->tbqc", go.double().abs(), mf64.abs()) / T
+        assert ((e.grad.double() - ge_ref).abs() <= 4e-6 * ge_bound + 1e-12).all()      # 6-pass split GEMM: fp32 class
         # library path (E not flagged exact) gives the same numbers to fp32 round-off
         e2, mf2 = e.detach().clone().requires_grad_(True), mf.detach().clone().requires_grad_(True)
         out2 = ops.mask_einsum(e2, mf2, 1.0 / T)
@@ -510,7 +511,7 @@ def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
     scale = torch.einsum("bml,bkl->mk", gy.abs().double(), x.abs().double()).max().item()
     gyc, xc = gy.cuda(), x.cuda()
     out = torch.full((M, K), float("nan"), device="cuda")
-    assert lib.s2f_spike_gemm_dw(gyc.data_ptr(), xc.data_ptr(), out.data_ptr(), B, M, K, L, 0, None) == 0
+    assert lib.s2f_spike_gemm_dw(gyc.data_ptr(), xc.data_ptr(), out.data_ptr(), B, M, K, L, 0, 1, None) == 0
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 3e-6 * scale, (err, scale)
 

@@ -16,5 +16,5 @@ for M in (256, 512):
             t = bench(lambda: ops.spike_gemm(x, w))
             gw = torch.empty(M, K, device="cuda")
             from spike2former_amd._lib import lib
-            tdw = bench(lambda: lib.s2f_spike_gemm_dw(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), N, M, K, L, 0, None)) if M >= 64 else 0
+            tdw = bench(lambda: lib.s2f_spike_gemm_dw(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), N, M, K, L, 0, 1, None)) if M >= 64 else 0
             print(f"M={M} L={L} K={K:5d}: fwd {t*1e6:7.1f} us ({t*1e6/(K/32):5.2f} us/step)   dW {tdw*1e6:7.1f} us")

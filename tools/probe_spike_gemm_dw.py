@@ -19,5 +19,5 @@ for name, M, K, L in shapes:
     gy = torch.randn(N, M, L, device="cuda"); x = (torch.randint(0, 9, (N, K, L), device="cuda").float()/8)
     out = torch.empty(M, K, device="cuda"); fl = 2.0*N*M*K*L
     t0 = bench(lambda: torch.bmm(gy, x.transpose(1, 2)).sum(0))
-    t1 = bench(lambda: lib.s2f_spike_gemm_dw(gy.data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, L, 0, s))
+    t1 = bench(lambda: lib.s2f_spike_gemm_dw(gy.data_ptr(), x.data_ptr(), out.data_ptr(), N, M, K, L, 0, 1, s))
     print(f"{name:22s} {t0*1e6:10.1f} {fl/t0/1e12:6.1f} | {t1*1e6:8.1f} {fl/t1/1e12:6.1f} | {t0/t1:5.2f}x")
