@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 7
+#define S2F_ABI_VERSION 8
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -41,7 +41,7 @@ const char* s2f_last_error(void);
  * (hipExtLaunchKernelGGL start/stop events = the dispatch packet's own begin/end timestamps, what rocprofv3 reports).
  *   s2f_event_create/destroy: a hipEvent_t as void*.
  *   s2f_time_next_call(start, stop): arms THIS thread; the next s2f_lif_fwd / s2f_lif_bwd / s2f_bn_stats /
- *       s2f_bn_act_fwd / s2f_bn_act_bwd / s2f_spike_gemm_fwd / s2f_spike_gemm_dw call stamps `start` with the begin of
+ *       s2f_bn_act_fwd / s2f_bn_act_bwd / s2f_spike_gemm_fwd / s2f_spike_gemm_dw / s2f_spike_conv3x3_* / s2f_split_gemm call stamps `start` with the begin of
  *       its first kernel and `stop` with the end of its last one, then disarms.  Not valid during stream capture.
  *   s2f_event_elapsed_us: stop - start in microseconds (both must have completed: synchronise first). */
 void* s2f_event_create(void);
@@ -140,6 +140,17 @@ int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, 
 int s2f_split_bf16x3(const float* w, uint16_t* w_split, int M, int K, int Mpad, int Kpad, void* stream);
 int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int N,
                        int K, int Mpad, int Kpad, int terms, void* stream);
+/* 3x3 convolution (stride 1, padding 1) of a SPIKE activation as an implicit GEMM on the same kernels: the B operand is
+ * the activation X [batch, C, H, W] itself, the kernels' loaders form the rows of the im2col matrix on the fly -- the 9x
+ * inflated column matrix of F.unfold is never materialised (MS_ConvBlock.conv1 / conv2,
+ * mmseg/models/backbones/sdtv2.py:197-204).  The contraction runs TAP-MAJOR, k = (3 ky + kx) C + c (C % 32 == 0: a 32-wide
+ * step lies in one tap): w_split = s2f_split_bf16x3 of weight.permute(0,2,3,1) viewed [M, 9C].  Y: [batch, M, H*W].
+ * s2f_spike_conv3x3_fwd needs W % 4 == 0; s2f_spike_conv3x3_dw needs W a power of two and writes dW in the same tap-major
+ * order, [M, 3, 3, C] (dY [batch, M, H*W]); the caller permutes it back to the weight's [M, C, 3, 3]. */
+int s2f_spike_conv3x3_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int C,
+                          int H, int W, int Mpad, int Kpad, int terms, void* stream);
+int s2f_spike_conv3x3_dw(const float* dY, const float* X, float* dW, int batch, int M, int C, int H, int W, int accumulate,
+                         void* stream);
 /* General split GEMM on the same kernel structure:  Y[b] (M x N) = out_scale * A[b] (M x K) @ X[b] (K x N).
  *   a_split: bf16 terms as written by s2f_split_bf16x3: term i of batch b starts at a_split + i*a_term_stride +
  *     b*a_batch_stride (ELEMENTS; rows Kpad apart, Mpad readable rows per batch; a_batch_stride = 0 shares one A; several

@@ -76,11 +76,37 @@ __device__ __forceinline__ void split3x2(float v0, float v1, unsigned int& h, un
   l = pack2(f32x2{r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u)});
 }
 
+// Geometry of the implicit 3x3 convolution mode (stride 1, padding 1): the B operand is the activation [C][H][W] itself and
+// "row k, column n" of the virtual im2col matrix is  x[c][y + ky - 1][x + kx - 1],  n = y W + x, with the TAP-MAJOR row order
+// k = (3 ky + kx) C + c  (C % 32 == 0: every 32-wide contraction step lies inside one tap, so ky / kx are uniform scalars
+// of the step and a row is just a channel plane shifted by (ky - 1) W + (kx - 1) elements).  The host permutes the weight to
+// the same order once (cached with its split).  The 9x inflated column matrix (2.4 GB for one 128-channel 256x256 map at
+// T*B = 8) is never written or read.
+struct Conv3 {
+  int H, W, C;
+};
+
+// 4 consecutive pixels n .. n+3 of one plane, shifted by the tap: ONE (generally unaligned) 16-byte load; the pixel that
+// falls off the row at its left / right end is zeroed, a row outside the plane reads as zeros.  `plane` = channel plane base.
+__device__ __forceinline__ f32x4 conv3_load(const float* __restrict__ plane, int n, int y, int x, int ky, int kx, Conv3 g,
+                                            bool ok) {
+  const int yy = y + ky - 1;
+  ok = ok && yy >= 0 && yy < g.H;
+  const bool cut_l = kx == 0 && x == 0, cut_r = kx == 2 && x + 4 == g.W;
+  // never address outside the plane: at a cut end load the aligned neighbour group and shift in registers
+  const int off = (ky - 1) * g.W + (kx - 1) + (cut_l ? 1 : 0) - (cut_r ? 1 : 0);
+  const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(plane + (ok ? n + off : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  if (cut_l) return f32x4{0.f, v.x, v.y, v.z};
+  if (cut_r) return f32x4{v.y, v.z, v.w, 0.f};
+  return v;
+}
+
 // global -> registers for the K step starting at kk (issued one step ahead of its use: the loads fly under the MFMAs)
-template <int WM, int TERMS>
+template <int WM, int TERMS, bool CONV>
 __device__ __forceinline__ void fetch_tile(u32x4 (&areg)[TERMS][2], f32x4 (&breg)[(256 + 128 * WM - 1) / (128 * WM)][4],
                                            const unsigned short* __restrict__ Wsplit, const float* __restrict__ Xb,
-                                           int64_t term_stride, int m0, int n0, int kk, int tid, int K, int N, int Kpad) {
+                                           int64_t term_stride, int m0, int n0, int kk, int tid, int K, int N, int Kpad,
+                                           Conv3 g) {
   constexpr int T = 128 * WM;
   constexpr int NP = (256 + T - 1) / T;
 #pragma unroll
@@ -97,20 +123,26 @@ __device__ __forceinline__ void fetch_tile(u32x4 (&areg)[TERMS][2], f32x4 (&breg
     const int p = tid + q * T;
     const int kb = p / (BN / 4), nb = p % (BN / 4);
     const int n = n0 + nb * 4;
+    const int py = CONV ? n / g.W : 0, px = CONV ? n - py * g.W : 0;
+    const int tap = CONV ? kk / g.C : 0, ky = tap / 3, kx = tap - 3 * ky;       // uniform over the step (C % 32 == 0)
+    const int c0 = CONV ? kk - tap * g.C : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = kk + kb * 4 + r;
-      breg[q][r] = (p < 256 && k < K && n < N) ? *reinterpret_cast<const f32x4*>(Xb + (int64_t)k * N + n)
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = p < 256 && k < K && n < N;
+      if (CONV)
+        breg[q][r] = conv3_load(Xb + (int64_t)(ok ? c0 + kb * 4 + r : 0) * N, n, py, px, ky, kx, g, ok);
+      else
+        breg[q][r] = ok ? *reinterpret_cast<const f32x4*>(Xb + (int64_t)k * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 }
 
-template <int WM, int TERMS>
+template <int WM, int TERMS, bool CONV>
 __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned short* __restrict__ Wsplit,
                                                               const float* __restrict__ X, const float* __restrict__ bias,
                                                               float* __restrict__ Y, int M, int N, int K, int Mpad, int Kpad,
-                                                              int n_tiles, int m_tiles) {
+                                                              int n_tiles, int m_tiles, Conv3 geo) {
   constexpr int BM = 64 * WM;
   constexpr int T = 128 * WM;
   __shared__ __attribute__((aligned(16))) unsigned short As[TERMS][BM][LDR];
@@ -124,7 +156,8 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
   const int mt = pid % m_tiles, nt = pid / m_tiles;
   const int b = blockIdx.y;
   const int m0 = mt * BM, n0 = nt * BN;
-  const float* Xb = X + (int64_t)b * K * N;
+  // conv mode: one batch element is the [C][H][W] activation = K / 9 planes of N pixels
+  const float* Xb = X + (int64_t)b * (CONV ? K / 9 : K) * N;
   float* Yb = Y + (int64_t)b * M * N;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,7 +176,7 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
   u32x4 areg[TERMS][2];
   f32x4 breg[NP][4];
 
-  fetch_tile<WM, TERMS>(areg, breg, Wsplit, Xb, term_stride, m0, n0, 0, tid, K, N, Kpad);
+  fetch_tile<WM, TERMS, CONV>(areg, breg, Wsplit, Xb, term_stride, m0, n0, 0, tid, K, N, Kpad, geo);
   for (int k0 = 0; k0 < Kpad; k0 += BK) {
     // registers -> LDS (A as is; X converted to bf16 and transposed to [n][k])
 #pragma unroll
@@ -172,7 +205,7 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
       }
     }
     __syncthreads();
-    if (k0 + BK < Kpad) fetch_tile<WM, TERMS>(areg, breg, Wsplit, Xb, term_stride, m0, n0, k0 + BK, tid, K, N, Kpad);
+    if (k0 + BK < Kpad) fetch_tile<WM, TERMS, CONV>(areg, breg, Wsplit, Xb, term_stride, m0, n0, k0 + BK, tid, K, N, Kpad, geo);
     // ---- MFMA: 2 k-slices x (2 x 2 tiles) x terms
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -360,10 +393,10 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
 // issue-bound (operand split + LDS staging ~1000 VALU cycles, 24 MFMAs 768 cycles, LDS ~300, serial within a wave; they
 // only overlap across the two waves a SIMD holds).  LDS rows are BKV + 8 bf16 (80 / 144 bytes: odd multiples of 16 bytes,
 // conflict-free ds_read_b128 fragments).
-template <int BKV, int XT>
+template <int BKV, int XT, bool CONV>
 __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                             float* __restrict__ dW, int B, int M, int K, int L,
-                                                            int steps_per_split, int k_tiles) {
+                                                            int steps_per_split, int k_tiles, Conv3 geo, int log_w) {
   constexpr int LD = BKV + 8;
   constexpr int QPR = BKV / 4;                 // float4 chunks per row
   constexpr int NH = 128 * QPR / 256;          // chunks per thread and operand
@@ -388,6 +421,13 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 areg[NH], breg[NH];
+  int crow[NH], ctap[NH];                      // conv mode: channel and tap of the X row each chunk of this thread reads
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int k = min(k0 + (tid + h * 256) / QPR, K - 1);
+    ctap[h] = CONV ? k / geo.C : 0;
+    crow[h] = CONV ? k - ctap[h] * geo.C : 0;
+  }
   // chunk c = tid + h*256: row = c / QPR (0..127), 16-byte column c % QPR (4 floats each)
   auto fetch = [&](int step, f32x4 (&a)[NH], f32x4 (&bq)[NH]) {
     const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
@@ -398,8 +438,29 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
       const bool lok = l < L;                                       // L % 4 == 0: the whole float4 is valid or not
       a[h] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-      bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + ((int64_t)b * K + k0 + row) * L + l)
-                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (CONV) {
+        // X is the activation [B][K/9][H][W]; row k0 + row of the virtual im2col matrix, pixels l .. l+3 (W a power of two)
+        // (channel, ky, kx) of this thread's row were decoded once, before the step loop
+        // An unaligned 16-byte load per lane (conv3_load) is split by the memory pipeline (measured: this loader 2.6x
+        // slower than the aligned one); here every lane loads its ALIGNED quad of the shifted row and the one pixel that
+        // the tap pulls in from the side comes from the neighbouring lane (the QPR lanes of a row slice are adjacent), or
+        // from one extra scalar load at the two ends of the slice.
+        const int ky = ctap[h] / 3, kx = ctap[h] - 3 * ky, lq = c % QPR;
+        const int yy = (l >> log_w) + ky - 1, px = l & (geo.W - 1);
+        const bool ok = lok && k0 + row < K && yy >= 0 && yy < geo.H;
+        const float* P = X + ((int64_t)b * geo.C + crow[h]) * L;
+        const int idx = ok ? l + (ky - 1) * geo.W : 0;
+        const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(P + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float lft = __shfl_up(v.w, 1, 64), rgt = __shfl_down(v.x, 1, 64);
+        if (lq == 0) lft = (ok && kx == 0 && px > 0) ? P[idx - 1] : 0.f;
+        if (lq == QPR - 1) rgt = (ok && kx == 2 && px + 4 < geo.W) ? P[idx + 4] : 0.f;
+        if (px == 0) lft = 0.f;
+        if (px + 4 == geo.W) rgt = 0.f;
+        bq[h] = kx == 0 ? f32x4{lft, v.x, v.y, v.z} : (kx == 2 ? f32x4{v.y, v.z, v.w, rgt} : v);
+      } else {
+        bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + ((int64_t)b * K + k0 + row) * L + l)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   fetch(s_begin, areg, breg);
@@ -478,15 +539,15 @@ extern "C" int s2f_split_bf16x3(const float* w, uint16_t* out, int M, int K, int
   return s2f_check_launch("s2f_split_bf16x3");
 }
 
-extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M,
-                                  int N, int K, int Mpad, int Kpad, int terms, void* stream) {
-  S2F_REQUIRE(w_split && X && Y, S2F_EINVAL, "s2f_spike_gemm_fwd: null pointer");
-  S2F_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL, "s2f_spike_gemm_fwd: bad sizes");
-  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "s2f_spike_gemm_fwd: N=%d must be a multiple of 4", N);
-  S2F_REQUIRE(Kpad >= K && Kpad % 32 == 0 && Mpad >= M && Mpad % 64 == 0, S2F_EINVAL, "s2f_spike_gemm_fwd: bad padding");
+static int spike_gemm_launch(const char* who, const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch,
+                             int M, int N, int K, int Mpad, int Kpad, int terms, bool conv, Conv3 geo, void* stream) {
+  S2F_REQUIRE(w_split && X && Y, S2F_EINVAL, "%s: null pointer", who);
+  S2F_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL, "%s: bad sizes", who);
+  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "%s: N=%d must be a multiple of 4", who, N);
+  S2F_REQUIRE(Kpad >= K && Kpad % 32 == 0 && Mpad >= M && Mpad % 64 == 0, S2F_EINVAL, "%s: bad padding", who);
   S2F_REQUIRE(s2f_aligned16(w_split) && s2f_aligned16(X) && s2f_aligned16(Y), S2F_EALIGN,
-              "s2f_spike_gemm_fwd: pointers must be 16-byte aligned");
-  S2F_REQUIRE(batch < 65536, S2F_EINVAL, "s2f_spike_gemm_fwd: batch too large");
+              "%s: pointers must be 16-byte aligned", who);
+  S2F_REQUIRE(batch < 65536, S2F_EINVAL, "%s: batch too large", who);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = (N + BN - 1) / BN;
   // Tile choice: the widest block tile (fewest re-reads of X) that still gives every CU >= 2 workgroups; short-and-fat
@@ -503,23 +564,45 @@ extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const
   }
   const int m_tiles = Mpad / (64 * wm);
   const dim3 grid(n_tiles * m_tiles, batch);
-#define S2F_GEMM_GO(WMV, TV)                                                                                           \
-  S2F_LAUNCH(true, true, (spike_gemm_kernel<WMV, TV>), grid, dim3(128 * WMV), 0, s, w_split, X, bias, Y, M, N, K, Mpad,  \
-             Kpad, n_tiles, m_tiles)
-#define S2F_GEMM_T(WMV)                 \
-  if (terms == 3) S2F_GEMM_GO(WMV, 3);   \
-  else if (terms == 2) S2F_GEMM_GO(WMV, 2); \
-  else S2F_GEMM_GO(WMV, 1)
-  if (wm == 4) {
-    S2F_GEMM_T(4);
-  } else if (wm == 2) {
-    S2F_GEMM_T(2);
-  } else {
-    S2F_GEMM_T(1);
+#define S2F_GEMM_GO(WMV, TV, CV)                                                                                        \
+  S2F_LAUNCH(true, true, (spike_gemm_kernel<WMV, TV, CV>), grid, dim3(128 * WMV), 0, s, w_split, X, bias, Y, M, N, K, Mpad, \
+             Kpad, n_tiles, m_tiles, geo)
+#define S2F_GEMM_T(WMV, CV)                    \
+  if (terms == 3) S2F_GEMM_GO(WMV, 3, CV);      \
+  else if (terms == 2) S2F_GEMM_GO(WMV, 2, CV); \
+  else S2F_GEMM_GO(WMV, 1, CV)
+#define S2F_GEMM_W(CV)     \
+  if (wm == 4) {           \
+    S2F_GEMM_T(4, CV);     \
+  } else if (wm == 2) {    \
+    S2F_GEMM_T(2, CV);     \
+  } else {                 \
+    S2F_GEMM_T(1, CV);     \
   }
+  if (conv) {
+    S2F_GEMM_W(true)
+  } else {
+    S2F_GEMM_W(false)
+  }
+#undef S2F_GEMM_W
 #undef S2F_GEMM_T
 #undef S2F_GEMM_GO
-  return s2f_check_launch("s2f_spike_gemm_fwd");
+  return s2f_check_launch(who);
+}
+
+extern "C" int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M,
+                                  int N, int K, int Mpad, int Kpad, int terms, void* stream) {
+  return spike_gemm_launch("s2f_spike_gemm_fwd", w_split, X, bias, Y, batch, M, N, K, Mpad, Kpad, terms, false, Conv3{0, 0, 0},
+                           stream);
+}
+
+extern "C" int s2f_spike_conv3x3_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M,
+                                     int C, int H, int W, int Mpad, int Kpad, int terms, void* stream) {
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W > 0 && (W & 3) == 0, S2F_EINVAL,
+              "s2f_spike_conv3x3_fwd: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  S2F_REQUIRE((int64_t)C * 9 < (1 << 30) && (int64_t)H * W < (1 << 30), S2F_EINVAL, "s2f_spike_conv3x3_fwd: too large");
+  return spike_gemm_launch("s2f_spike_conv3x3_fwd", w_split, X, bias, Y, batch, M, H * W, C * 9, Mpad, Kpad, terms, true,
+                           Conv3{H, W, C}, stream);
 }
 
 extern "C" int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_term_stride, int a_terms,
@@ -553,8 +636,8 @@ extern "C" int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, i
   return s2f_check_launch("s2f_split_gemm");
 }
 
-extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
-                                 int x_terms, void* stream) {
+static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
+                           int x_terms, bool conv, Conv3 geo, int log_w, void* stream) {
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw: null pointer");
   S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
               "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
@@ -565,7 +648,8 @@ extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int
   const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
   S2F_REQUIRE(x_terms == 1 || x_terms == 3, S2F_EINVAL, "s2f_spike_gemm_dw: x_terms must be 1 (X exact in bf16) or 3");
   // short ragged rows keep the 32-wide step; so does the general-X form (six LDS operand tiles)
-  const int bkv = (x_terms == 1 && (L % 64 == 0 || L >= 512)) ? 64 : 32;
+  // (the conv loader's extra state pushes the 64-wide variant to 257 registers = one wave per SIMD: 32-wide there)
+  const int bkv = (!conv && x_terms == 1 && (L % 64 == 0 || L >= 512)) ? 64 : 32;
   const int total_steps = batch * ((L + bkv - 1) / bkv);
   // Split count from a two-term cost model fitted on MI355X (tools/probe: one split = one workgroup per output tile):
   //   a workgroup spends ~2.3 us per 64-wide (1.2 us per 32-wide) contraction step, 512 workgroups run at a time;
@@ -587,15 +671,35 @@ extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int
   if (splits > 65535) splits = 65535;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
-#define S2F_DW_GO(BKV, XTV)                                                                                              \
-  S2F_LAUNCH(true, true, (spike_gemm_dw_kernel<BKV, XTV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, batch, \
-             M, K, L, steps_per_split, k_tiles)
-  if (x_terms == 3)
-    S2F_DW_GO(32, 3);
-  else if (bkv == 64)
-    S2F_DW_GO(64, 1);
-  else
-    S2F_DW_GO(32, 1);
+#define S2F_DW_GO(BKV, XTV, CV)                                                                                         \
+  S2F_LAUNCH(true, true, (spike_gemm_dw_kernel<BKV, XTV, CV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW,  \
+             batch, M, K, L, steps_per_split, k_tiles, geo, log_w)
+  if (conv) {
+    if (bkv == 64)
+      S2F_DW_GO(64, 1, true);
+    else
+      S2F_DW_GO(32, 1, true);
+  } else if (x_terms == 3) {
+    S2F_DW_GO(32, 3, false);
+  } else if (bkv == 64) {
+    S2F_DW_GO(64, 1, false);
+  } else {
+    S2F_DW_GO(32, 1, false);
+  }
 #undef S2F_DW_GO
   return s2f_check_launch("s2f_spike_gemm_dw");
+}
+
+extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
+                                 int x_terms, void* stream) {
+  return spike_dw_launch(dY, X, dW, batch, M, K, L, accumulate, x_terms, false, Conv3{0, 0, 0}, 0, stream);
+}
+
+extern "C" int s2f_spike_conv3x3_dw(const float* dY, const float* X, float* dW, int batch, int M, int C, int H, int W,
+                                    int accumulate, void* stream) {
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & (W - 1)) == 0, S2F_EINVAL,
+              "s2f_spike_conv3x3_dw: need C %% 32 == 0 and W a power of two >= 4 (C=%d, W=%d)", C, W);
+  int log_w = 0;
+  while ((1 << log_w) < W) ++log_w;
+  return spike_dw_launch(dY, X, dW, batch, M, C * 9, H * W, accumulate, 1, true, Conv3{H, W, C}, log_w, stream);
 }

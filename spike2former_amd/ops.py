@@ -424,6 +424,11 @@ def dwconv(x, w, pad, border=None):
 _SPLIT_CACHE = {}
 SPIKE_GEMM_TERMS = 3          # number of bf16 weight terms (3 == fp32-equivalent)
 SPIKE_GEMM_ENABLED = True
+# 3x3 / stride 1 / pad 1 spike convolutions as implicit GEMMs (no im2col matrix; s2f_spike_conv3x3_fwd / _dw).  Measured at
+# C2 (tools/probe_conv3.py): the forward wins 1.0-2.4x (CB1_1.conv2: 1429 -> 716 us), the weight gradient loses 1.8x against
+# the kernel that reads the saved column matrix (its loader's shifts and edge loads land on an issue-bound loop), net
+# 63.4 vs 62.8 ms/step -- OFF until the weight-gradient loader is cheaper.
+CONV3X3_IMPLICIT = False
 MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pass split GEMM) instead of rocBLAS fp32
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
@@ -441,6 +446,21 @@ def split_weight(w2d):
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=w2d.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d.detach().contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
     _SPLIT_CACHE[key] = (w2d._version, out, (M, K))
+    return out
+
+
+def split_weight_conv3(weight):
+    """[M, C, 3, 3] -> cached bf16 split of the TAP-MAJOR matrix [M, (ky, kx, c)] that the implicit 3x3 kernels contract over."""
+    key = ("tap", weight.data_ptr())
+    M, C = weight.shape[:2]
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0] == weight._version and hit[2] == (M, C):
+        return hit[1]
+    w2d = weight.detach().permute(0, 2, 3, 1).reshape(M, 9 * C)
+    Mpad, Kpad = (M + 63) // 64 * 64, (9 * C + 31) // 32 * 32
+    out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
+    check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), M, 9 * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
+    _SPLIT_CACHE[key] = (weight._version, out, (M, C))
     return out
 
 
@@ -623,6 +643,8 @@ class _ConvDense(torch.autograd.Function):
 
     forward : cols = im2col(x) ; y = W2d @ cols                       (spike GEMM when x is a neuron output)
     dW      : dY @ cols^T                                              (bf16-MFMA batch-reduce kernel for spike inputs)
+              3x3 / stride 1 / padding 1 on spikes: both as IMPLICIT GEMMs -- the kernels' loaders read x itself, `cols`
+              (9x the activation: 2.4 GB for MS_ConvBlock1_1.conv2 at C2) is neither written, read nor saved
     dX      : the cheaper of two equivalent lowerings --
                 M >= C : dcols = W2d^T @ dY ; dX = col2im(dcols)       (the adjoint of im2col; C*k*k rows)
                 M <  C : dX = flip(W)^T (*) dY = W_t2d @ im2col(dY)     (transposed convolution; M*k*k rows)
@@ -636,8 +658,25 @@ class _ConvDense(torch.autograd.Function):
         M, _, kh, kw = weight.shape
         Ho = (H + 2 * padding - kh) // stride + 1
         Wo = (W + 2 * padding - kw) // stride + 1
-        cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
         w2d = weight.view(M, -1)
+        # implicit GEMM: 3x3, stride 1, padding 1 on spikes -- the kernels' loaders read the activation itself
+        implicit = (spike_input and SPIKE_GEMM_ENABLED and CONV3X3_IMPLICIT and kh == 3 and kw == 3 and stride == 1
+                    and padding == 1 and C % 32 == 0 and W % 4 == 0 and (W & (W - 1)) == 0)
+        if implicit:
+            x = x.contiguous()
+            if SPIKE_GEMM_CHECK:
+                assert torch.equal(x * 8, torch.round(x * 8)) and float(x.abs().max()) <= 16, "not a spike tensor"
+            ws = split_weight_conv3(weight)
+            y = torch.empty(N, M, H * W, dtype=torch.float32, device=x.device)
+            _time_next("spike_gemm_fwd", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9 * SPIKE_GEMM_TERMS)
+            check(lib.s2f_spike_conv3x3_fwd(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, ws.shape[1], ws.shape[2],
+                                            SPIKE_GEMM_TERMS, _stream()), "s2f_spike_conv3x3_fwd")
+            ctx.save_for_backward(x, weight)
+            ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, True)
+            ctx.implicit = True
+            return y.view(N, M, Ho, Wo)
+        ctx.implicit = False
+        cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
         use_mfma = spike_input and SPIKE_GEMM_ENABLED and cols.shape[2] % 4 == 0
         if use_mfma:
             ws = split_weight(w2d)
@@ -670,7 +709,19 @@ class _ConvDense(torch.autograd.Function):
                 gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
         if ctx.needs_input_grad[1]:
             K = w2d.shape[1]
-            if use_mfma and SPIKE_GEMM_DW and M >= 64:
+            if ctx.implicit:
+                x = cols                                                  # the saved tensor is the activation itself
+                gt = torch.empty(M, 3, 3, C, dtype=torch.float32, device=gy.device)        # tap-major, as the kernel contracts
+                _time_next("spike_gemm_dw", 4 * N * H * W * (C + M), 2 * N * M * H * W * K * 3)
+                check(lib.s2f_spike_conv3x3_dw(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()),
+                      "s2f_spike_conv3x3_dw")
+                sink = _sink_for(weight)
+                if sink is not None:
+                    sink.view(M, C, 3, 3).add_(gt.permute(0, 3, 1, 2))
+                    gw = None
+                else:
+                    gw = gt.permute(0, 3, 1, 2).contiguous()
+            elif use_mfma and SPIKE_GEMM_DW and M >= 64:
                 sink = _sink_for(weight)
                 gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
                 _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K * 3)

@@ -518,7 +518,10 @@ def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
 
 @pytest.mark.parametrize("N,C,M,H,W,k,s,p,spike", [(2, 16, 64, 12, 16, 3, 1, 1, True), (2, 64, 16, 12, 16, 3, 1, 1, True),
                                                      (1, 8, 24, 9, 8, 3, 2, 1, True), (2, 3, 16, 16, 16, 7, 2, 3, False),
-                                                     (1, 128, 32, 8, 8, 3, 1, 1, True)])
+                                                     (1, 128, 32, 8, 8, 3, 1, 1, True),
+                                                     # implicit-GEMM 3x3 (W a power of two): ragged M / C / H, several tiles
+                                                     (2, 32, 72, 19, 32, 3, 1, 1, True), (3, 160, 40, 5, 64, 3, 1, 1, True),
+                                                     (1, 64, 200, 33, 4, 3, 1, 1, True)])
 def test_conv_dense_vs_aten_cpu(ops, N, C, M, H, W, k, s, p, spike):
     """The GEMM lowerings of the dense convolution (incl. the transposed-convolution form of dX used when M < C) against
     F.conv2d on CPU: 2e-5 of the max for outputs and all three gradients."""
@@ -531,8 +534,13 @@ def test_conv_dense_vs_aten_cpu(ops, N, C, M, H, W, k, s, p, spike):
     yo = F.conv2d(xo, wo, bo, s, p)
     gy = torch.randn(yo.shape, generator=g)
     yo.backward(gy)
-    xc, wc, bc = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
-    yc = ops.conv_dense(xc, wc, bc, s, p, spike)
-    yc.backward(gy.cuda())
-    for a, r in ((yc, yo), (xc.grad, xo.grad), (wc.grad, wo.grad), (bc.grad, bo.grad)):
-        assert (a.detach().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.abs().max().item()
+    for implicit in (False, True):            # im2col + GEMM lowering, and the implicit-GEMM kernels where they apply
+        ops.CONV3X3_IMPLICIT = implicit
+        try:
+            xc, wc, bc = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+            yc = ops.conv_dense(xc, wc, bc, s, p, spike)
+            yc.backward(gy.cuda())
+        finally:
+            ops.CONV3X3_IMPLICIT = False
+        for a, r in ((yc, yo), (xc.grad, xo.grad), (wc.grad, wo.grad), (bc.grad, bo.grad)):
+            assert (a.detach().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.abs().max().item(), implicit
