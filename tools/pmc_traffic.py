@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the streaming kernel families from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
+runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE in KiB x2 on gfx950 for 16 B/lane streams).
+    python tools/pmc_traffic.py <fetch.db> <write.db> > profiles/rNN_pmc_traffic.json"""
+import collections, json, sqlite3, sys
+
+FAMILIES = {          # bench.py roofline key -> predicate on the kernel name
+    "bn_lif_fwd": lambda n: "bn_apply_kernel<true" in n or "bn_fused_fwd_kernel<true" in n,
+    "bn_fwd": lambda n: "bn_apply_kernel<false" in n or "bn_fused_fwd_kernel<false" in n,
+    "bn_lif_bwd+bn_bwd": lambda n: "bn_bwd_apply_kernel" in n or "bn_bwd_reduce_kernel" in n or "bn_fused_bwd_kernel" in n,
+    "bn_stats": lambda n: "bn_stats_kernel" in n,
+    "lif_fwd": lambda n: "lif_fwd_kernel" in n,
+    "lif_bwd": lambda n: "lif_bwd_kernel" in n,
+    "spike_gemm_fwd": lambda n: "spike_gemm_kernel" in n,
+    "spike_gemm_dw": lambda n: "spike_gemm_dw_kernel" in n,
+}
+
+
+def per_family(db, counter):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    namecol = "kernel_name" if "kernel_name" in cols else "name"
+    ccol = "counter_name" if "counter_name" in cols else "counter"
+    vcol = "value" if "value" in cols else "counter_value"
+    per = collections.defaultdict(float); name = {}
+    for n, cn, v, d in c.execute(f"select {namecol}, {ccol}, {vcol}, dispatch_id from counters_collection"):
+        if cn == counter:
+            per[d] += float(v); name[d] = n
+    out = {}
+    for fam, pred in FAMILIES.items():
+        vals = [v for d, v in per.items() if pred(name[d])]
+        if vals:
+            out[fam] = (len(vals), sum(vals) / len(vals))
+    return out
+
+
+f, w = per_family(sys.argv[1], "FETCH_SIZE"), per_family(sys.argv[2], "WRITE_SIZE")
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-graph "
+                 "--no-kernel-events --no-cpu-baseline` at C2; correction: FETCH_SIZE x2 (gfx950, 16 B/lane streams), KiB -> bytes",
+       "kernels": {}}
+for fam in FAMILIES:
+    if fam in f and fam in w:
+        res["kernels"][fam] = {"launches_in_profile": f[fam][0], "fetch_kib_raw": round(f[fam][1], 1), "write_kib_raw": round(w[fam][1], 1),
+                               "hbm_bytes_per_launch": int(f[fam][1] * 1024 * 2 + w[fam][1] * 1024)}
+print(json.dumps(res, indent=1))

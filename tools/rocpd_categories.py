@@ -8,6 +8,7 @@ import sys
 
 def cat(name):
     if name.startswith('Cijk'): return 'GEMM (rocBLAS/Tensile)'
+    if 'split_gemm' in name: return 'split GEMM (mask einsum), bf16 MFMA (ours)'
     if 'spike_gemm_dw' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
     if 'spike_gemm' in name or 'split_bf16' in name: return 'spike GEMM fwd, bf16 MFMA (ours)'
     if 'up2x' in name: return 'upsample (ours)'
