@@ -441,22 +441,9 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
       if (CONV) {
         // X is the activation [B][K/9][H][W]; row k0 + row of the virtual im2col matrix, pixels l .. l+3 (W a power of two)
         // (channel, ky, kx) of this thread's row were decoded once, before the step loop
-        // An unaligned 16-byte load per lane (conv3_load) is split by the memory pipeline (measured: this loader 2.6x
-        // slower than the aligned one); here every lane loads its ALIGNED quad of the shifted row and the one pixel that
-        // the tap pulls in from the side comes from the neighbouring lane (the QPR lanes of a row slice are adjacent), or
-        // from one extra scalar load at the two ends of the slice.
-        const int ky = ctap[h] / 3, kx = ctap[h] - 3 * ky, lq = c % QPR;
-        const int yy = (l >> log_w) + ky - 1, px = l & (geo.W - 1);
-        const bool ok = lok && k0 + row < K && yy >= 0 && yy < geo.H;
-        const float* P = X + ((int64_t)b * geo.C + crow[h]) * L;
-        const int idx = ok ? l + (ky - 1) * geo.W : 0;
-        const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(P + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
-        float lft = __shfl_up(v.w, 1, 64), rgt = __shfl_down(v.x, 1, 64);
-        if (lq == 0) lft = (ok && kx == 0 && px > 0) ? P[idx - 1] : 0.f;
-        if (lq == QPR - 1) rgt = (ok && kx == 2 && px + 4 < geo.W) ? P[idx + 4] : 0.f;
-        if (px == 0) lft = 0.f;
-        if (px + 4 == geo.W) rgt = 0.f;
-        bq[h] = kx == 0 ? f32x4{lft, v.x, v.y, v.z} : (kx == 2 ? f32x4{v.y, v.z, v.w, rgt} : v);
+        const bool ok = lok && k0 + row < K;
+        bq[h] = conv3_load(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo,
+                           ok);
       } else {
         bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + ((int64_t)b * K + k0 + row) * L + l)
                                       : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -648,7 +635,8 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
   const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
   S2F_REQUIRE(x_terms == 1 || x_terms == 3, S2F_EINVAL, "s2f_spike_gemm_dw: x_terms must be 1 (X exact in bf16) or 3");
   // short ragged rows keep the 32-wide step; so does the general-X form (six LDS operand tiles)
-  // (the conv loader's extra state pushes the 64-wide variant to 257 registers = one wave per SIMD: 32-wide there)
+  // (the conv loader's extra state pushes the 64-wide variant to 257 registers = one wave per SIMD: 32-wide there; a
+  // loader built from aligned loads + neighbour-lane exchange was slower still than the unaligned 16-byte loads)
   const int bkv = (!conv && x_terms == 1 && (L % 64 == 0 || L >= 512)) ? 64 : 32;
   const int total_steps = batch * ((L + bkv - 1) / bkv);
   // Split count from a two-term cost model fitted on MI355X (tools/probe: one split = one workgroup per output tile):

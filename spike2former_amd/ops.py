@@ -425,10 +425,11 @@ _SPLIT_CACHE = {}
 SPIKE_GEMM_TERMS = 3          # number of bf16 weight terms (3 == fp32-equivalent)
 SPIKE_GEMM_ENABLED = True
 # 3x3 / stride 1 / pad 1 spike convolutions as implicit GEMMs (no im2col matrix; s2f_spike_conv3x3_fwd / _dw).  Measured at
-# C2 (tools/probe_conv3.py): the forward wins 1.0-2.4x (CB1_1.conv2: 1429 -> 716 us), the weight gradient loses 1.8x against
-# the kernel that reads the saved column matrix (its loader's shifts and edge loads land on an issue-bound loop), net
-# 63.4 vs 62.8 ms/step -- OFF until the weight-gradient loader is cheaper.
-CONV3X3_IMPLICIT = False
+# C2 (tools/probe_conv3.py, forward + weight gradient, us): 256x256 maps 627 vs 706 and 1676 vs 1856, 128x128 maps 530 vs
+# 513 and 772 vs 1054, 64x64 maps 485 vs 420 and 795 vs 660 -- the forward always wins (up to 2x), the weight gradient's
+# loader costs more than reading the saved column matrix, so the pair pays off on the large maps only.
+CONV3X3_IMPLICIT = True
+CONV3X3_IMPLICIT_MIN_PIXELS = 128 * 128
 MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pass split GEMM) instead of rocBLAS fp32
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
@@ -661,7 +662,8 @@ class _ConvDense(torch.autograd.Function):
         w2d = weight.view(M, -1)
         # implicit GEMM: 3x3, stride 1, padding 1 on spikes -- the kernels' loaders read the activation itself
         implicit = (spike_input and SPIKE_GEMM_ENABLED and CONV3X3_IMPLICIT and kh == 3 and kw == 3 and stride == 1
-                    and padding == 1 and C % 32 == 0 and W % 4 == 0 and (W & (W - 1)) == 0)
+                    and padding == 1 and C % 32 == 0 and W % 4 == 0 and (W & (W - 1)) == 0
+                    and H * W >= CONV3X3_IMPLICIT_MIN_PIXELS)
         if implicit:
             x = x.contiguous()
             if SPIKE_GEMM_CHECK:
