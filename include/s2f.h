@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 8
+#define S2F_ABI_VERSION 9
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -151,6 +151,11 @@ int s2f_spike_conv3x3_fwd(const uint16_t* w_split, const float* X, const float* 
                           int H, int W, int Mpad, int Kpad, int terms, void* stream);
 int s2f_spike_conv3x3_dw(const float* dY, const float* X, float* dW, int batch, int M, int C, int H, int W, int accumulate,
                          void* stream);
+/* 3x3 convolution (stride 1, padding 1) of a GENERAL fp32 tensor, implicit GEMM with both operands split hi+mid+lo
+ * (6 passes): Y[b] (M x H*W) = Wt (M x 9C, tap-major as above, Mpad % 128 == 0) (*) X[b] ([C, H, W]).  Used for the input
+ * gradient of the 3x3 convolutions as the transposed convolution dX = flip(W)^T (*) dY -- no unfold(dY), no col2im. */
+int s2f_conv3x3_general(const uint16_t* w_split, const float* X, float* Y, int batch, int M, int C, int H, int W, int Mpad,
+                        int Kpad, void* stream);
 /* General split GEMM on the same kernel structure:  Y[b] (M x N) = out_scale * A[b] (M x K) @ X[b] (K x N).
  *   a_split: bf16 terms as written by s2f_split_bf16x3: term i of batch b starts at a_split + i*a_term_stride +
  *     b*a_batch_stride (ELEMENTS; rows Kpad apart, Mpad readable rows per batch; a_batch_stride = 0 shares one A; several

@@ -37,6 +37,7 @@ SIGNATURES = {
     "s2f_upsample2x_bwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_spike_conv3x3_fwd": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),
     "s2f_spike_conv3x3_dw": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
+    "s2f_conv3x3_general": (_i, [_p, _p, _p] + [_i] * 7 + [_p]),
     "s2f_split_gemm": (_i, [_p, _i64, _i64, _i, _p, _i64, _i, _i64, _i, _p, _i64, _f, _i, _i, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_dw": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "s2f_sdsa_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),

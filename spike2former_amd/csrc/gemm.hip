@@ -256,13 +256,13 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
 // The bf16 products of term a_i x b_j are issued for i + j < max(AT, BT): (3,1) / (1,3) = 3 MFMA passes (one operand exact
 // in bf16, e.g. spikes), (3,3) = 6 passes = two general fp32 operands to 2^-24.  Used for the mask einsum (SDME):
 // forward (1,3) with K = T*C, d(mask_features) (1,3); same tiling and LDS layout as spike_gemm_kernel.
-template <int WM, int AT, int BT>
+template <int WM, int AT, int BT, bool CONV>
 __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned short* __restrict__ A, int64_t a_batch_stride,
                                                               int64_t term_stride, const float* __restrict__ X,
                                                               int64_t x_batch_stride,
                                                               int k_inner, int64_t x_outer_stride, float* __restrict__ Y,
                                                               int64_t y_batch_stride, float out_scale, int M, int N, int K,
-                                                              int Mpad, int Kpad, int n_tiles, int m_tiles) {
+                                                              int Mpad, int Kpad, int n_tiles, int m_tiles, Conv3 geo) {
   constexpr int BM = 64 * WM;
   constexpr int T = 128 * WM;
   constexpr int NP = (256 + T - 1) / T;
@@ -304,11 +304,19 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
       const int p = tid + q * T;
       const int kb = p / (BN / 4), nb = p % (BN / 4);
       const int n = n0 + nb * 4;
+      // conv mode (implicit 3x3, tap-major rows k = tap * C + c, see Conv3): X[b] is the [C][H][W] tensor itself
+      const int py = CONV ? n / geo.W : 0, px = CONV ? n - py * geo.W : 0;
+      const int tap = CONV ? kk / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky, c0 = CONV ? kk - tap * geo.C : 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = kk + kb * 4 + r;
-        const float* row = Xb + (int64_t)(k / k_inner) * x_outer_stride + (int64_t)(k % k_inner) * N;
-        breg[q][r] = (p < 256 && k < K && n < N) ? *reinterpret_cast<const f32x4*>(row + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = p < 256 && k < K && n < N;
+        if (CONV) {
+          breg[q][r] = conv3_load(Xb + (int64_t)(ok ? c0 + kb * 4 + r : 0) * N, n, py, px, ky, kx, geo, ok);
+        } else {
+          const float* row = Xb + (int64_t)(k / k_inner) * x_outer_stride + (int64_t)(k % k_inner) * N;
+          breg[q][r] = ok ? *reinterpret_cast<const f32x4*>(row + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
@@ -592,35 +600,56 @@ extern "C" int s2f_spike_conv3x3_fwd(const uint16_t* w_split, const float* X, co
                            Conv3{H, W, C}, stream);
 }
 
-extern "C" int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_term_stride, int a_terms,
-                              const float* X, int64_t x_batch_stride, int k_inner, int64_t x_outer_stride, int x_terms, float* Y,
-                              int64_t y_batch_stride, float out_scale, int batch, int M, int N, int K, int Mpad, int Kpad,
-                              void* stream) {
-  S2F_REQUIRE(a_split && X && Y, S2F_EINVAL, "s2f_split_gemm: null pointer");
-  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N > 0 && K > 0 && k_inner > 0, S2F_EINVAL, "s2f_split_gemm: bad sizes");
-  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "s2f_split_gemm: N=%d must be a multiple of 4", N);
+static int split_gemm_launch(const char* who, const uint16_t* a_split, int64_t a_batch_stride, int64_t a_term_stride,
+                             int a_terms, const float* X, int64_t x_batch_stride, int k_inner, int64_t x_outer_stride,
+                             int x_terms, float* Y, int64_t y_batch_stride, float out_scale, int batch, int M, int N, int K,
+                             int Mpad, int Kpad, bool conv, Conv3 geo, void* stream) {
+  S2F_REQUIRE(a_split && X && Y, S2F_EINVAL, "%s: null pointer", who);
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N > 0 && K > 0 && k_inner > 0, S2F_EINVAL, "%s: bad sizes", who);
+  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "%s: N=%d must be a multiple of 4", who, N);
   S2F_REQUIRE(Kpad >= K && Kpad % 32 == 0 && Mpad >= M && Mpad % 128 == 0, S2F_EINVAL,
-              "s2f_split_gemm: need Kpad %% 32 == 0 and Mpad %% 128 == 0");
+              "%s: need Kpad %% 32 == 0 and Mpad %% 128 == 0", who);
   S2F_REQUIRE((a_terms == 1 && x_terms == 3) || (a_terms == 3 && x_terms == 3) || (a_terms == 3 && x_terms == 1), S2F_EINVAL,
-              "s2f_split_gemm: (a_terms, x_terms) must be (1,3), (3,1) or (3,3)");
+              "%s: (a_terms, x_terms) must be (1,3), (3,1) or (3,3)", who);
   S2F_REQUIRE(s2f_aligned16(a_split) && s2f_aligned16(X) && s2f_aligned16(Y) && (x_batch_stride & 3) == 0 &&
                   (x_outer_stride & 3) == 0 && (a_batch_stride & 7) == 0 && (a_term_stride & 7) == 0,
-              S2F_EALIGN, "s2f_split_gemm: pointers / strides must keep 16-byte alignment");
+              S2F_EALIGN, "%s: pointers / strides must keep 16-byte alignment", who);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = (N + BN - 1) / BN, m_tiles = Mpad / 128;
   const dim3 grid(n_tiles * m_tiles, batch);
-#define S2F_SG(AT, BT)                                                                                                  \
-  S2F_LAUNCH(true, true, (split_gemm_kernel<2, AT, BT>), grid, dim3(256), 0, s, a_split, a_batch_stride, a_term_stride, X, \
-             x_batch_stride,                                                                                              \
-             k_inner, x_outer_stride, Y, y_batch_stride, out_scale, M, N, K, Mpad, Kpad, n_tiles, m_tiles)
-  if (a_terms == 1)
-    S2F_SG(1, 3);
-  else if (x_terms == 1)
-    S2F_SG(3, 1);
-  else
-    S2F_SG(3, 3);
+#define S2F_SG(AT, BT, CV)                                                                                              \
+  S2F_LAUNCH(true, true, (split_gemm_kernel<2, AT, BT, CV>), grid, dim3(256), 0, s, a_split, a_batch_stride, a_term_stride, \
+             X, x_batch_stride, k_inner, x_outer_stride, Y, y_batch_stride, out_scale, M, N, K, Mpad, Kpad, n_tiles,      \
+             m_tiles, geo)
+  if (conv) {
+    S2F_REQUIRE(a_terms == 3 && x_terms == 3, S2F_EINVAL, "%s: the convolution form takes two general operands", who);
+    S2F_SG(3, 3, true);
+  } else if (a_terms == 1) {
+    S2F_SG(1, 3, false);
+  } else if (x_terms == 1) {
+    S2F_SG(3, 1, false);
+  } else {
+    S2F_SG(3, 3, false);
+  }
 #undef S2F_SG
-  return s2f_check_launch("s2f_split_gemm");
+  return s2f_check_launch(who);
+}
+
+extern "C" int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_term_stride, int a_terms,
+                              const float* X, int64_t x_batch_stride, int k_inner, int64_t x_outer_stride, int x_terms,
+                              float* Y, int64_t y_batch_stride, float out_scale, int batch, int M, int N, int K, int Mpad,
+                              int Kpad, void* stream) {
+  return split_gemm_launch("s2f_split_gemm", a_split, a_batch_stride, a_term_stride, a_terms, X, x_batch_stride, k_inner,
+                           x_outer_stride, x_terms, Y, y_batch_stride, out_scale, batch, M, N, K, Mpad, Kpad, false,
+                           Conv3{0, 0, 0}, stream);
+}
+
+extern "C" int s2f_conv3x3_general(const uint16_t* w_split, const float* X, float* Y, int batch, int M, int C, int H, int W,
+                                   int Mpad, int Kpad, void* stream) {
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W > 0 && (W & 3) == 0, S2F_EINVAL,
+              "s2f_conv3x3_general: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  return split_gemm_launch("s2f_conv3x3_general", w_split, 0, (int64_t)Mpad * Kpad, 3, X, (int64_t)C * H * W, 1, 0, 3, Y,
+                           (int64_t)M * H * W, 1.0f, batch, M, H * W, 9 * C, Mpad, Kpad, true, Conv3{H, W, C}, stream);
 }
 
 static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,

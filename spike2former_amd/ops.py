@@ -430,6 +430,9 @@ SPIKE_GEMM_ENABLED = True
 # loader costs more than reading the saved column matrix, so the pair pays off on the large maps only.
 CONV3X3_IMPLICIT = True
 CONV3X3_IMPLICIT_MIN_PIXELS = 128 * 128
+# input gradient of the 3x3 convolutions as an implicit transposed convolution on the 6-pass split GEMM (no unfold / col2im)
+CONV3X3_DX_IMPLICIT = True
+CONV3X3_DX_MIN_PIXELS = 0          # measured at C2: a win on every map size (61.7 vs 62.3 ms/step)
 MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pass split GEMM) instead of rocBLAS fp32
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
@@ -461,6 +464,22 @@ def split_weight_conv3(weight):
     Mpad, Kpad = (M + 63) // 64 * 64, (9 * C + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), M, 9 * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
+    _SPLIT_CACHE[key] = (weight._version, out, (M, C))
+    return out
+
+
+def split_weight_tconv3(weight):
+    """[M, C, 3, 3] -> cached bf16 split of the transposed-convolution matrix [C, (ky, kx, m)] with flipped taps
+    (Wt[c][(ky, kx), m] = weight[m][c][2 - ky][2 - kx]), rows padded to a multiple of 128 for s2f_conv3x3_general."""
+    key = ("tconv", weight.data_ptr())
+    M, C = weight.shape[:2]
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0] == weight._version and hit[2] == (M, C):
+        return hit[1]
+    w2d = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * M)
+    Mpad, Kpad = (C + 127) // 128 * 128, (9 * M + 31) // 32 * 32
+    out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
+    check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), C, 9 * M, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
     _SPLIT_CACHE[key] = (weight._version, out, (M, C))
     return out
 
@@ -702,7 +721,14 @@ class _ConvDense(torch.autograd.Function):
         w2d = weight.view(M, -1)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            if M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
+            if (CONV3X3_DX_IMPLICIT and kh == 3 and kw == 3 and stride == 1 and padding == 1 and M % 32 == 0 and W % 4 == 0
+                    and gy.is_cuda and H * W >= CONV3X3_DX_MIN_PIXELS):
+                # transposed convolution dX = flip(W)^T (*) dY as an implicit 6-pass split GEMM: no unfold(dY), no col2im
+                wt = split_weight_tconv3(weight)
+                gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+                check(lib.s2f_conv3x3_general(_ptr(wt), _ptr(gy), _ptr(gx), N, C, M, H, W, wt.shape[1], wt.shape[2], _stream()),
+                      "s2f_conv3x3_general")
+            elif M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
                 wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
                 gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)
                 gx = torch.bmm(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)

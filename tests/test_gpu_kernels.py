@@ -536,11 +536,12 @@ def test_conv_dense_vs_aten_cpu(ops, N, C, M, H, W, k, s, p, spike):
     yo.backward(gy)
     for implicit in (False, True):            # im2col + GEMM lowering, and the implicit-GEMM kernels where they apply
         ops.CONV3X3_IMPLICIT, min_pixels, ops.CONV3X3_IMPLICIT_MIN_PIXELS = implicit, ops.CONV3X3_IMPLICIT_MIN_PIXELS, 0
+        ops.CONV3X3_DX_IMPLICIT = implicit
         try:
             xc, wc, bc = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
             yc = ops.conv_dense(xc, wc, bc, s, p, spike)
             yc.backward(gy.cuda())
         finally:
-            ops.CONV3X3_IMPLICIT, ops.CONV3X3_IMPLICIT_MIN_PIXELS = True, min_pixels
+            ops.CONV3X3_IMPLICIT, ops.CONV3X3_IMPLICIT_MIN_PIXELS, ops.CONV3X3_DX_IMPLICIT = True, min_pixels, True
         for a, r in ((yc, yo), (xc.grad, xo.grad), (wc.grad, wo.grad), (bc.grad, bo.grad)):
             assert (a.detach().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.abs().max().item(), implicit
