@@ -120,22 +120,28 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const float* __restrict
 template <int K>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ border,
                                                        const float* __restrict__ gy, float* __restrict__ gw, int C, int H,
-                                                       int W, int Ho, int Wo, int pad, int tiles_x) {
+                                                       int W, int Ho, int Wo, int pad, int tiles_x, int ntiles) {
   constexpr int HS = TS + K - 1;
   constexpr int KK = K * K;
   __shared__ float s[HS][HS + 1];
   __shared__ float red[4][KK];
   const int plane = blockIdx.y;
   const int c = plane % C;
-  const int ty = (blockIdx.x / tiles_x) * TS, tx = (blockIdx.x % tiles_x) * TS;
   const float* xp = x + (int64_t)plane * H * W;
   const float* gp = gy + (int64_t)plane * Ho * Wo;
   const float fillv = border ? border[c] : 0.f;
   const bool vec_ok = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15u) == 0;
-  stage_halo<K>(s, xp, H, W, ty - pad, tx - pad, pad, fillv, pad, vec_ok);
   const int r = threadIdx.x >> 3, q0 = (threadIdx.x & 7) * 4;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  {
+  float acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+  // a workgroup walks several tiles of its plane with the K*K partial sums in registers: the K*K block reductions (6
+  // shuffle steps each) and the atomics are paid once per workgroup, not once per tile
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ty = (tile / tiles_x) * TS, tx = (tile % tiles_x) * TS;
+    __syncthreads();                          // the previous tile's readers are done with s
+    stage_halo<K>(s, xp, H, W, ty - pad, tx - pad, pad, fillv, pad, vec_ok);
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
     const int oy = ty + r, ox = tx + q0;
     const float* p = gp + (int64_t)oy * Wo + ox;
     if (oy < Ho) {
@@ -148,16 +154,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
           if (ox + o < Wo) g[o] = p[o];
       }
     }
-  }
-  __syncthreads();
-  float acc[KK];
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    float row[K + 3];
+    for (int i = 0; i < K; ++i) {
+      float row[K + 3];
 #pragma unroll
-    for (int j = 0; j < K + 3; ++j) row[j] = s[r + i][q0 + j];
+      for (int j = 0; j < K + 3; ++j) row[j] = s[r + i][q0 + j];
 #pragma unroll
-    for (int j = 0; j < K; ++j) acc[i * K + j] = (g[0] * row[j] + g[1] * row[j + 1]) + (g[2] * row[j + 2] + g[3] * row[j + 3]);
+      for (int j = 0; j < K; ++j)
+        acc[i * K + j] += (g[0] * row[j] + g[1] * row[j + 1]) + (g[2] * row[j + 2] + g[3] * row[j + 3]);
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -232,12 +238,17 @@ extern "C" int s2f_dwconv_bwd_weight(const float* x, const float* border, const 
   if (!accumulate && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C * K * K, s) != hipSuccess)
     return s2f_check_launch("s2f_dwconv_bwd_weight memset");
   const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
-  const dim3 grid(tiles_x * tiles_y, N * C);
+  const int ntiles = tiles_x * tiles_y;
+  // workgroups per plane: enough for >= 2048 in flight, at most one per tile
+  int per_plane = (2048 + N * C - 1) / (N * C);
+  if (per_plane > ntiles) per_plane = ntiles;
+  if (per_plane < 1) per_plane = 1;
+  const dim3 grid(per_plane, N * C);
   if (K == 3)
-    hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x, ntiles);
   else if (K == 5)
-    hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x, ntiles);
   else
-    hipLaunchKernelGGL(dw_wgrad_kernel<7>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL(dw_wgrad_kernel<7>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x, ntiles);
   return s2f_check_launch("s2f_dwconv_bwd_weight");
 }
