@@ -111,6 +111,66 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// The 3x3 / Cg = 8 geometry of the pixel decoder, fully unrolled: the 27 offset / mask values of a (pixel, group) are loaded
+// first, then the 4 x 2 corner vectors of three taps at a time -- 1 + 3 dependent round trips per thread instead of the
+// 2 x 9 of the generic loop (whose trip count is a run-time value, so nothing is hoisted).
+__global__ __launch_bounds__(256) void dcn_fwd_k3c8_kernel(const float* __restrict__ in, const float* __restrict__ off,
+                                                           const float* __restrict__ msk, float* __restrict__ out, Geom g) {
+  typedef __attribute__((ext_vector_type(4))) float v4;
+  const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+  const int C = g.G * 8;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx % g.G);
+    int64_t r = idx / g.G;
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int n = (int)(r / g.Ho);
+    const int64_t pix = ((int64_t)n * g.Ho + ho) * g.Wo + wo;
+    const float* offp = off + (pix * g.G + gi) * 18;
+    const float* mp = msk + (pix * g.G + gi) * 9;
+    const float* inb = in + (int64_t)n * g.H * g.W * C + gi * 8;
+    float ov[18], mv[9];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) ov[k] = offp[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mv[k] = mp[k];
+    v4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < 9; k0 += 3) {
+      v4 c0[3][4], c1[3][4];
+      float wgt[3][4];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = k0 + u;
+        const Tap t = make_tap(g, ho, wo, k / 3, k % 3, ov[2 * k], ov[2 * k + 1]);
+        const float m = mv[k];
+        wgt[u][0] = (1.f - t.ly) * (1.f - t.lx) * m; wgt[u][1] = (1.f - t.ly) * t.lx * m;
+        wgt[u][2] = t.ly * (1.f - t.lx) * m;         wgt[u][3] = t.ly * t.lx * m;
+        const bool b[4] = {t.vy0 && t.vx0, t.vy0 && t.vx1, t.vy1 && t.vx0, t.vy1 && t.vx1};
+        const int64_t o00 = ((int64_t)t.y0 * g.W + t.x0) * C;
+        const int64_t o[4] = {o00, o00 + C, o00 + (int64_t)g.W * C, o00 + (int64_t)g.W * C + C};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* p = inb + (b[q] ? o[q] : 0);
+          const v4 z = {0.f, 0.f, 0.f, 0.f};
+          c0[u][q] = b[q] ? *reinterpret_cast<const v4*>(p) : z;
+          c1[u][q] = b[q] ? *reinterpret_cast<const v4*>(p + 4) : z;
+        }
+      }
+      // same operation order as the generic kernel: ((v00*w00 + v01*w01) + v10*w10) + v11*w11, tap after tap
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        acc0 += ((c0[u][0] * wgt[u][0] + c0[u][1] * wgt[u][1]) + c0[u][2] * wgt[u][2]) + c0[u][3] * wgt[u][3];
+        acc1 += ((c1[u][0] * wgt[u][0] + c1[u][1] * wgt[u][1]) + c1[u][2] * wgt[u][2]) + c1[u][3] * wgt[u][3];
+      }
+    }
+    float* outp = out + pix * C + gi * 8;
+    *reinterpret_cast<v4*>(outp) = acc0;
+    *reinterpret_cast<v4*>(outp + 4) = acc1;
+  }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void dcn_bwd_kernel(const float* __restrict__ in, const float* __restrict__ off,
                                                       const float* __restrict__ msk, const float* __restrict__ gout,
@@ -332,7 +392,10 @@ extern "C" int s2f_dcnv3_fwd(const float* input, const float* offset, const floa
   if (rc != S2F_OK) return rc;
   const int64_t total = (int64_t)N * g.Ho * g.Wo * G;
   const bool vec = (Cg % 4 == 0) && s2f_aligned16(input) && s2f_aligned16(output);
-  if (vec)
+  if (vec && Cg == 8 && Kh == 3 && Kw == 3)
+    hipLaunchKernelGGL(dcn_fwd_k3c8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
+                       output, g);
+  else if (vec)
     hipLaunchKernelGGL(dcn_fwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
                        output, g);
   else
