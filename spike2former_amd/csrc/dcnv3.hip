@@ -239,6 +239,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(const float* __restrict__ 
 // sum of 4*K*Ho*Wo contributions still fits in 62 bits: every contribution is then rounded at <= 2^-(acc_bits) of that
 // bound -- finer than one fp32 ulp of any partial sum an fp32 atomic would have formed -- and the result no longer depends
 // on the order of the adds (the reference's CUDA op, dcnv3_im2col_cuda.cuh:278-839, uses fp32 atomicAdd in global memory).
+// float -> round-to-nearest-even 64-bit integer for |v| < 2^51 in three instructions (v_cvt_f64_f32, v_add_f64, 64-bit
+// subtract): adding 1.5 * 2^52 leaves the integer in the low mantissa bits.  The generic float -> int64 conversion is a
+// ~15-instruction emulation, issued 32 times per work item here.
+__device__ __forceinline__ unsigned long long fix64(float v) {
+  const double magic = 6755399441055744.0;
+  return (unsigned long long)(__double_as_longlong((double)v + magic) - __double_as_longlong(magic));
+}
+
 constexpr int kChunk = 256;   // output pixels whose offsets / mask / grad_output are staged in LDS at a time
 
 __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ off,
@@ -250,8 +258,11 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
   const int n = blockIdx.x / g.G, gi = blockIdx.x % g.G;
   const int Cg = g.Cg, C = g.G * g.Cg, P = g.Kh * g.Kw;
   const int npix_in = g.H * g.W, npix_out = g.Ho * g.Wo;
-  unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(smem_raw);      // [H*W][Cg] fixed-point grad_input
-  float* s_in = reinterpret_cast<float*>(s_acc + (size_t)npix_in * Cg);             // [H*W][Cg]
+  // rows padded to Cg + 1 accumulators: with Cg = 8 consecutive pixels would lie 64 bytes apart and the 64 lanes of one
+  // ds_add_u64 (same channel, neighbouring pixels) would share 4 bank pairs
+  const int CA = Cg + 1;
+  unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(smem_raw);      // [H*W][Cg + 1] fixed-point grad_input
+  float* s_in = reinterpret_cast<float*>(s_acc + (size_t)npix_in * CA);             // [H*W][Cg]
   float* s_off = s_in + npix_in * Cg;       // [kChunk][P*2]
   float* s_msk = s_off + kChunk * P * 2;    // [kChunk][P]
   float* s_go = s_msk + kChunk * P;         // [kChunk][Cg]
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
   for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
     s_in[e] = inb[(int64_t)p * C + c];
-    s_acc[e] = 0ull;
+    s_acc[p * CA + c] = 0ull;
   }
   // scale of this slice: max|grad_output| * max|mask| bounds every contribution
   float mg = 0.f, mm = 0.f;
@@ -290,10 +301,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
   const float scale = ldexpf(1.f, shift);
   const double inv_scale = ldexp(1.0, -shift);
 
-  const bool lanes_per_channel = (Cg & (Cg - 1)) == 0 && Cg <= 64;
-  const int CL = lanes_per_channel ? Cg : 1;
-  const int cl = threadIdx.x % CL;
-  const int slots = blockDim.x / CL;
+  const int slots = blockDim.x;
   for (int p0 = 0; p0 < npix_out; p0 += kChunk) {
     // The offsets / mask / grad_output of a pixel chunk are staged with one bulk load (every thread of the 16 waves
     // issues its loads at once) instead of a dependent global round trip per item.
@@ -308,12 +316,12 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
     }
     for (int e = threadIdx.x; e < pc * Cg; e += blockDim.x) s_go[e] = gob[(int64_t)(p0 + e / Cg) * C + e % Cg];
     __syncthreads();
-    // Work item = (tap, pixel of the chunk).  With Cg a power of two the Cg channels of an item sit on Cg adjacent lanes
-    // and a wavefront handles 64/Cg consecutive pixels of one tap; the per-item sums for grad_mask / grad_offset finish
-    // with a log2(Cg)-step lane shuffle (no cross-thread reduction through memory, cf. .cuh:907-1039).
+    // Work item = (tap, pixel of the chunk), one per thread, the Cg channels in an inner loop: the tap geometry is computed
+    // once per item.  (Spreading the channels of an item over Cg adjacent lanes -- conflict-free LDS adds -- mattered with
+    // the slow ds_add_f32; with integer LDS atomics it only replicates the tap arithmetic Cg times: 199 vs 178 us.)
     const int items = pc * P;
     for (int it0 = 0; it0 < items; it0 += slots) {
-      const int it = it0 + threadIdx.x / CL;
+      const int it = it0 + threadIdx.x;
       const bool live = it < items;
       const int k = live ? it / pc : 0, pl = live ? it % pc : 0;
       const int pix = p0 + pl;
@@ -327,26 +335,39 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
                  b11 = live && t.vy1 && t.vx1;
       const int o00 = (t.y0 * g.W + t.x0) * Cg;
       const int o01 = o00 + Cg, o10 = o00 + g.W * Cg, o11 = o10 + Cg;
+      const int a00 = (t.y0 * g.W + t.x0) * CA;
       float am = 0.f, ax = 0.f, ay = 0.f;
-      for (int c = cl; c < Cg; c += CL) {
-        const float gv = live ? s_go[pl * Cg + c] : 0.f;
-        const float a = b00 ? s_in[o00 + c] : 0.f, b = b01 ? s_in[o01 + c] : 0.f;
-        const float cc = b10 ? s_in[o10 + c] : 0.f, d = b11 ? s_in[o11 + c] : 0.f;
+      // channels four at a time: 16-byte LDS reads of the grad_output row and the four corner rows (scalar reads put the
+      // lanes of a wave Cg floats apart = a Cg-way bank conflict)
+      auto body = [&](int c, float gv, float a, float b, float cc, float d) __attribute__((always_inline)) {
         am += gv * (a * w00 + b * w01 + cc * w10 + d * w11);
         ax += gv * ((1.f - t.ly) * (b - a) + t.ly * (d - cc));
         ay += gv * ((1.f - t.lx) * (cc - a) + t.lx * (d - b));
         const float gm = gv * m * scale;
-        if (b00) atomicAdd(&s_acc[o00 + c], (unsigned long long)__float2ll_rn(gm * w00));
-        if (b01) atomicAdd(&s_acc[o01 + c], (unsigned long long)__float2ll_rn(gm * w01));
-        if (b10) atomicAdd(&s_acc[o10 + c], (unsigned long long)__float2ll_rn(gm * w10));
-        if (b11) atomicAdd(&s_acc[o11 + c], (unsigned long long)__float2ll_rn(gm * w11));
+        if (b00) atomicAdd(&s_acc[a00 + c], fix64(gm * w00));
+        if (b01) atomicAdd(&s_acc[a00 + CA + c], fix64(gm * w01));
+        if (b10) atomicAdd(&s_acc[a00 + g.W * CA + c], fix64(gm * w10));
+        if (b11) atomicAdd(&s_acc[a00 + g.W * CA + CA + c], fix64(gm * w11));
+      };
+      if ((Cg & 3) == 0 && ((npix_in * CA) & 1) == 0) {          // second test: s_in starts 16-byte aligned
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < Cg; c += 4) {
+          const float4 gv = live ? *reinterpret_cast<const float4*>(&s_go[pl * Cg + c]) : z4;
+          const float4 a = b00 ? *reinterpret_cast<const float4*>(&s_in[o00 + c]) : z4;
+          const float4 b = b01 ? *reinterpret_cast<const float4*>(&s_in[o01 + c]) : z4;
+          const float4 cc = b10 ? *reinterpret_cast<const float4*>(&s_in[o10 + c]) : z4;
+          const float4 d = b11 ? *reinterpret_cast<const float4*>(&s_in[o11 + c]) : z4;
+          body(c, gv.x, a.x, b.x, cc.x, d.x);
+          body(c + 1, gv.y, a.y, b.y, cc.y, d.y);
+          body(c + 2, gv.z, a.z, b.z, cc.z, d.z);
+          body(c + 3, gv.w, a.w, b.w, cc.w, d.w);
+        }
+      } else {
+        for (int c = 0; c < Cg; ++c)
+          body(c, live ? s_go[pl * Cg + c] : 0.f, b00 ? s_in[o00 + c] : 0.f, b01 ? s_in[o01 + c] : 0.f,
+               b10 ? s_in[o10 + c] : 0.f, b11 ? s_in[o11 + c] : 0.f);
       }
-      for (int o = CL >> 1; o > 0; o >>= 1) {          // CL divides 64: the group never straddles a wavefront
-        am += __shfl_xor(am, o, 64);
-        ax += __shfl_xor(ax, o, 64);
-        ay += __shfl_xor(ay, o, 64);
-      }
-      if (live && cl == 0) {
+      if (live) {
         const int64_t ob = (((int64_t)n * npix_out + pix) * g.G + gi) * P + k;
         gmsk[ob] = am;
         goff[ob * 2] = ax * m * g.osc;
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
   float* ginb = gin + (int64_t)n * npix_in * C + gi * Cg;
   for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
     const int p = e / Cg, c = e % Cg;
-    ginb[(int64_t)p * C + c] = (float)((double)(long long)s_acc[e] * inv_scale);
+    ginb[(int64_t)p * C + c] = (float)((double)(long long)s_acc[p * CA + c] * inv_scale);
   }
 }
 
@@ -415,7 +436,7 @@ extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const floa
                      "s2f_dcnv3_bwd");
   if (rc != S2F_OK) return rc;
   const int64_t total = (int64_t)N * g.Ho * g.Wo * G;
-  const size_t lds = (size_t)12 * H * W * Cg + sizeof(float) * (size_t)kChunk * (Kh * Kw * 3 + Cg);
+  const size_t lds = (size_t)H * W * (8 * (Cg + 1) + 4 * Cg) + sizeof(float) * (size_t)kChunk * (Kh * Kw * 3 + Cg);
   constexpr size_t kMaxDynLds = 160 * 1024 - 256;          // the kernel also holds 128 B of static LDS
   if (lds <= kMaxDynLds) {
     // (n, group) slice fits in the CU's 160 KiB LDS: no global atomics
