@@ -93,3 +93,45 @@ def test_shard_batch():
     assert [shard_batch(16, r, 8) for r in (0, 7)] == [(0, 2), (14, 2)]
     with pytest.raises(ValueError):
         shard_batch(6, 0, 4)
+
+
+def test_flat_grad_buffer_sinks_and_compaction():
+    """Gradient sinks (dist.FlatGradAllReduce.install_sinks / compact): parameters whose gradient is accumulated straight
+    into the flat buffer by a kernel (p.grad stays None) are moved behind the others, packing the rest stays one batched
+    copy over the leading region, and the sunk slices are left untouched; without sinks a missing gradient packs as zeros."""
+    import torch
+
+    from spike2former_amd import ops
+    from spike2former_amd.dist import FlatGradAllReduce
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (3, 5, 2, 4)]
+    red = FlatGradAllReduce(ps, world_size=1)
+    # no sinks: None -> zeros (not the stale content of the slice)
+    red.flat.fill_(7.0)
+    red.zero()
+    ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
+    red.gather()
+    assert red.flat.tolist() == [1.0] * 3 + [0.0] * 5 + [2.0] * 2 + [0.0] * 4
+    try:
+        red.install_sinks()
+        assert set(ops.GRAD_SINKS) == {p.data_ptr() for p in ps}
+        # step 1: "kernels" add into the sinks of parameters 1 and 3, autograd assigns the others
+        red.zero()
+        assert float(red.flat.abs().sum()) == 0.0
+        ops.GRAD_SINKS[ps[1].data_ptr()].add_(torch.arange(5.0))
+        ops.GRAD_SINKS[ps[3].data_ptr()].add_(1.5)
+        ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
+        red.gather()                                       # not compacted yet: one copy per run
+        assert red.flat.tolist() == [1.0] * 3 + [0.0, 1.0, 2.0, 3.0, 4.0] + [2.0] * 2 + [1.5] * 4
+        red.compact()
+        assert [p.numel() for p in red.params] == [3, 2, 5, 4] and red._dense_elems == 5
+        # step 2 in the compacted layout
+        red.zero()
+        ops.GRAD_SINKS[ps[1].data_ptr()].add_(torch.arange(5.0))
+        ops.GRAD_SINKS[ps[3].data_ptr()].add_(1.5)
+        ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
+        red.gather()
+        assert red.flat.tolist() == [1.0] * 3 + [2.0] * 2 + [0.0, 1.0, 2.0, 3.0, 4.0] + [1.5] * 4
+        for p, v in zip(red.params, red.views):
+            assert v.shape == p.shape and ops.GRAD_SINKS[p.data_ptr()].data_ptr() == v.data_ptr()
+    finally:
+        ops.GRAD_SINKS = None
