@@ -138,15 +138,27 @@ __device__ __forceinline__ void fetch_tile(u32x4 (&areg)[TERMS][2], f32x4 (&breg
   }
 }
 
-template <int WM, int TERMS, bool CONV>
-__global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned short* __restrict__ Wsplit,
-                                                              const float* __restrict__ X, const float* __restrict__ bias,
-                                                              float* __restrict__ Y, int M, int N, int K, int Mpad, int Kpad,
-                                                              int n_tiles, int m_tiles, Conv3 geo) {
+// KG = 2: intra-workgroup split-K.  The 32x32-stage GEMMs of the path have only 128-256 output tiles of 64 x 128 (two waves
+// each): two waves per CU, every K step a serial load -> LDS -> MFMA chain.  With KG = 2 a second pair of waves walks the odd
+// K steps of the same tile in its own LDS buffers and the partial tiles are summed through LDS at the end: KG times the
+// waves in flight, 1/KG of the steps per wave.
+template <int WM, int TERMS, bool CONV, int KG>
+__global__ __launch_bounds__(128 * WM * KG) void spike_gemm_kernel(const unsigned short* __restrict__ Wsplit,
+                                                                   const float* __restrict__ X,
+                                                                   const float* __restrict__ bias, float* __restrict__ Y,
+                                                                   int M, int N, int K, int Mpad, int Kpad, int n_tiles,
+                                                                   int m_tiles, Conv3 geo) {
   constexpr int BM = 64 * WM;
   constexpr int T = 128 * WM;
-  __shared__ __attribute__((aligned(16))) unsigned short As[TERMS][BM][LDR];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[BN][LDR];
+  constexpr int GROUP_ELEMS = (TERMS * BM + BN) * LDR;                      // bf16 elements of one group's A + B tiles
+  constexpr int RED_BYTES = (KG - 1) * T * 64 * 4;                          // partial accumulators of groups 1 .. KG-1
+  constexpr int LDS_BYTES = KG * GROUP_ELEMS * 2 > RED_BYTES ? KG * GROUP_ELEMS * 2 : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  const int grp = KG > 1 ? threadIdx.x / T : 0;
+  const int tid = KG > 1 ? threadIdx.x - grp * T : threadIdx.x;
+  unsigned short(*As)[BM][LDR] = reinterpret_cast<unsigned short(*)[BM][LDR]>(smem + (size_t)grp * GROUP_ELEMS * 2);
+  unsigned short(*Bs)[LDR] =
+      reinterpret_cast<unsigned short(*)[LDR]>(smem + (size_t)grp * GROUP_ELEMS * 2 + (size_t)TERMS * BM * LDR * 2);
 
   // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a contiguous range of
   // tiles with the m-tiles of one n-tile adjacent, so that re-reads of an X tile hit that XCD's L2.
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
   const float* Xb = X + (int64_t)b * (CONV ? K / 9 : K) * N;
   float* Yb = Y + (int64_t)b * M * N;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
   f32x16 acc[2][2];
@@ -176,8 +188,23 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
   u32x4 areg[TERMS][2];
   f32x4 breg[NP][4];
 
-  fetch_tile<WM, TERMS, CONV>(areg, breg, Wsplit, Xb, term_stride, m0, n0, 0, tid, K, N, Kpad, geo);
-  for (int k0 = 0; k0 < Kpad; k0 += BK) {
+  // group g walks the K steps g, g + KG, ...; both groups run the same number of iterations (barriers), a step past the
+  // end contributes zeros (the A load is skipped there: the padded weight has no columns beyond Kpad)
+  const int kloop = (Kpad + KG * BK - 1) / (KG * BK) * (KG * BK);
+  auto fetch = [&](int kk) __attribute__((always_inline)) {
+    if (KG > 1 && kk >= Kpad) {
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t) areg[t][0] = areg[t][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) breg[q][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      fetch_tile<WM, TERMS, CONV>(areg, breg, Wsplit, Xb, term_stride, m0, n0, kk, tid, K, N, Kpad, geo);
+    }
+  };
+  fetch(grp * BK);
+  for (int k0 = grp * BK; k0 < kloop; k0 += KG * BK) {
     // registers -> LDS (A as is; X converted to bf16 and transposed to [n][k])
 #pragma unroll
     for (int t = 0; t < TERMS; ++t) {
@@ -205,7 +232,7 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
       }
     }
     __syncthreads();
-    if (k0 + BK < Kpad) fetch_tile<WM, TERMS, CONV>(areg, breg, Wsplit, Xb, term_stride, m0, n0, k0 + BK, tid, K, N, Kpad, geo);
+    if (k0 + KG * BK < kloop) fetch(k0 + KG * BK);
     // ---- MFMA: 2 k-slices x (2 x 2 tiles) x terms
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -228,6 +255,28 @@ __global__ __launch_bounds__(128 * WM) void spike_gemm_kernel(const unsigned sho
       }
     }
     __syncthreads();
+  }
+  if (KG > 1) {
+    // groups 1 .. KG-1 hand their partial tiles over through LDS (the operand tiles are dead after the last barrier)
+    float* red = reinterpret_cast<float*>(smem);
+    if (grp > 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((grp - 1) * 4 + i * 2 + j) * 16 + r) * T + tid] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((g - 1) * 4 + i * 2 + j) * 16 + r) * T + tid];
   }
   // ---- epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -559,20 +608,27 @@ static int spike_gemm_launch(const char* who, const uint16_t* w_split, const flo
   }
   const int m_tiles = Mpad / (64 * wm);
   const dim3 grid(n_tiles * m_tiles, batch);
-#define S2F_GEMM_GO(WMV, TV, CV)                                                                                        \
-  S2F_LAUNCH(true, true, (spike_gemm_kernel<WMV, TV, CV>), grid, dim3(128 * WMV), 0, s, w_split, X, bias, Y, M, N, K, Mpad, \
-             Kpad, n_tiles, m_tiles, geo)
-#define S2F_GEMM_T(WMV, CV)                    \
-  if (terms == 3) S2F_GEMM_GO(WMV, 3, CV);      \
-  else if (terms == 2) S2F_GEMM_GO(WMV, 2, CV); \
-  else S2F_GEMM_GO(WMV, 1, CV)
-#define S2F_GEMM_W(CV)     \
-  if (wm == 4) {           \
-    S2F_GEMM_T(4, CV);     \
-  } else if (wm == 2) {    \
-    S2F_GEMM_T(2, CV);     \
-  } else {                 \
-    S2F_GEMM_T(1, CV);     \
+  // intra-workgroup split-K for the narrowest tile when even that leaves the chip under-filled (see spike_gemm_kernel)
+  const bool thin = wm == 1 && (int64_t)n_tiles * m_tiles * batch < 512;
+  const int kg = (thin && Kpad >= 4 * BK) ? 2 : 1;          // KG = 4 measured slightly slower than 2 (58.7 vs 58.5 ms/step)
+#define S2F_GEMM_GO(WMV, TV, CV, KGV)                                                                                   \
+  S2F_LAUNCH(true, true, (spike_gemm_kernel<WMV, TV, CV, KGV>), grid, dim3(128 * WMV * KGV), 0, s, w_split, X, bias, Y, M, N, \
+             K, Mpad, Kpad, n_tiles, m_tiles, geo)
+#define S2F_GEMM_T(WMV, CV, KGV)                    \
+  if (terms == 3) S2F_GEMM_GO(WMV, 3, CV, KGV);      \
+  else if (terms == 2) S2F_GEMM_GO(WMV, 2, CV, KGV); \
+  else S2F_GEMM_GO(WMV, 1, CV, KGV)
+#define S2F_GEMM_W(CV)        \
+  if (wm == 4) {              \
+    S2F_GEMM_T(4, CV, 1);     \
+  } else if (wm == 2) {       \
+    S2F_GEMM_T(2, CV, 1);     \
+  } else if (kg == 4) {       \
+    S2F_GEMM_T(1, CV, 4);     \
+  } else if (kg == 2) {       \
+    S2F_GEMM_T(1, CV, 2);     \
+  } else {                    \
+    S2F_GEMM_T(1, CV, 1);     \
   }
   if (conv) {
     S2F_GEMM_W(true)
