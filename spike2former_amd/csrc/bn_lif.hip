@@ -393,6 +393,13 @@ __global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
     base[i] = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
     zv[i] = ld4(z + base[i]);
   }
+  // the residual is independent of the statistics: its loads ride with z's instead of forming a second dependent round trip
+  // after the block reduction (~1.5 us of a 9 us kernel)
+  Tile4 rvp[kTpw];
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < kTpw; ++i) rvp[i] = ld4(res + base[i]);
+  }
   float ps = 0.f, pq = 0.f;
 #pragma unroll
   for (int i = 0; i < kTpw; ++i) {
@@ -427,13 +434,12 @@ __global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
   for (int i = 0; i < kTpw; ++i) {
     bool inr[4] = {false, false, false, false};
     if (ok[i]) {                                            // wave-uniform
-      Tile4 rv, vv, uo, yo, vo;
-      if (res) rv = ld4(res + base[i]);
+      Tile4 vv, uo, yo, vo;
       if (LIF && HAS_V) vv = ld4(v_in + base[i]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float u = ((zv[i].a[j] + b) - mean) * rstd * g + be;
-        if (res) u += rv.a[j];
+        if (res) u += rvp[i].a[j];
         uo.a[j] = u;
         if (LIF) {
           const float h = HAS_V ? (vv.a[j] + u) : u;
