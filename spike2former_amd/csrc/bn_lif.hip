@@ -145,6 +145,18 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
   // the streaming loop then reads two LDS floats per lane.  Doing the fp64 arithmetic per tile instead kept the kernel
   // VALU-bound at 3.7 TB/s.
   extern __shared__ __attribute__((aligned(16))) float sstat[];      // [3][C]: mean, rstd, var
+  // The operands of a wave's next tile are requested one iteration ahead -- the first ones before the prologue -- so the
+  // statistics prologue and every tile's arithmetic run under a load instead of in front of one.
+  Tile4 zn, rn, vn;
+  auto request = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t base = tile * 256 + lane * 4;
+    if (tile < ntiles && base < total) {
+      zn = ld4(z + base);
+      if (res) rn = ld4(res + base);
+      if (LIF && HAS_V) vn = ld4(v_in + base);
+    }
+  };
+  request(wave0);
   for (int c = threadIdx.x; c < C; c += kBlock) {
     const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
     sstat[c] = cs.mean;
@@ -157,6 +169,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
     const int64_t base = tile * 256 + lane * 4;
     const bool ok = base < total;                       // total % 4 == 0 -> whole float4 valid or not
     bool inr[4] = {false, false, false, false};
+    const Tile4 zv = zn, rv = rn, vv = vn;
+    request(tile + nwaves);
     if (ok) {
       const int c = channel_of(base, C, L, small);
       const float b = bias ? bias[c] : 0.f;
@@ -176,10 +190,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
         stat[2 * C + c] = be - rm * g / sqrtf(rv + eps);      // BN(0) from the (updated) running statistics
         if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
       }
-      const Tile4 zv = ld4(z + base);
-      Tile4 rv, vv, uo, yo, vo;
-      if (res) rv = ld4(res + base);
-      if (LIF && HAS_V) vv = ld4(v_in + base);
+      Tile4 uo, yo, vo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float u = ((zv.a[j] + b) - mean) * rstd * g + be;
@@ -312,6 +323,22 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
   const int64_t ntiles = (total + 255) >> 8;
   extern __shared__ __attribute__((aligned(16))) float sstat[];      // [2][C]: mean(gu), mean(gu * xhat)
+  Tile4 zn, an, bn, cn;                       // next tile's operands, requested one iteration ahead (see bn_apply_kernel)
+  uint64_t mn[4] = {0, 0, 0, 0};
+  auto request = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t base = tile * 256 + lane * 4;
+    if (tile < ntiles && base < total) {
+      zn = ld4(z + base);
+      if (g_u) an = ld4(g_u + base);
+      if (g_y) bn = ld4(g_y + base);
+      if (g_v) cn = ld4(g_v + base);
+      if (mask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mn[j] = mask[tile * 4 + j];
+      }
+    }
+  };
+  request(wave0);
   for (int c = threadIdx.x; c < C; c += kBlock) {
     sstat[c] = training ? (float)(sums[2 * c] * inv_count) : 0.f;
     sstat[C + c] = training ? (float)(sums[2 * c + 1] * inv_count) : 0.f;
@@ -320,6 +347,9 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
   const bool small = (total >> 32) == 0;
   for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * 256 + lane * 4;
+    const Tile4 zv = zn, a = an, bb = bn, cc = cn;
+    const uint64_t mw[4] = {mn[0], mn[1], mn[2], mn[3]};
+    request(tile + nwaves);
     if (base >= total) continue;
     const int c = channel_of(base, C, L, small);
     const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
@@ -328,14 +358,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
       dbeta[c] = (float)sums[2 * c];
       dgamma[c] = (float)sums[2 * c + 1];
     }
-    const Tile4 zv = ld4(z + base);
-    Tile4 a, bb, cc, o, r;
-    if (g_u) a = ld4(g_u + base);
-    if (g_y) bb = ld4(g_y + base);
-    if (g_v) cc = ld4(g_v + base);
+    Tile4 o, r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool m = mask ? ((mask[tile * 4 + j] >> lane) & 1ull) : false;
+      const bool m = mask ? ((mw[j] >> lane) & 1ull) : false;
       const float gu = form_gu(g_u != nullptr, a.a[j], g_y != nullptr, bb.a[j], g_v != nullptr, cc.a[j], m, vth, Df);
       const float xhat = ((zv.a[j] + b) - mean) * rstd;
       o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
