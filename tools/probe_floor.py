@@ -25,7 +25,7 @@ for n in (1 << 16, 204800, 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24):
     t_bn = t_st = float("nan")
     if L >= 4:
         z = x[:8 * C * L].view(8, C, L); sums = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
-        stat = torch.empty(2 * C, device="cuda"); g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+        stat = torch.empty(3 * C, device="cuda"); g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
         rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda"); nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
         def st_():
             sums.zero_(); 

@@ -23,7 +23,7 @@ for N, C, L in [(8, 256, 1024), (8, 512, 1024), (8, 256, 4096), (8, 1024, 1024),
     t2 = timeit(lambda: lib.s2f_lif_bwd(x.data_ptr(), None, mask.data_ptr(), gx.data_ptr(), n, 1.0, 8, s))
     z = x.view(N, C, L)
     gamma = torch.ones(C, device="cuda"); beta = torch.zeros(C, device="cuda")
-    ws = torch.zeros(2 * C, dtype=torch.float64, device="cuda"); stat = torch.empty(2 * C, device="cuda")
+    ws = torch.zeros(2 * C, dtype=torch.float64, device="cuda"); stat = torch.empty(3 * C, device="cuda")
     lib.s2f_bn_stats(z.data_ptr(), None, ws.data_ptr(), N, C, L, s)
     t3 = timeit(lambda: lib.s2f_bn_act_fwd(z.data_ptr(), None, ws.data_ptr(), stat.data_ptr(), None, None, None, gamma.data_ptr(), beta.data_ptr(),
                                            None, None, None, y.data_ptr(), None, mask.data_ptr(), None, N, C, L, 0.1, 1e-5, 1, 1.0, 8, s))
