@@ -671,12 +671,22 @@ static int split_gemm_launch(const char* who, const uint16_t* a_split, int64_t a
                   (x_outer_stride & 3) == 0 && (a_batch_stride & 7) == 0 && (a_term_stride & 7) == 0,
               S2F_EALIGN, "%s: pointers / strides must keep 16-byte alignment", who);
   hipStream_t s = (hipStream_t)stream;
-  const int n_tiles = (N + BN - 1) / BN, m_tiles = Mpad / 128;
+  // 64-row tiles when M <= 64 (the input gradient of a 3x3 convolution has C rows: 32 / 64 on the large maps -- with
+  // 128-row tiles 3/4 or 1/2 of the six MFMA passes would multiply padding)
+  const bool narrow = M <= 64;
+  const int n_tiles = (N + BN - 1) / BN, m_tiles = narrow ? 1 : Mpad / 128;
   const dim3 grid(n_tiles * m_tiles, batch);
 #define S2F_SG(AT, BT, CV)                                                                                              \
-  S2F_LAUNCH(true, true, (split_gemm_kernel<2, AT, BT, CV>), grid, dim3(256), 0, s, a_split, a_batch_stride, a_term_stride, \
-             X, x_batch_stride, k_inner, x_outer_stride, Y, y_batch_stride, out_scale, M, N, K, Mpad, Kpad, n_tiles,      \
-             m_tiles, geo)
+  do {                                                                                                                  \
+    if (narrow)                                                                                                         \
+      S2F_LAUNCH(true, true, (split_gemm_kernel<1, AT, BT, CV>), grid, dim3(128), 0, s, a_split, a_batch_stride,           \
+                 a_term_stride, X, x_batch_stride, k_inner, x_outer_stride, Y, y_batch_stride, out_scale, M, N, K, Mpad,   \
+                 Kpad, n_tiles, m_tiles, geo);                                                                            \
+    else                                                                                                                \
+      S2F_LAUNCH(true, true, (split_gemm_kernel<2, AT, BT, CV>), grid, dim3(256), 0, s, a_split, a_batch_stride,           \
+                 a_term_stride, X, x_batch_stride, k_inner, x_outer_stride, Y, y_batch_stride, out_scale, M, N, K, Mpad,   \
+                 Kpad, n_tiles, m_tiles, geo);                                                                            \
+  } while (0)
   if (conv) {
     S2F_REQUIRE(a_terms == 3 && x_terms == 3, S2F_EINVAL, "%s: the convolution form takes two general operands", who);
     S2F_SG(3, 3, true);
