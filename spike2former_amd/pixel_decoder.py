@@ -83,7 +83,9 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
             up = ops.upsample_bilinear(y, feats[i].shape[-2:])
             # cur + upsample(y), then the output neuron: residual add and neuron fused into the BatchNorm kernel
             _, s = conv_bn(self.lateral_convs[i], x, residual=up, lif=self.output_convs_spike[i])
-            y = conv_bn(self.output_convs[i], s)[0]
+            # the last level feeds only mask_feature_spike: that neuron is applied by the same BatchNorm kernel (prefire)
+            # instead of a separate pass over the [T*B, C, H/2, W/2] map (537 MB at C2)
+            y = conv_bn(self.output_convs[i], s, next_lif=self.mask_feature_spike if i == 0 else None)[0]
             out.append(y.reshape(t, bs, *y.shape[1:]))
         y = self.mask_feature_spike(y)
         mf = self.mask_feature(y)
