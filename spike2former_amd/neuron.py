@@ -66,7 +66,18 @@ class Q_IFNode(nn.Module):
         v_in = None if isinstance(self.v, float) else self.v
         if self.stats is not None:
             self.stats_elems += x.numel()
+        # A neuron that starts from a reset membrane, keeps none and records nothing is a pure function of its input: two
+        # such neurons applied to the SAME tensor (the decoder's key / value neurons of the two layers that share a feature
+        # level) share one kernel launch forward and one backward.  Cleared by reset_net().
+        pure = PURE_MEMO and v_in is None and not self.keep_membrane and self.stats is None and x.is_cuda
+        if pure:
+            key = (x.data_ptr(), x._version, x.numel(), x.requires_grad, self.D, self.v_threshold)
+            hit = _PURE_MEMO.get(key)
+            if hit is not None:
+                return hit[1].view(x.shape)
         y, v_out = ops.lif(x, v_in, self.D, self.v_threshold, self.keep_membrane, self.stats)
+        if pure:
+            _PURE_MEMO[key] = (x, y)                      # holding x keeps its address from being reused
         if self.keep_membrane:
             self.v = v_out
         else:
@@ -74,8 +85,13 @@ class Q_IFNode(nn.Module):
         return y
 
 
+_PURE_MEMO = {}
+PURE_MEMO = True          # share the launch of pure neurons applied to the same tensor (57.3 vs 57.7 ms/step at C2)
+
+
 def reset_net(net: nn.Module):
     """functional.reset_net (functional.py:9-33): call `reset()` on every module that has one."""
+    _PURE_MEMO.clear()
     for m in net.modules():
         if hasattr(m, "reset"):
             m.reset()
