@@ -49,6 +49,10 @@ class Q_IFNode(nn.Module):
         """The producer of `u` (fused.bn_act with next_lif=self) has already applied this neuron to it -- same update, same
         membrane / mask / firing counters as a call would have done; the next forward(u) just hands `y` out."""
         self._prefired = (u, u._version, y)          # holding u keeps its address from being reused while pending
+        if PURE_MEMO and isinstance(self.v, float) and not self.keep_membrane and self.stats is None and u.is_cuda:
+            # ... and any other pure neuron applied to the same tensor (the pixel decoder's lateral neurons read the
+            # backbone taps that the next backbone stage's first neuron was just applied to) gets it from the memo
+            _PURE_MEMO[(u.data_ptr(), u._version, u.numel(), u.requires_grad, self.D, self.v_threshold)] = (u, y)
 
     def extra_repr(self):
         return f"v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}, D={self.D}"
