@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--dump-events", default=None, help="write (kernel, algorithmic bytes, us) of every timed launch here")
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="launch the sunk weight-gradient kernels on a side stream (measured: 69.4 vs 67.2 ms/step -- slower)")
+    ap.add_argument("--branch-streams", type=int, default=0,
+                    help="run independent branches (q / k / v projection chains) on this many side streams")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     return ap.parse_args()
 
@@ -88,6 +90,8 @@ def main():
     red.install_sinks()                             # weight-gradient kernels add straight into the flat buffer
     if args.wgrad_stream:
         ops.WGRAD_STREAM = torch.cuda.Stream(device=dev)   # ... from a side stream, off the data-gradient chain
+    if args.branch_streams > 0:
+        ops.BRANCH_STREAMS = [torch.cuda.Stream(device=dev) for _ in range(args.branch_streams)]
     img = torch.randn(B, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
 
     def eager_step():
@@ -106,7 +110,14 @@ def main():
     if not args.no_graph:
         # reset + grad clear + forward + loss + backward captured once as a hipGraph; the RCCL all-reduce stays eager
         from spike2former_amd.graph import GraphedStep
-        graphed = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=max(args.warmup, 2))
+        try:
+            graphed = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=max(args.warmup, 2))
+        except RuntimeError as e:                   # N > 1 only: keep the measurement alive on eager launches, and say so
+            if world == 1:
+                raise
+            print(f"[bench rank {rank}] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr, flush=True)
+            graphed = None
+            torch.cuda.synchronize()
 
     def step():
         if graphed is None:

@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 9
+#define S2F_ABI_VERSION 10
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -72,6 +72,16 @@ int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint6
 /* STE backward of one step:  gx = gv_out + (gy / D - gv_out * vth) * m   (gv_out? NULL == 0; dL/dv_in == gx). */
 int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth, int D,
                 void* stream);
+
+/* The decoder's value / key neurons on  a = x + e[c]  and  a + pos[b, c, l]  in one pass (x [TB, C, L] with tb = t*B + b,
+ * e [C] = level_embed row, pos [B, C, L] = key positional encoding; mmdet/models/dense_heads/maskformer_head.py:535-540,
+ * mmcv_spike/transformer.py:626-629): y_value = Q_IFNode(a), y_key = Q_IFNode(a + pos), reset stateless neurons, 1-bit
+ * in-range masks as s2f_lif_fwd.  Backward: gx = STE(g_key, mask_key) + STE(g_value, mask_value); the gradient of e is the
+ * per-channel sum of gx (left to the caller).  L % 4 == 0. */
+int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, float* y_key, float* y_value, uint64_t* mask_key,
+                     uint64_t* mask_value, int64_t TB, int64_t B, int64_t C, int64_t L, float vth, int D, void* stream);
+int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const uint64_t* mask_key, const uint64_t* mask_value,
+                     float* gx, int64_t n, int D, void* stream);
 
 /* ---- T successive stateful calls on one neuron, membrane carried in registers -----------------------
  * Same arithmetic as T calls of s2f_lif_fwd with v chained (what tools/cal_firing_num.py:203-225 does across

@@ -190,6 +190,68 @@ __global__ __launch_bounds__(kBlock) void lif_bwd_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------ two neurons on a biased tensor (decoder keys / values)
+// a = x + e[c] ;  y_v = Q_IFNode(a) ;  y_k = Q_IFNode(a + pos[b, c, l])      x: [TB, C, L], tb = t*B + b, pos: [B, C, L]
+// = the decoder's value / key neurons applied to  memory + level_embed  and  memory + level_embed + key_pos
+// (mmdet/models/dense_heads/maskformer_head.py:535-540; mmcv_spike/transformer.py:626-629, 213-236) without materialising
+// the two sums: they are read by nothing but these neurons.  Reset, stateless neurons only (no membrane in / out).
+__global__ __launch_bounds__(kBlock) void sum2_lif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                                                              const float* __restrict__ pos, float* __restrict__ yk,
+                                                              float* __restrict__ yv, uint64_t* __restrict__ mk,
+                                                              uint64_t* __restrict__ mv, int64_t n, int C, int L, int B,
+                                                              float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;                  // L % 4 == 0: the four elements share (tb, c)
+    bool ik[4] = {false, false, false, false}, iv[4] = {false, false, false, false};
+    if (base < n) {
+      const int64_t row = base / L;
+      const int l = (int)(base - row * L), c = (int)(row % C), b = (int)((row / C) % B);
+      const Tile4 xv = load4(x, base, n, 0.f), pv = load4(pos, ((int64_t)b * C + c) * L + l, (int64_t)B * C * L, 0.f);
+      const float ec = e[c];
+      Tile4 ok, ov;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = xv.a[j] + ec;
+        float sp, yy, vn;
+        s2f_lif_update(a, Df, 1.0f, vth, sp, yy, vn, iv[j]);
+        ov.a[j] = sp / Df;
+        s2f_lif_update(a + pv.a[j], Df, 1.0f, vth, sp, yy, vn, ik[j]);
+        ok.a[j] = sp / Df;
+      }
+      store4(yv, base, n, ov);
+      store4(yk, base, n, ok);
+    }
+    write_mask(mk, tile, lane, ik);
+    write_mask(mv, tile, lane, iv);
+  }
+}
+
+// gx = STE_k(g_k) + STE_v(g_v)   (the gradient with respect to x; the one with respect to e is its per-channel sum)
+__global__ __launch_bounds__(kBlock) void sum2_lif_bwd_kernel(const float* __restrict__ gk, const float* __restrict__ gv,
+                                                              const uint64_t* __restrict__ mk,
+                                                              const uint64_t* __restrict__ mv, float* __restrict__ gx,
+                                                              int64_t n, float Df) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    const Tile4 a = load4(gk, base, n, 0.f), b = load4(gv, base, n, 0.f);
+    Tile4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool bk = (mk[tile * 4 + j] >> lane) & 1ull, bv = (mv[tile * 4 + j] >> lane) & 1ull;
+      o.a[j] = (bv ? b.a[j] / Df : 0.f) + (bk ? a.a[j] / Df : 0.f);
+    }
+    store4(gx, base, n, o);
+  }
+}
+
 // ------------------------------------------------------------------ T chained steps, membrane in registers
 template <bool HAS_V0>
 __global__ __launch_bounds__(kBlock) void lif_seq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v0,
@@ -322,6 +384,31 @@ extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t*
     S2F_LAUNCH(true, true, lif_bwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
                        (float)D);
   return s2f_check_launch("s2f_lif_bwd");
+}
+
+extern "C" int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, float* y_key, float* y_value,
+                                uint64_t* mask_key, uint64_t* mask_value, int64_t TB, int64_t B, int64_t C, int64_t L,
+                                float vth, int D, void* stream) {
+  S2F_REQUIRE(x && e && pos && y_key && y_value && mask_key && mask_value, S2F_EINVAL, "s2f_sum2_lif_fwd: null pointer");
+  S2F_REQUIRE(TB > 0 && B > 0 && TB % B == 0 && C > 0 && L > 0 && (L & 3) == 0 && D >= 1 && D <= 255, S2F_EINVAL,
+              "s2f_sum2_lif_fwd: bad shape (L must be a multiple of 4, TB a multiple of B)");
+  S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(pos) && s2f_aligned16(y_key) && s2f_aligned16(y_value), S2F_EALIGN,
+              "s2f_sum2_lif_fwd: tensors must be 16-byte aligned");
+  const int64_t n = TB * C * L;
+  S2F_LAUNCH(true, true, sum2_lif_fwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, e, pos, y_key,
+             y_value, mask_key, mask_value, n, (int)C, (int)L, (int)B, vth, (float)D);
+  return s2f_check_launch("s2f_sum2_lif_fwd");
+}
+
+extern "C" int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const uint64_t* mask_key,
+                                const uint64_t* mask_value, float* gx, int64_t n, int D, void* stream) {
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(g_key && g_value && mask_key && mask_value && gx, S2F_EINVAL, "s2f_sum2_lif_bwd: null pointer");
+  S2F_REQUIRE(s2f_aligned16(g_key) && s2f_aligned16(g_value) && s2f_aligned16(gx), S2F_EALIGN,
+              "s2f_sum2_lif_bwd: tensors must be 16-byte aligned");
+  S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
+             mask_key, mask_value, gx, n, (float)D);
+  return s2f_check_launch("s2f_sum2_lif_bwd");
 }
 
 extern "C" int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq, float* vT, uint64_t* mask,

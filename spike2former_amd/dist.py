@@ -117,6 +117,10 @@ class FlatGradAllReduce:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+                if self.work is not None:
+                    # RCCL runs the collective on its own stream: order the side stream behind it before the division
+                    # (a stream-level wait, the host does not block); gloo: blocks until the result is there
+                    self.work.wait()
                 self.flat.div_(self.world)
         else:
             self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)

@@ -26,7 +26,11 @@ class GraphedStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, RCCL's watchdog thread polls its events while this thread captures: "thread_local"
+        # keeps its (legal, uncaptured) calls from invalidating the capture; single-process runs keep the strict default.
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_loss = self._eager_step()
         torch.cuda.synchronize()
 

@@ -255,22 +255,26 @@ class MultiHeadAttentionBlock(nn.Module):
         self.out_conv = proj()
         spikes_in(self.q_conv[0], self.k_conv[0], self.v_conv[0], self.out_conv[0])
 
-    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False):
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None):
         """query [t,b,nq,dim]; key/value [t,b,nk,dim] as in the reference, or -- `kv_channel_major` -- [t,b,dim,nk], the
         layout the pixel decoder produces them in (saves two 33 M-element transposes per projection at the 128x128 level;
-        the neuron is elementwise, so the values are the same)."""
+        the neuron is elementwise, so the values are the same).  `kv_spikes` = (k_conv_spike(key), v_conv_spike(value))
+        already formed by the caller (channel-major; the head's fused add + neuron kernel) -- key / value are then unused."""
         if attn_mask is not None:
             raise NotImplementedError("attn_mask is always None on the MaskFormerHead path (maskformer_head.py:554-564)")
         t, b, nq, dim = query.shape
 
-        def proj(spike_in, conv, spike_out, x, channel_major=False):   # -> channel-major spikes [t*b, dim, L]
-            x = spike_in(x)
+        def proj(spike_in, conv, spike_out, x, channel_major=False, fired=None):   # -> channel-major spikes [t*b, dim, L]
+            x = spike_in(x) if fired is None else fired
             x = x.flatten(0, 1) if channel_major else x.permute(0, 1, 3, 2).flatten(0, 1)
             return bn_act(conv[0].forward_nobias(x), conv[0].bias, conv[1], lif=spike_out)[1]
 
-        q = proj(self.q_conv_spike, self.q_conv, self.q_spike, query)
-        k = proj(self.k_conv_spike, self.k_conv, self.k_spike, key, kv_channel_major)
-        v = proj(self.v_conv_spike, self.v_conv, self.v_spike, value, kv_channel_major)
+        if kv_spikes is not None:
+            kv_channel_major = True
+        k, v, q = ops.branches([       # independent chains (the long ones first: keys / values are the 1 024 - 16 384-token maps)
+            lambda: proj(self.k_conv_spike, self.k_conv, self.k_spike, key, kv_channel_major, None if kv_spikes is None else kv_spikes[0]),
+            lambda: proj(self.v_conv_spike, self.v_conv, self.v_spike, value, kv_channel_major, None if kv_spikes is None else kv_spikes[1]),
+            lambda: proj(self.q_conv_spike, self.q_conv, self.q_spike, query)])
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5))      # embed_dim**0.5, not head dim
         o = self.attn_spike(o)
         o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
@@ -294,7 +298,10 @@ class MultiheadAttention(nn.Module):
         self.attn = MultiHeadAttentionBlock(embed_dims, num_heads, attn_drop, **kwargs)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
-                key_padding_mask=None, kv_channel_major=False, **kwargs):
+                key_padding_mask=None, kv_channel_major=False, kv_spikes=None, **kwargs):
+        if kv_spikes is not None:
+            return self.attn(query=query if query_pos is None else query + query_pos, key=None, value=None,
+                             attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes)[0]
         if key is None:
             key = query
         if value is None:
@@ -355,10 +362,10 @@ class DetrTransformerDecoderLayer(nn.Module):
         self.ffn = MSDA_FFN(**self.ffn_cfg)
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, self_attn_mask=None,
-                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=False, **kwargs):
+                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None, **kwargs):
         query = query + self.cross_attn(query=query, key=key, value=value, query_pos=query_pos, key_pos=key_pos,
                                         attn_mask=cross_attn_mask, key_padding_mask=key_padding_mask,
-                                        kv_channel_major=kv_channel_major)
+                                        kv_channel_major=kv_channel_major, kv_spikes=kv_spikes)
         query = query + self.self_attn(query=query, key=query, value=query, query_pos=query_pos, key_pos=query_pos,
                                        attn_mask=self_attn_mask)
         return query + self.ffn(query)

@@ -17,6 +17,10 @@ from .neuron import Q_IFNode, Quant
 from .registry import MODELS, ConfigDict
 
 
+# key / value neurons of the decoder straight from  memory (+ level_embed) (+ pos)  by one fused add + neuron kernel
+FUSED_KV_NEURONS = True
+
+
 def _lif():
     return Q_IFNode(surrogate_function=Quant())
 
@@ -92,18 +96,38 @@ class MaskFormerHead(nn.Module):
         # Keys / values stay in the channel-major layout the pixel decoder produced ([t, b, C, h*w]); the reference
         # transposes them to token-major and back around every projection (maskformer_head.py:535-540).  key + key_pos
         # depends only on the level, so it is formed once per level instead of once per decoder layer.
-        dec_in, dec_key = [], []
-        for i in range(self.num_transformer_feat_level):
-            d = self.decoder_input_projs[i](msm[i])
-            d = d.flatten(3) + self.level_embed.weight[i].view(1, 1, -1, 1)
+        nl = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
+
+        def pure(m):          # reset, stateless, unrecorded: the neuron is a pure function of its input
+            return isinstance(m.v, float) and not m.keep_membrane and m.stats is None
+
+        dec_in, dec_key, kv_spikes = [], [], []
+        for i in range(nl):
+            d = self.decoder_input_projs[i](msm[i]).flatten(3)
+            pos = self._pos(bs, msm[i].shape[-2], msm[i].shape[-1], d.device)
+            users = [layers[j].cross_attn.attn for j in range(i, self.num_transformer_decoder_layers, nl)]
+            if (FUSED_KV_NEURONS and d.is_cuda and d.shape[-1] % 4 == 0 and users
+                    and all(pure(a.k_conv_spike) and pure(a.v_conv_spike) for a in users)
+                    and len({(a.k_conv_spike.D, a.k_conv_spike.v_threshold, a.v_conv_spike.D, a.v_conv_spike.v_threshold)
+                             for a in users}) == 1 and users[0].k_conv_spike.D == users[0].v_conv_spike.D):
+                # the key / value neurons of every layer on this level, straight from the pixel decoder's map: neither
+                # d + level_embed nor d + level_embed + pos is materialised (only these neurons read them)
+                n0 = users[0].k_conv_spike
+                yk, yv = ops.sum2_lif(d.flatten(0, 1), self.level_embed.weight[i], pos, bs, n0.D, n0.v_threshold)
+                kv_spikes.append((yk.view(d.shape), yv.view(d.shape)))
+                dec_in.append(None); dec_key.append(None)
+                continue
+            d = d + self.level_embed.weight[i].view(1, 1, -1, 1)
             dec_in.append(d)
-            dec_key.append(d + self._pos(bs, msm[i].shape[-2], msm[i].shape[-1], d.device))
+            dec_key.append(d + pos)
+            kv_spikes.append(None)
         out_dec = [query_feat]
         for i in range(self.num_transformer_decoder_layers):
-            lv = i % self.num_transformer_feat_level
-            query_feat = self.transformer_decoder.layers[i](
+            lv = i % nl
+            query_feat = layers[i](
                 query=query_feat, key=dec_key[lv], value=dec_in[lv], query_pos=query_embed, key_pos=None,
-                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True)
+                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv])
             out_dec.append(query_feat)
         out_dec = torch.stack(out_dec)
         ln, t, bs, nq, C = out_dec.shape

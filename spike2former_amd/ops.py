@@ -111,6 +111,35 @@ def wgrad_join():
         _WGRAD_KEEP.clear()
 
 
+# Independent branches of the 32x32-stage blocks (the q / k / v projection chains of an attention block) each launch
+# kernels of 128-256 workgroups -- one wave per SIMD, nothing to hide latency with.  With side streams set, `branches()`
+# runs them concurrently: fork after the common input, join before the first common consumer; autograd replays each
+# branch's backward on the stream its forward ran on.  None = everything on the current stream.
+BRANCH_STREAMS = None
+
+
+def branches(fns):
+    """Run the independent callables `fns` (first one on the current stream, the others on ops.BRANCH_STREAMS) -> results."""
+    side = BRANCH_STREAMS
+    if not side or len(fns) < 2 or KERNEL_EVENTS is not None:
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    used = []
+    for i in range(1, len(fns)):
+        st = side[(i - 1) % len(side)]
+        if st not in used:
+            st.wait_stream(main)               # fork: everything enqueued so far (the common input) precedes the branch
+            used.append(st)
+    out = [None] * len(fns)
+    for i in range(1, len(fns)):
+        with torch.cuda.stream(side[(i - 1) % len(side)]):
+            out[i] = fns[i]()
+    out[0] = fns[0]()
+    for st in used:
+        main.wait_stream(st)                   # join
+    return out
+
+
 def _sink_for(w):
     if GRAD_SINKS is None:
         return None
@@ -180,6 +209,43 @@ def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None):
     """-> (y, v_out or None)"""
     y, v = _LIF.apply(x, v_in, D, vth, keep_v, stats)
     return y, (v if keep_v else None)
+
+
+class _Sum2LIF(torch.autograd.Function):
+    """The decoder's value / key neurons on  a = x + e[c]  and  a + pos[b]  in one pass, neither sum materialised
+    (maskformer_head.py:535-540 + transformer.py:626-629; s2f.h s2f_sum2_lif_fwd).  Reset, stateless neurons only."""
+
+    @staticmethod
+    def forward(ctx, x, e, pos, B, D, vth):
+        _need_cuda(x, e, pos)
+        x, e, pos = x.contiguous(), e.contiguous(), pos.contiguous()
+        TB, C, L = x.shape
+        n = x.numel()
+        yk, yv = torch.empty_like(x), torch.empty_like(x)
+        mk = torch.empty(mask_words(n), dtype=torch.int64, device=x.device)
+        mv = torch.empty_like(mk)
+        _time_next("lif_fwd", 12 * n)                   # read x, write two spike maps (pos is 1/T of a map)
+        check(lib.s2f_sum2_lif_fwd(_ptr(x), _ptr(e), _ptr(pos), _ptr(yk), _ptr(yv), _ptr(mk), _ptr(mv), TB, B, C, L, vth, D,
+                                   _stream()), "s2f_sum2_lif_fwd")
+        ctx.save_for_backward(mk, mv)
+        ctx.D = D
+        return yk, yv
+
+    @staticmethod
+    def backward(ctx, gk, gv):
+        mk, mv = ctx.saved_tensors
+        gk, gv = gk.contiguous(), gv.contiguous()
+        gx = torch.empty_like(gk)
+        _time_next("lif_bwd", 12 * gk.numel())
+        check(lib.s2f_sum2_lif_bwd(_ptr(gk), _ptr(gv), _ptr(mk), _ptr(mv), _ptr(gx), gk.numel(), ctx.D, _stream()),
+              "s2f_sum2_lif_bwd")
+        ge = gx.sum((0, 2)) if ctx.needs_input_grad[1] else None
+        return gx, ge, None, None, None, None
+
+
+def sum2_lif(x, e, pos, B, D=8, vth=1.0):
+    """x [T*B, C, L], e [C], pos [B, C, L] -> (Q_IFNode(x + e + pos), Q_IFNode(x + e))  (key spikes, value spikes)."""
+    return _Sum2LIF.apply(x, e, pos, B, D, vth)
 
 
 class _LIFSeq(torch.autograd.Function):

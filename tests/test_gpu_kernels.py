@@ -132,6 +132,30 @@ def test_lif_full_size_properties(ops):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("T_,B,C,L", [(4, 2, 256, 1024), (1, 1, 5, 4), (2, 3, 7, 36), (3, 1, 16, 260)])
+def test_sum2_lif_is_the_two_neurons_on_the_two_sums(ops, T_, B, C, L):
+    """Decoder key / value neurons from memory + level_embed (+ pos) in one launch (maskformer_head.py:535-540,
+    transformer.py:626-629): bit-identical, forward and backward, to the stand-alone neuron on the materialised sums."""
+    g = torch.Generator().manual_seed(T_ * 100 + L)
+    x = (torch.randn(T_ * B, C, L, generator=g) * 2 + 1).cuda().requires_grad_(True)
+    e = torch.randn(C, generator=g).cuda().requires_grad_(True)
+    pos = torch.randn(B, C, L, generator=g).cuda()
+    wk, wv = torch.randn(T_ * B, C, L, generator=g).cuda(), torch.randn(T_ * B, C, L, generator=g).cuda()
+    yk, yv = ops.sum2_lif(x, e, pos, B)
+    ((yk * wk).sum() + (yv * wv).sum()).backward()
+    gx, ge = x.grad.clone(), e.grad.clone()
+    x.grad = e.grad = None
+    a = x.view(T_, B, C, L) + e.view(1, 1, C, 1)
+    rv, _ = ops.lif(a, None, keep_v=False)
+    rk, _ = ops.lif(a + pos, None, keep_v=False)
+    ((rk.view_as(wk) * wk).sum() + (rv.view_as(wv) * wv).sum()).backward()
+    assert torch.equal(yk, rk.view_as(yk)) and torch.equal(yv, rv.view_as(yv))
+    assert torch.equal(gx, x.grad)
+    assert torch.allclose(ge, e.grad, rtol=1e-5, atol=1e-5)        # a [C] reduction: summation order differs
+    with pytest.raises(RuntimeError):
+        ops.sum2_lif(x[:, :, :L - 1].contiguous(), e, pos[:, :, :L - 1].contiguous(), B)     # L % 4 != 0
+
+
 # ----------------------------------------------------------------------------------------------- attention core
 @pytest.mark.parametrize("TB,heads,d,Nq,Nk", [(4, 8, 32, 1024, 1024), (2, 8, 45, 256, 256), (3, 8, 8, 10, 30),
                                                (2, 8, 32, 100, 4096), (1, 1, 64, 7, 513)])

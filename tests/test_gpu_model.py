@@ -24,6 +24,13 @@ def env():
     return s2f, so, cfg, model.cuda()
 
 
+def grad_gap(a, b):
+    """max over parameters of max|a - b| / (max|b| + 1e-3 * the largest gradient entry of the model): gradients that are
+    pure cancellation noise (a bias in front of a BatchNorm) are measured against the model's gradient scale."""
+    gscale = max(v.abs().max().item() for v in b.values())
+    return max((a[k] - b[k]).abs().max().item() / (b[k].abs().max().item() + 1e-3 * gscale) for k in b)
+
+
 def rel(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
@@ -141,6 +148,58 @@ def test_train_step_vs_oracle_on_fresh_input(env):
         mine = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
         worst = max(worst, (mine - ref).abs().max().item() / (ref.abs().max().item() + 1e-3 * gscale))
     assert worst <= 5e-2, worst
+
+
+def test_fused_key_value_neurons_do_not_change_the_step(env):
+    """The head's fused add + key/value-neuron kernel (maskformer_head.FUSED_KV_NEURONS) against the materialised sums and
+    stand-alone neurons: same logits bit for bit, same gradients (level_embed's is a reduction: fp32 round-off)."""
+    s2f, so, cfg, model = env
+    from spike2former_amd import maskformer_head as mh
+    img = so.synthetic_image(cfg, seed=5).cuda()
+    model.train()
+    s2f.set_keep_membrane(model, False)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    try:
+        for fused in (True, False):
+            mh.FUSED_KV_NEURONS = fused
+            model.load_state_dict(state)      # BN running statistics move with every training forward (BNAndPad reads them)
+            s2f.reset_net(model); model.zero_grad(set_to_none=True)
+            cls, masks = model(img)
+            s2f.headline_loss(cls, masks).backward()
+            runs.append((cls.detach(), masks.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        mh.FUSED_KV_NEURONS = True
+        s2f.set_keep_membrane(model, True)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2].keys() == runs[1][2].keys()
+    assert grad_gap(runs[0][2], runs[1][2]) <= 1e-3      # run-to-run noise of the split-K atomics is ~1e-5 on this metric
+
+
+def test_branch_streams_do_not_change_the_step(env):
+    """ops.BRANCH_STREAMS (independent q / k / v projection chains launched on side streams) is a scheduling choice only:
+    logits bit for bit; gradients to fp32 round-off (the split-K weight gradients use atomics, order-dependent)."""
+    s2f, so, cfg, model = env
+    from spike2former_amd import ops
+    img = so.synthetic_image(cfg, seed=6).cuda()
+    model.train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    try:
+        for side in (None, [torch.cuda.Stream(), torch.cuda.Stream()]):
+            ops.BRANCH_STREAMS = side
+            for _ in range(2):
+                model.load_state_dict(state)  # BN running statistics move with every training forward (BNAndPad reads them)
+                s2f.reset_net(model); model.zero_grad(set_to_none=True)
+                cls, masks = model(img)
+                s2f.headline_loss(cls, masks).backward()
+                torch.cuda.synchronize()
+            runs.append((cls.detach(), masks.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        ops.BRANCH_STREAMS = None
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2].keys() == runs[1][2].keys()
+    assert grad_gap(runs[0][2], runs[1][2]) <= 1e-3      # run-to-run noise of the split-K atomics is ~1e-5 on this metric
 
 
 def test_predict_and_keep_membrane_equivalence(env):
