@@ -35,7 +35,12 @@ def parse():
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="launch the sunk weight-gradient kernels on a side stream (measured: 69.4 vs 67.2 ms/step -- slower)")
     ap.add_argument("--branch-streams", type=int, default=0,
-                    help="run independent branches (q / k / v projection chains) on this many side streams")
+                    help="run sibling chains (q / k / v projections, DCN input vs offset/mask) on this many side streams; "
+                         "measured 54.4 - 56.6 vs 56.7 - 57.0 ms/step: the gain depends on how the HIP runtime maps the graph's "
+                         "branches onto its queues, which varies from process to process -- off by default")
+    ap.add_argument("--long-streams", type=int, default=0,
+                    help="1: lateral convs / H/2 FPN level + mask_feature / decoder key-value projections on side streams "
+                         "(S2F_LONG_WHAT=lat,mf,kv selects; measured: mf -0.8 ms, kv +0.7 ms, lat 0 -- off by default)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     return ap.parse_args()
 
@@ -79,7 +84,6 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True          # let MIOpen pick its fastest solver for the library convolutions
 
     w = s2f.WORKLOADS[args.workload]
     B = w["B"]                                      # per-GPU batch: weak scaling (BASELINE.json configs[1]: batch=2 on 1 GPU)
@@ -92,6 +96,10 @@ def main():
         ops.WGRAD_STREAM = torch.cuda.Stream(device=dev)   # ... from a side stream, off the data-gradient chain
     if args.branch_streams > 0:
         ops.BRANCH_STREAMS = [torch.cuda.Stream(device=dev) for _ in range(args.branch_streams)]
+    if args.long_streams:
+        ops.LONG_STREAMS = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        if os.environ.get("S2F_LONG_WHAT"):
+            ops.LONG_WHAT = tuple(os.environ["S2F_LONG_WHAT"].split(","))
     img = torch.randn(B, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
 
     def eager_step():

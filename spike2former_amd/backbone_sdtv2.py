@@ -202,7 +202,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         q, k, v = ops.branches([
             lambda: self.q_conv[0](s, outer_bn=self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N),
             lambda: self.k_conv[0](s, outer_bn=self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N),
-            lambda: self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)])
+            lambda: self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)], inputs=(s,))
         o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
         o = self.attn_spike(o).view(T * B, C, H, W)
         res = None if residual is None else residual.flatten(0, 1)

@@ -121,14 +121,24 @@ class DCNv3_pytorch(nn.Module):
         the Cg channels of a group as one vector): one transposition in, one out, instead of the reference's permute pair
         around every sub-module."""
         T, N, C, H, W = inp.shape
-        x = self.input_proj.forward_nchw(inp)
-        x = x.permute(0, 1, 3, 4, 2).contiguous().flatten(0, 1)              # [T*N, H, W, C]
-        x1 = self.dw_spike(inp).flatten(0, 1)
-        _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
-        # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
-        offset, _ = bn_act(self.offset[0].forward_nobias(x1), self.offset[0].bias, self.offset[1])
-        _, mask = bn_act(self.mask[0].forward_nobias(x1), self.mask[0].bias, self.mask[1], lif=self.mask_spike)
-        offset, mask = offset.reshape(T * N, H, W, -1), mask.reshape(T * N, H, W, -1)
+
+        def sampled_input():
+            x = self.input_proj.forward_nchw(inp)
+            return x.permute(0, 1, 3, 4, 2).contiguous().flatten(0, 1)              # [T*N, H, W, C]
+
+        def offset_and_mask():
+            x1 = self.dw_spike(inp).flatten(0, 1)
+            ops.use_here(x1)
+            _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
+            # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
+            offset, _ = bn_act(self.offset[0].forward_nobias(x1), self.offset[0].bias, self.offset[1])
+            _, mask = bn_act(self.mask[0].forward_nobias(x1), self.mask[0].bias, self.mask[1], lif=self.mask_spike)
+            return offset.reshape(T * N, H, W, -1), mask.reshape(T * N, H, W, -1)
+
+        # the two chains share only `inp`: launched side by side when ops.BRANCH_STREAMS is set.  (Forking offset / mask once
+        # more costs more than it hides: two 2-kernel chains, 56.9 vs 54.4 ms/step -- a fork / join pair in the replayed
+        # hipGraph is worth several short kernels.)
+        x, (offset, mask) = ops.branches([sampled_input, offset_and_mask], inputs=(inp,))
         k = self.kernel_size
         y = ops.dcnv3_core(x, offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
                            self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale)
@@ -255,7 +265,22 @@ class MultiHeadAttentionBlock(nn.Module):
         self.out_conv = proj()
         spikes_in(self.q_conv[0], self.k_conv[0], self.v_conv[0], self.out_conv[0])
 
-    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None):
+    @staticmethod
+    def _proj(spike_in, conv, spike_out, x, channel_major=False, fired=None):
+        """neuron -> Conv1d -> BN1d -> neuron on [t,b,L,dim] (or channel-major [t,b,dim,L]) -> channel-major spikes [t*b, dim, L]"""
+        x = spike_in(x) if fired is None else fired
+        x = x.flatten(0, 1) if channel_major else x.permute(0, 1, 3, 2).flatten(0, 1)
+        return bn_act(conv[0].forward_nobias(x), conv[0].bias, conv[1], lif=spike_out)[1]
+
+    def project_kv(self, key, value, kv_channel_major=False, kv_spikes=None):
+        """The key and value chains alone (they do not depend on the query) -> (k, v) channel-major spikes."""
+        cm = kv_channel_major or kv_spikes is not None
+        k = self._proj(self.k_conv_spike, self.k_conv, self.k_spike, key, cm, None if kv_spikes is None else kv_spikes[0])
+        v = self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, None if kv_spikes is None else kv_spikes[1])
+        return k, v
+
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None,
+                kv_projected=None):
         """query [t,b,nq,dim]; key/value [t,b,nk,dim] as in the reference, or -- `kv_channel_major` -- [t,b,dim,nk], the
         layout the pixel decoder produces them in (saves two 33 M-element transposes per projection at the 128x128 level;
         the neuron is elementwise, so the values are the same).  `kv_spikes` = (k_conv_spike(key), v_conv_spike(value))
@@ -264,17 +289,19 @@ class MultiHeadAttentionBlock(nn.Module):
             raise NotImplementedError("attn_mask is always None on the MaskFormerHead path (maskformer_head.py:554-564)")
         t, b, nq, dim = query.shape
 
-        def proj(spike_in, conv, spike_out, x, channel_major=False, fired=None):   # -> channel-major spikes [t*b, dim, L]
-            x = spike_in(x) if fired is None else fired
-            x = x.flatten(0, 1) if channel_major else x.permute(0, 1, 3, 2).flatten(0, 1)
-            return bn_act(conv[0].forward_nobias(x), conv[0].bias, conv[1], lif=spike_out)[1]
-
-        if kv_spikes is not None:
-            kv_channel_major = True
-        k, v, q = ops.branches([       # independent chains (the long ones first: keys / values are the 1 024 - 16 384-token maps)
-            lambda: proj(self.k_conv_spike, self.k_conv, self.k_spike, key, kv_channel_major, None if kv_spikes is None else kv_spikes[0]),
-            lambda: proj(self.v_conv_spike, self.v_conv, self.v_spike, value, kv_channel_major, None if kv_spikes is None else kv_spikes[1]),
-            lambda: proj(self.q_conv_spike, self.q_conv, self.q_spike, query)])
+        if kv_projected is not None:
+            # keys / values do not depend on the query: the head projected them for every layer ahead of the query chain
+            q = self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query)
+            k, v, handle = kv_projected
+            ops.join(handle, (k, v))
+        else:
+            cm = kv_channel_major or kv_spikes is not None
+            fk, fv = (None, None) if kv_spikes is None else kv_spikes
+            k, v, q = ops.branches([   # independent chains (the long ones first: keys / values are the 1 024 - 16 384-token maps)
+                lambda: self._proj(self.k_conv_spike, self.k_conv, self.k_spike, key, cm, fk),
+                lambda: self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, fv),
+                lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query)],
+                inputs=(query, key, value, fk, fv))
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5))      # embed_dim**0.5, not head dim
         o = self.attn_spike(o)
         o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
@@ -298,10 +325,11 @@ class MultiheadAttention(nn.Module):
         self.attn = MultiHeadAttentionBlock(embed_dims, num_heads, attn_drop, **kwargs)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
-                key_padding_mask=None, kv_channel_major=False, kv_spikes=None, **kwargs):
-        if kv_spikes is not None:
+                key_padding_mask=None, kv_channel_major=False, kv_spikes=None, kv_projected=None, **kwargs):
+        if kv_spikes is not None or kv_projected is not None:
             return self.attn(query=query if query_pos is None else query + query_pos, key=None, value=None,
-                             attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes)[0]
+                             attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes,
+                             kv_projected=kv_projected)[0]
         if key is None:
             key = query
         if value is None:
@@ -362,10 +390,11 @@ class DetrTransformerDecoderLayer(nn.Module):
         self.ffn = MSDA_FFN(**self.ffn_cfg)
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, self_attn_mask=None,
-                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None, **kwargs):
+                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None, kv_projected=None,
+                **kwargs):
         query = query + self.cross_attn(query=query, key=key, value=value, query_pos=query_pos, key_pos=key_pos,
                                         attn_mask=cross_attn_mask, key_padding_mask=key_padding_mask,
-                                        kv_channel_major=kv_channel_major, kv_spikes=kv_spikes)
+                                        kv_channel_major=kv_channel_major, kv_spikes=kv_spikes, kv_projected=kv_projected)
         query = query + self.self_attn(query=query, key=query, value=query, query_pos=query_pos, key_pos=query_pos,
                                        attn_mask=self_attn_mask)
         return query + self.ffn(query)

@@ -122,12 +122,24 @@ class MaskFormerHead(nn.Module):
             dec_in.append(d)
             dec_key.append(d + pos)
             kv_spikes.append(None)
+        # Keys / values do not depend on the query: with ops.LONG_STREAMS set, the key / value chains of ALL layers (the 1 024 -
+        # 16 384-token projections) are launched on a side stream ahead of the serial 100-query chain and overlap with it.
+        kv_proj = [None] * self.num_transformer_decoder_layers
+        if ops.LONG_STREAMS and "kv" in ops.LONG_WHAT:
+            for i in range(self.num_transformer_decoder_layers):
+                lv = i % nl
+                attn = layers[i].cross_attn.attn
+                (k, v), handle = ops.fork(
+                    1, lambda: attn.project_kv(dec_key[lv], dec_in[lv], True, kv_spikes[lv]),
+                    inputs=(dec_key[lv], dec_in[lv], kv_spikes[lv]), what="kv")
+                kv_proj[i] = (k, v, handle)
         out_dec = [query_feat]
         for i in range(self.num_transformer_decoder_layers):
             lv = i % nl
             query_feat = layers[i](
                 query=query_feat, key=dec_key[lv], value=dec_in[lv], query_pos=query_embed, key_pos=None,
-                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv])
+                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv],
+                kv_projected=kv_proj[i])
             out_dec.append(query_feat)
         out_dec = torch.stack(out_dec)
         ln, t, bs, nq, C = out_dec.shape
@@ -144,6 +156,7 @@ class MaskFormerHead(nn.Module):
         Hm, Wm = mask_features.shape[-2:]
         eq = e.permute(1, 2, 0, 3, 4).reshape(t, bs, ln * nq, C)        # [t, b, L*Q, C]: all L+1 predictions in one GEMM
         # e = alpha * spikes with alpha = 4: multiples of 1/2 <= 4, exact in bf16 -> the matrix-core path of ops.mask_einsum
+        ops.join(getattr(self.pixel_decoder, "mask_feature_handle", None), (mask_features,))   # its side-stream branch
         acc = ops.mask_einsum(eq, mask_features.flatten(3), 1.0 / t, e_exact=float(self.alpha) == 4.0)      # [b, L*Q, HW]
         all_mask_preds = acc.view(bs, ln, nq, Hm, Wm).permute(1, 0, 2, 3, 4)
         return all_cls_scores, all_mask_preds

@@ -111,33 +111,99 @@ def wgrad_join():
         _WGRAD_KEEP.clear()
 
 
-# Independent branches of the 32x32-stage blocks (the q / k / v projection chains of an attention block) each launch
-# kernels of 128-256 workgroups -- one wave per SIMD, nothing to hide latency with.  With side streams set, `branches()`
-# runs them concurrently: fork after the common input, join before the first common consumer; autograd replays each
-# branch's backward on the stream its forward ran on.  None = everything on the current stream.
+# ---- concurrency inside one step -------------------------------------------------------------------------------------
+# Most launches of a step are kernels of 128-256 workgroups (the 32x32-stage blocks, the decoder's 100-query chain): one
+# wave per SIMD, nothing to hide latency with, while other parts of the step (the 256x256-level FPN stage and mask_feature
+# convolution, the decoder's key / value projections over up to 16 384 tokens) are independent of them.  With side streams
+# set, independent work is launched concurrently; inside the captured hipGraph this becomes parallel branches.  Autograd
+# replays each branch's backward on the stream its forward ran on and orders the hand-overs itself.
+#   BRANCH_STREAMS : short fork / join around sibling chains (q / k / v projections; DCN input / offset / mask chains)
+#   LONG_STREAMS   : [0] lateral convolutions + the 256x256 FPN level + mask_feature,  [1] decoder key / value projections
+# A tensor allocated on one stream and consumed on another is registered with the allocator (`record_stream`), so its
+# block is not handed out again while the consumer may still be reading it.  None = everything on the current stream.
 BRANCH_STREAMS = None
+LONG_STREAMS = None
 
 
-def branches(fns):
-    """Run the independent callables `fns` (first one on the current stream, the others on ops.BRANCH_STREAMS) -> results."""
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors(o)
+
+
+def _seen_by(obj, stream):
+    for t in _tensors(obj):
+        if t.is_cuda and t.numel():
+            t.record_stream(stream)
+
+
+def use_here(*ts):
+    """The tensors are about to be read on the current stream although another one may have allocated them."""
+    if BRANCH_STREAMS or LONG_STREAMS:
+        _seen_by(ts, torch.cuda.current_stream())
+
+
+_RR = [0]          # round-robin cursor over BRANCH_STREAMS: consecutive forks land on different side streams
+
+
+def branches(fns, inputs=()):
+    """Run the independent callables `fns` (first one on the current stream, the others on ops.BRANCH_STREAMS) -> results.
+    `inputs`: tensors of the current stream that the branches read.  Forks only from the step's own stream: a fork out of
+    a side stream (nested branches) makes hipStreamEndCapture crash on ROCm 7.2 -- such calls run inline; fns[0] runs on
+    the current stream AFTER the side branches are launched, so it may itself fork again."""
     side = BRANCH_STREAMS
     if not side or len(fns) < 2 or KERNEL_EVENTS is not None:
         return [f() for f in fns]
     main = torch.cuda.current_stream()
-    used = []
-    for i in range(1, len(fns)):
-        st = side[(i - 1) % len(side)]
-        if st not in used:
-            st.wait_stream(main)               # fork: everything enqueued so far (the common input) precedes the branch
-            used.append(st)
+    if main in side or (LONG_STREAMS and main in LONG_STREAMS):
+        return [f() for f in fns]
+    where = [main]
+    for _ in range(1, len(fns)):
+        where.append(side[_RR[0] % len(side)])
+        _RR[0] += 1
+    for st in set(where[1:]):
+        st.wait_stream(main)                   # fork: everything enqueued so far (the common input) precedes the branch
+        _seen_by(inputs, st)
     out = [None] * len(fns)
     for i in range(1, len(fns)):
-        with torch.cuda.stream(side[(i - 1) % len(side)]):
+        with torch.cuda.stream(where[i]):
             out[i] = fns[i]()
     out[0] = fns[0]()
-    for st in used:
+    for st in set(where[1:]):
         main.wait_stream(st)                   # join
+    for i in range(1, len(fns)):
+        _seen_by(out[i], main)
     return out
+
+
+LONG_WHAT = ("lat", "mf", "kv")
+
+
+def fork(which, fn, inputs=(), what=None):
+    """Launch fn() on LONG_STREAMS[which] behind everything enqueued so far -> (result, handle); `join(handle, result)`
+    before the current stream reads the result.  Without side streams: runs inline, handle None."""
+    if not LONG_STREAMS or KERNEL_EVENTS is not None or (what is not None and what not in LONG_WHAT):
+        return fn(), None
+    st, main = LONG_STREAMS[which % len(LONG_STREAMS)], torch.cuda.current_stream()
+    if st == main:
+        return fn(), None
+    st.wait_stream(main)
+    _seen_by(inputs, st)
+    with torch.cuda.stream(st):
+        out = fn()
+        done = torch.cuda.Event()
+        done.record(st)
+    return out, (done, st)
+
+
+def join(handle, result=()):
+    if handle is not None:
+        main = torch.cuda.current_stream()
+        if main != handle[1]:
+            main.wait_event(handle[0])
+            _seen_by(result, main)
 
 
 def _sink_for(w):

@@ -72,21 +72,41 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         def conv_bn(seq, x, **kw):
             return bn_act(seq[0].forward_nobias(x), seq[0].bias, seq[1], **kw)
 
+        # The lateral 1x1 convolutions read only the backbone taps: with ops.LONG_STREAMS set they are launched on a side
+        # stream now and overlap with the six encoder layers (chains of 32x32-map kernels that leave most CUs idle).
+        def lateral(i):
+            def run():
+                x = self.lateral_convs_spike[i](feats[i]).flatten(0, 1)
+                ops.use_here(x)
+                return self.lateral_convs[i][0].forward_nobias(x)
+            return run
+        lat = {i: ops.fork(0, lateral(i), inputs=(feats[i],), what="lat") for i in range(self.num_inputs - 2, -1, -1)}
+
         y = self.last_feat_conv_spike(x4)
         y = conv_bn(self.encoder_in_proj, y.flatten(0, 1))[0].reshape(t, bs, E, h, w)
         memory = self.encoder.forward_nchw(y)          # == encoder(query=y.permute(0,1,3,4,2)).permute(0,1,4,2,3)
         memory = self.encoder_out_proj_spike(memory)
         y = conv_bn(self.encoder_out_proj, memory.flatten(0, 1))[0]
         out = [y.reshape(t, bs, E, h, w)]
-        for i in range(self.num_inputs - 2, -1, -1):
-            x = self.lateral_convs_spike[i](feats[i]).flatten(0, 1)
+
+        def level(i, y):
+            z, handle = lat[i]
+            ops.join(handle, (z,))
             up = ops.upsample_bilinear(y, feats[i].shape[-2:])
             # cur + upsample(y), then the output neuron: residual add and neuron fused into the BatchNorm kernel
-            _, s = conv_bn(self.lateral_convs[i], x, residual=up, lif=self.output_convs_spike[i])
+            _, s = bn_act(z, self.lateral_convs[i][0].bias, self.lateral_convs[i][1], residual=up, lif=self.output_convs_spike[i])
             # the last level feeds only mask_feature_spike: that neuron is applied by the same BatchNorm kernel (prefire)
             # instead of a separate pass over the [T*B, C, H/2, W/2] map (537 MB at C2)
-            y = conv_bn(self.output_convs[i], s, next_lif=self.mask_feature_spike if i == 0 else None)[0]
+            return conv_bn(self.output_convs[i], s, next_lif=self.mask_feature_spike if i == 0 else None)[0]
+
+        for i in range(self.num_inputs - 2, 0, -1):
+            y = level(i, y)
             out.append(y.reshape(t, bs, *y.shape[1:]))
-        y = self.mask_feature_spike(y)
-        mf = self.mask_feature(y)
+
+        # The H/2 level and the mask_feature convolution (the largest maps of the head) feed only the mask einsum at the very
+        # end: as a branch on the side stream they overlap with the transformer decoder; the head joins it (mask_feature_handle).
+        def finest(y=y):
+            y0 = level(0, y)
+            return self.mask_feature(self.mask_feature_spike(y0))
+        mf, self.mask_feature_handle = ops.fork(0, finest, inputs=(y,), what="mf")
         return mf.reshape(t, bs, *mf.shape[1:]), memory, out[:3]

@@ -15,9 +15,13 @@ img = so.synthetic_image(cfg, seed=5).cuda()
 state = {k: v.clone() for k, v in model.state_dict().items()}
 
 
-def run(fused, side):
+LONG = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+
+def run(fused, side, long=False):
     mh.FUSED_KV_NEURONS = fused
     ops.BRANCH_STREAMS = side
+    ops.LONG_STREAMS = LONG if long else None
     model.load_state_dict(state)
     s2f.reset_net(model); model.zero_grad(set_to_none=True)
     cls, masks = model(img)
@@ -38,3 +42,6 @@ r2 = run(True, None); cmp(r2, r0, "fused kv vs plain")
 r3 = run(False, side); cmp(r3, r0, "branch streams vs plain")
 r4 = run(False, side); cmp(r4, r3, "branch streams vs branch streams")
 r5 = run(True, side); cmp(r5, r0, "both vs plain")
+r6 = run(True, side, True); cmp(r6, r0, "all streams vs plain")
+r7 = run(False, None, True); cmp(r7, r0, "long streams, unfused kv vs plain")
+r8 = run(True, side, True); cmp(r8, r6, "all streams vs all streams")
