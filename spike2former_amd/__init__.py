@@ -7,6 +7,7 @@ from . import ops  # noqa: F401
 from .backbone_sdtv2 import Spiking_vit_MetaFormer  # noqa: F401
 from .configs import WORKLOADS, model_cfg  # noqa: F401
 from .firing import FiringRecorder  # noqa: F401
+from .loss import MaskFormerLoss, seg_to_instances  # noqa: F401
 from .maskformer_head import MaskFormerHead  # noqa: F401
 from .neuron import Q_IFNode, Quant, reset_net, set_keep_membrane  # noqa: F401
 from .pixel_decoder import DCNTransformerEncoderPixelDecoder  # noqa: F401

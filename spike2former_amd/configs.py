@@ -31,6 +31,16 @@ def model_cfg(name):
                     ffn_cfg=dict(embed_dims=Fc, feedforward_channels=w["pd"][1], num_fcs=2))),
                 positional_encoding=dict(num_feats=w["nf"], normalize=True)),
             enforce_decoder_input_project=False,
+            loss_cls=dict(type="mmdet.CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0, reduction="mean",
+                          class_weight=[1.0] * w["K"] + [0.1]),
+            loss_mask=dict(type="mmdet.FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=20.0),
+            loss_dice=dict(type="mmdet.DiceLoss", use_sigmoid=True, activate=True, reduction="mean", naive_dice=True, eps=1.0,
+                           loss_weight=1.0),
+            train_cfg=dict(assigner=dict(type="mmdet.HungarianAssigner", match_costs=[
+                dict(type="mmdet.ClassificationCost", weight=1.0),
+                dict(type="mmdet.FocalLossCost", weight=20.0, binary_input=True),
+                dict(type="mmdet.DiceCost", weight=1.0, pred_act=True, eps=1.0)]),
+                sampler=dict(type="mmdet.MaskPseudoSampler")),
             positional_encoding=dict(num_feats=w["nf"], normalize=True),
             transformer_decoder=dict(
                 return_intermediate=True, num_layers=w["dec"][0],

@@ -1,9 +1,9 @@
 """MaskFormer head with the SDME mask-embedding block, registry type 'MaskFormerHead'.
 
 One class covers the reference's two layers: mmdet `MaskFormerHead.forward`
-(mmdet/models/dense_heads/maskformer_head.py:31-160, 498-586) and the mmseg wrapper's `predict` / constructor
-(mmseg/models/decode_heads/maskformer_head.py:22-51, 138-180).  The Hungarian-matched loss (`loss_by_feat`) is SURVEY
-section 8 row f1 ("next") and is not part of this hot path; `loss()` raises.
+(mmdet/models/dense_heads/maskformer_head.py:31-160, 498-586) and the mmseg wrapper's `loss` / `predict` / constructor
+(mmseg/models/decode_heads/maskformer_head.py:22-51, 108-180).  The Hungarian-matched loss lives
+in loss.py; the benchmark's headline step keeps the data-independent loss of SURVEY 8d.
 """
 import torch
 import torch.nn as nn
@@ -13,6 +13,7 @@ from .head_layers import MLP, DetrTransformerDecoder, SinePositionalEncoding
 from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act
 from . import ops
+from .loss import MaskFormerLoss, seg_to_instances
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS, ConfigDict
 
@@ -71,6 +72,7 @@ class MaskFormerHead(nn.Module):
                                            nn.BatchNorm1d(num_queries))
         spikes_in(self.shortcut_conv[0])                    # reads alpha * spikes = multiples of 1/2
         self.test_cfg, self.train_cfg = test_cfg, train_cfg
+        self.criterion = MaskFormerLoss(num_classes, num_queries, loss_cls, loss_mask, loss_dice, train_cfg)
         self.align_corners = align_corners
         self.out_channels = num_classes
         self.ignore_index = ignore_index
@@ -169,5 +171,25 @@ class MaskFormerHead(nn.Module):
         cls_score = F.softmax(cls[-1], dim=-1)[..., :-1]
         return torch.einsum("bqc,bqhw->bchw", cls_score, mp.sigmoid())
 
+    def loss_by_feat(self, all_cls_scores, all_mask_preds, batch_gt_instances, batch_img_metas=None):
+        """mmdet MaskFormerHead.loss_by_feat (dense_heads/maskformer_head.py:376-414); `batch_gt_instances`: per image an
+        object with `.labels` / `.masks` or a (labels, masks) pair."""
+        gts = [g if isinstance(g, (tuple, list)) else (g.labels, g.masks) for g in batch_gt_instances]
+        reduce_fn = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            def reduce_fn(t):                                  # reduce_mean of num_total_masks (:459), all layers at once
+                t = t.clone()
+                torch.distributed.all_reduce(t.div_(torch.distributed.get_world_size()))
+                return t
+        return self.criterion.loss_by_feat(all_cls_scores, all_mask_preds, gts, reduce_fn=reduce_fn)
+
     def loss(self, x, batch_data_samples, train_cfg=None):
-        raise NotImplementedError("Hungarian-matched MaskFormer loss is SURVEY section 8 row f1 (next), not this path")
+        """mmseg MaskFormerHead.loss (decode_heads/maskformer_head.py:108-136): semantic maps -> per-class binary masks ->
+        forward -> Hungarian-matched loss dictionary.  `batch_data_samples`: SegDataSample-like objects
+        (`.gt_sem_seg.data` [1,H,W]) or the semantic maps themselves."""
+        gts = []
+        for d in batch_data_samples:
+            seg = d if torch.is_tensor(d) else d.gt_sem_seg.data
+            gts.append(seg_to_instances(seg, self.ignore_index))
+        all_cls_scores, all_mask_preds = self(x, batch_data_samples)
+        return self.loss_by_feat(all_cls_scores, all_mask_preds, gts)

@@ -202,6 +202,31 @@ def test_branch_streams_do_not_change_the_step(env):
     assert grad_gap(runs[0][2], runs[1][2]) <= 1e-3      # run-to-run noise of the split-K atomics is ~1e-5 on this metric
 
 
+def test_loss_mode_runs_the_hungarian_matched_loss(env):
+    """mode='loss' (EncoderDecoder.loss -> decode_head.loss, segmentors/encoder_decoder.py:125-141): the reference's loss
+    dictionary, finite, differentiable to every parameter that the headline loss reaches; equals the criterion applied to the
+    tensors of mode='tensor' (the loss itself is pinned against the reference's vectors in tests/test_loss.py)."""
+    s2f, so, cfg, model = env
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    img = so.synthetic_image(cfg, seed=8).cuda()
+    seg = torch.randint(0, cfg.num_classes, (cfg.B, 1, cfg.H, cfg.W), generator=torch.Generator().manual_seed(2)).cuda()
+    seg[0, :, :4] = 255
+    model.train(); s2f.reset_net(model); model.zero_grad(set_to_none=True)
+    losses = model(img, [seg[i] for i in range(cfg.B)], mode="loss")
+    L = cfg.dec_layers + 1
+    assert list(losses)[:3] == ["loss_cls", "loss_mask", "loss_dice"] and len(losses) == 3 * L
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    got = {k for k, p in model.named_parameters() if p.grad is not None and torch.isfinite(p.grad).all()}
+    model.load_state_dict(state); s2f.reset_net(model); model.zero_grad(set_to_none=True)
+    cls, masks = model(img)
+    again = model.decode_head.loss_by_feat(cls, masks, [s2f.seg_to_instances(seg[i]) for i in range(cfg.B)])
+    assert all(torch.equal(again[k], losses[k]) for k in losses)
+    s2f.headline_loss(cls, masks).backward()
+    assert got == {k for k, p in model.named_parameters() if p.grad is not None}
+
+
 def test_predict_and_keep_membrane_equivalence(env):
     """`keep_membrane=False` must not change outputs when a reset precedes every forward."""
     s2f, so, cfg, model = env

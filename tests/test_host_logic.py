@@ -67,8 +67,8 @@ def test_no_cpu_fallback(tiny):
         s2f.Q_IFNode()(torch.zeros(8))
     with pytest.raises(RuntimeError, match="GPU only"):
         tiny(torch.zeros(1, 3, 64, 64))
-    with pytest.raises(NotImplementedError):
-        tiny.decode_head.loss(None, None)
+    with pytest.raises(RuntimeError, match="GPU only"):         # the real loss runs the same (GPU-only) forward
+        tiny(torch.zeros(1, 3, 64, 64), [torch.zeros(1, 64, 64, dtype=torch.long)], mode="loss")
 
 
 def test_constructor_errors_mirror_the_reference():
