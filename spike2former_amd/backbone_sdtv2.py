@@ -18,6 +18,10 @@ from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
 
+# the q / k / v projection chains of an attention block as one 3C-channel chain (pure neurons only)
+QKV_BATCHED = True
+
+
 def _lif():
     return Q_IFNode(surrogate_function=Quant())
 
@@ -194,15 +198,86 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         self.v_spike = _lif()
         self.attn_spike = _lif()
         self.proj_conv = nn.Sequential(RepConv(dim, dim, bias=False), nn.BatchNorm2d(dim))
+        self._flatten_qkv()
+
+    # ---- q / k / v as ONE chain of 3C channels ---------------------------------------------------------------------------
+    # The three projection chains read the same spikes and have the same shapes; run separately each of their 18 forward
+    # (and ~32 backward) kernels is a 128-256-workgroup launch on a 32x32 map.  BatchNorm, the depthwise stencil and the
+    # neuron are per-channel, so on the channel-concatenated tensor they ARE the three separate ops; the first 1x1 conv is
+    # one GEMM with the stacked weight, the second a 3-group batched GEMM.  The parameters stay the reference's separate
+    # tensors (state_dict keys unchanged); `_flatten_qkv` lays the twins out back to back so that the concatenated views
+    # exist without copies (ops.cat_params falls back to torch.cat when something re-allocated them).
+    def _twins(self):
+        convs = (self.q_conv, self.k_conv, self.v_conv)
+        g = lambda f: [f(c) for c in convs]                               # noqa: E731
+        bn1, bn2, bn3 = g(lambda c: c[0].body[1].bn), g(lambda c: c[0].body[2][2]), g(lambda c: c[1])
+        return dict(w1=g(lambda c: c[0].body[0].weight), dw=g(lambda c: c[0].body[2][0].weight),
+                    w2=g(lambda c: c[0].body[2][1].weight), bns=(bn1, bn2, bn3))
+
+    def _flatten_qkv(self):
+        t = self._twins()
+        for ws in (t["w1"], t["dw"], t["w2"]):
+            ops.flatten_together(ws)
+        for bns in t["bns"]:
+            for name in ("weight", "bias", "running_mean", "running_var"):
+                ops.flatten_together([getattr(b, name) for b in bns])
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)            # .to() / .cuda() re-allocate every tensor: lay the twins out again
+        self._flatten_qkv()
+        return self
+
+    def _qkv_batched(self, s, T, B, C, H, W):
+        t = self._twins()
+        N = H * W
+        training = self.q_conv[1].training
+        out = []
+
+        class CatBN:                            # what fused.bn_act reads of a BatchNorm module
+            def __init__(bn, mods):
+                bn.weight, bn.bias = ops.cat_params([m.weight for m in mods]), ops.cat_params([m.bias for m in mods])
+                bn.running_mean, wb1 = ops.cat_buffers([m.running_mean for m in mods])
+                bn.running_var, wb2 = ops.cat_buffers([m.running_var for m in mods])
+                bn.num_batches_tracked = None   # counted below, once for all nine
+                bn.training, bn.momentum, bn.eps = mods[0].training, mods[0].momentum, mods[0].eps
+                out.append(wb1); out.append(wb2)
+
+        bn1, bn2, bn3 = (CatBN(m) for m in t["bns"])
+        w1 = ops.cat_params(t["w1"]).view(3 * C, C)
+        w1._s2f_version = sum(p._version for p in t["w1"])              # for the cached bf16 split (ops.split_weight)
+        z = ops.spike_gemm(s.view(T * B, C, N), w1).view(T * B, 3 * C, H, W)          # the three first 1x1 convs: one GEMM
+        z, _, border = bn_act(z, None, bn1, want_border=True)
+        z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, border)
+        w2 = ops.cat_params(t["w2"]).view(3, C, C)
+        z = torch.matmul(w2.unsqueeze(0), z.view(T * B, 3, C, N)).view(T * B, 3 * C, H, W)   # second 1x1: 3-group batched GEMM
+        z, _ = bn_act(z, None, bn2)
+        _, y = bn_act(z, None, bn3, lif=self.q_spike)     # q / k / v neurons: pure and identical here (checked by the caller)
+        for wb in out:
+            wb()
+        if training:
+            torch._foreach_add_([b.num_batches_tracked for bns in t["bns"] for b in bns], 1)
+        return ops.split3(y.view(T * B, 3 * C, N))
+
+    def _can_batch(self):
+        lifs = (self.q_spike, self.k_spike, self.v_spike)
+        bns = [b for group in self._twins()["bns"] for b in group]
+        return (QKV_BATCHED and all(isinstance(n.v, float) and not n.keep_membrane and n.stats is None for n in lifs)
+                and len({(n.D, n.v_threshold) for n in lifs}) == 1
+                and all(c[0].body[2][0].kernel_size == (3, 3) for c in (self.q_conv, self.k_conv, self.v_conv))
+                and len({(b.training, b.momentum, b.eps, b.running_mean is None) for b in bns}) == 1
+                and bns[0].momentum is not None and bns[0].running_mean is not None)
 
     def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
         N = H * W
         s = self.head_spike(x).flatten(0, 1)
-        q, k, v = ops.branches([
-            lambda: self.q_conv[0](s, outer_bn=self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N),
-            lambda: self.k_conv[0](s, outer_bn=self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N),
-            lambda: self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)], inputs=(s,))
+        if s.is_cuda and N % 4 == 0 and self._can_batch():
+            q, k, v = self._qkv_batched(s, T, B, C, H, W)
+        else:
+            q, k, v = ops.branches([
+                lambda: self.q_conv[0](s, outer_bn=self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N),
+                lambda: self.k_conv[0](s, outer_bn=self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N),
+                lambda: self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)], inputs=(s,))
         o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
         o = self.attn_spike(o).view(T * B, C, H, W)
         res = None if residual is None else residual.flatten(0, 1)

@@ -231,6 +231,94 @@ def mask_words(n):
     return ((n + 255) >> 8) * 4
 
 
+# ------------------------------------------------------------------------------------------------ parameter groups
+def adjacent(ts):
+    """True when the tensors lie back to back in ONE storage (same dtype / device, contiguous): their concatenation along
+    dim 0 then already exists in memory."""
+    t0 = ts[0]
+    base = t0.untyped_storage().data_ptr()
+    end = t0.data_ptr()
+    for t in ts:
+        if (t.dtype != t0.dtype or t.device != t0.device or not t.is_contiguous() or t.shape[1:] != t0.shape[1:]
+                or t.untyped_storage().data_ptr() != base or t.data_ptr() != end):
+            return False
+        end += t.numel() * t.element_size()
+    return True
+
+
+def _alias(ts):
+    t0 = ts[0]
+    rows = sum(t.shape[0] for t in ts)
+    return torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), t0.storage_offset(),
+                                                                 (rows,) + tuple(t0.shape[1:]))
+
+
+class _AliasCat(torch.autograd.Function):
+    """torch.cat(params, 0) without the copy, for parameters that are adjacent views of one flat storage (the q / k / v
+    twins of an attention block, flattened by the module): forward hands out the enclosing view, backward hands each
+    parameter its slice of the gradient (views, no copy)."""
+
+    @staticmethod
+    def forward(ctx, *ps):
+        ctx.rows = [p.shape[0] for p in ps]
+        return _alias([p.detach() for p in ps])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, 0))
+
+
+def cat_params(ps):
+    """Concatenation of sibling parameters along dim 0: zero-copy when they are adjacent in memory, torch.cat otherwise."""
+    ps = list(ps)
+    if adjacent([p.detach() for p in ps]):
+        return _AliasCat.apply(*ps) if any(p.requires_grad for p in ps) else _alias(ps)
+    return torch.cat(ps, 0)
+
+
+def cat_buffers(bs):
+    """-> (tensor, write_back): sibling buffers as one tensor that a kernel may update in place; `write_back()` copies the
+    result into the buffers when they were not adjacent (then the tensor is a temporary concatenation)."""
+    bs = list(bs)
+    if adjacent(bs):
+        return _alias(bs), (lambda: None)
+    cat = torch.cat(bs, 0)
+
+    def write_back():
+        for b, c in zip(bs, cat.split([b.shape[0] for b in bs], 0)):
+            b.copy_(c)
+    return cat, write_back
+
+
+def flatten_together(ts):
+    """Re-point the `.data` of sibling parameters / buffers at consecutive slices of one new flat tensor (values kept)."""
+    ts = list(ts)
+    flat = torch.cat([t.data.reshape(-1) for t in ts])
+    off = 0
+    for t in ts:
+        t.data = flat[off:off + t.numel()].view(t.shape)
+        off += t.numel()
+
+
+class _Split3(torch.autograd.Function):
+    """[N, 3C, L] -> three contiguous [N, C, L] tensors (one transposing copy); backward: one concatenating copy (autograd's
+    own slicing would zero-fill and add three full-size tensors)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        N, C3, L = y.shape
+        yp = y.view(N, 3, C3 // 3, L).permute(1, 0, 2, 3).contiguous()
+        return yp[0], yp[1], yp[2]
+
+    @staticmethod
+    def backward(ctx, ga, gb, gc):
+        return torch.stack([ga, gb, gc], 1).flatten(1, 2)
+
+
+def split3(y):
+    return _Split3.apply(y)
+
+
 # ------------------------------------------------------------------------------------------------ LIF
 class _LIF(torch.autograd.Function):
     """One Q_IFNode call (neuron.py:166-197 + surrogate.py:522-538).  Saves 1 bit/element for backward."""
@@ -573,15 +661,18 @@ SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a sp
 def split_weight(w2d):
     """fp32 [M, K] -> cached bf16 [3, Mpad, Kpad] (hi, mid, lo).  Re-split when the parameter is modified in place
     (optimiser step, load_state_dict) -- tracked through the tensor version counter."""
-    key = w2d.data_ptr()
+    key = (w2d.data_ptr(), w2d.numel())
     M, K = w2d.shape
+    # a zero-copy concatenation of sibling parameters (cat_params) is a fresh tensor every call: it carries the sum of the
+    # parameters' version counters instead of its own
+    version = getattr(w2d, "_s2f_version", w2d._version)
     hit = _SPLIT_CACHE.get(key)
-    if hit is not None and hit[0] == w2d._version and hit[1].shape[1] >= M and hit[2] == (M, K):
+    if hit is not None and hit[0] == version and hit[1].shape[1] >= M and hit[2] == (M, K):
         return hit[1]
     Mpad, Kpad = (M + 63) // 64 * 64, (K + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=w2d.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d.detach().contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _SPLIT_CACHE[key] = (w2d._version, out, (M, K))
+    _SPLIT_CACHE[key] = (version, out, (M, K))
     return out
 
 

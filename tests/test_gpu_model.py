@@ -227,6 +227,52 @@ def test_loss_mode_runs_the_hungarian_matched_loss(env):
     assert got == {k for k, p in model.named_parameters() if p.grad is not None}
 
 
+def test_batched_qkv_chain_is_the_three_chains(env):
+    """backbone_sdtv2.QKV_BATCHED: the q / k / v projection chains of an attention block as ONE 3C-channel chain (stacked
+    first 1x1 conv, per-channel BN / depthwise / neuron on the concatenated tensor, 3-group second 1x1) against the three
+    separate chains.  Per-channel ops are identical; the GEMMs sum in a different tile order, so pre-neuron values agree to
+    fp32 round-off and a borderline neuron may flip by one level: <= 1e-3 of the spikes may differ, each by exactly 1/8;
+    BatchNorm running statistics and parameter gradients agree to 1e-4 of their scale."""
+    s2f, so, cfg, model = env
+    from spike2former_amd import backbone_sdtv2 as bb, ops
+    attn = model.backbone.block3[0].attn
+    assert ops.adjacent([p.detach() for p in attn._twins()["w1"]])           # flattened again after .cuda()
+    s2f.set_keep_membrane(model, False)
+    attn.train()
+    state = {k: v.clone() for k, v in attn.state_dict().items()}
+    C = attn.dim
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(2, 2, C, 8, 8, generator=g) * 2).cuda()
+    wgt = torch.randn(2, 2, C, 8, 8, generator=g).cuda()
+    runs = []
+    try:
+        for batched in (True, False):
+            bb.QKV_BATCHED = batched
+            attn.load_state_dict(state)
+            s2f.reset_net(model); attn.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            spikes = {}
+            hooks = [m.register_forward_hook(lambda mod, i, o, n=n: spikes.__setitem__(n, o.detach().clone()))
+                     for n, m in (("attn", attn.attn_spike),)]
+            y = attn(xi)
+            (y * wgt).sum().backward()
+            for h in hooks:
+                h.remove()
+            runs.append((y.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in attn.named_parameters()},
+                         {k: v.clone() for k, v in attn.state_dict().items() if "running" in k or "num_batches" in k}, spikes))
+    finally:
+        bb.QKV_BATCHED = True
+        s2f.set_keep_membrane(model, True)
+    a, b = runs
+    d = (a[4]["attn"] - b[4]["attn"]).abs() * 8
+    assert float((d > 0).float().mean()) <= 1e-3 and float(d.max()) <= 1.0
+    if float(d.max()) == 0:                                                   # no flip: everything agrees to round-off
+        assert rel(a[0], b[0]) <= 1e-4 and rel(a[1], b[1]) <= 1e-3
+        assert grad_gap(a[2], b[2]) <= 1e-3
+    for k in b[3]:
+        assert torch.allclose(a[3][k].float(), b[3][k].float(), rtol=1e-4, atol=1e-6), k
+
+
 def test_predict_and_keep_membrane_equivalence(env):
     """`keep_membrane=False` must not change outputs when a reset precedes every forward."""
     s2f, so, cfg, model = env
