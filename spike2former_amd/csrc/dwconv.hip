@@ -113,6 +113,79 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const float* __restrict
   }
 }
 
+// Wide-map form of the same stencil (W % 4 == 0, W >= 64): a 64 x 32 output tile per workgroup, every thread a 2 x 4 output
+// block.  The halo is staged as whole 16-byte groups of an ALIGNED superset of its columns ([tx - 4, tx + 68): every group
+// lies entirely inside or entirely outside the plane, so the loads are branch-free vector loads with a select -- the scalar
+// ring loads of the 32 x 32 form each sat behind their own bounds branch), LDS rows are read back as ds_read_b128 (16
+// consecutive lanes read 256 consecutive bytes: conflict-free) and each staged row feeds two output rows.  Per output:
+// 1.5 LDS reads of 16 bytes instead of 17.5 of 4 bytes.  'Same' padding (pad == (K - 1) / 2) only.
+constexpr int WT = 64, HT = 32, WS = WT + 8;           // tile and staged row length (floats)
+
+template <int K, bool FLIP>
+__global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ border, float* __restrict__ y,
+                                                              int C, int H, int W, int Ho, int Wo, int pad, int tiles_x) {
+  constexpr int HR = HT + K - 1;                       // staged rows
+  __shared__ __attribute__((aligned(16))) float s[HR][WS];
+  const int plane = blockIdx.y;
+  const int c = plane % C;
+  const int ty = (blockIdx.x / tiles_x) * HT, tx = (blockIdx.x % tiles_x) * WT;
+  const float* xp = x + (int64_t)plane * H * W;
+  const float fillv = (!FLIP && border) ? border[c] : 0.f;    // every off-plane value a valid output reads is the border
+  const int po = pad;                                  // == K - 1 - pad
+  // stage rows ty - po .. ty - po + HR - 1, columns tx - 4 .. tx + 67 as 18 groups of 4
+  for (int e = threadIdx.x; e < HR * (WS / 4); e += 256) {
+    const int r = e / (WS / 4), g = e - r * (WS / 4);
+    const int iy = ty - po + r, ix = tx - 4 + g * 4;
+    const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float4 v = *reinterpret_cast<const float4*>(xp + (in ? (int64_t)iy * W + ix : 0));
+    *reinterpret_cast<float4*>(&s[r][g * 4]) = in ? v : make_float4(fillv, fillv, fillv, fillv);
+  }
+  float wk[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) wk[i] = w[c * K * K + i];
+  __syncthreads();
+  const int r2 = (threadIdx.x >> 4) * 2;               // first of the thread's two output rows (0, 2, .., 30)
+  const int q0 = (threadIdx.x & 15) * 4;               // first of its four output columns
+  // 'same' padding only (pad == (K - 1) / 2, so po == pad in both directions): output column q0 + o reads the staged
+  // columns q0 + o + j + SH, j = 0 .. K-1 -- inside the 12 floats from q0
+  constexpr int SH = 4 - (K - 1) / 2;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < K + 1; ++i) {
+    float row[12];
+#pragma unroll
+    for (int v4 = 0; v4 < 3; ++v4) {
+      const float4 t = *reinterpret_cast<const float4*>(&s[r2 + i][q0 + v4 * 4]);
+      row[v4 * 4] = t.x; row[v4 * 4 + 1] = t.y; row[v4 * 4 + 2] = t.z; row[v4 * 4 + 3] = t.w;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ki = i - a;                            // kernel row that staged row i is for output row r2 + a
+      if (ki < 0 || ki >= K) continue;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float wv = FLIP ? wk[(K - 1 - ki) * K + (K - 1 - j)] : wk[ki * K + j];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[a][o] += wv * row[j + o + SH];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int oy = ty + r2 + a, ox = tx + q0;
+    if (oy >= Ho) continue;
+    float* yp = y + (int64_t)plane * Ho * Wo + (int64_t)oy * Wo + ox;
+    if ((Wo & 3) == 0 && ox + 3 < Wo && (reinterpret_cast<uintptr_t>(yp) & 15u) == 0) {
+      *reinterpret_cast<float4*>(yp) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (ox + o < Wo) yp[o] = acc[a][o];
+    }
+  }
+}
+
 // gw[c][i][j] += sum over the tile of gy[oy][ox] * x[oy + i - pad][ox + j - pad].  Each thread owns 4 consecutive output
 // pixels of one tile row and forms its K*K partial sums in registers (K rows of K+3 staged inputs, as in the stencil); the
 // block sum runs over wave shuffles and one LDS round.  (A (tap, pixel-slice) thread mapping spent ~10 instructions per
@@ -193,6 +266,18 @@ int check(const char* who, int N, int C, int H, int W, int K, int pad, int& Ho, 
 template <bool FLIP>
 void launch_stencil(int K, dim3 grid, hipStream_t s, const float* x, const float* w, const float* border, float* y, int C,
                     int H, int W, int Ho, int Wo, int pad, int tiles_x) {
+  // wide maps with 'same' padding: 64 x 32 tiles, vector staging, 2 x 4 outputs per thread
+  if ((W & 3) == 0 && W >= WT && H >= HT && 2 * pad == K - 1 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    const int wx = (Wo + WT - 1) / WT, wy = (Ho + HT - 1) / HT;
+    const dim3 g(wx * wy, grid.y);
+    if (K == 3)
+      hipLaunchKernelGGL((dw_stencil_wide_kernel<3, FLIP>), g, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, wx);
+    else if (K == 5)
+      hipLaunchKernelGGL((dw_stencil_wide_kernel<5, FLIP>), g, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, wx);
+    else
+      hipLaunchKernelGGL((dw_stencil_wide_kernel<7, FLIP>), g, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, wx);
+    return;
+  }
   if (K == 3)
     hipLaunchKernelGGL((dw_stencil_kernel<3, FLIP>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
   else if (K == 5)
