@@ -12,6 +12,7 @@
 // materialised.  The input gradient is the same stencil with the kernel flipped; the weight gradient assigns one
 // (tap, pixel-slice) to each thread and finishes with K*K atomics per workgroup.
 #include "s2f_common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(fast)
 
@@ -266,16 +267,15 @@ int check(const char* who, int N, int C, int H, int W, int K, int pad, int& Ho, 
 template <bool FLIP>
 void launch_stencil(int K, dim3 grid, hipStream_t s, const float* x, const float* w, const float* border, float* y, int C,
                     int H, int W, int Ho, int Wo, int pad, int tiles_x) {
-  // wide maps with 'same' padding: 64 x 32 tiles, vector staging, 2 x 4 outputs per thread
-  if ((W & 3) == 0 && W >= WT && H >= HT && 2 * pad == K - 1 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+  // 3x3 on wide maps with 'same' padding: 64 x 32 tiles, vector staging, 2 x 4 outputs per thread.  Measured
+  // (tools/probe_dw.py, us, 32x32-tile form -> wide form): 3x3 [8,256,256,256] 267 -> 222, [8,256,128,128] 70 -> 53,
+  // [8,256,64,64] 17 -> 18; 7x7 [8,64,256,256] 109 -> 139 (49 multiply-adds per output: that stencil is VALU-bound and the
+  // 2 x 4 block only adds register pressure), so the wide form is used for K = 3, W >= 128 only.
+  static const bool wide_on = !getenv("S2F_DW_NO_WIDE");          // A/B switch for tools/probe_dw.py
+  if (wide_on && K == 3 && (W & 3) == 0 && W >= 2 * WT && H >= HT && pad == 1 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
     const int wx = (Wo + WT - 1) / WT, wy = (Ho + HT - 1) / HT;
-    const dim3 g(wx * wy, grid.y);
-    if (K == 3)
-      hipLaunchKernelGGL((dw_stencil_wide_kernel<3, FLIP>), g, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, wx);
-    else if (K == 5)
-      hipLaunchKernelGGL((dw_stencil_wide_kernel<5, FLIP>), g, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, wx);
-    else
-      hipLaunchKernelGGL((dw_stencil_wide_kernel<7, FLIP>), g, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, wx);
+    hipLaunchKernelGGL((dw_stencil_wide_kernel<3, FLIP>), dim3(wx * wy, grid.y), dim3(256), 0, s, x, w, border, y, C, H, W, Ho,
+                       Wo, pad, wx);
     return;
   }
   if (K == 3)

@@ -425,7 +425,12 @@ def test_mask_einsum_matrix_core_path_vs_fp64(ops):
 @pytest.mark.parametrize("N,C,H,W,K,pad,border", [(2, 8, 32, 32, 3, 1, True), (2, 6, 37, 45, 7, 3, False),
                                                    (1, 5, 4, 4, 5, 2, False), (3, 16, 64, 64, 5, 2, False),
                                                    (2, 4, 9, 7, 3, 1, True), (1, 3, 70, 33, 7, 3, False),
-                                                   (2, 4, 10, 10, 3, 0, False)])
+                                                   (2, 4, 10, 10, 3, 0, False),
+                                                   # wide-map form of the 3x3 (W % 4 == 0, W >= 128, H >= 32, pad 1): full and
+                                                   # partial 64 x 32 tiles, with / without border; other sizes on wide maps
+                                                   (2, 3, 96, 128, 3, 1, True), (1, 2, 33, 132, 3, 1, False),
+                                                   (1, 2, 40, 256, 3, 1, True), (1, 4, 64, 128, 7, 3, False),
+                                                   (1, 2, 40, 136, 5, 2, False)])
 def test_dwconv_vs_aten_cpu(ops, N, C, H, W, K, pad, border):
     """fp32, K*K <= 49 terms per output: rtol 2e-6 forward / input gradient; the weight gradient sums N*H*W terms in a
     different order than ATen: 2e-5.  `border` reproduces conv(pad-with-constant(x), padding=0) of BNAndPadLayer."""
