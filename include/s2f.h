@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 10
+#define S2F_ABI_VERSION 11
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -82,6 +82,13 @@ int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, float* y_
                      uint64_t* mask_value, int64_t TB, int64_t B, int64_t C, int64_t L, float vth, int D, void* stream);
 int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const uint64_t* mask_key, const uint64_t* mask_value,
                      float* gx, int64_t n, int D, void* stream);
+
+/* Layer scale folded into a BatchNorm's affine pair: w[c] = gamma[c] * s[c], b[c] = beta[c] * s[c]  (the pixel decoder's
+ * `q + gamma_i * f(q)`, detr_layers.py:331-337, with f ending in a BatchNorm: u = s * BN(z) = BN_{gamma s, beta s}(z)).
+ * Backward: dgamma = gw * s, dbeta = gb * s, ds = gw * gamma + gb * beta.  One launch each instead of 2 + 5 vector ops. */
+int s2f_scale_affine_fwd(const float* gamma, const float* beta, const float* s, float* w, float* b, int C, void* stream);
+int s2f_scale_affine_bwd(const float* gw, const float* gb, const float* gamma, const float* beta, const float* s,
+                         float* dgamma, float* dbeta, float* ds, int C, void* stream);
 
 /* ---- T successive stateful calls on one neuron, membrane carried in registers -----------------------
  * Same arithmetic as T calls of s2f_lif_fwd with v chained (what tools/cal_firing_num.py:203-225 does across

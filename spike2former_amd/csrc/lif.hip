@@ -252,6 +252,29 @@ __global__ __launch_bounds__(kBlock) void sum2_lif_bwd_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------ layer scale folded into a BatchNorm affine pair
+__global__ void scale_affine_fwd_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ s, float* __restrict__ w, float* __restrict__ b, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    w[c] = gamma[c] * s[c];
+    b[c] = beta[c] * s[c];
+  }
+}
+
+__global__ void scale_affine_bwd_kernel(const float* __restrict__ gw, const float* __restrict__ gb,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ s, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                        float* __restrict__ ds, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float a = gw ? gw[c] : 0.f, bb = gb ? gb[c] : 0.f;
+    dgamma[c] = a * s[c];
+    dbeta[c] = bb * s[c];
+    ds[c] = a * gamma[c] + bb * beta[c];
+  }
+}
+
 // ------------------------------------------------------------------ T chained steps, membrane in registers
 template <bool HAS_V0>
 __global__ __launch_bounds__(kBlock) void lif_seq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v0,
@@ -409,6 +432,22 @@ extern "C" int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const 
   S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
              mask_key, mask_value, gx, n, (float)D);
   return s2f_check_launch("s2f_sum2_lif_bwd");
+}
+
+extern "C" int s2f_scale_affine_fwd(const float* gamma, const float* beta, const float* s, float* w, float* b, int C,
+                                    void* stream) {
+  S2F_REQUIRE(gamma && beta && s && w && b && C > 0, S2F_EINVAL, "s2f_scale_affine_fwd: null pointer / empty");
+  hipLaunchKernelGGL(scale_affine_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, s, w, b,
+                     C);
+  return s2f_check_launch("s2f_scale_affine_fwd");
+}
+
+extern "C" int s2f_scale_affine_bwd(const float* gw, const float* gb, const float* gamma, const float* beta, const float* s,
+                                    float* dgamma, float* dbeta, float* ds, int C, void* stream) {
+  S2F_REQUIRE(gamma && beta && s && dgamma && dbeta && ds && C > 0, S2F_EINVAL, "s2f_scale_affine_bwd: null pointer / empty");
+  hipLaunchKernelGGL(scale_affine_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gw, gb, gamma, beta, s,
+                     dgamma, dbeta, ds, C);
+  return s2f_check_launch("s2f_scale_affine_bwd");
 }
 
 extern "C" int s2f_lif_seq_fwd(const float* x_seq, const float* v0, float* y_seq, float* vT, uint64_t* mask,

@@ -44,7 +44,7 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         v_in = lif.v
     if lif is not None and lif.stats is not None:
         lif.stats_elems += z.numel()
-    weight, bias = (bn.weight, bn.bias) if scale is None else (bn.weight * scale, bn.bias * scale)
+    weight, bias = (bn.weight, bn.bias) if scale is None else ops.scale_affine(bn.weight, bn.bias, scale)
     u, y, v_out, border = ops.bn_act(
         z, conv_bias, weight, bias, bn.running_mean, bn.running_var,
         bn.num_batches_tracked if training else None, training, bn.momentum, bn.eps,

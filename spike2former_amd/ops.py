@@ -595,6 +595,36 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
     return out + (border,) if want_border else out
 
 
+class _ScaleAffine(torch.autograd.Function):
+    """(gamma * s, beta * s) in one launch, gradients of all three in one launch (s2f.h s2f_scale_affine_*)."""
+
+    @staticmethod
+    def forward(ctx, gamma, beta, s):
+        _need_cuda(gamma, beta, s)
+        gamma, beta, s = gamma.contiguous(), beta.contiguous(), s.contiguous()
+        w, b = torch.empty_like(gamma), torch.empty_like(beta)
+        check(lib.s2f_scale_affine_fwd(_ptr(gamma), _ptr(beta), _ptr(s), _ptr(w), _ptr(b), gamma.numel(), _stream()),
+              "s2f_scale_affine_fwd")
+        ctx.save_for_backward(gamma, beta, s)
+        ctx.set_materialize_grads(False)
+        return w, b
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        gamma, beta, s = ctx.saved_tensors
+        if gw is None and gb is None:
+            return None, None, None
+        dg, db, ds = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(s)
+        check(lib.s2f_scale_affine_bwd(_ptr(None if gw is None else gw.contiguous()), _ptr(None if gb is None else gb.contiguous()),
+                                       _ptr(gamma), _ptr(beta), _ptr(s), _ptr(dg), _ptr(db), _ptr(ds), gamma.numel(), _stream()),
+              "s2f_scale_affine_bwd")
+        return dg, db, ds
+
+
+def scale_affine(gamma, beta, s):
+    return _ScaleAffine.apply(gamma, beta, s)
+
+
 # ------------------------------------------------------------------------------------------------ depthwise conv
 class _DWConv(torch.autograd.Function):
     """Depthwise KxK, stride 1 (nn.Conv2d(groups=C)); `border` = per-channel constant padding value (detached)."""

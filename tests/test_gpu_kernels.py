@@ -421,6 +421,21 @@ def test_mask_einsum_matrix_core_path_vs_fp64(ops):
         assert (mf2.grad - mf.grad).abs().max().item() <= 1e-4 * gmf_ref.abs().max().item()
 
 
+def test_scale_affine_matches_the_vector_ops(ops):
+    """Layer scale folded into a BatchNorm affine pair (detr_layers.py:331-337): (gamma*s, beta*s) and all three gradients."""
+    g = torch.Generator().manual_seed(4)
+    ga, be, sc = (torch.randn(300, generator=g).cuda().requires_grad_(True) for _ in range(3))
+    w, b = ops.scale_affine(ga, be, sc)
+    cw, cb = torch.randn(300, generator=g).cuda(), torch.randn(300, generator=g).cuda()
+    ((w * cw).sum() + (b * cb).sum()).backward()
+    got = [t.grad.clone() for t in (ga, be, sc)]
+    for t in (ga, be, sc):
+        t.grad = None
+    ((ga * sc * cw).sum() + (be * sc * cb).sum()).backward()
+    assert torch.equal(w, ga * sc) and torch.equal(b, be * sc)
+    assert torch.equal(got[0], ga.grad) and torch.equal(got[1], be.grad) and torch.allclose(got[2], sc.grad, rtol=1e-6, atol=1e-7)
+
+
 # ----------------------------------------------------------------------------------------------- depthwise stencils
 @pytest.mark.parametrize("N,C,H,W,K,pad,border", [(2, 8, 32, 32, 3, 1, True), (2, 6, 37, 45, 7, 3, False),
                                                    (1, 5, 4, 4, 5, 2, False), (3, 16, 64, 64, 5, 2, False),
