@@ -524,7 +524,8 @@ def test_spike_gemm_terms_and_resplit(ops):
 
 
 # ----------------------------------------------------------------------------------------------- 2x bilinear up-sampling
-@pytest.mark.parametrize("N,C,h,w", [(2, 3, 4, 4), (1, 5, 7, 6), (2, 16, 32, 32), (1, 2, 1, 2)])
+@pytest.mark.parametrize("N,C,h,w", [(2, 3, 4, 4), (1, 5, 7, 6), (2, 16, 32, 32), (1, 2, 1, 2), (1, 2, 2, 4), (2, 3, 6, 8),
+                                     (1, 4, 64, 64), (1, 2, 5, 8), (1, 2, 6, 10)])
 def test_upsample2x_matches_interpolate(ops, N, C, h, w):
     """Against F.interpolate on CPU (forward and adjoint through autograd): 2e-6 of the max -- ATen's CPU kernel
     associates the four weighted taps differently, so the last bit may differ."""
