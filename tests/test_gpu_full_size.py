@@ -240,6 +240,44 @@ def test_c2_step_properties(c2):
     s2f.set_keep_membrane(model, True)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload", ["C3", "C4"])
+def test_other_baseline_configs_step_properties(workload):
+    """BASELINE.json configs[2] (Cityscapes 1024x512, per-GPU shard of 2) and configs[3] (T = 8) at full size, through
+    properties that need no oracle run: output shapes, every activation handed to the bf16 spike GEMM on the spike grid,
+    finite non-zero gradients for the same parameter set as at C2, the T-fold structure of the workload (a reset step repeats the input T
+    times, so every time slice of a feature map is identical) and a firing rate inside (0, 1) on the last backbone tap."""
+    import spike2former_amd as s2f
+    from spike2former_amd import ops
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS[workload]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg(workload))).cuda().train()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(w["B"], 3, w["H"], w["W"], generator=torch.Generator().manual_seed(9)).cuda()
+    seen = {}
+    h = model.backbone.register_forward_hook(lambda m, i, o: seen.__setitem__("x4", o[-1].detach()))
+    s2f.reset_net(model); model.zero_grad(set_to_none=True)
+    ops.SPIKE_GEMM_CHECK = True
+    try:
+        cls, masks = model(img)
+    finally:
+        ops.SPIKE_GEMM_CHECK = False
+        h.remove()
+    assert cls.shape == (7, w["B"], w["Q"], w["K"] + 1) and masks.shape == (7, w["B"], w["Q"], w["H"] // 2, w["W"] // 2)
+    s2f.headline_loss(cls, masks).backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([g.flatten() for g in grads])
+    assert torch.isfinite(cls).all() and torch.isfinite(masks).all() and torch.isfinite(flat).all() and flat.abs().max() > 0
+    x4 = seen["x4"]                                          # last backbone tap [T, B, C, H/16, W/16]
+    assert x4.shape == (w["T"], w["B"], w["embed_dim"][3], w["H"] // 16, w["W"] // 16)
+    assert all(torch.equal(x4[0], x4[t]) for t in range(1, w["T"]))
+    y, _ = ops.lif(x4, None, keep_v=False)
+    c = y * 8
+    assert torch.equal(c, torch.round(c)) and 0 <= float(c.min()) and float(c.max()) <= 8 and 0 < float(y.mean()) < 1
+    del model, grads, flat
+    torch.cuda.empty_cache()
+
+
 def test_tiny_graph_replay_is_bitwise_the_eager_step():
     """On the well-conditioned tiny config the hipGraph replay must reproduce the eager step bit for bit."""
     import spike2former_amd as s2f
