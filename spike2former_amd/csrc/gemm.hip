@@ -450,34 +450,41 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
 // issue-bound (operand split + LDS staging ~1000 VALU cycles, 24 MFMAs 768 cycles, LDS ~300, serial within a wave; they
 // only overlap across the two waves a SIMD holds).  LDS rows are BKV + 8 bf16 (80 / 144 bytes: odd multiples of 16 bytes,
 // conflict-free ds_read_b128 fragments).
-template <int BKV, int XT, bool CONV>
+// TM = output rows per tile (dY rows staged per step): 128, or 64 / 32 for the M <= 64 / M <= 32 weight gradients of the
+// large maps (MS_ConvBlock1_x.conv2, the stage-1 pointwise convs: with a 128-row tile 1/2 or 3/4 of the MFMAs and of the dY
+// split work would process zero rows).  Wave layout 2 x 2 (64 x 64 each) for TM = 128, 1 x 4 (TM x 32 each) otherwise.
+template <int BKV, int XT, bool CONV, int TM>
 __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                             float* __restrict__ dW, int B, int M, int K, int L,
                                                             int steps_per_split, int k_tiles, Conv3 geo, int log_w) {
   constexpr int LD = BKV + 8;
   constexpr int QPR = BKV / 4;                 // float4 chunks per row
-  constexpr int NH = 128 * QPR / 256;          // chunks per thread and operand
-  __shared__ __attribute__((aligned(16))) unsigned short As[3][128][LD];
+  constexpr int NH = 128 * QPR / 256;          // X chunks per thread
+  constexpr int NHA = TM * QPR / 256;          // dY chunks per thread
+  constexpr int WMW = TM == 128 ? 2 : 1, WNW = 4 / WMW;        // waves along M / along K
+  constexpr int MI = TM / WMW / 32, NJ = 128 / WNW / 32;       // 32 x 32 MFMA tiles per wave
+  static_assert(NHA >= 1 && MI >= 1 && NJ >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][TM][LD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[XT][128][LD];      // XT = 1: X exact in bf16 (spikes); 3: general
   const int tile = blockIdx.x;
-  const int m0 = (tile / k_tiles) * 128, k0 = (tile % k_tiles) * 128;
+  const int m0 = (tile / k_tiles) * TM, k0 = (tile % k_tiles) * 128;
   const int lsteps = (L + BKV - 1) / BKV;
   const int total_steps = B * lsteps;
   const int s_begin = blockIdx.y * steps_per_split;
   const int s_end = min(total_steps, s_begin + steps_per_split);
   if (s_begin >= s_end) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 areg[NH], breg[NH];
+  f32x4 areg[NHA], breg[NH];
   int crow[NH], ctap[NH];                      // conv mode: channel and tap of the X row each chunk of this thread reads
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -485,16 +492,17 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
     ctap[h] = CONV ? k / geo.C : 0;
     crow[h] = CONV ? k - ctap[h] * geo.C : 0;
   }
-  // chunk c = tid + h*256: row = c / QPR (0..127), 16-byte column c % QPR (4 floats each)
-  auto fetch = [&](int step, f32x4 (&a)[NH], f32x4 (&bq)[NH]) {
+  // chunk c = tid + h*256: row = c / QPR, 16-byte column c % QPR (4 floats each)
+  auto fetch = [&](int step, f32x4 (&a)[NHA], f32x4 (&bq)[NH]) {
     const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int c = tid + h * 256;
       const int row = c / QPR, l = l0 + (c % QPR) * 4;
       const bool lok = l < L;                                       // L % 4 == 0: the whole float4 is valid or not
-      a[h] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
-                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (h < NHA)
+        a[h < NHA ? h : 0] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
       if (CONV) {
         // X is the activation [B][K/9][H][W]; row k0 + row of the virtual im2col matrix, pixels l .. l+3 (W a power of two)
         // (channel, ky, kx) of this thread's row were decoded once, before the step loop
@@ -513,12 +521,15 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
     for (int h = 0; h < NH; ++h) {
       const int c = tid + h * 256;
       const int row = c / QPR, col = (c % QPR) * 4;
-      unsigned int h0, m0_, l0_, h1, m1, l1;
-      split3x2(areg[h].x, areg[h].y, h0, m0_, l0_);
-      split3x2(areg[h].z, areg[h].w, h1, m1, l1);
-      *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
+      if (h < NHA) {
+        const f32x4 av = areg[h < NHA ? h : 0];
+        unsigned int h0, m0_, l0_, h1, m1, l1;
+        split3x2(av.x, av.y, h0, m0_, l0_);
+        split3x2(av.z, av.w, h1, m1, l1);
+        *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
+      }
       if (XT == 1) {
         *reinterpret_cast<u32x2*>(&Bs[0][row][col]) =
             u32x2{pack2(f32x2{breg[h].x, breg[h].y}), pack2(f32x2{breg[h].z, breg[h].w})};
@@ -536,21 +547,22 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
 #pragma unroll
     for (int ks = 0; ks < BKV / 16; ++ks) {
       const int kof = ks * 16 + 8 * (lane >> 5);
-      bf16x8 bfrag[XT][2];
+      bf16x8 bfrag[XT][NJ];
 #pragma unroll
       for (int tb = 0; tb < XT; ++tb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bfrag[tb][j] = *reinterpret_cast<const bf16x8*>(&Bs[tb][wn * 64 + j * 32 + (lane & 31)][kof]);
+        for (int j = 0; j < NJ; ++j)
+          bfrag[tb][j] = *reinterpret_cast<const bf16x8*>(&Bs[tb][wn * (NJ * 32) + j * 32 + (lane & 31)][kof]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
+        for (int i = 0; i < MI; ++i) {
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
 #pragma unroll
           for (int tb = 0; tb < XT; ++tb)
             if (t + tb < 3)              // terms hi*hi .. up to 2^-16 * 2^-8: 3 products with an exact X, 6 with a general one
 #pragma unroll
-              for (int j = 0; j < 2; ++j)
+              for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[tb][j], acc[i][j], 0, 0, 0);
         }
       }
@@ -558,13 +570,13 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = k0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+      const int col = k0 + wn * (NJ * 32) + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
       }
     }
@@ -727,8 +739,10 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess)
     return s2f_check_launch("s2f_spike_gemm_dw memset");
-  const int m_tiles = (M + 127) / 128, k_tiles = (K + 127) / 128;
   S2F_REQUIRE(x_terms == 1 || x_terms == 3, S2F_EINVAL, "s2f_spike_gemm_dw: x_terms must be 1 (X exact in bf16) or 3");
+  // rows of dY per output tile: narrow tiles for the small-M gradients (spike X only)
+  const int tm = (x_terms == 1 && M <= 32) ? 32 : (x_terms == 1 && M <= 64) ? 64 : 128;
+  const int m_tiles = (M + tm - 1) / tm, k_tiles = (K + 127) / 128;
   // short ragged rows keep the 32-wide step; so does the general-X form (six LDS operand tiles)
   // (the conv loader's extra state pushes the 64-wide variant to 257 registers = one wave per SIMD: 32-wide there; a
   // loader built from aligned loads + neighbour-lane exchange was slower still than the unaligned 16-byte loads)
@@ -738,7 +752,8 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
   //   a workgroup spends ~2.3 us per 64-wide (1.2 us per 32-wide) contraction step, 512 workgroups run at a time;
   //   every split adds its M x K partial tile into dW with fp32 atomics at ~1.7 TB/s (0.6 us per MB).
   const int tiles = m_tiles * k_tiles;
-  const double t_step = (bkv == 64 ? 2.3 : 1.2) * (x_terms == 3 ? 1.8 : 1.0), t_mb = 0.6 * (double)M * K * 4.0 / 1e6;
+  const double t_step = (bkv == 64 ? 2.3 : 1.2) * (x_terms == 3 ? 1.8 : 1.0) * (tm == 32 ? 0.6 : tm == 64 ? 0.75 : 1.0),
+               t_mb = 0.6 * (double)M * K * 4.0 / 1e6;
   int splits = 1;
   double best = 1e30;
   for (int cand = 1; cand <= total_steps && cand <= 65535; cand *= 2) {
@@ -754,21 +769,31 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
   if (splits > 65535) splits = 65535;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
+#define S2F_DW_GO1(BKV, XTV, CV, TMV)                                                                                   \
+  S2F_LAUNCH(true, true, (spike_gemm_dw_kernel<BKV, XTV, CV, TMV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, \
+             dW, batch, M, K, L, steps_per_split, k_tiles, geo, log_w)
 #define S2F_DW_GO(BKV, XTV, CV)                                                                                         \
-  S2F_LAUNCH(true, true, (spike_gemm_dw_kernel<BKV, XTV, CV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW,  \
-             batch, M, K, L, steps_per_split, k_tiles, geo, log_w)
+  do {                                                                                                                  \
+    if (tm == 32)                                                                                                       \
+      S2F_DW_GO1(BKV, XTV, CV, 32);                                                                                     \
+    else if (tm == 64)                                                                                                  \
+      S2F_DW_GO1(BKV, XTV, CV, 64);                                                                                     \
+    else                                                                                                                \
+      S2F_DW_GO1(BKV, XTV, CV, 128);                                                                                    \
+  } while (0)
   if (conv) {
     if (bkv == 64)
       S2F_DW_GO(64, 1, true);
     else
       S2F_DW_GO(32, 1, true);
   } else if (x_terms == 3) {
-    S2F_DW_GO(32, 3, false);
+    S2F_DW_GO1(32, 3, false, 128);
   } else if (bkv == 64) {
     S2F_DW_GO(64, 1, false);
   } else {
     S2F_DW_GO(32, 1, false);
   }
+#undef S2F_DW_GO1
 #undef S2F_DW_GO
   return s2f_check_launch("s2f_spike_gemm_dw");
 }

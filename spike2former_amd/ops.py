@@ -772,7 +772,7 @@ class _SpikeGemm(torch.autograd.Function):
             else:
                 gx = torch.bmm(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
         if ctx.needs_input_grad[1]:
-            if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 64:     # 128-row tiles: M <= 32 wastes 3/4 of the MFMAs
+            if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 16:     # 32- / 64- / 128-row tiles by M
                 M, K = w2d.shape
                 sink = _sink_for(w2d)
                 gw = torch.empty(M, K, dtype=torch.float32, device=x.device) if sink is None else None
@@ -1002,7 +1002,7 @@ class _ConvDense(torch.autograd.Function):
                     gw = None
                 else:
                     gw = gt.permute(0, 3, 1, 2).contiguous()
-            elif use_mfma and SPIKE_GEMM_DW and M >= 64:
+            elif use_mfma and SPIKE_GEMM_DW and M >= 16:
                 sink = _sink_for(weight)
                 gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
                 _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K * 3)

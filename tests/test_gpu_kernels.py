@@ -544,7 +544,9 @@ def test_upsample2x_matches_interpolate(ops, N, C, h, w):
 
 
 @pytest.mark.parametrize("B,M,K,L", [(2, 256, 256, 1024), (1, 32, 288, 4096), (3, 360, 360, 100), (2, 151, 100, 36),
-                                     (8, 128, 64, 4096), (1, 576, 256, 1024)])
+                                     (8, 128, 64, 4096), (1, 576, 256, 1024),
+                                     # narrow output tiles: 32 rows (M <= 32), 64 rows (M <= 64), ragged M / K / L
+                                     (2, 64, 96, 512), (2, 20, 64, 256), (3, 33, 130, 100), (2, 32, 1152, 4096)])
 def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
     """dW = sum_b dY[b] X[b]^T on the bf16 matrix cores (dY split hi+mid+lo, X spikes): error vs fp64 <= 3e-6 of
     sum|dY||X| -- fp32-GEMM class (split-K partials are combined with fp32 atomics)."""

@@ -11,7 +11,7 @@ shapes = [("CB1_1.conv1 im2col", 128, 288, 65536), ("CB1_1.conv2 im2col", 32, 11
           ("CB1_2.conv1", 256, 576, 16384), ("CB1_2.conv2", 64, 2304, 16384), ("CB2.conv1", 512, 1152, 4096), ("CB2.conv2", 128, 4608, 4096),
           ("block3 1x1", 256, 256, 1024), ("block3 mlp1", 1024, 256, 1024), ("block3 mlp2", 256, 1024, 1024), ("block4 1x1", 360, 360, 1024),
           ("mask_feature", 256, 256, 65536), ("lateral0", 256, 32, 65536), ("CA kv 16384", 256, 256, 16384), ("CA kv 4096", 256, 256, 4096),
-          ("dec ffn1 L=100", 2048, 256, 100), ("pd pw1", 512, 256, 1024), ("pd offset", 576, 256, 1024)]
+          ("qkv batched conv1", 768, 256, 1024), ("qkv batched block4", 1080, 360, 1024), ("dec ffn1 L=100", 2048, 256, 100), ("pd pw1", 512, 256, 1024), ("pd offset", 576, 256, 1024)]
 N = 8
 s = torch.cuda.current_stream().cuda_stream
 print(f"{'shape':22s} {'rocBLAS us':>10} {'TF':>6} | {'mfma us':>8} {'TF':>6} | speedup")
