@@ -30,9 +30,8 @@ def _gemm_nc(weight2d, x3, bias, spike_input=False):
     """x3 [N, K, L], weight2d [M, K] -> [N, M, L]."""
     if spike_input and ops.SPIKE_GEMM_ENABLED and x3.shape[2] % 4 == 0:
         return ops.spike_gemm(x3, weight2d, bias)       # bf16 matrix cores, exact for spike activations
-    # bmm with the weight broadcast through a zero batch stride: rocBLAS strided-batched GEMM, no operand copies
-    # (torch.matmul would fold the batch into the rows of a transposed -- i.e. copied -- activation matrix)
-    y = torch.bmm(weight2d.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+    # library GEMM with the weight broadcast through a zero batch stride (no operand copies), rocBLAS or hipBLASLt
+    y = ops.dense_gemm(x3, weight2d)
     if bias is not None:
         y = y + bias.view(1, -1, 1)
     return y

@@ -231,6 +231,94 @@ def mask_words(n):
     return ((n + 255) >> 8) * 4
 
 
+# ------------------------------------------------------------------------------------------------ library GEMMs
+# The fp32 GEMMs of two general operands (dX of the 1x1 / k x k convolutions, non-spike 1x1 convolutions) are plain library
+# calls.  PyTorch-ROCm can route torch.bmm through rocBLAS or hipBLASLt; neither wins everywhere on gfx950 (tools/probe_blas.py,
+# us: [256x1024]@[8x1024x1024] 56 vs 41, [256x512]@[8x512x1024] 35 vs 23, [256x2048]@[8x2048x100] 32 vs 20, but
+# [256x256]@[8x256x1024] 12.6 vs 19.8, [360x360]@[8x360x1024] 23 vs 30), so the first call of every distinct (shape, stride)
+# times both and the faster one is used from then on.  Never tunes inside a graph capture (the warm-up steps have seen
+# every shape by then).
+BLAS_AUTOTUNE = True
+_BLAS_CHOICE = {}
+
+
+def _time_bmm(a, b, backend, reps=5):
+    torch.backends.cuda.preferred_blas_library(backend)
+    for _ in range(2):
+        torch.bmm(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.bmm(a, b)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def bmm_tuned(a, b):
+    if not BLAS_AUTOTUNE or not a.is_cuda:
+        return torch.bmm(a, b)
+    key = (tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()))
+    choice = _BLAS_CHOICE.get(key)
+    prev = torch.backends.cuda.preferred_blas_library()
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.bmm(a, b)
+        try:
+            with torch.no_grad():
+                t = {lib_: _time_bmm(a.detach(), b.detach(), lib_) for lib_ in ("cublas", "cublaslt")}
+            choice = min(t, key=t.get)
+        except RuntimeError:                      # a backend that cannot run this problem: stay with the default
+            choice = "default"
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev)
+        _BLAS_CHOICE[key] = choice
+    if choice == "default":
+        return torch.bmm(a, b)
+    torch.backends.cuda.preferred_blas_library(choice)
+    try:
+        return torch.bmm(a, b)
+    finally:
+        torch.backends.cuda.preferred_blas_library(prev)
+
+
+class _DenseGemm(torch.autograd.Function):
+    """Y[b] = W @ X[b] for a general fp32 X (the 1x1 convolutions that do not read spikes: SepConv.pwconv2, RepConv's second
+    1x1, sdtv2.py:124-125, 164) with `groups` independent weights applied to consecutive channel groups: W [G, M, K],
+    X [B, G*K, L] -> [B, G*M, L].  Library GEMMs, each through the faster of rocBLAS / hipBLASLt (bmm_tuned)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_cuda(x, w)
+        G, M, K = w.shape
+        B, _, L = x.shape
+        x = x.contiguous()
+        wb = w.unsqueeze(0).expand(B, G, M, K).reshape(B * G, M, K) if G > 1 else w.expand(B, M, K)
+        y = bmm_tuned(wb, x.view(B * G, K, L))
+        ctx.save_for_backward(x, w)
+        return y.view(B, G * M, L)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        G, M, K = w.shape
+        B, _, L = x.shape
+        gy = gy.contiguous().view(B * G, M, L)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = w.transpose(1, 2)
+            wb = wt.unsqueeze(0).expand(B, G, K, M).reshape(B * G, K, M) if G > 1 else wt.expand(B, K, M)
+            gx = bmm_tuned(wb, gy).view(B, G * K, L)
+        if ctx.needs_input_grad[1]:
+            gw = bmm_tuned(gy, x.view(B * G, K, L).transpose(1, 2)).view(B, G, M, K).sum(0)
+        return gx, gw
+
+
+def dense_gemm(x, w):
+    """x [B, G*K, L], w [G, M, K] (or [M, K]) -> [B, G*M, L]"""
+    return _DenseGemm.apply(x, w if w.dim() == 3 else w.unsqueeze(0))
+
+
 # ------------------------------------------------------------------------------------------------ parameter groups
 def adjacent(ts):
     """True when the tensors lie back to back in ONE storage (same dtype / device, contiguous): their concatenation along
@@ -770,7 +858,7 @@ class _SpikeGemm(torch.autograd.Function):
                 # the same product through einsum's folding takes 12 us
                 gx = torch.einsum("mk,bml->bkl", w2d, gy)
             else:
-                gx = torch.bmm(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
+                gx = bmm_tuned(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
         if ctx.needs_input_grad[1]:
             if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 16:     # 32- / 64- / 128-row tiles by M
                 M, K = w2d.shape
@@ -959,7 +1047,7 @@ class _ConvDense(torch.autograd.Function):
             check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, Ho * Wo, cols.shape[1],
                                          ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
         else:
-            y = torch.bmm(w2d.unsqueeze(0).expand(N, -1, -1), cols)
+            y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
             if bias is not None:
                 y = y + bias.view(1, -1, 1)
         ctx.save_for_backward(cols, weight)
@@ -984,9 +1072,9 @@ class _ConvDense(torch.autograd.Function):
             elif M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
                 wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
                 gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)
-                gx = torch.bmm(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
+                gx = bmm_tuned(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
             else:
-                dcols = torch.bmm(w2d.t().unsqueeze(0).expand(N, -1, -1), gy)
+                dcols = bmm_tuned(w2d.t().unsqueeze(0).expand(N, -1, -1), gy)
                 gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
         if ctx.needs_input_grad[1]:
             K = w2d.shape[1]
