@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 11
+#define S2F_ABI_VERSION 12
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -202,6 +202,17 @@ int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int
  * (mmdet/models/layers/pixel_decoder.py:456-460).  w must be even (16-byte output stores). */
 int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream);
 int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream);
+
+/* ---- mask losses of the Hungarian-matched loss on the 2x up-sampled logits -------------------
+ * For matched prediction p: u = bilinear2x(pred[p]) (F.interpolate align_corners=False, dense_heads/maskformer_head.py:475-479),
+ * s = sigmoid(u), t = tgt[gt_index[p]] (uint8 0/1, [2h, 2w]):  sums[p] = { sum s t, sum s, sum t, sum focal(u, t) } with the
+ * sigmoid focal loss of losses/focal_loss.py:36-44; the naive dice loss (losses/dice_loss.py:45-50) follows from the first
+ * three.  Nothing of size [P, 2h, 2w] is materialised forward; backward writes d(sum_k g_sums[p][k] sums[p][k])/du, to be
+ * pulled back to the low-resolution logits by s2f_upsample2x_bwd.  w even; targets 4-byte aligned rows (2w % 4 == 0). */
+int s2f_mask_loss_fwd(const float* pred, const uint8_t* tgt, const int64_t* gt_index, float* sums, int64_t P, int h, int w,
+                      float alpha, float gamma, void* stream);
+int s2f_mask_loss_bwd(const float* pred, const uint8_t* tgt, const int64_t* gt_index, const float* g_sums, float* gup, int64_t P,
+                      int h, int w, float alpha, float gamma, void* stream);
 
 /* ---- a5 / a10: spike-driven (softmax-free) attention core --------------------------------------------
  * Replaces  kv = k^T @ v ; o = (q @ kv) * scale ; o.transpose(3,4).reshape(T,B,C,N)

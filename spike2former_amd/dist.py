@@ -96,6 +96,18 @@ class FlatGradAllReduce:
         pieces = [(p.grad if p.grad is not None else self._zero[:p.numel()]).reshape(-1) for p in dense]
         torch.cat(pieces, out=self.flat[:self._dense_elems])
 
+    def pack(self, grads):
+        """Like gather(), from an explicit gradient list aligned with `self.params` (torch.autograd.grad output; None =
+        no tensor: sunk or unused)."""
+        saved = [p.grad for p in self.params]
+        try:
+            for p, g in zip(self.params, grads):
+                p.grad = g
+            self.gather()
+        finally:
+            for p, g in zip(self.params, saved):
+                p.grad = g
+
     def compact(self):
         """After one step with sinks: move the parameters whose gradient arrived through a sink (p.grad is None) behind the
         others in the flat layout, so that packing stays ONE batched copy over the leading region."""

@@ -54,3 +54,62 @@ class GraphedStep:
             self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_loss
+
+
+class GraphedSplitStep:
+    """The training step with a loss that needs the host in the middle (the Hungarian assignment):
+    TWO hipGraphs around an eager loss --
+        graph A : membrane reset + gradient-buffer clear + model forward           (autograd recorded once, at capture)
+        eager   : loss(outputs.detach()) and its backward -> d loss / d outputs
+        graph B : backward of graph A's recorded autograd graph from those gradients + packing into the flat buffer
+    The same construction as torch.cuda.make_graphed_callables, but the parameter gradients never leave the graph as
+    per-parameter tensors (that path clones 1 200 gradients per step: 79 ms/step, no better than eager launches).
+    No autograd graph of an earlier eager step may be alive when this is built (drop the old outputs / losses first): its
+    gradient accumulators belong to the default stream, the capture would have to wait on it, and ROCm 7.2 crashes in
+    hipStreamEndCapture instead of reporting the illegal dependency."""
+
+    def __init__(self, model, example_input, grad_buffer, warmup=3):
+        self.model, self.red = model, grad_buffer
+        self.static_in = example_input.clone()
+        params = [p for p in grad_buffer.params]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                outs = self._forward()
+                torch.autograd.grad(outs, params, [torch.ones_like(o) for o in outs], allow_unused=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(self.graph_a, pool=pool, capture_error_mode=mode):
+            self.outs = self._forward()
+        self.grad_outs = [torch.zeros_like(o) for o in self.outs]
+        with torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode=mode):
+            grads = torch.autograd.grad(self.outs, params, self.grad_outs, allow_unused=True)
+            ops.wgrad_join()
+            self.red.pack(grads)
+        torch.cuda.synchronize()
+
+    def _forward(self):
+        reset_net(self.model)
+        self.red.zero()
+        return tuple(self.model(self.static_in))
+
+    def forward(self, x=None):
+        """-> the model outputs (static tensors, valid until the next forward), detached leaves that require grad."""
+        if x is not None:
+            self.static_in.copy_(x, non_blocking=True)
+        self.graph_a.replay()
+        return [o.detach().requires_grad_(True) for o in self.outs]
+
+    def backward(self, leaves):
+        """`leaves`: what forward() returned, after loss.backward() has filled their .grad."""
+        for buf, leaf in zip(self.grad_outs, leaves):
+            if leaf.grad is None:
+                buf.zero_()
+            else:
+                buf.copy_(leaf.grad)
+        self.graph_b.replay()

@@ -152,6 +152,23 @@ class MaskFormerLoss:
             num_masks = reduce_fn(num_masks)
         num_masks = num_masks.clamp(min=1.0)                                                # maskformer_head.py:459-460
         gt_all = torch.cat([m for _, m in batch_gt]) if gt_offsets[-1] > 0 else None       # [sum n, H, W]
+        h, w = all_mask_preds.shape[-2:]
+        # On the GPU, with targets at exactly twice the prediction's resolution (every Spike2Former config: masks at H/2),
+        # the up-sampling, the sigmoid and both mask losses of ALL layers run as one fused kernel forward and one backward
+        # (ops.mask_loss_sums): the reference's ~15 element-wise passes per layer over [num_masks, H, W] are 16.7 + 15.4 ms of
+        # a C2 step.  Everything else (CPU, other ratios) takes the same formulas through torch ops.
+        fused = (gt_all is not None and all_mask_preds.is_cuda and gt_all.shape[-2:] == (2 * h, 2 * w) and (2 * w) % 4 == 0
+                 and sum(len(p) for p in pred_idx) > 0)
+        sums = starts = None
+        if fused:
+            from . import ops
+            counts = [len(p) for p in pred_idx]
+            starts = np.cumsum([0] + counts)
+            pall = np.concatenate([l * B * Q + pred_idx[l] for l in range(L)])
+            pred_sel = all_mask_preds.flatten(0, 2)[torch.from_numpy(pall).to(dev)].float()
+            tgt_u8 = (gt_all if gt_all.dtype == torch.bool else gt_all != 0).contiguous().view(torch.uint8)
+            sums = ops.mask_loss_sums(pred_sel, tgt_u8, torch.from_numpy(np.concatenate(gt_idx)).to(dev), self.mask.alpha,
+                                      self.mask.gamma)
         losses = {}
         for l in range(L):
             name = "" if l == L - 1 else f"d{l}."
@@ -163,11 +180,17 @@ class MaskFormerLoss:
                 zero = all_mask_preds[l].flatten(0, 1)[:0].sum()
                 losses[name + "loss_mask"] = losses[name + "loss_dice"] = zero
                 continue
+            H, W = gt_all.shape[-2:]
+            if fused:
+                a, bsum, csum, fsum = sums[int(starts[l]):int(starts[l + 1])].unbind(1)
+                d = (2 * a + self.dice.eps) / (bsum + csum + self.dice.eps)                 # dice_loss.py:45-55, naive form
+                losses[name + "loss_dice"] = self.dice.loss_weight * (1 - d).sum() / (num_masks[l] + _EPS32)
+                losses[name + "loss_mask"] = self.mask.loss_weight * fsum.sum() / (num_masks[l] * (H * W) + _EPS32)
+                continue
             pidx = torch.from_numpy(pred_idx[l]).to(dev)
             tgt = gt_all[torch.from_numpy(gt_idx[l]).to(dev)].float()                       # [n_pos, H, W]
             pred = all_mask_preds[l].flatten(0, 1)[pidx].float()
             pred = F.interpolate(pred.unsqueeze(1), tgt.shape[-2:], mode="bilinear", align_corners=False).squeeze(1)
-            H, W = tgt.shape[-2:]
             s = pred.sigmoid()
             # dice (dice_loss.py:45-55, naive form)
             a = (s * tgt).flatten(1).sum(1)

@@ -998,6 +998,43 @@ def upsample_bilinear(x, size):
     return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
 
 
+# ------------------------------------------------------------------------------------------------ mask losses (row f1)
+class _MaskLossSums(torch.autograd.Function):
+    """sums[p] = {sum s t, sum s, sum t, sum focal} over the 2x up-sampled logits of matched prediction p against its binary
+    target (s2f.h s2f_mask_loss_fwd/bwd); nothing of size [P, 2h, 2w] exists forward, one such buffer backward."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt, gt_index, alpha, gamma):
+        _need_cuda(pred)
+        pred = pred.contiguous()
+        tgt = tgt.contiguous()
+        P, h, w = pred.shape
+        assert tgt.dtype == torch.uint8 and tgt.shape[1:] == (2 * h, 2 * w) and gt_index.dtype == torch.int64
+        sums = torch.empty(P, 4, dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_fwd(_ptr(pred), _ptr(tgt), _ptr(gt_index), _ptr(sums), P, h, w, alpha, gamma, _stream()),
+              "s2f_mask_loss_fwd")
+        ctx.save_for_backward(pred, tgt, gt_index)
+        ctx.cfg = (alpha, gamma)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt, gt_index = ctx.saved_tensors
+        P, h, w = pred.shape
+        g = g.contiguous()
+        gup = torch.empty(P, 2 * h, 2 * w, dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_bwd(_ptr(pred), _ptr(tgt), _ptr(gt_index), _ptr(g), _ptr(gup), P, h, w, *ctx.cfg, _stream()),
+              "s2f_mask_loss_bwd")
+        gp = torch.empty_like(pred)
+        check(lib.s2f_upsample2x_bwd(_ptr(gup), _ptr(gp), P, h, w, _stream()), "s2f_upsample2x_bwd")
+        return gp, None, None, None, None
+
+
+def mask_loss_sums(pred, tgt_u8, gt_index, alpha, gamma):
+    """pred [P, h, w] fp32 logits, tgt_u8 [G, 2h, 2w] uint8 0/1, gt_index [P] int64 -> [P, 4]"""
+    return _MaskLossSums.apply(pred, tgt_u8, gt_index, float(alpha), float(gamma))
+
+
 # ------------------------------------------------------------------------------------------------ dense k x k convolution
 class _ConvDense(torch.autograd.Function):
     """Dense k x k Conv2d lowered to GEMMs (MIOpen is not usable on this image, see conv.py).

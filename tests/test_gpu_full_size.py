@@ -300,3 +300,46 @@ def test_tiny_graph_replay_is_bitwise_the_eager_step():
     g1 = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
     assert l0 == l1
     assert (g0 - g1).abs().max().item() <= 1e-4 * g0.abs().max().item()       # LDS/atomic accumulation order in dW
+
+
+def test_tiny_split_graph_step_with_the_hungarian_loss_is_the_eager_step():
+    """graph.GraphedSplitStep (forward graph | eager Hungarian-matched loss | backward graph) against the eager
+    `mode="loss"` step on the tiny config: same loss values bit for bit, same gradients (flat buffer) to the run-to-run
+    noise of the split-K atomics."""
+    import spike2former_amd as s2f
+    from spike2former_amd.dist import FlatGradAllReduce
+    from spike2former_amd.graph import GraphedSplitStep
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C1_64"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1_64"))).cuda().train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(2, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(5)).cuda()
+    seg = torch.randint(0, w["K"], (2, 1, w["H"], w["W"]), generator=torch.Generator().manual_seed(6)).cuda()
+    gts = [s2f.seg_to_instances(seg[i]) for i in range(2)]
+    red = FlatGradAllReduce(model.parameters(), 1)
+
+    model.load_state_dict(sd); s2f.reset_net(model); red.zero()
+    losses = model(img, [seg[i] for i in range(2)], mode="loss")
+    sum(losses.values()).backward()
+    red.gather()
+    want_loss = {k: float(v) for k, v in losses.items()}
+    want = red.flat.clone()
+    del losses                                            # no autograd graph of the eager step may outlive this point
+    for p in model.parameters():
+        p.grad = None
+    import gc
+    gc.collect()
+
+    model.load_state_dict(sd)
+    step = GraphedSplitStep(model, img, red, warmup=1)
+    for _ in range(2):                                    # replayed twice: the second replay must not depend on the first
+        model.load_state_dict(sd)
+        leaves = step.forward()
+        got = model.decode_head.loss_by_feat(leaves[0], leaves[1], gts)
+        sum(got.values()).backward()
+        step.backward(leaves)
+        torch.cuda.synchronize()
+        assert {k: float(v) for k, v in got.items()} == want_loss
+        scale = want.abs().max().item()
+        assert (red.flat - want).abs().max().item() <= 1e-4 * scale
