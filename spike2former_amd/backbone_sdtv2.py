@@ -245,6 +245,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         bn1, bn2, bn3 = (CatBN(m) for m in t["bns"])
         w1 = ops.cat_params(t["w1"]).view(3 * C, C)
         w1._s2f_version = sum(p._version for p in t["w1"])              # for the cached bf16 split (ops.split_weight)
+        w1._s2f_owner = t["w1"][0]
         z = ops.spike_gemm(s.view(T * B, C, N), w1).view(T * B, 3 * C, H, W)          # the three first 1x1 convs: one GEMM
         z, _, border = bn_act(z, None, bn1, want_border=True)
         z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, border)

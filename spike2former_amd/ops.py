@@ -776,6 +776,31 @@ SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
 
 
+def _owner(t):
+    """The long-lived tensor object a cached split belongs to: the parameter a view was taken from (or the first twin of a
+    zero-copy concatenation).  The cache keeps a weak reference to it -- an address is not an identity: once a model is
+    freed, another model's weight of the same shape lands on the same address with the same version counter."""
+    o = getattr(t, "_s2f_owner", None)
+    if o is not None:
+        return o
+    return t._base if t._base is not None else t
+
+
+def _cache_get(key, version, shape, owner):
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0] == version and hit[2] == shape and hit[3]() is owner:
+        return hit[1]
+    return None
+
+
+def _cache_put(key, version, out, shape, owner):
+    import weakref
+    if len(_SPLIT_CACHE) > 4096:                       # dead entries of freed models
+        for k in [k for k, v in _SPLIT_CACHE.items() if v[3]() is None]:
+            del _SPLIT_CACHE[k]
+    _SPLIT_CACHE[key] = (version, out, shape, weakref.ref(owner))
+
+
 def split_weight(w2d):
     """fp32 [M, K] -> cached bf16 [3, Mpad, Kpad] (hi, mid, lo).  Re-split when the parameter is modified in place
     (optimiser step, load_state_dict) -- tracked through the tensor version counter."""
@@ -784,13 +809,14 @@ def split_weight(w2d):
     # a zero-copy concatenation of sibling parameters (cat_params) is a fresh tensor every call: it carries the sum of the
     # parameters' version counters instead of its own
     version = getattr(w2d, "_s2f_version", w2d._version)
-    hit = _SPLIT_CACHE.get(key)
-    if hit is not None and hit[0] == version and hit[1].shape[1] >= M and hit[2] == (M, K):
-        return hit[1]
+    owner = _owner(w2d)
+    hit = _cache_get(key, version, (M, K), owner)
+    if hit is not None:
+        return hit
     Mpad, Kpad = (M + 63) // 64 * 64, (K + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=w2d.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d.detach().contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _SPLIT_CACHE[key] = (version, out, (M, K))
+    _cache_put(key, version, out, (M, K), owner)
     return out
 
 
@@ -798,14 +824,14 @@ def split_weight_conv3(weight):
     """[M, C, 3, 3] -> cached bf16 split of the TAP-MAJOR matrix [M, (ky, kx, c)] that the implicit 3x3 kernels contract over."""
     key = ("tap", weight.data_ptr())
     M, C = weight.shape[:2]
-    hit = _SPLIT_CACHE.get(key)
-    if hit is not None and hit[0] == weight._version and hit[2] == (M, C):
-        return hit[1]
+    hit = _cache_get(key, weight._version, (M, C), _owner(weight))
+    if hit is not None:
+        return hit
     w2d = weight.detach().permute(0, 2, 3, 1).reshape(M, 9 * C)
     Mpad, Kpad = (M + 63) // 64 * 64, (9 * C + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), M, 9 * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _SPLIT_CACHE[key] = (weight._version, out, (M, C))
+    _cache_put(key, weight._version, out, (M, C), _owner(weight))
     return out
 
 
@@ -814,14 +840,14 @@ def split_weight_tconv3(weight):
     (Wt[c][(ky, kx), m] = weight[m][c][2 - ky][2 - kx]), rows padded to a multiple of 128 for s2f_conv3x3_general."""
     key = ("tconv", weight.data_ptr())
     M, C = weight.shape[:2]
-    hit = _SPLIT_CACHE.get(key)
-    if hit is not None and hit[0] == weight._version and hit[2] == (M, C):
-        return hit[1]
+    hit = _cache_get(key, weight._version, (M, C), _owner(weight))
+    if hit is not None:
+        return hit
     w2d = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * M)
     Mpad, Kpad = (C + 127) // 128 * 128, (9 * M + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), C, 9 * M, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _SPLIT_CACHE[key] = (weight._version, out, (M, C))
+    _cache_put(key, weight._version, out, (M, C), _owner(weight))
     return out
 
 

@@ -521,6 +521,13 @@ def test_spike_gemm_terms_and_resplit(ops):
     assert errs[0] > 100 * errs[1] and errs[1] > 3 * errs[2] and errs[2] < 3e-5     # 8 / 16 / 24 mantissa bits (x3 sits on the fp32 accumulation floor)
     w.mul_(2.0)                                                                           # in-place update -> re-split
     assert (ops.spike_gemm(x, w).double() - 2 * ref).abs().max().item() < 6e-5
+    # a freed weight's address is handed to the next allocation of the same size: the cached split must not outlive its owner
+    addr = w.data_ptr()
+    del w
+    w2 = torch.randn(128, 256, generator=g).cuda()
+    w2.mul_(1.0)                                          # same version counter as the freed weight had
+    assert w2.data_ptr() == addr and w2._version == 1, "allocator did not recycle the block (test premise)"
+    assert (ops.spike_gemm(x, w2).double() - torch.matmul(w2.double(), x.double())).abs().max().item() < 6e-5
 
 
 # ----------------------------------------------------------------------------------------------- 2x bilinear up-sampling
