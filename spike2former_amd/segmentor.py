@@ -16,6 +16,7 @@ class EncoderDecoder(nn.Module):
         super().__init__()
         if neck is not None or auxiliary_head is not None:
             raise NotImplementedError("neck / auxiliary_head are not used by the Spike2Former configs")
+        self.data_preprocessor = MODELS.build(data_preprocessor) if isinstance(data_preprocessor, dict) else data_preprocessor
         self.backbone = MODELS.build(backbone)
         self.decode_head = MODELS.build(decode_head)
         self.align_corners = self.decode_head.align_corners
