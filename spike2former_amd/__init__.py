@@ -5,6 +5,7 @@ loudly when it is missing.  The modules register under the reference's MODELS ty
 from . import _lib  # noqa: F401  (raises ImportError when the HIP library is not built)
 from . import ops  # noqa: F401
 from .backbone_sdtv2 import Spiking_vit_MetaFormer  # noqa: F401
+from .backbone_sdtv3 import Multispike_norm, Spiking_vit_MetaFormerv2  # noqa: F401
 from .configs import WORKLOADS, model_cfg  # noqa: F401
 from .data_preprocessor import SegDataPreProcessor, SegDataSample  # noqa: F401
 from .firing import FiringRecorder  # noqa: F401

@@ -8,6 +8,12 @@ WORKLOADS = {
     "C1_64": dict(H=64, W=64, T=2, B=2, K=20, embed_dim=[16, 32, 64, 72], Fc=64, Q=10, pd=(2, 256), dec=(2, 512), G=8, nf=32),
     "C2": dict(H=512, W=512, T=4, B=2, K=150, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 1024), dec=(6, 2048), G=32, nf=128),
     "C3": dict(H=512, W=1024, T=4, B=2, K=19, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 2048), dec=(6, 2048), G=32, nf=128),
+    # BASELINE configs[4]: COCO-panoptic-shaped, E-SpikeFormer (SDT-v3) backbone; 800x1333 padded to a multiple of 32;
+    # 80 things + 53 stuff classes (the head's defaults); no such config ships with the reference: synthesised
+    "C5": dict(H=800, W=1344, T=4, B=1, K=133, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 1024), dec=(6, 2048), G=32, nf=128,
+               backbone="Spiking_vit_MetaFormerv2", things=80, stuff=53),
+    "C5_tiny": dict(H=64, W=96, T=2, B=1, K=12, embed_dim=[16, 32, 64, 72], Fc=64, Q=10, pd=(2, 256), dec=(2, 512), G=8, nf=32,
+                    backbone="Spiking_vit_MetaFormerv2", things=7, stuff=5),
     "C4": dict(H=512, W=512, T=8, B=2, K=150, embed_dim=[64, 128, 256, 360], Fc=256, Q=100, pd=(6, 1024), dec=(6, 2048), G=32, nf=128),
 }
 
@@ -18,12 +24,14 @@ def model_cfg(name):
     norm_cfg = dict(type="SyncBN", requires_grad=True)       # accepted and ignored, as in the reference
     return ConfigDict(
         type="EncoderDecoder",
-        backbone=dict(type="Spiking_vit_MetaFormer", img_size_h=w["H"], img_size_w=w["W"], patch_size=16, embed_dim=e,
-                      num_heads=8, mlp_ratios=4, in_channels=3, num_classes=w["K"], qkv_bias=False, depths=8,
-                      sr_ratios=1, T=w["T"], norm_eval=True, norm_cfg=norm_cfg, decode_mode="Qsnn"),
+        backbone=dict(type=w.get("backbone", "Spiking_vit_MetaFormer"), img_size_h=w["H"], img_size_w=w["W"], patch_size=16,
+                      embed_dim=e, num_heads=8, mlp_ratios=4, in_channels=3, num_classes=w["K"], qkv_bias=False, depths=8,
+                      sr_ratios=1, T=w["T"], norm_eval=True, norm_cfg=norm_cfg,
+                      decode_mode="QTrick" if w.get("backbone") == "Spiking_vit_MetaFormerv2" else "Qsnn"),
         decode_head=dict(
             type="MaskFormerHead", in_channels=[e[0] // 2, e[0], e[1], e[3]], feat_channels=Fc, in_index=[0, 1, 2, 3],
             num_classes=w["K"], out_channels=Fc, num_queries=w["Q"], T=w["T"],
+            num_things_classes=w.get("things", w["K"]), num_stuff_classes=w.get("stuff", 0),
             pixel_decoder=dict(
                 type="mmdet.DCNTransformerEncoderPixelDecoder", norm_cfg=norm_cfg, T=w["T"],
                 encoder=dict(num_layers=w["pd"][0], layer_cfg=dict(

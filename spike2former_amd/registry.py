@@ -79,7 +79,8 @@ HOOKS = Registry("spike2former_amd.HOOKS")
 def register_upstream():
     """Best effort: also register into mmseg / mmdet registries when those packages exist."""
     done = []
-    for pkg, names in (("mmseg.registry", ("Spiking_vit_MetaFormer", "MaskFormerHead", "EncoderDecoder")),
+    for pkg, names in (("mmseg.registry", ("Spiking_vit_MetaFormer", "Spiking_vit_MetaFormerv2", "MaskFormerHead", "EncoderDecoder",
+                                          "SegDataPreProcessor")),
                        ("mmdet.registry", ("DCNTransformerEncoderPixelDecoder",))):
         try:
             mod = __import__(pkg, fromlist=["MODELS"])

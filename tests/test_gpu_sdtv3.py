@@ -1,0 +1,85 @@
+"""E-SpikeFormer backbone on the GPU against vectors produced by the reference's own sdtv3.py
+(oracle/gen_golden_sdtv3.py -> tests/golden/sdtv3_tiny.npz).  Tolerances as for the SDT-v2 path (tests/test_gpu_model.py):
+fp32 round-off before a neuron may flip a borderline spike by one level, so feature maps are compared at 2e-2 of their
+maximum and gradients at 5e-2 of the gradient scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(img_size_h=64, img_size_w=64, patch_size=16, in_channels=3, num_classes=20, embed_dim=[16, 32, 64, 72], num_heads=8,
+          mlp_ratios=4, qkv_bias=False, depths=8, sr_ratios=1, T=2, decode_mode="QTrick")
+
+
+def test_stateless_four_level_neuron():
+    import spike2former_amd as s2f
+    n = s2f.Multispike_norm().cuda()
+    x = torch.linspace(-1, 6, 4001, device="cuda", requires_grad=True)
+    y = n(x)
+    assert torch.equal(y, torch.round(torch.clamp(x.detach(), 0, 4)) / 4)
+    y.sum().backward()
+    assert torch.equal(x.grad, ((x.detach() >= 0) & (x.detach() <= 4)).float() / 4)
+    assert isinstance(n.v, float) and torch.equal(n(x.detach()), y.detach())          # no state between calls
+
+
+def test_sdtv3_backbone_vs_reference_vectors(golden):
+    import spike2former_amd as s2f
+    from spike2former_amd.init_utils import seeded_init
+    g = golden("sdtv3_tiny.npz")
+    model = seeded_init(s2f.MODELS.build(dict(type="Spiking_vit_MetaFormerv2", **KW))).cuda().train()
+    outs = model(torch.from_numpy(g["img"]).cuda())
+    sum((o * o).mean() for o in outs).backward()            # a plain mean of BatchNorm outputs has no gradient
+    assert [tuple(o.shape) for o in outs] == [tuple(g[f"x{i + 1}"].shape) for i in range(4)]
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(g[f"x{i + 1}"])
+        assert (o.detach().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), i
+        assert all(torch.equal(o[0], o[t]) for t in range(1, o.shape[0]))              # reset step: T identical slices
+    params = dict(model.named_parameters())
+    keys = [k[6:] for k in g.files if k.startswith("grad__")]
+    gscale = max(np.abs(g["grad__" + k]).max() for k in keys)
+    for k in keys:
+        ref = torch.from_numpy(g["grad__" + k])
+        assert (params[k].grad.cpu() - ref).abs().max().item() <= 5e-2 * (ref.abs().max().item() + 1e-3 * gscale), k
+    rm = dict(model.named_buffers())["block3.0.attn.q_conv.1.running_mean"].cpu()
+    assert torch.allclose(rm, torch.from_numpy(g["running_mean__block3.0.attn.q_conv.1"]), rtol=1e-3, atol=1e-5)
+
+
+def test_sdtv3_attention_is_the_reference_product_order():
+    """(q k^T) v * 2 scale with 4x wider value heads == four d-wide q (k^T v) problems, bit for bit on spike operands."""
+    from spike2former_amd import ops
+    g = torch.Generator().manual_seed(1)
+    TB, h, d, N, r = 3, 8, 9, 36, 4
+    C = h * d
+    q, k = (torch.randint(0, 5, (TB, C, N), generator=g).float() / 4 for _ in range(2))
+    v = torch.randint(0, 5, (TB, r * C, N), generator=g).float() / 4
+    qh = q.view(TB, h, d, N).transpose(2, 3)
+    kh = k.view(TB, h, d, N).transpose(2, 3)
+    vh = v.view(TB, h, r * d, N).transpose(2, 3)
+    want = ((qh @ kh.transpose(-2, -1)) @ vh * (d ** -0.5 * 2)).transpose(2, 3).reshape(TB, r * C, N)
+    vj = v.cuda().view(TB, h, r, d, N).permute(2, 0, 1, 3, 4).contiguous()
+    o = torch.stack([ops.sdsa(q.cuda(), k.cuda(), vj[j].reshape(TB, C, N), h, d ** -0.5 * 2) for j in range(r)], 0)
+    o = o.view(r, TB, h, d, N).permute(1, 2, 0, 3, 4).reshape(TB, r * C, N)
+    assert torch.allclose(o.cpu(), want, rtol=1e-6, atol=1e-6)
+
+
+def test_c5_tiny_step_with_the_panoptic_shaped_head():
+    """BASELINE configs[4] in its shrunken-width form: E-SpikeFormer backbone + MaskFormer head with things + stuff classes on a
+    non-square input; one fwd+bwd step with the Hungarian-matched loss -- shapes, finite loss dictionary, gradients reach the
+    backbone's first convolution."""
+    import spike2former_amd as s2f
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C5_tiny"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C5_tiny"))).cuda().train()
+    img = torch.randn(w["B"], 3, w["H"], w["W"], generator=torch.Generator().manual_seed(2)).cuda()
+    seg = torch.randint(0, w["K"], (w["B"], 1, w["H"], w["W"]), generator=torch.Generator().manual_seed(3)).cuda()
+    s2f.reset_net(model)
+    cls, masks = model(img)
+    assert cls.shape == (w["dec"][0] + 1, w["B"], w["Q"], w["K"] + 1) and masks.shape[-2:] == (w["H"] // 2, w["W"] // 2)
+    s2f.reset_net(model); model.zero_grad(set_to_none=True)
+    losses = model(img, [seg[i] for i in range(w["B"])], mode="loss")
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    g = model.backbone.downsample1_1.encode_conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0

@@ -82,6 +82,8 @@ def test_constructor_errors_mirror_the_reference():
 
 def test_workloads_agree_with_oracle_configs():
     for name, w in s2f.WORKLOADS.items():
+        if "backbone" in w:            # E-SpikeFormer workloads (row f3): pinned by the reference's vectors, not by the oracle port
+            continue
         c = so.CONFIGS[name]
         assert (w["H"], w["W"], w["T"], w["B"], w["K"]) == (c.H, c.W, c.T, c.B, c.num_classes)
         assert tuple(w["embed_dim"]) == tuple(c.embed_dim) and w["Fc"] == c.feat_channels and w["Q"] == c.num_queries
