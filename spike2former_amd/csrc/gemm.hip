@@ -16,6 +16,7 @@
 // fragments.  LDS rows are padded to 80 bytes: the 16-lane service groups of ds_read_b128 then cover all 64 banks exactly
 // once (conflict-free).  The split weight is pre-padded to multiples of the tile, so the A path has no bounds checks.
 #include "s2f_common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(fast)
 
@@ -741,7 +742,13 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
     return s2f_check_launch("s2f_spike_gemm_dw memset");
   S2F_REQUIRE(x_terms == 1 || x_terms == 3, S2F_EINVAL, "s2f_spike_gemm_dw: x_terms must be 1 (X exact in bf16) or 3");
   // rows of dY per output tile: narrow tiles for the small-M gradients (spike X only)
-  const int tm = (x_terms == 1 && M <= 32) ? 32 : (x_terms == 1 && M <= 64) ? 64 : 128;
+  int tm = (x_terms == 1 && M <= 32) ? 32 : (x_terms == 1 && M <= 64) ? 64 : 128;
+  // short contractions with more than four 128x128 tiles (the 32x32-stage gradients): 64-row tiles halve the atomic
+  // traffic per workgroup at the same workgroup count -- measured -8..-16 % (mlp 37.5 -> 33.9 us, block4 1x1 35.6 -> 29.8,
+  // stacked q/k/v 35.2 -> 30.1), +15..40 % on the long contractions of the large maps, which keep the 128-row tile
+  if (x_terms == 1 && tm == 128 && (int64_t)batch * L <= 16384 && (int64_t)M * K > 65536) tm = 64;
+  static const char* force_tm = getenv("S2F_DW_TM");           // probe switch (tools/probe_spike_gemm_dw.py)
+  if (force_tm && x_terms == 1 && M > 64) tm = atoi(force_tm);
   const int m_tiles = (M + tm - 1) / tm, k_tiles = (K + 127) / 128;
   // short ragged rows keep the 32-wide step; so does the general-X form (six LDS operand tiles)
   // (the conv loader's extra state pushes the 64-wide variant to 257 registers = one wave per SIMD: 32-wide there; a
