@@ -12,6 +12,13 @@ def init_process_group(backend=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
+        if os.environ.get("S2F_FORCE_DIST") and torch.cuda.is_available() and not dist.is_initialized():
+            # single-GPU rehearsal of the N > 1 path on the real RCCL: communicator, watchdog thread, hipGraph capture with a
+            # process group alive, the side-stream all-reduce of the flat gradient buffer (a one-rank all-reduce)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend=backend or os.environ.get("S2F_DIST_BACKEND") or "nccl", rank=0, world_size=1)
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
@@ -123,23 +130,27 @@ class FlatGradAllReduce:
             self.install_sinks()
 
     def reduce(self, async_op=True):
-        if self.world == 1:
+        if self.world == 1 and not (os.environ.get("S2F_FORCE_DIST") and dist.is_initialized()):
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-                if self.work is not None:
-                    # RCCL runs the collective on its own stream: order the side stream behind it before the division
-                    # (a stream-level wait, the host does not block); gloo: blocks until the result is there
-                    self.work.wait()
-                self.flat.div_(self.world)
+                if dist.get_backend() == "nccl":
+                    # RCCL averages inside the collective (ncclAvg): no separate pass over the 137 MB buffer
+                    self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, async_op=async_op)
+                    if self.work is not None:
+                        self.work.wait()         # orders the side stream behind RCCL's own stream; the host does not block
+                else:
+                    self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+                    if self.work is not None:
+                        self.work.wait()         # gloo: blocks until the result is there
+                    self.flat.div_(self.world)
         else:
             self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
             self.flat.div_(self.world)
 
     def wait(self):
-        if self.world == 1:
+        if self.world == 1 and not (os.environ.get("S2F_FORCE_DIST") and dist.is_initialized()):
             return
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
