@@ -116,6 +116,33 @@ def test_lif_seq_matches_chained_calls_and_golden(ops, golden):
     assert np.array_equal((y2 * 8).cpu().numpy(), g["kat_counts"])
 
 
+def test_lif_seq_deep_temporal_loop_T8(ops):
+    """BASELINE configs[3] (T = 8, membrane carried across the whole loop in registers): the fused-over-T kernel against eight
+    chained single-step launches on a 16.8 M-element map (block3's largest neuron call at C4), with a non-zero initial membrane,
+    forward and backward, bit for bit; firing counters per time step."""
+    T_, n = 8, 2 * 256 * 32 * 32 * 8
+    g = torch.Generator().manual_seed(8)
+    xs = (torch.randn(T_, n, generator=g) * 1.5 + 0.4).cuda().requires_grad_(True)
+    v0 = torch.rand(n, generator=g).cuda().requires_grad_(True)
+    wy, wv = torch.randn(T_, n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    stats = ops.new_stats("cuda", T=T_)
+    y, vT = ops.lif_seq(xs, v0, stats=stats)
+    ((y * wy).sum() + (vT * wv).sum()).backward()
+    gx, gv = xs.grad.clone(), v0.grad.clone()
+    xs.grad = v0.grad = None
+    v, ys = v0, []
+    for t in range(T_):
+        yt, v = ops.lif(xs[t], v)
+        ys.append(yt)
+    yc = torch.stack(ys)
+    ((yc * wy).sum() + (v * wv).sum()).backward()
+    assert torch.equal(y, yc) and torch.equal(vT, v)
+    assert torch.equal(gx, xs.grad) and torch.equal(gv, v0.grad)
+    counts = (y.detach() * 8).round().long()
+    assert ops.read_stats(stats)[:, 0].tolist() == counts.sum(1).tolist()
+    assert ops.read_stats(stats)[:, 1].tolist() == (counts != 0).sum(1).tolist()
+
+
 def test_lif_full_size_properties(ops):
     """BASELINE full size (the largest single neuron call at C2, [4,2,256,256,256] = 134 M elements): properties that
     do not need the oracle -- output on the 9-point grid, y + v' == x exactly, idempotence of the stateless map."""
