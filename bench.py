@@ -234,6 +234,16 @@ def main():
                                 "traffic": traffic.get(name) if args.workload == "C2" else None,
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
                                 "algorithmic_bytes_per_launch": nbytes // launches}
+            # the same fused forward kernel restricted to launches whose operands cannot sit in the caches (>= 128 MB of
+            # algorithmic traffic): what the kernel itself sustains, next to the all-launches figure above that is dominated
+            # by the 5 us launch floor of the 2-33 MB launches ("streaming-kernel efficiency")
+            big = [(nb, us) for name, nb, _, us in events if name == "bn_lif_fwd" and nb >= 128e6]
+            if big:
+                gbs = sum(nb for nb, _ in big) / sum(us for _, us in big) / 1e3
+                out["roofline_bn_lif_fwd_hbm_resident"] = {
+                    "kernel": "bn_lif_fwd", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(big),
+                    "avg_launch_us": round(sum(us for _, us in big) / len(big), 2), "min_algorithmic_bytes": 128000000}
             # the MFMA kernels: bf16 products actually issued (3 per fp32 multiply-add: W or dY split hi+mid+lo) against the
             # dense bf16 MFMA peak; the K <= 256 shapes of the path are bound by streaming X / Y, see DESIGN.md section 4
             for name, key in (("spike_gemm_fwd", "roofline_spike_gemm_fwd"), ("spike_gemm_dw", "roofline_spike_gemm_dw")):
