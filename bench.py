@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (informational: the metric's config is B = 2)")
     ap.add_argument("--loss", default="headline", choices=["headline", "hungarian"],
                     help="hungarian: the reference's real training loss (SURVEY 8 row f1) on a synthetic semantic map; the "
                          "matching runs on the host in the middle of the step, so the step is launched eagerly (secondary figure)")
@@ -89,7 +90,7 @@ def main():
     torch.cuda.set_device(dev)
 
     w = s2f.WORKLOADS[args.workload]
-    B = w["B"]                                      # per-GPU batch: weak scaling (BASELINE.json configs[1]: batch=2 on 1 GPU)
+    B = args.batch or w["B"]                        # per-GPU batch: weak scaling (BASELINE.json configs[1]: batch=2 on 1 GPU)
     model = seeded_init(s2f.MODELS.build(s2f.model_cfg(args.workload))).to(dev).train()
     broadcast_params(model)
     s2f.set_keep_membrane(model, False)             # a reset precedes every step -> the membrane is never read back
