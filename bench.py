@@ -207,6 +207,7 @@ def main():
                                    f"{w['embed_dim']} + MaskFormer head, per-GPU batch {B}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"},
         }
+        out["peak_hbm_GB"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)     # of 288 GB (allocator high-water mark)
         if events:
             # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
             # separate runs, gfx950 corrections applied there); null when no such profile exists for a kernel
