@@ -53,10 +53,7 @@ class FlatGradAllReduce:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        # The collective is queued on the caller's stream, right behind the replayed step.  On a side stream (room to overlap
-        # with whatever the caller queues next; S2F_REDUCE_SIDE_STREAM=1) the two event hand-overs around the graph launch cost
-        # ~1 ms each: 55.6 vs 53.5 ms/step in the one-rank RCCL rehearsal, and nothing in the step overlaps with it anyway.
-        self.stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and os.environ.get("S2F_REDUCE_SIDE_STREAM")) else None
+        self.stream = None                     # side stream, only for gloo on device memory (see reduce())
         self.work = None
         self.sinks = False
         self._zero = None
@@ -135,24 +132,26 @@ class FlatGradAllReduce:
     def reduce(self, async_op=True):
         if self.world == 1 and not (os.environ.get("S2F_FORCE_DIST") and dist.is_initialized()):
             return
-        if self.stream is not None:
+        if self.flat.is_cuda and dist.get_backend() == "nccl":
+            # RCCL: the blocking form queues the collective on the CALLER's stream, right behind the replayed step, and averages
+            # inside the collective (ncclAvg: no separate pass over the 137 MB buffer).  The asynchronous form runs on RCCL's own
+            # stream; its two event hand-overs around the graph launch cost ~1 ms each (55.6 vs 53.5 ms/step in the one-rank
+            # rehearsal), and nothing in the step overlaps with the collective anyway.
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, async_op=False)
+            return
+        if self.flat.is_cuda:
+            # gloo on device memory (two ranks rehearsing on one GPU): on a side stream -- queued on the step's own stream the
+            # staging copies took 21 s per call
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=self.flat.device)
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                if dist.get_backend() == "nccl":
-                    # RCCL averages inside the collective (ncclAvg): no separate pass over the 137 MB buffer
-                    self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, async_op=async_op)
-                    if self.work is not None:
-                        self.work.wait()         # orders the side stream behind RCCL's own stream; the host does not block
-                else:
-                    self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-                    if self.work is not None:
-                        self.work.wait()         # gloo: blocks until the result is there
-                    self.flat.div_(self.world)
-        elif self.flat.is_cuda and dist.get_backend() == "nccl":
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, async_op=False)
-        else:
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
-            self.flat.div_(self.world)
+                self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+                self.work.wait()
+                self.flat.div_(self.world)
+            return
+        self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
+        self.flat.div_(self.world)
 
     def wait(self):
         if self.world == 1 and not (os.environ.get("S2F_FORCE_DIST") and dist.is_initialized()):
