@@ -51,6 +51,55 @@ __global__ __launch_bounds__(256) void up2x_fwd_kernel(const float* __restrict__
   }
 }
 
+// w % 4 == 0: one thread produces a 2 x 8 block of outputs (rows 2i, 2i+1; columns 8k .. 8k+7) from input rows i-1, i, i+1
+// and columns 4k-1 .. 4k+4 -- one 16-byte load and two edge scalars per row (9 load instructions for 16 outputs instead of 32
+// scalar loads), same tap arithmetic as the kernel above ((1 - l) a + l b with l = 0.75 / 0.25 / 0 at the clamped edge).
+__global__ __launch_bounds__(256) void up2x_fwd_block_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes,
+                                                             int h, int w) {
+  const int W = 2 * w;
+  const int qw = w / 4;
+  const int64_t total = planes * h * qw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % qw);
+    const int64_t r = idx / qw;
+    const int i = (int)(r % h);
+    const int64_t p = r / h;
+    const float* base = x + p * h * w;
+    float c[3][6];                                       // rows i-1, i, i+1 (clamped); columns 4k-1 .. 4k+4 (clamped)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const int iy = min(max(i - 1 + rr, 0), h - 1);
+      const float* row = base + (int64_t)iy * w + 4 * k;
+      const float4 v = *reinterpret_cast<const float4*>(row);
+      c[rr][0] = k > 0 ? row[-1] : v.x;
+      c[rr][1] = v.x; c[rr][2] = v.y; c[rr][3] = v.z; c[rr][4] = v.w;
+      c[rr][5] = k + 1 < qw ? row[4] : v.w;
+    }
+    // horizontal pass: output column 8k + 2m     = 0.25 c[m] + 0.75 c[m+1]   (first column of the plane: c[1] alone)
+    //                  output column 8k + 2m + 1 = 0.75 c[m+1] + 0.25 c[m+2] (last column of the plane: the clamped tap = c[m+1])
+    float hx[3][8];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bool first = k == 0 && m == 0;
+        hx[rr][2 * m] = first ? (1.f - 0.f) * c[rr][1] + 0.f * c[rr][2] : (1.f - 0.75f) * c[rr][m] + 0.75f * c[rr][m + 1];
+        hx[rr][2 * m + 1] = (1.f - 0.25f) * c[rr][m + 1] + 0.25f * c[rr][m + 2];
+      }
+    float* o = y + (p * 2 * h + 2 * i) * W + 8 * k;
+    float ev[8], od[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ev[j] = i == 0 ? (1.f - 0.f) * hx[1][j] + 0.f * hx[2][j] : (1.f - 0.75f) * hx[0][j] + 0.75f * hx[1][j];   // output row 2i
+      od[j] = (1.f - 0.25f) * hx[1][j] + 0.25f * hx[2][j];                                                       // output row 2i + 1
+    }
+    *reinterpret_cast<float4*>(o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(ev[4], ev[5], ev[6], ev[7]);
+    *reinterpret_cast<float4*>(o + W) = make_float4(od[0], od[1], od[2], od[3]);
+    *reinterpret_cast<float4*>(o + W + 4) = make_float4(od[4], od[5], od[6], od[7]);
+  }
+}
+
 // adjoint: gx[i] gathers from the (at most) 4 outputs per dimension that read it
 __device__ __forceinline__ float wgt(int o, int i, int in_size) {     // d out[o] / d in[i] along one dimension
   int i0, i1;
@@ -270,8 +319,12 @@ extern "C" int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int 
   S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_upsample2x_fwd: null pointer");
   S2F_REQUIRE(planes > 0 && h > 0 && w > 0 && (w % 2) == 0, S2F_EINVAL, "s2f_upsample2x_fwd: need even input width");
   S2F_REQUIRE(s2f_aligned16(y), S2F_EALIGN, "s2f_upsample2x_fwd: output must be 16-byte aligned");
-  hipLaunchKernelGGL(up2x_fwd_kernel, dim3(grid_for(planes * 2 * h * (2 * w / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
-                     planes, h, w);
+  if ((w & 3) == 0 && s2f_aligned16(x))
+    hipLaunchKernelGGL(up2x_fwd_block_kernel, dim3(grid_for(planes * h * (w / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                       planes, h, w);
+  else
+    hipLaunchKernelGGL(up2x_fwd_kernel, dim3(grid_for(planes * 2 * h * (2 * w / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                       planes, h, w);
   return s2f_check_launch("s2f_upsample2x_fwd");
 }
 
