@@ -46,12 +46,16 @@ def parse():
                     help="1: lateral convs / H/2 FPN level + mask_feature / decoder key-value projections on side streams "
                          "(S2F_LONG_WHAT=lat,mf,kv selects; measured: mf -0.8 ms, kv +0.7 ms, lat 0 -- off by default)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--allow-eager", action="store_true",
+                    help="N > 1: fall back to eager launches when the hipGraph capture fails (host-bound, ~2x slower: a curve "
+                         "that mixes graph and eager points is meaningless, so the default is to fail)")
     return ap.parse_args()
 
 
-def cpu_baseline(workload):
+def cpu_baseline(workload, timed_steps=3):
     """The oracle (a port of the reference's PyTorch CPU path, pinned against it on golden vectors) timed on this box's
-    host cores: ONE fwd+bwd step at the workload's shapes with B=1 -- a bounded sample of the same workload."""
+    host cores: fwd+bwd steps at the workload's shapes with B=1 -- a bounded sample of the same workload -- 1 warm-up + 3
+    timed steps."""
     import torch
 
     from oracle import s2f_oracle as so        # cpu_baseline leg only
@@ -63,14 +67,20 @@ def cpu_baseline(workload):
     st = so.make_params(cfg)
     net = so.OracleNet(st, cfg, training=True)
     img = so.synthetic_image(cfg)
-    t0 = time.perf_counter()
-    net.reset()
-    cls, masks = net.forward(img)
-    so.headline_loss(cls, masks).backward()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(1 + timed_steps):
+        for p in st.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        net.reset()
+        cls, masks = net.forward(img)
+        so.headline_loss(cls, masks).backward()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / timed_steps
     return {"value": round(cfg.B / dt, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 un-warmed fwd+bwd step, B=1, {cfg.H}x{cfg.W}, T={cfg.T}, fp32, oracle/s2f_oracle.py "
-                      f"(torch {torch.__version__} CPU kernels), {dt:.1f} s"}
+            "sample": f"1 warm-up + {timed_steps} timed fwd+bwd steps, B=1, {cfg.H}x{cfg.W}, T={cfg.T}, fp32, "
+                      f"oracle/s2f_oracle.py (torch {torch.__version__} CPU kernels); step times "
+                      + ", ".join(f"{t:.1f}" for t in times) + " s (first = warm-up)"}
 
 
 def main():
@@ -149,8 +159,8 @@ def main():
         from spike2former_amd.graph import GraphedStep
         try:
             graphed = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=max(args.warmup, 2))
-        except RuntimeError as e:                   # N > 1 only: keep the measurement alive on eager launches, and say so
-            if world == 1:
+        except RuntimeError as e:                   # N > 1 with --allow-eager only: eager launches, labelled as such
+            if world == 1 or not args.allow_eager:
                 raise
             print(f"[bench rank {rank}] hipGraph capture failed ({e}); timing eager launches", file=sys.stderr, flush=True)
             graphed = None
@@ -203,7 +213,8 @@ def main():
             "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph replay",
-            "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']} Meta-SpikeFormer "
+            "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']} "
+                                   f"{'E-SpikeFormer (SDT-v3)' if 'v2' in str(w.get('backbone', '')) else 'Meta-SpikeFormer'} "
                                    f"{w['embed_dim']} + MaskFormer head, per-GPU batch {B}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"},
         }
@@ -219,43 +230,53 @@ def main():
                 pass
             if args.dump_events:
                 with open(args.dump_events, "w") as f:
-                    for name, nbytes, flops, us in events:
-                        f.write(f"{name} {nbytes} {flops} {us:.2f}\n")
+                    for name, nbytes, flops, us, moved in events:
+                        f.write(f"{name} {nbytes} {flops} {us:.2f} {moved}\n")
             agg = {}
-            for name, nbytes, flops, us in events:
-                a = agg.setdefault(name, [0, 0.0, 0, 0])
-                a[0] += nbytes; a[1] += us * 1e-6; a[2] += 1; a[3] += flops
+            for name, nbytes, flops, us, moved in events:
+                a = agg.setdefault(name, [0, 0.0, 0, 0, 0])
+                a[0] += nbytes; a[1] += us * 1e-6; a[2] += 1; a[3] += flops; a[4] += moved
             for name, key in (("bn_lif_fwd", "roofline"), ("bn_lif_bwd", "roofline_bn_lif_bwd"), ("lif_fwd", "roofline_lif_fwd"),
                               ("lif_bwd", "roofline_lif_bwd"), ("bn_fwd", "roofline_bn_fwd"), ("bn_bwd", "roofline_bn_bwd"),
                               ("bn_stats", "roofline_bn_stats")):
                 if name in agg:
-                    nbytes, secs, launches, _ = agg[name]
+                    nbytes, secs, launches, _, moved = agg[name]
                     gbs = nbytes / secs / 1e9
+                    # `achieved` prices the launch at SURVEY 8d's ALGORITHMIC bytes (the reference's fp32 tensors: 4 B per
+                    # element read or written); `moved_*` is what this build's kernel actually transfers for them (spike
+                    # maps leave as bf16: 2 B per element) -- both are reported, as 8d asks
                     out[key] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                 "traffic": traffic.get(name) if args.workload == "C2" else None,
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
-                                "algorithmic_bytes_per_launch": nbytes // launches}
+                                "algorithmic_bytes_per_launch": nbytes // launches,
+                                "moved_bytes_per_launch": moved // launches, "moved_GBps": round(moved / secs / 1e9, 1),
+                                "moved_frac": round(moved / secs / 1e9 / HBM_PEAK_GBS, 4)}
             # the same fused forward kernel restricted to launches whose operands cannot sit in the caches (>= 128 MB of
             # algorithmic traffic): what the kernel itself sustains, next to the all-launches figure above that is dominated
             # by the 5 us launch floor of the 2-33 MB launches ("streaming-kernel efficiency")
-            big = [(nb, us) for name, nb, _, us in events if name == "bn_lif_fwd" and nb >= 128e6]
+            big = [(nb, us) for name, nb, _, us, _m in events if name == "bn_lif_fwd" and nb >= 128e6]
             if big:
                 gbs = sum(nb for nb, _ in big) / sum(us for _, us in big) / 1e3
                 out["roofline_bn_lif_fwd_hbm_resident"] = {
                     "kernel": "bn_lif_fwd", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(big),
                     "avg_launch_us": round(sum(us for _, us in big) / len(big), 2), "min_algorithmic_bytes": 128000000}
-            # the MFMA kernels: bf16 products actually issued (3 per fp32 multiply-add: W or dY split hi+mid+lo) against the
-            # dense bf16 MFMA peak; the K <= 256 shapes of the path are bound by streaming X / Y, see DESIGN.md section 4
-            for name, key in (("spike_gemm_fwd", "roofline_spike_gemm_fwd"), ("spike_gemm_dw", "roofline_spike_gemm_dw")):
+            # the MFMA kernels: ALGORITHMIC flops (2 M N K per GEMM) against the dense bf16 MFMA peak.  Every fp32
+            # multiply-add is issued as 3 bf16 products (W or dY split hi + mid + lo, fp32-equivalent accuracy):
+            # `issued_frac` = 3 x frac is the matrix pipes' own utilisation.  The K <= 256 shapes of the path are bound by
+            # streaming X / Y (moved_GBps), see DESIGN.md section 4.
+            for name, key in (("spike_gemm_fwd", "roofline_spike_gemm_fwd"), ("spike_gemm_dw", "roofline_spike_gemm_dw"),
+                              ("dx_gemm", "roofline_dx_gemm")):
                 if name in agg:
-                    nbytes, secs, launches, flops = agg[name]
+                    nbytes, secs, launches, flops, moved = agg[name]
                     out[key] = {"kernel": name, "bound": "mfma", "achieved": round(flops / secs / 1e12, 1),
                                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "issued_frac": round((6 if name == "dx_gemm" else 3) * flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
-                                "hbm_GBps_algorithmic": round(nbytes / secs / 1e9, 1)}
+                                "hbm_GBps_algorithmic": round(nbytes / secs / 1e9, 1),
+                                "moved_GBps": round(moved / secs / 1e9, 1)}
             out["timed_kernels_ms_per_step"] = round(sum(a[1] for a in agg.values()) / 2 * 1e3, 3)
         if world == 1 and not args.no_cpu_baseline:
             del model, red

@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 12
+#define S2F_ABI_VERSION 13
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -65,9 +65,11 @@ int64_t s2f_lif_mask_words(int64_t n);
  *          slots (cal_firing_num.py:138-160 accumulates mean(y*D) = sum(stats[.][0])/n; firing_utils non-zero rate =
  *          sum(stats[.][1])/n).  Workgroup b adds into slot b % S2F_STAT_SLOTS: with ONE pair of counters the 2 048
  *          workgroups of a launch serialise on two L2 atomics (measured 52 us on a 5 us kernel).
- * x, y, v_* need 16-byte alignment when n >= 4. */
-int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
-                uint64_t* stats, int64_t n, float vth, int D, void* stream);
+ * x, y, v_* need 16-byte alignment when n >= 4.
+ * y_bf16 != 0: y points to uint16 storage and the spikes are written as bf16 -- exact (a spike has <= 8 significant bits),
+ *   2 bytes / element instead of the reference's 4; what the *_bf16 GEMM / attention entry points consume. */
+int s2f_lif_fwd(const float* x, const float* v_in, void* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
+                uint64_t* stats, int64_t n, float vth, int D, int y_bf16, void* stream);
 
 /* STE backward of one step:  gx = gv_out + (gy / D - gv_out * vth) * m   (gv_out? NULL == 0; dL/dv_in == gx). */
 int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth, int D,
@@ -78,8 +80,9 @@ int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, floa
  * mmcv_spike/transformer.py:626-629): y_value = Q_IFNode(a), y_key = Q_IFNode(a + pos), reset stateless neurons, 1-bit
  * in-range masks as s2f_lif_fwd.  Backward: gx = STE(g_key, mask_key) + STE(g_value, mask_value); the gradient of e is the
  * per-channel sum of gx (left to the caller).  L % 4 == 0. */
-int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, float* y_key, float* y_value, uint64_t* mask_key,
-                     uint64_t* mask_value, int64_t TB, int64_t B, int64_t C, int64_t L, float vth, int D, void* stream);
+int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, void* y_key, void* y_value, uint64_t* mask_key,
+                     uint64_t* mask_value, int64_t TB, int64_t B, int64_t C, int64_t L, float vth, int D, int y_bf16,
+                     void* stream);
 int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const uint64_t* mask_key, const uint64_t* mask_value,
                      float* gx, int64_t n, int D, void* stream);
 
@@ -124,9 +127,9 @@ int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, in
                  void* stream);
 int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
-                   const float* residual, float* u_out, const float* v_in, float* y, float* v_out, uint64_t* mask,
+                   const float* residual, float* u_out, const float* v_in, void* y, float* v_out, uint64_t* mask,
                    uint64_t* stats, int64_t N, int64_t C, int64_t L, float momentum, float eps, int training, float vth,
-                   int D, void* stream);
+                   int D, int y_bf16, void* stream);
 int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
                    const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
                    float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
@@ -155,6 +158,13 @@ int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, 
  * the accuracy of an fp32 GEMM on v_mfma_f32_32x32x16_bf16.  `terms` in {1,2,3} = number of weight terms used.
  * w_split: [3][Mpad][Kpad] bf16, zero padded, Mpad % 64 == 0, Kpad % 32 == 0.  N % 4 == 0. */
 int s2f_split_bf16x3(const float* w, uint16_t* w_split, int M, int K, int Mpad, int Kpad, void* stream);
+/* All weights of a model in ONE launch -- the re-split a training step owes after the optimiser has updated them, and the
+ * node a captured step replays so that every replay multiplies by the LIVE fp32 weights.  jobs (device): int64 [njobs][8] =
+ * {src fp32 pointer, dst bf16 pointer, M, K, Mpad, Kpad, mode | (C << 8), first workgroup}; job i owns workgroups
+ * [first_i, first_i + ceil(Mpad Kpad / 1024)), total_workgroups = their sum.  mode 0: src = the [M][K] matrix; 1: src = a
+ * conv weight [M][C][3][3] read tap-major (the w_split layout of s2f_spike_conv3x3_fwd); 2: the flipped, transposed
+ * matrix of a conv weight [C][M][3][3] that s2f_conv3x3_general takes for the input gradient (C field = its out-channels). */
+int s2f_split_bf16x3_multi(const int64_t* jobs, int njobs, int64_t total_workgroups, void* stream);
 int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int N,
                        int K, int Mpad, int Kpad, int terms, void* stream);
 /* 3x3 convolution (stride 1, padding 1) of a SPIKE activation as an implicit GEMM on the same kernels: the B operand is
@@ -196,6 +206,24 @@ int s2f_split_gemm(const uint16_t* a_split, int64_t a_batch_stride, int64_t a_te
  *   -- the "both operands contraction-contiguous" GEMM of two general tensors, e.g. dE = g @ MF^T of the mask einsum. */
 int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate, int x_terms,
                       void* stream);
+
+/* ---- the same GEMMs with the activation operand ARRIVING in bf16 ------------------------------------------------------
+ * The neuron kernels can write their spikes as bf16 (`y_bf16` of s2f_lif_fwd / s2f_bn_act_fwd / s2f_sum2_lif_fwd): spikes are
+ * multiples of 1/D with at most 8 significant bits, so bf16 holds them exactly, at half the bytes of the reference's fp32
+ * tensors.  X: bf16 [batch, K, N] (uint16_t storage), channel-major as above.  The K loops then hold loads, LDS traffic and
+ * MFMAs only: the forward kernel copies the X tile as it lies in memory and forms the k-contiguous MFMA fragments with the
+ * LDS transpose read (ds_read_b64_tr_b16); the weight-gradient kernel reads the contraction-contiguous rows directly.
+ * Same arithmetic, same results as the fp32-operand entry points above.  N % 4 == 0 (16-byte chunks when N % 8 == 0).
+ * s2f_to_bf16_exact: fp32 -> bf16 for a tensor that is exactly representable (spikes a caller still holds in fp32); n % 4 == 0. */
+int s2f_to_bf16_exact(const float* x, uint16_t* y, int64_t n, void* stream);
+int s2f_spike_gemm_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch, int M, int N,
+                            int K, int Mpad, int Kpad, int terms, void* stream);
+int s2f_spike_conv3x3_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch, int M,
+                               int C, int H, int W, int Mpad, int Kpad, int terms, void* stream);
+int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate,
+                           void* stream);
+int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,
+                              int accumulate, void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path

@@ -20,9 +20,9 @@ SIGNATURES = {
     "s2f_time_next_call": (_i, [_p, _p]),
     "s2f_event_elapsed_us": (_i, [_p, _p, ctypes.POINTER(ctypes.c_double)]),
     "s2f_lif_mask_words": (_i64, [_i64]),
-    "s2f_lif_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _i, _p]),
+    "s2f_lif_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _i, _i, _p]),
     "s2f_lif_bwd": (_i, [_p, _p, _p, _p, _i64, _f, _i, _p]),
-    "s2f_sum2_lif_fwd": (_i, [_p] * 7 + [_i64] * 4 + [_f, _i, _p]),
+    "s2f_sum2_lif_fwd": (_i, [_p] * 7 + [_i64] * 4 + [_f, _i, _i, _p]),
     "s2f_sum2_lif_bwd": (_i, [_p] * 5 + [_i64, _i, _p]),
     "s2f_mask_loss_fwd": (_i, [_p] * 4 + [_i64, _i, _i, _f, _f, _p]),
     "s2f_mask_loss_bwd": (_i, [_p] * 5 + [_i64, _i, _i, _f, _f, _p]),
@@ -32,12 +32,13 @@ SIGNATURES = {
     "s2f_lif_seq_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i64, _f, _i, _p]),
     "s2f_bn_single_pass": (_i, [_i64] * 3),
     "s2f_bn_stats": (_i, [_p] * 3 + [_i64] * 3 + [_p]),
-    "s2f_bn_act_fwd": (_i, [_p] * 16 + [_i64] * 3 + [_f, _f, _i, _f, _i, _p]),
+    "s2f_bn_act_fwd": (_i, [_p] * 16 + [_i64] * 3 + [_f, _f, _i, _f, _i, _i, _p]),
     "s2f_bn_act_bwd": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
     "s2f_dwconv_fwd": (_i, [_p] * 4 + [_i] * 6 + [_p]),
     "s2f_dwconv_bwd_input": (_i, [_p] * 3 + [_i] * 6 + [_p]),
     "s2f_dwconv_bwd_weight": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_split_bf16x3": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "s2f_split_bf16x3_multi": (_i, [_p, _i, _i64, _p]),
     "s2f_spike_gemm_fwd": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_upsample2x_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_upsample2x_bwd": (_i, [_p, _p, _i64, _i, _i, _p]),
@@ -46,6 +47,11 @@ SIGNATURES = {
     "s2f_conv3x3_general": (_i, [_p, _p, _p] + [_i] * 7 + [_p]),
     "s2f_split_gemm": (_i, [_p, _i64, _i64, _i, _p, _i64, _i, _i64, _i, _p, _i64, _f, _i, _i, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_dw": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "s2f_to_bf16_exact": (_i, [_p, _p, _i64, _p]),
+    "s2f_spike_gemm_fwd_bf16": (_i, [_p] * 4 + [_i] * 7 + [_p]),
+    "s2f_spike_conv3x3_fwd_bf16": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),
+    "s2f_spike_gemm_dw_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "s2f_spike_conv3x3_dw_bf16": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "s2f_sdsa_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_kv": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),

@@ -1,9 +1,9 @@
 """Meta-SpikeFormer (SDT-v2) backbone on the MI355X kernels.
 
 Mirrors the registry surface of the reference backbone -- class names, constructor kwargs and state_dict keys of
-mmseg/models/backbones/sdtv2.py:48-655 -- so reference configs and checkpoints load unchanged.  Every Q_IFNode, and
-the softmax-free attention core, run in libs2f_hip.so; dense/depthwise convolutions and train-mode BatchNorm go
-through ATen (MIOpen / rocBLAS) as plain library calls.
+mmseg/models/backbones/sdtv2.py:48-655 -- so reference configs and checkpoints load unchanged.  Every Q_IFNode, BatchNorm, depthwise
+stencil, spike GEMM and the softmax-free attention core run in libs2f_hip.so (csrc/*.hip); spike maps travel between them
+as bf16 (`ops.Spikes`); only the input gradients of the 1x1 convolutions are library GEMMs.
 """
 from collections import OrderedDict
 
@@ -116,7 +116,7 @@ class SepConv(nn.Module):
         """Returns SepConv(x) [+ residual] (the residual add is fused into the last BatchNorm kernel; `next_lif`, the
         neuron that reads the result next, is applied there as well -- fused.bn_act)."""
         T, B, C, H, W = x.shape
-        s = self.spike1(x)
+        s = self.spike1.fire(x)
         _, s = bn_act(self.pwconv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
         z = self.pwconv2(self.dwconv(s))
         u, _ = bn_act(z, None, self.bn2, residual=None if residual is None else residual.flatten(0, 1), next_lif=next_lif)
@@ -146,7 +146,7 @@ class MS_ConvBlock(nn.Module):
     def forward(self, x, next_lif=None):
         T, B, C, H, W = x.shape
         feat = self.Conv(x, residual=x, next_lif=self.spike1)            # x + SepConv(x)
-        s = self.spike1(feat)
+        s = self.spike1.fire(feat)
         _, s = bn_act(self.conv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
         u, _ = bn_act(self.conv2(s), None, self.bn2, residual=feat.flatten(0, 1), next_lif=next_lif)   # feat + BN(conv2(.))
         return u.reshape(T, B, C, H, W)
@@ -171,7 +171,7 @@ class MS_MLP(nn.Module):
 
     def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
-        s = self.fc1_spike(x.flatten(3)).flatten(0, 1)
+        s = self.fc1_spike.fire(x.flatten(3)).flatten(0, 1)
         _, s = bn_act(self.fc1_conv.forward_nobias(s), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
         res = None if residual is None else residual.reshape(T * B, C, H * W)
         u, _ = bn_act(self.fc2_conv.forward_nobias(s), self.fc2_conv.bias, self.fc2_bn, residual=res, next_lif=next_lif)
@@ -257,7 +257,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
             wb()
         if training:
             torch._foreach_add_([b.num_batches_tracked for bns in t["bns"] for b in bns], 1)
-        return ops.split3(y.view(T * B, 3 * C, N))
+        return ops.split3(y.float().view(T * B, 3 * C, N))
 
     def _can_batch(self):
         lifs = (self.q_spike, self.k_spike, self.v_spike)
@@ -271,7 +271,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
     def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
         N = H * W
-        s = self.head_spike(x).flatten(0, 1)
+        s = self.head_spike.fire(x).flatten(0, 1)
         if s.is_cuda and N % 4 == 0 and self._can_batch():
             q, k, v = self._qkv_batched(s, T, B, C, H, W)
         else:
@@ -280,7 +280,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
                 lambda: self.k_conv[0](s, outer_bn=self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N),
                 lambda: self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)], inputs=(s,))
         o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
-        o = self.attn_spike(o).view(T * B, C, H, W)
+        o = self.attn_spike.fire(o).view(T * B, C, H, W)
         res = None if residual is None else residual.flatten(0, 1)
         return self.proj_conv[0](o, outer_bn=self.proj_conv[1], residual=res, next_lif=next_lif)[0].reshape(T, B, C, H, W)
 
@@ -324,7 +324,7 @@ class MS_DownSampling(nn.Module):
     def forward(self, x, next_lif=None):
         T, B = x.shape[:2]
         if hasattr(self, "encode_spike"):
-            x = self.encode_spike(x)
+            x = self.encode_spike.fire(x)
         x, _ = bn_act(self.encode_conv.forward_nobias(x.flatten(0, 1)), self.encode_conv.bias, self.encode_bn,
                       next_lif=next_lif)
         return x.reshape(T, B, *x.shape[1:])

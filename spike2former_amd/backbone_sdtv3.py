@@ -52,7 +52,7 @@ class SepConv_Spike(nn.Module):
 
     def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
-        s = self.spike1(x).flatten(0, 1)
+        s = self.spike1.fire(x).flatten(0, 1)
         _, s = bn_act(self.pwconv1[0].forward_nobias(s), self.pwconv1[0].bias, self.pwconv1[1], lif=self.spike2)
         _, s = bn_act(self.dwconv[0].forward_nobias(s), self.dwconv[0].bias, self.dwconv[1], lif=self.spike3)
         u, _ = bn_act(self.pwconv2[0].forward_nobias(s), self.pwconv2[0].bias, self.pwconv2[1],
@@ -83,7 +83,7 @@ class MS_ConvBlock_spike_SepConv(nn.Module):
     def forward(self, x, next_lif=None):
         T, B, C, H, W = x.shape
         feat = self.Conv(x, residual=x, next_lif=self.spike1)
-        s = self.spike1(feat)
+        s = self.spike1.fire(feat)
         _, s = bn_act(self.conv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
         u, _ = bn_act(self.conv2(s), None, self.bn2, residual=feat.flatten(0, 1), next_lif=next_lif)
         return u.reshape(T, B, C, H, W)
@@ -134,15 +134,15 @@ class MS_Attention_linear(nn.Module):
         d = C // h
         r = int(self.lamda_ratio)
         assert r * C == int(C * self.lamda_ratio), "lamda_ratio must be an integer (4 in every config)"
-        s = self.head_spike(x).flatten(0, 1)
+        s = self.head_spike.fire(x).flatten(0, 1)
         q = bn_act(self.q_conv[0](s), None, self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N)
         k = bn_act(self.k_conv[0](s), None, self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N)
-        v = bn_act(self.v_conv[0](s), None, self.v_conv[1], lif=self.v_spike)[1]                 # [TB, r*C, H, W]
+        v = bn_act(self.v_conv[0](s), None, self.v_conv[1], lif=self.v_spike)[1].float()         # [TB, r*C, H, W]
         # value channel c_v = head * (r d) + j * d + jj: the j-th d-wide slice of every head is one ordinary attention problem
         vj = v.view(T * B, h, r, d, N).permute(2, 0, 1, 3, 4).contiguous()                      # [r, TB, h, d, N]
         o = torch.stack([ops.sdsa(q, k, vj[j].reshape(T * B, C, N), h, self.scale * 2) for j in range(r)], 0)
         o = o.view(r, T * B, h, d, N).permute(1, 2, 0, 3, 4).reshape(T * B, r * C, H, W)        # back to c_v order
-        o = self.attn_spike(o)
+        o = self.attn_spike.fire(o)
         res = None if residual is None else residual.flatten(0, 1)
         u, _ = bn_act(self.proj_conv[0](o), None, self.proj_conv[1], residual=res, next_lif=next_lif)
         return u.reshape(T, B, C, H, W)

@@ -7,7 +7,10 @@ touches MIOpen (`torch.backends.cudnn.enabled = False`, set when the package is 
   * 1x1 Conv2d / Conv1d(k=1) (the bulk of the path's FLOPs: q/k/v, MLP, pixel-decoder and decoder projections) are
     plain GEMMs  Y[n] = W @ X[n]  on the channel-major activations -> rocBLAS (prebuilt gfx950 kernels);
   * dense kxk convolutions (stem 7x7, MS_ConvBlock 3x3, downsampling 3x3/s2) are lowered to im2col + the same GEMM;
-  * depthwise convolutions and train-mode BatchNorm use ATen's native HIP kernels.
+  * depthwise convolutions and BatchNorm are this package's own kernels (csrc/dwconv.hip, csrc/bn_lif.hip).
+
+A convolution fed by a neuron takes the spike map as an `ops.Spikes` pair (bf16 data + autograd handle) and runs on the
+bf16 matrix cores (csrc/gemm_bf16.hip); a plain fp32 tensor of spikes is accepted as well.
 
 The classes subclass nn.Conv2d / nn.Conv1d, so parameter names and shapes -- the checkpoint ABI -- are unchanged.
 """
@@ -27,11 +30,11 @@ def spikes_in(*convs):
 
 
 def _gemm_nc(weight2d, x3, bias, spike_input=False):
-    """x3 [N, K, L], weight2d [M, K] -> [N, M, L]."""
-    if spike_input and ops.SPIKE_GEMM_ENABLED and x3.shape[2] % 4 == 0:
+    """x3 [N, K, L] (tensor or ops.Spikes), weight2d [M, K] -> [N, M, L]."""
+    if (spike_input or isinstance(x3, ops.Spikes)) and ops.SPIKE_GEMM_ENABLED and x3.shape[2] % 4 == 0:
         return ops.spike_gemm(x3, weight2d, bias)       # bf16 matrix cores, exact for spike activations
     # library GEMM with the weight broadcast through a zero batch stride (no operand copies), rocBLAS or hipBLASLt
-    y = ops.dense_gemm(x3, weight2d)
+    y = ops.dense_gemm(ops.spikes_float(x3), weight2d)
     if bias is not None:
         y = y + bias.view(1, -1, 1)
     return y
@@ -56,7 +59,7 @@ class Conv2d(nn.Conv2d):
                     and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding[0] == self.padding[1]):
                 return ops.dwconv(x, self.weight, self.padding[0], border)      # hand-written depthwise stencil
             assert border is None
-            return F.conv2d(x, self.weight, bias, self.stride, self.padding, self.dilation, self.groups)
+            return F.conv2d(ops.spikes_float(x), self.weight, bias, self.stride, self.padding, self.dilation, self.groups)
         N, C, H, W = x.shape
         M = self.out_channels
         kh, kw = self.kernel_size
@@ -66,7 +69,7 @@ class Conv2d(nn.Conv2d):
             return ops.conv_dense(x, self.weight, bias, self.stride[0], self.padding[0], self.spike_input)
         Ho = (H + 2 * self.padding[0] - self.dilation[0] * (kh - 1) - 1) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - self.dilation[1] * (kw - 1) - 1) // self.stride[1] + 1
-        cols = F.unfold(x, (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]
+        cols = F.unfold(ops.spikes_float(x), (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]
         return _gemm_nc(self.weight.view(M, -1), cols, bias, self.spike_input).view(N, M, Ho, Wo)
 
 

@@ -121,8 +121,14 @@ __device__ __forceinline__ void st4(float* p, const Tile4& t) {
   *reinterpret_cast<float4*>(p) = make_float4(t.a[0], t.a[1], t.a[2], t.a[3]);
 }
 
+// spikes as bf16 (exact: s2f_spikes_to_bf16x4); p addresses uint16 storage
+__device__ __forceinline__ void st4_bf16(float* p, int64_t base, const Tile4& t) {
+  *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + base) = s2f_spikes_to_bf16x4(t.a[0], t.a[1], t.a[2], t.a[3]);
+}
+
 // u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
-template <bool LIF, bool HAS_V>
+// YB: the spikes y are written as bf16 (2 bytes / element).
+template <bool LIF, bool HAS_V, bool YB>
 __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                           const double* __restrict__ sums, float* __restrict__ stat,
                                                           float* __restrict__ running_mean,
@@ -207,7 +213,10 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
       }
       if (u_out) st4(u_out + base, uo);
       if (LIF) {
-        st4(y + base, yo);
+        if (YB)
+          st4_bf16(y, base, yo);
+        else
+          st4(y + base, yo);
         if (v_out) st4(v_out + base, vo);
       }
     }
@@ -397,7 +406,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red, in
   }
 }
 
-template <bool LIF, bool HAS_V>
+template <bool LIF, bool HAS_V, bool YB>
 __global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ num_batches, const float* __restrict__ gamma,
@@ -478,7 +487,10 @@ __global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
       }
       if (u_out) st4(u_out + base[i], uo);
       if (LIF) {
-        st4(y + base[i], yo);
+        if (YB)
+          st4_bf16(y, base[i], yo);
+        else
+          st4(y + base[i], yo);
         if (v_out) st4(v_out + base[i], vo);
         const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
         const int64_t tile = base[i] >> 8;
@@ -620,9 +632,10 @@ extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums
 
 extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
                               float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
-                              const float* beta, const float* residual, float* u_out, const float* v_in, float* y,
+                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
                               float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
-                              float momentum, float eps, int training, float vth, int D, void* stream) {
+                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
+  float* y = reinterpret_cast<float*>(y_out);
   S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
   const bool single = training && single_pass_ok(N, C, L);
   S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
@@ -643,29 +656,43 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   const float unbias = count > 1 ? (float)(count / (count - 1.0)) : 1.0f;
   if (single) {
     const dim3 fgrid((unsigned)C), fblock(single_pass_threads(N, L));
-#define S2F_BN_FUSED(LIFV, HASV)                                                                                         \
-  S2F_LAUNCH(true, true, (bn_fused_fwd_kernel<LIFV, HASV>), fgrid, fblock, 0, s, z, conv_bias, stat_out, running_mean,    \
-             running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C, (int)L, inv_count, \
-             unbias, momentum, eps, vth, (float)D)
+#define S2F_BN_FUSED(LIFV, HASV, YBV)                                                                                    \
+  S2F_LAUNCH(true, true, (bn_fused_fwd_kernel<LIFV, HASV, YBV>), fgrid, fblock, 0, s, z, conv_bias, stat_out,             \
+             running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C,      \
+             (int)L, inv_count, unbias, momentum, eps, vth, (float)D)
     if (y == nullptr)
-      S2F_BN_FUSED(false, false);
-    else if (v_in == nullptr)
-      S2F_BN_FUSED(true, false);
-    else
-      S2F_BN_FUSED(true, true);
+      S2F_BN_FUSED(false, false, false);
+    else if (v_in == nullptr) {
+      if (y_bf16)
+        S2F_BN_FUSED(true, false, true);
+      else
+        S2F_BN_FUSED(true, false, false);
+    } else {
+      if (y_bf16)
+        S2F_BN_FUSED(true, true, true);
+      else
+        S2F_BN_FUSED(true, true, false);
+    }
 #undef S2F_BN_FUSED
     return s2f_check_launch("s2f_bn_act_fwd");
   }
-#define S2F_BN_APPLY(LIFV, HASV)                                                                                        \
-  S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV>), grid, block, 3 * C * sizeof(float) + 64, s, z, conv_bias, sums, stat_out, running_mean, \
+#define S2F_BN_APPLY(LIFV, HASV, YBV)                                                                                   \
+  S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, 3 * C * sizeof(float) + 64, s, z, conv_bias, sums, stat_out, running_mean, \
                      running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L,   \
                      inv_count, unbias, momentum, eps, training, vth, (float)D)
   if (y == nullptr)
-    S2F_BN_APPLY(false, false);
-  else if (v_in == nullptr)
-    S2F_BN_APPLY(true, false);
-  else
-    S2F_BN_APPLY(true, true);
+    S2F_BN_APPLY(false, false, false);
+  else if (v_in == nullptr) {
+    if (y_bf16)
+      S2F_BN_APPLY(true, false, true);
+    else
+      S2F_BN_APPLY(true, false, false);
+  } else {
+    if (y_bf16)
+      S2F_BN_APPLY(true, true, true);
+    else
+      S2F_BN_APPLY(true, true, false);
+  }
 #undef S2F_BN_APPLY
   return s2f_check_launch("s2f_bn_act_fwd");
 }

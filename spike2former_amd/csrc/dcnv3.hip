@@ -457,7 +457,7 @@ extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const floa
     return s2f_check_launch("s2f_dcnv3_bwd");
   }
   // global-atomic path: grad_input is accumulated into, zero it first (stream-ordered, capturable)
-  if (hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)N * H * W * G * Cg, (hipStream_t)stream) != hipSuccess)
+  if (s2f_zero_async(grad_input, sizeof(float) * (size_t)N * H * W * G * Cg, (hipStream_t)stream) != S2F_OK)
     return s2f_check_launch("s2f_dcnv3_bwd");
   const bool vec = (Cg % 4 == 0) && s2f_aligned16(input) && s2f_aligned16(grad_output);
   if (vec)

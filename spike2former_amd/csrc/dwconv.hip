@@ -320,7 +320,7 @@ extern "C" int s2f_dwconv_bwd_weight(const float* x, const float* border, const 
   int rc = check("s2f_dwconv_bwd_weight", N, C, H, W, K, pad, Ho, Wo);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C * K * K, s) != hipSuccess)
+  if (!accumulate && s2f_zero_async(gw, sizeof(float) * (size_t)C * K * K, s) != S2F_OK)
     return s2f_check_launch("s2f_dwconv_bwd_weight memset");
   const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
   const int ntiles = tiles_x * tiles_y;

@@ -64,6 +64,55 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ w, unsigned short*
   }
 }
 
+// Every weight of the model in ONE launch (the re-split a training step needs after the optimiser has changed them; also
+// what a captured hipGraph replays, so that a replay reads the LIVE fp32 weights).  jobs: int64 [njobs][8] =
+// {src fp32 pointer, dst bf16 pointer, M, K, Mpad, Kpad, mode | (C << 8), first workgroup}; a workgroup converts 1024
+// consecutive destination elements of its job.  mode 0: src is the [M][K] matrix; mode 1: src is a conv weight [M][C][3][3]
+// read TAP-MAJOR, (m, k = tap C + c) = src[(m C + c) 9 + tap]; mode 2: the transposed-convolution matrix of a conv weight
+// [Mw][Crows][3][3] with flipped taps, (c, k = tap Mw + mm) = src[(mm Crows + c) 9 + 8 - tap]  (C field = Mw, M = Crows).
+__global__ __launch_bounds__(256) void split_multi_kernel(const long long* __restrict__ jobs, int njobs) {
+  // binary search: last job whose first workgroup <= blockIdx.x
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[(int64_t)mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* j = jobs + (int64_t)lo * 8;
+  const float* __restrict__ w = reinterpret_cast<const float*>(j[0]);
+  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j[1]);
+  const int M = (int)j[2], K = (int)j[3], Kpad = (int)j[5];
+  const int64_t total = (int64_t)j[4] * Kpad;
+  const int mode = (int)(j[6] & 255), C = (int)(j[6] >> 8);
+  const int64_t base = ((int64_t)blockIdx.x - j[7]) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = base + u * 256 + threadIdx.x;
+    if (i >= total) continue;
+    const int m = (int)(i / Kpad), k = (int)(i % Kpad);
+    unsigned short h = 0, md = 0, l = 0;
+    if (m < M && k < K) {
+      int64_t src;
+      if (mode == 0) {
+        src = (int64_t)m * K + k;
+      } else if (mode == 1) {
+        const int tap = k / C, c = k - tap * C;
+        src = ((int64_t)m * C + c) * 9 + tap;
+      } else {
+        const int tap = k / C, mm = k - tap * C;
+        src = ((int64_t)mm * M + m) * 9 + (8 - tap);
+      }
+      const float v = w[src];
+      h = f2bf(v);
+      const float r1 = v - bf2f(h);
+      md = f2bf(r1);
+      l = f2bf(r1 - bf2f(md));
+    }
+    out[i] = h;
+    out[total + i] = md;
+    out[2 * total + i] = l;
+  }
+}
+
 // (v0, v1) -> three packed bf16 pairs hi, mid, lo with v = hi + mid + lo to 24 bits; v_cvt_pk_bf16_f32 rounds to nearest
 // even, the residuals are exact fp32 subtractions.
 __device__ __forceinline__ unsigned int pack2(f32x2 v) {
@@ -596,6 +645,15 @@ extern "C" int s2f_split_bf16x3(const float* w, uint16_t* out, int M, int K, int
   return s2f_check_launch("s2f_split_bf16x3");
 }
 
+extern "C" int s2f_split_bf16x3_multi(const int64_t* jobs, int njobs, int64_t total_workgroups, void* stream) {
+  if (njobs == 0) return S2F_OK;
+  S2F_REQUIRE(jobs && njobs > 0 && total_workgroups > 0 && total_workgroups < (1ll << 31), S2F_EINVAL,
+              "s2f_split_bf16x3_multi: bad job table");
+  hipLaunchKernelGGL(split_multi_kernel, dim3((unsigned)total_workgroups), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), njobs);
+  return s2f_check_launch("s2f_split_bf16x3_multi");
+}
+
 static int spike_gemm_launch(const char* who, const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch,
                              int M, int N, int K, int Mpad, int Kpad, int terms, bool conv, Conv3 geo, void* stream) {
   S2F_REQUIRE(w_split && X && Y, S2F_EINVAL, "%s: null pointer", who);
@@ -738,7 +796,7 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
               "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
   S2F_REQUIRE(s2f_aligned16(dY) && s2f_aligned16(X), S2F_EALIGN, "s2f_spike_gemm_dw: dY / X must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * K, s) != hipSuccess)
+  if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, s) != S2F_OK)
     return s2f_check_launch("s2f_spike_gemm_dw memset");
   S2F_REQUIRE(x_terms == 1 || x_terms == 3, S2F_EINVAL, "s2f_spike_gemm_dw: x_terms must be 1 (X exact in bf16) or 3");
   // rows of dY per output tile: narrow tiles for the small-M gradients (spike X only)

@@ -1,0 +1,506 @@
+// Spike GEMMs whose activation operand ARRIVES in bf16 (gfx950).
+//
+// The neuron kernels write spikes -- multiples of 1/D, at most 8 significant bits -- as bf16 (2 bytes / element instead of
+// 4), channel-major [batch, K, N] with N contiguous, exactly the layout the fp32 path used.  With the operand already in
+// the matrix cores' input type the K loops below contain loads, LDS traffic and MFMAs only:
+//   forward  Y[b] = W @ X[b]          X tile copied global -> LDS as it lies in memory ([k][n], 16-byte chunks, no
+//                                     conversion, no register transposition); the MFMA B fragments (k-contiguous per
+//                                     column) are formed by the LDS transpose read ds_read_b64_tr_b16;
+//   dW       dW = sum_b dY[b] X[b]^T  X rows are contraction-contiguous: copied as they lie, read as ds_read_b128.
+// W is pre-split into hi + mid + lo bf16 terms (s2f_split_bf16x3), dY is split in the kernel: exact products, fp32
+// accumulation, the accuracy of an fp32 GEMM (see gemm.hip).
+// Reference call sites: every 1x1 Conv2d / Conv1d / kxk convolution fed by a Q_IFNode (sdtv2.py:121-125, 197-204, 229-235,
+// 304-306, 399-405; mmcv_spike/transformer.py:213-236, 758-763; pixel_decoder.py:368-404; SNN_core.py:31-45).
+#include "gemm_common.h"
+#include <cstdlib>
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int BN = 128;
+constexpr int BK = 32;
+constexpr int LDA = 40;          // A rows in LDS: 32 + 8 bf16 = 80 bytes (conflict-free ds_read_b128 fragments)
+
+// 4 consecutive pixels n .. n+3 of one bf16 plane shifted by the 3x3 tap: ONE 8-byte load at 2-byte alignment; the pixel
+// that falls off the image row at its left / right end is zeroed, a row outside the plane reads as zeros.
+__device__ __forceinline__ u32x2 conv3_load_bf16(const unsigned short* __restrict__ plane, int n, int y, int x, int ky,
+                                                 int kx, Conv3 g, bool ok) {
+  const int yy = y + ky - 1;
+  ok = ok && yy >= 0 && yy < g.H;
+  const bool cut_l = kx == 0 && x == 0, cut_r = kx == 2 && x + 4 == g.W;
+  // never address outside the plane: at a cut end load the aligned neighbour group and shift in registers
+  const int off = (ky - 1) * g.W + (kx - 1) + (cut_l ? 1 : 0) - (cut_r ? 1 : 0);
+  const u32x2 v = ok ? *reinterpret_cast<const u32x2*>(plane + (ok ? n + off : 0)) : u32x2{0u, 0u};
+  if (cut_l) return u32x2{v.x << 16, (v.y << 16) | (v.x >> 16)};          // {0, p0, p1, p2}
+  if (cut_r) return u32x2{(v.x >> 16) | (v.y << 16), v.y >> 16};          // {p1, p2, p3, 0}
+  return v;
+}
+
+template <int CH>
+struct Chunk;
+template <>
+struct Chunk<8> {
+  typedef u32x4 type;
+};
+template <>
+struct Chunk<4> {
+  typedef u32x2 type;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward.  Block = WM x 2 wavefronts (x KG split-K groups), wavefront tile 64 x 64 = 2 x 2 MFMA tiles, block tile
+// (64 WM) x 128, K step 32 -- the tiling of spike_gemm_kernel (gemm.hip).
+// X tile in LDS: [32 k][128 n] bf16, rows of 256 bytes, the 64-byte chunk c of row k stored at chunk c ^ (k & 3): the four
+// rows k0 .. k0+3 that the 32 lanes of one transpose read touch then cover all 64 banks once.
+// CH = bf16 elements per staged chunk: 8 (16-byte loads, N % 8 == 0) or 4 (8-byte loads: N % 4 == 0, and the implicit
+// 3x3 mode whose shifted rows are only 2-byte aligned).
+template <int WM, int TERMS, int CH, bool CONV, int KG>
+__global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigned short* __restrict__ Wsplit,
+                                                                   const unsigned short* __restrict__ X,
+                                                                   const float* __restrict__ bias, float* __restrict__ Y,
+                                                                   int M, int N, int K, int Mpad, int Kpad, int n_tiles,
+                                                                   int m_tiles, Conv3 geo) {
+  constexpr int BM = 64 * WM;
+  constexpr int T = 128 * WM;
+  constexpr int A_ELEMS = TERMS * BM * LDA;
+  constexpr int GROUP_ELEMS = A_ELEMS + BK * BN;
+  constexpr int RED_BYTES = (KG - 1) * T * 64 * 4;
+  constexpr int LDS_BYTES = KG * GROUP_ELEMS * 2 > RED_BYTES ? KG * GROUP_ELEMS * 2 : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  const int grp = KG > 1 ? threadIdx.x / T : 0;
+  const int tid = KG > 1 ? threadIdx.x - grp * T : threadIdx.x;
+  unsigned short(*As)[BM][LDA] = reinterpret_cast<unsigned short(*)[BM][LDA]>(smem + (size_t)grp * GROUP_ELEMS * 2);
+  unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + (size_t)grp * GROUP_ELEMS * 2 + (size_t)A_ELEMS * 2);
+
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;          // XCD-aware tile order (see gemm.hip)
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const unsigned short* Xb = X + (int64_t)b * (CONV ? K / 9 : K) * N;
+  float* Yb = Y + (int64_t)b * M * N;
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t term_stride = (int64_t)Mpad * Kpad;
+  constexpr int CPR = BN / CH;                        // chunks per X row
+  constexpr int NQ = BK * CPR / T;                    // chunks per thread and K step
+  static_assert(NQ >= 1, "tile too small for the thread count");
+  typedef typename Chunk<CH>::type chunk_t;
+  u32x4 areg[TERMS][2];
+  chunk_t breg[NQ];
+
+  const int kloop = (Kpad + KG * BK - 1) / (KG * BK) * (KG * BK);
+  auto fetch = [&](int kk) __attribute__((always_inline)) {
+    const bool live = KG == 1 || kk < Kpad;
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = tid + h * T;
+        areg[t][h] = live ? *reinterpret_cast<const u32x4*>(Wsplit + t * term_stride + (int64_t)(m0 + (c >> 2)) * Kpad + kk +
+                                                           (c & 3) * 8)
+                          : u32x4{0u, 0u, 0u, 0u};
+      }
+    const int tap = CONV ? kk / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky;       // uniform over the step (C % 32 == 0)
+    const int c0 = CONV ? kk - tap * geo.C : 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = tid + q * T;
+      const int kr = p / CPR, nc = p % CPR;
+      const int n = n0 + nc * CH;
+      const bool ok = live && kk + kr < K && n < N;          // N % CH == 0: a chunk is valid as a whole
+      if constexpr (CONV) {
+        const int py = n / geo.W, px = n - py * geo.W;
+        breg[q] = conv3_load_bf16(Xb + (int64_t)(ok ? c0 + kr : 0) * N, n, py, px, ky, kx, geo, ok);
+      } else {
+        chunk_t z;
+#pragma unroll
+        for (int e = 0; e < CH / 2; ++e) z[e] = 0u;
+        breg[q] = ok ? *reinterpret_cast<const chunk_t*>(Xb + (int64_t)(kk + kr) * N + n) : z;
+      }
+    }
+  };
+
+  // per-lane part of the transpose-read addresses (bf16 elements): row 8 (lane >> 5) + kl, kl = (lane & 15) >> 2; inside the
+  // 32-column chunk the lane addresses columns 16 ((lane >> 4) & 1) + 4 (lane & 3)
+  const int kl = (lane & 15) >> 2;
+  int boff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    boff[j] = (8 * (lane >> 5) + kl) * BN + (((wn * 2 + j) ^ kl) << 5) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  fetch(grp * BK);
+  for (int k0 = grp * BK; k0 < kloop; k0 += KG * BK) {
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = tid + h * T;
+        *reinterpret_cast<u32x4*>(&As[t][c >> 2][(c & 3) * 8]) = areg[t][h];
+      }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = tid + q * T;
+      const int kr = p / CPR, nc = p % CPR;
+      constexpr int CPC = 32 / CH;                        // chunks per 64-byte swizzle unit
+      *reinterpret_cast<chunk_t*>(Bs + kr * BN + ((((nc / CPC) ^ (kr & 3))) << 5) + (nc % CPC) * CH) = breg[q];
+    }
+    __syncthreads();
+    if (k0 + KG * BK < kloop) fetch(k0 + KG * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kof = ks * 16 + 8 * (lane >> 5);
+      bf16x8 bfrag[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        union {
+          bf16x8 v;
+          s16x4 h[2];
+        } u;
+        u.h[0] = s2f_lds_tr16(Bs + boff[j] + (ks * 16) * BN);
+        u.h[1] = s2f_lds_tr16(Bs + boff[j] + (ks * 16 + 4) * BN);
+        bfrag[j] = u.v;
+      }
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  if (KG > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    if (grp > 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((grp - 1) * 4 + i * 2 + j) * 16 + r) * T + tid] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((g - 1) * 4 + i * 2 + j) * 16 + r) * T + tid];
+  }
+  // epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[row];
+          Yb[(int64_t)row * N + col] = v;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient with a bf16 activation:  dW[m][k] = sum_b sum_l dY[b][m][l] X[b][k][l].  The structure of
+// spike_gemm_dw_kernel (gemm.hip: 4 waves, output tile TM x 128, split-K over B*L with fp32 atomics, dY split hi+mid+lo
+// while it is staged); the X tile is copied as it lies (8-byte chunks of 4 contraction elements).
+template <int BKV, bool CONV, int TM>
+__global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
+                                                            const unsigned short* __restrict__ X, float* __restrict__ dW,
+                                                            int B, int M, int K, int L, int steps_per_split, int k_tiles,
+                                                            Conv3 geo, int log_w) {
+  constexpr int LD = BKV + 8;
+  constexpr int QPR = BKV / 4;                 // 4-element chunks per row
+  constexpr int NH = 128 * QPR / 256;          // X chunks per thread
+  constexpr int NHA = TM * QPR / 256;          // dY chunks per thread
+  constexpr int WMW = TM == 128 ? 2 : 1, WNW = 4 / WMW;
+  constexpr int MI = TM / WMW / 32, NJ = 128 / WNW / 32;
+  static_assert(NHA >= 1 && MI >= 1 && NJ >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][TM][LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[128][LD];
+  const int tile = blockIdx.x;
+  const int m0 = (tile / k_tiles) * TM, k0 = (tile % k_tiles) * 128;
+  const int lsteps = (L + BKV - 1) / BKV;
+  const int total_steps = B * lsteps;
+  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_end = min(total_steps, s_begin + steps_per_split);
+  if (s_begin >= s_end) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WNW, wn = wave % WNW;
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[NHA];
+  u32x2 breg[NH];
+  int crow[NH], ctap[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int k = min(k0 + (tid + h * 256) / QPR, K - 1);
+    ctap[h] = CONV ? k / geo.C : 0;
+    crow[h] = CONV ? k - ctap[h] * geo.C : 0;
+  }
+  auto fetch = [&](int step, f32x4 (&a)[NHA], u32x2 (&bq)[NH]) {
+    const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int c = tid + h * 256;
+      const int row = c / QPR, l = l0 + (c % QPR) * 4;
+      const bool lok = l < L;
+      if (h < NHA)
+        a[h < NHA ? h : 0] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (CONV) {
+        const bool ok = lok && k0 + row < K;
+        bq[h] = conv3_load_bf16(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3,
+                                ctap[h] % 3, geo, ok);
+      } else {
+        bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const u32x2*>(X + ((int64_t)b * K + k0 + row) * L + l)
+                                      : u32x2{0u, 0u};
+      }
+    }
+  };
+  fetch(s_begin, areg, breg);
+  for (int step = s_begin; step < s_end; ++step) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int c = tid + h * 256;
+      const int row = c / QPR, col = (c % QPR) * 4;
+      if (h < NHA) {
+        const f32x4 av = areg[h < NHA ? h : 0];
+        unsigned int h0, m0_, l0_, h1, m1, l1;
+        s2f_split3x2(av.x, av.y, h0, m0_, l0_);
+        s2f_split3x2(av.z, av.w, h1, m1, l1);
+        *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
+      }
+      *reinterpret_cast<u32x2*>(&Bs[row][col]) = breg[h];
+    }
+    __syncthreads();
+    if (step + 1 < s_end) fetch(step + 1, areg, breg);
+#pragma unroll
+    for (int ks = 0; ks < BKV / 16; ++ks) {
+      const int kof = ks * 16 + 8 * (lane >> 5);
+      bf16x8 bfrag[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bfrag[j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * (NJ * 32) + j * 32 + (lane & 31)][kof]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = k0 + wn * (NJ * 32) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
+      }
+    }
+}
+
+// fp32 -> bf16 of an exactly representable tensor (spikes handed over by a caller that still holds them in fp32):
+// truncation == rounding for such values; 4 elements per thread.
+__global__ void to_bf16_exact_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    *reinterpret_cast<u32x2*>(y + 4 * i) = u32x2{s2f_pack2(f32x2{v.x, v.y}), s2f_pack2(f32x2{v.z, v.w})};
+  }
+}
+
+int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch, int M, int N,
+               int K, int Mpad, int Kpad, int terms, bool conv, Conv3 geo, void* stream) {
+  S2F_REQUIRE(w_split && X && Y, S2F_EINVAL, "%s: null pointer", who);
+  S2F_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL, "%s: bad sizes", who);
+  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "%s: N=%d must be a multiple of 4", who, N);
+  S2F_REQUIRE(Kpad >= K && Kpad % 32 == 0 && Mpad >= M && Mpad % 64 == 0, S2F_EINVAL, "%s: bad padding", who);
+  S2F_REQUIRE(s2f_aligned16(w_split) && s2f_aligned16(X) && s2f_aligned16(Y), S2F_EALIGN,
+              "%s: pointers must be 16-byte aligned", who);
+  S2F_REQUIRE(batch < 65536, S2F_EINVAL, "%s: batch too large", who);
+  hipStream_t s = (hipStream_t)stream;
+  const int n_tiles = (N + BN - 1) / BN;
+  int wm = 1;
+  for (int cand = 4; cand >= 1; cand >>= 1) {          // tile choice as in gemm.hip
+    if (Mpad % (64 * cand) != 0) continue;
+    if (cand > 1 && M <= 32 * cand) continue;
+    const int64_t blocks = (int64_t)n_tiles * (Mpad / (64 * cand)) * batch;
+    if (blocks >= 512 || cand == 1) {
+      wm = cand;
+      break;
+    }
+  }
+  static const char* force_wm = getenv("S2F_GEMM_WM");           // probe switch
+  if (force_wm && Mpad % (64 * atoi(force_wm)) == 0) wm = atoi(force_wm);
+  const int m_tiles = Mpad / (64 * wm);
+  const dim3 grid(n_tiles * m_tiles, batch);
+  const bool thin = wm == 1 && (int64_t)n_tiles * m_tiles * batch < 512;
+  const int kg = (thin && Kpad >= 4 * BK) ? 2 : 1;
+  const bool wide = !conv && (N & 7) == 0;              // 16-byte chunks
+#define S2F_GO(WMV, TV, CHV, CV, KGV)                                                                                    \
+  S2F_LAUNCH(true, true, (sgemm_bf16_kernel<WMV, TV, CHV, CV, KGV>), grid, dim3(128 * WMV * KGV), 0, s, w_split, X, bias, Y, \
+             M, N, K, Mpad, Kpad, n_tiles, m_tiles, geo)
+#define S2F_T(WMV, CHV, CV, KGV)                    \
+  if (terms == 3) S2F_GO(WMV, 3, CHV, CV, KGV);      \
+  else if (terms == 2) S2F_GO(WMV, 2, CHV, CV, KGV); \
+  else S2F_GO(WMV, 1, CHV, CV, KGV)
+#define S2F_W(CHV, CV)        \
+  if (wm == 4) {              \
+    S2F_T(4, CHV, CV, 1);     \
+  } else if (wm == 2) {       \
+    S2F_T(2, CHV, CV, 1);     \
+  } else if (kg == 2) {       \
+    S2F_T(1, CHV, CV, 2);     \
+  } else {                    \
+    S2F_T(1, CHV, CV, 1);     \
+  }
+  if (conv) {
+    S2F_W(4, true)
+  } else if (wide) {
+    S2F_W(8, false)
+  } else {
+    S2F_W(4, false)
+  }
+#undef S2F_W
+#undef S2F_T
+#undef S2F_GO
+  return s2f_check_launch(who);
+}
+
+int dw_launch(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate, bool conv,
+              Conv3 geo, int log_w, void* stream) {
+  S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw_bf16: null pointer");
+  S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
+              "s2f_spike_gemm_dw_bf16: bad sizes (L=%d must be a positive multiple of 4)", L);
+  S2F_REQUIRE(s2f_aligned16(dY) && (reinterpret_cast<uintptr_t>(X) & 7u) == 0, S2F_EALIGN,
+              "s2f_spike_gemm_dw_bf16: dY must be 16-byte, X 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, s) != S2F_OK)
+    return s2f_check_launch("s2f_spike_gemm_dw_bf16 memset");
+  // tile / step / split choice: the measured model of gemm.hip's spike_dw_launch
+  int tm = M <= 32 ? 32 : M <= 64 ? 64 : 128;
+  if (tm == 128 && (int64_t)batch * L <= 16384 && (int64_t)M * K > 65536) tm = 64;
+  const int m_tiles = (M + tm - 1) / tm, k_tiles = (K + 127) / 128;
+  const int bkv = (!conv && (L % 64 == 0 || L >= 512)) ? 64 : 32;
+  const int total_steps = batch * ((L + bkv - 1) / bkv);
+  const int tiles = m_tiles * k_tiles;
+  const double t_step = (bkv == 64 ? 2.3 : 1.2) * (tm == 32 ? 0.6 : tm == 64 ? 0.75 : 1.0),
+               t_mb = 0.6 * (double)M * K * 4.0 / 1e6;
+  int splits = 1;
+  double best = 1e30;
+  for (int cand = 1; cand <= total_steps && cand <= 65535; cand *= 2) {
+    const int steps = (total_steps + cand - 1) / cand;
+    const int64_t rounds = ((int64_t)tiles * cand + 511) / 512;
+    const double cost = (double)steps * t_step * (double)rounds + (double)cand * t_mb;
+    if (cost < best) {
+      best = cost;
+      splits = cand;
+    }
+  }
+  if (splits > total_steps) splits = total_steps;
+  if (splits > 65535) splits = 65535;
+  const int steps_per_split = (total_steps + splits - 1) / splits;
+  splits = (total_steps + steps_per_split - 1) / steps_per_split;
+#define S2F_DW1(BKV, CV, TMV)                                                                                            \
+  S2F_LAUNCH(true, true, (sgemm_dw_bf16_kernel<BKV, CV, TMV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, \
+             batch, M, K, L, steps_per_split, k_tiles, geo, log_w)
+#define S2F_DW(BKV, CV)             \
+  do {                              \
+    if (tm == 32)                   \
+      S2F_DW1(BKV, CV, 32);         \
+    else if (tm == 64)              \
+      S2F_DW1(BKV, CV, 64);         \
+    else                            \
+      S2F_DW1(BKV, CV, 128);        \
+  } while (0)
+  if (conv)
+    S2F_DW(32, true);
+  else if (bkv == 64)
+    S2F_DW(64, false);
+  else
+    S2F_DW(32, false);
+#undef S2F_DW
+#undef S2F_DW1
+  return s2f_check_launch("s2f_spike_gemm_dw_bf16");
+}
+
+}  // namespace
+
+extern "C" int s2f_to_bf16_exact(const float* x, uint16_t* y, int64_t n, void* stream) {
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(x && y && n > 0 && (n & 3) == 0, S2F_EINVAL, "s2f_to_bf16_exact: null pointer or n %% 4 != 0");
+  S2F_REQUIRE(s2f_aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0, S2F_EALIGN, "s2f_to_bf16_exact: alignment");
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(to_bf16_exact_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n / 4);
+  return s2f_check_launch("s2f_to_bf16_exact");
+}
+
+extern "C" int s2f_spike_gemm_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch,
+                                       int M, int N, int K, int Mpad, int Kpad, int terms, void* stream) {
+  return fwd_launch("s2f_spike_gemm_fwd_bf16", w_split, X, bias, Y, batch, M, N, K, Mpad, Kpad, terms, false, Conv3{0, 0, 0},
+                    stream);
+}
+
+extern "C" int s2f_spike_conv3x3_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch,
+                                          int M, int C, int H, int W, int Mpad, int Kpad, int terms, void* stream) {
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W > 0 && (W & 3) == 0, S2F_EINVAL,
+              "s2f_spike_conv3x3_fwd_bf16: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  S2F_REQUIRE((int64_t)C * 9 < (1 << 30) && (int64_t)H * W < (1 << 30), S2F_EINVAL, "s2f_spike_conv3x3_fwd_bf16: too large");
+  return fwd_launch("s2f_spike_conv3x3_fwd_bf16", w_split, X, bias, Y, batch, M, H * W, C * 9, Mpad, Kpad, terms, true,
+                    Conv3{H, W, C}, stream);
+}
+
+extern "C" int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L,
+                                      int accumulate, void* stream) {
+  return dw_launch(dY, X, dW, batch, M, K, L, accumulate, false, Conv3{0, 0, 0}, 0, stream);
+}
+
+extern "C" int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,
+                                         int accumulate, void* stream) {
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & (W - 1)) == 0, S2F_EINVAL,
+              "s2f_spike_conv3x3_dw_bf16: need C %% 32 == 0 and W a power of two >= 4 (C=%d, W=%d)", C, W);
+  int log_w = 0;
+  while ((1 << log_w) < W) ++log_w;
+  return dw_launch(dY, X, dW, batch, M, C * 9, H * W, accumulate, true, Conv3{H, W, C}, log_w, stream);
+}

@@ -49,6 +49,14 @@ extern "C" int s2f_event_elapsed_us(void* start_event, void* stop_event, double*
 }
 extern "C" int64_t s2f_lif_mask_words(int64_t n) { return ((n + 255) >> 8) * 4; }
 
+__global__ void s2f_zero_kernel(float* __restrict__ p, int64_t n) {
+  const bool vec = (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -85,6 +93,16 @@ __device__ __forceinline__ void store4(float* p, int64_t base, int64_t n, const 
   }
 }
 
+__device__ __forceinline__ void store4_bf16(unsigned short* p, int64_t base, int64_t n, const Tile4& t) {
+  if (base + 3 < n) {
+    *reinterpret_cast<uint2*>(p + base) = s2f_spikes_to_bf16x4(t.a[0], t.a[1], t.a[2], t.a[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (base + j < n) p[base + j] = (unsigned short)(__float_as_uint(t.a[j]) >> 16);
+  }
+}
+
 __device__ __forceinline__ void write_mask(uint64_t* mask, int64_t tile, int lane, const bool inr[4]) {
   // wave ballot of each component; word j bit l <-> element 256*tile + 4*l + j
   uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
@@ -95,7 +113,8 @@ __device__ __forceinline__ void write_mask(uint64_t* mask, int64_t tile, int lan
 }
 
 // ------------------------------------------------------------------ single step
-template <bool HAS_V>
+// YB: the spikes are written as bf16 (exact, see s2f_spikes_to_bf16x4) -- y then points to uint16 storage
+template <bool HAS_V, bool YB>
 __global__ __launch_bounds__(kBlock) void lif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v_in,
                                                          float* __restrict__ y, float* __restrict__ v_out,
                                                          uint64_t* __restrict__ mask, uint8_t* __restrict__ cnt,
@@ -128,7 +147,10 @@ __global__ __launch_bounds__(kBlock) void lif_fwd_kernel(const float* __restrict
       }
       c4 |= si << (8 * j);
     }
-    store4(y, base, n, yv);
+    if (YB)
+      store4_bf16(reinterpret_cast<unsigned short*>(y), base, n, yv);
+    else
+      store4(y, base, n, yv);
     if (v_out != nullptr) store4(v_out, base, n, vo);
     if (cnt != nullptr) {
       if (base + 3 < n) {
@@ -195,6 +217,7 @@ __global__ __launch_bounds__(kBlock) void lif_bwd_kernel(const float* __restrict
 // = the decoder's value / key neurons applied to  memory + level_embed  and  memory + level_embed + key_pos
 // (mmdet/models/dense_heads/maskformer_head.py:535-540; mmcv_spike/transformer.py:626-629, 213-236) without materialising
 // the two sums: they are read by nothing but these neurons.  Reset, stateless neurons only (no membrane in / out).
+template <bool YB>
 __global__ __launch_bounds__(kBlock) void sum2_lif_fwd_kernel(const float* __restrict__ x, const float* __restrict__ e,
                                                               const float* __restrict__ pos, float* __restrict__ yk,
                                                               float* __restrict__ yv, uint64_t* __restrict__ mk,
@@ -222,8 +245,13 @@ __global__ __launch_bounds__(kBlock) void sum2_lif_fwd_kernel(const float* __res
         s2f_lif_update(a + pv.a[j], Df, 1.0f, vth, sp, yy, vn, ik[j]);
         ok.a[j] = sp / Df;
       }
-      store4(yv, base, n, ov);
-      store4(yk, base, n, ok);
+      if (YB) {
+        store4_bf16(reinterpret_cast<unsigned short*>(yv), base, n, ov);
+        store4_bf16(reinterpret_cast<unsigned short*>(yk), base, n, ok);
+      } else {
+        store4(yv, base, n, ov);
+        store4(yk, base, n, ok);
+      }
     }
     write_mask(mk, tile, lane, ik);
     write_mask(mv, tile, lane, iv);
@@ -372,8 +400,9 @@ inline int grid_for(int64_t n) {
 
 }  // namespace
 
-extern "C" int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v_out, uint64_t* mask, uint8_t* count_u8,
-                           uint64_t* stats, int64_t n, float vth, int D, void* stream) {
+extern "C" int s2f_lif_fwd(const float* x, const float* v_in, void* y_out, float* v_out, uint64_t* mask, uint8_t* count_u8,
+                           uint64_t* stats, int64_t n, float vth, int D, int y_bf16, void* stream) {
+  float* y = reinterpret_cast<float*>(y_out);
   if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_lif_fwd: null x/y");
   S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_fwd: bad n=%lld or D=%d", (long long)n, D);
@@ -383,12 +412,21 @@ extern "C" int s2f_lif_fwd(const float* x, const float* v_in, float* y, float* v
               "s2f_lif_fwd: count_u8 must be 4-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   auto* st = reinterpret_cast<unsigned long long*>(stats);
-  if (v_in != nullptr)
-    S2F_LAUNCH(true, true, lif_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
-                       st, n, vth, (float)D);
-  else
-    S2F_LAUNCH(true, true, lif_fwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, count_u8,
-                       st, n, vth, (float)D);
+#define S2F_LIF_GO(HV, YBV)                                                                                            \
+  S2F_LAUNCH(true, true, (lif_fwd_kernel<HV, YBV>), dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask,     \
+             count_u8, st, n, vth, (float)D)
+  if (v_in != nullptr) {
+    if (y_bf16)
+      S2F_LIF_GO(true, true);
+    else
+      S2F_LIF_GO(true, false);
+  } else {
+    if (y_bf16)
+      S2F_LIF_GO(false, true);
+    else
+      S2F_LIF_GO(false, false);
+  }
+#undef S2F_LIF_GO
   return s2f_check_launch("s2f_lif_fwd");
 }
 
@@ -409,17 +447,23 @@ extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t*
   return s2f_check_launch("s2f_lif_bwd");
 }
 
-extern "C" int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, float* y_key, float* y_value,
+extern "C" int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, void* y_key_out, void* y_value_out,
                                 uint64_t* mask_key, uint64_t* mask_value, int64_t TB, int64_t B, int64_t C, int64_t L,
-                                float vth, int D, void* stream) {
+                                float vth, int D, int y_bf16, void* stream) {
+  float* y_key = reinterpret_cast<float*>(y_key_out);
+  float* y_value = reinterpret_cast<float*>(y_value_out);
   S2F_REQUIRE(x && e && pos && y_key && y_value && mask_key && mask_value, S2F_EINVAL, "s2f_sum2_lif_fwd: null pointer");
   S2F_REQUIRE(TB > 0 && B > 0 && TB % B == 0 && C > 0 && L > 0 && (L & 3) == 0 && D >= 1 && D <= 255, S2F_EINVAL,
               "s2f_sum2_lif_fwd: bad shape (L must be a multiple of 4, TB a multiple of B)");
   S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(pos) && s2f_aligned16(y_key) && s2f_aligned16(y_value), S2F_EALIGN,
               "s2f_sum2_lif_fwd: tensors must be 16-byte aligned");
   const int64_t n = TB * C * L;
-  S2F_LAUNCH(true, true, sum2_lif_fwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, e, pos, y_key,
-             y_value, mask_key, mask_value, n, (int)C, (int)L, (int)B, vth, (float)D);
+  if (y_bf16)
+    S2F_LAUNCH(true, true, sum2_lif_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, e, pos,
+               y_key, y_value, mask_key, mask_value, n, (int)C, (int)L, (int)B, vth, (float)D);
+  else
+    S2F_LAUNCH(true, true, sum2_lif_fwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, e, pos,
+               y_key, y_value, mask_key, mask_value, n, (int)C, (int)L, (int)B, vth, (float)D);
   return s2f_check_launch("s2f_sum2_lif_fwd");
 }
 

@@ -60,3 +60,25 @@ __device__ __forceinline__ void s2f_lif_update(float h, float Df, float inv_d, f
   v_new = h - s * vth;
   in_range = (h >= 0.0f) && (h <= Df);
 }
+
+// Four spikes (multiples of 1/D, <= 8 significant bits) as bf16: the low 16 bits of such an fp32 are zero, so keeping the
+// high halves IS the exact conversion (no rounding instruction).
+__device__ __forceinline__ uint2 s2f_spikes_to_bf16x4(float a, float b, float c, float d) {
+  return make_uint2((__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u),
+                    (__float_as_uint(c) >> 16) | (__float_as_uint(d) & 0xffff0000u));
+}
+
+// Zero-fill by a KERNEL (grid-stride 16-byte stores; scalar tail).  The C ABI does not use hipMemsetAsync: a memset node in
+// a captured hipGraph gave garbage weight gradients on ROCm 7.2 -- replays after unrelated eager allocate / free cycles
+// returned 1e20..1e37 in exactly the split-K outputs that were cleared by a memset node (tools/debug_graph_spikes.py; the
+// launches that cleared with a kernel were never affected).
+__global__ void s2f_zero_kernel(float* __restrict__ p, int64_t n);
+static inline int s2f_zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return S2F_OK;
+  const int64_t n = (int64_t)(bytes / 4);          // every caller clears fp32 / 4-byte-aligned storage
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(s2f_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<float*>(ptr), n);
+  return hipGetLastError() == hipSuccess ? S2F_OK : S2F_ELAUNCH;
+}

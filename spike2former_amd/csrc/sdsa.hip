@@ -217,7 +217,7 @@ extern "C" int s2f_sdsa_kv(const float* k, const float* v, float* kv, int TB, in
   hipStream_t s = (hipStream_t)stream;
   const int ns = pick_split(TB * heads, N);
   if (ns > 1) {
-    if (hipMemsetAsync(kv, 0, sizeof(float) * (size_t)TB * heads * d * d, s) != hipSuccess)
+    if (s2f_zero_async(kv, sizeof(float) * (size_t)TB * heads * d * d, s) != S2F_OK)
       return s2f_check_launch("s2f_sdsa_kv memset");
   }
   hipLaunchKernelGGL(outer_kernel, dim3(TB * heads, ns), dim3(256), 0, s, k, v, kv, heads, d, N, alpha);

@@ -346,7 +346,7 @@ extern "C" int s2f_mask_loss_fwd(const float* pred, const uint8_t* tgt, const in
   S2F_REQUIRE(P > 0 && P < 65536 && h > 0 && w > 0 && (w % 2) == 0, S2F_EINVAL, "s2f_mask_loss_fwd: need 0 < P < 65536, even w");
   S2F_REQUIRE((reinterpret_cast<uintptr_t>(tgt) & 3u) == 0, S2F_EALIGN, "s2f_mask_loss_fwd: targets must be 4-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)P, s) != hipSuccess) return s2f_check_launch("s2f_mask_loss_fwd memset");
+  if (s2f_zero_async(sums, sizeof(float) * 4 * (size_t)P, s) != S2F_OK) return s2f_check_launch("s2f_mask_loss_fwd memset");
   const int64_t total = (int64_t)2 * h * (2 * w / 4);
   int chunks = (int)((total + 256 * 8 - 1) / (256 * 8));       // >= 8 iterations per thread: few atomics per mask
   if (chunks < 1) chunks = 1;

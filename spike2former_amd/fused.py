@@ -10,7 +10,7 @@ from .neuron import Q_IFNode
 def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None,
            want_border=False, scale=None):
     """z: conv output WITHOUT its bias, [N, C, *].  Returns (u, y): u = BN(z + bias) [+ residual] (None unless wanted),
-    y = lif(u) (None without lif).  Shapes follow z.  want_border: also return BN(0) from the running statistics as
+    y = lif(u) as an ops.Spikes pair (None without lif).  Shapes follow z.  want_border: also return BN(0) from the running statistics as
     updated by this call (BNAndPadLayer's padding value, sdtv2.py:68-78) -- written by the same kernel.
     next_lif: the neuron that the caller's consumer will apply to `u` next (the first Q_IFNode of the following block on
     the residual stream).  Its update is done by this kernel as well and handed over with Q_IFNode.prefire: the reference's
@@ -35,13 +35,15 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
             u = u * scale.view(1, -1, *([1] * (z.dim() - 2)))
         if residual is not None:
             u = u + residual.reshape(shape)
-        out = (u if want_pre else None), (lif(u) if lif is not None else None)
+        out = (u if want_pre else None), (lif.fire(u) if lif is not None else None)
         if want_border:
             out += ((bn.bias.detach() - bn.running_mean * bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)),)
         return out
     v_in = None
     if lif is not None and not isinstance(lif.v, float):
-        v_in = lif.v
+        # the carried membrane enters as a constant: the fused kernel has no gradient path into it (ResetModelHook zeroes it
+        # before every training iteration, resetmodel_hook.py:17-37; the stand-alone neuron op does back-propagate through it)
+        v_in = lif.v.detach()
     if lif is not None and lif.stats is not None:
         lif.stats_elems += z.numel()
     weight, bias = (bn.weight, bn.bias) if scale is None else ops.scale_affine(bn.weight, bn.bias, scale)

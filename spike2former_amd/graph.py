@@ -5,6 +5,13 @@ before the GPU is busy.  Shapes are static (fixed crop, fixed T), so the step --
 forward, loss, backward -- is captured once into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: one host call
 per step.  The kernels launched through the C ABI take the capture stream like any other launch; the ABI allocates
 nothing and never synchronises, so it is capture-safe by construction (s2f_* use hipMemsetAsync only).
+
+Weights: the spike GEMMs read bf16 hi / mid / lo terms of every weight that `ops.split_weight*` caches per weight version.
+A captured step does not rely on that cache: `reset_net -> ops.begin_step` re-splits EVERY registered weight inside the
+graph (ops.resplit_all, one launch over a pointer table), so each replay multiplies by the live fp32 weights -- an optimiser
+step or load_state_dict between replays is honoured, forward and backward stay consistent
+(tests/test_gpu_full_size.py::test_graph_replay_follows_weight_updates).  Weights that enter the model only after the
+capture (none on this path) would need a new capture.
 """
 import torch
 
@@ -25,6 +32,7 @@ class GraphedStep:
             for _ in range(warmup):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        ops.resplit_all(self.static_in.device)          # builds the weight-split job table the captured step replays
         torch.cuda.synchronize()
         # With a process group alive, RCCL's watchdog thread polls its events while this thread captures: "thread_local"
         # keeps its (legal, uncaptured) calls from invalidating the capture; single-process runs keep the strict default.
@@ -79,6 +87,7 @@ class GraphedSplitStep:
                 outs = self._forward()
                 torch.autograd.grad(outs, params, [torch.ones_like(o) for o in outs], allow_unused=True)
         torch.cuda.current_stream().wait_stream(side)
+        ops.resplit_all(self.static_in.device)          # builds the weight-split job table graph A replays
         torch.cuda.synchronize()
         import torch.distributed as dist
         mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"

@@ -40,7 +40,7 @@ class SepConv_Spike(nn.Module):
         """Channel-major form: x, residual, result [T,B,C,H,W].  -> scale * SepConv(x) [+ residual]; the layer scale, the
         residual add and the next neuron on the stream are folded into the last BatchNorm kernel (fused.bn_act)."""
         T, B, C, H, W = x.shape
-        x = self.spike1(x).flatten(0, 1)
+        x = self.spike1.fire(x).flatten(0, 1)
         _, x = bn_act(self.pwconv1[0](x), None, self.pwconv1[1], lif=self.spike2)
         _, x = bn_act(self.dwconv[0](x), None, self.dwconv[1], lif=self.spike3)
         x, _ = bn_act(self.pwconv2[0](x), None, self.pwconv2[1], scale=scale, next_lif=next_lif,
@@ -127,7 +127,7 @@ class DCNv3_pytorch(nn.Module):
             return x.permute(0, 1, 3, 4, 2).contiguous().flatten(0, 1)              # [T*N, H, W, C]
 
         def offset_and_mask():
-            x1 = self.dw_spike(inp).flatten(0, 1)
+            x1 = self.dw_spike.fire(inp).flatten(0, 1)
             ops.use_here(x1)
             _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
             # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
@@ -171,7 +171,7 @@ class MS_MLP(nn.Module):
     def forward_nchw(self, x):
         """x [T,B,C,H,W] -> the FFN output as it lies in memory, [T*B, C, H*W] (the caller applies the reference's
         reinterpretation of that buffer as [T,B,H,W,C], :829)."""
-        x = self.fc1_spike(x.flatten(3)).flatten(0, 1)
+        x = self.fc1_spike.fire(x.flatten(3)).flatten(0, 1)
         _, x = bn_act(self.fc1_conv.forward_nobias(x), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
         x, _ = bn_act(self.fc2_conv.forward_nobias(x), self.fc2_conv.bias, self.fc2_bn)
         return x
@@ -268,7 +268,7 @@ class MultiHeadAttentionBlock(nn.Module):
     @staticmethod
     def _proj(spike_in, conv, spike_out, x, channel_major=False, fired=None):
         """neuron -> Conv1d -> BN1d -> neuron on [t,b,L,dim] (or channel-major [t,b,dim,L]) -> channel-major spikes [t*b, dim, L]"""
-        x = spike_in(x) if fired is None else fired
+        x = spike_in.fire(x) if fired is None else fired
         x = x.flatten(0, 1) if channel_major else x.permute(0, 1, 3, 2).flatten(0, 1)
         return bn_act(conv[0].forward_nobias(x), conv[0].bias, conv[1], lif=spike_out)[1]
 
@@ -303,7 +303,7 @@ class MultiHeadAttentionBlock(nn.Module):
                 lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query)],
                 inputs=(query, key, value, fk, fv))
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5))      # embed_dim**0.5, not head dim
-        o = self.attn_spike(o)
+        o = self.attn_spike.fire(o)
         o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
         return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
 
@@ -365,7 +365,7 @@ class MSDA_FFN(nn.Module):
 
     def forward(self, x, identity=None):
         t, bs, N, C = x.shape
-        a = self.fc1_spike(x).reshape(t * bs, C, N)
+        a = self.fc1_spike.fire(x).reshape(t * bs, C, N)
         _, a = bn_act(self.fc1.forward_nobias(a), self.fc1.bias, self.bn1, lif=self.fc2_spike)
         a, _ = bn_act(self.fc2.forward_nobias(a), self.fc2.bias, self.bn2)
         return a.reshape(t, bs, N, C)

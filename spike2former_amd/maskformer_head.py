@@ -91,7 +91,7 @@ class MaskFormerHead(nn.Module):
 
     def forward(self, x, batch_data_samples=None):
         """x: the 4 backbone maps.  -> all_cls_scores [L+1,B,Q,K+1], all_mask_preds [L+1,B,Q,H/2,W/2]."""
-        mask_features, memory, msm = self.pixel_decoder(x, None)
+        mask_features, memory, msm = self.pixel_decoder(x, None, spike_memory=True)
         t, bs = memory.shape[:2]
         query_feat = self.query_feat.weight.unsqueeze(0).repeat((t, bs, 1, 1))
         query_embed = self.query_embed.weight.unsqueeze(0).repeat(bs, 1, 1)

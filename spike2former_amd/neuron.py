@@ -49,7 +49,8 @@ class Q_IFNode(nn.Module):
         """The producer of `u` (fused.bn_act with next_lif=self) has already applied this neuron to it -- same update, same
         membrane / mask / firing counters as a call would have done; the next forward(u) just hands `y` out."""
         self._prefired = (u, u._version, y)          # holding u keeps its address from being reused while pending
-        if PURE_MEMO and isinstance(self.v, float) and not self.keep_membrane and self.stats is None and u.is_cuda:
+        if (PURE_MEMO and isinstance(self.v, float) and not self.keep_membrane and self.stats is None and u.is_cuda
+                and u.is_contiguous()):
             # ... and any other pure neuron applied to the same tensor (the pixel decoder's lateral neurons read the
             # backbone taps that the next backbone stage's first neuron was just applied to) gets it from the memo
             _PURE_MEMO[(u.data_ptr(), u._version, u.numel(), u.requires_grad, self.D, self.v_threshold)] = (u, y)
@@ -63,23 +64,35 @@ class Q_IFNode(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def forward(self, x):
+        """The reference's interface: fp32 in, fp32 spikes out."""
+        return self.fire(x, as_float=True)
+
+    def fire(self, x, as_float=False):
+        """One call of the neuron -> ops.Spikes: the spike map as the kernels of this package pass it on (bf16 data + fp32
+        autograd handle, ops.SPIKES_BF16).  `as_float`: the fp32 tensor instead (what `forward` returns)."""
+        if not as_float and (self._forward_hooks or self._forward_pre_hooks):
+            # somebody watches this neuron through nn.Module hooks (the reference's tools do): take the module call, whose
+            # hooks see the fp32 spikes of the reference's interface
+            return ops.as_spikes(self(x))
         pf, self._prefired = self._prefired, None
         if (pf is not None and pf[0].data_ptr() == x.data_ptr() and pf[0].numel() == x.numel() and x.is_contiguous()
                 and x._version == pf[1]):
-            return pf[2].view(x.shape)
+            y = pf[2].view(x.shape)
+            return y.float() if as_float else y
         v_in = None if isinstance(self.v, float) else self.v
         if self.stats is not None:
             self.stats_elems += x.numel()
         # A neuron that starts from a reset membrane, keeps none and records nothing is a pure function of its input: two
         # such neurons applied to the SAME tensor (the decoder's key / value neurons of the two layers that share a feature
         # level) share one kernel launch forward and one backward.  Cleared by reset_net().
-        pure = PURE_MEMO and v_in is None and not self.keep_membrane and self.stats is None and x.is_cuda
+        pure = (PURE_MEMO and v_in is None and not self.keep_membrane and self.stats is None and x.is_cuda
+                and x.is_contiguous() and not as_float)
         if pure:
             key = (x.data_ptr(), x._version, x.numel(), x.requires_grad, self.D, self.v_threshold)
             hit = _PURE_MEMO.get(key)
             if hit is not None:
-                return hit[1].view(x.shape)
-        y, v_out = ops.lif(x, v_in, self.D, self.v_threshold, self.keep_membrane, self.stats)
+                return hit[1].view(x.shape)          # both tensors are contiguous: same address + size = same layout
+        y, v_out = ops.lif(x, v_in, self.D, self.v_threshold, self.keep_membrane, self.stats, spikes=not as_float)
         if pure:
             _PURE_MEMO[key] = (x, y)                      # holding x keeps its address from being reused
         if self.keep_membrane:

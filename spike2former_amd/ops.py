@@ -12,25 +12,28 @@ from ._lib import check, lib
 KERNEL_EVENTS = None
 
 
-def _time_next(name, nbytes, flops=0):
+def _time_next(name, nbytes, flops=0, moved=None):
+    """nbytes: ALGORITHMIC bytes (the fp32 figures of the reference's tensors); moved: the bytes this build's kernel
+    actually reads + writes for them (bf16 spike maps), reported next to the algorithmic figure; flops: ALGORITHMIC flops
+    (2 M N K per GEMM -- not the 3 / 6 bf16 passes issued for them)."""
     if KERNEL_EVENTS is not None:
         e0, e1 = lib.s2f_event_create(), lib.s2f_event_create()
         if not e0 or not e1:
             raise RuntimeError("s2f_event_create failed: " + lib.s2f_last_error().decode())
         lib.s2f_time_next_call(e0, e1)
-        KERNEL_EVENTS.append((name, int(nbytes), int(flops), e0, e1))
+        KERNEL_EVENTS.append((name, int(nbytes), int(flops), e0, e1, int(nbytes if moved is None else moved)))
 
 
 def drain_kernel_events():
-    """-> [(name, algorithmic_bytes, flops, microseconds)] of the launches timed since KERNEL_EVENTS was set; synchronises,
-    frees the events and switches the timing off."""
+    """-> [(name, algorithmic_bytes, algorithmic_flops, microseconds, moved_bytes)] of the launches timed since KERNEL_EVENTS
+    was set; synchronises, frees the events and switches the timing off."""
     global KERNEL_EVENTS
     import ctypes
     torch.cuda.synchronize()
     out, us = [], ctypes.c_double()
-    for name, nbytes, flops, e0, e1 in (KERNEL_EVENTS or []):
+    for name, nbytes, flops, e0, e1, moved in (KERNEL_EVENTS or []):
         check(lib.s2f_event_elapsed_us(e0, e1, ctypes.byref(us)), "s2f_event_elapsed_us")
-        out.append((name, nbytes, flops, us.value))
+        out.append((name, nbytes, flops, us.value, moved))
         lib.s2f_event_destroy(e0)
         lib.s2f_event_destroy(e1)
     KERNEL_EVENTS = None
@@ -46,6 +49,18 @@ _ARENA_DOUBLES = 1 << 20
 
 
 def begin_step(device=None):
+    # a step that is being captured into a hipGraph re-splits every weight first (one launch, recorded in the graph): the
+    # replays then read the live fp32 weights instead of the bf16 terms of capture time
+    _TRUST_ALL[0] = False
+    if device is not None and torch.cuda.is_current_stream_capturing():
+        n = resplit_all(device, build=False)
+        if n > 0:
+            _TRUST_ALL[0] = True
+        elif n < 0:
+            # no job table for the current set of weights: forget every cached version instead, so that each weight is
+            # re-split by its own launch inside this capture (correct, ~180 launches more per replay)
+            for k, v in list(_SPLIT_CACHE.items()):
+                _SPLIT_CACHE[k] = (None,) + v[1:]
     a = _ARENA
     if a["buf"] is None:
         if device is None:
@@ -74,12 +89,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _need_cuda(*ts):
+def _need_cuda(*ts, spikes=None):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         if t is not None and t.dtype != torch.float32:
             raise RuntimeError(f"spike2former_amd ops compute in fp32; got {t.dtype}")
+    if spikes is not None:
+        if not spikes.is_cuda:
+            raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+        if spikes.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"a spike operand is fp32 or bf16; got {spikes.dtype}")
 
 
 # Gradient sinks: {parameter data_ptr: fp32 view of a pre-zeroed flat gradient buffer}.  When a weight has a sink, the
@@ -126,7 +146,9 @@ LONG_STREAMS = None
 
 
 def _tensors(obj):
-    if torch.is_tensor(obj):
+    if isinstance(obj, Spikes):
+        yield obj.data
+    elif torch.is_tensor(obj):
         yield obj
     elif isinstance(obj, (tuple, list)):
         for o in obj:
@@ -207,10 +229,18 @@ def join(handle, result=()):
 
 
 def _sink_for(w):
+    """The flat-buffer slice that collects this weight's gradient, if its parameter registered one.  `w` is the parameter or
+    a view of it that starts at its first element (weight.view(M, -1))."""
     if GRAD_SINKS is None:
         return None
-    v = GRAD_SINKS.get(w.data_ptr())
-    return v if (v is not None and v.numel() == w.numel()) else None
+    hit = GRAD_SINKS.get(w.data_ptr())
+    if hit is None:
+        return None
+    ref, v = hit
+    p = ref()
+    if p is None or p.data_ptr() != w.data_ptr() or v.numel() != w.numel():
+        return None          # the address belonged to a parameter that has since been freed or re-allocated
+    return v
 
 
 STAT_SLOTS = 256         # include/s2f.h S2F_STAT_SLOTS
@@ -229,6 +259,98 @@ def read_stats(stats):
 
 def mask_words(n):
     return ((n + 255) >> 8) * 4
+
+
+# ------------------------------------------------------------------------------------------------ spike maps in bf16
+# A Q_IFNode output holds multiples of 1/D with at most 8 significant bits: bf16 represents it exactly.  With SPIKES_BF16 the
+# neuron kernels write their spikes as bf16 (2 B / element instead of the reference's 4) and every consumer on the path -- the
+# spike GEMMs, the implicit 3x3 convolutions, the attention core, the depthwise stencils -- reads that tensor directly: the
+# GEMM loops lose their fp32 -> bf16 conversion and every pass over a spike map moves half the bytes.
+# Autograd casts a gradient to the dtype of the tensor it belongs to, so a bf16 tensor cannot carry an fp32 gradient across
+# an autograd edge.  A spike map therefore travels as a pair: `data` (bf16, not differentiable) and `tok`, its autograd
+# handle -- an fp32 tensor of the same SHAPE whose strides are all zero (4 bytes of storage, never read).  The producer
+# returns `tok` as a differentiable output; a consumer takes (data, tok) and hands the fp32 gradient of the spike map back
+# as the gradient of `tok`.  View-type reshapes act on both halves (any view of an all-zero-stride tensor is legal and free).
+# In the fp32 mode (SPIKES_BF16 = False, or spikes handed in by an outside caller) `tok` is None and `data` is an ordinary
+# fp32 autograd tensor.
+SPIKES_BF16 = True
+
+
+class Spikes:
+    __slots__ = ("data", "tok")
+
+    def __init__(self, data, tok=None):
+        self.data, self.tok = data, tok
+
+    shape = property(lambda self: self.data.shape)
+    device = property(lambda self: self.data.device)
+    is_cuda = property(lambda self: self.data.is_cuda)
+    requires_grad = property(lambda self: self.data.requires_grad if self.tok is None else self.tok.requires_grad)
+
+    def numel(self):
+        return self.data.numel()
+
+    def dim(self):
+        return self.data.dim()
+
+    def _both(self, f):
+        return Spikes(f(self.data), None if self.tok is None else f(self.tok))
+
+    def view(self, *shape):
+        return self._both(lambda t: t.view(*shape))
+
+    def reshape(self, *shape):
+        return self._both(lambda t: t.reshape(*shape))
+
+    def flatten(self, *a):
+        return self._both(lambda t: t.flatten(*a))
+
+    def permute(self, *dims):
+        return self._both(lambda t: t.permute(*dims))
+
+    def unflatten(self, dim, sizes):
+        return self._both(lambda t: t.unflatten(dim, sizes))
+
+    def contiguous(self):
+        return Spikes(self.data.contiguous(), self.tok)
+
+    def float(self):
+        """The fp32 tensor the reference would hold at this point (one conversion pass; only for consumers off the path)."""
+        if self.tok is None:
+            return self.data
+        return _SpikesToFloat.apply(self.data, self.tok)
+
+
+def _new_tok(like):
+    return torch.empty((), dtype=torch.float32, device=like.device).expand(like.shape)
+
+
+def as_spikes(x):
+    return x if isinstance(x, Spikes) else Spikes(x, None)
+
+
+def spikes_float(x):
+    return x.float() if isinstance(x, Spikes) else x
+
+
+def _unpack(x):
+    """-> (data, tok or None) of a spike operand handed over as Spikes or as a plain fp32 tensor"""
+    return (x.data, x.tok) if isinstance(x, Spikes) else (x, None)
+
+
+class _SpikesToFloat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, tok):
+        return data.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g
+
+
+def _grad_pair(ctx_has_tok, g):
+    """gradient slots of a (data, tok) operand pair"""
+    return (None, g) if ctx_has_tok else (g, None)
 
 
 # ------------------------------------------------------------------------------------------------ library GEMMs
@@ -412,28 +534,33 @@ class _LIF(torch.autograd.Function):
     """One Q_IFNode call (neuron.py:166-197 + surrogate.py:522-538).  Saves 1 bit/element for backward."""
 
     @staticmethod
-    def forward(ctx, x, v_in, D, vth, keep_v, stats):
+    def forward(ctx, x, v_in, D, vth, keep_v, stats, bf16):
         _need_cuda(x, v_in)
         x = x.contiguous()
         if v_in is not None:
             v_in = v_in.contiguous()
         n = x.numel()
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device)
         v_out = torch.empty_like(x) if keep_v else None
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
-        _time_next("lif_fwd", 8 * n)
-        check(lib.s2f_lif_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), 0, _ptr(stats), n, vth, D,
+        _time_next("lif_fwd", 8 * n, moved=(6 if bf16 else 8) * n)
+        check(lib.s2f_lif_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), 0, _ptr(stats), n, vth, D, int(bf16),
                               _stream()), "s2f_lif_fwd")
         ctx.save_for_backward(mask)
         ctx.D, ctx.vth, ctx.has_v = D, vth, v_in is not None
         if v_out is None:
             v_out = x.new_empty(0)
             ctx.mark_non_differentiable(v_out)
-        return y, v_out
+        if bf16:                       # (autograd handle, membrane, bf16 spikes)
+            ctx.mark_non_differentiable(y)
+            return _new_tok(x), v_out, y
+        aux = x.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return y, v_out, aux
 
     @staticmethod
-    def backward(ctx, gy, gv):
+    def backward(ctx, gy, gv, _g2):
         (mask,) = ctx.saved_tensors
         gy = gy.contiguous()
         if gv is not None and gv.numel() != gy.numel():
@@ -444,12 +571,15 @@ class _LIF(torch.autograd.Function):
         _time_next("lif_bwd", 12 * gy.numel())
         check(lib.s2f_lif_bwd(_ptr(gy), _ptr(gv), _ptr(mask), _ptr(gx), gy.numel(), ctx.vth, ctx.D, _stream()),
               "s2f_lif_bwd")
-        return gx, (gx if ctx.has_v else None), None, None, None, None
+        return gx, (gx if ctx.has_v else None), None, None, None, None, None
 
 
-def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None):
-    """-> (y, v_out or None)"""
-    y, v = _LIF.apply(x, v_in, D, vth, keep_v, stats)
+def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None, spikes=False):
+    """-> (y, v_out or None); `spikes`: y as a Spikes pair (bf16 when SPIKES_BF16 and the size allows 8-byte stores)"""
+    bf16 = bool(spikes) and SPIKES_BF16 and x.numel() % 4 == 0 and x.numel() > 0
+    y, v, data = _LIF.apply(x, v_in, D, vth, keep_v, stats, bf16)
+    if spikes:
+        y = Spikes(data, y) if bf16 else Spikes(y, None)
     return y, (v if keep_v else None)
 
 
@@ -458,23 +588,29 @@ class _Sum2LIF(torch.autograd.Function):
     (maskformer_head.py:535-540 + transformer.py:626-629; s2f.h s2f_sum2_lif_fwd).  Reset, stateless neurons only."""
 
     @staticmethod
-    def forward(ctx, x, e, pos, B, D, vth):
+    def forward(ctx, x, e, pos, B, D, vth, bf16):
         _need_cuda(x, e, pos)
         x, e, pos = x.contiguous(), e.contiguous(), pos.contiguous()
         TB, C, L = x.shape
         n = x.numel()
-        yk, yv = torch.empty_like(x), torch.empty_like(x)
+        dt = torch.bfloat16 if bf16 else torch.float32
+        yk, yv = torch.empty(x.shape, dtype=dt, device=x.device), torch.empty(x.shape, dtype=dt, device=x.device)
         mk = torch.empty(mask_words(n), dtype=torch.int64, device=x.device)
         mv = torch.empty_like(mk)
-        _time_next("lif_fwd", 12 * n)                   # read x, write two spike maps (pos is 1/T of a map)
+        _time_next("lif_fwd", 12 * n, moved=(8 if bf16 else 12) * n)          # read x, write two spike maps (pos is 1/T of a map)
         check(lib.s2f_sum2_lif_fwd(_ptr(x), _ptr(e), _ptr(pos), _ptr(yk), _ptr(yv), _ptr(mk), _ptr(mv), TB, B, C, L, vth, D,
-                                   _stream()), "s2f_sum2_lif_fwd")
+                                   int(bf16), _stream()), "s2f_sum2_lif_fwd")
         ctx.save_for_backward(mk, mv)
         ctx.D = D
-        return yk, yv
+        if bf16:
+            ctx.mark_non_differentiable(yk, yv)
+            return _new_tok(x), _new_tok(x), yk, yv
+        aux = x.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return yk, yv, aux, aux
 
     @staticmethod
-    def backward(ctx, gk, gv):
+    def backward(ctx, gk, gv, _a, _b):
         mk, mv = ctx.saved_tensors
         gk, gv = gk.contiguous(), gv.contiguous()
         gx = torch.empty_like(gk)
@@ -482,12 +618,14 @@ class _Sum2LIF(torch.autograd.Function):
         check(lib.s2f_sum2_lif_bwd(_ptr(gk), _ptr(gv), _ptr(mk), _ptr(mv), _ptr(gx), gk.numel(), ctx.D, _stream()),
               "s2f_sum2_lif_bwd")
         ge = gx.sum((0, 2)) if ctx.needs_input_grad[1] else None
-        return gx, ge, None, None, None, None
+        return gx, ge, None, None, None, None, None
 
 
 def sum2_lif(x, e, pos, B, D=8, vth=1.0):
-    """x [T*B, C, L], e [C], pos [B, C, L] -> (Q_IFNode(x + e + pos), Q_IFNode(x + e))  (key spikes, value spikes)."""
-    return _Sum2LIF.apply(x, e, pos, B, D, vth)
+    """x [T*B, C, L], e [C], pos [B, C, L] -> (Q_IFNode(x + e + pos), Q_IFNode(x + e))  (key spikes, value spikes), as Spikes."""
+    bf16 = SPIKES_BF16
+    hk, hv, dk, dv = _Sum2LIF.apply(x, e, pos, B, D, vth, bf16)
+    return (Spikes(dk, hk), Spikes(dv, hv)) if bf16 else (Spikes(hk), Spikes(hv))
 
 
 class _LIFSeq(torch.autograd.Function):
@@ -557,7 +695,7 @@ class _SDSA(torch.autograd.Function):
 
 
 def sdsa(q, k, v, heads, scale):
-    return _SDSA.apply(q, k, v, heads, scale)
+    return _SDSA.apply(spikes_float(q), spikes_float(k), spikes_float(v), heads, scale)
 
 
 # ------------------------------------------------------------------------------------------------ DCNv3 core
@@ -592,7 +730,8 @@ class _DCNv3(torch.autograd.Function):
 
 
 def dcnv3_core(x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, offset_scale):
-    return _DCNv3.apply(x, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, float(offset_scale))
+    """`mask` may arrive as a Spikes pair (the module's mask neuron): the gather reads it as fp32."""
+    return _DCNv3.apply(x, offset, spikes_float(mask), kh, kw, sh, sw, ph, pw, dh, dw, G, Cg, float(offset_scale))
 
 
 # ------------------------------------------------------------------------------------------------ BN (+bias, +residual, +LIF)
@@ -602,7 +741,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
-                eps, lif_on, want_pre, keep_v, D, vth, stats):
+                eps, lif_on, want_pre, keep_v, D, vth, stats, bf16):
         _need_cuda(z, conv_bias, gamma, beta, residual, v_in)
         z = z.contiguous()
         N, C = z.shape[0], z.shape[1]
@@ -620,29 +759,35 @@ class _BNAct(torch.autograd.Function):
             residual = residual.contiguous()
         if v_in is not None:
             v_in = v_in.contiguous()
+        bf16 = bool(bf16) and lif_on
         u = torch.empty_like(z) if want_pre else None
-        y = torch.empty_like(z) if lif_on else None
+        y = torch.empty(z.shape, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev) if lif_on else None
         v_out = torch.empty_like(z) if (lif_on and keep_v) else None
         need_grad = any(ctx.needs_input_grad[:5])
         mask = torch.empty(mask_words(z.numel()), dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
         n = z.numel()
         # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
-        _time_next("bn_lif_fwd" if lif_on else "bn_fwd", 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on)))
+        alg = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
+        _time_next("bn_lif_fwd" if lif_on else "bn_fwd", alg, moved=alg - (2 * n if bf16 else 0))
         check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
                                  _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
-                                 _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D, s),
-              "s2f_bn_act_fwd")
+                                 _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D,
+                                 int(bf16), s), "s2f_bn_act_fwd")
         buf = stat
         stat, border = buf[:2 * C], buf[2 * C:]
         ctx.save_for_backward(z, conv_bias, gamma, stat, mask)
         ctx.cfg = (N, C, L, bool(training), D, vth, residual is not None, conv_bias is not None)
         ctx.set_materialize_grads(False)
+        # bf16 spikes: slot 1 carries the autograd handle, slot 4 the (non-differentiable) bf16 tensor
+        ydata = z.new_empty(0)
+        if bf16:
+            ydata, y = y, _new_tok(z)
         outs = [t if t is not None else z.new_empty(0) for t in (u, y, v_out)]
-        ctx.mark_non_differentiable(border, *[o for o, t in zip(outs, (u, y, v_out)) if t is None])
-        return tuple(outs) + (border,)
+        ctx.mark_non_differentiable(border, ydata, *[o for o, t in zip(outs, (u, y, v_out)) if t is None])
+        return tuple(outs) + (border, ydata)
 
     @staticmethod
-    def backward(ctx, g_u, g_y, g_v, g_border):
+    def backward(ctx, g_u, g_y, g_v, g_border, _g_ydata):
         z, conv_bias, gamma, stat, mask = ctx.saved_tensors
         N, C, L, training, D, vth, has_res, has_bias = ctx.cfg
 
@@ -650,7 +795,7 @@ class _BNAct(torch.autograd.Function):
             return None if (g is None or g.numel() == 0) else g.contiguous()
         g_u, g_y, g_v = prep(g_u), prep(g_y), prep(g_v)
         if g_u is None and g_y is None and g_v is None:
-            return (None,) * 18
+            return (None,) * 19
         dev = z.device
         gz = torch.empty_like(z)
         g_res = torch.empty_like(z) if (has_res and ctx.needs_input_grad[4]) else None
@@ -670,15 +815,18 @@ class _BNAct(torch.autograd.Function):
             g_bias = None if training else gamma * stat[C:2 * C] * dbeta
         if ctx.needs_input_grad[5]:
             raise RuntimeError("gradient w.r.t. the incoming membrane is not supported by the fused BN+LIF op")
-        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 13
+        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 14
 
 
 def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, residual=None,
            lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False):
-    """-> (u or None, y or None, v_out or None [, border]); border [C] = BN(0) from the updated running statistics
-    (BNAndPadLayer's padding value), produced by the same kernel."""
-    u, y, v, border = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
-                                   momentum, eps, lif, want_pre, keep_v, D, vth, stats)
+    """-> (u or None, y or None, v_out or None [, border]); y is a Spikes pair (bf16 when SPIKES_BF16); border [C] = BN(0)
+    from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel."""
+    bf16 = bool(lif) and SPIKES_BF16
+    u, y, v, border, ydata = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
+                                          momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16)
+    if lif:
+        y = Spikes(ydata, y) if bf16 else Spikes(y, None)
     out = (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
     return out + (border,) if want_border else out
 
@@ -755,7 +903,7 @@ class _DWConv(torch.autograd.Function):
 
 
 def dwconv(x, w, pad, border=None):
-    return _DWConv.apply(x, w, border, pad)
+    return _DWConv.apply(spikes_float(x), w, border, pad)
 
 
 # ------------------------------------------------------------------------------------------------ spike GEMM (bf16 MFMA)
@@ -786,24 +934,69 @@ def _owner(t):
     return t._base if t._base is not None else t
 
 
+# A cache entry: (version, out, shape, weakref(owner), job) with job = (src address, mode, C, M, K) -- what
+# s2f_split_bf16x3_multi needs to redo this split from the live weight (resplit_all).  Only the address is kept (a tensor
+# would keep a freed model's weights allocated); it is used only while the owner is alive and its storage still covers it.
+_TRUST_ALL = [False]          # set by resplit_all() inside a capture: every registered split was just redone from the live weights
+
+
 def _cache_get(key, version, shape, owner):
     hit = _SPLIT_CACHE.get(key)
-    if hit is not None and hit[0] == version and hit[2] == shape and hit[3]() is owner:
-        return hit[1]
+    if hit is not None and hit[2] == shape and hit[3]() is owner:
+        if hit[0] == version:
+            return hit[1]
+        if _TRUST_ALL[0] and hit[4] is not None and torch.cuda.is_current_stream_capturing():
+            _SPLIT_CACHE[key] = (version,) + hit[1:]
+            return hit[1]
     return None
 
 
-def _cache_put(key, version, out, shape, owner):
+def _cache_put(key, version, out, shape, owner, job=None):
     import weakref
     if len(_SPLIT_CACHE) > 4096:                       # dead entries of freed models
         for k in [k for k, v in _SPLIT_CACHE.items() if v[3]() is None]:
             del _SPLIT_CACHE[k]
-    _SPLIT_CACHE[key] = (version, out, shape, weakref.ref(owner))
+    _SPLIT_CACHE[key] = (version, out, shape, weakref.ref(owner), job)
+    _SPLIT_TABLE["keys"] = None
+
+
+_SPLIT_TABLE = {"keys": None, "jobs": None, "blocks": 0}
+
+
+def resplit_all(device, build=True):
+    """Redo EVERY cached weight split from the live fp32 weights in one launch (s2f_split_bf16x3_multi).  A training step owes
+    this after each optimiser update; a captured step (graph.GraphedStep) records it, so every replay multiplies by the
+    current weights -- without it the graph would replay the bf16 terms of capture time while its backward reads the live
+    fp32 weights.  -> number of weights re-split; -1 when the job table would have to be (re)built and `build` is False (the
+    table is uploaded from the host, which a stream capture does not allow: GraphedStep calls this once before capturing)."""
+    def covered(v):
+        o = v[3]()
+        if o is None or v[4] is None or v[1].device != device:
+            return False
+        st = o.untyped_storage()
+        return st.data_ptr() <= v[4][0] and v[4][0] + 4 * v[4][3] * v[4][4] <= st.data_ptr() + st.nbytes()
+    live = [(k, v) for k, v in _SPLIT_CACHE.items() if covered(v)]
+    if not live:
+        return 0
+    keys = tuple(k for k, _ in live)
+    if _SPLIT_TABLE["keys"] != keys or _SPLIT_TABLE["jobs"] is None or _SPLIT_TABLE["jobs"].device != device:
+        if not build:
+            return -1
+        rows, first = [], 0
+        for _, (_ver, out, _shape, _own, (src, mode, cdim, M, K)) in live:
+            Mpad, Kpad = out.shape[1], out.shape[2]
+            rows.append([src, out.data_ptr(), M, K, Mpad, Kpad, mode | (cdim << 8), first])
+            first += (Mpad * Kpad + 1023) // 1024
+        _SPLIT_TABLE.update(keys=keys, jobs=torch.tensor(rows, dtype=torch.int64).to(device), blocks=first)
+    check(lib.s2f_split_bf16x3_multi(_ptr(_SPLIT_TABLE["jobs"]), len(live), _SPLIT_TABLE["blocks"], _stream()),
+          "s2f_split_bf16x3_multi")
+    return len(live)
 
 
 def split_weight(w2d):
     """fp32 [M, K] -> cached bf16 [3, Mpad, Kpad] (hi, mid, lo).  Re-split when the parameter is modified in place
-    (optimiser step, load_state_dict) -- tracked through the tensor version counter."""
+    (optimiser step, load_state_dict) -- tracked through the tensor version counter; weights must not be mutated through
+    `.data` (its own version counter).  Inside a captured step the splits are redone by resplit_all()."""
     key = (w2d.data_ptr(), w2d.numel())
     M, K = w2d.shape
     # a zero-copy concatenation of sibling parameters (cat_params) is a fresh tensor every call: it carries the sum of the
@@ -815,8 +1008,10 @@ def split_weight(w2d):
         return hit
     Mpad, Kpad = (M + 63) // 64 * 64, (K + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=w2d.device)
-    check(lib.s2f_split_bf16x3(_ptr(w2d.detach().contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _cache_put(key, version, out, (M, K), owner)
+    src = w2d.detach()
+    job = (src.data_ptr(), 0, 0, M, K) if src.is_contiguous() else None
+    check(lib.s2f_split_bf16x3(_ptr(src.contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
+    _cache_put(key, version, out, (M, K), owner, job)
     return out
 
 
@@ -831,7 +1026,8 @@ def split_weight_conv3(weight):
     Mpad, Kpad = (M + 63) // 64 * 64, (9 * C + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), M, 9 * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _cache_put(key, weight._version, out, (M, C), _owner(weight))
+    src = weight.detach()
+    _cache_put(key, weight._version, out, (M, C), _owner(weight), (src.data_ptr(), 1, C, M, 9 * C) if src.is_contiguous() else None)
     return out
 
 
@@ -847,29 +1043,37 @@ def split_weight_tconv3(weight):
     Mpad, Kpad = (C + 127) // 128 * 128, (9 * M + 31) // 32 * 32
     out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), C, 9 * M, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
-    _cache_put(key, weight._version, out, (M, C), _owner(weight))
+    src = weight.detach()
+    _cache_put(key, weight._version, out, (M, C), _owner(weight), (src.data_ptr(), 2, M, C, 9 * M) if src.is_contiguous() else None)
     return out
 
 
+def _is_spike_grid(x):
+    xf = x.float()
+    return torch.equal(xf * 8, torch.round(xf * 8)) and float(xf.abs().max()) <= 16
+
+
 class _SpikeGemm(torch.autograd.Function):
-    """Y[b] = W @ X[b] (+ bias) with X spikes: forward on the bf16 matrix cores (W split hi+mid+lo), backward on rocBLAS."""
+    """Y[b] = W @ X[b] (+ bias) with X spikes (bf16 pair or fp32): forward and weight gradient on the bf16 matrix cores (W /
+    dY split hi+mid+lo), input gradient on the library (fp32)."""
 
     @staticmethod
-    def forward(ctx, x, w2d, bias):
-        _need_cuda(x, w2d, bias)
+    def forward(ctx, x, tok, w2d, bias):
+        _need_cuda(w2d, bias, spikes=x)
         x = x.contiguous()
         B, K, N = x.shape
         M = w2d.shape[0]
         if SPIKE_GEMM_CHECK:
-            assert torch.equal(x * 8, torch.round(x * 8)) and float(x.abs().max()) <= 16, "not a spike tensor"
+            assert _is_spike_grid(x), "not a spike tensor"
         ws = split_weight(w2d)
         y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
-        # MFMA work actually issued: `terms` bf16 products per fp32 multiply-add
-        _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K * SPIKE_GEMM_TERMS)
-        check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, ws.shape[1], ws.shape[2],
-                                     SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
+        xb = x.dtype == torch.bfloat16
+        _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * ((2 if xb else 4) * K + 4 * M))
+        fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
+        check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()),
+              "s2f_spike_gemm_fwd")
         ctx.save_for_backward(x, w2d)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.has_tok = bias is not None, tok is not None
         return y
 
     @staticmethod
@@ -878,32 +1082,45 @@ class _SpikeGemm(torch.autograd.Function):
         gy = gy.contiguous()
         B = x.shape[0]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            if gy.shape[2] <= 128 and w2d.shape[0] <= 512 and w2d.shape[1] <= 512:
-                # rocBLAS picks a 40 us kernel for the batched [256x256]^T @ [256x100] of the decoder (tools/probe_small_dx.py);
-                # the same product through einsum's folding takes 12 us
-                gx = torch.einsum("mk,bml->bkl", w2d, gy)
-            else:
-                gx = bmm_tuned(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
-        if ctx.needs_input_grad[1]:
-            if SPIKE_GEMM_DW and x.shape[2] % 4 == 0 and w2d.shape[0] >= 16:     # 32- / 64- / 128-row tiles by M
-                M, K = w2d.shape
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx = dx_gemm(w2d, gy)
+        if ctx.needs_input_grad[2]:
+            M, K = w2d.shape
+            L = x.shape[2]
+            if SPIKE_GEMM_DW and L % 4 == 0 and M >= 16:     # 32- / 64- / 128-row tiles by M
                 sink = _sink_for(w2d)
                 gw = torch.empty(M, K, dtype=torch.float32, device=x.device) if sink is None else None
-                _time_next("spike_gemm_dw", 4 * B * x.shape[2] * (K + M), 2 * B * M * x.shape[2] * K * 3)
+                xb = x.dtype == torch.bfloat16
+                _time_next("spike_gemm_dw", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, x)
-                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, x.shape[2],
-                                            int(sink is not None), 1, side.cuda_stream if side is not None else _stream()),
-                      "s2f_spike_gemm_dw")
+                st = side.cuda_stream if side is not None else _stream()
+                if xb:
+                    check(lib.s2f_spike_gemm_dw_bf16(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, L,
+                                                     int(sink is not None), st), "s2f_spike_gemm_dw_bf16")
+                else:
+                    check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, L,
+                                                int(sink is not None), 1, st), "s2f_spike_gemm_dw")
             else:
-                gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                gw = torch.bmm(gy, x.float().transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))
-        return gx, gw, gb
+        return _grad_pair(ctx.has_tok, gx) + (gw, gb)
+
+
+def dx_gemm(w2d, gy):
+    """Input gradient of a 1x1 convolution: gx[b] = W^T @ gy[b]  (two general fp32 operands)."""
+    B = gy.shape[0]
+    if gy.shape[2] <= 128 and w2d.shape[0] <= 512 and w2d.shape[1] <= 512:
+        # rocBLAS picks a 40 us kernel for the batched [256x256]^T @ [256x100] of the decoder (tools/probe_small_dx.py);
+        # the same product through einsum's folding takes 12 us
+        return torch.einsum("mk,bml->bkl", w2d, gy)
+    return bmm_tuned(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
 
 
 def spike_gemm(x, w2d, bias=None):
-    return _SpikeGemm.apply(x, w2d, bias)
+    """x: Spikes or an fp32 spike tensor [B, K, N]"""
+    data, tok = _unpack(x)
+    return _SpikeGemm.apply(data, tok, w2d, bias)
 
 
 # ------------------------------------------------------------------------------------------------ mask einsum (SDME)
@@ -1076,8 +1293,10 @@ class _ConvDense(torch.autograd.Function):
               stride 1 (MS_ConvBlock.conv2: 4C -> C, sdtv2.py:202-204)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, spike_input):
-        _need_cuda(x, weight, bias)
+    def forward(ctx, x, tok, weight, bias, stride, padding, spike_input):
+        _need_cuda(weight, bias, spikes=x)
+        ctx.has_tok = tok is not None
+        xb = x.dtype == torch.bfloat16
         N, C, H, W = x.shape
         M, _, kh, kw = weight.shape
         Ho = (H + 2 * padding - kh) // stride + 1
@@ -1090,12 +1309,14 @@ class _ConvDense(torch.autograd.Function):
         if implicit:
             x = x.contiguous()
             if SPIKE_GEMM_CHECK:
-                assert torch.equal(x * 8, torch.round(x * 8)) and float(x.abs().max()) <= 16, "not a spike tensor"
+                assert _is_spike_grid(x), "not a spike tensor"
             ws = split_weight_conv3(weight)
             y = torch.empty(N, M, H * W, dtype=torch.float32, device=x.device)
-            _time_next("spike_gemm_fwd", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9 * SPIKE_GEMM_TERMS)
-            check(lib.s2f_spike_conv3x3_fwd(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, ws.shape[1], ws.shape[2],
-                                            SPIKE_GEMM_TERMS, _stream()), "s2f_spike_conv3x3_fwd")
+            _time_next("spike_gemm_fwd", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9,
+                       moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
+            fn = lib.s2f_spike_conv3x3_fwd_bf16 if xb else lib.s2f_spike_conv3x3_fwd
+            check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS,
+                     _stream()), "s2f_spike_conv3x3_fwd")
             ctx.save_for_backward(x, weight)
             ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, True)
             ctx.implicit = True
@@ -1106,10 +1327,14 @@ class _ConvDense(torch.autograd.Function):
         if use_mfma:
             ws = split_weight(w2d)
             y = torch.empty(N, M, Ho * Wo, dtype=torch.float32, device=x.device)
-            _time_next("spike_gemm_fwd", 4 * N * Ho * Wo * (cols.shape[1] + M), 2 * N * M * Ho * Wo * cols.shape[1] * SPIKE_GEMM_TERMS)
-            check(lib.s2f_spike_gemm_fwd(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, Ho * Wo, cols.shape[1],
-                                         ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
+            _time_next("spike_gemm_fwd", 4 * N * Ho * Wo * (cols.shape[1] + M), 2 * N * M * Ho * Wo * cols.shape[1],
+                       moved=N * Ho * Wo * ((2 if xb else 4) * cols.shape[1] + 4 * M))
+            fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
+            check(fn(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, Ho * Wo, cols.shape[1], ws.shape[1], ws.shape[2],
+                     SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
         else:
+            if xb:
+                cols = cols.float()
             y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
             if bias is not None:
                 y = y + bias.view(1, -1, 1)
@@ -1124,7 +1349,8 @@ class _ConvDense(torch.autograd.Function):
         gy = gy.contiguous().view(N, M, Ho * Wo)
         w2d = weight.view(M, -1)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        xb = cols.dtype == torch.bfloat16
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if (CONV3X3_DX_IMPLICIT and kh == 3 and kw == 3 and stride == 1 and padding == 1 and M % 32 == 0 and W % 4 == 0
                     and gy.is_cuda and H * W >= CONV3X3_DX_MIN_PIXELS):
                 # transposed convolution dX = flip(W)^T (*) dY as an implicit 6-pass split GEMM: no unfold(dY), no col2im
@@ -1139,14 +1365,15 @@ class _ConvDense(torch.autograd.Function):
             else:
                 dcols = bmm_tuned(w2d.t().unsqueeze(0).expand(N, -1, -1), gy)
                 gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[2]:
             K = w2d.shape[1]
             if ctx.implicit:
                 x = cols                                                  # the saved tensor is the activation itself
                 gt = torch.empty(M, 3, 3, C, dtype=torch.float32, device=gy.device)        # tap-major, as the kernel contracts
-                _time_next("spike_gemm_dw", 4 * N * H * W * (C + M), 2 * N * M * H * W * K * 3)
-                check(lib.s2f_spike_conv3x3_dw(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()),
-                      "s2f_spike_conv3x3_dw")
+                _time_next("spike_gemm_dw", 4 * N * H * W * (C + M), 2 * N * M * H * W * K,
+                           moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
+                fn = lib.s2f_spike_conv3x3_dw_bf16 if xb else lib.s2f_spike_conv3x3_dw
+                check(fn(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")
                 sink = _sink_for(weight)
                 if sink is not None:
                     sink.view(M, C, 3, 3).add_(gt.permute(0, 3, 1, 2))
@@ -1156,18 +1383,25 @@ class _ConvDense(torch.autograd.Function):
             elif use_mfma and SPIKE_GEMM_DW and M >= 16:
                 sink = _sink_for(weight)
                 gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
-                _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K * 3)
+                _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K,
+                           moved=N * Ho * Wo * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, cols)
-                check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
-                                            int(sink is not None), 1, side.cuda_stream if side is not None else _stream()),
-                      "s2f_spike_gemm_dw")
+                st = side.cuda_stream if side is not None else _stream()
+                if xb:
+                    check(lib.s2f_spike_gemm_dw_bf16(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                                     int(sink is not None), st), "s2f_spike_gemm_dw_bf16")
+                else:
+                    check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                                int(sink is not None), 1, st), "s2f_spike_gemm_dw")
             else:
-                gw = torch.bmm(gy, cols.transpose(1, 2)).sum(0)
+                gw = torch.bmm(gy, cols.float().transpose(1, 2)).sum(0)
             gw = gw.view_as(weight) if gw is not None else None
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))
-        return gx, gw, gb, None, None, None
+        return _grad_pair(ctx.has_tok, gx) + (gw, gb, None, None, None)
 
 
 def conv_dense(x, weight, bias, stride, padding, spike_input):
-    return _ConvDense.apply(x, weight, bias, stride, padding, spike_input)
+    """x: fp32 tensor, or Spikes (then `spike_input` is implied)"""
+    data, tok = _unpack(x)
+    return _ConvDense.apply(data, tok, weight, bias, stride, padding, spike_input or isinstance(x, Spikes))

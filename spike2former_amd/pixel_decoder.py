@@ -65,7 +65,9 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
     def init_weights(self):
         pass
 
-    def forward(self, feats, batch_img_metas=None):
+    def forward(self, feats, batch_img_metas=None, spike_memory=False):
+        """`spike_memory`: hand `memory` (a spike map) out as the ops.Spikes pair instead of converting it to the fp32 tensor
+        of the reference's interface (the head only reads its shape)."""
         x4 = feats[-1]
         t, bs, c, h, w = x4.shape
         E = self.encoder_embed_dims
@@ -76,16 +78,16 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         # stream now and overlap with the six encoder layers (chains of 32x32-map kernels that leave most CUs idle).
         def lateral(i):
             def run():
-                x = self.lateral_convs_spike[i](feats[i]).flatten(0, 1)
+                x = self.lateral_convs_spike[i].fire(feats[i]).flatten(0, 1)
                 ops.use_here(x)
                 return self.lateral_convs[i][0].forward_nobias(x)
             return run
         lat = {i: ops.fork(0, lateral(i), inputs=(feats[i],), what="lat") for i in range(self.num_inputs - 2, -1, -1)}
 
-        y = self.last_feat_conv_spike(x4)
+        y = self.last_feat_conv_spike.fire(x4)
         y = conv_bn(self.encoder_in_proj, y.flatten(0, 1))[0].reshape(t, bs, E, h, w)
         memory = self.encoder.forward_nchw(y)          # == encoder(query=y.permute(0,1,3,4,2)).permute(0,1,4,2,3)
-        memory = self.encoder_out_proj_spike(memory)
+        memory = self.encoder_out_proj_spike.fire(memory)
         y = conv_bn(self.encoder_out_proj, memory.flatten(0, 1))[0]
         out = [y.reshape(t, bs, E, h, w)]
 
@@ -107,6 +109,6 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         # end: as a branch on the side stream they overlap with the transformer decoder; the head joins it (mask_feature_handle).
         def finest(y=y):
             y0 = level(0, y)
-            return self.mask_feature(self.mask_feature_spike(y0))
+            return self.mask_feature(self.mask_feature_spike.fire(y0))
         mf, self.mask_feature_handle = ops.fork(0, finest, inputs=(y,), what="mf")
-        return mf.reshape(t, bs, *mf.shape[1:]), memory, out[:3]
+        return mf.reshape(t, bs, *mf.shape[1:]), (memory if spike_memory else memory.float()), out[:3]

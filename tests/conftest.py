@@ -39,3 +39,15 @@ def _build_oracle_c():
     so = os.path.join(ROOT, "oracle", "liblif_ref.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture
+def spike_mode():
+    """spike_mode(True / False): spike maps between kernels as bf16 (the product default) or as fp32; restored afterwards."""
+    from spike2former_amd import ops
+    before = ops.SPIKES_BF16
+
+    def set_mode(bf16):
+        ops.SPIKES_BF16 = bool(bf16)
+    yield set_mode
+    ops.SPIKES_BF16 = before

@@ -51,7 +51,7 @@ def test_ctypes_table_matches_header():
 def test_argument_errors_are_reported_without_a_gpu():
     """Validation happens before any launch, so the error convention can be checked on CPU."""
     from spike2former_amd._lib import lib
-    assert lib.s2f_lif_fwd(None, None, None, None, None, None, None, 16, 1.0, 8, None) == -1
+    assert lib.s2f_lif_fwd(None, None, None, None, None, None, None, 16, 1.0, 8, 0, None) == -1
     assert b"null" in lib.s2f_last_error()
     assert lib.s2f_dcnv3_fwd(1, 1, 1, 1, 0, 4, 4, 1, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1.0, None) == -1
     assert lib.s2f_sdsa_fwd(1, 1, 1, 1, 1, 1, 8, 65, 4, 4, 1.0, None) == -1     # head dim > 64

@@ -302,6 +302,42 @@ def test_tiny_graph_replay_is_bitwise_the_eager_step():
     assert (g0 - g1).abs().max().item() <= 1e-4 * g0.abs().max().item()       # LDS/atomic accumulation order in dW
 
 
+def test_graph_replay_follows_weight_updates():
+    """A captured step multiplies by the LIVE weights: the bf16 hi / mid / lo terms of every weight are re-split inside the
+    graph (ops.resplit_all, one launch), so a replay after an optimiser-style in-place update equals the eager step on the
+    updated weights -- not the step of capture time (the stale-split hazard of a cached weight split)."""
+    import spike2former_amd as s2f
+    from spike2former_amd import ops
+    from spike2former_amd.graph import GraphedStep
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C1_64"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1_64"))).cuda().train()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(2, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(5)).cuda()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def eager():
+        s2f.reset_net(model); model.zero_grad(set_to_none=True)
+        loss = s2f.headline_loss(*model(img)); loss.backward()
+        return float(loss.detach()), torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    gs = GraphedStep(model, s2f.headline_loss, img, warmup=1)
+    assert ops.resplit_all(img.device) > 50                  # every spike-GEMM weight of the model is a registered job
+    model.load_state_dict(sd0)                               # capture / warm-up steps moved the BatchNorm running statistics
+    l_before = float(gs())
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():                                    # an "optimiser step": every parameter changed in place
+        for p in model.parameters():
+            p.add_(0.05 * p.abs().mean() * torch.randn(p.shape, generator=g).to(p.device))
+    sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+    l_replay = float(gs())
+    g_replay = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    model.load_state_dict(sd1)
+    l_eager, g_eager = eager()
+    assert l_replay != l_before
+    assert l_replay == l_eager
+    assert (g_replay - g_eager).abs().max().item() <= 1e-4 * g_eager.abs().max().item()
+
+
 def test_tiny_split_graph_step_with_the_hungarian_loss_is_the_eager_step():
     """graph.GraphedSplitStep (forward graph | eager Hungarian-matched loss | backward graph) against the eager
     `mode="loss"` step on the tiny config: same loss values bit for bit, same gradients (flat buffer) to the run-to-run

@@ -85,9 +85,15 @@ def test_lif_vs_c_oracle_ragged_sizes(ops, n):
     yy = torch.empty(n, device="cuda"); cnt = torch.empty(n, dtype=torch.uint8, device="cuda")
     mask = torch.zeros(int(lib.s2f_lif_mask_words(n)), dtype=torch.int64, device="cuda")
     assert lib.s2f_lif_fwd(xt.data_ptr(), vt.data_ptr(), yy.data_ptr(), None, mask.data_ptr(), cnt.data_ptr(), None, n,
-                           1.0, 8, None) == 0
+                           1.0, 8, 0, None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(unpack_mask(mask, n), rin[0].astype(bool)) and np.array_equal(cnt.cpu().numpy(), rc[0])
+    # the same call writing its spikes as bf16 (y_bf16 = 1): exactly the fp32 values
+    if n % 4 == 0 and n > 0:
+        yb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        assert lib.s2f_lif_fwd(xt.data_ptr(), vt.data_ptr(), yb.data_ptr(), None, None, None, None, n, 1.0, 8, 1, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(yb.float(), yy)
 
 
 def test_lif_four_levels_stateless(ops):
@@ -159,8 +165,9 @@ def test_lif_full_size_properties(ops):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("bf16", [True, False])
 @pytest.mark.parametrize("T_,B,C,L", [(4, 2, 256, 1024), (1, 1, 5, 4), (2, 3, 7, 36), (3, 1, 16, 260)])
-def test_sum2_lif_is_the_two_neurons_on_the_two_sums(ops, T_, B, C, L):
+def test_sum2_lif_is_the_two_neurons_on_the_two_sums(ops, spike_mode, bf16, T_, B, C, L):
     """Decoder key / value neurons from memory + level_embed (+ pos) in one launch (maskformer_head.py:535-540,
     transformer.py:626-629): bit-identical, forward and backward, to the stand-alone neuron on the materialised sums."""
     g = torch.Generator().manual_seed(T_ * 100 + L)
@@ -168,7 +175,10 @@ def test_sum2_lif_is_the_two_neurons_on_the_two_sums(ops, T_, B, C, L):
     e = torch.randn(C, generator=g).cuda().requires_grad_(True)
     pos = torch.randn(B, C, L, generator=g).cuda()
     wk, wv = torch.randn(T_ * B, C, L, generator=g).cuda(), torch.randn(T_ * B, C, L, generator=g).cuda()
+    spike_mode(bf16)
     yk, yv = ops.sum2_lif(x, e, pos, B)
+    assert yk.data.dtype == (torch.bfloat16 if bf16 else torch.float32)
+    yk, yv = yk.float(), yv.float()          # Spikes -> the reference's fp32 tensors (gradients flow through the handle)
     ((yk * wk).sum() + (yv * wv).sum()).backward()
     gx, ge = x.grad.clone(), e.grad.clone()
     x.grad = e.grad = None
@@ -340,7 +350,8 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      # single-pass kernels (s2f_bn_single_pass): full / ragged wave counts
                                                      (8, 256, 1024, True, False, True), (8, 64, 1024, True, True, True),
                                                      (2, 128, 512, True, True, False), (3, 64, 768, True, False, True)])
-def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
+@pytest.mark.parametrize("bf16", [True, False])
+def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
     Pre-activation: rtol 2e-5 (different but equally valid fp32 evaluation orders); spikes: at most 1e-4 of the
     elements may differ, each by exactly one level; gradients: 1e-4 of their max."""
@@ -372,8 +383,12 @@ def test_bn_act_vs_oracle(so, N, C, L, training, res, lif):
     rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")
     fstats = ops.new_stats("cuda") if lif else None
+    spike_mode(bf16)
     uu, yy, _, border = ops.bn_act(zc, bc, gc, bec, rmc, rvc, nbt if training else None, training, 0.1, 1e-5, residual=rc,
                                    lif=lif, want_pre=True, stats=fstats, want_border=True)
+    if lif:
+        assert yy.data.dtype == (torch.bfloat16 if bf16 else torch.float32)
+        yy = yy.float()
     # BNAndPadLayer's padding value BN(0), from the running statistics AFTER this call's update (sdtv2.py:68-78)
     bref = beta - rmo * gamma / torch.sqrt(rvo + 1e-5)
     assert (border.cpu() - bref).abs().max().item() <= 1e-5 * max(bref.abs().max().item(), 1.0)
@@ -416,6 +431,7 @@ def test_bn_act_stateful_lif_matches_unfused(ops):
                              keep_v=True, stats=stats_a)
     u2, _, _ = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=False, want_pre=True)
     y2, v2 = ops.lif(u2, v, stats=stats_b)
+    y = y.float()
     assert torch.equal(u, u2) and torch.equal(y, y2) and torch.equal(v_out, v2) and torch.equal(ops.read_stats(stats_a), ops.read_stats(stats_b))
 
 
@@ -626,3 +642,25 @@ def test_conv_dense_vs_aten_cpu(ops, N, C, M, H, W, k, s, p, spike):
             ops.CONV3X3_IMPLICIT, ops.CONV3X3_IMPLICIT_MIN_PIXELS, ops.CONV3X3_DX_IMPLICIT = True, min_pixels, True
         for a, r in ((yc, yo), (xc.grad, xo.grad), (wc.grad, wo.grad), (bc.grad, bo.grad)):
             assert (a.detach().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.abs().max().item(), implicit
+
+
+def test_resplit_all_redoes_every_cached_split(ops):
+    """ops.resplit_all (s2f_split_bf16x3_multi: all weights in one launch) writes, for each of the three source layouts, exactly
+    the bf16 terms the per-weight split wrote -- checked after changing the weights THROUGH `.data` (no version bump), i.e.
+    only the multi-launch can have produced the new terms."""
+    g = torch.Generator().manual_seed(3)
+    w2d = torch.randn(100, 72, generator=g).cuda()
+    wc = torch.randn(40, 32, 3, 3, generator=g).cuda()
+    a, b, c = ops.split_weight(w2d), ops.split_weight_conv3(wc), ops.split_weight_tconv3(wc)
+    assert ops.resplit_all(w2d.device) >= 3
+    torch.cuda.synchronize()
+    a0, b0, c0 = a.clone(), b.clone(), c.clone()
+    assert torch.equal(a0, a) and torch.equal(b0, b) and torch.equal(c0, c)          # same weights -> same terms
+    w2d.data.mul_(1.7); wc.data.mul_(-0.3)
+    assert ops.resplit_all(w2d.device) >= 3
+    ops._SPLIT_CACHE.clear()
+    a1, b1, c1 = ops.split_weight(w2d), ops.split_weight_conv3(wc), ops.split_weight_tconv3(wc)      # fresh per-weight splits
+    assert not torch.equal(a0, a) and torch.equal(a1, a) and torch.equal(b1, b) and torch.equal(c1, c)
+    # hi + mid + lo reproduces the fp32 weight to 2^-24
+    terms = (a.view(torch.bfloat16).float().sum(0))[:100, :72]
+    assert (terms - w2d).abs().max().item() <= 2.0 ** -22 * w2d.abs().max().item()

@@ -119,8 +119,8 @@ def test_flat_grad_buffer_sinks_and_compaction():
         # step 1: "kernels" add into the sinks of parameters 1 and 3, autograd assigns the others
         red.zero()
         assert float(red.flat.abs().sum()) == 0.0
-        ops.GRAD_SINKS[ps[1].data_ptr()].add_(torch.arange(5.0))
-        ops.GRAD_SINKS[ps[3].data_ptr()].add_(1.5)
+        ops._sink_for(ps[1]).add_(torch.arange(5.0))
+        ops._sink_for(ps[3]).add_(1.5)
         ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
         red.gather()                                       # not compacted yet: one copy per run
         assert red.flat.tolist() == [1.0] * 3 + [0.0, 1.0, 2.0, 3.0, 4.0] + [2.0] * 2 + [1.5] * 4
@@ -128,12 +128,18 @@ def test_flat_grad_buffer_sinks_and_compaction():
         assert [p.numel() for p in red.params] == [3, 2, 5, 4] and red._dense_elems == 5
         # step 2 in the compacted layout
         red.zero()
-        ops.GRAD_SINKS[ps[1].data_ptr()].add_(torch.arange(5.0))
-        ops.GRAD_SINKS[ps[3].data_ptr()].add_(1.5)
+        ops._sink_for(ps[1]).add_(torch.arange(5.0))
+        ops._sink_for(ps[3]).add_(1.5)
         ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
         red.gather()
         assert red.flat.tolist() == [1.0] * 3 + [2.0] * 2 + [0.0, 1.0, 2.0, 3.0, 4.0] + [1.5] * 4
         for p, v in zip(red.params, red.views):
-            assert v.shape == p.shape and ops.GRAD_SINKS[p.data_ptr()].data_ptr() == v.data_ptr()
+            assert v.shape == p.shape and ops._sink_for(p).data_ptr() == v.data_ptr()
+        # an address is not an identity: a sink is only handed to the parameter it was registered for, and dropping the
+        # buffer detaches the (process-global) table
+        stale = torch.nn.Parameter(torch.zeros(5))
+        assert ops._sink_for(stale) is None
+        red.close()
+        assert ops.GRAD_SINKS is None and ops._sink_for(ps[1]) is None
     finally:
         ops.GRAD_SINKS = None
