@@ -140,13 +140,15 @@ int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, co
  * 3x3 on the BNAndPadLayer output (sdtv2.py:48-89, 123-127), SepConv_Spike.dwconv (mmcv_spike/SNN_core.py:36-40),
  * DCNv3_pytorch.dw_conv (ops_dcnv3/modules/dcnv3.py:161-169) and the pixel decoder's output_convs (pixel_decoder.py:374-378).
  * w: [C, K, K].  Output size Ho = H + 2*pad - K + 1.  border?: per-channel value read inside the padding ring instead of
- * zero (BNAndPadLayer's constant border, sdtv2.py:68-84) -- the padded tensor is never materialised. */
-int s2f_dwconv_fwd(const float* x, const float* w, const float* border, float* y, int N, int C, int H, int W, int K,
-                   int pad, void* stream);
+ * zero (BNAndPadLayer's constant border, sdtv2.py:68-84) -- the padded tensor is never materialised.
+ * x_bf16 != 0: x is a bf16 spike map (uint16 storage) as the neuron kernels write it (SepConv.dwconv, the pixel decoder's
+ * output convolutions and DCNv3's dw_conv all read a neuron output); the arithmetic stays fp32. */
+int s2f_dwconv_fwd(const void* x, const float* w, const float* border, float* y, int N, int C, int H, int W, int K,
+                   int pad, int x_bf16, void* stream);
 int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, int N, int C, int H, int W, int K, int pad,
                          void* stream);
-int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, float* gw, int N, int C, int H, int W,
-                          int K, int pad, int accumulate, void* stream);
+int s2f_dwconv_bwd_weight(const void* x, const float* border, const float* gy, float* gw, int N, int C, int H, int W,
+                          int K, int pad, int accumulate, int x_bf16, void* stream);
 
 /* ---- spike GEMM on the bf16 matrix cores ---------------------------------------------------------------
  * Y[b] (M x N) = W (M x K) @ X[b] (K x N) [+ bias[M]]   for b in [0, batch): the 1x1 Conv2d / Conv1d(k=1) / im2col'd kxk
@@ -263,6 +265,31 @@ int s2f_sdsa_bwd(const float* q, const float* k, const float* v, const float* kv
 int s2f_sdsa_kv(const float* k, const float* v, float* kv, int TB, int heads, int d, int N, float alpha, void* stream);
 int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, int heads, int d, int N, float alpha,
                    int transpose_m, void* stream);
+
+/* The same core on bf16 spike operands (uint16_t storage; what the neuron kernels write with y_bf16): exact, half the bytes.
+ * q / k / v may be channel ranges of ONE tensor (the stacked q|k|v map [TB, 3C, N] of the batched projection chain): each
+ * operand comes with the distance between its batch elements, in elements (multiples of 4; C*N for a plain [TB, C, N]).
+ * s2f_sdsa_bwd_bf16: `go` is the gradient of o [TB, C, Nq] -- or, with go_mask != NULL, the gradient of the SPIKES
+ * y = Q_IFNode(o) of the fused forward below: the straight-through estimator (in-range bit ? g / D : 0, mask layout of
+ * s2f_lif_mask_words over the contiguous [TB, C, Nq]) is applied inside the loaders, no separate neuron backward pass.
+ * gq / gk / gv are fp32 with their own batch strides (three ranges of one [TB, 3C, N] gradient, or three tensors). */
+int s2f_sdsa_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                      int64_t k_batch_stride, int64_t v_batch_stride, float* o, float* kv_save, int TB, int heads, int d,
+                      int Nq, int Nk, float scale, void* stream);
+int s2f_sdsa_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                      int64_t k_batch_stride, int64_t v_batch_stride, const float* kv_save, const float* go,
+                      const uint64_t* go_mask, int D, float* gq, float* gk, float* gv, int64_t gq_batch_stride,
+                      int64_t gk_batch_stride, int64_t gv_batch_stride, float* gkv_ws, int TB, int heads, int d, int Nq,
+                      int Nk, float scale, void* stream);
+/* Attention core AND the neuron behind it as one kernel -- north_star's "spike-masked attention + LIF as one CDNA4 kernel"
+ * for the backbone's self-attention (sdtv2.py:335-342: kv = k^T v; o = scale q kv; attn_spike(o)): one workgroup per
+ * (tb, head); kv on the matrix cores straight from memory (contraction-contiguous bf16 rows, exact), kept in LDS for the
+ * q kv product; o never reaches HBM: the Q_IFNode update of s2f_lif_fwd (reset membrane) runs in the epilogue and writes
+ * y as bf16 spikes [TB, C, N] + the 1-bit in-range mask (mask? NULL == no backward) + the firing counters (stats? as
+ * s2f_lif_fwd).  kv_save [TB, heads, d, d] leaves for the backward pass.  Needs N % 256 == 0, batch strides % 8 == 0. */
+int s2f_sdsa_lif_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                          int64_t k_batch_stride, int64_t v_batch_stride, uint16_t* y_spikes, uint64_t* mask, uint64_t* stats,
+                          float* kv_save, int TB, int heads, int d, int N, float scale, float vth, int D, void* stream);
 
 /* ---- a9: DCNv3 core ---------------------------------------------------------------------------------
  * Replaces dcnv3_core_pytorch (ops_dcnv3/functions/dcnv3_func.py:147-189; = the dormant CUDA op

@@ -34,9 +34,9 @@ SIGNATURES = {
     "s2f_bn_stats": (_i, [_p] * 3 + [_i64] * 3 + [_p]),
     "s2f_bn_act_fwd": (_i, [_p] * 16 + [_i64] * 3 + [_f, _f, _i, _f, _i, _i, _p]),
     "s2f_bn_act_bwd": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
-    "s2f_dwconv_fwd": (_i, [_p] * 4 + [_i] * 6 + [_p]),
+    "s2f_dwconv_fwd": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_dwconv_bwd_input": (_i, [_p] * 3 + [_i] * 6 + [_p]),
-    "s2f_dwconv_bwd_weight": (_i, [_p] * 4 + [_i] * 7 + [_p]),
+    "s2f_dwconv_bwd_weight": (_i, [_p] * 4 + [_i] * 8 + [_p]),
     "s2f_split_bf16x3": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "s2f_split_bf16x3_multi": (_i, [_p, _i, _i64, _p]),
     "s2f_spike_gemm_fwd": (_i, [_p] * 4 + [_i] * 7 + [_p]),
@@ -54,6 +54,9 @@ SIGNATURES = {
     "s2f_spike_conv3x3_dw_bf16": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "s2f_sdsa_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _f, _p]),
+    "s2f_sdsa_fwd_bf16": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "s2f_sdsa_bwd_bf16": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _i, _p, _p, _p, _i64, _i64, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "s2f_sdsa_lif_fwd_bf16": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p]),
     "s2f_sdsa_kv": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_apply": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "s2f_dcnv3_fwd": (_i, [_p] * 4 + [_i] * 13 + [_f, _p]),

@@ -257,7 +257,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
             wb()
         if training:
             torch._foreach_add_([b.num_batches_tracked for bns in t["bns"] for b in bns], 1)
-        return ops.split3(y.float().view(T * B, 3 * C, N))
+        return y.view(T * B, 3 * C, N)          # q | k | v spikes, channel-stacked: the attention core reads the ranges in place
 
     def _can_batch(self):
         lifs = (self.q_spike, self.k_spike, self.v_spike)
@@ -272,15 +272,16 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         T, B, C, H, W = x.shape
         N = H * W
         s = self.head_spike.fire(x).flatten(0, 1)
+        # attention core + attn_spike: one fused kernel on the bf16 spikes when the neuron is stateless (ops.sdsa)
         if s.is_cuda and N % 4 == 0 and self._can_batch():
-            q, k, v = self._qkv_batched(s, T, B, C, H, W)
+            o = ops.sdsa_packed(self._qkv_batched(s, T, B, C, H, W), self.num_heads, self.scale, lif=self.attn_spike)
         else:
             q, k, v = ops.branches([
                 lambda: self.q_conv[0](s, outer_bn=self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N),
                 lambda: self.k_conv[0](s, outer_bn=self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N),
                 lambda: self.v_conv[0](s, outer_bn=self.v_conv[1], lif=self.v_spike)[1].view(T * B, C, N)], inputs=(s,))
-        o = ops.sdsa(q, k, v, self.num_heads, self.scale)           # [TB, C, N], c = head*d + j
-        o = self.attn_spike.fire(o).view(T * B, C, H, W)
+            o = ops.sdsa(q, k, v, self.num_heads, self.scale, lif=self.attn_spike)           # [TB, C, N], c = head*d + j
+        o = o.view(T * B, C, H, W)
         res = None if residual is None else residual.flatten(0, 1)
         return self.proj_conv[0](o, outer_bn=self.proj_conv[1], residual=res, next_lif=next_lif)[0].reshape(T, B, C, H, W)
 

@@ -20,16 +20,26 @@ namespace {
 
 constexpr int TS = 32;   // tile side (outputs)
 
+// The stencil input is fp32, or a bf16 spike map (uint16 storage, exact) as the neuron kernels write it.
+__device__ __forceinline__ float ldx(const float* p) { return *p; }
+__device__ __forceinline__ float ldx(const unsigned short* p) { return __uint_as_float(((unsigned int)*p) << 16); }
+__device__ __forceinline__ float4 ldx4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldx4(const unsigned short* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+
 // Stage the (TS + K - 1)^2 halo tile whose origin is (oy0, ox0) in plane coordinates.  The aligned TS x TS block inside
 // it (offset `po` in both directions: plane pixel (ty, tx), tx % 4 == 0) is loaded with ONE 16-byte load per thread; the
 // K - 1 wide ring around it with scalar loads by the first threads.  `fill` = value read in the padding ring of width
 // `fpad` around the plane (BNAndPadLayer's border), zero further out.
-template <int K>
-__device__ __forceinline__ void stage_halo(float (&s)[TS + K - 1][TS + K], const float* __restrict__ xp, int H, int W, int oy0,
+template <int K, typename TX>
+__device__ __forceinline__ void stage_halo(float (&s)[TS + K - 1][TS + K], const TX* __restrict__ xp, int H, int W, int oy0,
                                            int ox0, int po, float fillv, int fpad, bool vec_ok) {
   constexpr int HS = TS + K - 1;
   auto at = [&](int iy, int ix) -> float {
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) return xp[(int64_t)iy * W + ix];
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) return ldx(xp + (int64_t)iy * W + ix);
     if (iy >= -fpad && iy < H + fpad && ix >= -fpad && ix < W + fpad) return fillv;
     return 0.f;
   };
@@ -38,7 +48,7 @@ __device__ __forceinline__ void stage_halo(float (&s)[TS + K - 1][TS + K], const
     const int iy = oy0 + po + ri, ix = ox0 + po + qi;
     float4 v;
     if (vec_ok && iy >= 0 && iy < H && ix >= 0 && ix + 3 < W) {
-      v = *reinterpret_cast<const float4*>(xp + (int64_t)iy * W + ix);
+      v = ldx4(xp + (int64_t)iy * W + ix);
     } else {
       v = make_float4(at(iy, ix), at(iy, ix + 1), at(iy, ix + 2), at(iy, ix + 3));
     }
@@ -67,8 +77,8 @@ __device__ __forceinline__ void stage_halo(float (&s)[TS + K - 1][TS + K], const
 
 // FLIP = false: y[oy][ox] = sum_{i,j} w[i][j] * x[oy + i - pad][ox + j - pad]           (x: H x W, y: Ho x Wo)
 // FLIP = true : y[oy][ox] = sum_{i,j} w[i][j] * x[oy - i + pad][ox - j + pad]           (input gradient: x = gy)
-template <int K, bool FLIP>
-__global__ __launch_bounds__(256) void dw_stencil_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int K, bool FLIP, typename TX>
+__global__ __launch_bounds__(256) void dw_stencil_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ border, float* __restrict__ y, int C,
                                                          int H, int W, int Ho, int Wo, int pad, int tiles_x) {
   constexpr int HS = TS + K - 1;
@@ -76,12 +86,12 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const float* __restrict
   const int plane = blockIdx.y;
   const int c = plane % C;
   const int ty = (blockIdx.x / tiles_x) * TS, tx = (blockIdx.x % tiles_x) * TS;
-  const float* xp = x + (int64_t)plane * H * W;
+  const TX* xp = x + (int64_t)plane * H * W;
   const float fillv = (!FLIP && border) ? border[c] : 0.f;
   // halo origin in input coordinates; the aligned block (ty, tx) sits `po` inside it
   const int po = FLIP ? K - 1 - pad : pad;
-  const bool vec_ok = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15u) == 0;
-  stage_halo<K>(s, xp, H, W, ty - po, tx - po, po, fillv, FLIP ? 0 : pad, vec_ok);
+  const bool vec_ok = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & (4 * sizeof(TX) - 1)) == 0;
+  stage_halo<K, TX>(s, xp, H, W, ty - po, tx - po, po, fillv, FLIP ? 0 : pad, vec_ok);
   float wk[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) wk[i] = w[c * K * K + i];
@@ -122,8 +132,8 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const float* __restrict
 // 1.5 LDS reads of 16 bytes instead of 17.5 of 4 bytes.  'Same' padding (pad == (K - 1) / 2) only.
 constexpr int WT = 64, HT = 32, WS = WT + 8;           // tile and staged row length (floats)
 
-template <int K, bool FLIP>
-__global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int K, bool FLIP, typename TX>
+__global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ border, float* __restrict__ y,
                                                               int C, int H, int W, int Ho, int Wo, int pad, int tiles_x) {
   constexpr int HR = HT + K - 1;                       // staged rows
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const float* __res
   const int plane = blockIdx.y;
   const int c = plane % C;
   const int ty = (blockIdx.x / tiles_x) * HT, tx = (blockIdx.x % tiles_x) * WT;
-  const float* xp = x + (int64_t)plane * H * W;
+  const TX* xp = x + (int64_t)plane * H * W;
   const float fillv = (!FLIP && border) ? border[c] : 0.f;    // every off-plane value a valid output reads is the border
   const int po = pad;                                  // == K - 1 - pad
   // stage rows ty - po .. ty - po + HR - 1, columns tx - 4 .. tx + 67 as 18 groups of 4
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const float* __res
     const int r = e / (WS / 4), g = e - r * (WS / 4);
     const int iy = ty - po + r, ix = tx - 4 + g * 4;
     const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const float4 v = *reinterpret_cast<const float4*>(xp + (in ? (int64_t)iy * W + ix : 0));
+    const float4 v = ldx4(xp + (in ? (int64_t)iy * W + ix : 0));
     *reinterpret_cast<float4*>(&s[r][g * 4]) = in ? v : make_float4(fillv, fillv, fillv, fillv);
   }
   float wk[K * K];
@@ -191,8 +201,8 @@ __global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const float* __res
 // pixels of one tile row and forms its K*K partial sums in registers (K rows of K+3 staged inputs, as in the stencil); the
 // block sum runs over wave shuffles and one LDS round.  (A (tap, pixel-slice) thread mapping spent ~10 instructions per
 // multiply-add on index arithmetic: 1.9 TB/s on the 537 MB maps.)
-template <int K>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ border,
+template <int K, typename TX>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const TX* __restrict__ x, const float* __restrict__ border,
                                                        const float* __restrict__ gy, float* __restrict__ gw, int C, int H,
                                                        int W, int Ho, int Wo, int pad, int tiles_x, int ntiles) {
   constexpr int HS = TS + K - 1;
@@ -201,10 +211,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   __shared__ float red[4][KK];
   const int plane = blockIdx.y;
   const int c = plane % C;
-  const float* xp = x + (int64_t)plane * H * W;
+  const TX* xp = x + (int64_t)plane * H * W;
   const float* gp = gy + (int64_t)plane * Ho * Wo;
   const float fillv = border ? border[c] : 0.f;
-  const bool vec_ok = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15u) == 0;
+  const bool vec_ok = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & (4 * sizeof(TX) - 1)) == 0;
   const int r = threadIdx.x >> 3, q0 = (threadIdx.x & 7) * 4;
   float acc[KK];
 #pragma unroll
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int ty = (tile / tiles_x) * TS, tx = (tile % tiles_x) * TS;
     __syncthreads();                          // the previous tile's readers are done with s
-    stage_halo<K>(s, xp, H, W, ty - pad, tx - pad, pad, fillv, pad, vec_ok);
+    stage_halo<K, TX>(s, xp, H, W, ty - pad, tx - pad, pad, fillv, pad, vec_ok);
     float g[4] = {0.f, 0.f, 0.f, 0.f};
     const int oy = ty + r, ox = tx + q0;
     const float* p = gp + (int64_t)oy * Wo + ox;
@@ -264,39 +274,43 @@ int check(const char* who, int N, int C, int H, int W, int K, int pad, int& Ho, 
   return S2F_OK;
 }
 
-template <bool FLIP>
-void launch_stencil(int K, dim3 grid, hipStream_t s, const float* x, const float* w, const float* border, float* y, int C,
+template <bool FLIP, typename TX>
+void launch_stencil(int K, dim3 grid, hipStream_t s, const TX* x, const float* w, const float* border, float* y, int C,
                     int H, int W, int Ho, int Wo, int pad, int tiles_x) {
   // 3x3 on wide maps with 'same' padding: 64 x 32 tiles, vector staging, 2 x 4 outputs per thread.  Measured
   // (tools/probe_dw.py, us, 32x32-tile form -> wide form): 3x3 [8,256,256,256] 267 -> 222, [8,256,128,128] 70 -> 53,
   // [8,256,64,64] 17 -> 18; 7x7 [8,64,256,256] 109 -> 139 (49 multiply-adds per output: that stencil is VALU-bound and the
   // 2 x 4 block only adds register pressure), so the wide form is used for K = 3, W >= 128 only.
   static const bool wide_on = !getenv("S2F_DW_NO_WIDE");          // A/B switch for tools/probe_dw.py
-  if (wide_on && K == 3 && (W & 3) == 0 && W >= 2 * WT && H >= HT && pad == 1 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+  if (wide_on && K == 3 && (W & 3) == 0 && W >= 2 * WT && H >= HT && pad == 1 && (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(TX) - 1)) == 0) {
     const int wx = (Wo + WT - 1) / WT, wy = (Ho + HT - 1) / HT;
-    hipLaunchKernelGGL((dw_stencil_wide_kernel<3, FLIP>), dim3(wx * wy, grid.y), dim3(256), 0, s, x, w, border, y, C, H, W, Ho,
+    hipLaunchKernelGGL((dw_stencil_wide_kernel<3, FLIP, TX>), dim3(wx * wy, grid.y), dim3(256), 0, s, x, w, border, y, C, H, W, Ho,
                        Wo, pad, wx);
     return;
   }
   if (K == 3)
-    hipLaunchKernelGGL((dw_stencil_kernel<3, FLIP>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL((dw_stencil_kernel<3, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
   else if (K == 5)
-    hipLaunchKernelGGL((dw_stencil_kernel<5, FLIP>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL((dw_stencil_kernel<5, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
   else
-    hipLaunchKernelGGL((dw_stencil_kernel<7, FLIP>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL((dw_stencil_kernel<7, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
 }
 
 }  // namespace
 
-extern "C" int s2f_dwconv_fwd(const float* x, const float* w, const float* border, float* y, int N, int C, int H, int W,
-                              int K, int pad, void* stream) {
+extern "C" int s2f_dwconv_fwd(const void* x, const float* w, const float* border, float* y, int N, int C, int H, int W,
+                              int K, int pad, int x_bf16, void* stream) {
   S2F_REQUIRE(x && w && y, S2F_EINVAL, "s2f_dwconv_fwd: null pointer");
   int Ho, Wo;
   int rc = check("s2f_dwconv_fwd", N, C, H, W, K, pad, Ho, Wo);
   if (rc) return rc;
   const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
-  launch_stencil<false>(K, dim3(tiles_x * tiles_y, N * C), (hipStream_t)stream, x, w, border, y, C, H, W, Ho, Wo, pad,
-                        tiles_x);
+  if (x_bf16)
+    launch_stencil<false>(K, dim3(tiles_x * tiles_y, N * C), (hipStream_t)stream, reinterpret_cast<const unsigned short*>(x), w,
+                          border, y, C, H, W, Ho, Wo, pad, tiles_x);
+  else
+    launch_stencil<false>(K, dim3(tiles_x * tiles_y, N * C), (hipStream_t)stream, reinterpret_cast<const float*>(x), w, border,
+                          y, C, H, W, Ho, Wo, pad, tiles_x);
   return s2f_check_launch("s2f_dwconv_fwd");
 }
 
@@ -313,8 +327,10 @@ extern "C" int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, 
   return s2f_check_launch("s2f_dwconv_bwd_input");
 }
 
-extern "C" int s2f_dwconv_bwd_weight(const float* x, const float* border, const float* gy, float* gw, int N, int C, int H,
-                                     int W, int K, int pad, int accumulate, void* stream) {
+extern "C" int s2f_dwconv_bwd_weight(const void* x_in, const float* border, const float* gy, float* gw, int N, int C, int H,
+                                     int W, int K, int pad, int accumulate, int x_bf16, void* stream) {
+  const float* x = reinterpret_cast<const float*>(x_in);
+  const unsigned short* xh = reinterpret_cast<const unsigned short*>(x_in);
   S2F_REQUIRE(x && gy && gw, S2F_EINVAL, "s2f_dwconv_bwd_weight: null pointer");
   int Ho, Wo;
   int rc = check("s2f_dwconv_bwd_weight", N, C, H, W, K, pad, Ho, Wo);
@@ -329,11 +345,21 @@ extern "C" int s2f_dwconv_bwd_weight(const float* x, const float* border, const 
   if (per_plane > ntiles) per_plane = ntiles;
   if (per_plane < 1) per_plane = 1;
   const dim3 grid(per_plane, N * C);
+#define S2F_WG(KV)                                                                                                          \
+  do {                                                                                                                      \
+    if (x_bf16)                                                                                                             \
+      hipLaunchKernelGGL((dw_wgrad_kernel<KV, unsigned short>), grid, dim3(256), 0, s, xh, border, gy, gw, C, H, W, Ho, Wo, \
+                         pad, tiles_x, ntiles);                                                                             \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((dw_wgrad_kernel<KV, float>), grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad,      \
+                         tiles_x, ntiles);                                                                                  \
+  } while (0)
   if (K == 3)
-    hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x, ntiles);
+    S2F_WG(3);
   else if (K == 5)
-    hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x, ntiles);
+    S2F_WG(5);
   else
-    hipLaunchKernelGGL(dw_wgrad_kernel<7>, grid, dim3(256), 0, s, x, border, gy, gw, C, H, W, Ho, Wo, pad, tiles_x, ntiles);
+    S2F_WG(7);
+#undef S2F_WG
   return s2f_check_launch("s2f_dwconv_bwd_weight");
 }

@@ -21,9 +21,56 @@ namespace {
 constexpr int kDMax = 64;   // head dim limit (block3: 32, block4: 45, decoder: 32)
 constexpr int kNT = 64;     // columns staged per step
 
+// Operand element types: fp32, or bf16 spikes (exact; 2 bytes / element) as the neuron kernels write them.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const unsigned short* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const unsigned short* p) { return __uint_as_float(((unsigned int)*p) << 16); }
+
+// An operand of the two building blocks: rows [h*d, (h+1)*d) of batch element tb of a channel-major tensor whose batch
+// elements lie `batch_stride` elements apart (q / k / v may be channel ranges of one [TB, 3C, N] tensor).  With `mask` set the
+// operand is the straight-through gradient of a neuron output: value = in-range bit ? g / D : 0, the bit of element e of
+// the CONTIGUOUS [TB, C, N] spike tensor in the layout of s2f_lif_mask_words (word (e & 3) of tile e >> 8, bit (e & 255) >> 2).
+template <typename T>
+struct Operand {
+  const T* base;
+  int64_t batch_stride;
+  const uint64_t* mask;
+  float inv_d;
+};
+
+template <typename T>
+__device__ __forceinline__ float4 opnd_ld4(const Operand<T>& o, const T* row, int64_t e_row, int n) {
+  float4 v = ld4(row + n);
+  if (o.mask) {
+    const int64_t e = e_row + n;               // e % 4 == 0: the four elements share tile and bit position
+    const uint64_t* w = o.mask + (e >> 8) * 4;
+    const int bit = (int)((e & 255) >> 2);
+    v.x = ((w[0] >> bit) & 1ull) ? v.x * o.inv_d : 0.f;
+    v.y = ((w[1] >> bit) & 1ull) ? v.y * o.inv_d : 0.f;
+    v.z = ((w[2] >> bit) & 1ull) ? v.z * o.inv_d : 0.f;
+    v.w = ((w[3] >> bit) & 1ull) ? v.w * o.inv_d : 0.f;
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ float opnd_ld1(const Operand<T>& o, const T* row, int64_t e_row, int n) {
+  float v = ld1(row + n);
+  if (o.mask) {
+    const int64_t e = e_row + n;
+    v = ((o.mask[(e >> 8) * 4 + (e & 3)] >> ((e & 255) >> 2)) & 1ull) ? v * o.inv_d : 0.f;
+  }
+  return v;
+}
+
 // grid (TB*heads, nsplit); block 256.  LDS: two [d][kNT+1] tiles.
-__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                    float* __restrict__ M, int heads, int d, int N, float alpha) {
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void outer_kernel(Operand<TA> OA, Operand<TB> OB, float* __restrict__ M, int heads, int d,
+                                                    int N, float alpha) {
   // rows padded to kNT + 4 floats: 16-byte aligned rows for float4 staging and ds_read_b128 in the product loop (the scalar
   // form issued four ds_read_b32 per four multiply-adds and was LDS-bound: 22 us for two 8 MB operands)
   __shared__ __attribute__((aligned(16))) float sa[kDMax][kNT + 4];
@@ -31,13 +78,15 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ A,
   const int bh = blockIdx.x;
   const int tb = bh / heads, h = bh % heads;
   const int C = heads * d;
-  const float* a = A + ((int64_t)tb * C + h * d) * N;
-  const float* b = B + ((int64_t)tb * C + h * d) * N;
+  const TA* a = OA.base + (int64_t)tb * OA.batch_stride + (int64_t)h * d * N;
+  const TB* b = OB.base + (int64_t)tb * OB.batch_stride + (int64_t)h * d * N;
+  const int64_t e0 = ((int64_t)tb * C + h * d) * N;          // element index of the head's first row in a contiguous [TB, C, N]
   const int nsplit = gridDim.y;
   const int chunk = ((N + nsplit - 1) / nsplit + kNT - 1) / kNT * kNT;
   const int n_begin = blockIdx.y * chunk;
   const int n_end = min(N, n_begin + chunk);
-  const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15u) == 0;
+  const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & (4 * sizeof(TA) - 1)) == 0 &&
+                   (reinterpret_cast<uintptr_t>(b) & (4 * sizeof(TB) - 1)) == 0 && ((OA.batch_stride | OB.batch_stride) & 3) == 0;
   // each thread owns a 2x2 micro-tile per pass over (i, j)
   const int dt = (d + 1) / 2;          // micro-tiles per side
   const int ntile = dt * dt;
@@ -52,15 +101,15 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ A,
         const int r = e / (kNT / 4), c = (e % (kNT / 4)) * 4;
         const bool ok = n0 + c < n_end;                  // n_end - n0 is a multiple of 4 here: whole groups
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&sa[r][c]) = ok ? *reinterpret_cast<const float4*>(a + (int64_t)r * N + n0 + c) : z4;
-        *reinterpret_cast<float4*>(&sb[r][c]) = ok ? *reinterpret_cast<const float4*>(b + (int64_t)r * N + n0 + c) : z4;
+        *reinterpret_cast<float4*>(&sa[r][c]) = ok ? opnd_ld4(OA, a + (int64_t)r * N, e0 + (int64_t)r * N, n0 + c) : z4;
+        *reinterpret_cast<float4*>(&sb[r][c]) = ok ? opnd_ld4(OB, b + (int64_t)r * N, e0 + (int64_t)r * N, n0 + c) : z4;
       }
     } else {
       for (int e = threadIdx.x; e < d * kNT; e += 256) {
         const int r = e / kNT, c = e % kNT;
         const bool ok = n0 + c < n_end;
-        sa[r][c] = ok ? a[(int64_t)r * N + n0 + c] : 0.f;
-        sb[r][c] = ok ? b[(int64_t)r * N + n0 + c] : 0.f;
+        sa[r][c] = ok ? opnd_ld1(OA, a + (int64_t)r * N, e0 + (int64_t)r * N, n0 + c) : 0.f;
+        sb[r][c] = ok ? opnd_ld1(OB, b + (int64_t)r * N, e0 + (int64_t)r * N, n0 + c) : 0.f;
       }
     }
     __syncthreads();
@@ -108,9 +157,9 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ A,
 // grid (TB*heads, ceil(N/256)); block 256 = 4 waves.  Lane l of every wave owns columns n0+4l .. n0+4l+3 (one 16-byte
 // load per row of X); wave w owns output rows j in [w*JC, (w+1)*JC).  M is staged in LDS zero-padded to 4*JC columns,
 // and read as broadcast 16-byte rows: one ds_read_b128 feeds 16 FMAs.
-template <bool TRANS, int JC>
-__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X, const float* __restrict__ M,
-                                                    float* __restrict__ Y, int heads, int d, int N, float alpha) {
+template <bool TRANS, int JC, typename TX>
+__global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float* __restrict__ M, float* __restrict__ Y,
+                                                    int64_t y_batch_stride, int heads, int d, int N, float alpha) {
   constexpr int LD = 4 * JC;
   __shared__ __attribute__((aligned(16))) float sm[kDMax * LD];
   const int bh = blockIdx.x;
@@ -125,9 +174,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.y * 256 + lane * 4;
   if (n >= N) return;
-  const float* x = X + ((int64_t)tb * C + h * d) * N + n;
-  float* y = Y + ((int64_t)tb * C + h * d) * N + n;
-  const bool vec = (n + 3 < N) && ((N & 3) == 0);
+  const TX* x = OX.base + (int64_t)tb * OX.batch_stride + (int64_t)h * d * N;
+  const int64_t e0 = ((int64_t)tb * C + h * d) * N;
+  float* y = Y + (int64_t)tb * y_batch_stride + (int64_t)h * d * N + n;
+  const bool vec = (n + 3 < N) && ((N & 3) == 0) && ((OX.batch_stride | y_batch_stride) & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(TX) - 1)) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0;
   float acc[JC][4];
 #pragma unroll
   for (int j = 0; j < JC; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
@@ -140,11 +191,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
     for (int u = 0; u < G; ++u) {
       const int i = min(i0 + u, d - 1);                  // clamped duplicate rows are skipped below
       if (vec) {
-        const float4 t = *reinterpret_cast<const float4*>(x + (int64_t)i * N);
+        const float4 t = opnd_ld4(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n);
         xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
       } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[u][c] = (n + c < N) ? x[(int64_t)i * N + c] : 0.f;
+        for (int c = 0; c < 4; ++c) xv[u][c] = (n + c < N) ? opnd_ld1(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n + c) : 0.f;
       }
     }
 #pragma unroll
@@ -178,19 +229,21 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
   }
 }
 
-template <bool TRANS>
-void launch_apply(const float* x, const float* m, float* y, int TB, int heads, int d, int N, float alpha, hipStream_t s) {
+template <bool TRANS, typename TX>
+void launch_apply(Operand<TX> x, const float* m, float* y, int64_t y_batch_stride, int TB, int heads, int d, int N, float alpha,
+                  hipStream_t s) {
   dim3 grid(TB * heads, (N + 255) / 256);
   const int jc = ((d + 3) / 4 + 3) / 4 * 4;     // rows per wave, rounded up to a multiple of 4
   if (jc <= 4)
-    hipLaunchKernelGGL((apply_kernel<TRANS, 4>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+    hipLaunchKernelGGL((apply_kernel<TRANS, 4, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
   else if (jc <= 8)
-    hipLaunchKernelGGL((apply_kernel<TRANS, 8>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+    hipLaunchKernelGGL((apply_kernel<TRANS, 8, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
   else if (jc <= 12)
-    hipLaunchKernelGGL((apply_kernel<TRANS, 12>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+    hipLaunchKernelGGL((apply_kernel<TRANS, 12, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
   else
-    hipLaunchKernelGGL((apply_kernel<TRANS, 16>), grid, dim3(256), 0, s, x, m, y, heads, d, N, alpha);
+    hipLaunchKernelGGL((apply_kernel<TRANS, 16, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
 }
+
 
 // Workgroups per (tb, head): the kernel walks its columns in 64-wide steps, each a global -> LDS -> FMA round trip with no
 // prefetch, so a workgroup should own ONE step when there are columns to spare (26 us with 4 steps per workgroup at
@@ -207,6 +260,178 @@ int check(const char* who, int TB, int heads, int d, int N) {
   return S2F_OK;
 }
 
+template <typename TA, typename TB>
+int launch_outer(Operand<TA> a, Operand<TB> b, float* kv, int TB_, int heads, int d, int N, float alpha, hipStream_t s) {
+  const int ns = pick_split(TB_ * heads, N);
+  if (ns > 1 && s2f_zero_async(kv, sizeof(float) * (size_t)TB_ * heads * d * d, s) != S2F_OK)
+    return s2f_check_launch("s2f_sdsa_kv clear");
+  hipLaunchKernelGGL((outer_kernel<TA, TB>), dim3(TB_ * heads, ns), dim3(256), 0, s, a, b, kv, heads, d, N, alpha);
+  return s2f_check_launch("s2f_sdsa_kv");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The attention core and the neuron behind it as ONE kernel (the backbone's self-attention, sdtv2.py:335-342):
+//     kv = k^T v  (d x d)  ->  o = scale * q kv  ->  y = Q_IFNode(o)   written as bf16 spikes + 1-bit in-range mask + counters
+// One workgroup per (tb, head).  q / k / v are bf16 spike maps (exact), possibly channel ranges of one [TB, 3C, N] tensor.
+// Phase 1: kv on the matrix cores straight from memory -- both operands are contraction-contiguous rows (A = k rows,
+// B = v rows, 8 consecutive columns per lane: v_mfma_f32_32x32x16_bf16), products and sums exact in fp32 (spike operands,
+// see the file header); the four waves own interleaved 16-column slices and add their partial tiles through LDS.
+// kv leaves for the backward pass; o never touches HBM, nor does a separate neuron kernel re-read it.
+// Phase 2: as apply_kernel (lane = 4 columns, wave = JC output rows, kv broadcast from LDS), then the neuron update of
+// s2f_lif_fwd on o (reset membrane), spikes as bf16, ballot mask, firing counters.  Needs N % 256 == 0 (a wave's 256
+// columns are one mask tile) and 16-byte aligned rows.
+typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
+typedef __attribute__((ext_vector_type(16))) float ff32x16;
+
+template <int DT, int JC>
+__global__ __launch_bounds__(256) void sdsa_lif_fwd_kernel(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
+                                                           const unsigned short* __restrict__ V, int64_t q_bs, int64_t k_bs,
+                                                           int64_t v_bs, unsigned short* __restrict__ Yspk,
+                                                           uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
+                                                           float* __restrict__ KV, int heads, int d, int N, float scale,
+                                                           float vth, float Df) {
+  constexpr int LD = 4 * JC;                         // kv row length in LDS (>= d, zero padded)
+  __shared__ __attribute__((aligned(16))) float red[3][DT * DT][16][64];      // partial tiles of waves 1..3
+  __shared__ __attribute__((aligned(16))) float sm[kDMax * LD];
+  __shared__ unsigned int sred[8];
+  const int bh = blockIdx.x;
+  const int tb = bh / heads, h = bh % heads;
+  const int C = heads * d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned short* kr = K + (int64_t)tb * k_bs + (int64_t)h * d * N;
+  const unsigned short* vr = V + (int64_t)tb * v_bs + (int64_t)h * d * N;
+  const unsigned short* qr = Q + (int64_t)tb * q_bs + (int64_t)h * d * N;
+
+  // ---- phase 1: kv[i][j] = sum_n k[i][n] v[j][n]
+  ff32x16 acc[DT][DT];
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int row = lane & 31, ksub = 8 * (lane >> 5);
+  for (int n0 = wave * 16; n0 < N; n0 += 64) {
+    fbf16x8 af[DT], bf[DT];
+#pragma unroll
+    for (int a = 0; a < DT; ++a) {
+      const int i = a * 32 + row;
+      uint4 ka = make_uint4(0u, 0u, 0u, 0u), va = make_uint4(0u, 0u, 0u, 0u);
+      if (i < d) {
+        ka = *reinterpret_cast<const uint4*>(kr + (int64_t)i * N + n0 + ksub);
+        va = *reinterpret_cast<const uint4*>(vr + (int64_t)i * N + n0 + ksub);
+      }
+      af[a] = *reinterpret_cast<fbf16x8*>(&ka);
+      bf[a] = *reinterpret_cast<fbf16x8*>(&va);
+    }
+#pragma unroll
+    for (int a = 0; a < DT; ++a)
+#pragma unroll
+      for (int b = 0; b < DT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < DT; ++a)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][a * DT + b][r][lane] = acc[a][b][r];
+  }
+  for (int e = threadIdx.x; e < kDMax * LD; e += 256) sm[e] = 0.f;
+  __syncthreads();
+  if (wave == 0) {
+    float* kvg = KV + (int64_t)bh * d * d;
+#pragma unroll
+    for (int a = 0; a < DT; ++a)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[a][b][r] + red[0][a * DT + b][r][lane] + red[1][a * DT + b][r][lane] + red[2][a * DT + b][r][lane];
+          // C layout of the 32x32 MFMA: column (j) = lane & 31, row (i) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+          const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = b * 32 + (lane & 31);
+          if (i < d && j < d) {
+            sm[i * LD + j] = v;
+            kvg[i * d + j] = v;
+          }
+        }
+  }
+  __syncthreads();
+
+  // ---- phase 2: o[j][n] = scale * sum_i q[i][n] kv[i][j]; y = Q_IFNode(o)
+  unsigned int csum = 0, cnz = 0;
+  const int64_t e_head = ((int64_t)tb * C + h * d) * N;            // element index in the contiguous [TB, C, N] output
+  for (int nb = 0; nb < N; nb += 256) {
+    const int n = nb + lane * 4;
+    float o[JC][4];
+#pragma unroll
+    for (int j = 0; j < JC; ++j) o[j][0] = o[j][1] = o[j][2] = o[j][3] = 0.f;
+    constexpr int G = 8;
+    for (int i0 = 0; i0 < d; i0 += G) {
+      float4 xv[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) xv[u] = ld4(qr + (int64_t)min(i0 + u, d - 1) * N + n);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (i0 + u < d) {
+          const float* rowp = sm + (i0 + u) * LD + wave * JC;
+          const float xq[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+          for (int j4 = 0; j4 < JC; j4 += 4) {
+            const float4 mv = *reinterpret_cast<const float4*>(rowp + j4);
+            const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[j4 + jj][c] += xq[c] * mm[jj];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const int jg = wave * JC + j;                   // wave-uniform
+      if (jg < d) {
+        float yv[4];
+        bool inr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float sp, yy, vn;
+          s2f_lif_update(o[j][c] * scale, Df, 1.0f, vth, sp, yy, vn, inr[c]);
+          yv[c] = sp / Df;
+          csum += (unsigned int)sp;
+          cnz += ((unsigned int)sp != 0);
+        }
+        const int64_t e = e_head + (int64_t)jg * N + n;
+        *reinterpret_cast<uint2*>(Yspk + e) = s2f_spikes_to_bf16x4(yv[0], yv[1], yv[2], yv[3]);
+        const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+        if (mask != nullptr && lane < 4) mask[(e >> 8) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+      }
+    }
+  }
+  if (stats != nullptr) {
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+      csum += __shfl_xor(csum, ofs, 64);
+      cnz += __shfl_xor(cnz, ofs, 64);
+    }
+    if (lane == 0) {
+      sred[wave * 2] = csum;
+      sred[wave * 2 + 1] = cnz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long a = 0, b = 0;
+      for (int w = 0; w < 4; ++w) {
+        a += sred[2 * w];
+        b += sred[2 * w + 1];
+      }
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (a) atomicAdd(&slot[0], a);
+      if (b) atomicAdd(&slot[1], b);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int s2f_sdsa_kv(const float* k, const float* v, float* kv, int TB, int heads, int d, int N, float alpha,
@@ -214,14 +439,9 @@ extern "C" int s2f_sdsa_kv(const float* k, const float* v, float* kv, int TB, in
   S2F_REQUIRE(k && v && kv, S2F_EINVAL, "s2f_sdsa_kv: null pointer");
   int rc = check("s2f_sdsa_kv", TB, heads, d, N);
   if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  const int ns = pick_split(TB * heads, N);
-  if (ns > 1) {
-    if (s2f_zero_async(kv, sizeof(float) * (size_t)TB * heads * d * d, s) != S2F_OK)
-      return s2f_check_launch("s2f_sdsa_kv memset");
-  }
-  hipLaunchKernelGGL(outer_kernel, dim3(TB * heads, ns), dim3(256), 0, s, k, v, kv, heads, d, N, alpha);
-  return s2f_check_launch("s2f_sdsa_kv");
+  const int64_t bs = (int64_t)heads * d * N;
+  return launch_outer(Operand<float>{k, bs, nullptr, 0.f}, Operand<float>{v, bs, nullptr, 0.f}, kv, TB, heads, d, N, alpha,
+                      (hipStream_t)stream);
 }
 
 extern "C" int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, int heads, int d, int N, float alpha,
@@ -230,10 +450,11 @@ extern "C" int s2f_sdsa_apply(const float* x, const float* m, float* y, int TB, 
   int rc = check("s2f_sdsa_apply", TB, heads, d, N);
   if (rc) return rc;
   S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y), S2F_EALIGN, "s2f_sdsa_apply: x/y must be 16-byte aligned");
+  const int64_t bs = (int64_t)heads * d * N;
   if (transpose_m)
-    launch_apply<true>(x, m, y, TB, heads, d, N, alpha, (hipStream_t)stream);
+    launch_apply<true>(Operand<float>{x, bs, nullptr, 0.f}, m, y, bs, TB, heads, d, N, alpha, (hipStream_t)stream);
   else
-    launch_apply<false>(x, m, y, TB, heads, d, N, alpha, (hipStream_t)stream);
+    launch_apply<false>(Operand<float>{x, bs, nullptr, 0.f}, m, y, bs, TB, heads, d, N, alpha, (hipStream_t)stream);
   return s2f_check_launch("s2f_sdsa_apply");
 }
 
@@ -259,4 +480,89 @@ extern "C" int s2f_sdsa_bwd(const float* q, const float* k, const float* v, cons
   rc = s2f_sdsa_apply(v, gkv_ws, gk, TB, heads, d, Nk, 1.0f, 1, stream);
   if (rc) return rc;
   return s2f_sdsa_apply(k, gkv_ws, gv, TB, heads, d, Nk, 1.0f, 0, stream);
+}
+
+// ---- bf16 spike operands --------------------------------------------------------------------------------------------
+static int check_bf16(const char* who, const void* q, const void* k, const void* v, int64_t qs, int64_t ks, int64_t vs, int Nq,
+                      int Nk) {
+  S2F_REQUIRE(q && k && v, S2F_EINVAL, "%s: null pointer", who);
+  S2F_REQUIRE((Nq & 3) == 0 && (Nk & 3) == 0 && ((qs | ks | vs) & 3) == 0, S2F_EINVAL,
+              "%s: bf16 operands need token counts and batch strides that are multiples of 4", who);
+  S2F_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 7u) == 0,
+              S2F_EALIGN, "%s: bf16 operands must be 8-byte aligned", who);
+  return S2F_OK;
+}
+
+extern "C" int s2f_sdsa_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                                 int64_t k_batch_stride, int64_t v_batch_stride, float* o, float* kv_save, int TB, int heads,
+                                 int d, int Nq, int Nk, float scale, void* stream) {
+  S2F_REQUIRE(o && kv_save, S2F_EINVAL, "s2f_sdsa_fwd_bf16: null pointer");
+  int rc = check("s2f_sdsa_fwd_bf16", TB, heads, d, Nq);
+  if (rc) return rc;
+  rc = check_bf16("s2f_sdsa_fwd_bf16", q, k, v, q_batch_stride, k_batch_stride, v_batch_stride, Nq, Nk);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  rc = launch_outer(Operand<unsigned short>{k, k_batch_stride, nullptr, 0.f}, Operand<unsigned short>{v, v_batch_stride, nullptr, 0.f},
+                    kv_save, TB, heads, d, Nk, 1.0f, s);
+  if (rc) return rc;
+  launch_apply<false>(Operand<unsigned short>{q, q_batch_stride, nullptr, 0.f}, kv_save, o, (int64_t)heads * d * Nq, TB, heads, d,
+                      Nq, scale, s);
+  return s2f_check_launch("s2f_sdsa_fwd_bf16");
+}
+
+extern "C" int s2f_sdsa_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                                 int64_t k_batch_stride, int64_t v_batch_stride, const float* kv_save, const float* go,
+                                 const uint64_t* go_mask, int D, float* gq, float* gk, float* gv, int64_t gq_batch_stride,
+                                 int64_t gk_batch_stride, int64_t gv_batch_stride, float* gkv_ws, int TB, int heads, int d,
+                                 int Nq, int Nk, float scale, void* stream) {
+  S2F_REQUIRE(kv_save && go && gq && gk && gv && gkv_ws, S2F_EINVAL, "s2f_sdsa_bwd_bf16: null pointer");
+  int rc = check("s2f_sdsa_bwd_bf16", TB, heads, d, Nq);
+  if (rc) return rc;
+  rc = check_bf16("s2f_sdsa_bwd_bf16", q, k, v, q_batch_stride, k_batch_stride, v_batch_stride, Nq, Nk);
+  if (rc) return rc;
+  S2F_REQUIRE(go_mask == nullptr || (D >= 1 && D <= 255), S2F_EINVAL, "s2f_sdsa_bwd_bf16: bad D");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t obs = (int64_t)heads * d * Nq;
+  // the incoming gradient: of o, or -- with go_mask -- of the spikes y = Q_IFNode(o): straight-through inside the loaders
+  const Operand<float> G{go, obs, go_mask, go_mask ? 1.0f / (float)D : 0.f};
+  launch_apply<true>(G, kv_save, gq, gq_batch_stride, TB, heads, d, Nq, scale, s);
+  rc = launch_outer(Operand<unsigned short>{q, q_batch_stride, nullptr, 0.f}, G, gkv_ws, TB, heads, d, Nq, scale, s);
+  if (rc) return rc;
+  launch_apply<true>(Operand<unsigned short>{v, v_batch_stride, nullptr, 0.f}, gkv_ws, gk, gk_batch_stride, TB, heads, d, Nk, 1.0f, s);
+  launch_apply<false>(Operand<unsigned short>{k, k_batch_stride, nullptr, 0.f}, gkv_ws, gv, gv_batch_stride, TB, heads, d, Nk, 1.0f, s);
+  return s2f_check_launch("s2f_sdsa_bwd_bf16");
+}
+
+extern "C" int s2f_sdsa_lif_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                                     int64_t k_batch_stride, int64_t v_batch_stride, uint16_t* y_spikes, uint64_t* mask,
+                                     uint64_t* stats, float* kv_save, int TB, int heads, int d, int N, float scale, float vth,
+                                     int D, void* stream) {
+  S2F_REQUIRE(y_spikes && kv_save, S2F_EINVAL, "s2f_sdsa_lif_fwd_bf16: null pointer");
+  int rc = check("s2f_sdsa_lif_fwd_bf16", TB, heads, d, N);
+  if (rc) return rc;
+  rc = check_bf16("s2f_sdsa_lif_fwd_bf16", q, k, v, q_batch_stride, k_batch_stride, v_batch_stride, N, N);
+  if (rc) return rc;
+  S2F_REQUIRE((N & 255) == 0 && ((q_batch_stride | k_batch_stride | v_batch_stride) & 7) == 0 && D >= 1 && D <= 255, S2F_EINVAL,
+              "s2f_sdsa_lif_fwd_bf16: needs N %% 256 == 0 and batch strides that are multiples of 8");
+  S2F_REQUIRE(s2f_aligned16(q) && s2f_aligned16(k) && s2f_aligned16(v) && (reinterpret_cast<uintptr_t>(y_spikes) & 7u) == 0,
+              S2F_EALIGN, "s2f_sdsa_lif_fwd_bf16: q / k / v must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  auto* st = reinterpret_cast<unsigned long long*>(stats);
+  const int jc = ((d + 3) / 4 + 3) / 4 * 4;
+#define S2F_SL(DTV, JCV)                                                                                               \
+  S2F_LAUNCH(true, true, (sdsa_lif_fwd_kernel<DTV, JCV>), dim3(TB * heads), dim3(256), 0, s, q, k, v, q_batch_stride,    \
+             k_batch_stride, v_batch_stride, y_spikes, mask, st, kv_save, heads, d, N, scale, vth, (float)D)
+  if (d <= 32) {
+    if (jc <= 4)
+      S2F_SL(1, 4);
+    else
+      S2F_SL(1, 8);
+  } else {
+    if (jc <= 12)
+      S2F_SL(2, 12);
+    else
+      S2F_SL(2, 16);
+  }
+#undef S2F_SL
+  return s2f_check_launch("s2f_sdsa_lif_fwd_bf16");
 }

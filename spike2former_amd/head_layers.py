@@ -302,8 +302,7 @@ class MultiHeadAttentionBlock(nn.Module):
                 lambda: self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, fv),
                 lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query)],
                 inputs=(query, key, value, fk, fv))
-        o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5))      # embed_dim**0.5, not head dim
-        o = self.attn_spike.fire(o)
+        o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)      # embed_dim**0.5, not head dim
         o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
         return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
 

@@ -694,8 +694,113 @@ class _SDSA(torch.autograd.Function):
         return gq, gk, gv, None, None
 
 
-def sdsa(q, k, v, heads, scale):
-    return _SDSA.apply(spikes_float(q), spikes_float(k), spikes_float(v), heads, scale)
+class _SDSASpikes(torch.autograd.Function):
+    """The attention core on bf16 spike operands (s2f.h s2f_sdsa_*_bf16), optionally fused with the neuron that follows it
+    (s2f_sdsa_lif_fwd_bf16: kv on the matrix cores, o never written, spikes + mask + counters from the epilogue).
+    packed: `qd` is the stacked q|k|v map [TB, 3C, N] of the batched projection chain (one autograd handle `qt`, one
+    [TB, 3C, N] gradient -- no split / stack copies); otherwise three [TB, C, N*] tensors with a handle each."""
+
+    @staticmethod
+    def forward(ctx, qd, kd, vd, qt, kt, vt, heads, scale, packed, fuse, D, vth, stats):
+        qd = qd.contiguous()
+        TB = qd.shape[0]
+        if packed:
+            C, Nq = qd.shape[1] // 3, qd.shape[2]
+            Nk = Nq
+            qs = ks = vs = 3 * C * Nq
+            qp = qd.data_ptr()
+            kp, vp = qp + 2 * C * Nq, qp + 4 * C * Nq
+        else:
+            kd, vd = kd.contiguous(), vd.contiguous()
+            C, Nq, Nk = qd.shape[1], qd.shape[2], kd.shape[2]
+            qs, ks, vs = C * Nq, C * Nk, C * Nk
+            qp, kp, vp = qd.data_ptr(), kd.data_ptr(), vd.data_ptr()
+        d = C // heads
+        dev = qd.device
+        kv = torch.empty(TB, heads, d, d, dtype=torch.float32, device=dev)
+        ctx.cfg = (TB, C, Nq, Nk, d, heads, scale, packed, fuse, D, (qs, ks, vs))
+        ctx.ptrs_of = (kp - qp, vp - qp)
+        need = any(ctx.needs_input_grad[3:6])
+        if fuse:
+            y = torch.empty(TB, C, Nq, dtype=torch.bfloat16, device=dev)
+            mask = torch.empty(mask_words(y.numel()), dtype=torch.int64, device=dev) if need else None
+            _time_next("sdsa_lif_fwd", 4 * TB * C * (2 * Nk + 2 * Nq), 4 * TB * heads * d * d * (Nk + Nq),
+                       moved=2 * TB * C * (2 * Nk + 2 * Nq))
+            check(lib.s2f_sdsa_lif_fwd_bf16(qp, kp, vp, qs, ks, vs, _ptr(y), _ptr(mask), _ptr(stats), _ptr(kv), TB, heads, d, Nq,
+                                            scale, vth, D, _stream()), "s2f_sdsa_lif_fwd_bf16")
+            ctx.save_for_backward(qd, kd, vd, kv, mask)
+            ctx.mark_non_differentiable(y)
+            return _new_tok(y), y
+        o = torch.empty(TB, C, Nq, dtype=torch.float32, device=dev)
+        check(lib.s2f_sdsa_fwd_bf16(qp, kp, vp, qs, ks, vs, _ptr(o), _ptr(kv), TB, heads, d, Nq, Nk, scale, _stream()),
+              "s2f_sdsa_fwd_bf16")
+        ctx.save_for_backward(qd, kd, vd, kv, None)
+        aux = o.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return o, aux
+
+    @staticmethod
+    def backward(ctx, g, _g1):
+        qd, kd, vd, kv, mask = ctx.saved_tensors
+        TB, C, Nq, Nk, d, heads, scale, packed, fuse, D, (qs, ks, vs) = ctx.cfg
+        g = g.contiguous()
+        dev = g.device
+        qp = qd.data_ptr()
+        if packed:
+            G = torch.empty(TB, 3 * C, Nq, dtype=torch.float32, device=dev)
+            gq, gk, gv = G.data_ptr(), G.data_ptr() + 4 * C * Nq, G.data_ptr() + 8 * C * Nq
+            gs = (3 * C * Nq,) * 3
+            kp, vp = qp + ctx.ptrs_of[0], qp + ctx.ptrs_of[1]
+            out = (G, None, None)
+        else:
+            Gq = torch.empty(TB, C, Nq, dtype=torch.float32, device=dev)
+            Gk = torch.empty(TB, C, Nk, dtype=torch.float32, device=dev)
+            Gv = torch.empty(TB, C, Nk, dtype=torch.float32, device=dev)
+            gq, gk, gv = Gq.data_ptr(), Gk.data_ptr(), Gv.data_ptr()
+            gs = (C * Nq, C * Nk, C * Nk)
+            kp, vp = kd.data_ptr(), vd.data_ptr()
+            out = (Gq, Gk, Gv)
+        ws = torch.empty_like(kv)
+        check(lib.s2f_sdsa_bwd_bf16(qp, kp, vp, qs, ks, vs, _ptr(kv), _ptr(g), _ptr(mask) if fuse else 0, D, gq, gk, gv, *gs,
+                                    _ptr(ws), TB, heads, d, Nq, Nk, scale, _stream()), "s2f_sdsa_bwd_bf16")
+        return (None, None, None) + out + (None,) * 7
+
+
+def sdsa(q, k, v, heads, scale, lif=None):
+    """o = scale * q (k^T v) on channel-major spike maps.  q, k, v: fp32 tensors or Spikes.  `lif`: the Q_IFNode applied to o
+    (the attention's attn_spike); given, the result is its spike map (Spikes) -- from ONE fused kernel when the neuron starts
+    from a reset membrane and keeps none and the shapes allow it (backbone self-attention), else core + neuron."""
+    bf = all(isinstance(t, Spikes) and t.tok is not None for t in (q, k, v))
+    bf = bf and q.shape[2] % 4 == 0 and k.shape[2] % 4 == 0 and q.shape[1] // heads <= 64
+    if not bf:
+        o = _SDSA.apply(spikes_float(q), spikes_float(k), spikes_float(v), heads, scale)
+        return o if lif is None else lif.fire(o)
+    return _sdsa_spikes(q.data, k.data, v.data, q.tok, k.tok, v.tok, heads, scale, False, lif)
+
+
+def sdsa_packed(y, heads, scale, lif=None):
+    """The same with q | k | v = the three channel ranges of one spike map y [TB, 3C, N] (the batched projection chain)."""
+    if not (isinstance(y, Spikes) and y.tok is not None and y.shape[2] % 4 == 0 and y.shape[1] // 3 // heads <= 64):
+        q, k, v = split3(spikes_float(y))
+        return sdsa(q, k, v, heads, scale, lif)
+    return _sdsa_spikes(y.data, None, None, y.tok, None, None, heads, scale, True, lif)
+
+
+def _sdsa_spikes(qd, kd, vd, qt, kt, vt, heads, scale, packed, lif):
+    C = qd.shape[1] // 3 if packed else qd.shape[1]
+    Nq = qd.shape[2]
+    Nk = Nq if packed else kd.shape[2]
+    pure = (lif is not None and isinstance(lif.v, float) and not lif.keep_membrane
+            and not lif._forward_hooks and not lif._forward_pre_hooks)          # hooks want the module call
+    fuse = pure and Nq == Nk and Nq % 256 == 0 and (C * Nq) % 8 == 0
+    if fuse and lif.stats is not None:
+        lif.stats_elems += qd.shape[0] * C * Nq
+    o, ydata = _SDSASpikes.apply(qd, kd, vd, qt, kt, vt, heads, scale, packed, fuse, lif.D if fuse else 8,
+                                 lif.v_threshold if fuse else 1.0, lif.stats if fuse else None)
+    if fuse:
+        lif.v = 0.0
+        return Spikes(ydata, o)
+    return o if lif is None else lif.fire(o)
 
 
 # ------------------------------------------------------------------------------------------------ DCNv3 core
@@ -863,11 +968,12 @@ def scale_affine(gamma, beta, s):
 
 # ------------------------------------------------------------------------------------------------ depthwise conv
 class _DWConv(torch.autograd.Function):
-    """Depthwise KxK, stride 1 (nn.Conv2d(groups=C)); `border` = per-channel constant padding value (detached)."""
+    """Depthwise KxK, stride 1 (nn.Conv2d(groups=C)); `border` = per-channel constant padding value (detached).
+    x: fp32, or a bf16 spike map with its autograd handle `tok`."""
 
     @staticmethod
-    def forward(ctx, x, w, border, pad):
-        _need_cuda(x, w, border)
+    def forward(ctx, x, tok, w, border, pad):
+        _need_cuda(w, border, spikes=x)
         x, w = x.contiguous(), w.contiguous()
         N, C, H, W = x.shape
         K = w.shape[-1]
@@ -875,10 +981,11 @@ class _DWConv(torch.autograd.Function):
         y = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=x.device)
         if border is not None:
             border = border.contiguous()
-        check(lib.s2f_dwconv_fwd(_ptr(x), _ptr(w), _ptr(border), _ptr(y), N, C, H, W, K, pad, _stream()),
+        xb = int(x.dtype == torch.bfloat16)
+        check(lib.s2f_dwconv_fwd(_ptr(x), _ptr(w), _ptr(border), _ptr(y), N, C, H, W, K, pad, xb, _stream()),
               "s2f_dwconv_fwd")
         ctx.save_for_backward(x, w, border)
-        ctx.pad = pad
+        ctx.pad, ctx.has_tok = pad, tok is not None
         return y
 
     @staticmethod
@@ -888,22 +995,24 @@ class _DWConv(torch.autograd.Function):
         N, C, H, W = x.shape
         K = w.shape[-1]
         gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
             check(lib.s2f_dwconv_bwd_input(_ptr(gy), _ptr(w), _ptr(gx), N, C, H, W, K, ctx.pad, _stream()),
                   "s2f_dwconv_bwd_input")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[2]:
             sink = _sink_for(w)
             gw = torch.empty_like(w) if sink is None else None
             side = _wgrad_stream(sink, gy, x, border)
             check(lib.s2f_dwconv_bwd_weight(_ptr(x), _ptr(border), _ptr(gy), _ptr(gw if sink is None else sink), N, C, H, W,
-                                            K, ctx.pad, int(sink is not None),
+                                            K, ctx.pad, int(sink is not None), int(x.dtype == torch.bfloat16),
                                             side.cuda_stream if side is not None else _stream()), "s2f_dwconv_bwd_weight")
-        return gx, gw, None, None
+        return _grad_pair(ctx.has_tok, gx) + (gw, None, None)
 
 
 def dwconv(x, w, pad, border=None):
-    return _DWConv.apply(spikes_float(x), w, border, pad)
+    """x: fp32 tensor or Spikes"""
+    data, tok = _unpack(x)
+    return _DWConv.apply(data, tok, w, border, pad)
 
 
 # ------------------------------------------------------------------------------------------------ spike GEMM (bf16 MFMA)

@@ -9,14 +9,17 @@ import sys
 def cat(name):
     if name.startswith('Cijk'): return 'GEMM (rocBLAS/Tensile)'
     if 'split_gemm' in name: return 'split GEMM (mask einsum), bf16 MFMA (ours)'
-    if 'spike_gemm_dw' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
-    if 'spike_gemm' in name or 'split_bf16' in name: return 'spike GEMM fwd, bf16 MFMA (ours)'
+    if 'split_multi' in name: return 'weight re-split (ours)'
+    if 'spike_gemm_dw' in name or 'sgemm_dw' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
+    if 'dx_' in name: return 'dX GEMM, bf16 MFMA (ours)'
+    if 'spike_gemm' in name or 'split_bf16' in name or 'sgemm_bf16' in name: return 'spike GEMM fwd, bf16 MFMA (ours)'
     if 'up2x' in name: return 'upsample (ours)'
     if 'dcn_' in name: return 'dcn (ours)'
     if 'dw_' in name: return 'dwconv (ours)'
     if 'bn_' in name: return 'bn(+lif) fused (ours)'
     if 'lif_' in name: return 'lif (ours)'
-    if 'apply_kernel' in name or 'outer_kernel' in name: return 'sdsa (ours)'
+    if 'apply_kernel' in name or 'outer_kernel' in name or 'sdsa' in name: return 'sdsa (ours)'
+    if 's2f_zero' in name: return 'fill/memset'
     if 'depthwise' in name: return 'depthwise conv (ATen)'
     if 'batch_norm' in name: return 'batch_norm (ATen)'
     if 'im2col' in name or 'col2im' in name: return 'im2col/col2im (ATen)'
