@@ -226,6 +226,13 @@ int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float* dW, int ba
                            void* stream);
 int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,
                               int accumulate, void* stream);
+/* MANY weight gradients in one launch.  jobs: HOST array of njobs (<= 56) records {dY, X, dW (device pointers), batch, M, K,
+ * L} as int64; each is the product of s2f_spike_gemm_dw_bf16 with accumulate != 0 (dW += ...: the destinations are slices
+ * of a pre-zeroed flat gradient buffer).  The short-contraction layers of the path (32x32 / 64x64 stages, the decoder's
+ * 100-token layers: ~180 launches per step of 18-35 us each, every one split 32-64 ways to fill the chip) become one grid
+ * over all (job, tile, split) triples with a launch-wide contraction length per workgroup; the job table travels in the
+ * kernel arguments.  bkv = contraction elements per step: 64 (rows with L % 64 == 0 or L >= 512) or 32. */
+int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path

@@ -229,10 +229,9 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
 // spike_gemm_dw_kernel (gemm.hip: 4 waves, output tile TM x 128, split-K over B*L with fp32 atomics, dY split hi+mid+lo
 // while it is staged); the X tile is copied as it lies (8-byte chunks of 4 contraction elements).
 template <int BKV, bool CONV, int TM>
-__global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
-                                                            const unsigned short* __restrict__ X, float* __restrict__ dW,
-                                                            int B, int M, int K, int L, int steps_per_split, int k_tiles,
-                                                            Conv3 geo, int log_w) {
+__device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const unsigned short* __restrict__ X,
+                                             float* __restrict__ dW, int B, int M, int K, int L, int steps_per_split,
+                                             int k_tiles, Conv3 geo, int log_w, int tile, int split) {
   constexpr int LD = BKV + 8;
   constexpr int QPR = BKV / 4;                 // 4-element chunks per row
   constexpr int NH = 128 * QPR / 256;          // X chunks per thread
@@ -242,11 +241,10 @@ __global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restr
   static_assert(NHA >= 1 && MI >= 1 && NJ >= 1, "tile too small for 256 threads");
   __shared__ __attribute__((aligned(16))) unsigned short As[3][TM][LD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[128][LD];
-  const int tile = blockIdx.x;
   const int m0 = (tile / k_tiles) * TM, k0 = (tile % k_tiles) * 128;
   const int lsteps = (L + BKV - 1) / BKV;
   const int total_steps = B * lsteps;
-  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_begin = split * steps_per_split;
   const int s_end = min(total_steps, s_begin + steps_per_split);
   if (s_begin >= s_end) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,6 +336,47 @@ __global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restr
         if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
       }
     }
+}
+
+template <int BKV, bool CONV, int TM>
+__global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
+                                                            const unsigned short* __restrict__ X, float* __restrict__ dW,
+                                                            int B, int M, int K, int L, int steps_per_split, int k_tiles,
+                                                            Conv3 geo, int log_w) {
+  dw_tile_body<BKV, CONV, TM>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, blockIdx.x, blockIdx.y);
+}
+
+// MANY weight gradients in ONE launch.  The 32x32- and 64x64-stage layers (and the decoder's 100-token layers) each owe a
+// weight gradient of 1-4 GFLOP whose contraction is only B*L = 8 192 .. 32 768 long: as separate launches (~180 per step)
+// each one fills the chip only by splitting its contraction 32-64 ways, i.e. 2-4 steps of work per workgroup in front of a
+// 32 KiB atomic tile, 18-35 us apiece.  Nothing downstream waits for a weight gradient until the gradients are packed, so
+// the host defers them (ops.DEFER_DW) and hands the whole list over at the end of the backward pass: one grid over all
+// (job, tile, split) triples, the job table in the kernel arguments (baked into a captured hipGraph like any other
+// argument), every workgroup long enough to amortise its atomics.
+constexpr int kMaxJobs = 56;
+struct DwJob {
+  const float* dY;
+  const unsigned short* X;
+  float* dW;
+  int B, M, K, L;
+  int first_block, steps_per_split, k_tiles, tiles;
+};
+struct DwJobTable {
+  int njobs;
+  DwJob job[kMaxJobs];
+};
+
+template <int BKV, int TM>
+__global__ __launch_bounds__(256) void sgemm_dw_grouped_kernel(const DwJobTable tab) {
+  int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= blockIdx.x (wave-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab.job[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const DwJob& j = tab.job[lo];
+  const int local = blockIdx.x - j.first_block;
+  dw_tile_body<BKV, false, TM>(j.dY, j.X, j.dW, j.B, j.M, j.K, j.L, j.steps_per_split, j.k_tiles, Conv3{0, 0, 0}, 0,
+                               local % j.tiles, local / j.tiles);
 }
 
 // fp32 -> bf16 of an exactly representable tensor (spikes handed over by a caller that still holds them in fp32):
@@ -503,4 +542,47 @@ extern "C" int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, flo
   int log_w = 0;
   while ((1 << log_w) < W) ++log_w;
   return dw_launch(dY, X, dW, batch, M, C * 9, H * W, accumulate, true, Conv3{H, W, C}, log_w, stream);
+}
+
+extern "C" int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* stream) {
+  // jobs (HOST array): njobs x {dY, X, dW (pointers), batch, M, K, L}; every dW is accumulated into (accumulate semantics)
+  S2F_REQUIRE(jobs && njobs > 0 && njobs <= kMaxJobs && (bkv == 32 || bkv == 64), S2F_EINVAL,
+              "s2f_spike_gemm_dw_grouped: 1 .. %d jobs, bkv 32 or 64", kMaxJobs);
+  DwJobTable tab;
+  tab.njobs = njobs;
+  int64_t work = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const int64_t* r = jobs + 7 * i;
+    DwJob& j = tab.job[i];
+    j.dY = reinterpret_cast<const float*>(r[0]);
+    j.X = reinterpret_cast<const unsigned short*>(r[1]);
+    j.dW = reinterpret_cast<float*>(r[2]);
+    j.B = (int)r[3], j.M = (int)r[4], j.K = (int)r[5], j.L = (int)r[6];
+    S2F_REQUIRE(j.dY && j.X && j.dW && j.B > 0 && j.M > 0 && j.K > 0 && j.L > 0 && (j.L & 3) == 0, S2F_EINVAL,
+                "s2f_spike_gemm_dw_grouped: bad job %d", i);
+    S2F_REQUIRE(s2f_aligned16(j.dY) && (reinterpret_cast<uintptr_t>(j.X) & 7u) == 0, S2F_EALIGN,
+                "s2f_spike_gemm_dw_grouped: job %d misaligned", i);
+    j.k_tiles = (j.K + 127) / 128;
+    j.tiles = ((j.M + 63) / 64) * j.k_tiles;
+    work += (int64_t)j.tiles * j.B * ((j.L + bkv - 1) / bkv);
+  }
+  // one contraction length per workgroup for the whole launch: ~1024 workgroups, at least 4 steps each
+  int sps = (int)((work + 1023) / 1024);
+  if (sps < 4) sps = 4;
+  int64_t first = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DwJob& j = tab.job[i];
+    const int steps = j.B * ((j.L + bkv - 1) / bkv);
+    j.steps_per_split = sps < steps ? sps : steps;
+    const int splits = (steps + j.steps_per_split - 1) / j.steps_per_split;
+    j.first_block = (int)first;
+    first += (int64_t)j.tiles * splits;
+  }
+  S2F_REQUIRE(first < (1ll << 31), S2F_EINVAL, "s2f_spike_gemm_dw_grouped: grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (bkv == 64)
+    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<64, 64>), dim3((unsigned)first), dim3(256), 0, s, tab);
+  else
+    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<32, 64>), dim3((unsigned)first), dim3(256), 0, s, tab);
+  return s2f_check_launch("s2f_spike_gemm_dw_grouped");
 }

@@ -92,6 +92,8 @@ class FlatGradAllReduce:
 
     def gather(self):
         """After backward: pack p.grad into the flat buffer (parameters without a gradient keep zeros)."""
+        from . import ops
+        ops.wgrad_flush()                      # deferred weight gradients (ops.DEFER_DW) go into their sinks now
         # No gradient tensor: with sinks the parameter's slice already holds the sum (or the zeros of `zero()`) and is left
         # alone -- the packing runs over the maximal runs of parameters that do have a tensor; without sinks it is a zero.
         if not self.sinks:

@@ -126,9 +126,42 @@ def _wgrad_stream(sink, *inputs):
 
 
 def wgrad_join():
+    """Every weight gradient of the backward pass is in its sink after this: joins the side stream (WGRAD_STREAM) and
+    launches the deferred ones (DEFER_DW)."""
+    wgrad_flush()
     if WGRAD_STREAM is not None:
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
         _WGRAD_KEEP.clear()
+
+
+# Deferred weight gradients.  Nothing downstream of a weight gradient runs until the gradients are packed, and the short-
+# contraction layers (32x32 / 64x64 stages, the decoder's 100-token layers) each owe one of only 1-4 GFLOP: launched one by
+# one (~180 per step) they cost 18-35 us apiece because each must split its B*L = 8 192 .. 32 768 contraction 32-64 ways to
+# fill the chip.  With gradient sinks installed they are collected instead -- (dY, X, sink) kept alive -- and launched
+# together by wgrad_flush() as ONE grouped kernel per contraction-step class (s2f_spike_gemm_dw_grouped).
+DEFER_DW = True
+DEFER_DW_MAX_CONTRACTION = 32768
+_DW_PENDING = {64: [], 32: []}
+
+
+def _defer_dw(gy, x, sink, B, M, K, L):
+    _DW_PENDING[64 if (L % 64 == 0 or L >= 512) else 32].append((gy, x, sink, B, M, K, L))
+
+
+def wgrad_flush():
+    import ctypes
+    for bkv, jobs in _DW_PENDING.items():
+        while jobs:
+            chunk, rest = jobs[:56], jobs[56:]
+            flat = []
+            for gy, x, sink, B, M, K, L in chunk:
+                flat += [gy.data_ptr(), x.data_ptr(), sink.data_ptr(), B, M, K, L]
+            arr = (ctypes.c_int64 * len(flat))(*flat)
+            _time_next("spike_gemm_dw", sum(4 * B * L * (K + M) for _, _, _, B, M, K, L in chunk),
+                       sum(2 * B * M * L * K for _, _, _, B, M, K, L in chunk),
+                       moved=sum(B * L * (2 * K + 4 * M) for _, _, _, B, M, K, L in chunk))
+            check(lib.s2f_spike_gemm_dw_grouped(arr, len(chunk), bkv, _stream()), "s2f_spike_gemm_dw_grouped")
+            jobs[:] = rest
 
 
 # ---- concurrency inside one step -------------------------------------------------------------------------------------
@@ -1200,6 +1233,10 @@ class _SpikeGemm(torch.autograd.Function):
                 sink = _sink_for(w2d)
                 gw = torch.empty(M, K, dtype=torch.float32, device=x.device) if sink is None else None
                 xb = x.dtype == torch.bfloat16
+                if (DEFER_DW and sink is not None and xb and B * L <= DEFER_DW_MAX_CONTRACTION and WGRAD_STREAM is None
+                        and x.data_ptr() % 8 == 0):
+                    _defer_dw(gy, x, sink, B, M, K, L)
+                    return _grad_pair(ctx.has_tok, gx) + (None, gy.sum((0, 2)) if (ctx.has_bias and ctx.needs_input_grad[3]) else None)
                 _time_next("spike_gemm_dw", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, x)
                 st = side.cuda_stream if side is not None else _stream()
@@ -1492,6 +1529,10 @@ class _ConvDense(torch.autograd.Function):
             elif use_mfma and SPIKE_GEMM_DW and M >= 16:
                 sink = _sink_for(weight)
                 gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
+                if (DEFER_DW and sink is not None and xb and N * Ho * Wo <= DEFER_DW_MAX_CONTRACTION and WGRAD_STREAM is None):
+                    _defer_dw(gy, cols, sink, N, M, K, Ho * Wo)
+                    return _grad_pair(ctx.has_tok, gx) + (None, gy.sum((0, 2)) if (has_bias and ctx.needs_input_grad[3]) else None,
+                                                          None, None, None)
                 _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K,
                            moved=N * Ho * Wo * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, cols)

@@ -735,3 +735,32 @@ def test_dwconv_on_bf16_spikes_is_the_fp32_stencil(ops, N, C, H, W, K):
     # the weight gradient is summed over workgroups with atomics: equal to round-off
     assert (wa.grad - wb.grad).abs().max().item() <= 1e-5 * wa.grad.abs().max().item()
     assert torch.equal(xa.grad / 8, xs.grad)                              # d(k/8)/dk = 1/8 inside [0, 8]
+
+
+def test_grouped_weight_gradients_are_the_single_launches(ops):
+    """s2f_spike_gemm_dw_grouped (many short-contraction weight gradients in one launch, job table in the kernel arguments)
+    accumulates into each destination exactly what one s2f_spike_gemm_dw_bf16 launch per job does (to the fp32 round-off of
+    the split-K atomics), ragged shapes and both contraction-step classes included."""
+    import ctypes
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(21)
+    s = torch.cuda.current_stream().cuda_stream
+    for bkv, shapes in ((64, [(8, 256, 256, 1024), (8, 768, 256, 1024), (2, 360, 360, 256), (8, 72, 40, 64), (1, 1024, 256, 4096)]),
+                        (32, [(8, 2048, 256, 100), (8, 256, 2048, 100), (3, 151, 100, 36)])):
+        jobs, keep = [], []
+        for B, M, K, L in shapes:
+            gy = torch.randn(B, M, L, generator=g).cuda()
+            x = (torch.randint(0, 9, (B, K, L), generator=g).float() / 8).cuda().to(torch.bfloat16)
+            base = torch.randn(M, K, generator=g).cuda()                     # accumulate semantics: dW += ...
+            got, want = base.clone(), base.clone()
+            check(lib.s2f_spike_gemm_dw_bf16(gy.data_ptr(), x.data_ptr(), want.data_ptr(), B, M, K, L, 1, s), "single")
+            jobs += [gy.data_ptr(), x.data_ptr(), got.data_ptr(), B, M, K, L]
+            keep.append((gy, x, got, want, base))
+        arr = (ctypes.c_int64 * len(jobs))(*jobs)
+        check(lib.s2f_spike_gemm_dw_grouped(arr, len(shapes), bkv, s), "grouped")
+        torch.cuda.synchronize()
+        for gy, x, got, want, base in keep:
+            ref = base.double() + torch.einsum("bml,bkl->mk", gy.double(), x.double())
+            scale = ref.abs().max().item()
+            assert (got.double() - ref).abs().max().item() <= 2e-6 * scale * 4
+            assert (got - want).abs().max().item() <= 1e-5 * scale

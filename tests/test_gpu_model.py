@@ -299,3 +299,45 @@ def test_cal_firing_num_tool(tmp_path):
     assert all(0.0 <= v <= 8.0 for v in res["t0"].values())
     res2 = cal_firing_num.main(["--workload", "C1_64", "--test-num", "3", "--out-dir", str(tmp_path), "--reset-between-images"])
     assert max(abs(res["t0"][k] - res2["t0"][k]) for k in res["t0"]) > 1e-3
+
+
+def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
+    """The benchmark's gradient path -- weight-gradient kernels adding straight into the flat all-reduce buffer (sinks), the
+    short-contraction ones deferred and launched as one grouped kernel (ops.DEFER_DW) -- against plain autograd gradients of
+    the same step: every parameter's slice of the flat buffer equals p.grad to the round-off of the split-K atomics."""
+    s2f, so, cfg, model = env
+    from spike2former_amd import ops
+    from spike2former_amd.dist import FlatGradAllReduce
+    model.train()
+    s2f.set_keep_membrane(model, False)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    img = so.synthetic_image(cfg, seed=4).cuda()
+
+    def step():
+        model.load_state_dict(state)
+        s2f.reset_net(model)
+        cls, masks = model(img)
+        s2f.headline_loss(cls, masks).backward()
+    try:
+        model.zero_grad(set_to_none=True)
+        step()
+        want = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+        red = FlatGradAllReduce(model.parameters(), 1)
+        red.install_sinks()
+        red.zero()
+        step()
+        assert sum(len(v) for v in ops._DW_PENDING.values()) > 20          # the tiny model's layers are all short-contraction
+        red.gather()                                                      # flushes the deferred launches
+        assert sum(len(v) for v in ops._DW_PENDING.values()) == 0
+        names = {id(p): n for n, p in model.named_parameters()}
+        gscale = max(v.abs().max().item() for v in want.values())
+        for p, v in zip(red.params, red.views):
+            n = names[id(p)]
+            err = (v - want[n]).abs().max().item()
+            assert err <= 1e-4 * want[n].abs().max().item() + 1e-6 * gscale, (n, err)
+    finally:
+        ops.GRAD_SINKS = None
+        for v in ops._DW_PENDING.values():
+            v.clear()
+        s2f.set_keep_membrane(model, True)
+        model.zero_grad(set_to_none=True)
