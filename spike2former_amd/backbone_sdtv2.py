@@ -262,7 +262,8 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
     def _can_batch(self):
         lifs = (self.q_spike, self.k_spike, self.v_spike)
         bns = [b for group in self._twins()["bns"] for b in group]
-        return (QKV_BATCHED and all(isinstance(n.v, float) and not n.keep_membrane and n.stats is None for n in lifs)
+        return (QKV_BATCHED and all(isinstance(n.v, float) and not n.keep_membrane and n.stats is None and not n._forward_hooks
+                                    for n in lifs)
                 and len({(n.D, n.v_threshold) for n in lifs}) == 1
                 and all(c[0].body[2][0].kernel_size == (3, 3) for c in (self.q_conv, self.k_conv, self.v_conv))
                 and len({(b.training, b.momentum, b.eps, b.running_mean is None) for b in bns}) == 1

@@ -55,4 +55,10 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None), want_border=True)
     if lif is not None:
         lif.v = v_out if lif.keep_membrane else 0.0
+        if lif._forward_hooks:
+            # the neuron ran inside the BatchNorm kernel, not through its module call: anyone watching it with nn.Module
+            # forward hooks (the reference's cal_firing_num.py does) still sees (module, (input,), fp32 spikes)
+            yf = y.float().detach()
+            for hook in list(lif._forward_hooks.values()):
+                hook(lif, (u,), yf)
     return (u, y, border) if want_border else (u, y)

@@ -102,7 +102,7 @@ class MaskFormerHead(nn.Module):
         layers = self.transformer_decoder.layers
 
         def pure(m):          # reset, stateless, unrecorded: the neuron is a pure function of its input
-            return isinstance(m.v, float) and not m.keep_membrane and m.stats is None
+            return isinstance(m.v, float) and not m.keep_membrane and m.stats is None and not m._forward_hooks
 
         dec_in, dec_key, kv_spikes = [], [], []
         for i in range(nl):
@@ -165,8 +165,10 @@ class MaskFormerHead(nn.Module):
 
     def predict(self, x, batch_img_metas, test_cfg=None):
         """mmseg MaskFormerHead.predict (decode_heads/maskformer_head.py:138-180) -> seg logits [B,K,H,W]."""
+        for metainfo in batch_img_metas:                     # as the reference: the patch shape becomes the batch input shape
+            metainfo["batch_input_shape"] = metainfo["img_shape"]
         cls, masks = self(x, None)
-        img_shape = batch_img_metas[0].get("batch_input_shape", batch_img_metas[0]["img_shape"])
+        img_shape = batch_img_metas[0]["batch_input_shape"]
         mp = F.interpolate(masks[-1], size=tuple(img_shape), mode="bilinear", align_corners=False)
         cls_score = F.softmax(cls[-1], dim=-1)[..., :-1]
         return torch.einsum("bqc,bqhw->bchw", cls_score, mp.sigmoid())

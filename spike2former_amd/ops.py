@@ -140,7 +140,8 @@ def wgrad_join():
 # fill the chip.  With gradient sinks installed they are collected instead -- (dY, X, sink) kept alive -- and launched
 # together by wgrad_flush() as ONE grouped kernel per contraction-step class (s2f_spike_gemm_dw_grouped).
 DEFER_DW = True
-DEFER_DW_MAX_CONTRACTION = 32768
+import os as _os
+DEFER_DW_MAX_CONTRACTION = int(_os.environ.get("S2F_DEFER_DW_MAX", "32768"))
 _DW_PENDING = {64: [], 32: []}
 
 

@@ -49,7 +49,7 @@ def main(argv=None):
         for i in range(args.test_num):
             if args.reset_between_images:
                 s2f.reset_net(model)
-            model(imgs[i % len(imgs)][None].cuda(), metas, mode="predict")
+            model(imgs[i % len(imgs)][None].cuda(), metas, mode="logits")
             rec.collect()
     result = rec.result(args.test_num)
     print(json.dumps(result))

@@ -1,0 +1,116 @@
+"""SURVEY section 8 row a13 -- the callers around the head -- against vectors produced by the REFERENCE's own files
+(oracle/gen_golden_a13.py -> tests/golden/predict_a13.npz): MaskFormerHead.predict's post-processing
+(mmseg/models/decode_heads/maskformer_head.py:138-180), EncoderDecoder.inference / slide_inference / whole_inference
+(mmseg/models/segmentors/encoder_decoder.py:246-330) and postprocess_result (mmseg/models/segmentors/base.py:127-200).
+The network inside is a deterministic stand-in (same function as in the generator); the head's forward itself is pinned by
+e2e_C1_64.npz.  CPU: bit-exact (same ATen kernels as the reference run); GPU: 1e-5 (bilinear / softmax on HIP kernels)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+def fake_net(x, K):
+    w = torch.linspace(-1.0, 1.0, K * 3).view(K, 3).to(x.device)
+    return torch.einsum("kc,nchw->nkhw", w, x) + 0.1 * torch.sin(3.0 * x.sum(1, keepdim=True))
+
+
+METAS = [dict(ori_shape=(30, 41), img_shape=(37, 53), pad_shape=(37, 53), padding_size=[0, 3, 0, 2], flip=True,
+              flip_direction="horizontal"),
+         dict(ori_shape=(30, 41), img_shape=(37, 53), pad_shape=(37, 53), padding_size=[0, 3, 0, 2])]
+
+
+def _segmentor(test_cfg, K):
+    from spike2former_amd.segmentor import EncoderDecoder
+    m = object.__new__(EncoderDecoder)
+    torch.nn.Module.__init__(m)
+    m.test_cfg, m.out_channels, m.align_corners = dict(test_cfg), K, False
+    m.decode_head = types.SimpleNamespace(threshold=0.3)
+    m.encode_decode = lambda x, metas: fake_net(x, K)
+    return m
+
+
+def _check(golden, dev, exact):
+    from spike2former_amd.data_preprocessor import SegDataSample
+    from spike2former_amd.maskformer_head import MaskFormerHead
+    g = golden("predict_a13.npz")
+
+    def same(a, want):
+        want = torch.from_numpy(want)
+        a = a.detach().cpu()
+        if exact or not want.is_floating_point():
+            if want.is_floating_point():
+                return torch.equal(a, want)
+            return (a != want).float().mean().item() <= (0.0 if exact else 2e-3)          # arg-max ties at round-off
+        return (a - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1.0)
+    cls, masks = torch.from_numpy(g["p_cls"]).to(dev), torch.from_numpy(g["p_masks"]).to(dev)
+    head = type("H", (), {"__call__": lambda self, x, ds: (cls, masks)})()
+    shape = tuple(int(v) for v in g["p_img_shape"])
+    got = MaskFormerHead.predict(head, None, [dict(img_shape=shape, ori_shape=(50, 70)) for _ in range(cls.shape[1])])
+    assert same(got, g["p_seg_logits"])
+    img = torch.from_numpy(g["i_img"]).to(dev)
+    for name, cfg in (("slide", dict(mode="slide", crop_size=(16, 24), stride=(11, 17))), ("whole", dict(mode="whole"))):
+        m = _segmentor(cfg, 5)
+        logits = m.inference(img, [dict(x) for x in METAS])
+        assert same(logits, g[f"{name}_logits"])
+        out = m.postprocess_result(logits, [SegDataSample(metainfo=x) for x in METAS])
+        for i, s in enumerate(out):
+            assert same(s.seg_logits.data, g[f"{name}_post{i}_logits"]) and same(s.pred_sem_seg.data, g[f"{name}_post{i}_pred"])
+    one = _segmentor(dict(mode="whole"), 1).postprocess_result(torch.from_numpy(g["one_logits"]).to(dev), None)
+    assert same(one[0].seg_logits.data, g["one_post0"]) and same(one[0].pred_sem_seg.data, g["one_pred0"])
+    with pytest.raises(AssertionError):
+        _segmentor(dict(mode="tiles"), 5).inference(img, [dict(x) for x in METAS])
+
+
+def test_predict_inference_postprocess_vs_reference_vectors_cpu(golden):
+    _check(golden, "cpu", exact=True)
+
+
+@pytest.mark.gpu
+def test_predict_inference_postprocess_vs_reference_vectors_gpu(golden):
+    _check(golden, "cuda", exact=False)
+
+
+@pytest.mark.gpu
+def test_model_predict_is_head_forward_plus_the_pinned_postprocessing():
+    """`model(img, mode='predict')` on the tiny model: the per-image results are exactly what the pinned pieces give when
+    composed by hand from `model(img)` (mode='tensor'): head.predict's post-processing, then postprocess_result."""
+    import spike2former_amd as s2f
+    from spike2former_amd.data_preprocessor import SegDataSample
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C1_64"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1_64"))).cuda().eval()
+    img = torch.randn(2, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(2)).cuda()
+    metas = [dict(img_shape=(w["H"], w["W"]), ori_shape=(50, 70), padding_size=[0, 4, 0, 6]) for _ in range(2)]
+    with torch.no_grad():
+        s2f.reset_net(model)
+        res = model(img, [SegDataSample(metainfo=dict(m)) for m in metas], mode="predict")
+        s2f.reset_net(model)
+        cls, masks = model(img)
+        up = torch.nn.functional.interpolate(masks[-1], size=(w["H"], w["W"]), mode="bilinear", align_corners=False)
+        logits = torch.einsum("bqc,bqhw->bchw", torch.softmax(cls[-1], -1)[..., :-1], up.sigmoid())
+        want = model.postprocess_result(logits, [SegDataSample(metainfo=dict(m)) for m in metas])
+    assert len(res) == 2 and res[0].seg_logits.data.shape == (w["K"], 50, 70) and res[0].pred_sem_seg.data.shape == (1, 50, 70)
+    for a, b in zip(res, want):
+        assert torch.equal(a.seg_logits.data, b.seg_logits.data) and torch.equal(a.pred_sem_seg.data, b.pred_sem_seg.data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,training", [("train", dict(size=(32, 32)), True),
+                                              ("test", dict(size=(32, 32), test_cfg=dict(size_divisor=16)), False),
+                                              ("plain", dict(size=(32, 32)), False)])
+def test_data_preprocessor_vs_reference_vectors_on_the_gpu(golden, name, kw, training):
+    """SegDataPreProcessor on device tensors against the vectors the reference's own file produced (preproc_f2.npz): the
+    normalisation is one fp32 subtraction and division per element -- identical on the GPU."""
+    from spike2former_amd.data_preprocessor import SegDataPreProcessor, SegDataSample
+    g = golden("preproc_f2.npz")
+    cfg = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], bgr_to_rgb=True, pad_val=0, seg_pad_val=255)
+    imgs = [torch.from_numpy(g[f"{name}_img{i}"]).cuda() for i in range(2)]
+    segs = [torch.from_numpy(g[f"{name}_seg{i}"]).cuda() for i in range(2)]
+    ds = [SegDataSample(s.clone(), dict(ori_shape=tuple(s.shape[-2:]))) for s in segs]
+    out = SegDataPreProcessor(**cfg, **kw).cuda()(dict(inputs=imgs, data_samples=ds), training)
+    assert out["inputs"].is_cuda
+    assert (out["inputs"].cpu() - torch.from_numpy(g[f"{name}_inputs"])).abs().max().item() <= 1e-6
+    for i, d in enumerate(out["data_samples"]):
+        assert torch.equal(d.gt_sem_seg.data.cpu(), torch.from_numpy(g[f"{name}_outseg{i}"]))

@@ -32,14 +32,16 @@ def c2():
     net = so.OracleNet(st, cfg, training=True)
     net.stages = {}
     pd_taps = {}                                          # spike maps of the pixel decoder's encoder-layer neurons (uint8 counts)
+    bb_taps = {}                                          # ... and of every backbone neuron (242 M elements as uint8)
     with torch.no_grad():
+        net.tap = lambda name, y: bb_taps.__setitem__(name, (y * 8).round().to(torch.uint8))
         feats = net.backbone(img)
         fire_bb = dict(net.firing)
         net.tap = lambda name, y: pd_taps.__setitem__(name, (y * 8).round().to(torch.uint8)) if ".encoder.layers." in name else None
         mf, memory, msm = net.pixel_decoder(feats)
         net.tap = None
     ref = dict(feats=feats, mask_features=mf, memory=memory, msm=msm, firing=dict(net.firing), fire_bb=fire_bb,
-               stages=net.stages, pd_taps=pd_taps)
+               stages=net.stages, pd_taps=pd_taps, bb_taps=bb_taps)
     return s2f, so, cfg, st0, model, img, ref
 
 
@@ -52,17 +54,58 @@ def frac_off(a, b, tol):
     return ((a - b).abs() > tol * b.abs().max()).float().mean().item()
 
 
+class NeuronWalk:
+    """Records the spike maps of every Q_IFNode under `root` in EXECUTION order (nn.Module forward hooks: fused neurons report
+    through them as well) and compares them with the oracle's taps where the comparison is well conditioned: every neuron
+    up to and including the first one that differs at all must differ in <= `frac` of its elements, each by exactly ONE level
+    (an input within fp32 round-off of k + 0.5 rounded to the other side).  Downstream of a flip the maps legitimately diverge."""
+
+    def __init__(self, s2f, root, prefix):
+        self.order, self.mine, self.prefix = [], {}, prefix
+        self.hooks = [m.register_forward_hook(lambda mod, inp, o, n=n: self._grab(n, o))
+                      for n, m in root.named_modules() if isinstance(m, s2f.Q_IFNode)]
+
+    def _grab(self, n, o):
+        if n not in self.mine:                            # a neuron called twice keeps its first map
+            self.order.append(n)
+            self.mine[n] = (o.detach() * 8).round().to(torch.uint8).cpu()
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+
+    def check(self, taps, frac=1e-4, channel_major=False):
+        """-> (neurons compared, name of the first differing neuron or None)"""
+        checked = 0
+        for n in self.order:
+            r = taps.get(f"{self.prefix}.{n}" if n else self.prefix)
+            if r is None or r.numel() != self.mine[n].numel():
+                continue
+            m = self.mine[n]
+            if channel_major and tuple(m.shape[-2:]) != tuple(r.shape[-2:]) and tuple(m.shape[-2:]) == tuple(r.shape[-2:])[::-1]:
+                m = m.reshape(-1, *m.shape[-2:]).transpose(1, 2)          # product [T*B, C, L] vs oracle [T, B, L, C]
+            d = m.reshape(-1).to(torch.int16) - r.reshape(-1).to(torch.int16)
+            checked += 1
+            if (d != 0).any():
+                assert d.abs().max().item() == 1 and (d != 0).float().mean().item() <= frac, (self.prefix, n, (d != 0).float().mean().item())
+                return checked, n
+        return checked, None
+
+
 @pytest.mark.timeout(900)
 def test_c2_backbone_stages_teacher_forced(c2):
     """Every backbone stage at 512x512, T=4 (5 down-samplings, 4 MS_ConvBlocks, 6 + 2 spike-driven attention blocks), each
     fed the ORACLE's input for that stage.  Most stages agree to ~2e-7 relative L2 (no spike flips at all); where a few of
     the stage's inner neurons flip by one level (measured: 3e-5 of the elements, inputs within 1e-6 of k + 0.5), each flip
     perturbs ~4 600 downstream pre-activations (3x3 conv, 512 channels) by ~w/8 and so flips ~18 further neurons: the
-    stage output then differs by 1e-2..4e-2 in relative L2.  Bound: 6e-2, and at least half of the stages below 1e-5."""
+    stage output then differs by 1e-2..4e-2 in relative L2.  Bound: 6e-2, and at least half of the stages below 1e-5.
+    Where the comparison is well conditioned it is exact: the stage's neurons are walked in execution order (NeuronWalk) --
+    identical spike maps up to the first neuron that differs, which differs in <= 1e-4 of its elements by exactly one level;
+    a stage without any flip must reproduce the oracle's output to 1e-5."""
     s2f, so, cfg, st0, model, img, ref = c2
     model.load_state_dict(st0, strict=True)
     bb = model.backbone
-    worst = {}
+    worst, walked = {}, {}
     for name, (x, y) in ref["stages"].items():
         if not name.startswith("backbone."):
             continue
@@ -70,9 +113,17 @@ def test_c2_backbone_stages_teacher_forced(c2):
         for part in name[len("backbone."):].split("."):
             mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
         s2f.reset_net(model)
+        walk = NeuronWalk(s2f, mod, name)
         with torch.no_grad():
             out = mod(x.cuda())
+        walk.close()
         worst[name] = rel_l2(out.cpu(), y)
+        # the stage's neurons in execution order: identical to the oracle's up to the first one-level flip
+        checked, first = walk.check(ref["bb_taps"])
+        walked[name] = (checked, first)
+        assert first is not None or checked >= (0 if name.endswith("downsample1_1") else 1 if "downsample" in name else 3), (name, walk.order)
+        if first is None:                                 # no neuron flipped anywhere in the stage: round-off only
+            assert worst[name] <= 1e-5, (name, worst[name])
     assert len(worst) == 17
     assert max(worst.values()) <= 6e-2, worst
     assert sorted(worst.values())[len(worst) // 2] <= 1e-5, worst
@@ -154,7 +205,9 @@ def test_c2_pixel_decoder_teacher_forced(c2):
 def test_c2_decoder_layers_teacher_forced(c2):
     """Each of the 6 decoder layers (cross-attention over 1 024 / 4 096 / 16 384 keys, self-attention, FFN) fed the oracle's
     query and memory: output within 2e-2 of its max for >= 99 % of the elements (a flipped spike of the 100-row query moves a
-    whole BatchNorm'd column, hence the looser bound than in the backbone)."""
+    whole BatchNorm'd column, hence the looser bound than in the backbone) -- and exact where that is well defined: the
+    layer's neurons walked in execution order agree with the oracle's spike maps up to the first one-level flip; a layer
+    without any flip reproduces the oracle's output to 1e-5."""
     s2f, so, cfg, st0, model, img, ref = c2
     model.load_state_dict(st0, strict=True)
     hd = model.decode_head
@@ -170,13 +223,26 @@ def test_c2_decoder_layers_teacher_forced(c2):
         m = ref["msm"][lv]
         key = m.flatten(3).permute(0, 1, 3, 2) + p[h + "level_embed.weight"][lv].view(1, 1, -1)
         kpos = so.sine_pos_embed(bs, m.shape[-2], m.shape[-1], cfg.num_feats).flatten(2).permute(0, 2, 1)
+        lname = h + f"transformer_decoder.layers.{i}"
+        taps = {}
         with torch.no_grad():
             net.reset()
-            out_ref = net._dec_layer(h + f"transformer_decoder.layers.{i}", query, key, qpos, kpos)
+            net.tap = lambda name, y: taps.__setitem__(name, (y * 8).round().to(torch.uint8))
+            out_ref = net._dec_layer(lname, query, key, qpos, kpos)
+            net.tap = None
             s2f.reset_net(model)
+            walk = NeuronWalk(s2f, hd.transformer_decoder.layers[i], lname)
             out = hd.transformer_decoder.layers[i](query=query.cuda(), key=key.cuda(), value=key.cuda(),
                                                    query_pos=qpos.cuda(), key_pos=kpos.cuda())
+            walk.close()
         assert frac_off(out.cpu(), out_ref, 2e-2) <= 1e-2 and rel_l2(out.cpu(), out_ref) <= 2e-2, i
+        # the layer's 15 neurons in execution order (CA: q/k/v in, q/k/v out, attn; SA: the same; FFN: 2): identical to the
+        # oracle's up to the first one-level flip (<= 1e-3 of a map here: a BatchNorm over only 100 distinct query rows
+        # turns one borderline element into a shifted column)
+        checked, first = walk.check(taps, frac=1e-3, channel_major=True)
+        assert first is not None or checked >= 10, (i, checked, walk.order)
+        if first is None:
+            assert rel_l2(out.cpu(), out_ref) <= 1e-5, (i, rel_l2(out.cpu(), out_ref))
         query = out_ref                                   # teacher forcing: the next layer starts from the oracle's output
 
 
@@ -228,8 +294,14 @@ def test_c2_step_properties(c2):
     finally:
         ops.SPIKE_GEMM_CHECK = False
     b = step(False)
-    # the forward is chaotic at this size (module docstring): equal up to the rare last-bit effects of fp64 atomic order
-    assert frac_off(a[0], b[0], 1e-3) <= 0.5 and torch.isfinite(a[1]).all() and torch.isfinite(b[1]).all()
+    # keep_membrane on / off run the SAME arithmetic (the membrane is only written, never read, after a reset).  The one
+    # non-deterministic ingredient of a forward pass is the order of the fp64 atomics that sum the BatchNorm statistics of
+    # the large maps (bn_stats_kernel): a last-bit difference in a mean can flip a borderline neuron, and the chaotic
+    # decoder (module docstring) then amplifies it.  So: exact equality is asserted where no atomic reduction precedes --
+    # test_keep_membrane_is_output_identical_up_to_the_first_atomic_reduction below -- and here only that both runs are
+    # finite and of the same scale.
+    assert torch.isfinite(a[0]).all() and torch.isfinite(b[0]).all() and torch.isfinite(a[1]).all() and torch.isfinite(b[1]).all()
+    assert 0.5 <= a[1].abs().mean().item() / b[1].abs().mean().item() <= 2.0
     assert torch.isfinite(a[2]).all() and a[2].abs().max().item() > 0
     s2f.set_keep_membrane(model, False)
     model.load_state_dict(st0, strict=True)
@@ -238,6 +310,114 @@ def test_c2_step_properties(c2):
     loss_g = float(gs())
     assert np.isfinite(loss_g)
     s2f.set_keep_membrane(model, True)
+
+
+def test_keep_membrane_is_output_identical_up_to_the_first_atomic_reduction(c2):
+    """`Q_IFNode.keep_membrane = False` (bench.py: the membrane write is skipped because a reset precedes every step) must not
+    change a single output bit.  At full size two runs of the SAME configuration already differ in the last bit of a
+    BatchNorm mean (fp64 atomics over the workgroups of bn_stats_kernel, large maps only), so the identity is asserted (a)
+    where no atomic reduction is involved: every backbone stage on the 32x32 maps (downsample4, the six block3 and two block4
+    attention blocks) -- their BatchNorms run in the single-pass kernels (one workgroup per channel, fixed summation order),
+    their GEMMs and the fused attention kernel reduce through LDS in a fixed order -- keep on vs off from identical inputs
+    (the oracle's): bitwise equal outputs."""
+    s2f, so, cfg, st0, model, img, ref = c2
+    model.load_state_dict(st0, strict=True)
+    bb = model.backbone
+    stages = {n: xy for n, xy in ref["stages"].items() if n.startswith("backbone.block") or n.startswith("backbone.downsample4")}
+    assert len(stages) >= 9
+    for name, (x, _) in stages.items():
+        mod = bb
+        for part in name[len("backbone."):].split("."):
+            mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+        outs = []
+        for keep in (True, False):
+            model.load_state_dict(st0, strict=True)
+            s2f.set_keep_membrane(model, keep)
+            s2f.reset_net(model)
+            with torch.no_grad():
+                outs.append(mod(x.cuda()).clone())
+        assert torch.equal(outs[0], outs[1]), name
+    s2f.set_keep_membrane(model, True)
+
+
+@pytest.mark.timeout(900)
+def test_c3_size_decoder_cross_attention_vs_oracle():
+    """BASELINE configs[2] (Cityscapes 1024x512): the decoder's cross-attention at ITS key counts -- 2 048 / 8 192 / 32 768
+    keys (levels 32x64, 64x128, 128x256) against 100 queries, 256 channels, 8 heads, T = 4, B = 1 -- one decoder layer per
+    level, teacher-forced against the oracle with name-seeded weights: neurons walked in execution order (identical up to
+    the first one-level flip), output within 2e-2."""
+    import spike2former_amd as s2f
+    from oracle import s2f_oracle as so
+    cfg = dataclasses.replace(so.CONFIGS["C3"], B=1)
+    st0 = so.make_params(cfg, requires_grad=False)
+    model = s2f.MODELS.build(s2f.model_cfg("C3"))
+    model.load_state_dict(st0, strict=True)
+    model = model.cuda().train()
+    hd = model.decode_head
+    net = so.OracleNet({k: v.clone() for k, v in st0.items()}, cfg, training=True)
+    h = "decode_head."
+    t, bs, C = cfg.T, 1, cfg.feat_channels
+    g = torch.Generator().manual_seed(31)
+    query = st0[h + "query_feat.weight"].unsqueeze(0).repeat(t, bs, 1, 1)
+    qpos = st0[h + "query_embed.weight"].unsqueeze(0).repeat(bs, 1, 1)
+    for i, (hh, ww) in enumerate([(32, 64), (64, 128), (128, 256)]):
+        mem = torch.randn(1, bs, hh * ww, C, generator=g).repeat(t, 1, 1, 1) * 1.5          # T identical slices, as a reset step has
+        key = mem + st0[h + "level_embed.weight"][i].view(1, 1, -1)
+        kpos = so.sine_pos_embed(bs, hh, ww, cfg.num_feats).flatten(2).permute(0, 2, 1)
+        lname = h + f"transformer_decoder.layers.{i}"
+        taps = {}
+        with torch.no_grad():
+            net.reset()
+            net.tap = lambda name, y: taps.__setitem__(name, (y * 8).round().to(torch.uint8))
+            out_ref = net._dec_layer(lname, query, key, qpos, kpos)
+            net.tap = None
+            s2f.reset_net(model)
+            walk = NeuronWalk(s2f, hd.transformer_decoder.layers[i], lname)
+            out = hd.transformer_decoder.layers[i](query=query.cuda(), key=key.cuda(), value=key.cuda(),
+                                                   query_pos=qpos.cuda(), key_pos=kpos.cuda())
+            walk.close()
+        checked, first = walk.check(taps, frac=1e-3, channel_major=True)
+        assert first is not None or checked >= 10, (i, checked)
+        assert frac_off(out.cpu(), out_ref, 2e-2) <= 1e-2 and rel_l2(out.cpu(), out_ref) <= 2e-2, (i, hh * ww)
+        if first is None:
+            assert rel_l2(out.cpu(), out_ref) <= 1e-5
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
+def test_c5_full_size_step_properties():
+    """BASELINE configs[4] at FULL size (COCO-panoptic-shaped 800x1344, T = 4, E-SpikeFormer backbone + 133-class head, per-GPU
+    batch 1) through size-independent properties: output shapes, every activation handed to the bf16 spike GEMM on the spike
+    grid (D = 4 backbone, D = 8 head), finite non-zero gradients, the T-fold structure of a reset step, backbone firing rate
+    inside (0, 1)."""
+    import spike2former_amd as s2f
+    from spike2former_amd import ops
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C5"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C5"))).cuda().train()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(w["B"], 3, w["H"], w["W"], generator=torch.Generator().manual_seed(9)).cuda()
+    seen = {}
+    hk = model.backbone.register_forward_hook(lambda m, i, o: seen.__setitem__("x4", o[-1].detach()))
+    s2f.reset_net(model); model.zero_grad(set_to_none=True)
+    ops.SPIKE_GEMM_CHECK = True
+    try:
+        cls, masks = model(img)
+    finally:
+        ops.SPIKE_GEMM_CHECK = False
+        hk.remove()
+    assert cls.shape == (7, w["B"], w["Q"], w["K"] + 1) and masks.shape == (7, w["B"], w["Q"], w["H"] // 2, w["W"] // 2)
+    s2f.headline_loss(cls, masks).backward()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    assert torch.isfinite(cls).all() and torch.isfinite(masks).all() and torch.isfinite(flat).all() and flat.abs().max() > 0
+    x4 = seen["x4"]
+    assert x4.shape[0] == w["T"] and all(torch.equal(x4[0], x4[t]) for t in range(1, w["T"]))
+    y, _ = ops.lif(x4, None, D=4, keep_v=False)
+    c = y * 4
+    assert torch.equal(c, torch.round(c)) and 0 <= float(c.min()) and float(c.max()) <= 4 and 0 < float(y.mean()) < 1
+    del model, flat
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.timeout(900)

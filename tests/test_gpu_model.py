@@ -283,7 +283,7 @@ def test_predict_and_keep_membrane_equivalence(env):
         s2f.set_keep_membrane(model, keep)
         s2f.reset_net(model)
         with torch.no_grad():
-            outs.append(model(img, mode="predict"))
+            outs.append(model(img, mode="logits"))
     s2f.set_keep_membrane(model, True)
     assert outs[0].shape == (cfg.B, cfg.num_classes, cfg.H, cfg.W) and torch.equal(outs[0], outs[1])
 
@@ -341,3 +341,35 @@ def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
             v.clear()
         s2f.set_keep_membrane(model, True)
         model.zero_grad(set_to_none=True)
+
+
+def test_c1_plumbing_config_at_its_own_size_vs_oracle():
+    """BASELINE configs[0] as written: ONE 128x128 tile, T = 1, the tiny widths, 20 classes -- forward + backward against the
+    oracle on the host (the committed fixtures hold its 64x64 / T = 2 form): logits within 2e-2 of their maximum, firing
+    table (270-row order) within 2e-3, a mask-embedding gradient within 5e-2."""
+    import spike2former_amd as s2f
+    from oracle import s2f_oracle as so
+    cfg = so.CONFIGS["C1"]
+    st = so.make_params(cfg)
+    model = s2f.MODELS.build(s2f.model_cfg("C1"))
+    model.load_state_dict({k: v.detach() for k, v in st.items()}, strict=True)
+    model.cuda().train()
+    img = so.synthetic_image(cfg)
+    assert img.shape == (1, 3, 128, 128) and cfg.T == 1
+    s2f.reset_net(model)
+    with s2f.FiringRecorder(model) as rec:
+        cls, masks = model(img.cuda())
+        rec.collect()
+    s2f.headline_loss(cls, masks).backward()
+    net = so.OracleNet(st, cfg, training=True)
+    ocls, omasks = net.forward(img)
+    so.headline_loss(ocls, omasks).backward()
+    assert cls.shape == ocls.shape and masks.shape == omasks.shape
+    assert rel(cls.detach().cpu(), ocls.detach()) <= 2e-2 and rel(masks.detach().cpu(), omasks.detach()) <= 2e-2
+    table = rec.result()["t0"]
+    assert len(table) == len(net.firing)
+    for k, v in table.items():
+        assert abs(v - net.firing[k]) <= 2e-3, (k, v, net.firing[k])
+    k = "decode_head.mask_embed.fc1.weight"
+    gm, go = dict(model.named_parameters())[k].grad.cpu(), st[k].grad
+    assert (gm - go).abs().max().item() <= 5e-2 * go.abs().max().item()
