@@ -46,6 +46,11 @@ def parse():
                     help="1: lateral convs / H/2 FPN level + mask_feature / decoder key-value projections on side streams "
                          "(S2F_LONG_WHAT=lat,mf,kv selects; measured: mf -0.8 ms, kv +0.7 ms, lat 0 -- off by default)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="N > 1: forward / backward as two graphs with the all-reduce of step k overlapped with the forward of "
+                         "step k + 1 (graph.GraphedOverlapStep) instead of ONE graph + a blocking all-reduce behind it.  "
+                         "Measured in the one-rank RCCL rehearsal: 52.1 vs 49.8 ms/step -- the second graph launch and the "
+                         "two stream hand-overs cost ~2.3 ms, more than the 0.2-1.6 ms collective they hide: off by default")
     ap.add_argument("--allow-eager", action="store_true",
                     help="N > 1: fall back to eager launches when the hipGraph capture fails (host-bound, ~2x slower: a curve "
                          "that mixes graph and eager points is meaningless, so the default is to fail)")
@@ -153,8 +158,19 @@ def main():
         # are captured as two graphs around the eager loss (graph.GraphedSplitStep).
         from spike2former_amd.graph import GraphedSplitStep
         graphed_model = GraphedSplitStep(model, img, red, warmup=max(args.warmup, 2))
-    graphed = None
-    if not args.no_graph:
+    graphed = overlapped = None
+    distributed = dist.is_available() and dist.is_initialized()
+    if not args.no_graph and distributed and args.overlap_allreduce:
+        # N > 1: forward and backward as two graphs, the all-reduce of step k under the forward of step k + 1
+        from spike2former_amd.graph import GraphedOverlapStep
+        try:
+            overlapped = GraphedOverlapStep(model, s2f.headline_loss, img, red, warmup=max(args.warmup, 2))
+        except RuntimeError as e:
+            print(f"[bench rank {rank}] forward / backward graph capture failed ({e}); single graph + blocking all-reduce",
+                  file=sys.stderr, flush=True)
+            overlapped = None
+            torch.cuda.synchronize()
+    if not args.no_graph and overlapped is None:
         # reset + grad clear + forward + loss + backward captured once as a hipGraph; the RCCL all-reduce stays eager
         from spike2former_amd.graph import GraphedStep
         try:
@@ -167,6 +183,8 @@ def main():
             torch.cuda.synchronize()
 
     def step():
+        if overlapped is not None:
+            return overlapped()
         if graphed is None:
             return eager_step()
         graphed()
@@ -181,10 +199,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if overlapped is not None:
+        overlapped.finish()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if overlapped is not None:
+        overlapped.finish()               # the last step's all-reduce belongs to the timed region
     fence()
     dt = time.perf_counter() - t0
     # Per-launch durations of the neuron kernels: HIP events cannot be read back from inside a replayed hipGraph, so the
@@ -212,7 +234,8 @@ def main():
                                                         if graphed_model is not None else "eager]")) if seg is not None else ""),
             "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph replay",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": ("forward / backward hipGraphs, all-reduce of step k under the forward of step k+1" if overlapped is not None
+                                             else "eager" if graphed is None else "hipGraph replay"),
             "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']} "
                                    f"{'E-SpikeFormer (SDT-v3)' if 'v2' in str(w.get('backbone', '')) else 'Meta-SpikeFormer'} "
                                    f"{w['embed_dim']} + MaskFormer head, per-GPU batch {B}",

@@ -148,6 +148,36 @@ class FlatGradAllReduce:
         if self.sinks:
             self.install_sinks()
 
+    def reduce_async(self, buckets=1):
+        """The averaging all-reduce issued WITHOUT blocking the caller's stream: it runs on a side stream behind everything
+        enqueued so far, as `buckets` back-to-back collectives over consecutive slices of the flat buffer (137 MB at C2: one
+        bucket ~ 0.2-1.6 ms over xGMI; more buckets let a consumer start on the first slice while the rest is in flight).
+        The caller's stream goes on -- graph.GraphedOverlapStep replays the NEXT step's forward under it -- and `wait()`
+        orders the caller behind the collectives before the buffer is touched again."""
+        if self.world == 1 and not (os.environ.get("S2F_FORCE_DIST") and dist.is_initialized()):
+            return
+        if not self.flat.is_cuda:                 # host tensors (the gloo tests): the same bucketing, blocking
+            n = self.flat.numel()
+            step = (n + buckets - 1) // buckets
+            for lo in range(0, n, step):
+                piece = self.flat[lo:lo + step]
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                piece.div_(self.world)
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.flat.device)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        n = self.flat.numel()
+        step = (n + buckets - 1) // buckets
+        avg = dist.get_backend() == "nccl"
+        with torch.cuda.stream(self.stream):
+            for lo in range(0, n, step):
+                piece = self.flat[lo:lo + step]
+                w = dist.all_reduce(piece, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=not avg)
+                if not avg:
+                    w.wait()
+                    piece.div_(self.world)
+
     def reduce(self, async_op=True):
         if self.world == 1 and not (os.environ.get("S2F_FORCE_DIST") and dist.is_initialized()):
             return

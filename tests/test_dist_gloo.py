@@ -37,6 +37,36 @@ def _worker(rank, world, port, out):
     ok = torch.equal(local, want_local) and torch.allclose(red.flat, want, atol=1e-7) and all(
         torch.equal(v, red.flat[o:o + v.numel()].view_as(v))
         for v, o in zip(red.views, [0] + list(torch.tensor([v.numel() for v in red.views]).cumsum(0)[:-1])))
+    # ---- the benchmark's gradient path: sinks (kernels add straight into the flat buffer), compaction, bucketed all-reduce
+    from spike2former_amd import ops
+    params = list(lin.parameters())
+    red.install_sinks()
+    red.zero()
+    lin(data[start:start + per]).square().mean().backward()
+    sunk = [params[0], params[4]]                        # pretend two weight gradients were produced by sink kernels
+    keep = {id(p): p.grad.clone() for p in sunk}
+    for p in sunk:
+        ops._sink_for(p).add_(p.grad)
+        p.grad = None
+    red.gather()
+    red.compact()                                        # sunk parameters move behind the others
+    assert [id(p) for p in red.params[-2:]] == [id(p) for p in sunk] and red._n_dense == len(params) - 2
+    red.zero()
+    lin(data[start:start + per]).square().mean().backward()
+    for p in sunk:
+        ops._sink_for(p).add_(p.grad)
+        p.grad = None
+    red.gather()
+    local2 = red.flat.clone()
+    for p, v in zip(red.params, red.views):              # every slice holds that parameter's local gradient
+        ok = ok and torch.allclose(v, keep[id(p)] if id(p) in keep else p.grad, atol=1e-7)
+    red.reduce_async(buckets=3)                          # three collectives over consecutive slices
+    red.wait()
+    g2 = [torch.zeros_like(local2) for _ in range(w)]
+    dist.all_gather(g2, local2)
+    ok = ok and torch.allclose(red.flat, torch.stack(g2).mean(0), atol=1e-7)
+    red.close()
+    ok = ok and ops.GRAD_SINKS is None
     p0 = torch.cat([p.detach().flatten() for p in lin.parameters()])
     ps = [torch.zeros_like(p0) for _ in range(w)]
     dist.all_gather(ps, p0)

@@ -518,6 +518,36 @@ def test_graph_replay_follows_weight_updates():
     assert (g_replay - g_eager).abs().max().item() <= 1e-4 * g_eager.abs().max().item()
 
 
+def test_overlap_step_is_the_single_graph_step():
+    """graph.GraphedOverlapStep (forward graph | backward graph, all-reduce of step k under the forward of step k + 1; here
+    without a process group, so the collectives are no-ops) leaves in the flat gradient buffer what graph.GraphedStep leaves,
+    step after step: same loss bit for bit, gradients to the round-off of the split-K atomics."""
+    import spike2former_amd as s2f
+    from spike2former_amd.dist import FlatGradAllReduce
+    from spike2former_amd.graph import GraphedOverlapStep, GraphedStep
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C1_64"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1_64"))).cuda().train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(2, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(5)).cuda()
+    red = FlatGradAllReduce(model.parameters(), 1)
+    red.install_sinks()
+    try:
+        single = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=1)
+        model.load_state_dict(sd)
+        l0 = float(single()); g0 = red.flat.clone()
+        over = GraphedOverlapStep(model, s2f.headline_loss, img, red, warmup=1, buckets=2)
+        for _ in range(2):
+            model.load_state_dict(sd)
+            l1 = float(over()); over.finish()
+            torch.cuda.synchronize()
+            assert l1 == l0
+            assert (red.flat - g0).abs().max().item() <= 1e-4 * g0.abs().max().item()
+    finally:
+        red.close()
+
+
 def test_tiny_split_graph_step_with_the_hungarian_loss_is_the_eager_step():
     """graph.GraphedSplitStep (forward graph | eager Hungarian-matched loss | backward graph) against the eager
     `mode="loss"` step on the tiny config: same loss values bit for bit, same gradients (flat buffer) to the run-to-run
