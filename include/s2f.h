@@ -222,6 +222,16 @@ int s2f_spike_gemm_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const fl
                             int K, int Mpad, int Kpad, int terms, void* stream);
 int s2f_spike_conv3x3_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch, int M,
                                int C, int H, int W, int Mpad, int Kpad, int terms, void* stream);
+/* General form of the forward kernel: Y[b] (M x N) = out_scale * (A[b] (M x K) @ X[b] (K x N) + bias[b][m]) with a weight per
+ * batch element (a_split + b * a_batch_stride: three bf16 terms [3][Mpad][Kpad] per batch, Mpad * Kpad * 3 apart at least),
+ * and the contraction running over K / k_inner slabs of a bf16 spike map that lie x_outer_stride elements apart (row k of
+ * batch b at X + b * x_batch_stride + (k / k_inner) * x_outer_stride + (k % k_inner) * N; k_inner % 32 == 0).  Call site:
+ * the mask contraction of the head with the mask_feature 1x1 convolution folded into it (ops.mask_einsum_folded):
+ * sum_t (E_t W_mf) @ S_t over the T time slices of mask_feature_spike's output as ONE contraction of length T*C
+ * (mmdet/models/dense_heads/maskformer_head.py:582-583 + mmdet/models/layers/pixel_decoder.py:467-470). */
+int s2f_spike_gemm_fwd_bf16_ex(const uint16_t* a_split, int64_t a_batch_stride, const uint16_t* X, int64_t x_batch_stride,
+                               int k_inner, int64_t x_outer_stride, const float* bias, int64_t bias_batch_stride,
+                               float out_scale, float* Y, int batch, int M, int N, int K, int Mpad, int Kpad, void* stream);
 int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate,
                            void* stream);
 int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "s2f_spike_gemm_fwd_bf16": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_spike_conv3x3_fwd_bf16": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),
     "s2f_spike_gemm_dw_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "s2f_spike_gemm_fwd_bf16_ex": (_i, [_p, _i64, _p, _i64, _i, _i64, _p, _i64, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_dw_grouped": (_i, [_p, _i, _i, _p]),
     "s2f_spike_conv3x3_dw_bf16": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "s2f_sdsa_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),

@@ -37,6 +37,17 @@ __device__ __forceinline__ u32x2 conv3_load_bf16(const unsigned short* __restric
   return v;
 }
 
+// General form of the forward kernel (the mask contraction with the mask_feature convolution folded into it, ops.py):
+// a weight per batch element (a_batch_stride elements apart), the contraction running over `K / k_inner` slabs of the
+// activation that lie x_outer_stride elements apart (the T time slices of a [T, B, C, HW] map as ONE contraction of length
+// T*C), a per-batch row bias, an output scale.  general == 0: the plain layout, every other field unused.
+struct GemmEx {
+  int general;
+  int k_inner;
+  int64_t a_batch_stride, x_batch_stride, x_outer_stride, bias_batch_stride;
+  float out_scale;
+};
+
 template <int CH>
 struct Chunk;
 template <>
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
                                                                    const unsigned short* __restrict__ X,
                                                                    const float* __restrict__ bias, float* __restrict__ Y,
                                                                    int M, int N, int K, int Mpad, int Kpad, int n_tiles,
-                                                                   int m_tiles, Conv3 geo) {
+                                                                   int m_tiles, Conv3 geo, GemmEx ex) {
   constexpr int BM = 64 * WM;
   constexpr int T = 128 * WM;
   constexpr int A_ELEMS = TERMS * BM * LDA;
@@ -79,8 +90,10 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
   const int mt = pid % m_tiles, nt = pid / m_tiles;
   const int b = blockIdx.y;
   const int m0 = mt * BM, n0 = nt * BN;
-  const unsigned short* Xb = X + (int64_t)b * (CONV ? K / 9 : K) * N;
+  const unsigned short* Xb = X + (ex.general ? (int64_t)b * ex.x_batch_stride : (int64_t)b * (CONV ? K / 9 : K) * N);
   float* Yb = Y + (int64_t)b * M * N;
+  Wsplit += (int64_t)b * ex.a_batch_stride;
+  if (bias) bias += (int64_t)b * ex.bias_batch_stride;
 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -128,7 +141,11 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
         chunk_t z;
 #pragma unroll
         for (int e = 0; e < CH / 2; ++e) z[e] = 0u;
-        breg[q] = ok ? *reinterpret_cast<const chunk_t*>(Xb + (int64_t)(kk + kr) * N + n) : z;
+        // general form: row r of the contraction lies in slab r / k_inner (slabs x_outer_stride apart; k_inner % 32 == 0, so
+        // a K step never straddles two slabs)
+        const int64_t rowoff = ex.general ? (int64_t)(kk / ex.k_inner) * ex.x_outer_stride + (int64_t)(kk % ex.k_inner + kr) * N
+                                          : (int64_t)(kk + kr) * N;
+        breg[q] = ok ? *reinterpret_cast<const chunk_t*>(Xb + rowoff + n) : z;
       }
     }
   };
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
         if (row < M && col < N) {
           float v = acc[i][j][r];
           if (bias) v += bias[row];
-          Yb[(int64_t)row * N + col] = v;
+          Yb[(int64_t)row * N + col] = ex.general ? v * ex.out_scale : v;
         }
       }
     }
@@ -389,7 +406,7 @@ __global__ void to_bf16_exact_kernel(const float* __restrict__ x, unsigned short
 }
 
 int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, const float* bias, float* Y, int batch, int M, int N,
-               int K, int Mpad, int Kpad, int terms, bool conv, Conv3 geo, void* stream) {
+               int K, int Mpad, int Kpad, int terms, bool conv, Conv3 geo, void* stream, GemmEx ex = GemmEx{0, 1, 0, 0, 0, 0, 1.f}) {
   S2F_REQUIRE(w_split && X && Y, S2F_EINVAL, "%s: null pointer", who);
   S2F_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL, "%s: bad sizes", who);
   S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "%s: N=%d must be a multiple of 4", who, N);
@@ -418,7 +435,7 @@ int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, cons
   const bool wide = !conv && (N & 7) == 0;              // 16-byte chunks
 #define S2F_GO(WMV, TV, CHV, CV, KGV)                                                                                    \
   S2F_LAUNCH(true, true, (sgemm_bf16_kernel<WMV, TV, CHV, CV, KGV>), grid, dim3(128 * WMV * KGV), 0, s, w_split, X, bias, Y, \
-             M, N, K, Mpad, Kpad, n_tiles, m_tiles, geo)
+             M, N, K, Mpad, Kpad, n_tiles, m_tiles, geo, ex)
 #define S2F_T(WMV, CHV, CV, KGV)                    \
   if (terms == 3) S2F_GO(WMV, 3, CHV, CV, KGV);      \
   else if (terms == 2) S2F_GO(WMV, 2, CHV, CV, KGV); \
@@ -585,4 +602,16 @@ extern "C" int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv
   else
     S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<32, 64>), dim3((unsigned)first), dim3(256), 0, s, tab);
   return s2f_check_launch("s2f_spike_gemm_dw_grouped");
+}
+
+extern "C" int s2f_spike_gemm_fwd_bf16_ex(const uint16_t* a_split, int64_t a_batch_stride, const uint16_t* X,
+                                          int64_t x_batch_stride, int k_inner, int64_t x_outer_stride, const float* bias,
+                                          int64_t bias_batch_stride, float out_scale, float* Y, int batch, int M, int N, int K,
+                                          int Mpad, int Kpad, void* stream) {
+  S2F_REQUIRE(k_inner > 0 && k_inner % 32 == 0 && K % k_inner == 0, S2F_EINVAL,
+              "s2f_spike_gemm_fwd_bf16_ex: k_inner must be a multiple of 32 that divides K");
+  S2F_REQUIRE((a_batch_stride & 7) == 0 && (x_batch_stride & 7) == 0 && (x_outer_stride & 7) == 0, S2F_EALIGN,
+              "s2f_spike_gemm_fwd_bf16_ex: strides must keep 16-byte alignment");
+  return fwd_launch("s2f_spike_gemm_fwd_bf16_ex", a_split, X, bias, Y, batch, M, N, K, Mpad, Kpad, 3, false, Conv3{0, 0, 0}, stream,
+                    GemmEx{1, k_inner, a_batch_stride, x_batch_stride, x_outer_stride, bias_batch_stride, out_scale});
 }

@@ -20,6 +20,8 @@ from .registry import MODELS, ConfigDict
 
 # key / value neurons of the decoder straight from  memory (+ level_embed) (+ pos)  by one fused add + neuron kernel
 FUSED_KV_NEURONS = True
+# the pixel decoder's mask_feature 1x1 convolution folded into the mask contraction (ops.mask_einsum_folded)
+FOLD_MASK_FEATURE = True
 
 
 def _lif():
@@ -91,7 +93,7 @@ class MaskFormerHead(nn.Module):
 
     def forward(self, x, batch_data_samples=None):
         """x: the 4 backbone maps.  -> all_cls_scores [L+1,B,Q,K+1], all_mask_preds [L+1,B,Q,H/2,W/2]."""
-        mask_features, memory, msm = self.pixel_decoder(x, None, spike_memory=True)
+        mask_features, memory, msm = self.pixel_decoder(x, None, spike_memory=True, fold_mask_feature=FOLD_MASK_FEATURE)
         t, bs = memory.shape[:2]
         query_feat = self.query_feat.weight.unsqueeze(0).repeat((t, bs, 1, 1))
         query_embed = self.query_embed.weight.unsqueeze(0).repeat(bs, 1, 1)
@@ -159,7 +161,14 @@ class MaskFormerHead(nn.Module):
         eq = e.permute(1, 2, 0, 3, 4).reshape(t, bs, ln * nq, C)        # [t, b, L*Q, C]: all L+1 predictions in one GEMM
         # e = alpha * spikes with alpha = 4: multiples of 1/2 <= 4, exact in bf16 -> the matrix-core path of ops.mask_einsum
         ops.join(getattr(self.pixel_decoder, "mask_feature_handle", None), (mask_features,))   # its side-stream branch
-        acc = ops.mask_einsum(eq, mask_features.flatten(3), 1.0 / t, e_exact=float(self.alpha) == 4.0)      # [b, L*Q, HW]
+        if isinstance(mask_features, ops.Spikes):
+            # the pixel decoder handed over mask_feature_spike's output: the 1x1 mask_feature convolution is folded into the
+            # contraction, sum_t (E_t W) @ S_t + bias term -- the convolution and its 537 MB output never run / exist
+            mfc = self.pixel_decoder.mask_feature
+            acc = ops.mask_einsum_folded(eq, mask_features.flatten(0, 1).flatten(2), mfc.weight.view(mfc.out_channels, -1), mfc.bias,
+                                         1.0 / t, t, bs, e_exact=float(self.alpha) == 4.0)
+        else:
+            acc = ops.mask_einsum(eq, mask_features.flatten(3), 1.0 / t, e_exact=float(self.alpha) == 4.0)      # [b, L*Q, HW]
         all_mask_preds = acc.view(bs, ln, nq, Hm, Wm).permute(1, 0, 2, 3, 4)
         return all_cls_scores, all_mask_preds
 

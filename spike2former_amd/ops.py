@@ -1359,6 +1359,105 @@ def mask_einsum(e, mf, scale, e_exact=False):
     return _MaskEinsum.apply(e, mf, float(scale), bool(e_exact))
 
 
+class _MaskEinsumFolded(torch.autograd.Function):
+    """The mask contraction of the head with the pixel decoder's mask_feature 1x1 convolution FOLDED into it:
+
+        out[b] = scale * sum_t E[t, b] @ (W S[t, b] + bias)          (maskformer_head.py:582-583 on pixel_decoder.py:467-470)
+               = scale * ( sum_t (E[t, b] W) @ S[t, b]  +  (sum_t E[t, b] bias) 1^T )
+
+    S = mask_feature_spike's output, a bf16 spike map [T*B, C, HW]; W [Co, C], bias [Co] = the mask_feature convolution;
+    E [T, B, Q, Co].  (E W) is a [Q, C] product per (t, b) -- 0.1 GFLOP -- after which the contraction runs over the SPIKES:
+    the convolution's own forward (69 GFLOP at C2), its weight gradient and the 537 MB fp32 mask_features tensor it wrote for
+    the einsum to read back never exist, and dE needs 3 MFMA passes (spike operand) instead of 6.  Same value as the
+    reference's two steps up to the association of fp32 sums (nothing thresholds this output).
+    Backward: G[t,b] = scale E[t,b]^T g[b] (3 passes, E exact in bf16) -> dS = W^T G (the convolution's input gradient);
+    H[t,b] = g[b] S[t,b]^T (weight-gradient kernel on a spike operand) -> dE = scale (H W^T + rowsum(g) bias^T),
+    dW = scale sum E^T H, dbias = scale sum E^T rowsum(g)."""
+
+    @staticmethod
+    def forward(ctx, e, sdata, stok, W, bias, scale, T, B, e_exact):
+        _need_cuda(e, W, bias, spikes=sdata)
+        Q, Co = e.shape[2], e.shape[3]
+        C, HW = sdata.shape[1], sdata.shape[2]
+        e = e.contiguous()
+        sdata = sdata.contiguous()
+        dev = e.device
+        ew = torch.matmul(e, W)                                               # [T, B, Q, C]
+        acat = ew.permute(1, 2, 0, 3).reshape(B, Q, T * C).contiguous()       # row (b, q), column (t, c)
+        Mpad = (Q + 255) // 256 * 256 if Q > 256 else (Q + 63) // 64 * 64
+        Kpad = T * C
+        a_split = torch.empty(B, 3, Mpad, Kpad, dtype=torch.int16, device=dev)
+        for b in range(B):
+            check(lib.s2f_split_bf16x3(_ptr(acat[b]), _ptr(a_split[b]), Q, T * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
+        rowb = None
+        if bias is not None:
+            rowb = torch.matmul(e.sum(0), bias).contiguous()                  # [B, Q]: sum_t E[t, b] bias
+        out = torch.empty(B, Q, HW, dtype=torch.float32, device=dev)
+        _time_next("spike_gemm_fwd", 4 * B * HW * (T * C + Q), 2 * B * Q * HW * T * C, moved=B * HW * (2 * T * C + 4 * Q))
+        check(lib.s2f_spike_gemm_fwd_bf16_ex(_ptr(a_split), 3 * Mpad * Kpad, _ptr(sdata), C * HW, C, B * C * HW, _ptr(rowb),
+                                             Q if rowb is not None else 0, scale, _ptr(out), B, Q, HW, T * C, Mpad, Kpad, _stream()),
+              "s2f_spike_gemm_fwd_bf16_ex")
+        ctx.save_for_backward(e, sdata, W, bias)
+        ctx.cfg = (scale, T, B, bool(e_exact))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        e, sdata, W, bias = ctx.saved_tensors
+        scale, T, B, e_exact = ctx.cfg
+        Q, Co = e.shape[2], e.shape[3]
+        C, HW = sdata.shape[1], sdata.shape[2]
+        g = g.contiguous()
+        dev = g.device
+        gs = ge = gW = gb = None
+        S = sdata.view(T, B, C, HW)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # dS[t, b] = W^T (scale E[t, b]^T g[b]): the first product as in _MaskEinsum (E exact in bf16: 3 passes), the
+            # second is the mask_feature convolution's input gradient
+            G = torch.empty(T, B, Co, HW, dtype=torch.float32, device=dev)
+            if e_exact and HW % 4 == 0:
+                et = e.permute(0, 1, 3, 2).reshape(T * B * Co, Q)
+                a_split, Rpad, Kp = _split_rows(et, 128)
+                for t in range(T):
+                    check(lib.s2f_split_gemm(_ptr(a_split) + 2 * t * B * Co * Kp, Co * Kp, Rpad * Kp, 1, _ptr(g), Q * HW, Q, 0, 3,
+                                             _ptr(G[t]), Co * HW, scale, B, Co, HW, Q, (Co + 127) // 128 * 128, Kp, _stream()),
+                          "s2f_split_gemm")
+            else:
+                es = e * scale
+                for t in range(T):
+                    torch.bmm(es[t].transpose(1, 2), g, out=G[t])
+            gs = dx_gemm(W, G.view(T * B, Co, HW))
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            H = torch.empty(T, B, Q, C, dtype=torch.float32, device=dev)
+            xb = sdata.dtype == torch.bfloat16
+            _time_next("spike_gemm_dw", 4 * T * B * HW * (C + Q), 2 * T * B * Q * HW * C, moved=T * B * HW * ((2 if xb else 4) * C + 4 * Q))
+            for t in range(T):
+                for b in range(B):
+                    if xb:
+                        check(lib.s2f_spike_gemm_dw_bf16(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, _stream()),
+                              "s2f_spike_gemm_dw_bf16")
+                    else:
+                        check(lib.s2f_spike_gemm_dw(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, 1, _stream()),
+                              "s2f_spike_gemm_dw")
+            rs = g.sum(-1) if bias is not None else None                      # [B, Q]
+            if ctx.needs_input_grad[0]:
+                ge = torch.matmul(H, W.t())
+                if bias is not None:
+                    ge = ge + rs.unsqueeze(0).unsqueeze(-1) * bias.view(1, 1, 1, -1)
+                ge = ge * scale
+            if ctx.needs_input_grad[3]:
+                gW = torch.einsum("tbqo,tbqc->oc", e, H) * scale
+            if bias is not None and ctx.needs_input_grad[4]:
+                gb = torch.einsum("tbqo,bq->o", e, rs) * scale
+        return (ge,) + _grad_pair(True, gs) + (gW, gb, None, None, None, None)
+
+
+def mask_einsum_folded(e, spikes, W, bias, scale, T, B, e_exact=False):
+    """e [T, B, Q, Co], spikes: bf16 Spikes [T*B, C, HW] (mask_feature_spike's output), W [Co, C], bias [Co] or None -> [B, Q, HW]"""
+    assert isinstance(spikes, Spikes) and spikes.tok is not None and spikes.data.dtype == torch.bfloat16
+    return _MaskEinsumFolded.apply(e, spikes.data, spikes.tok, W, bias, float(scale), int(T), int(B), bool(e_exact))
+
+
 # ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
 class _Up2x(torch.autograd.Function):
     @staticmethod

@@ -65,9 +65,12 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
     def init_weights(self):
         pass
 
-    def forward(self, feats, batch_img_metas=None, spike_memory=False):
+    def forward(self, feats, batch_img_metas=None, spike_memory=False, fold_mask_feature=False):
         """`spike_memory`: hand `memory` (a spike map) out as the ops.Spikes pair instead of converting it to the fp32 tensor
-        of the reference's interface (the head only reads its shape)."""
+        of the reference's interface (the head only reads its shape).
+        `fold_mask_feature`: return mask_feature_spike's OUTPUT (the bf16 spike map [T, B, C, H/2, W/2]) in place of
+        mask_feature(...) when that is possible: the head then folds the 1x1 convolution into its mask contraction
+        (ops.mask_einsum_folded) and the 537 MB mask_features tensor never exists."""
         x4 = feats[-1]
         t, bs, c, h, w = x4.shape
         E = self.encoder_embed_dims
@@ -107,8 +110,15 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
 
         # The H/2 level and the mask_feature convolution (the largest maps of the head) feed only the mask einsum at the very
         # end: as a branch on the side stream they overlap with the transformer decoder; the head joins it (mask_feature_handle).
+        mfc = self.mask_feature
+        fold = (fold_mask_feature and ops.SPIKES_BF16 and mfc.kernel_size == (1, 1) and mfc.stride == (1, 1) and mfc.groups == 1
+                and mfc.in_channels % 32 == 0 and not self.mask_feature_spike._forward_hooks)
+
         def finest(y=y):
             y0 = level(0, y)
-            return self.mask_feature(self.mask_feature_spike.fire(y0))
+            s0 = self.mask_feature_spike.fire(y0)
+            if fold and isinstance(s0, ops.Spikes) and s0.tok is not None and (s0.shape[-1] * s0.shape[-2]) % 8 == 0:
+                return s0
+            return self.mask_feature(s0)
         mf, self.mask_feature_handle = ops.fork(0, finest, inputs=(y,), what="mf")
         return mf.reshape(t, bs, *mf.shape[1:]), (memory if spike_memory else memory.float()), out[:3]

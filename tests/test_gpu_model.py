@@ -373,3 +373,35 @@ def test_c1_plumbing_config_at_its_own_size_vs_oracle():
     k = "decode_head.mask_embed.fc1.weight"
     gm, go = dict(model.named_parameters())[k].grad.cpu(), st[k].grad
     assert (gm - go).abs().max().item() <= 5e-2 * go.abs().max().item()
+
+
+def test_folded_mask_feature_convolution_does_not_change_the_step(env):
+    """maskformer_head.FOLD_MASK_FEATURE: the pixel decoder's mask_feature 1x1 convolution folded into the mask contraction,
+    sum_t (E_t W) S_t + bias term (ops.mask_einsum_folded: the convolution, its weight gradient and the fp32 mask_features
+    tensor never exist), against the reference's two steps, conv then einsum: mask logits, class scores and every parameter
+    gradient agree to fp32 round-off (only the association of the sums differs; nothing thresholds this output)."""
+    s2f, so, cfg, model = env
+    from spike2former_amd import maskformer_head as mh
+    model.train()
+    s2f.set_keep_membrane(model, False)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    img = so.synthetic_image(cfg, seed=5).cuda()
+    runs = []
+    try:
+        for fold in (True, False):
+            mh.FOLD_MASK_FEATURE = fold
+            model.load_state_dict(state)
+            s2f.reset_net(model); model.zero_grad(set_to_none=True)
+            cls, masks = model(img)
+            (cls.float().mean() + (masks * torch.linspace(-1, 1, masks.shape[-1], device="cuda")).mean()).backward()
+            runs.append((cls.detach().clone(), masks.detach().clone(),
+                         {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        mh.FOLD_MASK_FEATURE = True
+        s2f.set_keep_membrane(model, True)
+    a, b = runs
+    assert torch.equal(a[0], b[0])                                   # class scores do not depend on the mask branch
+    assert rel(a[1], b[1]) <= 1e-5
+    assert set(a[2]) == set(b[2]) and grad_gap(a[2], b[2]) <= 1e-3
+    k = "decode_head.pixel_decoder.mask_feature.weight"
+    assert rel(a[2][k], b[2][k]) <= 1e-4 and rel(a[2]["decode_head.pixel_decoder.mask_feature.bias"], b[2]["decode_head.pixel_decoder.mask_feature.bias"]) <= 1e-4
