@@ -247,8 +247,11 @@ def main():
             # separate runs, gfx950 corrections applied there); null when no such profile exists for a kernel
             traffic = {}
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+                for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json"):          # the newest profile wins
+                    path = os.path.join(ROOT, "profiles", name)
+                    if os.path.exists(path):
+                        with open(path) as f:
+                            traffic.update({k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()})
             except (OSError, KeyError, ValueError):
                 pass
             if args.dump_events:
