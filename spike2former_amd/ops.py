@@ -583,6 +583,7 @@ class _LIF(torch.autograd.Function):
                               _stream()), "s2f_lif_fwd")
         ctx.save_for_backward(mask)
         ctx.D, ctx.vth, ctx.has_v = D, vth, v_in is not None
+        ctx.set_materialize_grads(False)          # no zero-filled stand-ins for the gradients of unused / bf16 outputs
         if v_out is None:
             v_out = x.new_empty(0)
             ctx.mark_non_differentiable(v_out)
@@ -596,6 +597,10 @@ class _LIF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gv, _g2):
         (mask,) = ctx.saved_tensors
+        if gy is None and gv is None:
+            return (None,) * 7
+        if gy is None:                              # only the membrane carries a gradient
+            gy = torch.zeros_like(gv)
         gy = gy.contiguous()
         if gv is not None and gv.numel() != gy.numel():
             gv = None
@@ -636,6 +641,7 @@ class _Sum2LIF(torch.autograd.Function):
                                    int(bf16), _stream()), "s2f_sum2_lif_fwd")
         ctx.save_for_backward(mk, mv)
         ctx.D = D
+        ctx.set_materialize_grads(False)
         if bf16:
             ctx.mark_non_differentiable(yk, yv)
             return _new_tok(x), _new_tok(x), yk, yv
@@ -646,6 +652,10 @@ class _Sum2LIF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gk, gv, _a, _b):
         mk, mv = ctx.saved_tensors
+        if gk is None and gv is None:
+            return (None,) * 7
+        gk = torch.zeros_like(gv) if gk is None else gk
+        gv = torch.zeros_like(gk) if gv is None else gv
         gk, gv = gk.contiguous(), gv.contiguous()
         gx = torch.empty_like(gk)
         _time_next("lif_bwd", 12 * gk.numel())
@@ -754,6 +764,7 @@ class _SDSASpikes(torch.autograd.Function):
         kv = torch.empty(TB, heads, d, d, dtype=torch.float32, device=dev)
         ctx.cfg = (TB, C, Nq, Nk, d, heads, scale, packed, fuse, D, (qs, ks, vs))
         ctx.ptrs_of = (kp - qp, vp - qp)
+        ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[3:6])
         if fuse:
             y = torch.empty(TB, C, Nq, dtype=torch.bfloat16, device=dev)
@@ -777,6 +788,8 @@ class _SDSASpikes(torch.autograd.Function):
     def backward(ctx, g, _g1):
         qd, kd, vd, kv, mask = ctx.saved_tensors
         TB, C, Nq, Nk, d, heads, scale, packed, fuse, D, (qs, ks, vs) = ctx.cfg
+        if g is None:
+            return (None,) * 13
         g = g.contiguous()
         dev = g.device
         qp = qd.data_ptr()
