@@ -126,6 +126,19 @@ __device__ __forceinline__ void st4_bf16(float* p, int64_t base, const Tile4& t)
   *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + base) = s2f_spikes_to_bf16x4(t.a[0], t.a[1], t.a[2], t.a[3]);
 }
 
+// streaming (non-temporal) forms of the two stores
+__device__ __forceinline__ void st4_nt(float* p, const Tile4& t) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 v = {t.a[0], t.a[1], t.a[2], t.a[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+}
+__device__ __forceinline__ void st4_bf16_nt(float* p, int64_t base, const Tile4& t) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const uint2 w = s2f_spikes_to_bf16x4(t.a[0], t.a[1], t.a[2], t.a[3]);
+  u2 v = {w.x, w.y};
+  __builtin_nontemporal_store(v, reinterpret_cast<u2*>(reinterpret_cast<unsigned short*>(p) + base));
+}
+
 // u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
 // YB: the spikes y are written as bf16 (2 bytes / element).
 template <bool LIF, bool HAS_V, bool YB>
@@ -382,6 +395,287 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Row-walking forms of the three streaming kernels, for L % 256 == 0 (every 256-element tile lies in ONE channel row) and a
+// power-of-two D.  The generic kernels above spend ~300 VALU instructions per tile on per-lane index arithmetic (two
+// integer divisions for the channel, a float division per spike, 64-bit address checks) and ran at 3.1-3.9 TB/s moved
+// where a pure read reaches 5.8-6.5 TB/s (tools/probe_bn_stream.py): they were VALU-bound, not HBM-bound.  Here a wave owns
+// a CONTIGUOUS run of tiles; tile index, row, column-tile and channel are wave-uniform (readfirstlane on the wave id) and
+// live in SGPRs: the channel advances by a compare instead of a division, the per-channel parameters and the four in-range
+// mask words arrive through scalar loads, and a mask word is applied as a lane mask (inverse ballot -> v_cndmask) instead
+// of 64-bit shifts.  Same per-element expressions as the generic kernels, so the results are bit-identical.
+__device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+constexpr int kAhead = 2;                        // tiles of a wave in flight besides the one being worked on
+
+template <bool LIF, bool HAS_V, bool YB>
+__global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, const double* __restrict__ sums, float* __restrict__ stat,
+    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ num_batches,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out,
+    const float* __restrict__ v_in, float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask,
+    unsigned long long* __restrict__ stats, uint32_t ntiles, int C, uint32_t tpr, uint32_t chunk, double inv_count,
+    float unbias, float momentum, float eps, int training, float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
+  uint32_t t = wave * chunk;
+  const uint32_t t_end = min(ntiles, t + chunk);
+  extern __shared__ __attribute__((aligned(16))) float sstat[];      // [3][C]: mean, rstd, var
+  Tile4 zn[kAhead], rn[kAhead], vn[kAhead];
+  auto request = [&](int slot, uint32_t tile) __attribute__((always_inline)) {
+    if (tile < t_end) {
+      const int64_t base = (int64_t)tile * 256 + lane * 4;
+      zn[slot] = ld4(z + base);
+      if (res) rn[slot] = ld4(res + base);
+      if (LIF && HAS_V) vn[slot] = ld4(v_in + base);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < kAhead; ++i) request(i, t + i);
+  for (int c = threadIdx.x; c < C; c += kBlock) {
+    const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+    sstat[c] = cs.mean;
+    sstat[C + c] = cs.rstd;
+    sstat[2 * C + c] = cs.var;
+  }
+  __syncthreads();
+  uint32_t row = t / tpr, q = t - row * tpr;
+  uint32_t c = row % (uint32_t)C;
+  float b, mean, rstd, g, be;
+  auto params = [&]() __attribute__((always_inline)) {
+    b = bias ? bias[c] : 0.f;
+    mean = sstat[c];
+    rstd = sstat[C + c];
+    g = gamma[c];
+    be = beta[c];
+  };
+  if (t < t_end) params();
+  const float inv_d = 1.0f / Df;                          // exact: D is a power of two on this path
+  const bool count = LIF && stats != nullptr;
+  uint32_t csum = 0, cnz = 0;
+  // one tile: BN (+ residual) (+ neuron), stores, mask words; then the (row, channel) walk
+  auto work = [&](uint32_t tile, const Tile4& zv, const Tile4& rv, const Tile4& vv) __attribute__((always_inline)) {
+    const int64_t base = (int64_t)tile * 256 + lane * 4;
+    if (q == 0 && row < (uint32_t)C && lane == 0) {
+      // first tile of channel c in batch row 0: publish the statistics for the backward pass and update the running
+      // statistics (torch.nn.BatchNorm: momentum, unbiased variance)
+      stat[c] = mean;
+      stat[C + c] = rstd;
+      float rm = running_mean ? running_mean[c] : 0.f, rvv = running_var ? running_var[c] : 1.f;
+      if (training && running_mean != nullptr) {
+        rm = (1.f - momentum) * rm + momentum * mean;
+        rvv = (1.f - momentum) * rvv + momentum * (sstat[2 * C + c] * unbias);
+        running_mean[c] = rm;
+        running_var[c] = rvv;
+      }
+      stat[2 * C + c] = be - rm * g / sqrtf(rvv + eps);
+      if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
+    }
+    bool inr[4];
+    Tile4 uo, yo, vo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float u = ((zv.a[j] + b) - mean) * rstd * g + be;
+      if (res) u += rv.a[j];
+      uo.a[j] = u;
+      if (LIF) {
+        const float h = HAS_V ? (vv.a[j] + u) : u;
+        float sp;
+        s2f_lif_update(h, Df, inv_d, vth, sp, yo.a[j], vo.a[j], inr[j]);
+        if (count) {
+          csum += (uint32_t)sp;
+          cnz += ((uint32_t)sp != 0);
+        }
+      }
+    }
+    if (u_out) st4(u_out + base, uo);
+    if (LIF) {
+      if (YB)
+        st4_bf16(y, base, yo);
+      else
+        st4(y + base, yo);
+      if (v_out) st4(v_out + base, vo);
+      const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+      if (mask != nullptr && lane < 4) mask[(int64_t)tile * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    }
+    if (++q == tpr) {
+      q = 0;
+      ++row;
+      if (++c == (uint32_t)C) c = 0;
+      params();
+    }
+  };
+  for (; t < t_end; t += kAhead) {
+    Tile4 zv[kAhead], rv[kAhead], vv[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) {
+      zv[i] = zn[i];
+      rv[i] = rn[i];
+      vv[i] = vn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) request(i, t + kAhead + i);
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i)
+      if (t + i < t_end) work(t + i, zv[i], rv[i], vv[i]);
+  }
+  if (count) {
+    for (int o = 32; o > 0; o >>= 1) {
+      csum += __shfl_xor(csum, o, 64);
+      cnz += __shfl_xor(cnz, o, 64);
+    }
+    __syncthreads();
+    uint32_t* red = reinterpret_cast<uint32_t*>(sstat);
+    if (lane == 0) {
+      red[(threadIdx.x >> 6) * 2] = csum;
+      red[(threadIdx.x >> 6) * 2 + 1] = cnz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long a = 0, bq = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        a += red[2 * w];
+        bq += red[2 * w + 1];
+      }
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (a) atomicAdd(&slot[0], a);
+      if (bq) atomicAdd(&slot[1], bq);
+    }
+  }
+}
+
+// gu of one element with the in-range bit delivered as a lane predicate
+template <bool GU, bool GY, bool GV>
+__device__ __forceinline__ float form_gu_rows(float gu, float gy, float gv, bool m, float vth, float inv_d) {
+  float r = GU ? gu : 0.f;
+  if (GY || GV) {
+    const float gvv = GV ? gv : 0.f;
+    const float through = GY ? gy * inv_d : 0.f;
+    const float lif = GV ? (m ? (gvv + (through - gvv * vth)) : gvv) : (m ? through : 0.f);
+    r = GU ? r + lif : lif;
+  }
+  return r;
+}
+
+// grid (C, S): block (c, s) reduces rows n*C + c, tiles [s*tps, (s+1)*tps) of each row; wave w takes tiles w, w+4, ... of a
+// row, kRowUnroll of them with every load issued before the first use.
+constexpr int kRowUnroll = 4;
+template <bool GU, bool GY, bool GV>
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
+    const float* __restrict__ g_u, const float* __restrict__ g_y, const float* __restrict__ g_v,
+    const uint64_t* __restrict__ mask, double* __restrict__ sums, int N, int C, int tpr, int tps, float vth, float Df) {
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = wave_id_uniform();
+  const int q_lo = blockIdx.y * tps, q_hi = min(tpr, q_lo + tps);
+  const float b = bias ? bias[c] : 0.0f, mean = stat[c], rstd = stat[C + c];
+  const float inv_d = 1.0f / Df;
+  float ps = 0.f, pq = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int64_t row_tile = ((int64_t)n * C + c) * tpr;        // first tile of the row
+    for (int q0 = q_lo + wv; q0 < q_hi; q0 += kWaves * kRowUnroll) {
+      Tile4 zv[kRowUnroll], a[kRowUnroll], bb[kRowUnroll], cc[kRowUnroll];
+      uint64_t mw[kRowUnroll][4];
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        const int q = q0 + u * kWaves;
+        if (q < q_hi) {                                          // wave-uniform
+          const int64_t tile = row_tile + q, base = tile * 256 + lane * 4;
+          zv[u] = ld4(z + base);
+          if (GU) a[u] = ld4(g_u + base);
+          if (GY) bb[u] = ld4(g_y + base);
+          if (GV) cc[u] = ld4(g_v + base);
+          if (GY || GV) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mw[u][j] = mask[tile * 4 + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        if (q0 + u * kWaves >= q_hi) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool m = (GY || GV) ? __builtin_amdgcn_inverse_ballot_w64(mw[u][j]) : false;
+          const float gu = form_gu_rows<GU, GY, GV>(GU ? a[u].a[j] : 0.f, GY ? bb[u].a[j] : 0.f, GV ? cc[u].a[j] : 0.f, m, vth, inv_d);
+          const float xhat = ((zv[u].a[j] + b) - mean) * rstd;
+          ps += gu;
+          pq += gu * xhat;
+        }
+      }
+    }
+  }
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
+}
+
+template <bool GU, bool GY, bool GV>
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
+    const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
+    const float* __restrict__ g_v, const uint64_t* __restrict__ mask, const double* __restrict__ sums,
+    float* __restrict__ gz, float* __restrict__ g_res, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    uint32_t ntiles, int C, uint32_t tpr, uint32_t chunk, double inv_count, int training, float vth, float Df) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
+  uint32_t t = wave * chunk;
+  const uint32_t t_end = min(ntiles, t + chunk);
+  Tile4 zn, an, bn, cn;
+  uint64_t mn[4] = {0, 0, 0, 0};
+  auto request = [&](uint32_t tile) __attribute__((always_inline)) {
+    if (tile < t_end) {
+      const int64_t base = (int64_t)tile * 256 + lane * 4;
+      zn = ld4(z + base);
+      if (GU) an = ld4(g_u + base);
+      if (GY) bn = ld4(g_y + base);
+      if (GV) cn = ld4(g_v + base);
+      if (GY || GV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mn[j] = mask[(int64_t)tile * 4 + j];
+      }
+    }
+  };
+  request(t);
+  uint32_t row = t / tpr, q = t - row * tpr;
+  uint32_t c = row % (uint32_t)C;
+  float b, mean, rstd, g, m1, m2;
+  auto params = [&]() __attribute__((always_inline)) {
+    b = bias ? bias[c] : 0.f;
+    mean = stat[c];
+    rstd = stat[C + c];
+    g = gamma[c];
+    m1 = training ? (float)(sums[2 * c] * inv_count) : 0.f;
+    m2 = training ? (float)(sums[2 * c + 1] * inv_count) : 0.f;
+  };
+  if (t < t_end) params();
+  const float inv_d = 1.0f / Df;
+  for (; t < t_end; ++t) {
+    const int64_t base = (int64_t)t * 256 + lane * 4;
+    const Tile4 zv = zn, a = an, bb = bn, cc = cn;
+    const uint64_t mw[4] = {mn[0], mn[1], mn[2], mn[3]};
+    request(t + 1);
+    if (q == 0 && row < (uint32_t)C && lane == 0) {          // dbeta = sum(gu), dgamma = sum(gu * xhat)
+      dbeta[c] = (float)sums[2 * c];
+      dgamma[c] = (float)sums[2 * c + 1];
+    }
+    Tile4 o, r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool m = (GY || GV) ? __builtin_amdgcn_inverse_ballot_w64(mw[j]) : false;
+      const float gu = form_gu_rows<GU, GY, GV>(GU ? a.a[j] : 0.f, GY ? bb.a[j] : 0.f, GV ? cc.a[j] : 0.f, m, vth, inv_d);
+      const float xhat = ((zv.a[j] + b) - mean) * rstd;
+      o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
+      r.a[j] = gu;
+    }
+    st4(gz + base, o);
+    if (g_res) st4(g_res + base, r);
+    if (++q == tpr) {
+      q = 0;
+      ++row;
+      if (++c == (uint32_t)C) c = 0;
+      params();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Single-pass forms for small maps.  When one channel's N*L elements fit in the registers of one workgroup (4 waves x
 // 8 tiles x 256 elements = 8 192; L % 256 == 0 so that the 256-element mask tiles do not straddle channels) the workgroup of
 // channel c loads its slice ONCE, reduces the statistics through LDS and applies them from registers: z is read once instead
@@ -597,6 +891,46 @@ inline int pick_slices(int C, int L, int& slice) {
   return S;
 }
 
+// Row-walking forms: eligibility, slice picker (in tiles) and the persistent grid.
+inline bool rows_ok(int64_t N, int64_t C, int64_t L, int D) {
+  return (L & 255) == 0 && N * C * L < ((int64_t)1 << 39) && N * C < ((int64_t)1 << 31) && D >= 1 && (D & (D - 1)) == 0;
+}
+inline int pick_slices_rows(int C, int tpr, int& tps) {
+  int S = 1;
+  while ((int64_t)C * S < 2048 && tpr / (S * 2) >= 8) S *= 2;       // >= 8 tiles per (row, slice): two per wave
+  tps = (tpr + S - 1) / S;
+  return (tpr + tps - 1) / tps;
+}
+// Workgroups of `Kern` that can be resident on the whole chip at once: a persistent kernel launched with more than that
+// runs a second, partly filled round (2 048 workgroups on 1 792 slots cost 14 %).
+template <auto Kern>
+int resident_blocks(size_t lds) {
+  static int cus = 0, per_cu_small = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+      cus = 256;
+  }
+  int per_cu = lds <= 16384 ? per_cu_small : 0;
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kern, kBlock, lds <= 16384 ? 16384 : lds) != hipSuccess || per_cu < 1)
+      per_cu = 4;
+    if (lds <= 16384) per_cu_small = per_cu;
+  }
+  return cus * per_cu;
+}
+// -> grid; chunk = contiguous tiles per wave
+template <auto Kern>
+int grid_rows(uint32_t ntiles, size_t lds, uint32_t& chunk) {
+  const int64_t cap = resident_blocks<Kern>(lds);
+  int64_t blocks = ((int64_t)ntiles + 4 * kWaves - 1) / (4 * kWaves);      // >= 4 tiles per wave amortise the prologue
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  chunk = (uint32_t)(((int64_t)ntiles + blocks * kWaves - 1) / (blocks * kWaves));
+  return (int)(((int64_t)ntiles + (int64_t)chunk * kWaves - 1) / ((int64_t)chunk * kWaves));
+}
+
 inline int grid_flat(int64_t total) {
   int64_t tiles = (total + 255) >> 8;
   int64_t blocks = (tiles + 4 * kWaves - 1) / (4 * kWaves);      // >= 4 tiles per wave amortise the per-block prologue
@@ -641,6 +975,8 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
               "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
+  S2F_REQUIRE(!(y && y_bf16) || s2f_bf16_spikes_exact(D), S2F_EINVAL,
+              "s2f_bn_act_fwd: bf16 spikes need D a power of two <= 128 (D=%d)", D);
   int rc = check_shape("s2f_bn_act_fwd", N, C, L);
   if (rc) return rc;
   S2F_REQUIRE(s2f_aligned16(z) && s2f_aligned16(residual) && s2f_aligned16(u_out) && s2f_aligned16(v_in) &&
@@ -676,10 +1012,23 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
 #undef S2F_BN_FUSED
     return s2f_check_launch("s2f_bn_act_fwd");
   }
+  const bool rows = rows_ok(N, C, L, D);
+  const size_t lds = 3 * C * sizeof(float) + 64;
 #define S2F_BN_APPLY(LIFV, HASV, YBV)                                                                                   \
-  S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, 3 * C * sizeof(float) + 64, s, z, conv_bias, sums, stat_out, running_mean, \
-                     running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, (int)L,   \
-                     inv_count, unbias, momentum, eps, training, vth, (float)D)
+  do {                                                                                                                  \
+    if (rows) {                                                                                                         \
+      uint32_t chunk;                                                                                                   \
+      const uint32_t ntiles = (uint32_t)(total >> 8);                                                                   \
+      const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV>>(ntiles, lds, chunk);                           \
+      S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV>), dim3(rgrid), block, lds, s, z, conv_bias, sums,    \
+                 stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
+                 ntiles, (int)C, (uint32_t)(L >> 8), chunk, inv_count, unbias, momentum, eps, training, vth, (float)D); \
+    } else {                                                                                                            \
+      S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, lds, s, z, conv_bias, sums, stat_out,      \
+                 running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, \
+                 (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D);                                    \
+    }                                                                                                                   \
+  } while (0)
   if (y == nullptr)
     S2F_BN_APPLY(false, false, false);
   else if (v_in == nullptr) {
@@ -726,6 +1075,34 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
       default: S2F_BN_FB(true, true, true); break;
     }
 #undef S2F_BN_FB
+    return s2f_check_launch("s2f_bn_act_bwd");
+  }
+  if (rows_ok(N, C, L, D)) {
+    const int tpr = (int)(L >> 8);
+    int tps;
+    const int S = pick_slices_rows((int)C, tpr, tps);
+    const uint32_t ntiles = (uint32_t)(total >> 8);
+    const double inv_count = 1.0 / ((double)N * (double)L);
+#define S2F_BN_ROWS_BWD(A, B, Cc)                                                                                        \
+  do {                                                                                                                   \
+    S2F_LAUNCH(true, false, (bn_bwd_reduce_rows_kernel<A, B, Cc>), dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, \
+               stat, g_u, g_y, g_v, mask, sums_zeroed, (int)N, (int)C, tpr, tps, vth, (float)D);                          \
+    uint32_t chunk;                                                                                                      \
+    const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc>>(ntiles, 0, chunk);                                   \
+    S2F_LAUNCH(false, true, (bn_bwd_apply_rows_kernel<A, B, Cc>), dim3(rgrid), dim3(kBlock), 0, s, z, conv_bias, stat,     \
+               gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, ntiles, (int)C, (uint32_t)tpr,     \
+               chunk, inv_count, training, vth, (float)D);                                                               \
+  } while (0)
+    switch ((g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0)) {
+      case 1: S2F_BN_ROWS_BWD(false, false, true); break;
+      case 2: S2F_BN_ROWS_BWD(false, true, false); break;
+      case 3: S2F_BN_ROWS_BWD(false, true, true); break;
+      case 4: S2F_BN_ROWS_BWD(true, false, false); break;
+      case 5: S2F_BN_ROWS_BWD(true, false, true); break;
+      case 6: S2F_BN_ROWS_BWD(true, true, false); break;
+      default: S2F_BN_ROWS_BWD(true, true, true); break;
+    }
+#undef S2F_BN_ROWS_BWD
     return s2f_check_launch("s2f_bn_act_bwd");
   }
   int slice;

@@ -406,6 +406,7 @@ extern "C" int s2f_lif_fwd(const float* x, const float* v_in, void* y_out, float
   if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_lif_fwd: null x/y");
   S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_fwd: bad n=%lld or D=%d", (long long)n, D);
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_lif_fwd: bf16 spikes need D a power of two <= 128 (D=%d)", D);
   S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y) && s2f_aligned16(v_in) && s2f_aligned16(v_out), S2F_EALIGN,
               "s2f_lif_fwd: x/y/v must be 16-byte aligned");
   S2F_REQUIRE(count_u8 == nullptr || (reinterpret_cast<uintptr_t>(count_u8) & 3u) == 0, S2F_EALIGN,
@@ -457,6 +458,7 @@ extern "C" int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos
               "s2f_sum2_lif_fwd: bad shape (L must be a multiple of 4, TB a multiple of B)");
   S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(pos) && s2f_aligned16(y_key) && s2f_aligned16(y_value), S2F_EALIGN,
               "s2f_sum2_lif_fwd: tensors must be 16-byte aligned");
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_sum2_lif_fwd: bf16 spikes need D a power of two <= 128 (D=%d)", D);
   const int64_t n = TB * C * L;
   if (y_bf16)
     S2F_LAUNCH(true, true, sum2_lif_fwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, e, pos,

@@ -61,6 +61,9 @@ __device__ __forceinline__ void s2f_lif_update(float h, float Df, float inv_d, f
   in_range = (h >= 0.0f) && (h <= Df);
 }
 
+// bf16 spike storage is exact only for k / D with D a power of two <= 128 (k <= D: at most 8 significant bits).
+static inline bool s2f_bf16_spikes_exact(int D) { return D >= 1 && D <= 128 && (D & (D - 1)) == 0; }
+
 // Four spikes (multiples of 1/D, <= 8 significant bits) as bf16: the low 16 bits of such an fp32 are zero, so keeping the
 // high halves IS the exact conversion (no rounding instruction).
 __device__ __forceinline__ uint2 s2f_spikes_to_bf16x4(float a, float b, float c, float d) {

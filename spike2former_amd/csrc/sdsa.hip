@@ -542,8 +542,8 @@ extern "C" int s2f_sdsa_lif_fwd_bf16(const uint16_t* q, const uint16_t* k, const
   if (rc) return rc;
   rc = check_bf16("s2f_sdsa_lif_fwd_bf16", q, k, v, q_batch_stride, k_batch_stride, v_batch_stride, N, N);
   if (rc) return rc;
-  S2F_REQUIRE((N & 255) == 0 && ((q_batch_stride | k_batch_stride | v_batch_stride) & 7) == 0 && D >= 1 && D <= 255, S2F_EINVAL,
-              "s2f_sdsa_lif_fwd_bf16: needs N %% 256 == 0 and batch strides that are multiples of 8");
+  S2F_REQUIRE((N & 255) == 0 && ((q_batch_stride | k_batch_stride | v_batch_stride) & 7) == 0 && s2f_bf16_spikes_exact(D), S2F_EINVAL,
+              "s2f_sdsa_lif_fwd_bf16: needs N %% 256 == 0, batch strides that are multiples of 8 and D a power of two <= 128");
   S2F_REQUIRE(s2f_aligned16(q) && s2f_aligned16(k) && s2f_aligned16(v) && (reinterpret_cast<uintptr_t>(y_spikes) & 7u) == 0,
               S2F_EALIGN, "s2f_sdsa_lif_fwd_bf16: q / k / v must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;

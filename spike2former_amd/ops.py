@@ -310,6 +310,12 @@ def mask_words(n):
 SPIKES_BF16 = True
 
 
+def spikes_bf16_ok(D):
+    """bf16 storage is exact only for k / D with D a power of two (D <= 128: k <= D needs <= 8 significant bits)."""
+    D = int(D)
+    return SPIKES_BF16 and 0 < D <= 128 and (D & (D - 1)) == 0
+
+
 class Spikes:
     __slots__ = ("data", "tok")
 
@@ -615,7 +621,7 @@ class _LIF(torch.autograd.Function):
 
 def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None, spikes=False):
     """-> (y, v_out or None); `spikes`: y as a Spikes pair (bf16 when SPIKES_BF16 and the size allows 8-byte stores)"""
-    bf16 = bool(spikes) and SPIKES_BF16 and x.numel() % 4 == 0 and x.numel() > 0
+    bf16 = bool(spikes) and spikes_bf16_ok(D) and x.numel() % 4 == 0 and x.numel() > 0
     y, v, data = _LIF.apply(x, v_in, D, vth, keep_v, stats, bf16)
     if spikes:
         y = Spikes(data, y) if bf16 else Spikes(y, None)
@@ -667,7 +673,7 @@ class _Sum2LIF(torch.autograd.Function):
 
 def sum2_lif(x, e, pos, B, D=8, vth=1.0):
     """x [T*B, C, L], e [C], pos [B, C, L] -> (Q_IFNode(x + e + pos), Q_IFNode(x + e))  (key spikes, value spikes), as Spikes."""
-    bf16 = SPIKES_BF16
+    bf16 = spikes_bf16_ok(D)
     hk, hv, dk, dv = _Sum2LIF.apply(x, e, pos, B, D, vth, bf16)
     return (Spikes(dk, hk), Spikes(dv, hv)) if bf16 else (Spikes(hk), Spikes(hv))
 
@@ -839,7 +845,7 @@ def _sdsa_spikes(qd, kd, vd, qt, kt, vt, heads, scale, packed, lif):
     Nk = Nq if packed else kd.shape[2]
     pure = (lif is not None and isinstance(lif.v, float) and not lif.keep_membrane
             and not lif._forward_hooks and not lif._forward_pre_hooks)          # hooks want the module call
-    fuse = pure and Nq == Nk and Nq % 256 == 0 and (C * Nq) % 8 == 0
+    fuse = pure and Nq == Nk and Nq % 256 == 0 and (C * Nq) % 8 == 0 and spikes_bf16_ok(lif.D)
     if fuse and lif.stats is not None:
         lif.stats_elems += qd.shape[0] * C * Nq
     o, ydata = _SDSASpikes.apply(qd, kd, vd, qt, kt, vt, heads, scale, packed, fuse, lif.D if fuse else 8,
@@ -974,7 +980,7 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
            lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False):
     """-> (u or None, y or None, v_out or None [, border]); y is a Spikes pair (bf16 when SPIKES_BF16); border [C] = BN(0)
     from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel."""
-    bf16 = bool(lif) and SPIKES_BF16
+    bf16 = bool(lif) and spikes_bf16_ok(D)
     u, y, v, border, ydata = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
                                           momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16)
     if lif:
