@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 13
+#define S2F_ABI_VERSION 14
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -249,6 +249,11 @@ int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* str
  * (mmdet/models/layers/pixel_decoder.py:456-460).  w must be even (16-byte output stores). */
 int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream);
 int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream);
+
+/* ---- batched transposition of the last two dimensions: x [B, R, C] -> y [B, C, R] (fp32) -----------------------------------
+ * Replaces the `.permute(0, 1, 3, 4, 2)` / `.permute(0, 1, 4, 2, 3)` copies around the DCNv3 sampling core
+ * (ops_dcnv3/modules/dcnv3.py:198-233; mmdet/models/layers/detr_layers.py:331-337).  x != y; B < 65536. */
+int s2f_transpose_last2(const float* x, float* y, int64_t B, int R, int C, void* stream);
 
 /* ---- mask losses of the Hungarian-matched loss on the 2x up-sampled logits -------------------
  * For matched prediction p: u = bilinear2x(pred[p]) (F.interpolate align_corners=False, dense_heads/maskformer_head.py:475-479),

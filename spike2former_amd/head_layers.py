@@ -124,7 +124,7 @@ class DCNv3_pytorch(nn.Module):
 
         def sampled_input():
             x = self.input_proj.forward_nchw(inp)
-            return x.permute(0, 1, 3, 4, 2).contiguous().flatten(0, 1)              # [T*N, H, W, C]
+            return ops.transpose_last2(x.reshape(T * N, C, H * W)).view(T * N, H, W, C)   # NCHW -> [T*N, H, W, C]
 
         def offset_and_mask():
             x1 = self.dw_spike.fire(inp).flatten(0, 1)
@@ -142,7 +142,7 @@ class DCNv3_pytorch(nn.Module):
         k = self.kernel_size
         y = ops.dcnv3_core(x, offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
                            self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale)
-        y = y.view(T, N, H, W, C).permute(0, 1, 4, 2, 3).contiguous()
+        y = ops.transpose_last2(y.reshape(T * N, H * W, C)).view(T, N, C, H, W)
         return self.output_proj.forward_nchw(y, scale=scale, residual=residual, next_lif=next_lif)
 
     def forward(self, inp):
@@ -214,7 +214,7 @@ class DCNDetrTransformerEncoderLayer(nn.Module):
         q = self.Conv.forward_nchw(q, scale=self.gamma1, residual=q, next_lif=self.dcn.input_proj.spike1)
         q = self.dcn.forward_nchw(q, scale=self.gamma2, residual=q, next_lif=self.ffn.fc1_spike)
         m = self.ffn.forward_nchw(q)                                     # [T*B, C, H*W] in memory == [T,B,H,W,C] semantically
-        m = m.view(T, B, H * W, C).permute(0, 1, 3, 2).reshape(T, B, C, H, W)
+        m = ops.transpose_last2(m.view(T * B, H * W, C)).view(T, B, C, H, W)
         return torch.addcmul(q, m, self.gamma3.view(1, 1, C, 1, 1))
 
     def forward(self, query):

@@ -1477,6 +1477,38 @@ def mask_einsum_folded(e, spikes, W, bias, scale, T, B, e_exact=False):
     return _MaskEinsumFolded.apply(e, spikes.data, spikes.tok, W, bias, float(scale), int(T), int(B), bool(e_exact))
 
 
+# ------------------------------------------------------------------------------------------------ transposition
+class _TransposeLast2(torch.autograd.Function):
+    """x [B, R, C] -> [B, C, R], contiguous (the adjoint is the same kernel the other way round)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, R, C = x.shape
+        y = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+        check(lib.s2f_transpose_last2(_ptr(x), _ptr(y), B, R, C, _stream()), "s2f_transpose_last2")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B, C, R = gy.shape
+        gx = torch.empty(B, R, C, dtype=torch.float32, device=gy.device)
+        check(lib.s2f_transpose_last2(_ptr(gy), _ptr(gx), B, C, R, _stream()), "s2f_transpose_last2")
+        return gx
+
+
+def transpose_last2(x):
+    """x [..., R, C] (fp32, CUDA) -> contiguous [..., C, R]: the `.permute(...).contiguous()` copies around the DCNv3 sampling
+    core as one tiled kernel (s2f_transpose_last2)."""
+    lead = x.shape[:-2]
+    R, C = x.shape[-2:]
+    if x.dtype != torch.float32 or x.numel() == 0:
+        return x.transpose(-1, -2).contiguous()
+    return _TransposeLast2.apply(x.reshape(-1, R, C)).view(*lead, C, R)
+
+
 # ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
 class _Up2x(torch.autograd.Function):
     @staticmethod

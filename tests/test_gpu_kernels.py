@@ -764,3 +764,39 @@ def test_grouped_weight_gradients_are_the_single_launches(ops):
             scale = ref.abs().max().item()
             assert (got.double() - ref).abs().max().item() <= 2e-6 * scale * 4
             assert (got - want).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 256, 1024), (3, 100, 256), (2, 70, 36), (1, 5, 3), (2, 64, 130)])
+def test_transpose_last2_is_the_permuted_copy(shape):
+    """s2f_transpose_last2 == x.transpose(-1, -2).contiguous(), forward and adjoint, incl. ragged / unaligned tiles."""
+    from spike2former_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    y = ops.transpose_last2(x)
+    assert y.is_contiguous() and torch.equal(y, x.detach().transpose(-1, -2).contiguous())
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad, g.transpose(-1, -2).contiguous())
+    x4 = torch.randn(2, 3, *shape[1:], device="cuda")
+    assert torch.equal(ops.transpose_last2(x4), x4.transpose(-1, -2).contiguous())
+
+
+@pytest.mark.gpu
+def test_bf16_spike_storage_needs_a_power_of_two_D():
+    """k / D is exact in bf16 only for a power-of-two D: other D keep fp32 spikes, and the C entry point refuses."""
+    from spike2former_amd import ops
+    from spike2former_amd._lib import S2FError, lib
+    x = torch.randn(4, 64, 256, device="cuda") * 3
+    y6, _ = ops.lif(x, D=6, keep_v=False, spikes=True)
+    assert y6.tok is None and y6.data.dtype == torch.float32
+    # the CPU quotient: ATen's CUDA `tensor / scalar` multiplies by the rounded reciprocal, the reference's CPU path divides
+    assert torch.equal(y6.data.cpu(), torch.round(torch.clamp(x.cpu(), 0, 6)) / 6)
+    y8, _ = ops.lif(x, D=8, keep_v=False, spikes=True)
+    assert y8.data.dtype == torch.bfloat16 and torch.equal(y8.data.float(), torch.round(torch.clamp(x, 0, 8)) / 8)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    rc = lib.s2f_lif_fwd(x.data_ptr(), None, out.data_ptr(), None, None, None, None, x.numel(), 1.0, 6, 1,
+                         torch.cuda.current_stream().cuda_stream)
+    assert rc != 0
+    with pytest.raises(S2FError):
+        ops.check(rc, "s2f_lif_fwd")
