@@ -280,18 +280,24 @@ class MultiHeadAttentionBlock(nn.Module):
         return k, v
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None,
-                kv_projected=None):
+                kv_projected=None, query_channel_major=False):
         """query [t,b,nq,dim]; key/value [t,b,nk,dim] as in the reference, or -- `kv_channel_major` -- [t,b,dim,nk], the
         layout the pixel decoder produces them in (saves two 33 M-element transposes per projection at the 128x128 level;
         the neuron is elementwise, so the values are the same).  `kv_spikes` = (k_conv_spike(key), v_conv_spike(value))
-        already formed by the caller (channel-major; the head's fused add + neuron kernel) -- key / value are then unused."""
+        already formed by the caller (channel-major; the head's fused add + neuron kernel) -- key / value are then unused.
+        `query_channel_major`: query is [t,b,dim,nq] and so is the result (the decoder's channel-major query stream: the
+        projections and the attention core work on channel-major maps anyway, so nothing is transposed)."""
         if attn_mask is not None:
             raise NotImplementedError("attn_mask is always None on the MaskFormerHead path (maskformer_head.py:554-564)")
-        t, b, nq, dim = query.shape
+        if query_channel_major:
+            t, b, dim, nq = query.shape
+        else:
+            t, b, nq, dim = query.shape
+        qcm = query_channel_major
 
         if kv_projected is not None:
             # keys / values do not depend on the query: the head projected them for every layer ahead of the query chain
-            q = self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query)
+            q = self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm)
             k, v, handle = kv_projected
             ops.join(handle, (k, v))
         else:
@@ -300,10 +306,12 @@ class MultiHeadAttentionBlock(nn.Module):
             k, v, q = ops.branches([   # independent chains (the long ones first: keys / values are the 1 024 - 16 384-token maps)
                 lambda: self._proj(self.k_conv_spike, self.k_conv, self.k_spike, key, cm, fk),
                 lambda: self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, fv),
-                lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query)],
+                lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm)],
                 inputs=(query, key, value, fk, fv))
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)      # embed_dim**0.5, not head dim
         o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
+        if qcm:
+            return o.view(t, b, dim, nq), None
         return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
 
 
@@ -325,10 +333,11 @@ class MultiheadAttention(nn.Module):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
                 key_padding_mask=None, kv_channel_major=False, kv_spikes=None, kv_projected=None, **kwargs):
+        qcm = bool(kwargs.get("query_channel_major", False))
         if kv_spikes is not None or kv_projected is not None:
             return self.attn(query=query if query_pos is None else query + query_pos, key=None, value=None,
                              attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes,
-                             kv_projected=kv_projected)[0]
+                             kv_projected=kv_projected, query_channel_major=qcm)[0]
         if key is None:
             key = query
         if value is None:
@@ -340,7 +349,7 @@ class MultiheadAttention(nn.Module):
         if key_pos is not None:
             key = key + key_pos
         return self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask,
-                         kv_channel_major=kv_channel_major)[0]
+                         kv_channel_major=kv_channel_major, query_channel_major=qcm)[0]
 
 
 class MSDA_FFN(nn.Module):
@@ -397,6 +406,21 @@ class DetrTransformerDecoderLayer(nn.Module):
         query = query + self.self_attn(query=query, key=query, value=query, query_pos=query_pos, key_pos=query_pos,
                                        attn_mask=self_attn_mask)
         return query + self.ffn(query)
+
+    def forward_stream(self, q_cm, query_pos_cm, key=None, value=None, kv_spikes=None, kv_projected=None, last=False):
+        """The layer on the channel-major query stream q_cm [t,b,dim,nq] (query_pos_cm [b,dim,nq]; keys / values
+        channel-major as with `kv_channel_major`) -> (query token-major [t,b,nq,dim], query channel-major or None when
+        `last`).  Value-identical to `forward`: the reference keeps the queries token-major and transposes around each of
+        the seven projections of a layer (12 copies per layer and step, forward + backward); the projections and the
+        attention core are channel-major, so only the FFN's bug-compatible reinterpretation of the token-major buffer
+        (transformer.py:777,:781) needs the other layout -- one transposition in, one out."""
+        q_cm = q_cm + self.cross_attn(query=q_cm, key=key, value=value, query_pos=query_pos_cm, kv_channel_major=True,
+                                      kv_spikes=kv_spikes, kv_projected=kv_projected, query_channel_major=True)
+        qp = q_cm + query_pos_cm                       # query + query_pos == key + key_pos: formed once
+        q_cm = q_cm + self.self_attn.attn(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True)[0]
+        q_tm = ops.transpose_last2(q_cm)
+        out = q_tm + self.ffn(q_tm)
+        return out, (None if last else ops.transpose_last2(out))
 
 
 class DetrTransformerDecoder(nn.Module):

@@ -22,6 +22,7 @@ from .registry import MODELS, ConfigDict
 FUSED_KV_NEURONS = True
 # the pixel decoder's mask_feature 1x1 convolution folded into the mask contraction (ops.mask_einsum_folded)
 FOLD_MASK_FEATURE = True
+QUERY_STREAM_CHANNEL_MAJOR = True     # decoder queries channel-major between the layers (no transposes around the projections)
 
 
 def _lif():
@@ -138,13 +139,24 @@ class MaskFormerHead(nn.Module):
                     inputs=(dec_key[lv], dec_in[lv], kv_spikes[lv]), what="kv")
                 kv_proj[i] = (k, v, handle)
         out_dec = [query_feat]
-        for i in range(self.num_transformer_decoder_layers):
-            lv = i % nl
-            query_feat = layers[i](
-                query=query_feat, key=dec_key[lv], value=dec_in[lv], query_pos=query_embed, key_pos=None,
-                cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv],
-                kv_projected=kv_proj[i])
-            out_dec.append(query_feat)
+        if QUERY_STREAM_CHANNEL_MAJOR and query_feat.is_cuda:
+            # the queries travel channel-major between the layers (head_layers.DetrTransformerDecoderLayer.forward_stream)
+            q_cm = query_feat.transpose(2, 3).contiguous()
+            pos_cm = query_embed.transpose(1, 2).contiguous()
+            n = self.num_transformer_decoder_layers
+            for i in range(n):
+                lv = i % nl
+                q_tm, q_cm = layers[i].forward_stream(q_cm, pos_cm, key=dec_key[lv], value=dec_in[lv], kv_spikes=kv_spikes[lv],
+                                                      kv_projected=kv_proj[i], last=i == n - 1)
+                out_dec.append(q_tm)
+        else:
+            for i in range(self.num_transformer_decoder_layers):
+                lv = i % nl
+                query_feat = layers[i](
+                    query=query_feat, key=dec_key[lv], value=dec_in[lv], query_pos=query_embed, key_pos=None,
+                    cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv],
+                    kv_projected=kv_proj[i])
+                out_dec.append(query_feat)
         out_dec = torch.stack(out_dec)
         ln, t, bs, nq, C = out_dec.shape
         # ---- SDME block (maskformer_head.py:568-582)

@@ -405,3 +405,50 @@ def test_folded_mask_feature_convolution_does_not_change_the_step(env):
     assert set(a[2]) == set(b[2]) and grad_gap(a[2], b[2]) <= 1e-3
     k = "decode_head.pixel_decoder.mask_feature.weight"
     assert rel(a[2][k], b[2][k]) <= 1e-4 and rel(a[2]["decode_head.pixel_decoder.mask_feature.bias"], b[2]["decode_head.pixel_decoder.mask_feature.bias"]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_decoder_layer_on_the_channel_major_query_stream_is_the_token_major_layer():
+    """DetrTransformerDecoderLayer.forward_stream (queries channel-major between the projections) == forward: outputs,
+    input gradients and parameter gradients, up to the order of the kernels' atomic sums."""
+    from spike2former_amd.head_layers import DetrTransformerDecoderLayer
+    from spike2former_amd.neuron import reset_net
+    torch.manual_seed(3)
+    cfg = dict(embed_dims=64, num_heads=8, batch_first=True)
+    layer = DetrTransformerDecoderLayer(self_attn_cfg=dict(cfg), cross_attn_cfg=dict(cfg),
+                                        ffn_cfg=dict(embed_dims=64, feedforward_channels=128, num_fcs=2)).cuda().train()
+    for p in layer.parameters():
+        if p.dim() == 1:
+            torch.nn.init.uniform_(p, 0.5, 1.5)
+    t, b, nq, dim, nk = 2, 2, 100, 64, 256
+    q = (torch.randn(t, b, nq, dim, device="cuda") * 2).requires_grad_()
+    pos = torch.randn(b, nq, dim, device="cuda")
+    key = (torch.randn(t, b, dim, nk, device="cuda") * 2).requires_grad_()
+    value = (torch.randn(t, b, dim, nk, device="cuda") * 2).requires_grad_()
+    w = torch.randn(t, b, nq, dim, device="cuda")
+
+    def run(stream):
+        reset_net(layer)
+        layer.zero_grad(set_to_none=True)
+        for x in (q, key, value):
+            x.grad = None
+        if stream:
+            out, out_cm = layer.forward_stream(q.transpose(2, 3).contiguous(), pos.transpose(1, 2).contiguous(), key=key, value=value)
+            assert torch.equal(out_cm, out.transpose(2, 3))
+        else:
+            out = layer(query=q, key=key, value=value, query_pos=pos, kv_channel_major=True)
+        (out * w).sum().backward()
+        return out.detach().clone(), [x.grad.clone() for x in (q, key, value)], {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}
+
+    o1, gi1, gp1 = run(False)
+    o2, gi2, gp2 = run(True)
+    # the attention core sums its k^T v partial tiles with fp32 atomics: two runs of the SAME layer can differ in the last bit
+    # of a product and, rarely, flip a spike at a rounding boundary -- so "equal" is asked of all but a sliver of the elements
+    def same(a, c, tol):
+        return ((a - c).abs() > tol * (1 + c.abs())).float().mean().item() < 5e-3
+    assert same(o1, o2, 1e-6)
+    for a, c in zip(gi1, gi2):
+        assert same(a, c, 1e-5)
+    assert gp1.keys() == gp2.keys()
+    for n in gp1:
+        assert same(gp1[n], gp2[n], 1e-4), n

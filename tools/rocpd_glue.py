@@ -8,7 +8,10 @@ gx = "grid_size_x" if "grid_size_x" in cols else ("grid_x" if "grid_x" in cols e
 q = f"select name, start, end{', ' + gx if gx else ''} from kernels order by start"
 rows = c.execute(q).fetchall()
 marks = [i for i, r in enumerate(rows) if 'dcn_bwd' in r[0]]
-sel = rows[marks[-6 * replays]:]
+# whole steps between consecutive "first dcn_bwd of a step" marks, as rocpd_categories.py: replays - 1 steps
+starts = [marks[-6 * k] for k in range(replays, 0, -1)]
+sel = rows[starts[0]:starts[-1]]
+replays -= 1
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in sel:
     n = r[0]
