@@ -67,7 +67,7 @@ __device__ __forceinline__ float opnd_ld1(const Operand<T>& o, const T* row, int
   return v;
 }
 
-// grid (TB*heads, nsplit); block 256.  LDS: two [d][kNT+1] tiles.
+// grid (nsplit, TB*heads) -- column chunk fastest, see apply_kernel; block 256.  LDS: two [d][kNT+1] tiles.
 template <typename TA, typename TB>
 __global__ __launch_bounds__(256) void outer_kernel(Operand<TA> OA, Operand<TB> OB, float* __restrict__ M, int heads, int d,
                                                     int N, float alpha) {
@@ -75,15 +75,15 @@ __global__ __launch_bounds__(256) void outer_kernel(Operand<TA> OA, Operand<TB> 
   // form issued four ds_read_b32 per four multiply-adds and was LDS-bound: 22 us for two 8 MB operands)
   __shared__ __attribute__((aligned(16))) float sa[kDMax][kNT + 4];
   __shared__ __attribute__((aligned(16))) float sb[kDMax][kNT + 4];
-  const int bh = blockIdx.x;
+  const int bh = blockIdx.y;
   const int tb = bh / heads, h = bh % heads;
   const int C = heads * d;
   const TA* a = OA.base + (int64_t)tb * OA.batch_stride + (int64_t)h * d * N;
   const TB* b = OB.base + (int64_t)tb * OB.batch_stride + (int64_t)h * d * N;
   const int64_t e0 = ((int64_t)tb * C + h * d) * N;          // element index of the head's first row in a contiguous [TB, C, N]
-  const int nsplit = gridDim.y;
+  const int nsplit = gridDim.x;
   const int chunk = ((N + nsplit - 1) / nsplit + kNT - 1) / kNT * kNT;
-  const int n_begin = blockIdx.y * chunk;
+  const int n_begin = blockIdx.x * chunk;
   const int n_end = min(N, n_begin + chunk);
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & (4 * sizeof(TA) - 1)) == 0 &&
                    (reinterpret_cast<uintptr_t>(b) & (4 * sizeof(TB) - 1)) == 0 && ((OA.batch_stride | OB.batch_stride) & 3) == 0;
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void outer_kernel(Operand<TA> OA, Operand<TB> 
   }
 }
 
-// grid (TB*heads, ceil(N/256)); block 256 = 4 waves.  Lane l of every wave owns columns n0+4l .. n0+4l+3 (one 16-byte
+// grid (ceil(N/256), TB*heads) -- the column chunk is the FAST grid index: workgroups that run side by side then write
+// neighbouring 1 KB pieces of the same rows.  With (tb, head) fastest they all wrote the same column chunk of rows 64 KB - 2 MB
+// apart, i.e. one HBM channel at a time (1.8 TB/s on the 16 384-token maps).  Block 256 = 4 waves.  Lane l of every wave owns columns n0+4l .. n0+4l+3 (one 16-byte
 // load per row of X); wave w owns output rows j in [w*JC, (w+1)*JC).  M is staged in LDS zero-padded to 4*JC columns,
 // and read as broadcast 16-byte rows: one ds_read_b128 feeds 16 FMAs.
 template <bool TRANS, int JC, typename TX>
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
                                                     int64_t y_batch_stride, int heads, int d, int N, float alpha) {
   constexpr int LD = 4 * JC;
   __shared__ __attribute__((aligned(16))) float sm[kDMax * LD];
-  const int bh = blockIdx.x;
+  const int bh = blockIdx.y;
   const int tb = bh / heads, h = bh % heads;
   const int C = heads * d;
   const float* m = M + (int64_t)bh * d * d;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.y * 256 + lane * 4;
+  const int n = blockIdx.x * 256 + lane * 4;
   if (n >= N) return;
   const TX* x = OX.base + (int64_t)tb * OX.batch_stride + (int64_t)h * d * N;
   const int64_t e0 = ((int64_t)tb * C + h * d) * N;
@@ -182,25 +184,57 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
   float acc[JC][4];
 #pragma unroll
   for (int j = 0; j < JC; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
-  // rows of X in groups of 8 with all loads of a group issued before the first use: one dependent L2 round trip per row
-  // made the loop latency-bound (17.9 us for a 16.8 MB launch)
-  constexpr int G = 8;
+  // rows of X in groups with all loads of a group issued before the first use: one dependent L2 round trip per row made the
+  // loop latency-bound (17.9 us for a 16.8 MB launch).  bf16 rows are held raw (2 registers per row and lane), so a whole
+  // head of d <= 32 rows is ONE group; fp32 rows (4 registers) go 8 at a time.
+  constexpr bool kRaw16 = sizeof(TX) == 2;
+  constexpr int G = kRaw16 ? 32 : 8;
+  const bool masked = OX.mask != nullptr;
   for (int i0 = 0; i0 < d; i0 += G) {
-    float xv[G][4];
+    float xv[kRaw16 ? 1 : G][4];
+    uint2 xr[kRaw16 ? G : 1];
+    const bool raw = kRaw16 && vec && !masked;
+    if (raw) {
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const int i = min(i0 + u, d - 1);                  // clamped duplicate rows are skipped below
-      if (vec) {
-        const float4 t = opnd_ld4(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n);
-        xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
-      } else {
+      for (int u = 0; u < G; ++u) {
+        const int i = min(i0 + u, d - 1);
+        xr[kRaw16 ? u : 0] = *reinterpret_cast<const uint2*>(x + (int64_t)i * N + n);
+      }
+    } else if (!kRaw16) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[u][c] = (n + c < N) ? opnd_ld1(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n + c) : 0.f;
+      for (int u = 0; u < G; ++u) {
+        const int i = min(i0 + u, d - 1);                  // clamped duplicate rows are skipped below
+        if (vec) {
+          const float4 t = opnd_ld4(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n);
+          xv[kRaw16 ? 0 : u][0] = t.x; xv[kRaw16 ? 0 : u][1] = t.y; xv[kRaw16 ? 0 : u][2] = t.z; xv[kRaw16 ? 0 : u][3] = t.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            xv[kRaw16 ? 0 : u][c] = (n + c < N) ? opnd_ld1(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n + c) : 0.f;
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       if (i0 + u < d) {
+        float xc[4];
+        if (raw) {
+          const uint2 r = xr[kRaw16 ? u : 0];
+          xc[0] = __uint_as_float(r.x << 16); xc[1] = __uint_as_float(r.x & 0xffff0000u);
+          xc[2] = __uint_as_float(r.y << 16); xc[3] = __uint_as_float(r.y & 0xffff0000u);
+        } else if (kRaw16) {                               // ragged / masked bf16 rows: loaded at use
+          const int i = i0 + u;
+          if (vec) {
+            const float4 t = opnd_ld4(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n);
+            xc[0] = t.x; xc[1] = t.y; xc[2] = t.z; xc[3] = t.w;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xc[c] = (n + c < N) ? opnd_ld1(OX, x + (int64_t)i * N, e0 + (int64_t)i * N, n + c) : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xc[c] = xv[kRaw16 ? 0 : u][c];
+        }
         const float* row = sm + (i0 + u) * LD + wave * JC;
 #pragma unroll
         for (int j4 = 0; j4 < JC; j4 += 4) {
@@ -209,7 +243,7 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[j4 + jj][c] += xv[u][c] * mm[jj];
+            for (int c = 0; c < 4; ++c) acc[j4 + jj][c] += xc[c] * mm[jj];
         }
       }
     }
@@ -232,7 +266,7 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
 template <bool TRANS, typename TX>
 void launch_apply(Operand<TX> x, const float* m, float* y, int64_t y_batch_stride, int TB, int heads, int d, int N, float alpha,
                   hipStream_t s) {
-  dim3 grid(TB * heads, (N + 255) / 256);
+  dim3 grid((N + 255) / 256, TB * heads);
   const int jc = ((d + 3) / 4 + 3) / 4 * 4;     // rows per wave, rounded up to a multiple of 4
   if (jc <= 4)
     hipLaunchKernelGGL((apply_kernel<TRANS, 4, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
@@ -265,7 +299,7 @@ int launch_outer(Operand<TA> a, Operand<TB> b, float* kv, int TB_, int heads, in
   const int ns = pick_split(TB_ * heads, N);
   if (ns > 1 && s2f_zero_async(kv, sizeof(float) * (size_t)TB_ * heads * d * d, s) != S2F_OK)
     return s2f_check_launch("s2f_sdsa_kv clear");
-  hipLaunchKernelGGL((outer_kernel<TA, TB>), dim3(TB_ * heads, ns), dim3(256), 0, s, a, b, kv, heads, d, N, alpha);
+  hipLaunchKernelGGL((outer_kernel<TA, TB>), dim3(ns, TB_ * heads), dim3(256), 0, s, a, b, kv, heads, d, N, alpha);
   return s2f_check_launch("s2f_sdsa_kv");
 }
 
