@@ -61,6 +61,22 @@ __device__ __forceinline__ void s2f_lif_update(float h, float Df, float inv_d, f
   in_range = (h >= 0.0f) && (h <= Df);
 }
 
+// Sum over the 64 lanes of a wave on the VALU's DPP path (no LDS traffic): inclusive prefix sums inside each row of 16
+// lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3
+// (row_bcast:31).  The TOTAL IS IN LANE 63 ONLY.  `__shfl_xor` lowers to ds_bpermute_b32, ~7 LDS-pipeline cycles per wave
+// and step: the 25 x 6 of them in the 5x5 depthwise weight gradient were 27 of that kernel's 35 us.
+#define S2F_DPP_ADD(v, ctrl, rows) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false))
+__device__ __forceinline__ float s2f_wave_sum_lane63(float v) {
+  S2F_DPP_ADD(v, 0x111, 0xf);
+  S2F_DPP_ADD(v, 0x112, 0xf);
+  S2F_DPP_ADD(v, 0x114, 0xf);
+  S2F_DPP_ADD(v, 0x118, 0xf);
+  S2F_DPP_ADD(v, 0x142, 0xa);
+  S2F_DPP_ADD(v, 0x143, 0xc);
+  return v;
+}
+
 // bf16 spike storage is exact only for k / D with D a power of two <= 128 (k <= D: at most 8 significant bits).
 static inline bool s2f_bf16_spikes_exact(int D) { return D >= 1 && D <= 128 && (D & (D - 1)) == 0; }
 

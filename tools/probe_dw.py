@@ -31,11 +31,11 @@ for (N, C, H, W, K) in [(8, 64, 256, 256, 7), (8, 128, 128, 128, 7), (8, 256, 64
 # ---- weight gradient alone, back-to-back launches through the C ABI (kernel + its memset)
 from spike2former_amd._lib import lib
 print("weight gradient (s2f_dwconv_bwd_weight), us per call:")
-for (N, C, H, W, K) in [(8, 256, 32, 32, 3), (8, 512, 32, 32, 3), (8, 256, 32, 32, 5), (8, 720, 32, 32, 3), (8, 256, 64, 64, 3),
+for (N, C, H, W, K) in [(8, 256, 32, 32, 3), (8, 512, 32, 32, 3), (8, 256, 32, 32, 5), (8, 512, 32, 32, 5), (8, 720, 32, 32, 3), (8, 256, 64, 64, 3),
                         (8, 256, 128, 128, 3), (8, 256, 256, 256, 3), (8, 64, 256, 256, 7), (8, 256, 64, 64, 7)]:
     x = torch.randn(N, C, H, W, device="cuda"); gy = torch.randn(N, C, H, W, device="cuda")
     gw = torch.zeros(C, 1, K, K, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for acc in (0, 1):
-        us = t(lambda: lib.s2f_dwconv_bwd_weight(x.data_ptr(), None, gy.data_ptr(), gw.data_ptr(), N, C, H, W, K, K // 2, acc, st), n=50)
+        us = t(lambda: lib.s2f_dwconv_bwd_weight(x.data_ptr(), None, gy.data_ptr(), gw.data_ptr(), N, C, H, W, K, K // 2, acc, 0, st), n=50)
         print(f"  N{N} C{C} {H}x{W} K{K} accumulate={acc}: {us:7.1f} us  ({x.numel() * 8 / us * 1e-3:6.0f} GB/s)")
