@@ -395,34 +395,52 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Row-walking forms of the three streaming kernels, for L % 256 == 0 (every 256-element tile lies in ONE channel row) and a
-// power-of-two D.  The generic kernels above spend ~300 VALU instructions per tile on per-lane index arithmetic (two
-// integer divisions for the channel, a float division per spike, 64-bit address checks) and ran at 3.1-3.9 TB/s moved
-// where a pure read reaches 5.8-6.5 TB/s (tools/probe_bn_stream.py): they were VALU-bound, not HBM-bound.  Here a wave owns
-// a CONTIGUOUS run of tiles; tile index, row, column-tile and channel are wave-uniform (readfirstlane on the wave id) and
-// live in SGPRs: the channel advances by a compare instead of a division, the per-channel parameters and the four in-range
-// mask words arrive through scalar loads, and a mask word is applied as a lane mask (inverse ballot -> v_cndmask) instead
-// of 64-bit shifts.  Same per-element expressions as the generic kernels, so the results are bit-identical.
+// Row-walking forms of the three streaming kernels, for L % 4 == 0, L >= 256 and a power-of-two D (the ALIGNED variants: L %
+// 256 == 0, every 256-element tile lies in ONE channel row; the others let a tile end one row and start the next).  The
+// generic kernels above spend ~300 VALU instructions per tile on per-lane index arithmetic (two integer divisions for the
+// channel, a float division per spike, 64-bit address checks) and ran at 3.1-3.9 TB/s moved where a pure read reaches
+// 5.8-6.5 TB/s (tools/probe_bn_stream.py): they were VALU-bound, not HBM-bound.  Here a wave owns a CONTIGUOUS run of tiles;
+// tile index, row, position in the row and channel are wave-uniform (readfirstlane on the wave id) and live in SGPRs: the
+// channel advances by a compare instead of a division, the per-channel parameters and the four in-range mask words arrive
+// through scalar loads, and a mask word is applied as a lane mask (inverse ballot -> v_cndmask) instead of 64-bit shifts.
+// Same per-element expressions as the generic kernels, so the results are bit-identical.
 __device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 constexpr int kAhead = 2;                        // tiles of a wave in flight besides the one being worked on
 
-template <bool LIF, bool HAS_V, bool YB>
+// The wave-uniform walk over flat 256-element tiles of [N, C, L]: `row` = n * C + c of the tile's first element, `off` its
+// position inside that row.  ALIGNED (L % 256 == 0, whole tiles): a tile lies in one row.  Otherwise (L % 4 == 0, L >= 256)
+// the first `bnd` < 256 elements of a tile may end a row and the rest start the next one: the per-channel parameters of
+// both channels are loaded (scalar) and each lane selects by its position -- at most one row boundary per tile.
+struct RowWalk {
+  uint32_t row, off, c;
+};
+__device__ __forceinline__ RowWalk walk_begin(uint32_t tile, uint32_t L, uint32_t C) {
+  const uint64_t base = (uint64_t)tile * 256u;
+  RowWalk w;
+  w.row = (uint32_t)(base / L);
+  w.off = (uint32_t)(base - (uint64_t)w.row * L);
+  w.c = w.row % C;
+  return w;
+}
+
+template <bool LIF, bool HAS_V, bool YB, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const double* __restrict__ sums, float* __restrict__ stat,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ num_batches,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out,
     const float* __restrict__ v_in, float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask,
-    unsigned long long* __restrict__ stats, uint32_t ntiles, int C, uint32_t tpr, uint32_t chunk, double inv_count,
-    float unbias, float momentum, float eps, int training, float vth, float Df) {
+    unsigned long long* __restrict__ stats, int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk,
+    double inv_count, float unbias, float momentum, float eps, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
   uint32_t t = wave * chunk;
   const uint32_t t_end = min(ntiles, t + chunk);
+  const uint32_t tail = (uint32_t)(total - (int64_t)(ntiles - 1) * 256);      // valid elements of the last tile (1..256)
   extern __shared__ __attribute__((aligned(16))) float sstat[];      // [3][C]: mean, rstd, var
   Tile4 zn[kAhead], rn[kAhead], vn[kAhead];
   auto request = [&](int slot, uint32_t tile) __attribute__((always_inline)) {
-    if (tile < t_end) {
+    if (tile < t_end && (ALIGNED || tile + 1 < ntiles || (uint32_t)lane * 4 < tail)) {
       const int64_t base = (int64_t)tile * 256 + lane * 4;
       zn[slot] = ld4(z + base);
       if (res) rn[slot] = ld4(res + base);
@@ -438,70 +456,89 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     sstat[2 * C + c] = cs.var;
   }
   __syncthreads();
-  uint32_t row = t / tpr, q = t - row * tpr;
-  uint32_t c = row % (uint32_t)C;
-  float b, mean, rstd, g, be;
-  auto params = [&]() __attribute__((always_inline)) {
-    b = bias ? bias[c] : 0.f;
-    mean = sstat[c];
-    rstd = sstat[C + c];
-    g = gamma[c];
-    be = beta[c];
+  RowWalk w = walk_begin(t, L, (uint32_t)C);
+  struct Par {
+    float b, mean, rstd, g, be;
+  } p0, p1;
+  auto params = [&](uint32_t c) __attribute__((always_inline)) {
+    Par p;
+    p.b = bias ? bias[c] : 0.f;
+    p.mean = sstat[c];
+    p.rstd = sstat[C + c];
+    p.g = gamma[c];
+    p.be = beta[c];
+    return p;
   };
-  if (t < t_end) params();
+  if (t < t_end) p0 = params(w.c);
+  p1 = p0;
   const float inv_d = 1.0f / Df;                          // exact: D is a power of two on this path
   const bool count = LIF && stats != nullptr;
   uint32_t csum = 0, cnz = 0;
+  // first element of channel c in batch row 0: publish the statistics for the backward pass and update the running
+  // statistics (torch.nn.BatchNorm: momentum, unbiased variance); executed by the one lane that owns that element
+  auto publish = [&](uint32_t c, const Par& p) __attribute__((always_inline)) {
+    stat[c] = p.mean;
+    stat[C + c] = p.rstd;
+    float rm = running_mean ? running_mean[c] : 0.f, rvv = running_var ? running_var[c] : 1.f;
+    if (training && running_mean != nullptr) {
+      rm = (1.f - momentum) * rm + momentum * p.mean;
+      rvv = (1.f - momentum) * rvv + momentum * (sstat[2 * C + c] * unbias);
+      running_mean[c] = rm;
+      running_var[c] = rvv;
+    }
+    stat[2 * C + c] = p.be - rm * p.g / sqrtf(rvv + eps);
+    if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
+  };
   // one tile: BN (+ residual) (+ neuron), stores, mask words; then the (row, channel) walk
   auto work = [&](uint32_t tile, const Tile4& zv, const Tile4& rv, const Tile4& vv) __attribute__((always_inline)) {
     const int64_t base = (int64_t)tile * 256 + lane * 4;
-    if (q == 0 && row < (uint32_t)C && lane == 0) {
-      // first tile of channel c in batch row 0: publish the statistics for the backward pass and update the running
-      // statistics (torch.nn.BatchNorm: momentum, unbiased variance)
-      stat[c] = mean;
-      stat[C + c] = rstd;
-      float rm = running_mean ? running_mean[c] : 0.f, rvv = running_var ? running_var[c] : 1.f;
-      if (training && running_mean != nullptr) {
-        rm = (1.f - momentum) * rm + momentum * mean;
-        rvv = (1.f - momentum) * rvv + momentum * (sstat[2 * C + c] * unbias);
-        running_mean[c] = rm;
-        running_var[c] = rvv;
-      }
-      stat[2 * C + c] = be - rm * g / sqrtf(rvv + eps);
-      if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
-    }
-    bool inr[4];
-    Tile4 uo, yo, vo;
+    const uint32_t bnd = L - w.off;                       // elements of this tile that still belong to `row`
+    const bool split = !ALIGNED && bnd < 256u;
+    const uint32_t c2 = w.c + 1 == (uint32_t)C ? 0u : w.c + 1;
+    if (split) p1 = params(c2);
+    if (w.off == 0 && w.row < (uint32_t)C && lane == 0) publish(w.c, p0);
+    if (split && w.row + 1 < (uint32_t)C && (uint32_t)lane == (bnd >> 2)) publish(c2, p1);
+    const bool first = !split || (uint32_t)lane * 4 < bnd;
+    const bool ok = ALIGNED || tile + 1 < ntiles || (uint32_t)lane * 4 < tail;
+    const float b = first ? p0.b : p1.b, mean = first ? p0.mean : p1.mean, rstd = first ? p0.rstd : p1.rstd,
+                g = first ? p0.g : p1.g, be = first ? p0.be : p1.be;
+    bool inr[4] = {false, false, false, false};
+    if (ok) {
+      Tile4 uo, yo, vo;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float u = ((zv.a[j] + b) - mean) * rstd * g + be;
-      if (res) u += rv.a[j];
-      uo.a[j] = u;
-      if (LIF) {
-        const float h = HAS_V ? (vv.a[j] + u) : u;
-        float sp;
-        s2f_lif_update(h, Df, inv_d, vth, sp, yo.a[j], vo.a[j], inr[j]);
-        if (count) {
-          csum += (uint32_t)sp;
-          cnz += ((uint32_t)sp != 0);
+      for (int j = 0; j < 4; ++j) {
+        float u = ((zv.a[j] + b) - mean) * rstd * g + be;
+        if (res) u += rv.a[j];
+        uo.a[j] = u;
+        if (LIF) {
+          const float h = HAS_V ? (vv.a[j] + u) : u;
+          float sp;
+          s2f_lif_update(h, Df, inv_d, vth, sp, yo.a[j], vo.a[j], inr[j]);
+          if (count) {
+            csum += (uint32_t)sp;
+            cnz += ((uint32_t)sp != 0);
+          }
         }
       }
+      if (u_out) st4(u_out + base, uo);
+      if (LIF) {
+        if (YB)
+          st4_bf16(y, base, yo);
+        else
+          st4(y + base, yo);
+        if (v_out) st4(v_out + base, vo);
+      }
     }
-    if (u_out) st4(u_out + base, uo);
     if (LIF) {
-      if (YB)
-        st4_bf16(y, base, yo);
-      else
-        st4(y + base, yo);
-      if (v_out) st4(v_out + base, vo);
       const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
       if (mask != nullptr && lane < 4) mask[(int64_t)tile * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
     }
-    if (++q == tpr) {
-      q = 0;
-      ++row;
-      if (++c == (uint32_t)C) c = 0;
-      params();
+    w.off += 256u;
+    if (w.off >= L) {
+      w.off -= L;
+      ++w.row;
+      w.c = c2;
+      p0 = split ? p1 : params(c2);
     }
   };
   for (; t < t_end; t += kAhead) {
@@ -532,9 +569,9 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned long long a = 0, bq = 0;
-      for (int w = 0; w < kWaves; ++w) {
-        a += red[2 * w];
-        bq += red[2 * w + 1];
+      for (int wv = 0; wv < kWaves; ++wv) {
+        a += red[2 * wv];
+        bq += red[2 * wv + 1];
       }
       unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
       if (a) atomicAdd(&slot[0], a);
@@ -556,49 +593,60 @@ __device__ __forceinline__ float form_gu_rows(float gu, float gy, float gv, bool
   return r;
 }
 
-// grid (C, S): block (c, s) reduces rows n*C + c, tiles [s*tps, (s+1)*tps) of each row; wave w takes tiles w, w+4, ... of a
-// row, kRowUnroll of them with every load issued before the first use.
+// grid (C, S): block (c, s) reduces columns [s*slice, (s+1)*slice) of the rows n*C + c.  The columns of a row are walked as
+// the FLAT 256-element tiles that overlap them (the in-range masks are stored per flat tile: a uniform tile index keeps the
+// four mask words scalar loads); lanes outside [row start + l0, row start + l1) contribute nothing.  Wave w takes tiles
+// w, w+4, ... of a row, kRowUnroll of them with every load issued before the first use.
 constexpr int kRowUnroll = 4;
 template <bool GU, bool GY, bool GV>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
     const float* __restrict__ g_u, const float* __restrict__ g_y, const float* __restrict__ g_v,
-    const uint64_t* __restrict__ mask, double* __restrict__ sums, int N, int C, int tpr, int tps, float vth, float Df) {
+    const uint64_t* __restrict__ mask, double* __restrict__ sums, int N, int C, int L, int slice, float vth, float Df) {
   const int c = blockIdx.x, lane = threadIdx.x & 63, wv = wave_id_uniform();
-  const int q_lo = blockIdx.y * tps, q_hi = min(tpr, q_lo + tps);
+  const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
   const float b = bias ? bias[c] : 0.0f, mean = stat[c], rstd = stat[C + c];
   const float inv_d = 1.0f / Df;
   float ps = 0.f, pq = 0.f;
   for (int n = 0; n < N; ++n) {
-    const int64_t row_tile = ((int64_t)n * C + c) * tpr;        // first tile of the row
-    for (int q0 = q_lo + wv; q0 < q_hi; q0 += kWaves * kRowUnroll) {
+    const int64_t e0 = ((int64_t)n * C + c) * L + l0, e1 = e0 + (l1 - l0);
+    const uint32_t t_first = (uint32_t)(e0 >> 8), t_last = (uint32_t)((e1 - 1) >> 8);      // < 2^31 tiles (rows_ok)
+    const int lo_first = (int)(e0 - (int64_t)t_first * 256);          // first valid element of the first tile
+    const int hi_last = (int)(e1 - (int64_t)t_last * 256);            // end of the valid elements of the last tile
+    for (uint32_t t0 = t_first + (uint32_t)wv; t0 <= t_last; t0 += kWaves * kRowUnroll) {
       Tile4 zv[kRowUnroll], a[kRowUnroll], bb[kRowUnroll], cc[kRowUnroll];
       uint64_t mw[kRowUnroll][4];
+      bool act[kRowUnroll];
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) {
-        const int q = q0 + u * kWaves;
-        if (q < q_hi) {                                          // wave-uniform
-          const int64_t tile = row_tile + q, base = tile * 256 + lane * 4;
+        const uint32_t tile = t0 + u * kWaves;
+        const bool live = tile <= t_last;                        // wave-uniform
+        const int lo = tile == t_first ? lo_first : 0, hi = tile == t_last ? hi_last : 256;
+        act[u] = live && lane * 4 >= lo && lane * 4 < hi;
+        if (act[u]) {
+          const int64_t base = (int64_t)tile * 256 + lane * 4;
           zv[u] = ld4(z + base);
           if (GU) a[u] = ld4(g_u + base);
           if (GY) bb[u] = ld4(g_y + base);
           if (GV) cc[u] = ld4(g_v + base);
-          if (GY || GV) {
+        }
+        if ((GY || GV) && live) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mw[u][j] = mask[tile * 4 + j];
-          }
+          for (int j = 0; j < 4; ++j) mw[u][j] = mask[(int64_t)tile * 4 + j];
         }
       }
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) {
-        if (q0 + u * kWaves >= q_hi) continue;
+        if (t0 + u * kWaves > t_last) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool m = (GY || GV) ? __builtin_amdgcn_inverse_ballot_w64(mw[u][j]) : false;
           const float gu = form_gu_rows<GU, GY, GV>(GU ? a[u].a[j] : 0.f, GY ? bb[u].a[j] : 0.f, GV ? cc[u].a[j] : 0.f, m, vth, inv_d);
           const float xhat = ((zv[u].a[j] + b) - mean) * rstd;
-          ps += gu;
-          pq += gu * xhat;
+          if (act[u]) {
+            ps += gu;
+            pq += gu * xhat;
+          }
         }
       }
     }
@@ -606,26 +654,29 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
   block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
 }
 
-template <bool GU, bool GY, bool GV>
+template <bool GU, bool GY, bool GV, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
     const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, const double* __restrict__ sums,
     float* __restrict__ gz, float* __restrict__ g_res, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    uint32_t ntiles, int C, uint32_t tpr, uint32_t chunk, double inv_count, int training, float vth, float Df) {
+    int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk, double inv_count, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
   uint32_t t = wave * chunk;
   const uint32_t t_end = min(ntiles, t + chunk);
+  const uint32_t tail = (uint32_t)(total - (int64_t)(ntiles - 1) * 256);
   Tile4 zn, an, bn, cn;
   uint64_t mn[4] = {0, 0, 0, 0};
   auto request = [&](uint32_t tile) __attribute__((always_inline)) {
     if (tile < t_end) {
-      const int64_t base = (int64_t)tile * 256 + lane * 4;
-      zn = ld4(z + base);
-      if (GU) an = ld4(g_u + base);
-      if (GY) bn = ld4(g_y + base);
-      if (GV) cn = ld4(g_v + base);
+      if (ALIGNED || tile + 1 < ntiles || (uint32_t)lane * 4 < tail) {
+        const int64_t base = (int64_t)tile * 256 + lane * 4;
+        zn = ld4(z + base);
+        if (GU) an = ld4(g_u + base);
+        if (GY) bn = ld4(g_y + base);
+        if (GV) cn = ld4(g_v + base);
+      }
       if (GY || GV) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) mn[j] = mask[(int64_t)tile * 4 + j];
@@ -633,44 +684,64 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
     }
   };
   request(t);
-  uint32_t row = t / tpr, q = t - row * tpr;
-  uint32_t c = row % (uint32_t)C;
-  float b, mean, rstd, g, m1, m2;
-  auto params = [&]() __attribute__((always_inline)) {
-    b = bias ? bias[c] : 0.f;
-    mean = stat[c];
-    rstd = stat[C + c];
-    g = gamma[c];
-    m1 = training ? (float)(sums[2 * c] * inv_count) : 0.f;
-    m2 = training ? (float)(sums[2 * c + 1] * inv_count) : 0.f;
+  RowWalk w = walk_begin(t, L, (uint32_t)C);
+  struct Par {
+    float b, mean, rstd, g, m1, m2;
+  } p0, p1;
+  auto params = [&](uint32_t c) __attribute__((always_inline)) {
+    Par p;
+    p.b = bias ? bias[c] : 0.f;
+    p.mean = stat[c];
+    p.rstd = stat[C + c];
+    p.g = gamma[c];
+    p.m1 = training ? (float)(sums[2 * c] * inv_count) : 0.f;
+    p.m2 = training ? (float)(sums[2 * c + 1] * inv_count) : 0.f;
+    return p;
   };
-  if (t < t_end) params();
+  if (t < t_end) p0 = params(w.c);
+  p1 = p0;
   const float inv_d = 1.0f / Df;
   for (; t < t_end; ++t) {
     const int64_t base = (int64_t)t * 256 + lane * 4;
     const Tile4 zv = zn, a = an, bb = bn, cc = cn;
     const uint64_t mw[4] = {mn[0], mn[1], mn[2], mn[3]};
     request(t + 1);
-    if (q == 0 && row < (uint32_t)C && lane == 0) {          // dbeta = sum(gu), dgamma = sum(gu * xhat)
-      dbeta[c] = (float)sums[2 * c];
-      dgamma[c] = (float)sums[2 * c + 1];
+    const uint32_t bnd = L - w.off;
+    const bool split = !ALIGNED && bnd < 256u;
+    const uint32_t c2 = w.c + 1 == (uint32_t)C ? 0u : w.c + 1;
+    if (split) p1 = params(c2);
+    // dbeta = sum(gu), dgamma = sum(gu * xhat): written by the lane that owns the channel's first element
+    if (w.off == 0 && w.row < (uint32_t)C && lane == 0) {
+      dbeta[w.c] = (float)sums[2 * w.c];
+      dgamma[w.c] = (float)sums[2 * w.c + 1];
     }
-    Tile4 o, r;
+    if (split && w.row + 1 < (uint32_t)C && (uint32_t)lane == (bnd >> 2)) {
+      dbeta[c2] = (float)sums[2 * c2];
+      dgamma[c2] = (float)sums[2 * c2 + 1];
+    }
+    const bool first = !split || (uint32_t)lane * 4 < bnd;
+    const bool ok = ALIGNED || t + 1 < ntiles || (uint32_t)lane * 4 < tail;
+    const float b = first ? p0.b : p1.b, mean = first ? p0.mean : p1.mean, rstd = first ? p0.rstd : p1.rstd,
+                g = first ? p0.g : p1.g, m1 = first ? p0.m1 : p1.m1, m2 = first ? p0.m2 : p1.m2;
+    if (ok) {
+      Tile4 o, r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool m = (GY || GV) ? __builtin_amdgcn_inverse_ballot_w64(mw[j]) : false;
-      const float gu = form_gu_rows<GU, GY, GV>(GU ? a.a[j] : 0.f, GY ? bb.a[j] : 0.f, GV ? cc.a[j] : 0.f, m, vth, inv_d);
-      const float xhat = ((zv.a[j] + b) - mean) * rstd;
-      o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
-      r.a[j] = gu;
+      for (int j = 0; j < 4; ++j) {
+        const bool m = (GY || GV) ? __builtin_amdgcn_inverse_ballot_w64(mw[j]) : false;
+        const float gu = form_gu_rows<GU, GY, GV>(GU ? a.a[j] : 0.f, GY ? bb.a[j] : 0.f, GV ? cc.a[j] : 0.f, m, vth, inv_d);
+        const float xhat = ((zv.a[j] + b) - mean) * rstd;
+        o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
+        r.a[j] = gu;
+      }
+      st4(gz + base, o);
+      if (g_res) st4(g_res + base, r);
     }
-    st4(gz + base, o);
-    if (g_res) st4(g_res + base, r);
-    if (++q == tpr) {
-      q = 0;
-      ++row;
-      if (++c == (uint32_t)C) c = 0;
-      params();
+    w.off += 256u;
+    if (w.off >= L) {
+      w.off -= L;
+      ++w.row;
+      w.c = c2;
+      p0 = split ? p1 : params(c2);
     }
   }
 }
@@ -893,13 +964,14 @@ inline int pick_slices(int C, int L, int& slice) {
 
 // Row-walking forms: eligibility, slice picker (in tiles) and the persistent grid.
 inline bool rows_ok(int64_t N, int64_t C, int64_t L, int D) {
-  return (L & 255) == 0 && N * C * L < ((int64_t)1 << 39) && N * C < ((int64_t)1 << 31) && D >= 1 && (D & (D - 1)) == 0;
+  return (L & 3) == 0 && L >= 256 && N * C * L < ((int64_t)1 << 39) && N * C < ((int64_t)1 << 31) && D >= 1 && (D & (D - 1)) == 0;
 }
-inline int pick_slices_rows(int C, int tpr, int& tps) {
+inline bool rows_aligned(int64_t total, int64_t L) { return (L & 255) == 0 && (total & 255) == 0; }
+inline int pick_slices_rows(int C, int L, int& slice) {
   int S = 1;
-  while ((int64_t)C * S < 2048 && tpr / (S * 2) >= 8) S *= 2;       // >= 8 tiles per (row, slice): two per wave
-  tps = (tpr + S - 1) / S;
-  return (tpr + tps - 1) / tps;
+  while ((int64_t)C * S < 2048 && L / (S * 2) >= 2048) S *= 2;       // >= 8 tiles per (row, slice): two per wave
+  slice = ((L + S - 1) / S + 255) / 256 * 256;                      // whole tiles when the rows are tile-aligned
+  return (L + slice - 1) / slice;
 }
 // Workgroups of `Kern` that can be resident on the whole chip at once: a persistent kernel launched with more than that
 // runs a second, partly filled round (2 048 workgroups on 1 792 slots cost 14 %).
@@ -1012,17 +1084,23 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
 #undef S2F_BN_FUSED
     return s2f_check_launch("s2f_bn_act_fwd");
   }
-  const bool rows = rows_ok(N, C, L, D);
+  const bool rows = rows_ok(N, C, L, D), aligned = rows_aligned(total, L);
   const size_t lds = 3 * C * sizeof(float) + 64;
+#define S2F_BN_ROWS_FWD(LIFV, HASV, YBV, AL)                                                                              \
+  do {                                                                                                                  \
+    uint32_t chunk;                                                                                                     \
+    const uint32_t ntiles = (uint32_t)((total + 255) >> 8);                                                             \
+    const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                         \
+    S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias, sums,  \
+               stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, \
+               ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth, (float)D);          \
+  } while (0)
 #define S2F_BN_APPLY(LIFV, HASV, YBV)                                                                                   \
   do {                                                                                                                  \
-    if (rows) {                                                                                                         \
-      uint32_t chunk;                                                                                                   \
-      const uint32_t ntiles = (uint32_t)(total >> 8);                                                                   \
-      const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV>>(ntiles, lds, chunk);                           \
-      S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV>), dim3(rgrid), block, lds, s, z, conv_bias, sums,    \
-                 stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
-                 ntiles, (int)C, (uint32_t)(L >> 8), chunk, inv_count, unbias, momentum, eps, training, vth, (float)D); \
+    if (rows && aligned) {                                                                                              \
+      S2F_BN_ROWS_FWD(LIFV, HASV, YBV, true);                                                                           \
+    } else if (rows) {                                                                                                  \
+      S2F_BN_ROWS_FWD(LIFV, HASV, YBV, false);                                                                          \
     } else {                                                                                                            \
       S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, lds, s, z, conv_bias, sums, stat_out,      \
                  running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, \
@@ -1043,6 +1121,7 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
       S2F_BN_APPLY(true, true, false);
   }
 #undef S2F_BN_APPLY
+#undef S2F_BN_ROWS_FWD
   return s2f_check_launch("s2f_bn_act_fwd");
 }
 
@@ -1078,20 +1157,27 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
     return s2f_check_launch("s2f_bn_act_bwd");
   }
   if (rows_ok(N, C, L, D)) {
-    const int tpr = (int)(L >> 8);
-    int tps;
-    const int S = pick_slices_rows((int)C, tpr, tps);
-    const uint32_t ntiles = (uint32_t)(total >> 8);
+    int slice;
+    const int S = pick_slices_rows((int)C, (int)L, slice);
+    const uint32_t ntiles = (uint32_t)((total + 255) >> 8);
     const double inv_count = 1.0 / ((double)N * (double)L);
+    const bool aligned = rows_aligned(total, L);
+#define S2F_BN_ROWS_APPLY(A, B, Cc, AL)                                                                                  \
+  do {                                                                                                                   \
+    uint32_t chunk;                                                                                                      \
+    const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc, AL>>(ntiles, 0, chunk);                               \
+    S2F_LAUNCH(false, true, (bn_bwd_apply_rows_kernel<A, B, Cc, AL>), dim3(rgrid), dim3(kBlock), 0, s, z, conv_bias, stat, \
+               gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, ntiles, (int)C, (uint32_t)L, \
+               chunk, inv_count, training, vth, (float)D);                                                               \
+  } while (0)
 #define S2F_BN_ROWS_BWD(A, B, Cc)                                                                                        \
   do {                                                                                                                   \
     S2F_LAUNCH(true, false, (bn_bwd_reduce_rows_kernel<A, B, Cc>), dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, \
-               stat, g_u, g_y, g_v, mask, sums_zeroed, (int)N, (int)C, tpr, tps, vth, (float)D);                          \
-    uint32_t chunk;                                                                                                      \
-    const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc>>(ntiles, 0, chunk);                                   \
-    S2F_LAUNCH(false, true, (bn_bwd_apply_rows_kernel<A, B, Cc>), dim3(rgrid), dim3(kBlock), 0, s, z, conv_bias, stat,     \
-               gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, ntiles, (int)C, (uint32_t)tpr,     \
-               chunk, inv_count, training, vth, (float)D);                                                               \
+               stat, g_u, g_y, g_v, mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);                     \
+    if (aligned)                                                                                                         \
+      S2F_BN_ROWS_APPLY(A, B, Cc, true);                                                                                 \
+    else                                                                                                                 \
+      S2F_BN_ROWS_APPLY(A, B, Cc, false);                                                                                \
   } while (0)
     switch ((g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0)) {
       case 1: S2F_BN_ROWS_BWD(false, false, true); break;
@@ -1103,6 +1189,7 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
       default: S2F_BN_ROWS_BWD(true, true, true); break;
     }
 #undef S2F_BN_ROWS_BWD
+#undef S2F_BN_ROWS_APPLY
     return s2f_check_launch("s2f_bn_act_bwd");
   }
   int slice;

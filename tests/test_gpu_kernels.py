@@ -349,7 +349,12 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      (8, 256, 4096, True, False, True),
                                                      # single-pass kernels (s2f_bn_single_pass): full / ragged wave counts
                                                      (8, 256, 1024, True, False, True), (8, 64, 1024, True, True, True),
-                                                     (2, 128, 512, True, True, False), (3, 64, 768, True, False, True)])
+                                                     (2, 128, 512, True, True, False), (3, 64, 768, True, False, True),
+                                                     # row-walking kernels with tiles that straddle two channel rows / a ragged
+                                                     # last tile (L % 256 != 0; C5's 1050- and 4200-pixel maps), train and eval
+                                                     (3, 5, 260, True, True, True), (2, 7, 1052, True, False, True),
+                                                     (1, 3, 300, True, True, False), (2, 6, 4200, False, True, True),
+                                                     (8, 3, 16800, True, False, True)])
 @pytest.mark.parametrize("bf16", [True, False])
 def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
