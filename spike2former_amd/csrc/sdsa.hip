@@ -159,16 +159,28 @@ __global__ __launch_bounds__(256) void outer_kernel(Operand<TA> OA, Operand<TB> 
 // apart, i.e. one HBM channel at a time (1.8 TB/s on the 16 384-token maps).  Block 256 = 4 waves.  Lane l of every wave owns columns n0+4l .. n0+4l+3 (one 16-byte
 // load per row of X); wave w owns output rows j in [w*JC, (w+1)*JC).  M is staged in LDS zero-padded to 4*JC columns,
 // and read as broadcast 16-byte rows: one ds_read_b128 feeds 16 FMAs.
-template <bool TRANS, int JC, typename TX>
-__global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float* __restrict__ M, float* __restrict__ Y,
-                                                    int64_t y_batch_stride, int heads, int d, int N, float alpha) {
-  constexpr int LD = 4 * JC;
+// NW = 4 or 8 waves per workgroup (the output rows of a head are spread over them: with few workgroups in flight -- the
+// 100-query and 1 024-token maps -- a wave's share of the d x d products is the critical path, so it is halved).
+// LO: the Q_IFNode epilogue -- y = Q_IFNode(alpha * product) leaves as bf16 spikes with the in-range mask and the firing
+// counters, in the layout of the neuron kernels (N % 256 == 0: a lane's four columns are one mask-tile position); the
+// product itself never reaches HBM.
+struct LifOut {
+  unsigned short* y;                 // [TB, C, N] bf16 spikes
+  uint64_t* mask;                    // s2f_lif_mask_words(TB * C * N) or nullptr
+  unsigned long long* stats;         // uint64[S2F_STAT_SLOTS][2] or nullptr
+  float vth, Df, inv_d;
+};
+
+template <bool TRANS, int JC, typename TX, int NW, bool LO>
+__global__ __launch_bounds__(64 * NW) void apply_kernel(Operand<TX> OX, const float* __restrict__ M, float* __restrict__ Y,
+                                                        int64_t y_batch_stride, int heads, int d, int N, float alpha, LifOut lo) {
+  constexpr int LD = NW * JC;
   __shared__ __attribute__((aligned(16))) float sm[kDMax * LD];
   const int bh = blockIdx.y;
   const int tb = bh / heads, h = bh % heads;
   const int C = heads * d;
   const float* m = M + (int64_t)bh * d * d;
-  for (int e = threadIdx.x; e < d * LD; e += 256) {
+  for (int e = threadIdx.x; e < d * LD; e += 64 * NW) {
     const int i = e / LD, j = e % LD;
     sm[e] = j < d ? (TRANS ? m[j * d + i] : m[i * d + j]) : 0.f;
   }
@@ -248,11 +260,26 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
       }
     }
   }
+  unsigned int csum = 0, cnz = 0;
 #pragma unroll
   for (int j = 0; j < JC; ++j) {
     const int jg = wave * JC + j;
     if (jg < d) {
-      if (vec) {
+      if (LO) {                                          // vec holds (N % 256 == 0 is required by the host)
+        float yv[4];
+        bool inr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float sp, vn;
+          s2f_lif_update(acc[j][c] * alpha, lo.Df, lo.inv_d, lo.vth, sp, yv[c], vn, inr[c]);
+          csum += (unsigned int)sp;
+          cnz += ((unsigned int)sp != 0);
+        }
+        const int64_t e = e0 + (int64_t)jg * N + n;      // element index in the contiguous [TB, C, N] output
+        *reinterpret_cast<uint2*>(lo.y + e) = s2f_spikes_to_bf16x4(yv[0], yv[1], yv[2], yv[3]);
+        const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+        if (lo.mask != nullptr && lane < 4) lo.mask[(e >> 8) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+      } else if (vec) {
         *reinterpret_cast<float4*>(y + (int64_t)jg * N) =
             make_float4(acc[j][0] * alpha, acc[j][1] * alpha, acc[j][2] * alpha, acc[j][3] * alpha);
       } else {
@@ -261,21 +288,43 @@ __global__ __launch_bounds__(256) void apply_kernel(Operand<TX> OX, const float*
       }
     }
   }
+  if (LO && lo.stats != nullptr) {
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+      csum += __shfl_xor(csum, ofs, 64);
+      cnz += __shfl_xor(cnz, ofs, 64);
+    }
+    if (lane == 0) {                                     // one pair of atomics per wave, spread over the slots
+      unsigned long long* slot = lo.stats + 2 * ((blockIdx.x + blockIdx.y * gridDim.x + wave) % S2F_STAT_SLOTS);
+      if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+      if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+    }
+  }
 }
 
-template <bool TRANS, typename TX>
+template <bool TRANS, typename TX, bool LO = false>
 void launch_apply(Operand<TX> x, const float* m, float* y, int64_t y_batch_stride, int TB, int heads, int d, int N, float alpha,
-                  hipStream_t s) {
+                  hipStream_t s, LifOut lo = LifOut{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f}) {
   dim3 grid((N + 255) / 256, TB * heads);
-  const int jc = ((d + 3) / 4 + 3) / 4 * 4;     // rows per wave, rounded up to a multiple of 4
-  if (jc <= 4)
-    hipLaunchKernelGGL((apply_kernel<TRANS, 4, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
+  // eight waves when the launch cannot fill the chip with four-wave workgroups anyway
+  const bool wide = (int64_t)grid.x * grid.y <= 1024 && d > 8;
+  const int nw = wide ? 8 : 4;
+  const int jc = ((d + nw - 1) / nw + 3) / 4 * 4;     // rows per wave, rounded up to a multiple of 4
+#define S2F_AP(JCV, NWV) \
+  hipLaunchKernelGGL((apply_kernel<TRANS, JCV, TX, NWV, LO>), grid, dim3(64 * NWV), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha, lo)
+  if (wide) {
+    if (jc <= 4)
+      S2F_AP(4, 8);
+    else
+      S2F_AP(8, 8);
+  } else if (jc <= 4)
+    S2F_AP(4, 4);
   else if (jc <= 8)
-    hipLaunchKernelGGL((apply_kernel<TRANS, 8, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
+    S2F_AP(8, 4);
   else if (jc <= 12)
-    hipLaunchKernelGGL((apply_kernel<TRANS, 12, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
+    S2F_AP(12, 4);
   else
-    hipLaunchKernelGGL((apply_kernel<TRANS, 16, TX>), grid, dim3(256), 0, s, x, m, y, y_batch_stride, heads, d, N, alpha);
+    S2F_AP(16, 4);
+#undef S2F_AP
 }
 
 
@@ -304,39 +353,29 @@ int launch_outer(Operand<TA> a, Operand<TB> b, float* kv, int TB_, int heads, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The attention core and the neuron behind it as ONE kernel (the backbone's self-attention, sdtv2.py:335-342):
-//     kv = k^T v  (d x d)  ->  o = scale * q kv  ->  y = Q_IFNode(o)   written as bf16 spikes + 1-bit in-range mask + counters
-// One workgroup per (tb, head).  q / k / v are bf16 spike maps (exact), possibly channel ranges of one [TB, 3C, N] tensor.
-// Phase 1: kv on the matrix cores straight from memory -- both operands are contraction-contiguous rows (A = k rows,
-// B = v rows, 8 consecutive columns per lane: v_mfma_f32_32x32x16_bf16), products and sums exact in fp32 (spike operands,
-// see the file header); the four waves own interleaved 16-column slices and add their partial tiles through LDS.
-// kv leaves for the backward pass; o never touches HBM, nor does a separate neuron kernel re-read it.
-// Phase 2: as apply_kernel (lane = 4 columns, wave = JC output rows, kv broadcast from LDS), then the neuron update of
-// s2f_lif_fwd on o (reset membrane), spikes as bf16, ballot mask, firing counters.  Needs N % 256 == 0 (a wave's 256
-// columns are one mask tile) and 16-byte aligned rows.
+// kv[i][j] = alpha * sum_n a[i][n] b[j][n] for two bf16 SPIKE maps on the matrix cores, straight from memory: both operands
+// are contraction-contiguous rows (A = a rows, B = b rows, 8 consecutive columns per lane: v_mfma_f32_32x32x16_bf16), no LDS
+// staging and no transposition.  Products and partial sums are exact in fp32 (multiples of 1/D^2 below 2^24 / D^2: see the
+// file header), so neither the four waves' interleaved 16-column slices (added through LDS) nor the split-N atomics depend
+// on the order of the additions.  The VALU form (outer_kernel) spent 17 us on the 1 024-token maps of the backbone, most
+// of it in 2 M fp32 atomics of its 16-way split, and 51 us on the decoder's 16 384-token keys.
+// grid (nsplit, TB*heads); N % 64 == 0, 16-byte aligned rows.  DT = ceil(d / 32) tiles per side.
 typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
 typedef __attribute__((ext_vector_type(16))) float ff32x16;
 
-template <int DT, int JC>
-__global__ __launch_bounds__(256) void sdsa_lif_fwd_kernel(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
-                                                           const unsigned short* __restrict__ V, int64_t q_bs, int64_t k_bs,
-                                                           int64_t v_bs, unsigned short* __restrict__ Yspk,
-                                                           uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
-                                                           float* __restrict__ KV, int heads, int d, int N, float scale,
-                                                           float vth, float Df) {
-  constexpr int LD = 4 * JC;                         // kv row length in LDS (>= d, zero padded)
+template <int DT>
+__global__ __launch_bounds__(256) void outer_mfma_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                                         int64_t a_bs, int64_t b_bs, float* __restrict__ KV, int heads, int d,
+                                                         int N, float alpha) {
   __shared__ __attribute__((aligned(16))) float red[3][DT * DT][16][64];      // partial tiles of waves 1..3
-  __shared__ __attribute__((aligned(16))) float sm[kDMax * LD];
-  __shared__ unsigned int sred[8];
-  const int bh = blockIdx.x;
+  const int bh = blockIdx.y;
   const int tb = bh / heads, h = bh % heads;
-  const int C = heads * d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned short* kr = K + (int64_t)tb * k_bs + (int64_t)h * d * N;
-  const unsigned short* vr = V + (int64_t)tb * v_bs + (int64_t)h * d * N;
-  const unsigned short* qr = Q + (int64_t)tb * q_bs + (int64_t)h * d * N;
-
-  // ---- phase 1: kv[i][j] = sum_n k[i][n] v[j][n]
+  const unsigned short* ar = A + (int64_t)tb * a_bs + (int64_t)h * d * N;
+  const unsigned short* br = B + (int64_t)tb * b_bs + (int64_t)h * d * N;
+  const int nsplit = gridDim.x;
+  const int chunk = ((N + nsplit - 1) / nsplit + 63) / 64 * 64;
+  const int n_begin = blockIdx.x * chunk, n_end = min(N, n_begin + chunk);
   ff32x16 acc[DT][DT];
 #pragma unroll
   for (int a = 0; a < DT; ++a)
@@ -345,23 +384,30 @@ __global__ __launch_bounds__(256) void sdsa_lif_fwd_kernel(const unsigned short*
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int row = lane & 31, ksub = 8 * (lane >> 5);
-  for (int n0 = wave * 16; n0 < N; n0 += 64) {
-    fbf16x8 af[DT], bf[DT];
+  constexpr int U = 4;                               // 16-column steps whose loads are issued together
+  for (int n0 = n_begin + wave * 16; n0 < n_end; n0 += 64 * U) {
+    uint4 ka[U][DT], vb[U][DT];
 #pragma unroll
-    for (int a = 0; a < DT; ++a) {
-      const int i = a * 32 + row;
-      uint4 ka = make_uint4(0u, 0u, 0u, 0u), va = make_uint4(0u, 0u, 0u, 0u);
-      if (i < d) {
-        ka = *reinterpret_cast<const uint4*>(kr + (int64_t)i * N + n0 + ksub);
-        va = *reinterpret_cast<const uint4*>(vr + (int64_t)i * N + n0 + ksub);
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int a = 0; a < DT; ++a) {
+        const int i = a * 32 + row, n = n0 + u * 64;
+        ka[u][a] = vb[u][a] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < d && n < n_end) {
+          ka[u][a] = *reinterpret_cast<const uint4*>(ar + (int64_t)i * N + n + ksub);
+          vb[u][a] = *reinterpret_cast<const uint4*>(br + (int64_t)i * N + n + ksub);
+        }
       }
-      af[a] = *reinterpret_cast<fbf16x8*>(&ka);
-      bf[a] = *reinterpret_cast<fbf16x8*>(&va);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (n0 + u * 64 >= n_end) continue;            // wave-uniform
+#pragma unroll
+      for (int a = 0; a < DT; ++a)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<fbf16x8*>(&ka[u][a]),
+                                                              *reinterpret_cast<fbf16x8*>(&vb[u][b]), acc[a][b], 0, 0, 0);
     }
-#pragma unroll
-    for (int a = 0; a < DT; ++a)
-#pragma unroll
-      for (int b = 0; b < DT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
   if (wave > 0) {
 #pragma unroll
@@ -371,7 +417,6 @@ __global__ __launch_bounds__(256) void sdsa_lif_fwd_kernel(const unsigned short*
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave - 1][a * DT + b][r][lane] = acc[a][b][r];
   }
-  for (int e = threadIdx.x; e < kDMax * LD; e += 256) sm[e] = 0.f;
   __syncthreads();
   if (wave == 0) {
     float* kvg = KV + (int64_t)bh * d * d;
@@ -385,85 +430,34 @@ __global__ __launch_bounds__(256) void sdsa_lif_fwd_kernel(const unsigned short*
           // C layout of the 32x32 MFMA: column (j) = lane & 31, row (i) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
           const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = b * 32 + (lane & 31);
           if (i < d && j < d) {
-            sm[i * LD + j] = v;
-            kvg[i * d + j] = v;
+            if (nsplit > 1)
+              atomicAdd(&kvg[i * d + j], v * alpha);
+            else
+              kvg[i * d + j] = v * alpha;
           }
         }
   }
-  __syncthreads();
+}
 
-  // ---- phase 2: o[j][n] = scale * sum_i q[i][n] kv[i][j]; y = Q_IFNode(o)
-  unsigned int csum = 0, cnz = 0;
-  const int64_t e_head = ((int64_t)tb * C + h * d) * N;            // element index in the contiguous [TB, C, N] output
-  for (int nb = 0; nb < N; nb += 256) {
-    const int n = nb + lane * 4;
-    float o[JC][4];
-#pragma unroll
-    for (int j = 0; j < JC; ++j) o[j][0] = o[j][1] = o[j][2] = o[j][3] = 0.f;
-    constexpr int G = 8;
-    for (int i0 = 0; i0 < d; i0 += G) {
-      float4 xv[G];
-#pragma unroll
-      for (int u = 0; u < G; ++u) xv[u] = ld4(qr + (int64_t)min(i0 + u, d - 1) * N + n);
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
-        if (i0 + u < d) {
-          const float* rowp = sm + (i0 + u) * LD + wave * JC;
-          const float xq[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-#pragma unroll
-          for (int j4 = 0; j4 < JC; j4 += 4) {
-            const float4 mv = *reinterpret_cast<const float4*>(rowp + j4);
-            const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) o[j4 + jj][c] += xq[c] * mm[jj];
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < JC; ++j) {
-      const int jg = wave * JC + j;                   // wave-uniform
-      if (jg < d) {
-        float yv[4];
-        bool inr[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float sp, yy, vn;
-          s2f_lif_update(o[j][c] * scale, Df, 1.0f, vth, sp, yy, vn, inr[c]);
-          yv[c] = sp / Df;
-          csum += (unsigned int)sp;
-          cnz += ((unsigned int)sp != 0);
-        }
-        const int64_t e = e_head + (int64_t)jg * N + n;
-        *reinterpret_cast<uint2*>(Yspk + e) = s2f_spikes_to_bf16x4(yv[0], yv[1], yv[2], yv[3]);
-        const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
-        if (mask != nullptr && lane < 4) mask[(e >> 8) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-      }
-    }
-  }
-  if (stats != nullptr) {
-    for (int ofs = 32; ofs > 0; ofs >>= 1) {
-      csum += __shfl_xor(csum, ofs, 64);
-      cnz += __shfl_xor(cnz, ofs, 64);
-    }
-    if (lane == 0) {
-      sred[wave * 2] = csum;
-      sred[wave * 2 + 1] = cnz;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long a = 0, b = 0;
-      for (int w = 0; w < 4; ++w) {
-        a += sred[2 * w];
-        b += sred[2 * w + 1];
-      }
-      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
-      if (a) atomicAdd(&slot[0], a);
-      if (b) atomicAdd(&slot[1], b);
-    }
-  }
+// spike x spike outer product: the matrix-core form when the rows allow 16-byte loads
+int launch_outer_spikes(const unsigned short* a, int64_t a_bs, const unsigned short* b, int64_t b_bs, float* kv, int TB_, int heads,
+                        int d, int N, float alpha, hipStream_t s) {
+  const bool mfma = (N & 63) == 0 && ((a_bs | b_bs) & 7) == 0 && s2f_aligned16(a) && s2f_aligned16(b);
+  if (!mfma)
+    return launch_outer(Operand<unsigned short>{a, a_bs, nullptr, 0.f}, Operand<unsigned short>{b, b_bs, nullptr, 0.f}, kv, TB_,
+                        heads, d, N, alpha, s);
+  // four 16-column steps per wave and workgroup (one round of loads) while that leaves the chip busy; 1 024 workgroups at most
+  int ns = N / 256;
+  const int cap = 1024 / (TB_ * heads) > 1 ? 1024 / (TB_ * heads) : 1;
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  if (ns > 1 && s2f_zero_async(kv, sizeof(float) * (size_t)TB_ * heads * d * d, s) != S2F_OK)
+    return s2f_check_launch("s2f_sdsa_kv clear");
+  if (d <= 32)
+    hipLaunchKernelGGL((outer_mfma_kernel<1>), dim3(ns, TB_ * heads), dim3(256), 0, s, a, b, a_bs, b_bs, kv, heads, d, N, alpha);
+  else
+    hipLaunchKernelGGL((outer_mfma_kernel<2>), dim3(ns, TB_ * heads), dim3(256), 0, s, a, b, a_bs, b_bs, kv, heads, d, N, alpha);
+  return s2f_check_launch("s2f_sdsa_kv");
 }
 
 }  // namespace
@@ -536,8 +530,7 @@ extern "C" int s2f_sdsa_fwd_bf16(const uint16_t* q, const uint16_t* k, const uin
   rc = check_bf16("s2f_sdsa_fwd_bf16", q, k, v, q_batch_stride, k_batch_stride, v_batch_stride, Nq, Nk);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  rc = launch_outer(Operand<unsigned short>{k, k_batch_stride, nullptr, 0.f}, Operand<unsigned short>{v, v_batch_stride, nullptr, 0.f},
-                    kv_save, TB, heads, d, Nk, 1.0f, s);
+  rc = launch_outer_spikes(k, k_batch_stride, v, v_batch_stride, kv_save, TB, heads, d, Nk, 1.0f, s);
   if (rc) return rc;
   launch_apply<false>(Operand<unsigned short>{q, q_batch_stride, nullptr, 0.f}, kv_save, o, (int64_t)heads * d * Nq, TB, heads, d,
                       Nq, scale, s);
@@ -581,22 +574,18 @@ extern "C" int s2f_sdsa_lif_fwd_bf16(const uint16_t* q, const uint16_t* k, const
   S2F_REQUIRE(s2f_aligned16(q) && s2f_aligned16(k) && s2f_aligned16(v) && (reinterpret_cast<uintptr_t>(y_spikes) & 7u) == 0,
               S2F_EALIGN, "s2f_sdsa_lif_fwd_bf16: q / k / v must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  auto* st = reinterpret_cast<unsigned long long*>(stats);
-  const int jc = ((d + 3) / 4 + 3) / 4 * 4;
-#define S2F_SL(DTV, JCV)                                                                                               \
-  S2F_LAUNCH(true, true, (sdsa_lif_fwd_kernel<DTV, JCV>), dim3(TB * heads), dim3(256), 0, s, q, k, v, q_batch_stride,    \
-             k_batch_stride, v_batch_stride, y_spikes, mask, st, kv_save, heads, d, N, scale, vth, (float)D)
-  if (d <= 32) {
-    if (jc <= 4)
-      S2F_SL(1, 4);
-    else
-      S2F_SL(1, 8);
-  } else {
-    if (jc <= 12)
-      S2F_SL(2, 12);
-    else
-      S2F_SL(2, 16);
-  }
-#undef S2F_SL
+  // kv = k^T v: sums of products of multiples of 1/D <= 1 -- every partial sum is a multiple of 1/D^2 below 2^24 / D^2, so
+  // the fp32 additions are exact and the split-N atomics of outer_kernel are order-independent: the result is deterministic
+  S2fTiming* tm = s2f_timing_tls();
+  hipEvent_t ev_start = tm->start, ev_stop = tm->stop;
+  tm->start = tm->stop = nullptr;
+  if (ev_start) (void)hipEventRecord(ev_start, s);
+  rc = launch_outer_spikes(k, k_batch_stride, v, v_batch_stride, kv_save, TB, heads, d, N, 1.0f, s);
+  if (rc) return rc;
+  launch_apply<false, unsigned short, true>(Operand<unsigned short>{q, q_batch_stride, nullptr, 0.f}, kv_save, nullptr,
+                                            (int64_t)heads * d * N, TB, heads, d, N, scale, s,
+                                            LifOut{y_spikes, mask, reinterpret_cast<unsigned long long*>(stats), vth, (float)D,
+                                                   1.0f / (float)D});
+  if (ev_stop) (void)hipEventRecord(ev_stop, s);
   return s2f_check_launch("s2f_sdsa_lif_fwd_bf16");
 }

@@ -8,4 +8,5 @@ python3 $R/tools/rocpd_categories.py $DB 7 > $R/gpurun_out/prof_$1_categories.tx
 python3 $R/tools/rocpd_stats.py $DB > $R/gpurun_out/prof_$1_stats.txt 2>&1
 python3 $R/tools/rocpd_top.py $DB 7 > $R/gpurun_out/prof_$1_top.txt 2>&1
 python3 $R/tools/rocpd_glue.py $DB 7 > $R/gpurun_out/prof_$1_glue.txt 2>&1
+python3 $R/tools/rocpd_top.py $DB 7 apply_kernel outer_kernel outer_mfma sdsa > $R/gpurun_out/prof_$1_sdsa.txt 2>&1
 tail -1 $R/gpurun_out/prof_$1.log | cut -c1-300

@@ -18,7 +18,7 @@ def cat(name):
     if 'dw_' in name: return 'dwconv (ours)'
     if 'bn_' in name: return 'bn(+lif) fused (ours)'
     if 'lif_' in name: return 'lif (ours)'
-    if 'apply_kernel' in name or 'outer_kernel' in name or 'sdsa' in name: return 'sdsa (ours)'
+    if 'apply_kernel' in name or 'outer_kernel' in name or 'outer_mfma' in name or 'sdsa' in name: return 'sdsa (ours)'
     if 's2f_zero' in name: return 'fill/memset'
     if 'depthwise' in name: return 'depthwise conv (ATen)'
     if 'batch_norm' in name: return 'batch_norm (ATen)'

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Top kernels by (name, grid) per step over the graph replays of a bench profile + the idle time between kernels.
-    python tools/rocpd_top.py <results.db> <replays>"""
+    python tools/rocpd_top.py <results.db> <replays> [substring ...]   # with substrings: every (kernel, grid) whose name has one"""
 import collections, re, sqlite3, sys
 c = sqlite3.connect(sys.argv[1]); replays = int(sys.argv[2])
 rows = c.execute("select name,start,end,grid_x,grid_y from kernels order by start").fetchall()
@@ -18,5 +18,7 @@ for name, s, e, gx, gy in sel:
     prev_end = max(prev_end or 0, e)
 span = sel[-1][2] - sel[0][1]
 print(f"# {n} steps: span {span/n/1e6:.2f} ms/step, kernel time {busy/n/1e6:.2f} ms/step, idle between kernels {gaps['idle']/n/1e6:.2f} ms/step, {len(sel)//n} launches/step")
-for k, v in agg.most_common(60):
+pats = sys.argv[3:]
+for k, v in (agg.most_common() if pats else agg.most_common(60)):
+    if pats and not any(p in k[0] for p in pats): continue
     print(f"{v/n/1e3:9.1f} us {cnt[k]//n:4d}x avg {v/cnt[k]/1e3:8.2f} us  {k}")
