@@ -66,14 +66,16 @@ struct Chunk<4> {
 // rows k0 .. k0+3 that the 32 lanes of one transpose read touch then cover all 64 banks once.
 // CH = bf16 elements per staged chunk: 8 (16-byte loads, N % 8 == 0) or 4 (8-byte loads: N % 4 == 0, and the implicit
 // 3x3 mode whose shifted rows are only 2-byte aligned).
-template <int WM, int TERMS, int CH, bool CONV, int KG>
-__global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigned short* __restrict__ Wsplit,
+template <int WM, int TERMS, int CH, bool CONV, int KG, int WNW = 2>
+__global__ __launch_bounds__(64 * WNW * WM * KG) void sgemm_bf16_kernel(const unsigned short* __restrict__ Wsplit,
                                                                    const unsigned short* __restrict__ X,
                                                                    const float* __restrict__ bias, float* __restrict__ Y,
                                                                    int M, int N, int K, int Mpad, int Kpad, int n_tiles,
                                                                    int m_tiles, Conv3 geo, GemmEx ex) {
   constexpr int BM = 64 * WM;
-  constexpr int T = 128 * WM;
+  constexpr int T = 64 * WNW * WM;
+  constexpr int NJ = 4 / WNW;                         // 32-column MFMA tiles per wavefront (wave tile 64 x 32 NJ)
+  constexpr int AH = 4 / WNW;                         // 16-byte A chunks per thread, term and K step
   constexpr int A_ELEMS = TERMS * BM * LDA;
   constexpr int GROUP_ELEMS = A_ELEMS + BK * BN;
   constexpr int RED_BYTES = (KG - 1) * T * 64 * 4;
@@ -96,13 +98,13 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
   if (bias) bias += (int64_t)b * ex.bias_batch_stride;
 
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
   constexpr int CPR = BN / CH;                        // chunks per X row
   constexpr int NQ = BK * CPR / T;                    // chunks per thread and K step
   static_assert(NQ >= 1, "tile too small for the thread count");
+  static_assert(KG == 1 || WNW == 2, "the split-K groups assume 2 x 2 MFMA tiles per wavefront");
   typedef typename Chunk<CH>::type chunk_t;
-  u32x4 areg[TERMS][2];
+  u32x4 areg[TERMS][AH];
   chunk_t breg[NQ];
 
   const int kloop = (Kpad + KG * BK - 1) / (KG * BK) * (KG * BK);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
 #pragma unroll
     for (int t = 0; t < TERMS; ++t)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < AH; ++h) {
         const int c = tid + h * T;
         areg[t][h] = live ? *reinterpret_cast<const u32x4*>(Wsplit + t * term_stride + (int64_t)(m0 + (c >> 2)) * Kpad + kk +
                                                            (c & 3) * 8)
@@ -153,17 +156,17 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
   // per-lane part of the transpose-read addresses (bf16 elements): row 8 (lane >> 5) + kl, kl = (lane & 15) >> 2; inside the
   // 32-column chunk the lane addresses columns 16 ((lane >> 4) & 1) + 4 (lane & 3)
   const int kl = (lane & 15) >> 2;
-  int boff[2];
+  int boff[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-    boff[j] = (8 * (lane >> 5) + kl) * BN + (((wn * 2 + j) ^ kl) << 5) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  for (int j = 0; j < NJ; ++j)
+    boff[j] = (8 * (lane >> 5) + kl) * BN + (((wn * NJ + j) ^ kl) << 5) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   fetch(grp * BK);
   for (int k0 = grp * BK; k0 < kloop; k0 += KG * BK) {
 #pragma unroll
     for (int t = 0; t < TERMS; ++t)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < AH; ++h) {
         const int c = tid + h * T;
         *reinterpret_cast<u32x4*>(&As[t][c >> 2][(c & 3) * 8]) = areg[t][h];
       }
@@ -175,13 +178,16 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
       *reinterpret_cast<chunk_t*>(Bs + kr * BN + ((((nc / CPC) ^ (kr & 3))) << 5) + (nc % CPC) * CH) = breg[q];
     }
     __syncthreads();
+#ifndef GP_NO_GLOBAL
     if (k0 + KG * BK < kloop) fetch(k0 + KG * BK);
+#endif
+#ifndef GP_NO_LDSREAD
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kof = ks * 16 + 8 * (lane >> 5);
-      bf16x8 bfrag[2];
+      bf16x8 bfrag[NJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         union {
           bf16x8 v;
           s16x4 h[2];
@@ -196,10 +202,25 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
         for (int i = 0; i < 2; ++i) {
           const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
+#ifdef GP_NO_MFMA
+            acc[i][j][0] += (float)afrag[0] + (float)bfrag[j][0];
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+#endif
         }
     }
+#else
+    {                                          // probe: the MFMA stream alone, operands from registers
+      bf16x8 af, bfr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) af[e] = bfr[e] = (__bf16)1.0f;
+#pragma unroll
+      for (int rep = 0; rep < 2 * TERMS * 2; ++rep)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[rep & 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[rep & 1][j], 0, 0, 0);
+    }
+#endif
     __syncthreads();
   }
   if (KG > 1) {
@@ -227,16 +248,20 @@ __global__ __launch_bounds__(128 * WM * KG) void sgemm_bf16_kernel(const unsigne
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (NJ * 32) + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#ifdef GP_NO_STORE
+        if (row < M && col < N && acc[i][j][r] == 123.456f) Yb[0] = 1.f;
+#else
         if (row < M && col < N) {
           float v = acc[i][j][r];
           if (bias) v += bias[row];
           Yb[(int64_t)row * N + col] = ex.general ? v * ex.out_scale : v;
         }
+#endif
       }
     }
 }
@@ -416,23 +441,29 @@ int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, cons
   S2F_REQUIRE(batch < 65536, S2F_EINVAL, "%s: batch too large", who);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = (N + BN - 1) / BN;
+  static const int s_min_blocks = getenv("S2F_GEMM_MINBLOCKS") ? atoi(getenv("S2F_GEMM_MINBLOCKS")) : 512;   // probe switch
   int wm = 1;
   for (int cand = 4; cand >= 1; cand >>= 1) {          // tile choice as in gemm.hip
     if (Mpad % (64 * cand) != 0) continue;
     if (cand > 1 && M <= 32 * cand) continue;
     const int64_t blocks = (int64_t)n_tiles * (Mpad / (64 * cand)) * batch;
-    if (blocks >= 512 || cand == 1) {
+    // one workgroup per CU is enough for the larger tile: measured (tools/micro/gemm_fwd_probe.hip) [512x512]@[8x512x1024]
+    // 28.7 us as 512 tiles of 64 rows, 23.9 us as 256 tiles of 128 rows; [512x1536] 68.5 -> 55.9 us
+    if (blocks >= s_min_blocks || cand == 1) {
       wm = cand;
       break;
     }
   }
   static const char* force_wm = getenv("S2F_GEMM_WM");           // probe switch
-  if (force_wm && Mpad % (64 * atoi(force_wm)) == 0) wm = atoi(force_wm);
+  if (force_wm && atoi(force_wm) > 0 && Mpad % (64 * atoi(force_wm)) == 0) wm = atoi(force_wm);
   const int m_tiles = Mpad / (64 * wm);
   const dim3 grid(n_tiles * m_tiles, batch);
   const bool thin = wm == 1 && (int64_t)n_tiles * m_tiles * batch < 512;
   const int kg = (thin && Kpad >= 4 * BK) ? 2 : 1;
   const bool wide = !conv && (N & 7) == 0;              // 16-byte chunks
+  // (A 64 x 128 wavefront tile -- WNW = 1, half the wavefronts, 37 % less LDS read traffic per MFMA -- measured SLOWER:
+  // [512x1152]@[8x1152x4096] 119 -> 149 us, [256x256]@[8x256x16384] 67 -> 89 us (tools/micro/gemm_fwd_probe.hip): the loop
+  // is bound by the latency of its LDS reads and barriers at two wavefronts per SIMD, not by LDS bandwidth.)
 #define S2F_GO(WMV, TV, CHV, CV, KGV)                                                                                    \
   S2F_LAUNCH(true, true, (sgemm_bf16_kernel<WMV, TV, CHV, CV, KGV>), grid, dim3(128 * WMV * KGV), 0, s, w_split, X, bias, Y, \
              M, N, K, Mpad, Kpad, n_tiles, m_tiles, geo, ex)
