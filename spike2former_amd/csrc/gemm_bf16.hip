@@ -459,7 +459,9 @@ int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, cons
   const int m_tiles = Mpad / (64 * wm);
   const dim3 grid(n_tiles * m_tiles, batch);
   const bool thin = wm == 1 && (int64_t)n_tiles * m_tiles * batch < 512;
-  const int kg = (thin && Kpad >= 4 * BK) ? 2 : 1;
+  // thin launches (fewer than 512 workgroups of 2 wavefronts) are one dependent load -> LDS -> MFMA chain per K step: the
+  // contraction is split over 2 or 4 groups of wavefronts inside the workgroup (summed through LDS in a fixed order)
+  const int kg = !thin ? 1 : (Kpad >= 16 * BK ? 4 : (Kpad >= 4 * BK ? 2 : 1));
   const bool wide = !conv && (N & 7) == 0;              // 16-byte chunks
   // (A 64 x 128 wavefront tile -- WNW = 1, half the wavefronts, 37 % less LDS read traffic per MFMA -- measured SLOWER:
   // [512x1152]@[8x1152x4096] 119 -> 149 us, [256x256]@[8x256x16384] 67 -> 89 us (tools/micro/gemm_fwd_probe.hip): the loop
@@ -476,6 +478,8 @@ int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, cons
     S2F_T(4, CHV, CV, 1);     \
   } else if (wm == 2) {       \
     S2F_T(2, CHV, CV, 1);     \
+  } else if (kg == 4) {       \
+    S2F_T(1, CHV, CV, 4);     \
   } else if (kg == 2) {       \
     S2F_T(1, CHV, CV, 2);     \
   } else {                    \
