@@ -309,45 +309,104 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     ctap[h] = CONV ? k / geo.C : 0;
     crow[h] = CONV ? k - ctap[h] * geo.C : 0;
   }
+  // Per-lane element offsets inside the (batch element, K step) slab, fixed for the whole kernel; the slab origin is a
+  // wave-uniform pointer, so a load is "scalar base + 32-bit lane offset" with no per-step address arithmetic on the VALU
+  // (the flat 64-bit form cost 32 v_mul_lo_u32 + 32 64-bit multiply-adds per wavefront and step -- about the MFMA time).
+  unsigned int oa[NHA], ox[NH];                 // row part of the offset (elements)
+  int lq[NH];
+  bool rok_a[NHA], rok_x[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int c = tid + h * 256;
+    const int row = c / QPR;
+    lq[h] = (c % QPR) * 4;
+    if (h < NHA) {
+      rok_a[h < NHA ? h : 0] = m0 + row < M;
+      oa[h < NHA ? h : 0] = (unsigned int)min(row, M - 1 - m0) * (unsigned int)L;
+    }
+    rok_x[h] = k0 + row < K;
+    ox[h] = (unsigned int)min(row, K - 1 - k0) * (unsigned int)L;
+  }
   auto fetch = [&](int step, f32x4 (&a)[NHA], u32x2 (&bq)[NH]) {
     const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
+    const float* pa = dY + ((int64_t)b * M + m0) * L;                            // wave-uniform
+    const unsigned short* px = X + ((int64_t)b * K + k0) * L;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      const int c = tid + h * 256;
-      const int row = c / QPR, l = l0 + (c % QPR) * 4;
+      // Unconditional loads from clamped addresses, zeroed by a select: a load under a branch makes the number of loads in
+      // flight unknown to the compiler, which then waits with s_waitcnt vmcnt(0) -- i.e. also for the NEWEST prefetch.
+      const int l = l0 + lq[h];
       const bool lok = l < L;
-      if (h < NHA)
-        a[h < NHA ? h : 0] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned int col = (unsigned int)min(l, L - 4);          // L % 4 == 0, L >= 4
+      // raw loads only: the out-of-range lanes are zeroed in stage(), one K step later -- with the select next to the load
+      // the compiler sinks the load under the predicate and waits for it on the spot
+      if (h < NHA) a[h < NHA ? h : 0] = *reinterpret_cast<const f32x4*>(pa + (oa[h < NHA ? h : 0] + col));
       if constexpr (CONV) {
-        const bool ok = lok && k0 + row < K;
+        const bool ok = lok && rok_x[h];
         bq[h] = conv3_load_bf16(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3,
                                 ctap[h] % 3, geo, ok);
       } else {
-        bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const u32x2*>(X + ((int64_t)b * K + k0 + row) * L + l)
-                                      : u32x2{0u, 0u};
+        bq[h] = *reinterpret_cast<const u32x2*>(px + (ox[h] + col));
       }
     }
   };
-  fetch(s_begin, areg, breg);
-  for (int step = s_begin; step < s_end; ++step) {
+  auto stage = [&](int step, const f32x4 (&a)[NHA], const u32x2 (&bq)[NH]) __attribute__((always_inline)) {
+    const int l0s = (step - (step / lsteps) * lsteps) * BKV;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int c = tid + h * 256;
       const int row = c / QPR, col = (c % QPR) * 4;
+      const bool lok = l0s + lq[h] < L;
       if (h < NHA) {
-        const f32x4 av = areg[h < NHA ? h : 0];
+        const f32x4 av = (lok && rok_a[h < NHA ? h : 0]) ? a[h < NHA ? h : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned int h0, m0_, l0_, h1, m1, l1;
+#ifdef GP_NO_SPLIT
+        h0 = m0_ = l0_ = __float_as_uint(av.x) ^ __float_as_uint(av.y);
+        h1 = m1 = l1 = __float_as_uint(av.z) ^ __float_as_uint(av.w);
+#else
         s2f_split3x2(av.x, av.y, h0, m0_, l0_);
         s2f_split3x2(av.z, av.w, h1, m1, l1);
+#endif
         *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
       }
-      *reinterpret_cast<u32x2*>(&Bs[row][col]) = breg[h];
+      *reinterpret_cast<u32x2*>(&Bs[row][col]) = (CONV || (lok && rok_x[h])) ? bq[h] : u32x2{0u, 0u};
     }
-    __syncthreads();
-    if (step + 1 < s_end) fetch(step + 1, areg, breg);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+#ifndef GP_NO_LDSREAD
+#ifdef DW_FRAG_PIPE
+    constexpr int KS = BKV / 16;
+    bf16x8 afr[2][3][MI], bfr2[2][NJ];
+    auto ldfrag = [&](int ks, int buf) __attribute__((always_inline)) {
+      const int kof = ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bfr2[buf][j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * (NJ * 32) + j * 32 + (lane & 31)][kof]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          afr[buf][t][i] = *reinterpret_cast<const bf16x8*>(&As[t][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
+    };
+    ldfrag(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) ldfrag(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks & 1][t][i], bfr2[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    // (Requesting the fragments of sub-step ks + 1 before the MFMAs of sub-step ks -- two register sets, s_waitcnt lgkmcnt(n)
+    // counting down instead of lgkmcnt(0) before every pair of MFMAs -- measured no gain: 184.8 vs 180.6 us.)
 #pragma unroll
     for (int ks = 0; ks < BKV / 16; ++ks) {
       const int kof = ks * 16 + 8 * (lane >> 5);
@@ -359,14 +418,67 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+#ifdef GP_A_ONE_TERM
+          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[0][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
+#else
           const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
+#endif
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
+#ifdef GP_NO_MFMA
+            acc[i][j][0] += (float)afrag[0] + (float)bfrag[j][0];
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+#endif
         }
     }
+#endif
+#else
+    {
+      bf16x8 af, bfr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) af[e] = bfr[e] = (__bf16)1.0f;
+#pragma unroll
+      for (int rep = 0; rep < (BKV / 16) * 3; ++rep)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i][j], 0, 0, 0);
+    }
+#endif
+  };
+#ifdef DW_PREFETCH2
+  // Two register sets, each fetched TWO K steps ahead of its use: a step lasts ~0.35 us, a global load 1-2 us.
+  f32x4 areg2[NHA];
+  u32x2 breg2[NH];
+  fetch(s_begin, areg, breg);
+  if (s_begin + 1 < s_end) fetch(s_begin + 1, areg2, breg2);
+  for (int step = s_begin; step < s_end; step += 2) {
+    stage(step, areg, breg);
+    __syncthreads();
+    if (step + 2 < s_end) fetch(step + 2, areg, breg);
+    compute();
+    __syncthreads();
+    if (step + 1 < s_end) {
+      stage(step + 1, areg2, breg2);
+      __syncthreads();
+      if (step + 3 < s_end) fetch(step + 3, areg2, breg2);
+      compute();
+      __syncthreads();
+    }
+  }
+#else
+  fetch(s_begin, areg, breg);
+  for (int step = s_begin; step < s_end; ++step) {
+    stage(step, areg, breg);
+    __syncthreads();
+#ifndef GP_NO_GLOBAL
+    if (step + 1 < s_end) fetch(step + 1, areg, breg);
+#endif
+    compute();
     __syncthreads();
   }
+#endif
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -375,7 +487,11 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#ifdef GP_NO_STORE
+        if (row < M && col < K && acc[i][j][r] == 123.456f) dW[0] = 1.f;
+#else
         if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
+#endif
       }
     }
 }
