@@ -24,17 +24,30 @@ constexpr int LDA = 40;          // A rows in LDS: 32 + 8 bf16 = 80 bytes (confl
 
 // 4 consecutive pixels n .. n+3 of one bf16 plane shifted by the 3x3 tap: ONE 8-byte load at 2-byte alignment; the pixel
 // that falls off the image row at its left / right end is zeroed, a row outside the plane reads as zeros.
+// Split in three so that the LOAD can be issued a K step ahead with nothing depending on it: the predicate, the (always
+// valid) element offset, and the fix-up applied when the tile is staged.  With the select next to the load the compiler
+// sinks the load under the predicate and waits for it on the spot (s_waitcnt vmcnt(0) per load).
+struct Conv3Pred {
+  bool ok, cut_l, cut_r;
+};
+__device__ __forceinline__ Conv3Pred conv3_pred(int y, int x, int ky, int kx, Conv3 g, bool ok) {
+  const int yy = y + ky - 1;
+  return Conv3Pred{ok && yy >= 0 && yy < g.H, kx == 0 && x == 0, kx == 2 && x + 4 == g.W};
+}
+// never addresses outside the plane: at a cut end the aligned neighbour group is loaded and shifted in registers
+__device__ __forceinline__ int conv3_off(int n, int ky, int kx, Conv3 g, Conv3Pred p) {
+  return p.ok ? n + (ky - 1) * g.W + (kx - 1) + (p.cut_l ? 1 : 0) - (p.cut_r ? 1 : 0) : 0;
+}
+__device__ __forceinline__ u32x2 conv3_fix(u32x2 v, Conv3Pred p) {
+  if (!p.ok) return u32x2{0u, 0u};
+  if (p.cut_l) return u32x2{v.x << 16, (v.y << 16) | (v.x >> 16)};          // {0, p0, p1, p2}
+  if (p.cut_r) return u32x2{(v.x >> 16) | (v.y << 16), v.y >> 16};          // {p1, p2, p3, 0}
+  return v;
+}
 __device__ __forceinline__ u32x2 conv3_load_bf16(const unsigned short* __restrict__ plane, int n, int y, int x, int ky,
                                                  int kx, Conv3 g, bool ok) {
-  const int yy = y + ky - 1;
-  ok = ok && yy >= 0 && yy < g.H;
-  const bool cut_l = kx == 0 && x == 0, cut_r = kx == 2 && x + 4 == g.W;
-  // never address outside the plane: at a cut end load the aligned neighbour group and shift in registers
-  const int off = (ky - 1) * g.W + (kx - 1) + (cut_l ? 1 : 0) - (cut_r ? 1 : 0);
-  const u32x2 v = ok ? *reinterpret_cast<const u32x2*>(plane + (ok ? n + off : 0)) : u32x2{0u, 0u};
-  if (cut_l) return u32x2{v.x << 16, (v.y << 16) | (v.x >> 16)};          // {0, p0, p1, p2}
-  if (cut_r) return u32x2{(v.x >> 16) | (v.y << 16), v.y >> 16};          // {p1, p2, p3, 0}
-  return v;
+  const Conv3Pred p = conv3_pred(y, x, ky, kx, g, ok);
+  return conv3_fix(*reinterpret_cast<const u32x2*>(plane + conv3_off(n, ky, kx, g, p)), p);
 }
 
 // General form of the forward kernel (the mask contraction with the mask_feature convolution folded into it, ops.py):
@@ -138,8 +151,14 @@ __global__ __launch_bounds__(64 * WNW * WM * KG) void sgemm_bf16_kernel(const un
       const int n = n0 + nc * CH;
       const bool ok = live && kk + kr < K && n < N;          // N % CH == 0: a chunk is valid as a whole
       if constexpr (CONV) {
+        // raw load; the border fix-up happens when the tile is staged (conv3_fix), one K step later
         const int py = n / geo.W, px = n - py * geo.W;
+#ifdef S2F_CONV_PRED_LOADS
         breg[q] = conv3_load_bf16(Xb + (int64_t)(ok ? c0 + kr : 0) * N, n, py, px, ky, kx, geo, ok);
+#else
+        const Conv3Pred pr = conv3_pred(py, px, ky, kx, geo, ok);
+        breg[q] = *reinterpret_cast<const chunk_t*>(Xb + (int64_t)(ok ? c0 + kr : 0) * N + conv3_off(n, ky, kx, geo, pr));
+#endif
       } else {
         chunk_t z;
 #pragma unroll
@@ -175,7 +194,16 @@ __global__ __launch_bounds__(64 * WNW * WM * KG) void sgemm_bf16_kernel(const un
       const int p = tid + q * T;
       const int kr = p / CPR, nc = p % CPR;
       constexpr int CPC = 32 / CH;                        // chunks per 64-byte swizzle unit
-      *reinterpret_cast<chunk_t*>(Bs + kr * BN + ((((nc / CPC) ^ (kr & 3))) << 5) + (nc % CPC) * CH) = breg[q];
+      chunk_t bv = breg[q];
+#ifndef S2F_CONV_PRED_LOADS
+      if constexpr (CONV) {
+        const int tap = k0 / geo.C, ky = tap / 3, kx = tap - 3 * ky;
+        const int n = n0 + nc * CH, py = n / geo.W, px = n - py * geo.W;
+        const bool ok = (KG == 1 || k0 < Kpad) && k0 + kr < K && n < N;
+        bv = conv3_fix(bv, conv3_pred(py, px, ky, kx, geo, ok));
+      }
+#endif
+      *reinterpret_cast<chunk_t*>(Bs + kr * BN + ((((nc / CPC) ^ (kr & 3))) << 5) + (nc % CPC) * CH) = bv;
     }
     __syncthreads();
 #ifndef GP_NO_GLOBAL
@@ -342,9 +370,13 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       // the compiler sinks the load under the predicate and waits for it on the spot
       if (h < NHA) a[h < NHA ? h : 0] = *reinterpret_cast<const f32x4*>(pa + (oa[h < NHA ? h : 0] + col));
       if constexpr (CONV) {
-        const bool ok = lok && rok_x[h];
-        bq[h] = conv3_load_bf16(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3,
-                                ctap[h] % 3, geo, ok);
+#ifdef S2F_CONV_PRED_LOADS
+        bq[h] = conv3_load_bf16(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo,
+                                lok && rok_x[h]);
+#else
+        const Conv3Pred pr = conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]);
+        bq[h] = *reinterpret_cast<const u32x2*>(X + ((int64_t)b * geo.C + crow[h]) * L + conv3_off(l, ctap[h] / 3, ctap[h] % 3, geo, pr));
+#endif
       } else {
         bq[h] = *reinterpret_cast<const u32x2*>(px + (ox[h] + col));
       }
@@ -371,7 +403,17 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
         *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
       }
-      *reinterpret_cast<u32x2*>(&Bs[row][col]) = (CONV || (lok && rok_x[h])) ? bq[h] : u32x2{0u, 0u};
+      if constexpr (CONV) {
+#ifdef S2F_CONV_PRED_LOADS
+        *reinterpret_cast<u32x2*>(&Bs[row][col]) = bq[h];
+#else
+        const int l = l0s + lq[h];
+        *reinterpret_cast<u32x2*>(&Bs[row][col]) =
+            conv3_fix(bq[h], conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]));
+#endif
+      } else {
+        *reinterpret_cast<u32x2*>(&Bs[row][col]) = (lok && rok_x[h]) ? bq[h] : u32x2{0u, 0u};
+      }
     }
   };
   auto compute = [&]() __attribute__((always_inline)) {
