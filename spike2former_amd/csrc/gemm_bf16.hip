@@ -418,35 +418,6 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
   };
   auto compute = [&]() __attribute__((always_inline)) {
 #ifndef GP_NO_LDSREAD
-#ifdef DW_FRAG_PIPE
-    constexpr int KS = BKV / 16;
-    bf16x8 afr[2][3][MI], bfr2[2][NJ];
-    auto ldfrag = [&](int ks, int buf) __attribute__((always_inline)) {
-      const int kof = ks * 16 + 8 * (lane >> 5);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        bfr2[buf][j] = *reinterpret_cast<const bf16x8*>(&Bs[wn * (NJ * 32) + j * 32 + (lane & 31)][kof]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          afr[buf][t][i] = *reinterpret_cast<const bf16x8*>(&As[t][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
-    };
-    ldfrag(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) ldfrag(ks + 1, (ks + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks & 1][t][i], bfr2[ks & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#else
     // (Requesting the fragments of sub-step ks + 1 before the MFMAs of sub-step ks -- two register sets, s_waitcnt lgkmcnt(n)
     // counting down instead of lgkmcnt(0) before every pair of MFMAs -- measured no gain: 184.8 vs 180.6 us.)
 #pragma unroll
@@ -474,7 +445,6 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
 #endif
         }
     }
-#endif
 #else
     {
       bf16x8 af, bfr;
@@ -489,27 +459,7 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     }
 #endif
   };
-#ifdef DW_PREFETCH2
-  // Two register sets, each fetched TWO K steps ahead of its use: a step lasts ~0.35 us, a global load 1-2 us.
-  f32x4 areg2[NHA];
-  u32x2 breg2[NH];
-  fetch(s_begin, areg, breg);
-  if (s_begin + 1 < s_end) fetch(s_begin + 1, areg2, breg2);
-  for (int step = s_begin; step < s_end; step += 2) {
-    stage(step, areg, breg);
-    __syncthreads();
-    if (step + 2 < s_end) fetch(step + 2, areg, breg);
-    compute();
-    __syncthreads();
-    if (step + 1 < s_end) {
-      stage(step + 1, areg2, breg2);
-      __syncthreads();
-      if (step + 3 < s_end) fetch(step + 3, areg2, breg2);
-      compute();
-      __syncthreads();
-    }
-  }
-#else
+  // (Two register sets fetched TWO steps ahead: no gain in the probe or in the step -- 45.76/45.81 vs 45.83/45.82 ms.)
   fetch(s_begin, areg, breg);
   for (int step = s_begin; step < s_end; ++step) {
     stage(step, areg, breg);
@@ -520,7 +470,6 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     compute();
     __syncthreads();
   }
-#endif
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
