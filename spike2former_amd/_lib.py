@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2f_hip.so")
+LIB_PATH = os.environ.get("S2F_LIB") or os.path.join(_HERE, "libs2f_hip.so")      # S2F_LIB: another build of the same ABI (A/B runs)
 
 _p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 

@@ -138,17 +138,29 @@ struct Conv3 {
 
 // 4 consecutive pixels n .. n+3 of one plane, shifted by the tap: ONE (generally unaligned) 16-byte load; the pixel that
 // falls off the row at its left / right end is zeroed, a row outside the plane reads as zeros.  `plane` = channel plane base.
+// Split in three (predicate, always-valid offset, fix-up) so that a prefetch is a bare load with nothing depending on it:
+// with the select next to the load the compiler sinks the load under the predicate and waits for it on the spot.
+struct Conv3PredF {
+  bool ok, cut_l, cut_r;
+};
+__device__ __forceinline__ Conv3PredF conv3f_pred(int y, int x, int ky, int kx, Conv3 g, bool ok) {
+  const int yy = y + ky - 1;
+  return Conv3PredF{ok && yy >= 0 && yy < g.H, kx == 0 && x == 0, kx == 2 && x + 4 == g.W};
+}
+// never addresses outside the plane: at a cut end the aligned neighbour group is loaded and shifted in registers
+__device__ __forceinline__ int conv3f_off(int n, int ky, int kx, Conv3 g, Conv3PredF p) {
+  return p.ok ? n + (ky - 1) * g.W + (kx - 1) + (p.cut_l ? 1 : 0) - (p.cut_r ? 1 : 0) : 0;
+}
+__device__ __forceinline__ f32x4 conv3f_fix(f32x4 v, Conv3PredF p) {
+  if (!p.ok) return f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.cut_l) return f32x4{0.f, v.x, v.y, v.z};
+  if (p.cut_r) return f32x4{v.y, v.z, v.w, 0.f};
+  return v;
+}
 __device__ __forceinline__ f32x4 conv3_load(const float* __restrict__ plane, int n, int y, int x, int ky, int kx, Conv3 g,
                                             bool ok) {
-  const int yy = y + ky - 1;
-  ok = ok && yy >= 0 && yy < g.H;
-  const bool cut_l = kx == 0 && x == 0, cut_r = kx == 2 && x + 4 == g.W;
-  // never address outside the plane: at a cut end load the aligned neighbour group and shift in registers
-  const int off = (ky - 1) * g.W + (kx - 1) + (cut_l ? 1 : 0) - (cut_r ? 1 : 0);
-  const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(plane + (ok ? n + off : 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-  if (cut_l) return f32x4{0.f, v.x, v.y, v.z};
-  if (cut_r) return f32x4{v.y, v.z, v.w, 0.f};
-  return v;
+  const Conv3PredF p = conv3f_pred(y, x, ky, kx, g, ok);
+  return conv3f_fix(*reinterpret_cast<const f32x4*>(plane + conv3f_off(n, ky, kx, g, p)), p);
 }
 
 // global -> registers for the K step starting at kk (issued one step ahead of its use: the loads fly under the MFMAs)
@@ -410,11 +422,14 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
       for (int r = 0; r < 4; ++r) {
         const int k = kk + kb * 4 + r;
         const bool ok = p < 256 && k < K && n < N;
+        // bare loads from always-valid addresses; zeroing / border fix-up when the tile is staged (see conv3f_fix)
         if (CONV) {
-          breg[q][r] = conv3_load(Xb + (int64_t)(ok ? c0 + kb * 4 + r : 0) * N, n, py, px, ky, kx, geo, ok);
+          const Conv3PredF pr = conv3f_pred(py, px, ky, kx, geo, ok);
+          breg[q][r] = *reinterpret_cast<const f32x4*>(Xb + (int64_t)(ok ? c0 + kb * 4 + r : 0) * N + conv3f_off(n, ky, kx, geo, pr));
         } else {
-          const float* row = Xb + (int64_t)(k / k_inner) * x_outer_stride + (int64_t)(k % k_inner) * N;
-          breg[q][r] = ok ? *reinterpret_cast<const f32x4*>(row + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const int kc_ = ok ? k : 0;
+          const float* row = Xb + (int64_t)(kc_ / k_inner) * x_outer_stride + (int64_t)(kc_ % k_inner) * N;
+          breg[q][r] = *reinterpret_cast<const f32x4*>(row + (ok ? n : 0));
         }
       }
     }
@@ -434,11 +449,25 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
       if (p < 256) {
         const int kb = p / (BN / 4), nb = p % (BN / 4);
         const int kc = ((((kb >> 1) ^ (nb >> 2)) & 3) << 3) + ((kb & 1) << 2);          // swizzle as in spike_gemm_kernel
+        f32x4 bv[4];
+        {
+          const int n = n0 + nb * 4;
+          const int py = CONV ? n / geo.W : 0, px = CONV ? n - py * geo.W : 0;
+          const int tap = CONV ? k0 / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = k0 + kb * 4 + r < K && n < N;
+            if (CONV)
+              bv[r] = conv3f_fix(breg[q][r], conv3f_pred(py, px, ky, kx, geo, ok));
+            else
+              bv[r] = ok ? breg[q][r] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned int h0, m0_, l0_, h1, m1, l1;
-          split3x2(breg[q][0][e], breg[q][1][e], h0, m0_, l0_);
-          split3x2(breg[q][2][e], breg[q][3][e], h1, m1, l1);
+          split3x2(bv[0][e], bv[1][e], h0, m0_, l0_);
+          split3x2(bv[2][e], bv[3][e], h1, m1, l1);
           *reinterpret_cast<u32x2*>(&Bs[0][nb * 4 + e][kc]) = u32x2{h0, h1};
           if (BT > 1) *reinterpret_cast<u32x2*>(&Bs[BT > 1 ? 1 : 0][nb * 4 + e][kc]) = u32x2{m0_, m1};
           if (BT > 2) *reinterpret_cast<u32x2*>(&Bs[BT > 2 ? 2 : 0][nb * 4 + e][kc]) = u32x2{l0_, l1};
