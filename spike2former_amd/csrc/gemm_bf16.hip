@@ -160,14 +160,13 @@ __global__ __launch_bounds__(64 * WNW * WM * KG) void sgemm_bf16_kernel(const un
         breg[q] = *reinterpret_cast<const chunk_t*>(Xb + (int64_t)(ok ? c0 + kr : 0) * N + conv3_off(n, ky, kx, geo, pr));
 #endif
       } else {
-        chunk_t z;
-#pragma unroll
-        for (int e = 0; e < CH / 2; ++e) z[e] = 0u;
         // general form: row r of the contraction lies in slab r / k_inner (slabs x_outer_stride apart; k_inner % 32 == 0, so
         // a K step never straddles two slabs)
+        // bare load from an always-valid address (row / column 0 when out of range); zeroed when the tile is staged
+        const int krc = ok ? kr : -kk;                      // kk + krc == 0
         const int64_t rowoff = ex.general ? (int64_t)(kk / ex.k_inner) * ex.x_outer_stride + (int64_t)(kk % ex.k_inner + kr) * N
-                                          : (int64_t)(kk + kr) * N;
-        breg[q] = ok ? *reinterpret_cast<const chunk_t*>(Xb + rowoff + n) : z;
+                                          : (int64_t)(kk + krc) * N;
+        breg[q] = *reinterpret_cast<const chunk_t*>(Xb + (ex.general && !ok ? 0 : rowoff) + (ok ? n : 0));
       }
     }
   };
@@ -195,6 +194,13 @@ __global__ __launch_bounds__(64 * WNW * WM * KG) void sgemm_bf16_kernel(const un
       const int kr = p / CPR, nc = p % CPR;
       constexpr int CPC = 32 / CH;                        // chunks per 64-byte swizzle unit
       chunk_t bv = breg[q];
+      if constexpr (!CONV) {
+        const bool ok = (KG == 1 || k0 < Kpad) && k0 + kr < K && n0 + nc * CH < N;
+        if (!ok) {
+#pragma unroll
+          for (int e = 0; e < CH / 2; ++e) bv[e] = 0u;
+        }
+      }
 #ifndef S2F_CONV_PRED_LOADS
       if constexpr (CONV) {
         const int tap = k0 / geo.C, ky = tap / 3, kx = tap - 3 * ky;
