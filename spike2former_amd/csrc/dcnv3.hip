@@ -249,6 +249,25 @@ __device__ __forceinline__ unsigned long long fix64(float v) {
 
 constexpr int kChunk = 256;   // output pixels whose offsets / mask / grad_output are staged in LDS at a time
 
+// for e in [tid, n) step blockDim: use(e, load(e)) -- with the loads of U iterations issued TOGETHER from always-valid
+// (clamped) indices.  Written as a plain loop with a run-time trip count, every iteration is a dependent global round trip
+// (load, wait, use): the staging loops of the backward kernel were ~40 such round trips per workgroup, with one workgroup
+// per CU and nothing else to run meanwhile.
+template <int U, typename Load, typename Use>
+__device__ __forceinline__ void grouped_loads(int n, Load load, Use use) {
+  if (n <= 0) return;
+  for (int e0 = threadIdx.x; e0 < n; e0 += U * (int)blockDim.x) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = load(min(e0 + u * (int)blockDim.x, n - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      if (e < n) use(e, v[u]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restrict__ in, const float* __restrict__ off,
                                                           const float* __restrict__ msk, const float* __restrict__ gout,
                                                           float* __restrict__ gin, float* __restrict__ goff,
@@ -268,16 +287,17 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
   float* s_go = s_msk + kChunk * P;         // [kChunk][Cg]
   const float* inb = in + (int64_t)n * npix_in * C + gi * Cg;
   const float* gob = gout + (int64_t)n * npix_out * C + gi * Cg;
-  for (int e = threadIdx.x; e < npix_in * Cg; e += blockDim.x) {
-    const int p = e / Cg, c = e % Cg;
-    s_in[e] = inb[(int64_t)p * C + c];
-    s_acc[p * CA + c] = 0ull;
-  }
+  grouped_loads<8>(npix_in * Cg, [&](int e) { return inb[(int64_t)(e / Cg) * C + e % Cg]; },
+                   [&](int e, float v) {
+                     s_in[e] = v;
+                     s_acc[(e / Cg) * CA + e % Cg] = 0ull;
+                   });
   // scale of this slice: max|grad_output| * max|mask| bounds every contribution
   float mg = 0.f, mm = 0.f;
-  for (int e = threadIdx.x; e < npix_out * Cg; e += blockDim.x) mg = fmaxf(mg, fabsf(gob[(int64_t)(e / Cg) * C + e % Cg]));
-  for (int e = threadIdx.x; e < npix_out * P; e += blockDim.x)
-    mm = fmaxf(mm, fabsf(msk[(((int64_t)n * npix_out + e / P) * g.G + gi) * P + e % P]));
+  grouped_loads<8>(npix_out * Cg, [&](int e) { return gob[(int64_t)(e / Cg) * C + e % Cg]; },
+                   [&](int, float v) { mg = fmaxf(mg, fabsf(v)); });
+  grouped_loads<8>(npix_out * P, [&](int e) { return msk[(((int64_t)n * npix_out + e / P) * g.G + gi) * P + e % P]; },
+                   [&](int, float v) { mm = fmaxf(mm, fabsf(v)); });
   for (int o = 32; o > 0; o >>= 1) {
     mg = fmaxf(mg, __shfl_xor(mg, o, 64));
     mm = fmaxf(mm, __shfl_xor(mm, o, 64));
@@ -306,15 +326,11 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
     // The offsets / mask / grad_output of a pixel chunk are staged with one bulk load (every thread of the 16 waves
     // issues its loads at once) instead of a dependent global round trip per item.
     const int pc = min(kChunk, npix_out - p0);
-    for (int e = threadIdx.x; e < pc * P * 2; e += blockDim.x) {
-      const int pp = e / (P * 2), j = e % (P * 2);
-      s_off[e] = off[(((int64_t)n * npix_out + p0 + pp) * g.G + gi) * P * 2 + j];
-    }
-    for (int e = threadIdx.x; e < pc * P; e += blockDim.x) {
-      const int pp = e / P, j = e % P;
-      s_msk[e] = msk[(((int64_t)n * npix_out + p0 + pp) * g.G + gi) * P + j];
-    }
-    for (int e = threadIdx.x; e < pc * Cg; e += blockDim.x) s_go[e] = gob[(int64_t)(p0 + e / Cg) * C + e % Cg];
+    grouped_loads<5>(pc * P * 2, [&](int e) { return off[(((int64_t)n * npix_out + p0 + e / (P * 2)) * g.G + gi) * P * 2 + e % (P * 2)]; },
+                     [&](int e, float v) { s_off[e] = v; });
+    grouped_loads<3>(pc * P, [&](int e) { return msk[(((int64_t)n * npix_out + p0 + e / P) * g.G + gi) * P + e % P]; },
+                     [&](int e, float v) { s_msk[e] = v; });
+    grouped_loads<2>(pc * Cg, [&](int e) { return gob[(int64_t)(p0 + e / Cg) * C + e % Cg]; }, [&](int e, float v) { s_go[e] = v; });
     __syncthreads();
     // Work item = (tap, pixel of the chunk), one per thread, the Cg channels in an inner loop: the tap geometry is computed
     // once per item.  (Spreading the channels of an item over Cg adjacent lanes -- conflict-free LDS adds -- mattered with
