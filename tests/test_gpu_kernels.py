@@ -805,3 +805,24 @@ def test_bf16_spike_storage_needs_a_power_of_two_D():
     assert rc != 0
     with pytest.raises(S2FError):
         ops.check(rc, "s2f_lif_fwd")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,M,K,L", [(2, 130, 300, 260), (3, 256, 256, 1024), (1, 97, 1152, 520), (8, 128, 4608, 64), (5, 512, 512, 36)])
+def test_wide_weight_gradient_producer_consumer_kernel(B, M, K, L):
+    """The 128 x 256-tile producer / consumer weight gradient (K >= 256) against the fp64 contraction: ragged M / K / L, odd
+    and even step counts per split, fresh and accumulating destinations; 2e-6 of the scale per product term."""
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 1000 + M + K + L)
+    gy = (torch.randn(B, M, L, generator=g) * torch.rand(B, M, 1, generator=g) * 10).cuda()
+    x = (torch.randint(0, 9, (B, K, L), generator=g).float() / 8).cuda().to(torch.bfloat16)
+    ref = torch.einsum("bml,bkl->mk", gy.double(), x.double())
+    scale = torch.einsum("bml,bkl->mk", gy.abs().double(), x.abs().double()).max().item()
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.full((M, K), float("nan"), device="cuda")
+    check(lib.s2f_spike_gemm_dw_bf16(gy.data_ptr(), x.data_ptr(), out.data_ptr(), B, M, K, L, 0, s), "dw")
+    assert (out.double() - ref).abs().max().item() <= 3e-6 * scale
+    base = torch.randn(M, K, generator=g).cuda()
+    acc = base.clone()
+    check(lib.s2f_spike_gemm_dw_bf16(gy.data_ptr(), x.data_ptr(), acc.data_ptr(), B, M, K, L, 1, s), "dw accumulate")
+    assert (acc.double() - (base.double() + ref)).abs().max().item() <= 3e-6 * scale + 1e-6 * base.abs().max().item()
