@@ -362,6 +362,9 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     ox[h] = (unsigned int)min(row, K - 1 - k0) * (unsigned int)L;
   }
   auto fetch = [&](int step, f32x4 (&a)[NHA], u32x2 (&bq)[NH]) {
+#ifdef GP_SAME_SLAB
+    step = 0;                                       // probe: every step re-reads the first slab (cache-resident operands)
+#endif
     const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
     const float* pa = dY + ((int64_t)b * M + m0) * L;                            // wave-uniform
     const unsigned short* px = X + ((int64_t)b * K + k0) * L;
@@ -493,12 +496,28 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     }
 }
 
+// Workgroup f of `total` runs on XCD f % 8 (round-robin dispatch); this gives XCD j a CONTIGUOUS range of logical ids.  The
+// weight gradient orders its workgroups tile-fastest inside a contraction split, so the workgroups of one XCD are the tiles
+// of the same few splits: they stream the same dY / X slices at the same time and share them through that XCD's L2.  With
+// the plain order the ~36 tiles of a split were spread over all eight L2s and every tile re-fetched its operands (885 MB of
+// L2 misses for 142 MB of operands on [512x1152] over [8x4096]: the kernel ran at that traffic, not at its MFMA rate).
+__device__ __forceinline__ int xcd_contiguous(int f, int total) {
+#ifdef S2F_DW_NO_XCD_ORDER
+  return f;
+#else
+  const int chunk = total >> 3, rem = total & 7;
+  const int xcd = f & 7, idx = f >> 3;
+  return xcd * chunk + min(xcd, rem) + idx;
+#endif
+}
+
 template <int BKV, bool CONV, int TM>
 __global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
                                                             const unsigned short* __restrict__ X, float* __restrict__ dW,
                                                             int B, int M, int K, int L, int steps_per_split, int k_tiles,
                                                             Conv3 geo, int log_w) {
-  dw_tile_body<BKV, CONV, TM>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, blockIdx.x, blockIdx.y);
+  const int id = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  dw_tile_body<BKV, CONV, TM>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, id % (int)gridDim.x, id / (int)gridDim.x);
 }
 
 // MANY weight gradients in ONE launch.  The 32x32- and 64x64-stage layers (and the decoder's 100-token layers) each owe a
@@ -523,200 +542,25 @@ struct DwJobTable {
 
 template <int BKV, int TM>
 __global__ __launch_bounds__(256) void sgemm_dw_grouped_kernel(const DwJobTable tab) {
-  int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= blockIdx.x (wave-uniform)
+  const int id = xcd_contiguous(blockIdx.x, gridDim.x);
+  int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= id (wave-uniform)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (tab.job[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (tab.job[mid].first_block <= id) lo = mid; else hi = mid - 1;
   }
   const DwJob& j = tab.job[lo];
-  const int local = blockIdx.x - j.first_block;
+  const int local = id - j.first_block;
   dw_tile_body<BKV, false, TM>(j.dY, j.X, j.dW, j.B, j.M, j.K, j.L, j.steps_per_split, j.k_tiles, Conv3{0, 0, 0}, 0,
                                local % j.tiles, local / j.tiles);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the weight gradient (K >= 256).  The kernels above run "stage, barrier, multiply, barrier" with
-// every wavefront doing both: the matrix pipe idles while the tile is converted and staged, and the two workgroups of a CU
-// fall into step with each other (tools/micro/gemm_dw_probe.hip: 180 us with the MFMAs, 159 us without them, 63 us for the MFMA
-// stream alone).  Here a 512-thread workgroup is split by role: wavefronts 4-7 PRODUCE -- prefetch dY / X three steps ahead,
-// split dY into its bf16 terms, write tile s+1 into one half of a double-buffered LDS -- while wavefronts 0-3 CONSUME tile s
-// from the other half (64 x 128 per wavefront: 2 x 4 MFMA tiles, A fragments reused four times).  One barrier per step; each
-// SIMD hosts one producer and one consumer wavefront, so VALU / LDS-write work and MFMA work overlap inside the workgroup
-// instead of between workgroups.  Output tile 128 x 256, K step 32, LDS 2 x 50 KiB.
-constexpr int WS_TM = 128, WS_TN = 256, WS_BK = 32, WS_LD = WS_BK + 8;
-constexpr int WS_A_ELEMS = 3 * WS_TM * WS_LD, WS_B_ELEMS = WS_TN * WS_LD;
-constexpr int WS_BUF_ELEMS = WS_A_ELEMS + WS_B_ELEMS;
-constexpr int WS_LDS_BYTES = 2 * WS_BUF_ELEMS * 2;
-
-template <bool CONV>
-__device__ __forceinline__ void dw_ws_body(const float* __restrict__ dY, const unsigned short* __restrict__ X,
-                                           float* __restrict__ dW, int B, int M, int K, int L, int steps_per_split, int k_tiles,
-                                           Conv3 geo, int log_w, int tile, int split, unsigned short* smem) {
-  const int m0 = (tile / k_tiles) * WS_TM, k0 = (tile % k_tiles) * WS_TN;
-  const int lsteps = (L + WS_BK - 1) / WS_BK;
-  const int total_steps = B * lsteps;
-  const int s_begin = split * steps_per_split;
-  const int s_end = min(total_steps, s_begin + steps_per_split);
-  if (s_begin >= s_end) return;                           // uniform over the workgroup
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto a_tile = [&](int buf, int t) { return smem + buf * WS_BUF_ELEMS + t * (WS_TM * WS_LD); };
-  auto b_tile = [&](int buf) { return smem + buf * WS_BUF_ELEMS + WS_A_ELEMS; };
-
-  if (wave >= 4) {
-    // ------------------------------------------------------------------ producers (256 threads)
-    const int pt = tid - 256;
-    constexpr int NA = WS_TM * (WS_BK / 4) / 256;          // 4 dY chunks (4 fp32) per thread and step
-    constexpr int NB = WS_TN * (WS_BK / 4) / 256;          // 8 X chunks (4 bf16) per thread and step
-    unsigned int oa[NA], ox[NB];
-    int lqa[NA], lqb[NB], rowa[NA], rowb[NB];
-    bool rok_a[NA], rok_x[NB];
-    int crow[NB], ctap[NB];
-#pragma unroll
-    for (int h = 0; h < NA; ++h) {
-      const int c = pt + h * 256;
-      rowa[h] = c >> 3;
-      lqa[h] = (c & 7) * 4;
-      rok_a[h] = m0 + rowa[h] < M;
-      oa[h] = (unsigned int)min(rowa[h], M - 1 - m0) * (unsigned int)L;
-    }
-#pragma unroll
-    for (int h = 0; h < NB; ++h) {
-      const int c = pt + h * 256;
-      rowb[h] = c >> 3;
-      lqb[h] = (c & 7) * 4;
-      rok_x[h] = k0 + rowb[h] < K;
-      ox[h] = (unsigned int)min(rowb[h], K - 1 - k0) * (unsigned int)L;
-      const int k = min(k0 + rowb[h], K - 1);
-      ctap[h] = CONV ? k / geo.C : 0;
-      crow[h] = CONV ? k - ctap[h] * geo.C : 0;
-    }
-    // bare loads from always-valid addresses (see dw_tile_body); predicates and the 3x3 border fix-up at staging time
-    auto fetch = [&](int step, f32x4 (&a)[NA], u32x2 (&bq)[NB]) __attribute__((always_inline)) {
-      const int b = step / lsteps, l0 = (step - b * lsteps) * WS_BK;
-      const float* pa = dY + ((int64_t)b * M + m0) * L;
-      const unsigned short* px = X + ((int64_t)b * K + k0) * L;
-#pragma unroll
-      for (int h = 0; h < NA; ++h) a[h] = *reinterpret_cast<const f32x4*>(pa + (oa[h] + (unsigned int)min(l0 + lqa[h], L - 4)));
-#pragma unroll
-      for (int h = 0; h < NB; ++h) {
-        const int l = l0 + lqb[h];
-        if constexpr (CONV) {
-          const Conv3Pred pr = conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, l < L && rok_x[h]);
-          bq[h] = *reinterpret_cast<const u32x2*>(X + ((int64_t)b * geo.C + crow[h]) * L + conv3_off(l, ctap[h] / 3, ctap[h] % 3, geo, pr));
-        } else {
-          bq[h] = *reinterpret_cast<const u32x2*>(px + (ox[h] + (unsigned int)min(l, L - 4)));
-        }
-      }
-    };
-    auto stage = [&](int step, int buf, const f32x4 (&a)[NA], const u32x2 (&bq)[NB]) __attribute__((always_inline)) {
-      const int l0 = (step - (step / lsteps) * lsteps) * WS_BK;
-#pragma unroll
-      for (int h = 0; h < NA; ++h) {
-        const bool ok = l0 + lqa[h] < L && rok_a[h];
-        const f32x4 av = ok ? a[h] : f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned int h0, m0_, l0_, h1, m1, l1;
-        s2f_split3x2(av.x, av.y, h0, m0_, l0_);
-        s2f_split3x2(av.z, av.w, h1, m1, l1);
-        const int o = rowa[h] * WS_LD + lqa[h];
-        *reinterpret_cast<u32x2*>(a_tile(buf, 0) + o) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(a_tile(buf, 1) + o) = u32x2{m0_, m1};
-        *reinterpret_cast<u32x2*>(a_tile(buf, 2) + o) = u32x2{l0_, l1};
-      }
-#pragma unroll
-      for (int h = 0; h < NB; ++h) {
-        const int l = l0 + lqb[h];
-        const bool ok = l < L && rok_x[h];
-        u32x2 v;
-        if constexpr (CONV)
-          v = conv3_fix(bq[h], conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, ok));
-        else
-          v = ok ? bq[h] : u32x2{0u, 0u};
-        *reinterpret_cast<u32x2*>(b_tile(buf) + rowb[h] * WS_LD + lqb[h]) = v;
-      }
-    };
-    f32x4 a0[NA], a1[NA];
-    u32x2 b0[NB], b1[NB];
-    fetch(s_begin, a0, b0);
-    if (s_begin + 1 < s_end) fetch(s_begin + 1, a1, b1);
-    stage(s_begin, 0, a0, b0);
-    if (s_begin + 2 < s_end) fetch(s_begin + 2, a0, b0);
-    __syncthreads();
-    for (int s = s_begin; s < s_end; s += 2) {
-      // consumers work on buffer 0 (tile s); tile s+1 goes to buffer 1
-      if (s + 1 < s_end) {
-        stage(s + 1, 1, a1, b1);
-        if (s + 3 < s_end) fetch(s + 3, a1, b1);
-      }
-      __syncthreads();
-      if (s + 1 < s_end) {
-        // consumers work on buffer 1 (tile s+1); tile s+2 goes to buffer 0
-        if (s + 2 < s_end) {
-          stage(s + 2, 0, a0, b0);
-          if (s + 4 < s_end) fetch(s + 4, a0, b0);
-        }
-        __syncthreads();
-      }
-    }
-    return;
-  }
-  // -------------------------------------------------------------------- consumers (wavefronts 0-3)
-  const int wm = wave >> 1, wn = wave & 1;
-  constexpr int MI = 2, NJ = 4;
-  f32x16 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ks = 0; ks < WS_BK / 16; ++ks) {
-      const int kof = ks * 16 + 8 * (lane >> 5);
-      bf16x8 bfrag[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        bfrag[j] = *reinterpret_cast<const bf16x8*>(b_tile(buf) + (wn * 128 + j * 32 + (lane & 31)) * WS_LD + kof);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(a_tile(buf, t) + (wm * 64 + i * 32 + (lane & 31)) * WS_LD + kof);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  };
-  __syncthreads();                                          // tile s_begin staged
-  for (int s = s_begin; s < s_end; s += 2) {
-    compute(0);
-    __syncthreads();
-    if (s + 1 < s_end) {
-      compute(1);
-      __syncthreads();
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int col = k0 + wn * 128 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
-      }
-    }
-}
-
-template <bool CONV>
-__global__ __launch_bounds__(512) void sgemm_dw_ws_kernel(const float* __restrict__ dY, const unsigned short* __restrict__ X,
-                                                          float* __restrict__ dW, int B, int M, int K, int L, int steps_per_split,
-                                                          int k_tiles, Conv3 geo, int log_w) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short ws_smem[];
-  dw_ws_body<CONV>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, blockIdx.x, blockIdx.y, ws_smem);
-}
-
+// (Two larger-tile forms of this kernel were built and measured, then removed -- tools/micro/gemm_dw_probe.hip, us on
+// [512x1152] over [8x4096] against 171 for the kernel above: a PRODUCER / CONSUMER split of a 512-thread workgroup over
+// double-buffered LDS (wavefronts 4-7 prefetch three steps ahead, split and stage tile s+1 while wavefronts 0-3 multiply tile s
+// on 64 x 128 wavefront tiles, one barrier per step): 247; its halves alone: consumers 159, producers 170 -- one wavefront per
+// SIMD cannot hide the LDS round trip in front of its MFMAs, nor the staging chain; and a 256 x 256 tile with all eight
+// wavefronts staging and multiplying (half the LDS / vL1D / VALU traffic per MFMA): 256.  Cache-resident operands (every step
+// re-reading the first slab) leave the time unchanged, as does the XCD-contiguous order below: the loop is bound inside the CU.)
 // fp32 -> bf16 of an exactly representable tensor (spikes handed over by a caller that still holds them in fp32):
 // truncation == rounding for such values; 4 elements per thread.
 __global__ void to_bf16_exact_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n4) {
@@ -804,34 +648,6 @@ int dw_launch(const float* dY, const uint16_t* X, float* dW, int batch, int M, i
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, s) != S2F_OK)
     return s2f_check_launch("s2f_spike_gemm_dw_bf16 memset");
-  // wide outputs: the producer / consumer kernel (one 512-thread workgroup per CU, 128 x 256 tiles)
-  static const bool ws_off = getenv("S2F_DW_NO_WS") != nullptr;          // A/B switch
-  if (!ws_off && M >= 96 && K >= 256 && (K % 256 == 0 || K % 256 >= 96 || K >= 1024)) {
-    static bool raised[2] = {false, false};
-    if (!raised[conv]) {
-      const hipError_t e = conv ? hipFuncSetAttribute(reinterpret_cast<const void*>(sgemm_dw_ws_kernel<true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES)
-                                : hipFuncSetAttribute(reinterpret_cast<const void*>(sgemm_dw_ws_kernel<false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-      S2F_REQUIRE(e == hipSuccess, S2F_ELAUNCH, "s2f_spike_gemm_dw_bf16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      raised[conv] = true;
-    }
-    const int m_tiles = (M + WS_TM - 1) / WS_TM, k_tiles = (K + WS_TN - 1) / WS_TN, tiles = m_tiles * k_tiles;
-    const int total_steps = batch * ((L + WS_BK - 1) / WS_BK);
-    int splits = (256 + tiles - 1) / tiles;                              // about one workgroup per CU ...
-    if (splits > total_steps / 8) splits = total_steps / 8;              // ... of at least 8 steps
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    const int steps_per_split = (total_steps + splits - 1) / splits;
-    splits = (total_steps + steps_per_split - 1) / steps_per_split;
-    if (conv)
-      S2F_LAUNCH(true, true, (sgemm_dw_ws_kernel<true>), dim3(tiles, splits), dim3(512), WS_LDS_BYTES, s, dY, X, dW, batch, M, K, L,
-                 steps_per_split, k_tiles, geo, log_w);
-    else
-      S2F_LAUNCH(true, true, (sgemm_dw_ws_kernel<false>), dim3(tiles, splits), dim3(512), WS_LDS_BYTES, s, dY, X, dW, batch, M, K,
-                 L, steps_per_split, k_tiles, geo, log_w);
-    return s2f_check_launch("s2f_spike_gemm_dw_bf16");
-  }
   // tile / step / split choice: the measured model of gemm.hip's spike_dw_launch
   int tm = M <= 32 ? 32 : M <= 64 ? 64 : 128;
   if (tm == 128 && (int64_t)batch * L <= 16384 && (int64_t)M * K > 65536) tm = 64;

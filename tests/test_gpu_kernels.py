@@ -809,9 +809,9 @@ def test_bf16_spike_storage_needs_a_power_of_two_D():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,M,K,L", [(2, 130, 300, 260), (3, 256, 256, 1024), (1, 97, 1152, 520), (8, 128, 4608, 64), (5, 512, 512, 36)])
-def test_wide_weight_gradient_producer_consumer_kernel(B, M, K, L):
-    """The 128 x 256-tile producer / consumer weight gradient (K >= 256) against the fp64 contraction: ragged M / K / L, odd
-    and even step counts per split, fresh and accumulating destinations; 2e-6 of the scale per product term."""
+def test_wide_weight_gradients_vs_fp64(B, M, K, L):
+    """Weight gradients with wide outputs (K >= 256) against the fp64 contraction: ragged M / K / L, odd and even step counts
+    per split, fresh and accumulating destinations; 3e-6 of the scale."""
     from spike2former_amd._lib import check, lib
     g = torch.Generator().manual_seed(B * 1000 + M + K + L)
     gy = (torch.randn(B, M, L, generator=g) * torch.rand(B, M, 1, generator=g) * 10).cuda()
