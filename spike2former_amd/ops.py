@@ -1072,12 +1072,13 @@ def dwconv(x, w, pad, border=None):
 _SPLIT_CACHE = {}
 SPIKE_GEMM_TERMS = 3          # number of bf16 weight terms (3 == fp32-equivalent)
 SPIKE_GEMM_ENABLED = True
-# 3x3 / stride 1 / pad 1 spike convolutions as implicit GEMMs (no im2col matrix; s2f_spike_conv3x3_fwd / _dw).  Measured at
-# C2 (tools/probe_conv3.py, forward + weight gradient, us): 256x256 maps 627 vs 706 and 1676 vs 1856, 128x128 maps 530 vs
-# 513 and 772 vs 1054, 64x64 maps 485 vs 420 and 795 vs 660 -- the forward always wins (up to 2x), the weight gradient's
-# loader costs more than reading the saved column matrix, so the pair pays off on the large maps only.
+# 3x3 / stride 1 / pad 1 spike convolutions as implicit GEMMs (no im2col matrix; s2f_spike_conv3x3_fwd / _dw).  Round 1 measured
+# the pair (forward + weight gradient) as a win on the >= 128x128 maps only (tools/probe_conv3.py: 64x64 maps 485 vs 420 and
+# 795 vs 660 us against the saved column matrix).  With the loaders' prefetches freed of their predicates (round 2, conv3_fix)
+# the implicit form wins from 32x32 up -- same-box A/B of the step: threshold 128x128 43.92, 64x64 43.39, 32x32 43.44 ms -- and
+# the bf16 column matrices of the 64x64 / 32x32 stages (ATen im2col) are gone.
 CONV3X3_IMPLICIT = True
-CONV3X3_IMPLICIT_MIN_PIXELS = 128 * 128
+CONV3X3_IMPLICIT_MIN_PIXELS = int(_os.environ.get("S2F_CONV3_MIN_PIXELS", 32 * 32))
 # input gradient of the 3x3 convolutions as an implicit transposed convolution on the 6-pass split GEMM (no unfold / col2im)
 CONV3X3_DX_IMPLICIT = True
 CONV3X3_DX_MIN_PIXELS = 0          # measured at C2: a win on every map size (61.7 vs 62.3 ms/step)
