@@ -511,8 +511,16 @@ __device__ __forceinline__ int xcd_contiguous(int f, int total) {
 #endif
 }
 
+// Workgroups per CU the register allocation must leave room for: the 64-row tiles sat at 172 registers, 4 above the limit for
+// three wavefronts per SIMD (the LDS tile allows three workgroups).
+#ifndef S2F_DW_OCC
+#define DW_MIN_BLOCKS(TMV, BKVV) ((TMV) <= 64 ? 3 : 2)
+#else
+#define DW_MIN_BLOCKS(TMV, BKVV) 1
+#endif
+
 template <int BKV, bool CONV, int TM>
-__global__ __launch_bounds__(256) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
+__global__ __launch_bounds__(256, DW_MIN_BLOCKS(TM, BKV)) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
                                                             const unsigned short* __restrict__ X, float* __restrict__ dW,
                                                             int B, int M, int K, int L, int steps_per_split, int k_tiles,
                                                             Conv3 geo, int log_w) {
@@ -541,7 +549,7 @@ struct DwJobTable {
 };
 
 template <int BKV, int TM>
-__global__ __launch_bounds__(256) void sgemm_dw_grouped_kernel(const DwJobTable tab) {
+__global__ __launch_bounds__(256, DW_MIN_BLOCKS(TM, BKV)) void sgemm_dw_grouped_kernel(const DwJobTable tab) {
   const int id = xcd_contiguous(blockIdx.x, gridDim.x);
   int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= id (wave-uniform)
   while (lo < hi) {
