@@ -79,8 +79,18 @@ struct Chunk<4> {
 // rows k0 .. k0+3 that the 32 lanes of one transpose read touch then cover all 64 banks once.
 // CH = bf16 elements per staged chunk: 8 (16-byte loads, N % 8 == 0) or 4 (8-byte loads: N % 4 == 0, and the implicit
 // 3x3 mode whose shifted rows are only 2-byte aligned).
+// Wavefronts per SIMD the register allocation must leave room for (HIP's second launch-bound; the LDS tiles allow them):
+// without the hint the 128-row tile took 172 registers = two workgroups per CU of four possible.
+#ifndef FWD_WM4_WAVES
+#define FWD_WM4_WAVES 2
+#endif
+#ifndef S2F_FWD_OCC
+#define FWD_MIN_BLOCKS(WMV, KGV) ((KGV) == 4 ? 2 : (KGV) == 2 ? 3 : (WMV) == 4 ? FWD_WM4_WAVES : 3)      /* wavefronts per SIMD */
+#else
+#define FWD_MIN_BLOCKS(WMV, KGV) 1
+#endif
 template <int WM, int TERMS, int CH, bool CONV, int KG, int WNW = 2>
-__global__ __launch_bounds__(64 * WNW * WM * KG) void sgemm_bf16_kernel(const unsigned short* __restrict__ Wsplit,
+__global__ __launch_bounds__(64 * WNW * WM * KG, FWD_MIN_BLOCKS(WM, KG)) void sgemm_bf16_kernel(const unsigned short* __restrict__ Wsplit,
                                                                    const unsigned short* __restrict__ X,
                                                                    const float* __restrict__ bias, float* __restrict__ Y,
                                                                    int M, int N, int K, int Mpad, int Kpad, int n_tiles,
@@ -514,7 +524,7 @@ __device__ __forceinline__ int xcd_contiguous(int f, int total) {
 // Workgroups per CU the register allocation must leave room for: the 64-row tiles sat at 172 registers, 4 above the limit for
 // three wavefronts per SIMD (the LDS tile allows three workgroups).
 #ifndef S2F_DW_OCC
-#define DW_MIN_BLOCKS(TMV, BKVV) ((TMV) <= 64 ? 3 : 2)
+#define DW_MIN_BLOCKS(TMV, BKVV) ((TMV) <= 64 ? 3 : 2)      /* wavefronts per SIMD (= workgroups per CU: 4 wavefronts each) */
 #else
 #define DW_MIN_BLOCKS(TMV, BKVV) 1
 #endif
