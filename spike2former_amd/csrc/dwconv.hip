@@ -354,7 +354,9 @@ extern "C" int s2f_dwconv_bwd_weight(const void* x_in, const float* border, cons
   const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
   const int ntiles = tiles_x * tiles_y;
   // workgroups per plane: enough for >= 2048 in flight, at most one per tile
-  int per_plane = (2048 + N * C - 1) / (N * C);
+  // enough workgroups for ~32 per CU: a workgroup that walks several tiles pays a global round trip per tile (the block
+  // reduction at the end is cheap since the wave sums run on DPP)
+  int per_plane = (8192 + N * C - 1) / (N * C);
   if (per_plane > ntiles) per_plane = ntiles;
   if (per_plane < 1) per_plane = 1;
   const dim3 grid(per_plane, N * C);

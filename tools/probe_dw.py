@@ -39,3 +39,12 @@ for (N, C, H, W, K) in [(8, 256, 32, 32, 3), (8, 512, 32, 32, 3), (8, 256, 32, 3
     for acc in (0, 1):
         us = t(lambda: lib.s2f_dwconv_bwd_weight(x.data_ptr(), None, gy.data_ptr(), gw.data_ptr(), N, C, H, W, K, K // 2, acc, 0, st), n=50)
         print(f"  N{N} C{C} {H}x{W} K{K} accumulate={acc}: {us:7.1f} us  ({x.numel() * 8 / us * 1e-3:6.0f} GB/s)")
+
+print("weight gradient with a bf16 spike input (x_bf16 = 1), us per call:")
+for (N, C, H, W, K) in [(8, 256, 32, 32, 3), (8, 512, 32, 32, 3), (8, 256, 32, 32, 5), (8, 512, 32, 32, 5), (8, 768, 32, 32, 3)]:
+    x = (torch.randint(0, 9, (N, C, H, W), device="cuda").float() / 8).to(torch.bfloat16); gy = torch.randn(N, C, H, W, device="cuda")
+    gw = torch.zeros(C, 1, K, K, device="cuda"); border = torch.randn(C, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for b in (None, border):
+        us = t(lambda: lib.s2f_dwconv_bwd_weight(x.data_ptr(), None if b is None else b.data_ptr(), gy.data_ptr(), gw.data_ptr(), N, C, H, W, K, K // 2, 1, 1, st), n=50)
+        print(f"  N{N} C{C} {H}x{W} K{K} border={'yes' if b is not None else 'no '}: {us:7.1f} us")
