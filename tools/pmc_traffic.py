@@ -5,15 +5,16 @@ runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE in KiB x2
 import collections, json, sqlite3, sys
 
 FAMILIES = {          # bench.py roofline key -> predicate on the kernel name
-    "bn_lif_fwd": lambda n: "bn_apply_kernel<true" in n or "bn_fused_fwd_kernel<true" in n,
-    "bn_fwd": lambda n: "bn_apply_kernel<false" in n or "bn_fused_fwd_kernel<false" in n,
-    "bn_lif_bwd+bn_bwd": lambda n: "bn_bwd_apply_kernel" in n or "bn_bwd_reduce_kernel" in n or "bn_fused_bwd_kernel" in n,
+    "bn_lif_fwd": lambda n: "bn_apply_kernel<true" in n or "bn_apply_rows_kernel<true" in n or "bn_fused_fwd_kernel<true" in n,
+    "bn_fwd": lambda n: "bn_apply_kernel<false" in n or "bn_apply_rows_kernel<false" in n or "bn_fused_fwd_kernel<false" in n,
+    "bn_lif_bwd+bn_bwd": lambda n: ("bn_bwd_apply_kernel" in n or "bn_bwd_reduce_kernel" in n or "bn_bwd_apply_rows_kernel" in n
+                                    or "bn_bwd_reduce_rows_kernel" in n or "bn_fused_bwd_kernel" in n),
     "bn_stats": lambda n: "bn_stats_kernel" in n,
     "lif_fwd": lambda n: "lif_fwd_kernel" in n and "sdsa" not in n,
     "lif_bwd": lambda n: "lif_bwd_kernel" in n,
     "spike_gemm_fwd": lambda n: "spike_gemm_kernel" in n or "sgemm_bf16_kernel" in n,
     "spike_gemm_dw": lambda n: "spike_gemm_dw_kernel" in n or "sgemm_dw" in n,
-    "sdsa_lif_fwd": lambda n: "sdsa_lif_fwd_kernel" in n,
+    "sdsa_lif_fwd": lambda n: "apply_kernel<" in n and ", true>" in n,
 }
 
 
