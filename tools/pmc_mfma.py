@@ -16,7 +16,7 @@ FAMILIES = [("spike GEMM forward (sgemm_bf16_kernel)", lambda n: "sgemm_bf16_ker
             ("general weight gradient, 6 passes (spike_gemm_dw_kernel<.., 3, ..>)", lambda n: "spike_gemm_dw_kernel" in n),
             ("split GEMM (mask contraction backward, 3x3 input gradients)", lambda n: "split_gemm_kernel" in n),
             ("library fp32 GEMM (rocBLAS / hipBLASLt: 1x1 input gradients)", lambda n: n.startswith("Cijk")),
-            ("fused attention + neuron (sdsa_lif_fwd_kernel)", lambda n: "sdsa_lif_fwd" in n)]
+            ("attention k^T v on the matrix cores (outer_mfma_kernel)", lambda n: "outer_mfma_kernel" in n)]
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
 namecol = "kernel_name" if "kernel_name" in cols else "name"
