@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 14
+#define S2F_ABI_VERSION 15
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -243,6 +243,37 @@ int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int
  * over all (job, tile, split) triples with a launch-wide contraction length per workgroup; the job table travels in the
  * kernel arguments.  bkv = contraction elements per step: 64 (rows with L % 64 == 0 or L >= 512) or 32. */
 int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* stream);
+
+/* ---- pipelined GEMMs fed by LDS-DMA (csrc/pgemm.hip, round 3) ------------------------------------------------------------
+ * The same products as s2f_spike_gemm_fwd_bf16 and as the autograd input gradient of a 1x1 convolution
+ * (mmseg/models/backbones/sdtv2.py:121-125, 164, 222-255, 304-306; mmcv_spike/transformer.py:196-361), with the operand tiles
+ * copied global -> LDS asynchronously (global_load_lds_dwordx4), 2-3 LDS stages and one barrier per K step.
+ * The weight operand is PRE-PACKED into the kernels' LDS image: blocks of [3 terms hi|mid|lo][64 rows][32 k] bf16, block
+ * (mb, kb) at element ((mb * ceil(K/32) + kb) * 6144), the 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3), rows
+ * and columns past M / K zero.  s2f_pack_elems(M, K) = bf16 elements of a pack.
+ * s2f_pack_bf16x3_multi: every pack of a model in one launch (what a training step owes after the optimiser update; recorded
+ *   in a captured step).  jobs (device): int64 [njobs][8] = {src fp32 pointer, dst bf16 pointer, M, K, mode | (C << 8), first
+ *   workgroup, 0, 0}; job i owns workgroups [first_i, first_i + ceil(ceil(M/64) ceil(K/32) 2048 / 1024)).  mode 0: src is the
+ *   [M][K] matrix; 1: a conv weight [M][C][3][3] read tap-major (k = tap C + c); 2: the flipped, transposed matrix of a conv
+ *   weight [Mw][M][3][3] (C field = Mw): A[c][tap Mw + m] = src[(m M + c) 9 + 8 - tap]; 3: the transpose of a [K][M] matrix.
+ * s2f_pack_bf16x3: one matrix (the job in the kernel arguments: usable inside a stream capture).
+ * s2f_pgemm_nn_bf16:  Y[b] (M x N) = A (M x K, packed) @ X[b] (K x N bf16 spikes, n contiguous) [+ bias[m]];  N % 8 == 0;
+ *   terms in {1,2,3}; cfg: 0 = pick a tile by the problem size, 1..5 = force one (probe switch).
+ * s2f_pgemm_dx_f32:   DX[b] (Ki x N) = W^T (Ki x Mo) @ G[b] (Mo x N, fp32) [+ beta * DX[b]] with W (Mo x Ki) given as ITS
+ *   forward pack (the same buffer the forward product reads); G is split hi + mid + lo in the kernel: 6 MFMA passes, 2^-24.
+ *   N % 4 == 0; batch strides in elements (0 = dense).  With the pack of W^T (mode 3) the same kernel is the forward product
+ *   Y = W @ X of a convolution whose input X is a general fp32 tensor.  Replaces the library fp32 GEMM (rocBLAS / hipBLASLt) of round 1-2. */
+int64_t s2f_pack_elems(int M, int K);
+int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream);
+int s2f_pack_bf16x3_multi(const int64_t* jobs, int njobs, int64_t total_workgroups, void* stream);
+int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M, int N, int K,
+                      int terms, int cfg, void* stream);
+int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
+                     int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream);
+/* dW (+)= sum_b dY[b] (M x L) X[b]^T (L x K), both operands general fp32 (6 passes), batch strides in elements (0 = dense):
+ * the weight gradient of the 1x1 convolutions whose input is not a spike map. */
+int s2f_gemm_dw_general(const float* dY, int64_t dy_batch_stride, const float* X, int64_t x_batch_stride, float* dW, int batch,
+                        int M, int K, int L, int accumulate, void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path

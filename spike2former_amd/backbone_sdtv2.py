@@ -249,8 +249,8 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         z = ops.spike_gemm(s.view(T * B, C, N), w1).view(T * B, 3 * C, H, W)          # the three first 1x1 convs: one GEMM
         z, _, border = bn_act(z, None, bn1, want_border=True)
         z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, border)
-        w2 = ops.cat_params(t["w2"]).view(3, C, C)
-        z = ops.dense_gemm(z.view(T * B, 3 * C, N), w2).view(T * B, 3 * C, H, W)             # second 1x1: 3-group batched GEMM
+        # second 1x1: three products on the channel groups of z, each with its own parameter (cached pack, gradient sink)
+        z = ops.dense_gemm(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]]).view(T * B, 3 * C, H, W)
         z, _ = bn_act(z, None, bn2)
         _, y = bn_act(z, None, bn3, lif=self.q_spike)     # q / k / v neurons: pure and identical here (checked by the caller)
         for wb in out:

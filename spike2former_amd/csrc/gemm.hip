@@ -535,7 +535,8 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
 template <int BKV, int XT, bool CONV, int TM>
 __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                             float* __restrict__ dW, int B, int M, int K, int L,
-                                                            int steps_per_split, int k_tiles, Conv3 geo, int log_w) {
+                                                            int steps_per_split, int k_tiles, Conv3 geo, int log_w,
+                                                            int64_t dy_bs, int64_t x_bs) {
   constexpr int LD = BKV + 8;
   constexpr int QPR = BKV / 4;                 // float4 chunks per row
   constexpr int NH = 128 * QPR / 256;          // X chunks per thread
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
       const int row = c / QPR, l = l0 + (c % QPR) * 4;
       const bool lok = l < L;                                       // L % 4 == 0: the whole float4 is valid or not
       if (h < NHA)
-        a[h < NHA ? h : 0] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + ((int64_t)b * M + m0 + row) * L + l)
+        a[h < NHA ? h : 0] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + (int64_t)b * dy_bs + (int64_t)(m0 + row) * L + l)
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
       if (CONV) {
         // X is the activation [B][K/9][H][W]; row k0 + row of the virtual im2col matrix, pixels l .. l+3 (W a power of two)
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
         bq[h] = conv3_load(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo,
                            ok);
       } else {
-        bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + ((int64_t)b * K + k0 + row) * L + l)
+        bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + (int64_t)b * x_bs + (int64_t)(k0 + row) * L + l)
                                       : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -819,7 +820,9 @@ extern "C" int s2f_conv3x3_general(const uint16_t* w_split, const float* X, floa
 }
 
 static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
-                           int x_terms, bool conv, Conv3 geo, int log_w, void* stream) {
+                           int x_terms, bool conv, Conv3 geo, int log_w, void* stream, int64_t dy_bs = 0, int64_t x_bs = 0) {
+  if (dy_bs == 0) dy_bs = (int64_t)M * L;
+  if (x_bs == 0) x_bs = (int64_t)K * L;          // conv mode: the kernel addresses X through geo, x_bs is unused there
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw: null pointer");
   S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
               "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
@@ -865,7 +868,7 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
 #define S2F_DW_GO1(BKV, XTV, CV, TMV)                                                                                   \
   S2F_LAUNCH(true, true, (spike_gemm_dw_kernel<BKV, XTV, CV, TMV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, \
-             dW, batch, M, K, L, steps_per_split, k_tiles, geo, log_w)
+             dW, batch, M, K, L, steps_per_split, k_tiles, geo, log_w, dy_bs, x_bs)
 #define S2F_DW_GO(BKV, XTV, CV)                                                                                         \
   do {                                                                                                                  \
     if (tm == 32)                                                                                                       \
@@ -895,6 +898,17 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
 extern "C" int s2f_spike_gemm_dw(const float* dY, const float* X, float* dW, int batch, int M, int K, int L, int accumulate,
                                  int x_terms, void* stream) {
   return spike_dw_launch(dY, X, dW, batch, M, K, L, accumulate, x_terms, false, Conv3{0, 0, 0}, 0, stream);
+}
+
+/* dW (+)= sum_b dY[b] X[b]^T with BOTH operands general fp32 (6 passes) and explicit batch strides (elements): the weight
+ * gradient of the 1x1 convolutions that do not read spikes (RepConv's second 1x1, SepConv.pwconv2: sdtv2.py:124-125, 164) --
+ * group g of a grouped product is the call with dY + g M L, X + g K L and the strides of the full tensors. */
+extern "C" int s2f_gemm_dw_general(const float* dY, int64_t dy_batch_stride, const float* X, int64_t x_batch_stride, float* dW,
+                                   int batch, int M, int K, int L, int accumulate, void* stream) {
+  S2F_REQUIRE((dy_batch_stride & 3) == 0 && (x_batch_stride & 3) == 0, S2F_EALIGN,
+              "s2f_gemm_dw_general: batch strides must keep 16-byte alignment");
+  return spike_dw_launch(dY, X, dW, batch, M, K, L, accumulate, 3, false, Conv3{0, 0, 0}, 0, stream, dy_batch_stride,
+                         x_batch_stride);
 }
 
 extern "C" int s2f_spike_conv3x3_dw(const float* dY, const float* X, float* dW, int batch, int M, int C, int H, int W,

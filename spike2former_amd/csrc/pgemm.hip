@@ -1,0 +1,671 @@
+// Pipelined bf16-term GEMMs fed by LDS-DMA (gfx950), round 3.
+//
+// The spike GEMMs of gemm.hip / gemm_bf16.hip stage every K step through registers and run a serial
+//   store-to-LDS -> barrier -> LDS fragment reads -> MFMA -> barrier
+// chain: the knock-out probes of round 2 (profiles/r02_probe_gemm_*_knockouts.txt) showed the phases ADDING instead of
+// overlapping (MFMA stream alone 55 us, LDS reads +58, global +32 on [512x1152]@[8x1152x4096]).  The kernels here are built
+// around the asynchronous global -> LDS copy (`global_load_lds_dwordx4`: 64 lanes x 16 bytes land in 1 KiB of LDS, no
+// registers, no ds_write pass) with NST LDS stages and ONE barrier per K step:
+//   wait (counted vmcnt) for tile t  ->  barrier  ->  issue the copies of tile t + NST - 1  ->  fragments + MFMAs of tile t.
+// An LDS-DMA lands lane-linear (wave-uniform base + 16 lane), so every swizzle is applied to the per-lane SOURCE address:
+//   * the weight operand is PRE-PACKED (s2f_pack_bf16x3) into the kernels' LDS image: blocks of [3 terms][64 rows][32 k] bf16
+//     whose 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3) -- conflict-free ds_read_b128 fragments, and one 1 KiB
+//     copy instruction reads 1 KiB of CONTIGUOUS global memory (full cache lines; the plain [M][K] split gave 64-byte
+//     fragments of rows).  The same pack serves the transposed product of the input gradient: there a copy takes 16 rows x 64
+//     bytes of one block verbatim and the fragments are formed by the LDS transpose read (ds_read_b64_tr_b16).
+//   * the activation tile [32 k][128 n] (bf16 spikes, n contiguous) is copied row-major with the 64-byte units of row k
+//     stored at unit ^ (k & 3) (the layout of sgemm_bf16_kernel, read with ds_read_b64_tr_b16).
+// fp32 operands (the incoming gradient dY of the input-gradient product) are split hi + mid + lo while they are staged
+// through registers; with both operands general the product takes 6 MFMA passes (terms i + j <= 2: 2^-24).
+// Reference call sites: every 1x1 Conv2d / Conv1d of the path and its autograd input gradient
+// (mmseg/models/backbones/sdtv2.py:121-125, 164, 222-255, 304-306; mmcv_spike/transformer.py:196-361, 758-763).
+#include "gemm_common.h"
+#include <cstdlib>
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int PK = 32;                        // contraction elements per pack block
+constexpr int PR = 64;                        // rows per pack block
+constexpr int PTERM = PR * PK;                // bf16 elements of one term of a block (4 KiB)
+constexpr int PBLOCK = 3 * PTERM;             // bf16 elements of a block (12 KiB)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+// LDS transpose read issued from inline asm.  hipcc orders the ds_read_tr BUILTIN behind every LDS-DMA in flight (it emits
+// s_waitcnt vmcnt(0) in front of it: the copies of the NEXT tile would be drained before the fragments of the current one are
+// read); an asm read is invisible to that bookkeeping.  The caller waits (lds_wait_all) before the first use.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16_asm(unsigned byte_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(byte_addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_b128_asm(unsigned byte_addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(byte_addr), "n"(OFF));
+  return r;
+}
+// at most N of the asm LDS reads issued so far may still be in flight
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// The MFMAs are asm statements as well: `asm volatile` statements keep their source order, so the stream is exactly
+//   fragment reads (both k slices) | wait for slice 0 | MFMAs of slice 0 | wait for slice 1 | MFMAs of slice 1.
+// With the builtin the MFMAs are register-only instructions that hipcc places freely around an asm wait: it moved the MFMAs of
+// slice 0 behind the wait for slice 1 (no overlap left), and nothing but a scheduling barrier kept them behind the wait for
+// their own operands.  Accumulators live in the AGPR half of the register file ("a").  Back-to-back MFMAs on one accumulator
+// need no wait states (accumulate chain); mfma_fence() pads the read-after-MFMA hazard the compiler cannot see.
+__device__ __forceinline__ void mfma_bf16(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int MI, int NJ>
+__device__ __forceinline__ void mfma_fence(f32x16 (&acc)[MI][NJ]) {
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long)(lds_void*)p; }
+
+// A global load hipcc does not see (next to LDS-DMA it waits vmcnt(0) for every ordinary load: the copies running two steps
+// ahead would be drained at every step).  The destination is in flight until a counted wait retires it: vm_landed() then
+// hands the registers back to the compiler (`+v`: no consumer is scheduled above it).
+__device__ __forceinline__ void gload16_asm(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int NQ>
+__device__ __forceinline__ void vm_landed(f32x4 (&r)[NQ]) {
+  static_assert(NQ >= 1 && NQ <= 4, "register set size");
+  if constexpr (NQ == 1) asm volatile("; landed" : "+v"(r[0]));
+  if constexpr (NQ == 2) asm volatile("; landed" : "+v"(r[0]), "+v"(r[1]));
+  if constexpr (NQ == 3) asm volatile("; landed" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
+  if constexpr (NQ == 4) asm volatile("; landed" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+// counted wait on the vector-memory queue (LDS-DMA and loads), all LDS operations, then the workgroup barrier
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pack.  A workgroup converts 1024 (row, k) positions of its job (three stores each).  mode 0: A[m][k] = src[m K + k];
+// mode 1: conv weight [M][C][3][3] read tap-major, A[m][tap C + c] = src[(m C + c) 9 + tap]; mode 2: transposed-convolution
+// matrix of a conv weight [Mw][Crows][3][3] with flipped taps, A[c][tap Mw + mm] = src[(mm Crows + c) 9 + 8 - tap]  (C field =
+// Mw, M = Crows); mode 3: the transpose of a [K][M] matrix, A[m][k] = src[k M + m].
+__device__ __forceinline__ void pack_body(const float* __restrict__ w, unsigned short* __restrict__ out, int M, int K,
+                                          int mode, int C, int64_t wg) {
+  const int Kb = (K + PK - 1) / PK, Mb = (M + PR - 1) / PR;
+  const int64_t total = (int64_t)Mb * Kb * PTERM;
+  const int64_t base = wg * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = base + u * 256 + threadIdx.x;          // (block, physical position inside a term)
+    if (i >= total) continue;
+    const int64_t blk = i / PTERM;
+    const int pos = (int)(i - blk * PTERM);
+    const int r = pos / PK, pc = (pos % PK) >> 3, e = pos & 7;
+    const int c = pc ^ ((r >> 2) & 3);
+    const int mb = (int)(blk / Kb), kb = (int)(blk - (int64_t)mb * Kb);
+    const int m = mb * PR + r, k = kb * PK + c * 8 + e;
+    unsigned short h = 0, md = 0, l = 0;
+    if (m < M && k < K) {
+      int64_t src;
+      if (mode == 0) {
+        src = (int64_t)m * K + k;
+      } else if (mode == 1) {
+        const int tap = k / C, cc = k - tap * C;
+        src = ((int64_t)m * C + cc) * 9 + tap;
+      } else if (mode == 2) {
+        const int tap = k / C, mm = k - tap * C;
+        src = ((int64_t)mm * M + m) * 9 + (8 - tap);
+      } else {
+        src = (int64_t)k * M + m;
+      }
+      const float v = w[src];
+      h = s2f_f2bf(v);
+      const float r1 = v - s2f_bf2f(h);
+      md = s2f_f2bf(r1);
+      l = s2f_f2bf(r1 - s2f_bf2f(md));
+    }
+    unsigned short* o = out + blk * PBLOCK + pos;
+    o[0] = h;
+    o[PTERM] = md;
+    o[2 * PTERM] = l;
+  }
+}
+// jobs int64 [njobs][8] = {src fp32, dst bf16, M, K, mode | (C << 8), first workgroup, 0, 0}
+__global__ __launch_bounds__(256) void pack_multi_kernel(const long long* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[(int64_t)mid * 8 + 5] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* j = jobs + (int64_t)lo * 8;
+  pack_body(reinterpret_cast<const float*>(j[0]), reinterpret_cast<unsigned short*>(j[1]), (int)j[2], (int)j[3],
+            (int)(j[4] & 255), (int)(j[4] >> 8), (int64_t)blockIdx.x - j[5]);
+}
+__global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int M,
+                                                       int K, int mode, int C) {
+  pack_body(w, out, M, K, mode, C, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NN:  Y[b] (M x N) = A (M x K, packed) @ X[b] (K x N, bf16 spikes, n contiguous) [+ bias].
+// Block = WMW x WNW wavefronts, wavefront tile (32 MI) x (32 NJ), K step 32, NST LDS stages.
+template <int MI, int NJ, int WMW, int WNW, int AT, int NST>
+__global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned short* __restrict__ Ap,
+                                                              const unsigned short* __restrict__ X,
+                                                              const float* __restrict__ bias, float* __restrict__ Y, int M,
+                                                              int N, int K, int Kb, int n_tiles, int m_tiles,
+                                                              int64_t x_batch_stride) {
+  constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW;
+  constexpr int A_BYTES = AT * BM * 64, B_BYTES = 32 * BN * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = AT * BM / 16, NB = B_BYTES / 1024;          // 1 KiB copies per stage
+  static_assert(NA % NW == 0 && NB % NW == 0, "copies must divide evenly over the wavefronts");
+  static_assert(BN == 128 || BN == 256, "unit swizzle assumes rows of >= 4 64-byte units");
+  constexpr int LPW = NA / NW + NB / NW;                         // copies per wavefront and stage
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;          // XCD-aware tile order
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const unsigned short* Xb = X + (int64_t)b * x_batch_stride;
+  float* Yb = Y + (int64_t)b * M * N;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave / WNW, wn = wave % WNW;
+
+  // per-lane source offsets of the activation copies (fixed over the K loop apart from the row)
+  constexpr int RPI = 1024 / (BN * 2), CPRW = BN * 2 / 16;        // rows per copy instruction, 16-byte chunks per row
+  const int b_kl = lane / CPRW, b_pc = lane % CPRW;
+  auto issue = [&](int kb, int st) __attribute__((always_inline)) {
+    unsigned char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int q = 0; q < NA / NW; ++q) {
+      const int idx = wave + q * NW;
+      const int t = idx / (BM / 16), R0 = (idx % (BM / 16)) * 16;
+      const int mb = min(m0 / PR + R0 / PR, (M - 1) / PR);          // row blocks past M hold rows that are never stored
+      const unsigned short* src = Ap + ((int64_t)mb * Kb + kb) * PBLOCK + t * PTERM + (R0 % PR) * PK + lane * 8;
+      dma16(src, sb + (t * BM + R0) * 64);
+    }
+#pragma unroll
+    for (int q = 0; q < NB / NW; ++q) {
+      const int idx = wave + q * NW;
+      const int k = idx * RPI + b_kl;
+      const int lc = (((b_pc >> 2) ^ (k & 3)) << 2) | (b_pc & 3);
+      const int kr = min(kb * 32 + k, K - 1);                     // rows past K meet zero weight columns
+      const int col = min(n0 + lc * 8, N - 8);                    // columns past N are never stored
+      dma16(Xb + (int64_t)kr * N + col, sb + A_BYTES + idx * 1024);
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses (bf16 elements inside a stage)
+  const int kl = (lane & 15) >> 2;
+  int boff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    boff[j] = (8 * (lane >> 5) + kl) * BN + (((wn * NJ + j) ^ kl) << 5) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int a_f = ((lane & 31) >> 2) & 3, a_h = lane >> 5;
+  int aoff[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) aoff[i] = (wm * (32 * MI) + i * 32 + (lane & 31)) * 32;
+
+  const unsigned smem_a = lds_addr(smem);
+  // byte offsets of the weight fragments inside a stage (term 0): row, swizzled chunk of k slice ks
+  unsigned abyte[2][MI];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) abyte[ks][i] = (unsigned)(aoff[i] + ((((ks * 2 + a_h) ^ a_f) << 3))) * 2u;
+  // One stage: every fragment read of both k slices is REQUESTED first (asm reads: hipcc orders the ds_read_tr builtin behind
+  // every LDS-DMA in flight, and it waits lgkmcnt(0) in front of each group of four MFMAs when it schedules the reads itself);
+  // the MFMAs of slice 0 start when its reads have landed and run under the landing of slice 1's.
+  constexpr int RPS = 2 * NJ + AT * MI;          // reads per k slice
+  auto compute = [&](int st) __attribute__((always_inline)) {
+    union BF {
+      bf16x8 v;
+      s16x4 h[2];
+    } bfrag[2][NJ];
+    bf16x8 afrag[2][AT][MI];
+    const unsigned sb = smem_a + st * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const unsigned a = sb + boff[j] * 2;
+        if (ks == 0) {
+          bfrag[0][j].h[0] = lds_tr16_asm<A_BYTES>(a);
+          bfrag[0][j].h[1] = lds_tr16_asm<A_BYTES + 4 * BN * 2>(a);
+        } else {
+          bfrag[1][j].h[0] = lds_tr16_asm<A_BYTES + 16 * BN * 2>(a);
+          bfrag[1][j].h[1] = lds_tr16_asm<A_BYTES + 20 * BN * 2>(a);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const unsigned a = sb + abyte[ks][i];
+        afrag[ks][0][i] = lds_b128_asm<0>(a);
+        if (AT > 1) afrag[ks][AT > 1 ? 1 : 0][i] = lds_b128_asm<BM * 64>(a);
+        if (AT > 2) afrag[ks][AT > 2 ? 2 : 0][i] = lds_b128_asm<2 * BM * 64>(a);
+      }
+    }
+    lds_wait<RPS>();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1) lds_wait<0>();
+#pragma unroll
+      for (int t = 0; t < AT; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            mfma_bf16(acc[i][j], afrag[ks][t][i], bfrag[ks][j].v);
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < Kb) issue(s, s);
+  int st = 0, st_next = NST - 1;
+  for (int t = 0; t < Kb; ++t) {
+    // tiles t+1 .. t+NST-2 may stay in flight when they exist
+    if (t + NST - 2 < Kb)
+      wait_vm_and_barrier<(NST - 2) * LPW>();
+    else
+      wait_vm_and_barrier<0>();
+    if (t + NST - 1 < Kb) issue(t + NST - 1, st_next);
+    compute(st);
+    st = st + 1 == NST ? 0 : st + 1;
+    st_next = st_next + 1 == NST ? 0 : st_next + 1;
+  }
+
+  // epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  mfma_fence(acc);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {              // the 16 bias values of this row block first (clamped addresses), one wait
+      const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      bv[r] = bias ? bias[min(row, M - 1)] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + (wn * NJ + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) Yb[(int64_t)row * N + col] = acc[i][j][r] + bv[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TN with a general fp32 right operand -- the input gradient of a 1x1 convolution:
+//   DX[b] (Ki x N) = W^T (Ki x Mo) @ G[b] (Mo x N),   W (Mo x Ki) given as ITS forward pack, G fp32 (n contiguous).
+// Contraction step 16 (rows of W / G).  A stage of the weight operand holds, per term and per 32-column panel of the output
+// rows, 16 pack rows x 64 bytes copied verbatim (1 KiB contiguous in global memory and in LDS); a stage of the G operand holds
+// the three bf16 terms of the tile [16][BN] row-major with the unit swizzle; both MFMA operands are formed by transpose
+// reads.  6 passes.  Pipeline: the weight copies run TWO steps ahead (3 LDS stages), the G loads two steps ahead in two
+// register sets (split + stored one step ahead, 2 LDS stages): most launches of the path are 32x32-map products with one
+// workgroup per CU, where nothing but the kernel's own prefetch depth hides the ~700-cycle fabric latency of an operand that
+// another XCD has just written.  KG = 2: a second set of wavefronts walks the odd contraction steps of the same tile with its
+// own stages (two wavefronts per SIMD on such a launch), the partial tiles are summed through LDS.
+template <int MI, int NJ, int WMW, int WNW, int KG, bool BETA>
+__global__ __launch_bounds__(64 * WMW * WNW * KG) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
+                                                                       const float* __restrict__ G, float* __restrict__ DX,
+                                                                       int Mo, int Ki, int N, int KbW, int n_tiles, int m_tiles,
+                                                                       float beta, int64_t g_batch_stride,
+                                                                       int64_t dx_batch_stride) {
+  constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
+  constexpr int KC = 16;
+  constexpr int A_BYTES = 3 * (BM / 32) * 1024, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM;
+  constexpr int GROUP_BYTES = 3 * A_BYTES + 2 * B_BYTES;
+  constexpr int NA = 3 * (BM / 32), NAW = (NA + NW - 1) / NW;       // 1 KiB copies per stage / per wavefront (padded: uniform)
+  constexpr int NQ = KC * BN / 4 / T;                             // float4 loads per thread and stage
+  static_assert(NQ >= 1 && (KC * BN / 4) % T == 0, "tile too small for the thread count");
+  constexpr int RED_BYTES = (KG - 1) * T * MI * NJ * 16 * 4;
+  constexpr int LDS_BYTES = KG * GROUP_BYTES > RED_BYTES ? KG * GROUP_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_all[LDS_BYTES];
+
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;                          // m0: first output row (a column of W)
+  const float* Gb = G + (int64_t)b * g_batch_stride;
+  float* Db = DX + (int64_t)b * dx_batch_stride;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int grp = KG > 1 ? wave_all / NW : 0;
+  const int wave = wave_all - grp * NW;
+  const int tid = threadIdx.x - grp * T, lane = tid & 63;
+  const int wm = wave / WNW, wn = wave % WNW;
+  unsigned char* smem = smem_all + grp * GROUP_BYTES;
+  const int nk = (Mo + KC - 1) / KC;
+  const int ns = (nk + KG - 1) / KG;                              // steps of every group (a step past nk contributes nothing)
+
+  // step s of this group = contraction step t = s KG + grp
+  auto issue_a = [&](int s, int slot) __attribute__((always_inline)) {
+    unsigned char* sb = smem + slot * A_BYTES;
+    const int c0 = min(s * KG + grp, nk - 1) * KC;                // first contraction row (a row of W); clamped: copy count stays uniform
+#pragma unroll
+    for (int q = 0; q < NAW; ++q) {
+      int idx = wave + q * NW;
+      if (NA % NW != 0 && idx >= NA) idx -= NW;                   // pad with a repeat of an earlier copy (same bytes, same place)
+      const int term = idx / (BM / 32), p = idx % (BM / 32);
+      const int kb = min(m0 / PK + p, KbW - 1);                   // panels past Ki belong to rows that are never stored
+      dma16(Wp + ((int64_t)(c0 / PR) * KbW + kb) * PBLOCK + term * PTERM + (c0 % PR) * PK + lane * 8, sb + idx * 1024);
+    }
+  };
+  auto fetch_b = [&](int s, f32x4 (&breg)[NQ]) __attribute__((always_inline)) {
+    const int t = min(s * KG + grp, nk - 1);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = tid + q * T;
+      const int k = p / (BN / 4), c4 = p % (BN / 4);
+      const int kr = min(t * KC + k, Mo - 1);                     // rows past Mo meet zero pack rows
+      const int col = min(n0 + c4 * 4, N - 4);
+      gload16_asm(breg[q], Gb + (int64_t)kr * N + col);
+    }
+  };
+  auto stage_b = [&](int slot, const f32x4 (&breg)[NQ], bool live) __attribute__((always_inline)) {
+    unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + 3 * A_BYTES + slot * B_BYTES);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = tid + q * T;
+      const int k = p / (BN / 4), c4 = p % (BN / 4);
+      const int off = k * BN + ((((c4 >> 3) ^ (k & 3)) << 5) | ((c4 & 7) << 2));
+      unsigned int h0 = 0, m0_ = 0, l0_ = 0, h1 = 0, m1 = 0, l1 = 0;
+      if (KG == 1 || live) {                                       // a step past nk (odd step count, KG = 2): zeros
+        s2f_split3x2(breg[q].x, breg[q].y, h0, m0_, l0_);
+        s2f_split3x2(breg[q].z, breg[q].w, h1, m1, l1);
+      }
+      *reinterpret_cast<u32x2*>(Bs + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(Bs + KC * BN + off) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(Bs + 2 * KC * BN + off) = u32x2{l0_, l1};
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read addresses.  lane: kl = row inside a 4-row group, (lane & 3) = 8-byte piece of a 32-byte half row,
+  // (lane >> 4) & 1 = which 16 columns, lane >> 5 = contraction rows +8.
+  const int kl = (lane & 15) >> 2, piece = lane & 3, hcol = (lane >> 4) & 1, kh = lane >> 5;
+  int boff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) boff[j] = (8 * kh + kl) * BN + (((wn * NJ + j) ^ kl) << 5) + 16 * hcol + 4 * piece;
+  // A panel rows are 32 bf16 (64 bytes); logical 16-byte chunk c = 2 hcol + (piece >> 1) sits at c ^ ((row >> 2) & 3), and
+  // (row >> 2) & 3 = (2 kh + half) & 3 for the rows 8 kh + kl + 4 half of a 16-row stage (stage rows start at a multiple of 16)
+  int aoff[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = 8 * kh + kl + 4 * half;
+      const int c = (2 * hcol + (piece >> 1)) ^ ((2 * kh + half) & 3);
+      aoff[i][half] = (wm * MI + i) * 512 + row * 32 + c * 8 + 4 * (piece & 1);
+    }
+
+  const unsigned smem_a = lds_addr(smem);
+  auto compute = [&](int aslot, int bslot) __attribute__((always_inline)) {
+    union BF {
+      bf16x8 v;
+      s16x4 h[2];
+    } bfrag[3][NJ], afrag[3][MI];
+    const unsigned sa = smem_a + aslot * A_BYTES, sbb = smem_a + 3 * A_BYTES + bslot * B_BYTES;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const unsigned a = sbb + boff[j] * 2;
+      bfrag[0][j].h[0] = lds_tr16_asm<0>(a);
+      bfrag[0][j].h[1] = lds_tr16_asm<4 * BN * 2>(a);
+      bfrag[1][j].h[0] = lds_tr16_asm<B_TERM>(a);
+      bfrag[1][j].h[1] = lds_tr16_asm<B_TERM + 4 * BN * 2>(a);
+      bfrag[2][j].h[0] = lds_tr16_asm<2 * B_TERM>(a);
+      bfrag[2][j].h[1] = lds_tr16_asm<2 * B_TERM + 4 * BN * 2>(a);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      afrag[0][i].h[0] = lds_tr16_asm<0>(sa + aoff[i][0] * 2);
+      afrag[0][i].h[1] = lds_tr16_asm<0>(sa + aoff[i][1] * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      afrag[1][i].h[0] = lds_tr16_asm<(BM / 32) * 1024>(sa + aoff[i][0] * 2);
+      afrag[1][i].h[1] = lds_tr16_asm<(BM / 32) * 1024>(sa + aoff[i][1] * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      afrag[2][i].h[0] = lds_tr16_asm<2 * (BM / 32) * 1024>(sa + aoff[i][0] * 2);
+      afrag[2][i].h[1] = lds_tr16_asm<2 * (BM / 32) * 1024>(sa + aoff[i][1] * 2);
+    }
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta) {
+      // reads were requested in the order B (all), A term 0, 1, 2 (2 MI each)
+      if (ta == 0) lds_wait<4 * MI>();
+      if (ta == 1) lds_wait<2 * MI>();
+      if (ta == 2) lds_wait<0>();
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+          if (ta + tb < 3)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              mfma_bf16(acc[i][j], afrag[ta][i].v, bfrag[tb][j].v);
+    }
+  };
+
+  // Two register sets for the G loads; the loop is unrolled by two so that each set has fixed registers.
+  // Vector-memory queue of a wavefront, oldest first, at the wait of step s >= 1:
+  //   ... copies A(s) | loads G(s+2) | copies A(s+1)          (issued during steps s-2 and s-1)
+  // so "at most NQ + NAW outstanding" == the copies of tile s have landed.
+  f32x4 bset0[NQ], bset1[NQ];
+  fetch_b(0, bset0);
+  fetch_b(1, bset1);
+  issue_a(0, 0);
+  issue_a(1, 1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ + 2 * NAW) : "memory");      // G(0) landed
+  vm_landed(bset0);
+  stage_b(0, bset0, grp < nk);
+  fetch_b(2, bset0);
+  int aslot = 0, aslot2 = 2;                                      // A slot of step s, of step s + 2
+  auto step = [&](int s, f32x4 (&bnext)[NQ]) __attribute__((always_inline)) {
+    // bnext: the register set holding G(s+1); it is refilled with G(s+3) once staged
+    if (s == 0)
+      wait_vm_and_barrier<NQ>();                                   // A(0), A(1) issued before G(2): all copies landed
+    else
+      wait_vm_and_barrier<NQ + NAW>();
+    if (s + 1 < ns) {
+      vm_landed(bnext);                                            // G(s+1) is older than the copies the wait just retired
+      stage_b((s + 1) & 1, bnext, (s + 1) * KG + grp < nk);
+      fetch_b(s + 3, bnext);
+      issue_a(s + 2, aslot2);
+    } else {
+      // keep the queue shape of the counted wait: nothing more is issued, the last waits drain
+    }
+    compute(aslot, s & 1);
+    aslot = aslot + 1 == 3 ? 0 : aslot + 1;
+    aslot2 = aslot2 + 1 == 3 ? 0 : aslot2 + 1;
+  };
+  for (int s = 0; s < ns; s += 2) {
+    step(s, bset1);
+    if (s + 1 < ns) step(s + 1, bset0);
+  }
+
+  mfma_fence(acc);
+  if (KG > 1) {
+    float* red = reinterpret_cast<float*>(smem_all);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every stage is dead
+    if (grp > 0) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * NJ + j) * 16 + r) * T + tid] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * NJ + j) * 16 + r) * T + tid];
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + (wn * NJ + j) * 32 + (lane & 31);
+      float prev[16];
+      if (BETA) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {          // every load of the tile first (clamped addresses), one wait
+          const int row = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          prev[r] = Db[(int64_t)min(row, Ki - 1) * N + min(col, N - 1)];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < Ki && col < N) Db[(int64_t)row * N + col] = BETA ? acc[i][j][r] + beta * prev[r] : acc[i][j][r];
+      }
+    }
+}
+
+int pick_cfg_nn(int M, int N, int batch, int force) {
+  if (force > 0) return force;
+  // measured (tools/probe_pgemm.py): 64 x 128 tiles on four wavefronts of 32 x 64 with two LDS stages (three workgroups per
+  // CU) win or tie on every shape of the path; 256-row tiles tie on the M >= 512 products of the large maps
+  return 4;
+}
+
+}  // namespace
+
+extern "C" int64_t s2f_pack_elems(int M, int K) { return (int64_t)((M + PR - 1) / PR) * ((K + PK - 1) / PK) * PBLOCK; }
+
+extern "C" int s2f_pack_bf16x3_multi(const int64_t* jobs, int njobs, int64_t total_workgroups, void* stream) {
+  if (njobs == 0) return S2F_OK;
+  S2F_REQUIRE(jobs && njobs > 0 && total_workgroups > 0 && total_workgroups < (1ll << 31), S2F_EINVAL,
+              "s2f_pack_bf16x3_multi: bad job table");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_workgroups), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), njobs);
+  return s2f_check_launch("s2f_pack_bf16x3_multi");
+}
+
+extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M,
+                                 int N, int K, int terms, int cfg, void* stream) {
+  S2F_REQUIRE(a_pack && X && Y, S2F_EINVAL, "s2f_pgemm_nn_bf16: null pointer");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL,
+              "s2f_pgemm_nn_bf16: bad sizes");
+  S2F_REQUIRE((N & 7) == 0, S2F_EINVAL, "s2f_pgemm_nn_bf16: N=%d must be a multiple of 8", N);
+  S2F_REQUIRE(s2f_aligned16(a_pack) && s2f_aligned16(X) && s2f_aligned16(Y), S2F_EALIGN,
+              "s2f_pgemm_nn_bf16: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int Kb = (K + PK - 1) / PK;
+  const int n_tiles = (N + 127) / 128;
+  static const char* force = getenv("S2F_PG_CFG");
+  const int c = pick_cfg_nn(M, N, batch, cfg > 0 ? cfg : (force ? atoi(force) : 0));
+  const int64_t xbs = (int64_t)K * N;
+#define S2F_PG(MI, NJ, WMW, WNW, ATV, NSTV)                                                                            \
+  do {                                                                                                                 \
+    const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                     \
+    S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, ATV, NSTV>), dim3(n_tiles * m_tiles, batch),                 \
+               dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs);                     \
+  } while (0)
+#define S2F_PG_T(MI, NJ, WMW, WNW, NSTV)          \
+  do {                                           \
+    if (terms == 3)                              \
+      S2F_PG(MI, NJ, WMW, WNW, 3, NSTV);         \
+    else if (terms == 2)                         \
+      S2F_PG(MI, NJ, WMW, WNW, 2, NSTV);         \
+    else                                         \
+      S2F_PG(MI, NJ, WMW, WNW, 1, NSTV);         \
+  } while (0)
+  switch (c) {
+    case 1: S2F_PG_T(2, 2, 2, 2, 2); break;          // 128 x 128, 4 wavefronts, 2 stages (64 KiB: two workgroups per CU)
+    case 2: S2F_PG_T(1, 2, 2, 2, 3); break;          // 64 x 128, 4 wavefronts of 32 x 64, 3 stages (60 KiB)
+    case 3: S2F_PG_T(2, 2, 2, 2, 3); break;          // 128 x 128, 3 stages (96 KiB: one workgroup per CU)
+    case 4: S2F_PG_T(1, 2, 2, 2, 2); break;          // 64 x 128, 2 stages (40 KiB: three workgroups per CU)
+    case 5: S2F_PG_T(2, 2, 4, 2, 2); break;          // 256 x 128, 8 wavefronts, 2 stages (112 KiB)
+    default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_nn_bf16: unknown cfg %d", c);
+  }
+#undef S2F_PG_T
+#undef S2F_PG
+  return s2f_check_launch("s2f_pgemm_nn_bf16");
+}
+
+extern "C" int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream) {
+  S2F_REQUIRE(src && dst && M > 0 && K > 0 && mode >= 0 && mode <= 3, S2F_EINVAL, "s2f_pack_bf16x3: bad arguments");
+  S2F_REQUIRE((mode != 1 && mode != 2) || C > 0, S2F_EINVAL, "s2f_pack_bf16x3: conv modes need C");
+  const int64_t wgs = (int64_t)((M + PR - 1) / PR) * ((K + PK - 1) / PK) * (PTERM / 1024);
+  hipLaunchKernelGGL(pack_one_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, src, dst, M, K, mode, C);
+  return s2f_check_launch("s2f_pack_bf16x3");
+}
+
+extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX,
+                                int64_t dx_batch_stride, int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream) {
+  if (g_batch_stride == 0) g_batch_stride = (int64_t)Mo * N;
+  if (dx_batch_stride == 0) dx_batch_stride = (int64_t)Ki * N;
+  S2F_REQUIRE((g_batch_stride & 3) == 0 && (dx_batch_stride & 3) == 0, S2F_EALIGN, "s2f_pgemm_dx_f32: batch strides must keep 16-byte alignment");
+  S2F_REQUIRE(w_pack && G && DX, S2F_EINVAL, "s2f_pgemm_dx_f32: null pointer");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && Mo > 0 && Ki > 0 && N >= 4 && (N & 3) == 0, S2F_EINVAL,
+              "s2f_pgemm_dx_f32: bad sizes (N=%d must be a positive multiple of 4)", N);
+  S2F_REQUIRE(s2f_aligned16(w_pack) && s2f_aligned16(G) && s2f_aligned16(DX), S2F_EALIGN,
+              "s2f_pgemm_dx_f32: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int KbW = (Ki + PK - 1) / PK;
+  const int n_tiles = (N + 127) / 128;
+  static const char* force = getenv("S2F_PG_DX_CFG");
+  int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
+  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
+#define S2F_PGD(MI, NJ, WMW, WNW, KGV)                                                                                  \
+  do {                                                                                                                 \
+    const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
+    if (beta != 0.f)                                                                                                   \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, KGV, true>), dim3(n_tiles * m_tiles, batch),           \
+                 dim3(64 * WMW * WNW * KGV), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, \
+                 dx_batch_stride);                                                                                     \
+    else                                                                                                               \
+    S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, KGV, false>), dim3(n_tiles * m_tiles, batch),            \
+               dim3(64 * WMW * WNW * KGV),                                                                             \
+               0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                                          \
+  } while (0)
+  switch (c) {
+    case 1: S2F_PGD(2, 2, 2, 2, 1); break;          // 128 x 128
+    case 2: S2F_PGD(1, 2, 2, 2, 1); break;          // 64 x 128
+    case 3: S2F_PGD(1, 2, 2, 2, 2); break;          // 64 x 128, contraction split over two sets of wavefronts
+    case 4: S2F_PGD(2, 2, 2, 2, 2); break;          // 128 x 128, split
+    default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_f32: unknown cfg %d", c);
+  }
+#undef S2F_PGD
+  return s2f_check_launch("s2f_pgemm_dx_f32");
+}

@@ -4,7 +4,7 @@ One C2 step issues ~5 000 kernel launches from Python; at ~20 us of host time pe
 before the GPU is busy.  Shapes are static (fixed crop, fixed T), so the step -- membrane reset, gradient-buffer clear,
 forward, loss, backward -- is captured once into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: one host call
 per step.  The kernels launched through the C ABI take the capture stream like any other launch; the ABI allocates
-nothing and never synchronises, so it is capture-safe by construction (s2f_* use hipMemsetAsync only).
+nothing and never synchronises, so it is capture-safe by construction (clears are fill KERNELS: no hipMemsetAsync nodes).
 
 Weights: the spike GEMMs read bf16 hi / mid / lo terms of every weight that `ops.split_weight*` caches per weight version.
 A captured step does not rely on that cache: `reset_net -> ops.begin_step` re-splits EVERY registered weight inside the
@@ -41,6 +41,9 @@ class GraphedStep:
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_loss = self._eager_step()
         torch.cuda.synchronize()
+        # the graph bakes in the addresses of the conversion job tables and of every cached split / pack buffer: hold them (an
+        # eager forward after an optimiser step re-converts INTO the same buffers, ops._cache_buffer, and replaces tables)
+        self._converted = ops.conversion_state()
 
     def _eager_step(self):
         reset_net(self.model)
@@ -101,6 +104,7 @@ class GraphedSplitStep:
             ops.wgrad_join()
             self.red.pack(grads)
         torch.cuda.synchronize()
+        self._converted = ops.conversion_state()          # see GraphedStep
 
     def _forward(self):
         reset_net(self.model)
@@ -125,7 +129,11 @@ class GraphedSplitStep:
 
 
 class GraphedOverlapStep:
-    """The data-parallel step with its gradient all-reduce OVERLAPPED ("launched as backward finishes"):
+    """BENCHMARK-ONLY (no weight update between steps): forward(k+1) replays before all-reduce(k) has finished, so an optimiser
+    could not apply the averaged gradients of step k before step k+1 reads (and re-splits) the weights -- with an optimiser in the
+    loop this would be one-step-stale data parallelism, not the reference's synchronous MMDistributedDataParallel step.  The
+    synchronous form is GraphedStep + FlatGradAllReduce.reduce().
+    The data-parallel step with its gradient all-reduce OVERLAPPED ("launched as backward finishes"):
     the step is two hipGraphs,
         graph F : membrane reset + weight re-split + forward + loss                    (does not touch the gradient buffer)
         graph B : gradient-buffer clear + backward + packing
@@ -163,6 +171,7 @@ class GraphedOverlapStep:
             ops.wgrad_join()
             self.red.pack(grads)
         torch.cuda.synchronize()
+        self._converted = ops.conversion_state()          # see GraphedStep
 
     def _forward(self):
         reset_net(self.model)

@@ -60,7 +60,7 @@ def begin_step(device=None):
             # no job table for the current set of weights: forget every cached version instead, so that each weight is
             # re-split by its own launch inside this capture (correct, ~180 launches more per replay)
             for k, v in list(_SPLIT_CACHE.items()):
-                _SPLIT_CACHE[k] = (None,) + v[1:]
+                _SPLIT_CACHE[k] = (None,) + tuple(v[1:])
     a = _ARENA
     if a["buf"] is None:
         if device is None:
@@ -446,39 +446,75 @@ def bmm_tuned(a, b):
 
 class _DenseGemm(torch.autograd.Function):
     """Y[b] = W @ X[b] for a general fp32 X (the 1x1 convolutions that do not read spikes: SepConv.pwconv2, RepConv's second
-    1x1, sdtv2.py:124-125, 164) with `groups` independent weights applied to consecutive channel groups: W [G, M, K],
-    X [B, G*K, L] -> [B, G*M, L].  Library GEMMs, each through the faster of rocBLAS / hipBLASLt (bmm_tuned)."""
+    1x1, sdtv2.py:124-125, 164) with G independent weights applied to consecutive channel groups: ws = G matrices [M, K],
+    X [B, G*K, L] -> [B, G*M, L].  Forward and input gradient on s2f_pgemm_dx_f32 (the transposed product on the pack of W^T
+    resp. W, X / dY split hi + mid + lo in the kernel: 6 passes), weight gradient on s2f_gemm_dw_general; a group is a call
+    with offset pointers and the batch strides of the full tensors (no copies).  Shapes the kernels do not take (L % 4 != 0,
+    L < 128) fall back to the library GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        _need_cuda(x, w)
-        G, M, K = w.shape
+    def forward(ctx, x, *ws):
+        _need_cuda(x, *ws)
+        G = len(ws)
+        M, K = ws[0].shape
         B, _, L = x.shape
         x = x.contiguous()
-        wb = w.unsqueeze(0).expand(B, G, M, K).reshape(B * G, M, K) if G > 1 else w.expand(B, M, K)
-        y = bmm_tuned(wb, x.view(B * G, K, L))
-        ctx.save_for_backward(x, w)
-        return y.view(B, G * M, L)
+        ctx.save_for_backward(x, *ws)
+        ctx.fast = PGEMM_DX and L % 4 == 0 and L >= PGEMM_MIN_N
+        if ctx.fast:
+            y = torch.empty(B, G * M, L, dtype=torch.float32, device=x.device)
+            for g, w in enumerate(ws):
+                _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)
+                check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w, transposed=True)), x.data_ptr() + 4 * g * K * L, G * K * L,
+                                           y.data_ptr() + 4 * g * M * L, G * M * L, B, K, M, L, 0.0, 0, _stream()),
+                      "s2f_pgemm_dx_f32")
+            return y
+        wb = torch.stack(ws, 0).unsqueeze(0).expand(B, G, M, K).reshape(B * G, M, K) if G > 1 else ws[0].expand(B, M, K)
+        return bmm_tuned(wb, x.view(B * G, K, L)).view(B, G * M, L)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        G, M, K = w.shape
+        x, *ws = ctx.saved_tensors
+        G = len(ws)
+        M, K = ws[0].shape
         B, _, L = x.shape
-        gy = gy.contiguous().view(B * G, M, L)
-        gx = gw = None
+        gy = gy.contiguous()
+        gx, gws = None, [None] * G
+        if ctx.fast:
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty(B, G * K, L, dtype=torch.float32, device=gy.device)
+                for g, w in enumerate(ws):
+                    _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)
+                    check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w)), gy.data_ptr() + 4 * g * M * L, G * M * L,
+                                               gx.data_ptr() + 4 * g * K * L, G * K * L, B, M, K, L, 0.0, 0, _stream()),
+                          "s2f_pgemm_dx_f32")
+            for g, w in enumerate(ws):
+                if not ctx.needs_input_grad[1 + g]:
+                    continue
+                sink = _sink_for(w)
+                if sink is None:
+                    gws[g] = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+                check(lib.s2f_gemm_dw_general(gy.data_ptr() + 4 * g * M * L, G * M * L, x.data_ptr() + 4 * g * K * L, G * K * L,
+                                              _ptr(gws[g] if sink is None else sink), B, M, K, L, int(sink is not None),
+                                              _stream()), "s2f_gemm_dw_general")
+            return (gx, *gws)
+        gyv = gy.view(B * G, M, L)
         if ctx.needs_input_grad[0]:
-            wt = w.transpose(1, 2)
-            wb = wt.unsqueeze(0).expand(B, G, K, M).reshape(B * G, K, M) if G > 1 else wt.expand(B, K, M)
-            gx = bmm_tuned(wb, gy).view(B, G * K, L)
-        if ctx.needs_input_grad[1]:
-            gw = bmm_tuned(gy, x.view(B * G, K, L).transpose(1, 2)).view(B, G, M, K).sum(0)
-        return gx, gw
+            wt = torch.stack(ws, 0).transpose(1, 2)
+            wb = wt.unsqueeze(0).expand(B, G, K, M).reshape(B * G, K, M) if G > 1 else wt[0].expand(B, K, M)
+            gx = bmm_tuned(wb, gyv).view(B, G * K, L)
+        if any(ctx.needs_input_grad[1:]):
+            gw = bmm_tuned(gyv, x.view(B * G, K, L).transpose(1, 2)).view(B, G, M, K).sum(0)
+            gws = [gw[g] for g in range(G)]
+        return (gx, *gws)
 
 
 def dense_gemm(x, w):
-    """x [B, G*K, L], w [G, M, K] (or [M, K]) -> [B, G*M, L]"""
-    return _DenseGemm.apply(x, w if w.dim() == 3 else w.unsqueeze(0))
+    """x [B, G*K, L]; w: one matrix [M, K], a stack [G, M, K], or a list of G matrices (e.g. views of G parameters: each then
+    keeps its own cached pack and gradient sink) -> [B, G*M, L]"""
+    if torch.is_tensor(w):
+        w = [w] if w.dim() == 2 else list(w.unbind(0))
+    return _DenseGemm.apply(x, *w)
 
 
 # ------------------------------------------------------------------------------------------------ parameter groups
@@ -1085,6 +1121,13 @@ CONV3X3_DX_MIN_PIXELS = 0          # measured at C2: a win on every map size (61
 MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pass split GEMM) instead of rocBLAS fp32
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
+# Round 3: the LDS-DMA pipelined kernels (csrc/pgemm.hip).  PGEMM: forward spike GEMMs on s2f_pgemm_nn_bf16 (packed weight, bf16
+# spikes, N % 8 == 0, N >= 128); PGEMM_DX: every fp32 x fp32 product that ran on the library in rounds 1-2 -- the input
+# gradients of the 1x1 convolutions and the forward products of the convolutions whose input is not a spike map -- on
+# s2f_pgemm_dx_f32 (6 bf16 passes = fp32 accuracy), their weight gradients on s2f_gemm_dw_general.
+PGEMM = _os.environ.get("S2F_PGEMM", "1") != "0"
+PGEMM_DX = _os.environ.get("S2F_PGEMM_DX", "1") != "0"
+PGEMM_MIN_N = 128
 
 
 def _owner(t):
@@ -1114,24 +1157,45 @@ def _cache_get(key, version, shape, owner):
     return None
 
 
-def _cache_put(key, version, out, shape, owner, job=None):
+def _cache_buffer(key, shape, owner, out_shape, device):
+    """The destination of a (re-)conversion: the buffer of a stale entry of the same weight is converted INTO again -- a
+    captured hipGraph (and the job tables of resplit_all) hold its address, a fresh allocation would leave them writing into
+    freed memory -- otherwise a new one."""
+    hit = _SPLIT_CACHE.get(key)
+    if (hit is not None and hit[2] == shape and hit[3]() is owner and hit[1].device == device
+            and tuple(hit[1].shape) == tuple(out_shape)):
+        return hit[1]
+    return torch.empty(out_shape, dtype=torch.int16, device=device)
+
+
+def _cache_put(key, version, out, shape, owner, job=None, kind="split"):
     import weakref
     if len(_SPLIT_CACHE) > 4096:                       # dead entries of freed models
         for k in [k for k, v in _SPLIT_CACHE.items() if v[3]() is None]:
             del _SPLIT_CACHE[k]
-    _SPLIT_CACHE[key] = (version, out, shape, weakref.ref(owner), job)
-    _SPLIT_TABLE["keys"] = None
+    old = _SPLIT_CACHE.get(key)
+    _SPLIT_CACHE[key] = (version, out, shape, weakref.ref(owner), job, kind)
+    if old is None or old[1] is not out or old[4] != job:
+        _SPLIT_TABLE["keys"] = None                    # a new destination: the job tables must be rebuilt (never mutated)
 
 
-_SPLIT_TABLE = {"keys": None, "jobs": None, "blocks": 0}
+# Job tables of resplit_all: one per conversion kernel.  A table tensor is REPLACED, never written again, once built: a
+# captured graph keeps reading the tensor it recorded (graph.py holds references to the tables and buffers of its capture).
+_SPLIT_TABLE = {"keys": None, "jobs": None, "blocks": 0, "njobs": 0, "pack_jobs": None, "pack_blocks": 0, "pack_njobs": 0}
+
+
+def conversion_state():
+    """What a captured step must keep alive: the job tables resplit_all launched with and every cached conversion buffer."""
+    return (_SPLIT_TABLE["jobs"], _SPLIT_TABLE["pack_jobs"], [v[1] for v in _SPLIT_CACHE.values()])
 
 
 def resplit_all(device, build=True):
-    """Redo EVERY cached weight split from the live fp32 weights in one launch (s2f_split_bf16x3_multi).  A training step owes
-    this after each optimiser update; a captured step (graph.GraphedStep) records it, so every replay multiplies by the
-    current weights -- without it the graph would replay the bf16 terms of capture time while its backward reads the live
-    fp32 weights.  -> number of weights re-split; -1 when the job table would have to be (re)built and `build` is False (the
-    table is uploaded from the host, which a stream capture does not allow: GraphedStep calls this once before capturing)."""
+    """Redo EVERY cached weight conversion (bf16 hi/mid/lo splits and packs) from the live fp32 weights: one launch per
+    conversion kernel (s2f_split_bf16x3_multi, s2f_pack_bf16x3_multi).  A training step owes this after each optimiser update;
+    a captured step (graph.GraphedStep) records it, so every replay multiplies by the current weights -- without it the graph
+    would replay the bf16 terms of capture time while its backward reads the live fp32 weights.  -> number of weights
+    converted; -1 when the job tables would have to be (re)built and `build` is False (they are uploaded from the host, which
+    a stream capture does not allow: GraphedStep calls this once before capturing)."""
     def covered(v):
         o = v[3]()
         if o is None or v[4] is None or v[1].device != device:
@@ -1142,17 +1206,28 @@ def resplit_all(device, build=True):
     if not live:
         return 0
     keys = tuple(k for k, _ in live)
-    if _SPLIT_TABLE["keys"] != keys or _SPLIT_TABLE["jobs"] is None or _SPLIT_TABLE["jobs"].device != device:
+    tab = _SPLIT_TABLE
+    if tab["keys"] != keys or (tab["jobs"] is None and tab["pack_jobs"] is None) or \
+            (tab["jobs"] if tab["jobs"] is not None else tab["pack_jobs"]).device != device:
         if not build:
             return -1
-        rows, first = [], 0
-        for _, (_ver, out, _shape, _own, (src, mode, cdim, M, K)) in live:
-            Mpad, Kpad = out.shape[1], out.shape[2]
-            rows.append([src, out.data_ptr(), M, K, Mpad, Kpad, mode | (cdim << 8), first])
-            first += (Mpad * Kpad + 1023) // 1024
-        _SPLIT_TABLE.update(keys=keys, jobs=torch.tensor(rows, dtype=torch.int64).to(device), blocks=first)
-    check(lib.s2f_split_bf16x3_multi(_ptr(_SPLIT_TABLE["jobs"]), len(live), _SPLIT_TABLE["blocks"], _stream()),
-          "s2f_split_bf16x3_multi")
+        rows, first, prows, pfirst = [], 0, [], 0
+        for _, (_ver, out, _shape, _own, (src, mode, cdim, M, K), kind) in live:
+            if kind == "pack":
+                prows.append([src, out.data_ptr(), M, K, mode | (cdim << 8), pfirst, 0, 0])
+                pfirst += ((M + 63) // 64) * ((K + 31) // 32) * 2
+            else:
+                Mpad, Kpad = out.shape[1], out.shape[2]
+                rows.append([src, out.data_ptr(), M, K, Mpad, Kpad, mode | (cdim << 8), first])
+                first += (Mpad * Kpad + 1023) // 1024
+        tab.update(keys=keys, blocks=first, njobs=len(rows), pack_blocks=pfirst, pack_njobs=len(prows),
+                   jobs=torch.tensor(rows, dtype=torch.int64).to(device) if rows else None,
+                   pack_jobs=torch.tensor(prows, dtype=torch.int64).to(device) if prows else None)
+    if tab["njobs"]:
+        check(lib.s2f_split_bf16x3_multi(_ptr(tab["jobs"]), tab["njobs"], tab["blocks"], _stream()), "s2f_split_bf16x3_multi")
+    if tab["pack_njobs"]:
+        check(lib.s2f_pack_bf16x3_multi(_ptr(tab["pack_jobs"]), tab["pack_njobs"], tab["pack_blocks"], _stream()),
+              "s2f_pack_bf16x3_multi")
     return len(live)
 
 
@@ -1170,11 +1245,33 @@ def split_weight(w2d):
     if hit is not None:
         return hit
     Mpad, Kpad = (M + 63) // 64 * 64, (K + 31) // 32 * 32
-    out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=w2d.device)
+    out = _cache_buffer(key, (M, K), owner, (3, Mpad, Kpad), w2d.device)
     src = w2d.detach()
     job = (src.data_ptr(), 0, 0, M, K) if src.is_contiguous() else None
     check(lib.s2f_split_bf16x3(_ptr(src.contiguous()), _ptr(out), M, K, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
     _cache_put(key, version, out, (M, K), owner, job)
+    return out
+
+
+def pack_weight(w2d, transposed=False):
+    """fp32 [M, K] -> the cached bf16 PACK of it (s2f.h "pipelined GEMMs": blocks of [3 terms][64 rows][32 k], the LDS image of
+    the LDS-DMA kernels), or of its transpose (`transposed`: the pack of w2d^T, the A operand of the forward product of a
+    convolution whose input is a general fp32 tensor).  The pack of W serves its forward product (s2f_pgemm_nn_bf16) AND the
+    input gradient W^T dY (s2f_pgemm_dx_f32).  Versioning and in-graph refresh as split_weight."""
+    key = ("pack", bool(transposed), w2d.data_ptr(), w2d.numel())
+    R, Cc = w2d.shape
+    M, K = (Cc, R) if transposed else (R, Cc)
+    version = getattr(w2d, "_s2f_version", w2d._version)
+    owner = _owner(w2d)
+    hit = _cache_get(key, version, (M, K), owner)
+    if hit is not None:
+        return hit
+    out = _cache_buffer(key, (M, K), owner, (int(lib.s2f_pack_elems(M, K)),), w2d.device)
+    src = w2d.detach()
+    mode = 3 if transposed else 0
+    job = (src.data_ptr(), mode, 0, M, K) if src.is_contiguous() else None
+    check(lib.s2f_pack_bf16x3(_ptr(src.contiguous()), _ptr(out), M, K, mode, 0, _stream()), "s2f_pack_bf16x3")
+    _cache_put(key, version, out, (M, K), owner, job, kind="pack")
     return out
 
 
@@ -1187,7 +1284,7 @@ def split_weight_conv3(weight):
         return hit
     w2d = weight.detach().permute(0, 2, 3, 1).reshape(M, 9 * C)
     Mpad, Kpad = (M + 63) // 64 * 64, (9 * C + 31) // 32 * 32
-    out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
+    out = _cache_buffer(key, (M, C), _owner(weight), (3, Mpad, Kpad), weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), M, 9 * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
     src = weight.detach()
     _cache_put(key, weight._version, out, (M, C), _owner(weight), (src.data_ptr(), 1, C, M, 9 * C) if src.is_contiguous() else None)
@@ -1204,7 +1301,7 @@ def split_weight_tconv3(weight):
         return hit
     w2d = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * M)
     Mpad, Kpad = (C + 127) // 128 * 128, (9 * M + 31) // 32 * 32
-    out = torch.empty(3, Mpad, Kpad, dtype=torch.int16, device=weight.device)
+    out = _cache_buffer(key, (M, C), _owner(weight), (3, Mpad, Kpad), weight.device)
     check(lib.s2f_split_bf16x3(_ptr(w2d), _ptr(out), C, 9 * M, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
     src = weight.detach()
     _cache_put(key, weight._version, out, (M, C), _owner(weight), (src.data_ptr(), 2, M, C, 9 * M) if src.is_contiguous() else None)
@@ -1228,13 +1325,17 @@ class _SpikeGemm(torch.autograd.Function):
         M = w2d.shape[0]
         if SPIKE_GEMM_CHECK:
             assert _is_spike_grid(x), "not a spike tensor"
-        ws = split_weight(w2d)
         y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
         xb = x.dtype == torch.bfloat16
         _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * ((2 if xb else 4) * K + 4 * M))
-        fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
-        check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()),
-              "s2f_spike_gemm_fwd")
+        if PGEMM and xb and N % 8 == 0 and N >= PGEMM_MIN_N:
+            check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, SPIKE_GEMM_TERMS, 0,
+                                        _stream()), "s2f_pgemm_nn_bf16")
+        else:
+            ws = split_weight(w2d)
+            fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
+            check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS, _stream()),
+                  "s2f_spike_gemm_fwd")
         ctx.save_for_backward(x, w2d)
         ctx.has_bias, ctx.has_tok = bias is not None, tok is not None
         return y
@@ -1275,8 +1376,16 @@ class _SpikeGemm(torch.autograd.Function):
 
 
 def dx_gemm(w2d, gy):
-    """Input gradient of a 1x1 convolution: gx[b] = W^T @ gy[b]  (two general fp32 operands)."""
-    B = gy.shape[0]
+    """Input gradient of a 1x1 convolution: gx[b] = W^T @ gy[b]  (two general fp32 operands): the transposed product on the
+    forward pack of W with gy split hi + mid + lo in the kernel (s2f_pgemm_dx_f32, 6 passes)."""
+    B, M, N = gy.shape
+    if PGEMM_DX and N % 4 == 0 and N >= PGEMM_MIN_N and gy.is_cuda:
+        K = w2d.shape[1]
+        gx = torch.empty(B, K, N, dtype=torch.float32, device=gy.device)
+        _time_next("dx_gemm", 4 * B * N * (K + M), 2 * B * M * N * K)
+        check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d)), _ptr(gy), 0, _ptr(gx), 0, B, M, K, N, 0.0, 0, _stream()),
+              "s2f_pgemm_dx_f32")
+        return gx
     if gy.shape[2] <= 128 and w2d.shape[0] <= 512 and w2d.shape[1] <= 512:
         # rocBLAS picks a 40 us kernel for the batched [256x256]^T @ [256x100] of the decoder (tools/probe_small_dx.py);
         # the same product through einsum's folding takes 12 us
@@ -1622,18 +1731,30 @@ class _ConvDense(torch.autograd.Function):
         ctx.implicit = False
         cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
         use_mfma = spike_input and SPIKE_GEMM_ENABLED and cols.shape[2] % 4 == 0
+        L = Ho * Wo
         if use_mfma:
-            ws = split_weight(w2d)
-            y = torch.empty(N, M, Ho * Wo, dtype=torch.float32, device=x.device)
-            _time_next("spike_gemm_fwd", 4 * N * Ho * Wo * (cols.shape[1] + M), 2 * N * M * Ho * Wo * cols.shape[1],
-                       moved=N * Ho * Wo * ((2 if xb else 4) * cols.shape[1] + 4 * M))
-            fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
-            check(fn(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, Ho * Wo, cols.shape[1], ws.shape[1], ws.shape[2],
-                     SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
+            y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
+            _time_next("spike_gemm_fwd", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1],
+                       moved=N * L * ((2 if xb else 4) * cols.shape[1] + 4 * M))
+            if PGEMM and xb and L % 8 == 0 and L >= PGEMM_MIN_N:
+                check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1],
+                                            SPIKE_GEMM_TERMS, 0, _stream()), "s2f_pgemm_nn_bf16")
+            else:
+                ws = split_weight(w2d)
+                fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
+                check(fn(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1], ws.shape[1], ws.shape[2],
+                         SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
         else:
             if xb:
                 cols = cols.float()
-            y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
+            if PGEMM_DX and L % 4 == 0 and L >= PGEMM_MIN_N:
+                # general fp32 input (the stem reads the image): the transposed product on the pack of W^T, 6 passes
+                y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
+                _time_next("dx_gemm", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1])
+                check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, N, cols.shape[1], M,
+                                           L, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
+            else:
+                y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
             if bias is not None:
                 y = y + bias.view(1, -1, 1)
         ctx.save_for_backward(cols, weight)
@@ -1661,7 +1782,7 @@ class _ConvDense(torch.autograd.Function):
                 gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)
                 gx = bmm_tuned(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
             else:
-                dcols = bmm_tuned(w2d.t().unsqueeze(0).expand(N, -1, -1), gy)
+                dcols = dx_gemm(w2d, gy)
                 gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
         if ctx.needs_input_grad[2]:
             K = w2d.shape[1]
@@ -1695,6 +1816,12 @@ class _ConvDense(torch.autograd.Function):
                 else:
                     check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
                                                 int(sink is not None), 1, st), "s2f_spike_gemm_dw")
+            elif PGEMM_DX and (Ho * Wo) % 4 == 0 and cols.dtype == torch.float32:
+                # both operands general fp32 (the stem): 6-pass weight-gradient kernel, straight into the sink when there is one
+                sink = _sink_for(weight)
+                gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
+                check(lib.s2f_gemm_dw_general(_ptr(gy), 0, _ptr(cols), 0, _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                              int(sink is not None), _stream()), "s2f_gemm_dw_general")
             else:
                 gw = torch.bmm(gy, cols.float().transpose(1, 2)).sum(0)
             gw = gw.view_as(weight) if gw is not None else None

@@ -826,3 +826,96 @@ def test_wide_weight_gradients_vs_fp64(B, M, K, L):
     acc = base.clone()
     check(lib.s2f_spike_gemm_dw_bf16(gy.data_ptr(), x.data_ptr(), acc.data_ptr(), B, M, K, L, 1, s), "dw accumulate")
     assert (acc.double() - (base.double() + ref)).abs().max().item() <= 3e-6 * scale + 1e-6 * base.abs().max().item()
+
+
+# ----------------------------------------------------------------------------------------------- LDS-DMA pipelined GEMMs (round 3)
+def _spikes_bf16(shape, g):
+    return (torch.randint(0, 9, shape, generator=g).float() / 8).cuda().bfloat16()
+
+
+@pytest.mark.parametrize("B,M,K,N", [(2, 64, 32, 128), (3, 100, 72, 136), (2, 256, 256, 1024), (1, 360, 360, 1024), (2, 700, 96, 384),
+                                     (8, 1024, 256, 1024), (1, 33, 1152, 256)])
+def test_pgemm_forward_is_the_round2_spike_gemm(ops, B, M, K, N):
+    """s2f_pgemm_nn_bf16 (packed weight, LDS-DMA, 2-3 stages) on ragged M / K and partial N tiles: against fp64 to the spike-GEMM
+    bound, and -- same products, same accumulation order over (k slice, term) -- BIT-IDENTICAL to s2f_spike_gemm_fwd_bf16 without
+    its in-workgroup K split; every tile configuration gives the same bits."""
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 1000 + M + K + N)
+    w = (torch.randn(M, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(M, generator=g).cuda()
+    x = _spikes_bf16((B, K, N), g)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.matmul(w.double(), x.double()) + bias.double().view(1, -1, 1)
+    bound = 2e-6 * (torch.matmul(w.abs().double(), x.double()) + bias.abs().double().view(1, -1, 1)).max().item()
+    outs = []
+    for cfg in (1, 2, 3, 4) + ((5,) if M >= 256 else ()):
+        y = torch.full((B, M, N), float("nan"), device="cuda")
+        check(lib.s2f_pgemm_nn_bf16(ops.pack_weight(w).data_ptr(), x.data_ptr(), bias.data_ptr(), y.data_ptr(), B, M, N, K, 3, cfg,
+                                    st), "pgemm")
+        assert (y.double() - ref).abs().max().item() <= bound, cfg
+        outs.append(y)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    if B * ((N + 127) // 128) * ((M + 63) // 64) >= 512 or K < 128:          # the round-2 kernel does not split K here
+        ws = ops.split_weight(w)
+        y0 = torch.empty(B, M, N, device="cuda")
+        check(lib.s2f_spike_gemm_fwd_bf16(ws.data_ptr(), x.data_ptr(), bias.data_ptr(), y0.data_ptr(), B, M, N, K, ws.shape[1],
+                                          ws.shape[2], 3, st), "old")
+        assert torch.equal(y0, outs[0])
+
+
+@pytest.mark.parametrize("B,Mo,Ki,N", [(2, 64, 32, 128), (3, 100, 72, 132), (2, 256, 256, 1024), (1, 360, 360, 1024),
+                                       (2, 1440, 360, 256), (8, 256, 1024, 1024), (2, 40, 600, 100), (1, 2048, 256, 100)])
+def test_pgemm_input_gradient_matches_fp64(ops, B, Mo, Ki, N):
+    """s2f_pgemm_dx_f32: dX = W^T dY from the FORWARD pack of W (transpose reads of both operands, dY split hi + mid + lo in the
+    kernel, 6 passes) on every kind of raggedness; fp32-GEMM accuracy, and beta = 1 accumulates."""
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 77 + Mo + Ki + N)
+    w = (torch.randn(Mo, Ki, generator=g) * Mo ** -0.5).cuda()
+    gy = torch.randn(B, Mo, N, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.matmul(w.t().double(), gy.double())
+    bound = 2e-6 * torch.matmul(w.t().abs().double(), gy.abs().double()).max().item()
+    for cfg in (1, 2, 3, 4):
+        dx = torch.full((B, Ki, N), float("nan"), device="cuda")
+        check(lib.s2f_pgemm_dx_f32(ops.pack_weight(w).data_ptr(), gy.data_ptr(), 0, dx.data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg, st), "dx")
+        assert (dx.double() - ref).abs().max().item() <= bound, cfg
+        check(lib.s2f_pgemm_dx_f32(ops.pack_weight(w).data_ptr(), gy.data_ptr(), 0, dx.data_ptr(), 0, B, Mo, Ki, N, 1.0, cfg, st), "dx")
+        assert (dx.double() - 2 * ref).abs().max().item() <= 2 * bound, cfg
+
+
+def test_dense_gemm_groups_forward_backward(ops):
+    """ops.dense_gemm (general fp32 input, G weights on consecutive channel groups -- the second 1x1 of the batched q / k / v
+    chain): forward on the pack of W^T, input gradient on the pack of W, weight gradient on the 6-pass kernel; against fp64."""
+    g = torch.Generator().manual_seed(5)
+    B, G, M, K, L = 3, 3, 72, 40, 256
+    x = torch.randn(B, G * K, L, generator=g).cuda().requires_grad_(True)
+    ws = [(torch.randn(M, K, generator=g) * K ** -0.5).cuda().requires_grad_(True) for _ in range(G)]
+    y = ops.dense_gemm(x, ws)
+    gy = torch.randn(B, G * M, L, generator=g).cuda()
+    y.backward(gy)
+    xd, gyd = x.detach().double().view(B, G, K, L), gy.double().view(B, G, M, L)
+    for i, w in enumerate(ws):
+        wd = w.detach().double()
+        assert (y.detach().double().view(B, G, M, L)[:, i] - torch.matmul(wd, xd[:, i])).abs().max().item() <= 1e-5
+        assert (x.grad.double().view(B, G, K, L)[:, i] - torch.matmul(wd.t(), gyd[:, i])).abs().max().item() <= 1e-5
+        gw = torch.einsum("bml,bkl->mk", gyd[:, i], xd[:, i])
+        assert (w.grad.double() - gw).abs().max().item() <= 2e-5 * gw.abs().max().item()
+
+
+def test_pack_is_refreshed_in_place(ops):
+    """A cached pack follows its weight: an in-place update bumps the version and the next use converts INTO THE SAME buffer (a
+    captured hipGraph holds its address); resplit_all redoes packs and splits alike from the live weights."""
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(100, 72, generator=g).cuda()
+    p0 = ops.pack_weight(w)
+    ptr, snap = p0.data_ptr(), p0.clone()
+    w.mul_(1.5)
+    p1 = ops.pack_weight(w)
+    assert p1.data_ptr() == ptr and not torch.equal(p1, snap)
+    w.data.mul_(2.0)                                        # no version bump: only resplit_all can refresh it
+    snap = p1.clone()
+    assert ops.resplit_all(w.device) >= 1
+    torch.cuda.synchronize()
+    assert ops.pack_weight(w).data_ptr() == ptr and not torch.equal(p1, snap)
+    pt = ops.pack_weight(w, transposed=True)
+    assert pt.numel() == ((72 + 63) // 64) * ((100 + 31) // 32) * 6144

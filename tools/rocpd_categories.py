@@ -11,7 +11,9 @@ def cat(name):
     if 'split_gemm' in name: return 'split GEMM (mask einsum), bf16 MFMA (ours)'
     if 'split_multi' in name: return 'weight re-split (ours)'
     if 'spike_gemm_dw' in name or 'sgemm_dw' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
-    if 'dx_' in name: return 'dX GEMM, bf16 MFMA (ours)'
+    if 'pg_tn' in name or 'dx_' in name: return 'dX / dense GEMM, 6-pass bf16 MFMA (ours)'
+    if 'pg_nn' in name: return 'spike GEMM fwd, bf16 MFMA (ours)'
+    if 'pack_' in name: return 'weight re-split (ours)'
     if 'spike_gemm' in name or 'split_bf16' in name or 'sgemm_bf16' in name: return 'spike GEMM fwd, bf16 MFMA (ours)'
     if 'up2x' in name: return 'upsample (ours)'
     if 'dcn_' in name: return 'dcn (ours)'
