@@ -75,20 +75,6 @@ __device__ __forceinline__ void mfma_fence(f32x16 (&acc)[MI][NJ]) {
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long)(lds_void*)p; }
 
-// A global load hipcc does not see (next to LDS-DMA it waits vmcnt(0) for every ordinary load: the copies running two steps
-// ahead would be drained at every step).  The destination is in flight until a counted wait retires it: vm_landed() then
-// hands the registers back to the compiler (`+v`: no consumer is scheduled above it).
-__device__ __forceinline__ void gload16_asm(f32x4& dst, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-template <int NQ>
-__device__ __forceinline__ void vm_landed(f32x4 (&r)[NQ]) {
-  static_assert(NQ >= 1 && NQ <= 4, "register set size");
-  if constexpr (NQ == 1) asm volatile("; landed" : "+v"(r[0]));
-  if constexpr (NQ == 2) asm volatile("; landed" : "+v"(r[0]), "+v"(r[1]));
-  if constexpr (NQ == 3) asm volatile("; landed" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
-  if constexpr (NQ == 4) asm volatile("; landed" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
-}
 // counted wait on the vector-memory queue (LDS-DMA and loads), all LDS operations, then the workgroup barrier
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
@@ -323,30 +309,29 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // ---------------------------------------------------------------------------------------------------------------------
 // TN with a general fp32 right operand -- the input gradient of a 1x1 convolution:
 //   DX[b] (Ki x N) = W^T (Ki x Mo) @ G[b] (Mo x N),   W (Mo x Ki) given as ITS forward pack, G fp32 (n contiguous).
-// Contraction step 16 (rows of W / G).  A stage of the weight operand holds, per term and per 32-column panel of the output
-// rows, 16 pack rows x 64 bytes copied verbatim (1 KiB contiguous in global memory and in LDS); a stage of the G operand holds
-// the three bf16 terms of the tile [16][BN] row-major with the unit swizzle; both MFMA operands are formed by transpose
-// reads.  6 passes.  Pipeline: the weight copies run TWO steps ahead (3 LDS stages), the G loads two steps ahead in two
-// register sets (split + stored one step ahead, 2 LDS stages): most launches of the path are 32x32-map products with one
-// workgroup per CU, where nothing but the kernel's own prefetch depth hides the ~700-cycle fabric latency of an operand that
-// another XCD has just written.  KG = 2: a second set of wavefronts walks the odd contraction steps of the same tile with its
-// own stages (two wavefronts per SIMD on such a launch), the partial tiles are summed through LDS.
-template <int MI, int NJ, int WMW, int WNW, int KG, bool BETA>
-__global__ __launch_bounds__(64 * WMW * WNW * KG) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
-                                                                       const float* __restrict__ G, float* __restrict__ DX,
-                                                                       int Mo, int Ki, int N, int KbW, int n_tiles, int m_tiles,
-                                                                       float beta, int64_t g_batch_stride,
-                                                                       int64_t dx_batch_stride) {
+// Contraction step 16 (rows of W / G), 2 LDS stages.  A stage holds, per term and per 32-column panel of the output rows,
+// 16 pack rows x 64 bytes copied verbatim by LDS-DMA (1 KiB contiguous in global memory and in LDS), and the three bf16
+// terms of the G tile [16][BN] -- loaded one step ahead into registers, split hi + mid + lo, stored row-major with the unit
+// swizzle; both MFMA operands are formed by transpose reads.  6 passes.
+// (Measured and dropped, tools/probe_pgemm.py: the G tile by LDS-DMA as raw fp32 + a read-back / split pass, weight copies two
+// steps ahead, and a second set of wavefronts on the odd contraction steps -- 15.0 vs 15.2 us on [256x256]^T [8x256x1024],
+// 137 vs 106 us on N = 16 384: per MFMA the kernel already moves ~8 LDS cycles, of which the three term stores (ds_write_b64 at
+// 85 B/clk) are 3 -- as many as the matrix pipe needs; more LDS traffic loses more than prefetch depth wins.  G loads issued
+// from inline asm two steps ahead (hipcc drains vmcnt(0) for its own loads next to LDS-DMA) were WRONG under register
+// pressure: the compiler spilled the in-flight destination registers to AGPRs.  What removes the stores is an operand that
+// ARRIVES split: the producer of dY writing bf16 hi / mid / lo planes -- DESIGN.md section 8.)
+template <int MI, int NJ, int WMW, int WNW, bool BETA>
+__global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
+                                                                  const float* __restrict__ G, float* __restrict__ DX, int Mo,
+                                                                  int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
+                                                                  int64_t g_batch_stride, int64_t dx_batch_stride) {
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   constexpr int KC = 16;
-  constexpr int A_BYTES = 3 * (BM / 32) * 1024, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM;
-  constexpr int GROUP_BYTES = 3 * A_BYTES + 2 * B_BYTES;
-  constexpr int NA = 3 * (BM / 32), NAW = (NA + NW - 1) / NW;       // 1 KiB copies per stage / per wavefront (padded: uniform)
+  constexpr int A_BYTES = 3 * (BM / 32) * 1024, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = 3 * (BM / 32);                               // 1 KiB copies per stage (the waits below do not count them)
   constexpr int NQ = KC * BN / 4 / T;                             // float4 loads per thread and stage
   static_assert(NQ >= 1 && (KC * BN / 4) % T == 0, "tile too small for the thread count");
-  constexpr int RED_BYTES = (KG - 1) * T * MI * NJ * 16 * 4;
-  constexpr int LDS_BYTES = KG * GROUP_BYTES > RED_BYTES ? KG * GROUP_BYTES : RED_BYTES;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem_all[LDS_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int tiles = n_tiles * m_tiles;
   int pid = blockIdx.x;
@@ -356,51 +341,45 @@ __global__ __launch_bounds__(64 * WMW * WNW * KG) void pg_tn_f32_kernel(const un
   const int m0 = mt * BM, n0 = nt * BN;                          // m0: first output row (a column of W)
   const float* Gb = G + (int64_t)b * g_batch_stride;
   float* Db = DX + (int64_t)b * dx_batch_stride;
-  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int grp = KG > 1 ? wave_all / NW : 0;
-  const int wave = wave_all - grp * NW;
-  const int tid = threadIdx.x - grp * T, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const int wm = wave / WNW, wn = wave % WNW;
-  unsigned char* smem = smem_all + grp * GROUP_BYTES;
   const int nk = (Mo + KC - 1) / KC;
-  const int ns = (nk + KG - 1) / KG;                              // steps of every group (a step past nk contributes nothing)
 
-  // step s of this group = contraction step t = s KG + grp
-  auto issue_a = [&](int s, int slot) __attribute__((always_inline)) {
-    unsigned char* sb = smem + slot * A_BYTES;
-    const int c0 = min(s * KG + grp, nk - 1) * KC;                // first contraction row (a row of W); clamped: copy count stays uniform
+  auto issue_a = [&](int t, int st) __attribute__((always_inline)) {
+    unsigned char* sb = smem + st * STAGE;
+    const int c0 = t * KC;                                        // first contraction row (a row of W)
+    const unsigned short* rows = Wp + (int64_t)(c0 / PR) * KbW * PBLOCK + (c0 % PR) * PK + lane * 8;
 #pragma unroll
-    for (int q = 0; q < NAW; ++q) {
-      int idx = wave + q * NW;
-      if (NA % NW != 0 && idx >= NA) idx -= NW;                   // pad with a repeat of an earlier copy (same bytes, same place)
+    for (int q = 0; q < (NA + NW - 1) / NW; ++q) {
+      const int idx = wave + q * NW;
+      if (NA % NW != 0 && idx >= NA) break;
       const int term = idx / (BM / 32), p = idx % (BM / 32);
       const int kb = min(m0 / PK + p, KbW - 1);                   // panels past Ki belong to rows that are never stored
-      dma16(Wp + ((int64_t)(c0 / PR) * KbW + kb) * PBLOCK + term * PTERM + (c0 % PR) * PK + lane * 8, sb + idx * 1024);
+      dma16(rows + kb * PBLOCK + term * PTERM, sb + idx * 1024);
     }
   };
-  auto fetch_b = [&](int s, f32x4 (&breg)[NQ]) __attribute__((always_inline)) {
-    const int t = min(s * KG + grp, nk - 1);
+  f32x4 breg[NQ];
+  auto fetch_b = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int p = tid + q * T;
       const int k = p / (BN / 4), c4 = p % (BN / 4);
       const int kr = min(t * KC + k, Mo - 1);                     // rows past Mo meet zero pack rows
       const int col = min(n0 + c4 * 4, N - 4);
-      gload16_asm(breg[q], Gb + (int64_t)kr * N + col);
+      breg[q] = *reinterpret_cast<const f32x4*>(Gb + (int64_t)kr * N + col);
     }
   };
-  auto stage_b = [&](int slot, const f32x4 (&breg)[NQ], bool live) __attribute__((always_inline)) {
-    unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + 3 * A_BYTES + slot * B_BYTES);
+  auto stage_b = [&](int st) __attribute__((always_inline)) {
+    unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + st * STAGE + A_BYTES);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int p = tid + q * T;
       const int k = p / (BN / 4), c4 = p % (BN / 4);
       const int off = k * BN + ((((c4 >> 3) ^ (k & 3)) << 5) | ((c4 & 7) << 2));
-      unsigned int h0 = 0, m0_ = 0, l0_ = 0, h1 = 0, m1 = 0, l1 = 0;
-      if (KG == 1 || live) {                                       // a step past nk (odd step count, KG = 2): zeros
-        s2f_split3x2(breg[q].x, breg[q].y, h0, m0_, l0_);
-        s2f_split3x2(breg[q].z, breg[q].w, h1, m1, l1);
-      }
+      unsigned int h0, m0_, l0_, h1, m1, l1;
+      s2f_split3x2(breg[q].x, breg[q].y, h0, m0_, l0_);
+      s2f_split3x2(breg[q].z, breg[q].w, h1, m1, l1);
       *reinterpret_cast<u32x2*>(Bs + off) = u32x2{h0, h1};
       *reinterpret_cast<u32x2*>(Bs + KC * BN + off) = u32x2{m0_, m1};
       *reinterpret_cast<u32x2*>(Bs + 2 * KC * BN + off) = u32x2{l0_, l1};
@@ -434,36 +413,36 @@ __global__ __launch_bounds__(64 * WMW * WNW * KG) void pg_tn_f32_kernel(const un
     }
 
   const unsigned smem_a = lds_addr(smem);
-  auto compute = [&](int aslot, int bslot) __attribute__((always_inline)) {
+  auto compute = [&](int st) __attribute__((always_inline)) {
     union BF {
       bf16x8 v;
       s16x4 h[2];
     } bfrag[3][NJ], afrag[3][MI];
-    const unsigned sa = smem_a + aslot * A_BYTES, sbb = smem_a + 3 * A_BYTES + bslot * B_BYTES;
+    const unsigned sb = smem_a + st * STAGE;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const unsigned a = sbb + boff[j] * 2;
-      bfrag[0][j].h[0] = lds_tr16_asm<0>(a);
-      bfrag[0][j].h[1] = lds_tr16_asm<4 * BN * 2>(a);
-      bfrag[1][j].h[0] = lds_tr16_asm<B_TERM>(a);
-      bfrag[1][j].h[1] = lds_tr16_asm<B_TERM + 4 * BN * 2>(a);
-      bfrag[2][j].h[0] = lds_tr16_asm<2 * B_TERM>(a);
-      bfrag[2][j].h[1] = lds_tr16_asm<2 * B_TERM + 4 * BN * 2>(a);
+      const unsigned a = sb + boff[j] * 2;
+      bfrag[0][j].h[0] = lds_tr16_asm<A_BYTES>(a);
+      bfrag[0][j].h[1] = lds_tr16_asm<A_BYTES + 4 * BN * 2>(a);
+      bfrag[1][j].h[0] = lds_tr16_asm<A_BYTES + B_TERM>(a);
+      bfrag[1][j].h[1] = lds_tr16_asm<A_BYTES + B_TERM + 4 * BN * 2>(a);
+      bfrag[2][j].h[0] = lds_tr16_asm<A_BYTES + 2 * B_TERM>(a);
+      bfrag[2][j].h[1] = lds_tr16_asm<A_BYTES + 2 * B_TERM + 4 * BN * 2>(a);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      afrag[0][i].h[0] = lds_tr16_asm<0>(sa + aoff[i][0] * 2);
-      afrag[0][i].h[1] = lds_tr16_asm<0>(sa + aoff[i][1] * 2);
+      afrag[0][i].h[0] = lds_tr16_asm<0>(sb + aoff[i][0] * 2);
+      afrag[0][i].h[1] = lds_tr16_asm<0>(sb + aoff[i][1] * 2);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      afrag[1][i].h[0] = lds_tr16_asm<(BM / 32) * 1024>(sa + aoff[i][0] * 2);
-      afrag[1][i].h[1] = lds_tr16_asm<(BM / 32) * 1024>(sa + aoff[i][1] * 2);
+      afrag[1][i].h[0] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][0] * 2);
+      afrag[1][i].h[1] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][1] * 2);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      afrag[2][i].h[0] = lds_tr16_asm<2 * (BM / 32) * 1024>(sa + aoff[i][0] * 2);
-      afrag[2][i].h[1] = lds_tr16_asm<2 * (BM / 32) * 1024>(sa + aoff[i][1] * 2);
+      afrag[2][i].h[0] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][0] * 2);
+      afrag[2][i].h[1] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][1] * 2);
     }
 #pragma unroll
     for (int ta = 0; ta < 3; ++ta) {
@@ -482,64 +461,26 @@ __global__ __launch_bounds__(64 * WMW * WNW * KG) void pg_tn_f32_kernel(const un
     }
   };
 
-  // Two register sets for the G loads; the loop is unrolled by two so that each set has fixed registers.
-  // Vector-memory queue of a wavefront, oldest first, at the wait of step s >= 1:
-  //   ... copies A(s) | loads G(s+2) | copies A(s+1)          (issued during steps s-2 and s-1)
-  // so "at most NQ + NAW outstanding" == the copies of tile s have landed.
-  f32x4 bset0[NQ], bset1[NQ];
-  fetch_b(0, bset0);
-  fetch_b(1, bset1);
+  fetch_b(0);
   issue_a(0, 0);
-  issue_a(1, 1);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ + 2 * NAW) : "memory");      // G(0) landed
-  vm_landed(bset0);
-  stage_b(0, bset0, grp < nk);
-  fetch_b(2, bset0);
-  int aslot = 0, aslot2 = 2;                                      // A slot of step s, of step s + 2
-  auto step = [&](int s, f32x4 (&bnext)[NQ]) __attribute__((always_inline)) {
-    // bnext: the register set holding G(s+1); it is refilled with G(s+3) once staged
-    if (s == 0)
-      wait_vm_and_barrier<NQ>();                                   // A(0), A(1) issued before G(2): all copies landed
+  stage_b(0);                                                      // the compiler waits for the loads of fetch_b(0) here
+  if (nk > 1) fetch_b(1);
+  for (int t = 0; t < nk; ++t) {
+    const int st = t & 1;
+    // copies of tile t are older than the loads of tile t+1 (NQ of them): a counted wait leaves those in flight
+    if (t + 1 < nk)
+      wait_vm_and_barrier<NQ>();
     else
-      wait_vm_and_barrier<NQ + NAW>();
-    if (s + 1 < ns) {
-      vm_landed(bnext);                                            // G(s+1) is older than the copies the wait just retired
-      stage_b((s + 1) & 1, bnext, (s + 1) * KG + grp < nk);
-      fetch_b(s + 3, bnext);
-      issue_a(s + 2, aslot2);
-    } else {
-      // keep the queue shape of the counted wait: nothing more is issued, the last waits drain
+      wait_vm_and_barrier<0>();
+    if (t + 1 < nk) {
+      stage_b(st ^ 1);                                             // tile t+1 from registers (loaded one step ago)
+      issue_a(t + 1, st ^ 1);
+      if (t + 2 < nk) fetch_b(t + 2);
     }
-    compute(aslot, s & 1);
-    aslot = aslot + 1 == 3 ? 0 : aslot + 1;
-    aslot2 = aslot2 + 1 == 3 ? 0 : aslot2 + 1;
-  };
-  for (int s = 0; s < ns; s += 2) {
-    step(s, bset1);
-    if (s + 1 < ns) step(s + 1, bset0);
+    compute(st);
   }
 
   mfma_fence(acc);
-  if (KG > 1) {
-    float* red = reinterpret_cast<float*>(smem_all);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every stage is dead
-    if (grp > 0) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[((i * NJ + j) * 16 + r) * T + tid] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (grp > 0) return;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * NJ + j) * 16 + r) * T + tid];
-  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -647,23 +588,21 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   static const char* force = getenv("S2F_PG_DX_CFG");
   int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
   if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
-#define S2F_PGD(MI, NJ, WMW, WNW, KGV)                                                                                  \
+#define S2F_PGD(MI, NJ, WMW, WNW)                                                                                       \
   do {                                                                                                                 \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
     if (beta != 0.f)                                                                                                   \
-      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, KGV, true>), dim3(n_tiles * m_tiles, batch),           \
-                 dim3(64 * WMW * WNW * KGV), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, true>), dim3(n_tiles * m_tiles, batch),                \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,     \
                  dx_batch_stride);                                                                                     \
     else                                                                                                               \
-    S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, KGV, false>), dim3(n_tiles * m_tiles, batch),            \
-               dim3(64 * WMW * WNW * KGV),                                                                             \
-               0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                                          \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, false>), dim3(n_tiles * m_tiles, batch),               \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,     \
+                 dx_batch_stride);                                                                                     \
   } while (0)
   switch (c) {
-    case 1: S2F_PGD(2, 2, 2, 2, 1); break;          // 128 x 128
-    case 2: S2F_PGD(1, 2, 2, 2, 1); break;          // 64 x 128
-    case 3: S2F_PGD(1, 2, 2, 2, 2); break;          // 64 x 128, contraction split over two sets of wavefronts
-    case 4: S2F_PGD(2, 2, 2, 2, 2); break;          // 128 x 128, split
+    case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
+    case 2: S2F_PGD(1, 2, 2, 2); break;          // 64 x 128
     default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_f32: unknown cfg %d", c);
   }
 #undef S2F_PGD
