@@ -263,6 +263,15 @@ int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* str
  *   forward pack (the same buffer the forward product reads); G is split hi + mid + lo in the kernel: 6 MFMA passes, 2^-24.
  *   N % 4 == 0; batch strides in elements (0 = dense).  With the pack of W^T (mode 3) the same kernel is the forward product
  *   Y = W @ X of a convolution whose input X is a general fp32 tensor.  Replaces the library fp32 GEMM (rocBLAS / hipBLASLt) of round 1-2. */
+/* Eval-mode fusion (the reference's fold: Qtrick_architecture/clock_driven/functional.py:574-692):
+ *   y = Q_IFNode( BatchNorm_running( W @ X + conv_bias ) [+ residual] )   as ONE launch -- the GEMM above with bn_apply's and
+ * the neuron's arithmetic in its epilogue (same per-element expressions: bit-identical to s2f_pgemm_nn_bf16 + s2f_bn_act_fwd in
+ * eval mode).  u_out? = the fp32 pre-activation, y_bf16? = the spikes (bf16), v_in? / v_out? = carried membrane, stats? = firing
+ * counters as in s2f_lif_fwd.  No backward (inference path). */
+int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, const float* conv_bias, const float* running_mean,
+                        const float* running_var, const float* gamma, const float* beta, float eps, const float* residual,
+                        float* u_out, const float* v_in, void* y_bf16, float* v_out, uint64_t* stats, int batch, int M, int N,
+                        int K, float vth, int D, void* stream);
 int64_t s2f_pack_elems(int M, int K);
 int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream);
 int s2f_pack_bf16x3_multi(const int64_t* jobs, int njobs, int64_t total_workgroups, void* stream);

@@ -14,6 +14,7 @@ from .maskformer_head import MaskFormerHead  # noqa: F401
 from .neuron import Q_IFNode, Quant, reset_net, set_keep_membrane  # noqa: F401
 from .pixel_decoder import DCNTransformerEncoderPixelDecoder  # noqa: F401
 from .registry import HOOKS, MODELS, ConfigDict, register_upstream  # noqa: F401
+from . import reparam  # noqa: F401
 from .segmentor import EncoderDecoder, ResetModelHook, headline_loss  # noqa: F401
 from .train import LinearThenPoly, OptimWrapper, parse_losses, train_step  # noqa: F401
 

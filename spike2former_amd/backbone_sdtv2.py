@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .conv import Conv1d, Conv2d, spikes_in
-from .fused import bn_act
+from .fused import bn_act, conv_bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -117,7 +117,7 @@ class SepConv(nn.Module):
         neuron that reads the result next, is applied there as well -- fused.bn_act)."""
         T, B, C, H, W = x.shape
         s = self.spike1.fire(x)
-        _, s = bn_act(self.pwconv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
+        _, s = conv_bn_act(self.pwconv1, s.flatten(0, 1), self.bn1, lif=self.spike2)
         z = self.pwconv2(self.dwconv(s))
         u, _ = bn_act(z, None, self.bn2, residual=None if residual is None else residual.flatten(0, 1), next_lif=next_lif)
         return u.reshape(T, B, C, H, W)
@@ -172,9 +172,9 @@ class MS_MLP(nn.Module):
     def forward(self, x, residual=None, next_lif=None):
         T, B, C, H, W = x.shape
         s = self.fc1_spike.fire(x.flatten(3)).flatten(0, 1)
-        _, s = bn_act(self.fc1_conv.forward_nobias(s), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
+        _, s = conv_bn_act(self.fc1_conv, s, self.fc1_bn, lif=self.fc2_spike)
         res = None if residual is None else residual.reshape(T * B, C, H * W)
-        u, _ = bn_act(self.fc2_conv.forward_nobias(s), self.fc2_conv.bias, self.fc2_bn, residual=res, next_lif=next_lif)
+        u, _ = conv_bn_act(self.fc2_conv, s, self.fc2_bn, residual=res, next_lif=next_lif)
         return u.reshape(T, B, C, H, W)
 
 

@@ -752,7 +752,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
 // channel c loads its slice ONCE, reduces the statistics through LDS and applies them from registers: z is read once instead
 // of twice and one launch replaces two.  At the 32x32 / 64x64 stages of the path the two-kernel form is launch-bound
 // (measured floors: bn_stats 4.3 us + bn_apply 5.5 us for <= 16 MB), which is where ~2/3 of the BatchNorm launches live.
-constexpr int kTpw = 8;                       // tiles per wave held in registers
+#ifndef S2F_BN_TPW
+#define S2F_BN_TPW 8
+#endif
+constexpr int kTpw = S2F_BN_TPW;              // tiles per wave held in registers
+constexpr int kFusedWaves = 32 / kTpw;        // wavefronts of a single-pass workgroup (a channel has at most 32 tiles)
+constexpr int kFusedBlock = 64 * kFusedWaves;
 
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int nwaves) {
   a = wave_sum_f64(a);
@@ -772,13 +777,13 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red, in
 }
 
 template <bool LIF, bool HAS_V, bool YB>
-__global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
+__global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ num_batches, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out, const float* __restrict__ v_in,
     float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
     int N, int C, int L, double inv_count, float unbias, float momentum, float eps, float vth, float Df) {
-  __shared__ double red[2 * kWaves];
+  __shared__ double red[2 * kFusedWaves];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = L >> 8, tiles = N * tpr;                  // tiles per row, tiles of this channel
   const float b = bias ? bias[c] : 0.f;
@@ -875,12 +880,12 @@ __global__ __launch_bounds__(kBlock) void bn_fused_fwd_kernel(
 }
 
 template <bool GU, bool GY, bool GV>
-__global__ __launch_bounds__(kBlock) void bn_fused_bwd_kernel(
+__global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
     const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df) {
-  __shared__ double red[2 * kWaves];
+  __shared__ double red[2 * kFusedWaves];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = L >> 8, tiles = N * tpr;
   const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(kBlock) void bn_fused_bwd_kernel(
 inline bool single_pass_ok(int64_t N, int64_t C, int64_t L) {
   if ((L & 255) != 0) return false;
   const int64_t tiles = N * (L >> 8);
-  return tiles >= 4 && tiles <= kWaves * kTpw && C >= 64 && N * C * L < ((int64_t)1 << 31);
+  return tiles >= 4 && tiles <= kFusedWaves * kTpw && C >= 64 && N * C * L < ((int64_t)1 << 31);
 }
 inline int single_pass_threads(int64_t N, int64_t L) {
   const int tiles = (int)(N * (L >> 8));

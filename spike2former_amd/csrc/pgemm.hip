@@ -143,15 +143,35 @@ __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__
   pack_body(w, out, M, K, mode, C, blockIdx.x);
 }
 
+// Epilogue of the eval-mode fusion  conv1x1 -> BatchNorm (running statistics) [+ residual] [-> Q_IFNode]  (s2f_gemm_bn_lif_fwd):
+// everything bn_apply_kernel does to a GEMM output, applied to the accumulator tile -- the fp32 pre-activation never makes
+// the round trip through HBM.  Per-element expressions are those of bn_lif.hip / lif.hip (contraction off): the spikes are
+// bit-identical to the two-kernel path.
+struct BnLifEpi {
+  const float* conv_bias;          // [M] or null
+  const float* mean;               // running_mean [M]
+  const float* var;                // running_var [M]
+  const float* gamma;              // [M]
+  const float* beta;               // [M]
+  const float* residual;           // [batch][M][N] fp32 or null
+  float* u_out;                    // [batch][M][N] fp32 or null: the pre-activation (residual stream)
+  const float* v_in;               // membrane carried in, or null (reset)
+  float* v_out;                    // membrane out, or null
+  unsigned short* y;               // [batch][M][N] bf16 spikes, or null (no neuron)
+  unsigned long long* stats;       // firing counters (s2f.h `stats`), or null
+  float eps, vth, Df, inv_d;
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // NN:  Y[b] (M x N) = A (M x K, packed) @ X[b] (K x N, bf16 spikes, n contiguous) [+ bias].
 // Block = WMW x WNW wavefronts, wavefront tile (32 MI) x (32 NJ), K step 32, NST LDS stages.
-template <int MI, int NJ, int WMW, int WNW, int AT, int NST>
+// EPI = 1: the BatchNorm (+ residual) (+ neuron) epilogue above instead of the plain store.
+template <int MI, int NJ, int WMW, int WNW, int AT, int NST, int EPI = 0>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned short* __restrict__ Ap,
                                                               const unsigned short* __restrict__ X,
                                                               const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                               int N, int K, int Kb, int n_tiles, int m_tiles,
-                                                              int64_t x_batch_stride) {
+                                                              int64_t x_batch_stride, BnLifEpi ep = BnLifEpi{}) {
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW;
   constexpr int A_BYTES = AT * BM * 64, B_BYTES = 32 * BN * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = AT * BM / 16, NB = B_BYTES / 1024;          // 1 KiB copies per stage
@@ -286,6 +306,60 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 
   // epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   mfma_fence(acc);
+  if constexpr (EPI == 1) {
+#pragma clang fp contract(off)
+    unsigned int csum = 0, cnz = 0;
+    const int64_t boff_ = (int64_t)b * M * N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float pb[16], pm[16], pr[16], pg[16], pe[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {            // per-row parameters first (clamped addresses), one wait
+        const int row = min(m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+        pb[r] = ep.conv_bias ? ep.conv_bias[row] : 0.f;
+        pm[r] = ep.mean[row];
+        pr[r] = 1.0f / sqrtf(ep.var[row] + ep.eps);
+        pg[r] = ep.gamma[row];
+        pe[r] = ep.beta[row];
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + (wn * NJ + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M && col < N) {
+            const int64_t o = boff_ + (int64_t)row * N + col;
+            float u = ((acc[i][j][r] + pb[r]) - pm[r]) * pr[r] * pg[r] + pe[r];
+            if (ep.residual) u += ep.residual[o];
+            if (ep.u_out) ep.u_out[o] = u;
+            if (ep.y) {
+              const float h = ep.v_in ? (ep.v_in[o] + u) : u;
+              float sp, yy, vn;
+              bool inr;
+              s2f_lif_update(h, ep.Df, ep.inv_d, ep.vth, sp, yy, vn, inr);
+              ep.y[o] = (unsigned short)(__float_as_uint(yy) >> 16);        // exact: a spike has <= 8 significant bits
+              if (ep.v_out) ep.v_out[o] = vn;
+              csum += (unsigned int)sp;
+              cnz += ((unsigned int)sp != 0);
+            }
+          }
+        }
+      }
+    }
+    if (ep.y && ep.stats) {
+      for (int o = 32; o > 0; o >>= 1) {
+        csum += __shfl_xor(csum, o, 64);
+        cnz += __shfl_xor(cnz, o, 64);
+      }
+      if (lane == 0) {
+        unsigned long long* slot = ep.stats + 2 * ((blockIdx.x * NW + wave) % S2F_STAT_SLOTS);
+        if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+        if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float bv[16];
@@ -320,11 +394,14 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // from inline asm two steps ahead (hipcc drains vmcnt(0) for its own loads next to LDS-DMA) were WRONG under register
 // pressure: the compiler spilled the in-flight destination registers to AGPRs.  What removes the stores is an operand that
 // ARRIVES split: the producer of dY writing bf16 hi / mid / lo planes -- DESIGN.md section 8.)
-template <int MI, int NJ, int WMW, int WNW, bool BETA>
+// EPI: 0 = store, 1 = DX = acc + beta * DX, 2 = atomic add into a zeroed DX (gridDim.z workgroups share the contraction: the
+// decoder's 100-token products with a 2 048-long contraction have 16 output tiles).
+template <int MI, int NJ, int WMW, int WNW, int EPI>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
                                                                   int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
                                                                   int64_t g_batch_stride, int64_t dx_batch_stride) {
+  constexpr bool BETA = EPI == 1;
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   constexpr int KC = 16;
   constexpr int A_BYTES = 3 * (BM / 32) * 1024, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM, STAGE = A_BYTES + B_BYTES;
@@ -344,11 +421,15 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const int wm = wave / WNW, wn = wave % WNW;
-  const int nk = (Mo + KC - 1) / KC;
+  const int nk_all = (Mo + KC - 1) / KC;
+  const int per_z = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int t_first = EPI == 2 ? (int)blockIdx.z * per_z : 0;
+  const int nk = EPI == 2 ? max(0, min(nk_all - t_first, per_z)) : nk_all;          // steps of this workgroup
+  if (EPI == 2 && nk == 0) return;
 
-  auto issue_a = [&](int t, int st) __attribute__((always_inline)) {
+  auto issue_a = [&](int tl, int st) __attribute__((always_inline)) {
     unsigned char* sb = smem + st * STAGE;
-    const int c0 = t * KC;                                        // first contraction row (a row of W)
+    const int c0 = (t_first + tl) * KC;                           // first contraction row (a row of W)
     const unsigned short* rows = Wp + (int64_t)(c0 / PR) * KbW * PBLOCK + (c0 % PR) * PK + lane * 8;
 #pragma unroll
     for (int q = 0; q < (NA + NW - 1) / NW; ++q) {
@@ -360,12 +441,12 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
     }
   };
   f32x4 breg[NQ];
-  auto fetch_b = [&](int t) __attribute__((always_inline)) {
+  auto fetch_b = [&](int tl) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int p = tid + q * T;
       const int k = p / (BN / 4), c4 = p % (BN / 4);
-      const int kr = min(t * KC + k, Mo - 1);                     // rows past Mo meet zero pack rows
+      const int kr = min((t_first + tl) * KC + k, Mo - 1);        // rows past Mo meet zero pack rows
       const int col = min(n0 + c4 * 4, N - 4);
       breg[q] = *reinterpret_cast<const f32x4*>(Gb + (int64_t)kr * N + col);
     }
@@ -497,7 +578,12 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < Ki && col < N) Db[(int64_t)row * N + col] = BETA ? acc[i][j][r] + beta * prev[r] : acc[i][j][r];
+        if (row < Ki && col < N) {
+          if (EPI == 2)
+            atomicAdd(Db + (int64_t)row * N + col, acc[i][j][r]);
+          else
+            Db[(int64_t)row * N + col] = BETA ? acc[i][j][r] + beta * prev[r] : acc[i][j][r];
+        }
       }
     }
 }
@@ -540,7 +626,7 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
   do {                                                                                                                 \
     const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                     \
     S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, ATV, NSTV>), dim3(n_tiles * m_tiles, batch),                 \
-               dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs);                     \
+               dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{});                     \
   } while (0)
 #define S2F_PG_T(MI, NJ, WMW, WNW, NSTV)          \
   do {                                           \
@@ -562,6 +648,25 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
 #undef S2F_PG_T
 #undef S2F_PG
   return s2f_check_launch("s2f_pgemm_nn_bf16");
+}
+
+extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, const float* conv_bias, const float* running_mean,
+                                   const float* running_var, const float* gamma, const float* beta, float eps,
+                                   const float* residual, float* u_out, const float* v_in, void* y_bf16, float* v_out,
+                                   uint64_t* stats, int batch, int M, int N, int K, float vth, int D, void* stream) {
+  S2F_REQUIRE(a_pack && X && running_mean && running_var && gamma && beta, S2F_EINVAL, "s2f_gemm_bn_lif_fwd: null pointer");
+  S2F_REQUIRE(u_out || y_bf16, S2F_EINVAL, "s2f_gemm_bn_lif_fwd: neither u_out nor y requested");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && (N & 7) == 0 && K > 0, S2F_EINVAL,
+              "s2f_gemm_bn_lif_fwd: bad sizes (N=%d must be a positive multiple of 8)", N);
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_gemm_bn_lif_fwd: bf16 spikes need D a power of two <= 128");
+  S2F_REQUIRE(s2f_aligned16(a_pack) && s2f_aligned16(X), S2F_EALIGN, "s2f_gemm_bn_lif_fwd: operands must be 16-byte aligned");
+  const int Kb = (K + PK - 1) / PK, n_tiles = (N + 127) / 128, m_tiles = (M + 63) / 64;
+  BnLifEpi ep{conv_bias, running_mean, running_var, gamma, beta, residual, u_out, v_in, v_out,
+              reinterpret_cast<unsigned short*>(y_bf16), reinterpret_cast<unsigned long long*>(stats), eps, vth, (float)D,
+              1.0f / (float)D};
+  S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, (hipStream_t)stream,
+             a_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep);
+  return s2f_check_launch("s2f_gemm_bn_lif_fwd");
 }
 
 extern "C" int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream) {
@@ -588,17 +693,31 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   static const char* force = getenv("S2F_PG_DX_CFG");
   int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
   if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
+  // few output tiles and a long contraction (the decoder's 100-token products): split the contraction over gridDim.z
+  int zsplit = 1;
+  {
+    const int64_t wgs = (int64_t)n_tiles * batch * ((Ki + 63) / 64);
+    const int steps = (Mo + 15) / 16;
+    while (beta == 0.f && wgs * zsplit < 128 && steps / (zsplit * 2) >= 8) zsplit *= 2;
+  }
+  if (zsplit > 1) {
+    S2F_REQUIRE(dx_batch_stride == (int64_t)Ki * N, S2F_EINVAL, "s2f_pgemm_dx_f32: the split form needs a dense DX");
+    if (s2f_zero_async(DX, sizeof(float) * (size_t)batch * Ki * N, s) != S2F_OK) return s2f_check_launch("s2f_pgemm_dx_f32 zero");
+    c = 2;
+  }
 #define S2F_PGD(MI, NJ, WMW, WNW)                                                                                       \
   do {                                                                                                                 \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
-    if (beta != 0.f)                                                                                                   \
-      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, true>), dim3(n_tiles * m_tiles, batch),                \
-                 dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,     \
-                 dx_batch_stride);                                                                                     \
+    const dim3 grid(n_tiles * m_tiles, batch, zsplit);                                                                 \
+    if (zsplit > 1)                                                                                                    \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 2>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,  \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                              \
+    else if (beta != 0.f)                                                                                              \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 1>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                              \
     else                                                                                                               \
-      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, false>), dim3(n_tiles * m_tiles, batch),               \
-                 dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,     \
-                 dx_batch_stride);                                                                                     \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                              \
   } while (0)
   switch (c) {
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128

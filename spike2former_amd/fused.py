@@ -23,6 +23,9 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         return u, None
     if want_pre is None:
         want_pre = lif is None
+    wanted_pre = want_pre
+    if lif is not None and lif._forward_hooks:
+        want_pre = True          # a forward hook receives the neuron's fp32 input: the kernel must write it out
     shape = z.shape
     N, C = shape[0], shape[1]
     L = z.numel() // max(N * C, 1)
@@ -61,4 +64,60 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
             yf = y.float().detach()
             for hook in list(lif._forward_hooks.values()):
                 hook(lif, (u,), yf)
+    if not wanted_pre:
+        u = None
     return (u, y, border) if want_border else (u, y)
+
+
+def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
+    """1x1 convolution (Conv2d / Conv1d of this package, fed by a neuron) -> BatchNorm [+ residual] [-> neuron]; x [N, K, *].
+    In eval mode on bf16 spikes this is ONE launch -- the packed-weight GEMM with the BatchNorm (running statistics), the
+    residual add and the neuron in its epilogue (ops.gemm_bn_lif_eval; the inference-time fold of SURVEY section 8 row f4,
+    reference helpers clock_driven/functional.py:574-692): the fp32 convolution output never reaches HBM.  Everything else
+    (training, fp32 inputs, shapes the kernel does not take, someone recording gradients) is conv.forward_nobias + bn_act.
+    Returns (u, y) as bn_act."""
+    shape_in = x.shape
+    L = 1
+    for d in shape_in[2:]:
+        L *= d
+    fire = next_lif if (next_lif is not None and lif is None) else lif
+    if want_pre is None:
+        want_pre = lif is None
+    pure_conv = (conv.kernel_size in ((1, 1), (1,)) and conv.groups == 1 and tuple(conv.stride) in ((1, 1), (1,))
+                 and tuple(conv.padding) in ((0, 0), (0,)))
+    eval_bn = (not bn.training) and bn.running_mean is not None and bn.affine
+    if not (pure_conv and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
+            and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
+        z = conv.forward_nobias(x)
+        return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
+    M = conv.out_channels
+    v_in = None
+    if fire is not None and not isinstance(fire.v, float):
+        v_in = fire.v.detach()
+    if fire is not None and fire.stats is not None:
+        fire.stats_elems += shape_in[0] * M * L
+    u, y, v_out = ops.gemm_bn_lif_eval(
+        x.reshape(shape_in[0], shape_in[1], L), conv.weight.view(M, -1), conv.bias, bn.running_mean, bn.running_var, bn.weight,
+        bn.bias, bn.eps, residual=None if residual is None else residual.reshape(shape_in[0], M, L),
+        want_pre=bool(want_pre or (next_lif is not None and lif is None) or (fire is not None and bool(fire._forward_hooks))),
+        lif=fire is not None, v_in=v_in,
+        keep_v=(fire is not None and fire.keep_membrane), D=(fire.D if fire is not None else 8),
+        vth=(fire.v_threshold if fire is not None else 1.0), stats=(fire.stats if fire is not None else None))
+    out_shape = (shape_in[0], M) + tuple(shape_in[2:])
+    if u is not None:
+        u = u.view(out_shape)
+    if y is not None:
+        y = y.view(*out_shape)
+    if fire is not None:
+        fire.v = v_out.view(out_shape) if fire.keep_membrane else 0.0
+        if fire._forward_hooks:
+            yf = y.float().detach()
+            for hook in list(fire._forward_hooks.values()):
+                hook(fire, (u,), yf)
+    if next_lif is not None and lif is None:
+        next_lif.prefire(u, y)
+        return u, None
+    return (u if want_pre else None), y
+
+
+EVAL_FUSION = True          # eval-mode conv + BatchNorm + neuron as one GEMM launch (False: the two-kernel path, for A/B and tests)

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import ops
 from .conv import Conv1d, Conv2d, spikes_in
-from .fused import bn_act
+from .fused import bn_act, conv_bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import ConfigDict
 
@@ -131,8 +131,8 @@ class DCNv3_pytorch(nn.Module):
             ops.use_here(x1)
             _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
             # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
-            offset, _ = bn_act(self.offset[0].forward_nobias(x1), self.offset[0].bias, self.offset[1])
-            _, mask = bn_act(self.mask[0].forward_nobias(x1), self.mask[0].bias, self.mask[1], lif=self.mask_spike)
+            offset, _ = conv_bn_act(self.offset[0], x1, self.offset[1])
+            _, mask = conv_bn_act(self.mask[0], x1, self.mask[1], lif=self.mask_spike)
             return offset.reshape(T * N, H, W, -1), mask.reshape(T * N, H, W, -1)
 
         # the two chains share only `inp`: launched side by side when ops.BRANCH_STREAMS is set.  (Forking offset / mask once
@@ -172,8 +172,8 @@ class MS_MLP(nn.Module):
         """x [T,B,C,H,W] -> the FFN output as it lies in memory, [T*B, C, H*W] (the caller applies the reference's
         reinterpretation of that buffer as [T,B,H,W,C], :829)."""
         x = self.fc1_spike.fire(x.flatten(3)).flatten(0, 1)
-        _, x = bn_act(self.fc1_conv.forward_nobias(x), self.fc1_conv.bias, self.fc1_bn, lif=self.fc2_spike)
-        x, _ = bn_act(self.fc2_conv.forward_nobias(x), self.fc2_conv.bias, self.fc2_bn)
+        _, x = conv_bn_act(self.fc1_conv, x, self.fc1_bn, lif=self.fc2_spike)
+        x, _ = conv_bn_act(self.fc2_conv, x, self.fc2_bn)
         return x
 
     def forward(self, x):
@@ -270,7 +270,7 @@ class MultiHeadAttentionBlock(nn.Module):
         """neuron -> Conv1d -> BN1d -> neuron on [t,b,L,dim] (or channel-major [t,b,dim,L]) -> channel-major spikes [t*b, dim, L]"""
         x = spike_in.fire(x) if fired is None else fired
         x = x.flatten(0, 1) if channel_major else x.permute(0, 1, 3, 2).flatten(0, 1)
-        return bn_act(conv[0].forward_nobias(x), conv[0].bias, conv[1], lif=spike_out)[1]
+        return conv_bn_act(conv[0], x, conv[1], lif=spike_out)[1]
 
     def project_kv(self, key, value, kv_channel_major=False, kv_spikes=None):
         """The key and value chains alone (they do not depend on the query) -> (k, v) channel-major spikes."""
@@ -309,7 +309,7 @@ class MultiHeadAttentionBlock(nn.Module):
                 lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm)],
                 inputs=(query, key, value, fk, fv))
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)      # embed_dim**0.5, not head dim
-        o, _ = bn_act(self.out_conv[0].forward_nobias(o), self.out_conv[0].bias, self.out_conv[1])
+        o, _ = conv_bn_act(self.out_conv[0], o, self.out_conv[1])
         if qcm:
             return o.view(t, b, dim, nq), None
         return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
@@ -374,8 +374,8 @@ class MSDA_FFN(nn.Module):
     def forward(self, x, identity=None):
         t, bs, N, C = x.shape
         a = self.fc1_spike.fire(x).reshape(t * bs, C, N)
-        _, a = bn_act(self.fc1.forward_nobias(a), self.fc1.bias, self.bn1, lif=self.fc2_spike)
-        a, _ = bn_act(self.fc2.forward_nobias(a), self.fc2.bias, self.bn2)
+        _, a = conv_bn_act(self.fc1, a, self.bn1, lif=self.fc2_spike)
+        a, _ = conv_bn_act(self.fc2, a, self.bn2)
         return a.reshape(t, bs, N, C)
 
 

@@ -1379,7 +1379,7 @@ def dx_gemm(w2d, gy):
     """Input gradient of a 1x1 convolution: gx[b] = W^T @ gy[b]  (two general fp32 operands): the transposed product on the
     forward pack of W with gy split hi + mid + lo in the kernel (s2f_pgemm_dx_f32, 6 passes)."""
     B, M, N = gy.shape
-    if PGEMM_DX and N % 4 == 0 and N >= PGEMM_MIN_N and gy.is_cuda:
+    if PGEMM_DX and N % 4 == 0 and gy.is_cuda:
         K = w2d.shape[1]
         gx = torch.empty(B, K, N, dtype=torch.float32, device=gy.device)
         _time_next("dx_gemm", 4 * B * N * (K + M), 2 * B * M * N * K)
@@ -1391,6 +1391,36 @@ def dx_gemm(w2d, gy):
         # the same product through einsum's folding takes 12 us
         return torch.einsum("mk,bml->bkl", w2d, gy)
     return bmm_tuned(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
+
+
+def gemm_bn_lif_eval_ok(x, N):
+    """The eval-mode fusion takes bf16 spikes with N % 8 == 0, N >= PGEMM_MIN_N, and builds no autograd graph."""
+    return (PGEMM and isinstance(x, Spikes) and x.data.dtype == torch.bfloat16 and x.data.is_cuda and N % 8 == 0
+            and N >= PGEMM_MIN_N and not (torch.is_grad_enabled() and x.requires_grad))
+
+
+def gemm_bn_lif_eval(x, w2d, conv_bias, running_mean, running_var, gamma, beta, eps, residual=None, want_pre=False, lif=False,
+                     v_in=None, keep_v=False, D=8, vth=1.0, stats=None):
+    """Eval-mode  conv1x1 -> BatchNorm(running statistics) [+ residual] [-> Q_IFNode]  as ONE launch (s2f_gemm_bn_lif_fwd: the
+    packed-weight GEMM with the BatchNorm and neuron arithmetic in its epilogue).  x: bf16 Spikes
+    [B, K, N].  -> (u fp32 or None, spikes as Spikes or None, v_out or None).  No backward: inference only."""
+    data = x.data.contiguous()
+    B, K, N = data.shape
+    M = w2d.shape[0]
+    dev = data.device
+    with torch.no_grad():
+        u = torch.empty(B, M, N, dtype=torch.float32, device=dev) if want_pre else None
+        y = torch.empty(B, M, N, dtype=torch.bfloat16, device=dev) if lif else None
+        v_out = torch.empty(B, M, N, dtype=torch.float32, device=dev) if (lif and keep_v) else None
+        if residual is not None:
+            residual = residual.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        _time_next("gemm_bn_lif", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * (2 * K + (4 if want_pre else 0) + (2 if lif else 0)))
+        check(lib.s2f_gemm_bn_lif_fwd(_ptr(pack_weight(w2d)), _ptr(data), _ptr(conv_bias), _ptr(running_mean), _ptr(running_var),
+                                      _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y), _ptr(v_out),
+                                      _ptr(stats), B, M, N, K, float(vth), int(D), _stream()), "s2f_gemm_bn_lif_fwd")
+    return u, (Spikes(y, _new_tok(y)) if lif else None), v_out
 
 
 def spike_gemm(x, w2d, bias=None):

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from .head_layers import DCNDetrTransformerEncoder, SinePositionalEncoding
 from . import ops
 from .conv import Conv1d, Conv2d, spikes_in
-from .fused import bn_act
+from .fused import bn_act, conv_bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -75,7 +75,7 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         t, bs, c, h, w = x4.shape
         E = self.encoder_embed_dims
         def conv_bn(seq, x, **kw):
-            return bn_act(seq[0].forward_nobias(x), seq[0].bias, seq[1], **kw)
+            return conv_bn_act(seq[0], x, seq[1], **kw)
 
         # The lateral 1x1 convolutions read only the backbone taps: with ops.LONG_STREAMS set they are launched on a side
         # stream now and overlap with the six encoder layers (chains of 32x32-map kernels that leave most CUs idle).

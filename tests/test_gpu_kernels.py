@@ -919,3 +919,50 @@ def test_pack_is_refreshed_in_place(ops):
     assert ops.pack_weight(w).data_ptr() == ptr and not torch.equal(p1, snap)
     pt = ops.pack_weight(w, transposed=True)
     assert pt.numel() == ((72 + 63) // 64) * ((100 + 31) // 32) * 6144
+
+
+# ----------------------------------------------------------------------------------------------- eval-mode fusion (row f4)
+@pytest.mark.parametrize("B,M,K,N,res,pre,stateful", [(2, 64, 32, 128, False, False, False), (3, 100, 72, 136, True, True, False),
+                                                      (2, 256, 256, 1024, True, True, True), (1, 360, 360, 256, False, False, True)])
+def test_gemm_bn_lif_eval_is_the_two_kernel_path(ops, B, M, K, N, res, pre, stateful):
+    """s2f_gemm_bn_lif_fwd (conv1x1 -> BatchNorm(running statistics) [+ residual] -> Q_IFNode in the GEMM epilogue) against the
+    unfused eval path  s2f_pgemm_nn_bf16 -> s2f_bn_act_fwd: same accumulator, same per-element expressions -> the spikes, the
+    pre-activation, the carried membrane and the firing counters are IDENTICAL."""
+    g = torch.Generator().manual_seed(B + M + K + N)
+    w = (torch.randn(M, K, generator=g) * K ** -0.5).cuda()
+    cb = torch.randn(M, generator=g).cuda()
+    rm, rv = torch.randn(M, generator=g).cuda() * 0.1, (torch.rand(M, generator=g) + 0.5).cuda()
+    ga, be = (torch.rand(M, generator=g) + 0.5).cuda(), torch.randn(M, generator=g).cuda() * 0.1
+    x = ops.Spikes(_spikes_bf16((B, K, N), g), None)
+    r = torch.randn(B, M, N, generator=g).cuda() if res else None
+    v = torch.rand(B, M, N, generator=g).cuda() if stateful else None
+    st_a, st_b = ops.new_stats("cuda"), ops.new_stats("cuda")
+    with torch.no_grad():
+        z = ops.spike_gemm(x, w)
+        u0, y0, v0 = ops.bn_act(z, cb, ga, be, rm, rv, None, False, 0.1, 1e-5, residual=r, lif=True, want_pre=pre, v_in=v,
+                                keep_v=stateful, stats=st_a)
+        u1, y1, v1 = ops.gemm_bn_lif_eval(x, w, cb, rm, rv, ga, be, 1e-5, residual=r, want_pre=pre, lif=True, v_in=v,
+                                          keep_v=stateful, stats=st_b)
+    assert torch.equal(y0.data, y1.data)
+    assert (u0 is None and u1 is None) or torch.equal(u0, u1)
+    assert (v0 is None and v1 is None) or torch.equal(v0, v1)
+    assert torch.equal(ops.read_stats(st_a), ops.read_stats(st_b)) and int(ops.read_stats(st_b)[1]) > 0
+
+
+def test_reparam_helpers_fold_like_the_reference():
+    """reparam.fused_conv2d_{weight,bias}_of_convbn2d / fuse_convbn2d (functional.py:574-692): conv(x; w', b') == BN_eval(conv(x; w))."""
+    import torch.nn as nn
+    from spike2former_amd import reparam
+    g = torch.Generator().manual_seed(1)
+    conv = nn.Conv2d(6, 10, 3, padding=1, bias=False)
+    bn = nn.BatchNorm2d(10).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g))
+        bn.weight.copy_(torch.rand(10, generator=g) + 0.5); bn.bias.copy_(torch.randn(10, generator=g))
+        bn.running_mean.copy_(torch.randn(10, generator=g)); bn.running_var.copy_(torch.rand(10, generator=g) + 0.5)
+        x = torch.randn(2, 6, 8, 8, generator=g)
+        want = bn(conv(x))
+        w2 = (conv.weight.transpose(0, 3) * bn.weight / (bn.running_var + bn.eps).sqrt()).transpose(0, 3)      # the reference's line
+        assert torch.allclose(reparam.fused_conv2d_weight_of_convbn2d(conv, bn), w2, atol=0, rtol=1e-6)
+        got = reparam.fuse_convbn2d(conv, bn)(x)
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)

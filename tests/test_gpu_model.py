@@ -452,3 +452,48 @@ def test_decoder_layer_on_the_channel_major_query_stream_is_the_token_major_laye
     assert gp1.keys() == gp2.keys()
     for n in gp1:
         assert same(gp1[n], gp2[n], 1e-4), n
+
+
+def test_eval_fusion_is_the_two_kernel_inference_path():
+    """Row f4: in eval mode every  conv1x1 -> BatchNorm -> Q_IFNode  chain fed by a neuron runs as ONE GEMM launch with the
+    BatchNorm + neuron epilogue (fused.conv_bn_act -> s2f_gemm_bn_lif_fwd).  With the plumbing config's widths on 256x256 images
+    (maps of 128 pixels and more take the fused kernel: SepConv / MLP convolutions of the backbone, the pixel decoder's
+    projections and MLPs, the decoder's key / value projections) the logits and the firing table -- with membranes carried
+    over three images as tools/cal_firing_num.py does -- are IDENTICAL to the unfused kernels' (fused.EVAL_FUSION = False)."""
+    import spike2former_amd as s2f
+    from spike2former_amd import fused
+    from oracle import s2f_oracle as so
+    cfg = so.CONFIGS["C1"]
+    model = s2f.MODELS.build(s2f.model_cfg("C1"))
+    model.load_state_dict(so.make_params(cfg, requires_grad=False), strict=True)
+    model.cuda().eval()
+    imgs = [torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(s)).cuda() for s in (11, 12, 13)]
+    calls = []
+    from spike2former_amd._lib import lib
+    orig = lib.s2f_gemm_bn_lif_fwd
+    lib.s2f_gemm_bn_lif_fwd = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        res = {}
+        for on in (True, False):
+            fused.EVAL_FUSION = on
+            s2f.set_keep_membrane(model, True)
+            s2f.reset_net(model)
+            outs = []
+            with torch.no_grad(), s2f.FiringRecorder(model) as rec:
+                for im in imgs:                      # no reset in between: membranes carried
+                    outs.append(model(im, mode="logits"))
+                rec.collect()
+            res[on] = (outs, dict(rec.table))
+            if on:
+                # the fused kernel really ran: per image 4 SepConv.pwconv1 + 12 block3 MLP convolutions + pixel-decoder and
+                # decoder projections (maps under 128 pixels keep the two-kernel path)
+                assert len(calls) >= 3 * 20 and len(calls) % 3 == 0, len(calls)
+                n_on = len(calls)
+        assert len(calls) == n_on                                   # ... and not with the switch off
+    finally:
+        fused.EVAL_FUSION = True
+        lib.s2f_gemm_bn_lif_fwd = orig
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert res[True][1].keys() == res[False][1].keys()
+    assert all(res[True][1][k] == res[False][1][k] for k in res[True][1])
