@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+DTYPE = "f32 (fp32-equivalent: bf16 hi+mid+lo split operands on bf16 MFMA, fp32 accumulate; spike maps stored as bf16, exact)"
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (no sparsity)
 
@@ -33,6 +34,11 @@ def parse():
     ap.add_argument("--loss", default="headline", choices=["headline", "hungarian"],
                     help="hungarian: the reference's real training loss (SURVEY 8 row f1) on a synthetic semantic map; the "
                          "matching runs on the host in the middle of the step, so the step is launched eagerly (secondary figure)")
+    ap.add_argument("--mode", default="train", choices=["train", "predict"],
+                    help="predict: SECONDARY figure (SURVEY section 8 row f4) -- the inference path in eval mode under no_grad "
+                         "(reset -> backbone -> head -> whole-image seg logits), hipGraph replay; --no-eval-fusion runs it on the "
+                         "two-kernel conv -> BatchNorm+neuron path for comparison")
+    ap.add_argument("--no-eval-fusion", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP-event pass on the LIF kernels")
     ap.add_argument("--dump-events", default=None, help="write (kernel, algorithmic bytes, us) of every timed launch here")
@@ -88,6 +94,52 @@ def cpu_baseline(workload, timed_steps=3):
                       + ", ".join(f"{t:.1f}" for t in times) + " s (first = warm-up)"}
 
 
+def predict_bench(args, s2f, ops, dev, w, B, rank, world):
+    """Secondary line: inference images/s (eval mode, running-statistics BatchNorm, no autograd), one hipGraph per step."""
+    import torch
+    from spike2former_amd import fused
+    from spike2former_amd.init_utils import seeded_init
+    fused.EVAL_FUSION = not args.no_eval_fusion
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg(args.workload))).to(dev).eval()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(B, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+
+    def fwd():
+        s2f.reset_net(model)
+        with torch.no_grad():
+            return model(img, mode="logits")
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(args.warmup, 2)):
+            fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    ops.resplit_all(dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd()
+    keep = ops.conversion_state()          # noqa: F841  (addresses baked into the graph)
+    for _ in range(args.warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"predict images/sec ({args.workload}: eval mode, whole-image inference to seg logits) [secondary]",
+            "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "launch": "hipGraph replay",
+            "eval_fusion": bool(fused.EVAL_FUSION), "logits_shape": list(out.shape),
+            "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']}, per-GPU batch {B}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"}}), flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -106,6 +158,8 @@ def main():
 
     w = s2f.WORKLOADS[args.workload]
     B = args.batch or w["B"]                        # per-GPU batch: weak scaling (BASELINE.json configs[1]: batch=2 on 1 GPU)
+    if args.mode == "predict":
+        return predict_bench(args, s2f, ops, dev, w, B, rank, world)
     model = seeded_init(s2f.MODELS.build(s2f.model_cfg(args.workload))).to(dev).train()
     broadcast_params(model)
     s2f.set_keep_membrane(model, False)             # a reset precedes every step -> the membrane is never read back
@@ -234,8 +288,10 @@ def main():
                                                         if graphed_model is not None else "eager]")) if seg is not None else ""),
             "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": ("forward / backward hipGraphs, all-reduce of step k under the forward of step k+1" if overlapped is not None
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "launch": ("forward / backward hipGraphs, all-reduce of step k under the forward of step k+1 (benchmark-only: no weight update fits in between)" if overlapped is not None
+                                             else "forward / backward hipGraphs around the host-side matching" if graphed_model is not None
                                              else "eager" if graphed is None else "hipGraph replay"),
+            "ranks_seen": (dist.get_world_size() if distributed else 1),
             "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']} "
                                    f"{'E-SpikeFormer (SDT-v3)' if 'v2' in str(w.get('backbone', '')) else 'Meta-SpikeFormer'} "
                                    f"{w['embed_dim']} + MaskFormer head, per-GPU batch {B}",
@@ -245,13 +301,14 @@ def main():
         if events:
             # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
             # separate runs, gfx950 corrections applied there); null when no such profile exists for a kernel
-            traffic = {}
+            traffic, traffic_src = {}, None
             try:
-                for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json"):          # the newest profile wins
+                for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest profile wins
                     path = os.path.join(ROOT, "profiles", name)
                     if os.path.exists(path):
                         with open(path) as f:
                             traffic.update({k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()})
+                        traffic_src = f"profiles/{name} (rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
             except (OSError, KeyError, ValueError):
                 pass
             if args.dump_events:
@@ -271,23 +328,31 @@ def main():
                     # `achieved` prices the launch at SURVEY 8d's ALGORITHMIC bytes (the reference's fp32 tensors: 4 B per
                     # element read or written); `moved_*` is what this build's kernel actually transfers for them (spike
                     # maps leave as bf16: 2 B per element) -- both are reported, as 8d asks
-                    out[key] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    # `achieved` / `frac`: the bytes this build's kernel actually MOVES (spike maps leave as bf16: 2 B per
+                    # element) over the launch time -- the bandwidth really used, which is what the 8 TB/s roof bounds.
+                    # `algorithmic_*`: the same launches priced at SURVEY 8d's figures for the reference's fp32 tensors (4 B
+                    # per element read or written) -- reported next to it, as 8d asks.
+                    mgbs = moved / secs / 1e9
+                    out[key] = {"kernel": name, "bound": "hbm", "achieved": round(mgbs, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(mgbs / HBM_PEAK_GBS, 4),
                                 "traffic": traffic.get(name) if args.workload == "C2" else None,
+                                "traffic_source": (traffic_src if (args.workload == "C2" and name in traffic) else None),
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
+                                "moved_bytes_per_launch": moved // launches,
                                 "algorithmic_bytes_per_launch": nbytes // launches,
-                                "moved_bytes_per_launch": moved // launches, "moved_GBps": round(moved / secs / 1e9, 1),
-                                "moved_frac": round(moved / secs / 1e9 / HBM_PEAK_GBS, 4)}
+                                "algorithmic_GBps": round(gbs, 1), "algorithmic_frac": round(gbs / HBM_PEAK_GBS, 4)}
             # the same fused forward kernel restricted to launches whose operands cannot sit in the caches (>= 128 MB of
             # algorithmic traffic): what the kernel itself sustains, next to the all-launches figure above that is dominated
             # by the 5 us launch floor of the 2-33 MB launches ("streaming-kernel efficiency")
-            big = [(nb, us) for name, nb, _, us, _m in events if name == "bn_lif_fwd" and nb >= 128e6]
+            big = [(nb, us, mv) for name, nb, _, us, mv in events if name == "bn_lif_fwd" and nb >= 128e6]
             if big:
-                gbs = sum(nb for nb, _ in big) / sum(us for _, us in big) / 1e3
+                tsec = sum(us for _, us, _ in big)
+                gbs, mgbs = sum(nb for nb, _, _ in big) / tsec / 1e3, sum(mv for _, _, mv in big) / tsec / 1e3
                 out["roofline_bn_lif_fwd_hbm_resident"] = {
-                    "kernel": "bn_lif_fwd", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(big),
-                    "avg_launch_us": round(sum(us for _, us in big) / len(big), 2), "min_algorithmic_bytes": 128000000}
+                    "kernel": "bn_lif_fwd", "bound": "hbm", "achieved": round(mgbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(mgbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(big),
+                    "avg_launch_us": round(tsec / len(big), 2), "min_algorithmic_bytes": 128000000,
+                    "algorithmic_GBps": round(gbs, 1), "algorithmic_frac": round(gbs / HBM_PEAK_GBS, 4)}
             # the MFMA kernels: ALGORITHMIC flops (2 M N K per GEMM) against the dense bf16 MFMA peak.  Every fp32
             # multiply-add is issued as 3 bf16 products (W or dY split hi + mid + lo, fp32-equivalent accuracy):
             # `issued_frac` = 3 x frac is the matrix pipes' own utilisation.  The K <= 256 shapes of the path are bound by

@@ -224,9 +224,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const TX* __restrict__ x,
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int ty = (tile / tiles_x) * TS, tx = (tile % tiles_x) * TS;
     __syncthreads();                          // the previous tile's readers are done with s
-#ifndef NO_STAGE
     stage_halo<K, TX>(s, xp, H, W, ty - pad, tx - pad, pad, fillv, pad, vec_ok);
-#endif
     float g[4] = {0.f, 0.f, 0.f, 0.f};
     const int oy = ty + r, ox = tx + q0;
     const float* p = gp + (int64_t)oy * Wo + ox;
@@ -241,7 +239,6 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const TX* __restrict__ x,
       }
     }
     __syncthreads();
-#ifndef NO_MAC
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       float row[K + 3];
@@ -251,15 +248,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const TX* __restrict__ x,
       for (int j = 0; j < K; ++j)
         acc[i * K + j] += (g[0] * row[j] + g[1] * row[j + 1]) + (g[2] * row[j + 2] + g[3] * row[j + 3]);
     }
-#else
-    acc[0] += g[0] + g[1] + g[2] + g[3] + s[r][q0];
-#endif
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifdef NO_REDUCE
-  if (acc[0] + acc[KK - 1] == 123.f) gw[0] = 1.f;
-  return;
-#endif
 #pragma unroll
   for (int t = 0; t < KK; ++t) {
     const float v = s2f_wave_sum_lane63(acc[t]);
@@ -268,11 +258,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const TX* __restrict__ x,
   __syncthreads();
   if (threadIdx.x < KK) {
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-#ifdef NO_ATOMIC
-    if (t == 123.f) gw[0] = t;
-#else
     atomicAdd(gw + c * KK + threadIdx.x, t);
-#endif
   }
 }
 

@@ -163,12 +163,8 @@ __global__ __launch_bounds__(64 * WNW * WM * KG, FWD_MIN_BLOCKS(WM, KG)) void sg
       if constexpr (CONV) {
         // raw load; the border fix-up happens when the tile is staged (conv3_fix), one K step later
         const int py = n / geo.W, px = n - py * geo.W;
-#ifdef S2F_CONV_PRED_LOADS
-        breg[q] = conv3_load_bf16(Xb + (int64_t)(ok ? c0 + kr : 0) * N, n, py, px, ky, kx, geo, ok);
-#else
         const Conv3Pred pr = conv3_pred(py, px, ky, kx, geo, ok);
         breg[q] = *reinterpret_cast<const chunk_t*>(Xb + (int64_t)(ok ? c0 + kr : 0) * N + conv3_off(n, ky, kx, geo, pr));
-#endif
       } else {
         // general form: row r of the contraction lies in slab r / k_inner (slabs x_outer_stride apart; k_inner % 32 == 0, so
         // a K step never straddles two slabs)
@@ -211,21 +207,16 @@ __global__ __launch_bounds__(64 * WNW * WM * KG, FWD_MIN_BLOCKS(WM, KG)) void sg
           for (int e = 0; e < CH / 2; ++e) bv[e] = 0u;
         }
       }
-#ifndef S2F_CONV_PRED_LOADS
       if constexpr (CONV) {
         const int tap = k0 / geo.C, ky = tap / 3, kx = tap - 3 * ky;
         const int n = n0 + nc * CH, py = n / geo.W, px = n - py * geo.W;
         const bool ok = (KG == 1 || k0 < Kpad) && k0 + kr < K && n < N;
         bv = conv3_fix(bv, conv3_pred(py, px, ky, kx, geo, ok));
       }
-#endif
       *reinterpret_cast<chunk_t*>(Bs + kr * BN + ((((nc / CPC) ^ (kr & 3))) << 5) + (nc % CPC) * CH) = bv;
     }
     __syncthreads();
-#ifndef GP_NO_GLOBAL
     if (k0 + KG * BK < kloop) fetch(k0 + KG * BK);
-#endif
-#ifndef GP_NO_LDSREAD
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kof = ks * 16 + 8 * (lane >> 5);
@@ -247,24 +238,9 @@ __global__ __launch_bounds__(64 * WNW * WM * KG, FWD_MIN_BLOCKS(WM, KG)) void sg
           const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * 64 + i * 32 + (lane & 31)][kof]);
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-#ifdef GP_NO_MFMA
-            acc[i][j][0] += (float)afrag[0] + (float)bfrag[j][0];
-#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
-#endif
         }
     }
-#else
-    {                                          // probe: the MFMA stream alone, operands from registers
-      bf16x8 af, bfr;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) af[e] = bfr[e] = (__bf16)1.0f;
-#pragma unroll
-      for (int rep = 0; rep < 2 * TERMS * 2; ++rep)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[rep & 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[rep & 1][j], 0, 0, 0);
-    }
-#endif
     __syncthreads();
   }
   if (KG > 1) {
@@ -297,15 +273,11 @@ __global__ __launch_bounds__(64 * WNW * WM * KG, FWD_MIN_BLOCKS(WM, KG)) void sg
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#ifdef GP_NO_STORE
-        if (row < M && col < N && acc[i][j][r] == 123.456f) Yb[0] = 1.f;
-#else
         if (row < M && col < N) {
           float v = acc[i][j][r];
           if (bias) v += bias[row];
           Yb[(int64_t)row * N + col] = ex.general ? v * ex.out_scale : v;
         }
-#endif
       }
     }
 }
@@ -372,9 +344,6 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     ox[h] = (unsigned int)min(row, K - 1 - k0) * (unsigned int)L;
   }
   auto fetch = [&](int step, f32x4 (&a)[NHA], u32x2 (&bq)[NH]) {
-#ifdef GP_SAME_SLAB
-    step = 0;                                       // probe: every step re-reads the first slab (cache-resident operands)
-#endif
     const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
     const float* pa = dY + ((int64_t)b * M + m0) * L;                            // wave-uniform
     const unsigned short* px = X + ((int64_t)b * K + k0) * L;
@@ -389,13 +358,8 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       // the compiler sinks the load under the predicate and waits for it on the spot
       if (h < NHA) a[h < NHA ? h : 0] = *reinterpret_cast<const f32x4*>(pa + (oa[h < NHA ? h : 0] + col));
       if constexpr (CONV) {
-#ifdef S2F_CONV_PRED_LOADS
-        bq[h] = conv3_load_bf16(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo,
-                                lok && rok_x[h]);
-#else
         const Conv3Pred pr = conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]);
         bq[h] = *reinterpret_cast<const u32x2*>(X + ((int64_t)b * geo.C + crow[h]) * L + conv3_off(l, ctap[h] / 3, ctap[h] % 3, geo, pr));
-#endif
       } else {
         bq[h] = *reinterpret_cast<const u32x2*>(px + (ox[h] + col));
       }
@@ -411,32 +375,22 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       if (h < NHA) {
         const f32x4 av = (lok && rok_a[h < NHA ? h : 0]) ? a[h < NHA ? h : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned int h0, m0_, l0_, h1, m1, l1;
-#ifdef GP_NO_SPLIT
-        h0 = m0_ = l0_ = __float_as_uint(av.x) ^ __float_as_uint(av.y);
-        h1 = m1 = l1 = __float_as_uint(av.z) ^ __float_as_uint(av.w);
-#else
         s2f_split3x2(av.x, av.y, h0, m0_, l0_);
         s2f_split3x2(av.z, av.w, h1, m1, l1);
-#endif
         *reinterpret_cast<u32x2*>(&As[0][row][col]) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(&As[1][row][col]) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2*>(&As[2][row][col]) = u32x2{l0_, l1};
       }
       if constexpr (CONV) {
-#ifdef S2F_CONV_PRED_LOADS
-        *reinterpret_cast<u32x2*>(&Bs[row][col]) = bq[h];
-#else
         const int l = l0s + lq[h];
         *reinterpret_cast<u32x2*>(&Bs[row][col]) =
             conv3_fix(bq[h], conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]));
-#endif
       } else {
         *reinterpret_cast<u32x2*>(&Bs[row][col]) = (lok && rok_x[h]) ? bq[h] : u32x2{0u, 0u};
       }
     }
   };
   auto compute = [&]() __attribute__((always_inline)) {
-#ifndef GP_NO_LDSREAD
     // (Requesting the fragments of sub-step ks + 1 before the MFMAs of sub-step ks -- two register sets, s_waitcnt lgkmcnt(n)
     // counting down instead of lgkmcnt(0) before every pair of MFMAs -- measured no gain: 184.8 vs 180.6 us.)
 #pragma unroll
@@ -450,42 +404,19 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-#ifdef GP_A_ONE_TERM
-          const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[0][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
-#else
           const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&As[t][wm * (MI * 32) + i * 32 + (lane & 31)][kof]);
-#endif
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-#ifdef GP_NO_MFMA
-            acc[i][j][0] += (float)afrag[0] + (float)bfrag[j][0];
-#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
-#endif
         }
     }
-#else
-    {
-      bf16x8 af, bfr;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) af[e] = bfr[e] = (__bf16)1.0f;
-#pragma unroll
-      for (int rep = 0; rep < (BKV / 16) * 3; ++rep)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i][j], 0, 0, 0);
-    }
-#endif
   };
   // (Two register sets fetched TWO steps ahead: no gain in the probe or in the step -- 45.76/45.81 vs 45.83/45.82 ms.)
   fetch(s_begin, areg, breg);
   for (int step = s_begin; step < s_end; ++step) {
     stage(step, areg, breg);
     __syncthreads();
-#ifndef GP_NO_GLOBAL
     if (step + 1 < s_end) fetch(step + 1, areg, breg);
-#endif
     compute();
     __syncthreads();
   }
@@ -497,11 +428,7 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#ifdef GP_NO_STORE
-        if (row < M && col < K && acc[i][j][r] == 123.456f) dW[0] = 1.f;
-#else
         if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
-#endif
       }
     }
 }
@@ -512,13 +439,9 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
 // the plain order the ~36 tiles of a split were spread over all eight L2s and every tile re-fetched its operands (885 MB of
 // L2 misses for 142 MB of operands on [512x1152] over [8x4096]: the kernel ran at that traffic, not at its MFMA rate).
 __device__ __forceinline__ int xcd_contiguous(int f, int total) {
-#ifdef S2F_DW_NO_XCD_ORDER
-  return f;
-#else
   const int chunk = total >> 3, rem = total & 7;
   const int xcd = f & 7, idx = f >> 3;
   return xcd * chunk + min(xcd, rem) + idx;
-#endif
 }
 
 // Workgroups per CU the register allocation must leave room for: the 64-row tiles sat at 172 registers, 4 above the limit for

@@ -72,6 +72,7 @@ class FlatGradAllReduce:
     def close(self):
         """Detach the gradient sinks (call before dropping this object: ops.GRAD_SINKS is process-global)."""
         from . import ops
+        ops.wgrad_drop()
         if self.sinks:
             if ops.GRAD_SINKS is getattr(self, "_sink_dict", None):          # not if a newer buffer has installed its own
                 ops.GRAD_SINKS = None
@@ -85,6 +86,8 @@ class FlatGradAllReduce:
 
     def zero(self):
         """Before backward: drop the old gradients so that autograd assigns instead of accumulating."""
+        from . import ops
+        ops.wgrad_drop()                       # deferred weight gradients of an abandoned step must not land in this one
         for p in self.params:
             p.grad = None
         if self.sinks:
@@ -137,6 +140,8 @@ class FlatGradAllReduce:
     def compact(self):
         """After one step with sinks: move the parameters whose gradient arrived through a sink (p.grad is None) behind the
         others in the flat layout, so that packing stays ONE batched copy over the leading region."""
+        from . import ops
+        ops.wgrad_drop()                       # pending jobs hold views of the OLD layout
         have = [p for p in self.params if p.grad is not None]
         rest = [p for p in self.params if p.grad is None]
         self.params = have + rest

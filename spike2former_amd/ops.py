@@ -149,6 +149,15 @@ def _defer_dw(gy, x, sink, B, M, K, L):
     _DW_PENDING[64 if (L % 64 == 0 or L >= 512) else 32].append((gy, x, sink, B, M, K, L))
 
 
+def wgrad_drop():
+    """Forget the deferred weight gradients that were never flushed (a backward that raised, an abandoned step): their sink
+    views and activations must not be added into the NEXT step's freshly zeroed buffer."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return                                 # inside a capture the step's own flush follows; nothing stale can be pending
+    for jobs in _DW_PENDING.values():
+        jobs.clear()
+
+
 def wgrad_flush():
     import ctypes
     for bkv, jobs in _DW_PENDING.items():

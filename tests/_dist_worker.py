@@ -1,0 +1,91 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a world-size-2 job whose ranks SHARE GPU 0 (gloo carries the collectives).
+Runs the N > 1 bench path on the real model: broadcast_params, FlatGradAllReduce with gradient sinks + deferred grouped weight
+gradients, GraphedStep capture with a process group alive, replay, reduce(); checks the reduced buffer against the mean of the
+two shards' plain-autograd gradients.  Prints `RANK r OK` or raises."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import spike2former_amd as s2f                                               # noqa: E402
+from spike2former_amd import ops                                             # noqa: E402
+from spike2former_amd.dist import FlatGradAllReduce, broadcast_params, init_process_group, shard_batch      # noqa: E402
+from spike2former_amd.graph import GraphedStep                              # noqa: E402
+from spike2former_amd.init_utils import seeded_init                         # noqa: E402
+
+rank, world, local = init_process_group()
+assert world == 2 and dist.get_backend() == "gloo"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+w = s2f.WORKLOADS["C1_64"]
+model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1_64"))).to(dev).train()
+with torch.no_grad():                                        # rank 1 starts from different weights: the broadcast must fix it
+    if rank == 1:
+        for p in model.parameters():
+            p.mul_(1.25)
+broadcast_params(model)
+chk = torch.cat([p.detach().flatten() for p in model.parameters()] + [b.detach().flatten().float() for b in model.buffers()])
+both = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(both, chk)
+assert torch.equal(both[0], both[1]), "parameters differ after broadcast_params"
+s2f.set_keep_membrane(model, False)
+
+G = 2 * w["B"]                                               # global batch, identical on every rank; each takes its shard
+imgs = torch.randn(G, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(5)).to(dev)
+start, per = shard_batch(G, rank, world)
+
+# reference: plain autograd gradients of BOTH shards on this rank (no sinks, no graph), averaged
+state = {k: v.clone() for k, v in model.state_dict().items()}
+
+
+def plain_grads(x):
+    model.load_state_dict(state)                             # the same running statistics before every step
+    for p in model.parameters():
+        p.grad = None
+    s2f.reset_net(model)
+    cls, masks = model(x)
+    s2f.headline_loss(cls, masks).backward()
+    return {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+
+
+ga, gb = plain_grads(imgs[:per]), plain_grads(imgs[per:])
+want = {n: (ga[n] + gb[n]) / 2 for n in ga}
+
+# the bench path
+model.load_state_dict(state)
+red = FlatGradAllReduce(model.parameters(), world)
+red.install_sinks()
+mine = imgs[start:start + per].clone()
+
+
+def eager():
+    s2f.reset_net(model)
+    red.zero()
+    cls, masks = model(mine)
+    s2f.headline_loss(cls, masks).backward()
+    ops.wgrad_join()
+    red.gather()
+
+
+eager()
+red.compact()
+model.load_state_dict(state)
+step = GraphedStep(model, s2f.headline_loss, mine, grad_buffer=red, warmup=2)
+model.load_state_dict(state)
+step()
+red.reduce()
+red.wait()
+torch.cuda.synchronize()
+name_of = {id(p): n for n, p in model.named_parameters()}
+gscale = max(v.abs().max().item() for v in want.values())
+worst = 0.0
+for p, v in zip(red.params, red.views):
+    ref = want[name_of[id(p)]]
+    worst = max(worst, (v - ref).abs().max().item() / (ref.abs().max().item() + 1e-3 * gscale))
+assert worst <= 2e-3, f"reduced gradients differ from the mean of the shards' gradients: {worst}"
+assert any(len(j) == 0 for j in ops._DW_PENDING.values()) and all(len(j) == 0 for j in ops._DW_PENDING.values())
+print(f"RANK {rank} OK worst {worst:.2e} ranks_seen {dist.get_world_size()}", flush=True)
+dist.barrier()
+dist.destroy_process_group()

@@ -1,0 +1,28 @@
+"""The N > 1 bench path on the REAL model, on one GPU: two fresh child processes (torch.distributed.run, gloo, both on GPU 0)
+run tests/_dist_worker.py -- broadcast_params, gradient sinks, deferred grouped weight gradients, a GraphedStep captured with
+a process group alive, FlatGradAllReduce.reduce() -- and compare the reduced flat buffer with the mean of the two shards'
+plain-autograd gradients.  (No scaling figure can come from one GPU; this is the correctness half of SURVEY section 8e.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_reduce_the_mean_of_their_shards():
+    env = dict(os.environ, S2F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=850)      # children only: nothing is re-exec'ed
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RANK 0 OK" in r.stdout and "RANK 1 OK" in r.stdout, r.stdout[-2000:]

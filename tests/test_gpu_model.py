@@ -1,6 +1,6 @@
 """GPU parity of the whole path (backbone + MaskFormer head) against the oracle / the reference's golden vectors.
 
-Tolerance statement.  Convolutions, BatchNorm statistics and sin/cos run through MIOpen / rocBLAS / ATen on the GPU and
+Tolerance statement.  Convolutions, BatchNorm statistics and sin/cos run through the HIP kernels of this package (and ATen for a little glue) on the GPU and
 through ATen-CPU in the reference: results agree to fp32 round-off (~1e-6 relative) *before* each neuron, and a neuron
 turns a round-off difference into a one-level (1/8) flip when its input sits within that distance of k + 0.5
 (SURVEY section 7 "hard parts").  So: pre-neuron quantities are compared with rtol 1e-4; spike maps are compared by the

@@ -1,3 +1,7 @@
+// NOTE (round 3): the -DGP_* / -DNO_* knock-out switches these probes were built with lived inside the product kernels in
+// round 2 (git revision cd1a9db); they were removed from spike2former_amd/csrc in round 3.  The measurements are kept in
+// profiles/r02_probe_*_knockouts.txt; to repeat them, check out that revision.  Without the switches this file times the
+// product kernel as it is.
 // Where does dw_wgrad_kernel<5> spend its 35 us on [8,512,32,32]?  Phases knocked out by -DNO_STAGE / -DNO_MAC / -DNO_REDUCE.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I spike2former_amd/csrc -I include tools/micro/dw_wgrad_probe.hip -o /tmp/dwp && /tmp/dwp
 #include "../../spike2former_amd/csrc/dwconv.hip"

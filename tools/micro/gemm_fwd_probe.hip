@@ -1,3 +1,7 @@
+// NOTE (round 3): the -DGP_* / -DNO_* knock-out switches these probes were built with lived inside the product kernels in
+// round 2 (git revision cd1a9db); they were removed from spike2former_amd/csrc in round 3.  The measurements are kept in
+// profiles/r02_probe_*_knockouts.txt; to repeat them, check out that revision.  Without the switches this file times the
+// product kernel as it is.
 // What bounds sgemm_bf16_kernel?  Phases knocked out by -DGP_NO_MFMA / -DGP_NO_LDSREAD / -DGP_NO_STORE / -DGP_NO_GLOBAL.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I spike2former_amd/csrc -I include tools/micro/gemm_fwd_probe.hip -o /tmp/gp && /tmp/gp
 #include "../../spike2former_amd/csrc/gemm_bf16.hip"
