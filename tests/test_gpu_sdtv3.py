@@ -83,3 +83,53 @@ def test_c5_tiny_step_with_the_panoptic_shaped_head():
     total.backward()
     g = model.backbone.downsample1_1.encode_conv.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_c5_size_attention_and_unaligned_batchnorm_at_their_own_size():
+    """BASELINE configs[4] at its own size (800x1344 -> 50x84 = 4 200 tokens at stride 16, D = 4 neurons, 256 channels):
+    (1) the attention core of MS_Attention_linear -- the reference's O(N^2) product order (q k^T) v with 4x wider value heads
+    (sdtv3.py:295-307) evaluated in fp64 per (tb, head) -- against the four d-wide q (k^T v) problems of ops.sdsa: spike operands
+    make every sum exact in fp32 (asserted: below 2^24 ulps), so the two orders give the SAME bits at N = 4 200;
+    (2) the row-walking BatchNorm + neuron kernels in their ALIGNED = false form (L = 4 200: a 256-element tile straddles two
+    channel rows) against ATen's batch_norm + the oracle's neuron: pre-activations to 1e-5, spikes equal except one-level flips in
+    <= 1e-4 of the elements, input / affine gradients to 1e-4 of their scale."""
+    from oracle import s2f_oracle as so
+    from spike2former_amd import ops
+    g = torch.Generator().manual_seed(2)
+    TB, h, d, r, N = 2, 8, 32, 4, 4200
+    C = h * d
+    q, k = (torch.randint(0, 5, (TB, C, N), generator=g).float() / 4 for _ in range(2))
+    v = torch.randint(0, 5, (TB, r * C, N), generator=g).float() / 4
+    scale = d ** -0.5 * 2
+    vj = v.cuda().view(TB, h, r, d, N).permute(2, 0, 1, 3, 4).contiguous()
+    got = torch.stack([ops.sdsa(q.cuda(), k.cuda(), vj[j].reshape(TB, C, N), h, scale) for j in range(r)], 0)
+    got = got.view(r, TB, h, d, N).permute(1, 2, 0, 3, 4).reshape(TB, r * C, N)
+    qh = q.cuda().double().view(TB, h, d, N).transpose(2, 3)
+    kh = k.cuda().double().view(TB, h, d, N).transpose(2, 3)
+    vh = v.cuda().double().view(TB, h, r * d, N).transpose(2, 3)
+    want = torch.empty(TB, h, r * d, N, dtype=torch.float64, device="cuda")
+    for tb in range(TB):
+        for hh in range(h):
+            want[tb, hh] = ((qh[tb, hh] @ kh[tb, hh].T) @ vh[tb, hh]).T          # the reference's order, exact in fp64
+    assert float(want.abs().max()) * 16 < 2 ** 24                                   # integer multiples of 1/16 below 2^24: exact in fp32
+    # the kernel multiplies the exact fp32 sum by the fp32 scale, rounding once
+    assert torch.equal(got, (want.float() * torch.tensor(scale, dtype=torch.float32, device="cuda")).reshape(TB, r * C, N))
+    # (2) unaligned row-walking BatchNorm + D = 4 neuron, forward and backward
+    Nn, Cc, L = 4, 64, 4200
+    z = (torch.randn(Nn, Cc, L, generator=g) * 1.5 + 0.7)
+    res = torch.randn(Nn, Cc, L, generator=g)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
+    gyo, guo = torch.randn(Nn, Cc, L, generator=g), torch.randn(Nn, Cc, L, generator=g)
+    zc, rc, gc, bc = (t.clone().requires_grad_(True) for t in (z, res, gamma, beta))
+    uo = torch.nn.functional.batch_norm(zc, None, None, gc, bc, True, 0.1, 1e-5) + rc
+    yo, _, _ = so.lif_step(uo, None, 4)
+    (yo * gyo).sum().backward(retain_graph=True); (uo * guo).sum().backward()
+    zg, rg, gg, bg = (t.clone().cuda().requires_grad_(True) for t in (z, res, gamma, beta))
+    u, y, _ = ops.bn_act(zg, None, gg, bg, None, None, None, True, 0.1, 1e-5, residual=rg, lif=True, want_pre=True, D=4)
+    ((y.float() * gyo.cuda()).sum() + (u * guo.cuda()).sum()).backward()
+    assert (u.detach().cpu() - uo.detach()).abs().max().item() <= 1e-5 * uo.detach().abs().max().item()
+    dlev = ((y.float().detach().cpu() - yo.detach()) * 4).round()
+    assert dlev.abs().max().item() <= 1 and (dlev != 0).float().mean().item() <= 1e-4
+    for mine, ref in ((zg.grad, zc.grad), (rg.grad, rc.grad), (gg.grad, gc.grad), (bg.grad, bc.grad)):
+        off = ((mine.cpu() - ref).abs() > 1e-4 * ref.abs().max()).float().mean().item()
+        assert off <= 1e-3, off          # a one-level / mask-bit difference moves single elements of gz, nothing systematic
