@@ -279,6 +279,17 @@ int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bi
                       int terms, int cfg, void* stream);
 int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
                      int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream);
+/* The gradient of a GEMM-produced pre-activation as THREE bf16 PLANES hi | mid | lo (gz = hi + mid + lo to 2^-24; plane p at
+ * gz_split + p * N C L): s2f_bn_act_bwd_split is s2f_bn_act_bwd writing that form instead of fp32 (6 instead of 4 bytes per
+ * element), s2f_pgemm_dx_split the input-gradient product reading it (plane p of batch b at G_split + p * plane_stride +
+ * b * Mo * N): both operands of its K loop arrive by LDS-DMA, nothing is converted or stored to LDS by the wavefronts.
+ * N % 8 == 0. */
+int s2f_bn_act_bwd_split(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
+                         const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, uint16_t* gz_split,
+                         float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
+                         float vth, int D, void* stream);
+int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_split, int64_t plane_stride, float* DX, int batch, int Mo,
+                       int Ki, int N, int cfg, void* stream);
 /* dW (+)= sum_b dY[b] (M x L) X[b]^T (L x K), both operands general fp32 (6 passes), batch strides in elements (0 = dense):
  * the weight gradient of the 1x1 convolutions whose input is not a spike map. */
 int s2f_gemm_dw_general(const float* dY, int64_t dy_batch_stride, const float* X, int64_t x_batch_stride, float* dW, int batch,

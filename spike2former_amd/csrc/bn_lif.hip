@@ -10,7 +10,7 @@
 // All kernels are HBM-bound streams over [N, C, L] (channel-major, L contiguous): lane l of a wave owns 4 consecutive
 // elements (one 16-byte access; L % 4 == 0 keeps them inside one channel row), the in-range bits are wave ballots as in
 // lif.hip.  Per-channel parameters are 2-3 floats per lane served from L1/L2.
-#include "s2f_common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -119,6 +119,23 @@ __device__ __forceinline__ Tile4 ld4(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, const Tile4& t) {
   *reinterpret_cast<float4*>(p) = make_float4(t.a[0], t.a[1], t.a[2], t.a[3]);
+}
+
+// The gradient gz of a GEMM-produced pre-activation, stored the way its consumers want it: fp32, or -- `gzs` != null -- as
+// three bf16 planes hi | mid | lo (gz = hi + mid + lo to 2^-24, plane p at gzs + p * total): the input-gradient and
+// weight-gradient GEMMs copy those straight into LDS (s2f_pgemm_dx_split / s2f_spike_gemm_dw_*_split), their K loops convert
+// nothing.  6 instead of 4 bytes per element written here, read back as bf16 instead of fp32 + a split per consuming tile.
+__device__ __forceinline__ void store_gz(float* gz, unsigned short* gzs, int64_t total, int64_t base, const Tile4& o) {
+  if (gzs != nullptr) {
+    unsigned int h0, m0, l0, h1, m1, l1;
+    s2f_split3x2(o.a[0], o.a[1], h0, m0, l0);
+    s2f_split3x2(o.a[2], o.a[3], h1, m1, l1);
+    *reinterpret_cast<uint2*>(gzs + base) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(gzs + total + base) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(gzs + 2 * total + base) = make_uint2(l0, l1);
+  } else {
+    *reinterpret_cast<float4*>(gz + base) = make_float4(o.a[0], o.a[1], o.a[2], o.a[3]);
+  }
 }
 
 // spikes as bf16 (exact: s2f_spikes_to_bf16x4); p addresses uint16 storage
@@ -339,7 +356,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
                                                               const double* __restrict__ sums, float* __restrict__ gz,
                                                               float* __restrict__ g_res, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int64_t total, int C, int L,
-                                                              double inv_count, int training, float vth, float Df) {
+                                                              double inv_count, int training, float vth, float Df,
+                                                              unsigned short* __restrict__ gzs) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
       o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
       r.a[j] = gu;
     }
-    st4(gz + base, o);
+    store_gz(gz, gzs, total, base, o);
     if (g_res) st4(g_res + base, r);
   }
 }
@@ -660,7 +678,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
     const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, const double* __restrict__ sums,
     float* __restrict__ gz, float* __restrict__ g_res, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk, double inv_count, int training, float vth, float Df) {
+    int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk, double inv_count, int training, float vth, float Df,
+    unsigned short* __restrict__ gzs) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
   uint32_t t = wave * chunk;
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
         o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
         r.a[j] = gu;
       }
-      st4(gz + base, o);
+      store_gz(gz, gzs, total, base, o);
       if (g_res) st4(g_res + base, r);
     }
     w.off += 256u;
@@ -884,7 +903,8 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
     const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df,
+    unsigned short* __restrict__ gzs) {
   __shared__ double red[2 * kFusedWaves];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = L >> 8, tiles = N * tpr;
@@ -943,7 +963,7 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     Tile4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o.a[j] = (g * rstd) * ((gu[i].a[j] - m1) - xh[i].a[j] * m2);
-    st4(gz + base, o);
+    store_gz(gz, gzs, (int64_t)N * C * L, base, o);
     if (g_res) st4(g_res + base, gu[i]);
   }
 }
@@ -1130,13 +1150,14 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   return s2f_check_launch("s2f_bn_act_fwd");
 }
 
-extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma,
-                              const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask,
-                              double* sums_zeroed, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
-                              int64_t C, int64_t L, int training, float vth, int D, void* stream) {
+static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
+                           const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
+                           float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
+                           float vth, int D, void* stream, unsigned short* gzs) {
   const bool single = training && single_pass_ok(N, C, L);
-  S2F_REQUIRE(z && stat && gamma && (single || sums_zeroed) && gz && dgamma && dbeta, S2F_EINVAL,
+  S2F_REQUIRE(z && stat && gamma && (single || sums_zeroed) && (gz || gzs) && dgamma && dbeta, S2F_EINVAL,
               "s2f_bn_act_bwd: null pointer");
+  S2F_REQUIRE(!gzs || (reinterpret_cast<uintptr_t>(gzs) & 7u) == 0, S2F_EALIGN, "s2f_bn_act_bwd_split: gz_split must be 8-byte aligned");
   S2F_REQUIRE(g_u || g_y || g_v, S2F_EINVAL, "s2f_bn_act_bwd: no incoming gradient");
   S2F_REQUIRE(!(g_y || g_v) || mask, S2F_EINVAL, "s2f_bn_act_bwd: spike gradients need the in-range mask");
   int rc = check_shape("s2f_bn_act_bwd", N, C, L);
@@ -1147,7 +1168,7 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
 #define S2F_BN_FB(A, B, Cc)                                                                                               \
   S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0, s, z,      \
              conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L,          \
-             1.0 / ((double)N * (double)L), vth, (float)D)
+             1.0 / ((double)N * (double)L), vth, (float)D, gzs)
     const int combo = (g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0);
     switch (combo) {
       case 1: S2F_BN_FB(false, false, true); break;
@@ -1173,7 +1194,7 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
     const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc, AL>>(ntiles, 0, chunk);                               \
     S2F_LAUNCH(false, true, (bn_bwd_apply_rows_kernel<A, B, Cc, AL>), dim3(rgrid), dim3(kBlock), 0, s, z, conv_bias, stat, \
                gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, ntiles, (int)C, (uint32_t)L, \
-               chunk, inv_count, training, vth, (float)D);                                                               \
+               chunk, inv_count, training, vth, (float)D, gzs);                                                          \
   } while (0)
 #define S2F_BN_ROWS_BWD(A, B, Cc)                                                                                        \
   do {                                                                                                                   \
@@ -1203,6 +1224,24 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
                      mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);
   S2F_LAUNCH(false, true, bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z, conv_bias, stat, gamma, g_u, g_y,
                      g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L,
-                     1.0 / ((double)N * (double)L), training, vth, (float)D);
+                     1.0 / ((double)N * (double)L), training, vth, (float)D, gzs);
   return s2f_check_launch("s2f_bn_act_bwd");
+}
+
+extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma,
+                              const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask,
+                              double* sums_zeroed, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
+                              int64_t C, int64_t L, int training, float vth, int D, void* stream) {
+  S2F_REQUIRE(gz, S2F_EINVAL, "s2f_bn_act_bwd: null gz");
+  return bn_act_bwd_impl(z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, N, C, L,
+                         training, vth, D, stream, nullptr);
+}
+
+extern "C" int s2f_bn_act_bwd_split(const float* z, const float* conv_bias, const float* stat, const float* gamma,
+                                    const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask,
+                                    double* sums_zeroed, uint16_t* gz_split, float* g_residual, float* dgamma, float* dbeta,
+                                    int64_t N, int64_t C, int64_t L, int training, float vth, int D, void* stream) {
+  S2F_REQUIRE(gz_split, S2F_EINVAL, "s2f_bn_act_bwd_split: null gz_split");
+  return bn_act_bwd_impl(z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, sums_zeroed, nullptr, g_residual, dgamma, dbeta, N, C,
+                         L, training, vth, D, stream, gz_split);
 }

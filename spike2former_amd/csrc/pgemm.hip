@@ -588,6 +588,166 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TN with a PRE-SPLIT right operand: the input gradient when the producer of dY (the BatchNorm backward kernels,
+// s2f_bn_act_bwd_split) has written it as three bf16 planes hi | mid | lo.
+//   DX[b] (Ki x N) = W^T (Ki x Mo) @ (G0 + G1 + G2)[b] (Mo x N),   plane p of batch b at Gs + p * plane_stride + b * Mo * N.
+// Both operands now arrive by LDS-DMA -- the weight panels verbatim from the forward pack, the G term tiles [16][BN] row-major
+// with the unit swizzle on the source address -- so the K loop is copies, transpose reads and MFMAs only: no loads into
+// registers, no split arithmetic, no ds_write (the three term stores of pg_tn_f32_kernel cost as many LDS cycles as the matrix
+// pipe needs for the step).  NST stages, one barrier per 16-row step, the structure of pg_nn_kernel.  6 passes.
+template <int MI, int NJ, int WMW, int WNW, int NST>
+__global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_split_kernel(const unsigned short* __restrict__ Wp,
+                                                                    const unsigned short* __restrict__ Gs, int64_t plane_stride,
+                                                                    float* __restrict__ DX, int Mo, int Ki, int N, int KbW,
+                                                                    int n_tiles, int m_tiles) {
+  constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW;
+  constexpr int KC = 16;
+  constexpr int A_BYTES = 3 * (BM / 32) * 1024, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = 3 * (BM / 32), NAW = (NA + NW - 1) / NW;       // 1 KiB weight copies per stage / per wavefront (padded)
+  constexpr int NBT = B_TERM / 1024, NB = 3 * NBT, NBW = NB / NW;   // 1 KiB copies of the G terms
+  static_assert(NB % NW == 0 && BN == 128, "tile shape");
+  constexpr int LPW = NAW + NBW;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const unsigned short* Gb = Gs + (int64_t)b * Mo * N;
+  float* Db = DX + (int64_t)b * Ki * N;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int nk = (Mo + KC - 1) / KC;
+
+  constexpr int CPRW = BN * 2 / 16;                               // 16-byte chunks per G row (16)
+  const int b_kl = lane / CPRW, b_pc = lane % CPRW;
+  auto issue = [&](int t, int st) __attribute__((always_inline)) {
+    unsigned char* sb = smem + st * STAGE;
+    const int c0 = t * KC;
+    const unsigned short* rows = Wp + (int64_t)(c0 / PR) * KbW * PBLOCK + (c0 % PR) * PK + lane * 8;
+#pragma unroll
+    for (int q = 0; q < NAW; ++q) {
+      int idx = wave + q * NW;
+      if (NA % NW != 0 && idx >= NA) idx -= NW;                   // pad with a repeat of an earlier copy: uniform counts
+      const int term = idx / (BM / 32), p = idx % (BM / 32);
+      const int kb = min(m0 / PK + p, KbW - 1);
+      dma16(rows + kb * PBLOCK + term * PTERM, sb + idx * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+      const int idx = wave + q * NW;
+      const int term = idx / NBT, r4 = idx % NBT;                 // a copy = 4 rows of one term
+      const int k = r4 * 4 + b_kl;
+      const int lc = (((b_pc >> 2) ^ (k & 3)) << 2) | (b_pc & 3);
+      const int kr = min(c0 + k, Mo - 1);                         // rows past Mo meet zero pack rows
+      const int col = min(n0 + lc * 8, N - 8);
+      dma16(Gb + term * plane_stride + (int64_t)kr * N + col, sb + A_BYTES + idx * 1024);
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kl = (lane & 15) >> 2, piece = lane & 3, hcol = (lane >> 4) & 1, kh = lane >> 5;
+  int boff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) boff[j] = (8 * kh + kl) * BN + (((wn * NJ + j) ^ kl) << 5) + 16 * hcol + 4 * piece;
+  int aoff[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = 8 * kh + kl + 4 * half;
+      const int c = (2 * hcol + (piece >> 1)) ^ ((2 * kh + half) & 3);
+      aoff[i][half] = (wm * MI + i) * 512 + row * 32 + c * 8 + 4 * (piece & 1);
+    }
+
+  const unsigned smem_a = lds_addr(smem);
+  auto compute = [&](int st) __attribute__((always_inline)) {
+    union BF {
+      bf16x8 v;
+      s16x4 h[2];
+    } bfrag[3][NJ], afrag[3][MI];
+    const unsigned sb = smem_a + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const unsigned a = sb + boff[j] * 2;
+      bfrag[0][j].h[0] = lds_tr16_asm<A_BYTES>(a);
+      bfrag[0][j].h[1] = lds_tr16_asm<A_BYTES + 4 * BN * 2>(a);
+      bfrag[1][j].h[0] = lds_tr16_asm<A_BYTES + B_TERM>(a);
+      bfrag[1][j].h[1] = lds_tr16_asm<A_BYTES + B_TERM + 4 * BN * 2>(a);
+      bfrag[2][j].h[0] = lds_tr16_asm<A_BYTES + 2 * B_TERM>(a);
+      bfrag[2][j].h[1] = lds_tr16_asm<A_BYTES + 2 * B_TERM + 4 * BN * 2>(a);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      afrag[0][i].h[0] = lds_tr16_asm<0>(sb + aoff[i][0] * 2);
+      afrag[0][i].h[1] = lds_tr16_asm<0>(sb + aoff[i][1] * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      afrag[1][i].h[0] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][0] * 2);
+      afrag[1][i].h[1] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][1] * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      afrag[2][i].h[0] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][0] * 2);
+      afrag[2][i].h[1] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][1] * 2);
+    }
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta) {
+      if (ta == 0) lds_wait<4 * MI>();
+      if (ta == 1) lds_wait<2 * MI>();
+      if (ta == 2) lds_wait<0>();
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+          if (ta + tb < 3)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              mfma_bf16(acc[i][j], afrag[ta][i].v, bfrag[tb][j].v);
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue(s, s);
+  int st = 0, st_next = NST - 1;
+  for (int t = 0; t < nk; ++t) {
+    if (t + NST - 2 < nk)
+      wait_vm_and_barrier<(NST - 2) * LPW>();
+    else
+      wait_vm_and_barrier<0>();
+    if (t + NST - 1 < nk) issue(t + NST - 1, st_next);
+    compute(st);
+    st = st + 1 == NST ? 0 : st + 1;
+    st_next = st_next + 1 == NST ? 0 : st_next + 1;
+  }
+
+  mfma_fence(acc);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + (wn * NJ + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < Ki && col < N) Db[(int64_t)row * N + col] = acc[i][j][r];
+      }
+    }
+}
+
 int pick_cfg_nn(int M, int N, int batch, int force) {
   if (force > 0) return force;
   // measured (tools/probe_pgemm.py): 64 x 128 tiles on four wavefronts of 32 x 64 with two LDS stages (three workgroups per
@@ -667,6 +827,36 @@ extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, co
   S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, (hipStream_t)stream,
              a_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep);
   return s2f_check_launch("s2f_gemm_bn_lif_fwd");
+}
+
+extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_split, int64_t plane_stride, float* DX, int batch,
+                                  int Mo, int Ki, int N, int cfg, void* stream) {
+  S2F_REQUIRE(w_pack && G_split && DX, S2F_EINVAL, "s2f_pgemm_dx_split: null pointer");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && Mo > 0 && Ki > 0 && N >= 8 && (N & 7) == 0, S2F_EINVAL,
+              "s2f_pgemm_dx_split: bad sizes (N=%d must be a positive multiple of 8)", N);
+  S2F_REQUIRE(s2f_aligned16(w_pack) && s2f_aligned16(G_split) && s2f_aligned16(DX) && (plane_stride & 7) == 0, S2F_EALIGN,
+              "s2f_pgemm_dx_split: pointers / plane stride must keep 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const int KbW = (Ki + PK - 1) / PK;
+  const int n_tiles = (N + 127) / 128;
+  static const char* force = getenv("S2F_PG_DXS_CFG");
+  int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
+  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
+#define S2F_PGS(MI, NJ, WMW, WNW, NSTV)                                                                                 \
+  do {                                                                                                                 \
+    const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
+    S2F_LAUNCH(true, true, (pg_tn_split_kernel<MI, NJ, WMW, WNW, NSTV>), dim3(n_tiles * m_tiles, batch),                \
+               dim3(64 * WMW * WNW), 0, s, w_pack, G_split, plane_stride, DX, Mo, Ki, N, KbW, n_tiles, m_tiles);        \
+  } while (0)
+  switch (c) {
+    case 1: S2F_PGS(2, 2, 2, 2, 3); break;          // 128 x 128, 3 stages (72 KiB)
+    case 2: S2F_PGS(1, 2, 2, 2, 3); break;          // 64 x 128, 3 stages (54 KiB)
+    case 3: S2F_PGS(2, 2, 2, 2, 2); break;          // 128 x 128, 2 stages
+    case 4: S2F_PGS(1, 2, 2, 2, 2); break;          // 64 x 128, 2 stages (36 KiB)
+    default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_split: unknown cfg %d", c);
+  }
+#undef S2F_PGS
+  return s2f_check_launch("s2f_pgemm_dx_split");
 }
 
 extern "C" int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream) {

@@ -883,6 +883,75 @@ def test_pgemm_input_gradient_matches_fp64(ops, B, Mo, Ki, N):
         assert (dx.double() - 2 * ref).abs().max().item() <= 2 * bound, cfg
 
 
+@pytest.mark.parametrize("B,Mo,Ki,N", [(2, 64, 32, 128), (3, 100, 72, 136), (2, 256, 256, 1024), (1, 360, 360, 1024),
+                                       (2, 1440, 360, 256), (8, 256, 1024, 1024), (1, 2048, 256, 104)])
+def test_pgemm_input_gradient_from_presplit_planes(ops, B, Mo, Ki, N):
+    """s2f_pgemm_dx_split: the same product from dY as three bf16 planes hi | mid | lo (what s2f_bn_act_bwd_split writes): the
+    terms are the ones the fp32 kernel forms in registers, so the two agree to the reordering of 6 x K products (fp32-GEMM
+    accuracy against fp64), every configuration."""
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 79 + Mo + Ki + N)
+    w = (torch.randn(Mo, Ki, generator=g) * Mo ** -0.5).cuda()
+    gy = torch.randn(B, Mo, N, generator=g).cuda()
+    hi = gy.bfloat16(); r1 = gy - hi.float(); mid = r1.bfloat16(); lo = (r1 - mid.float()).bfloat16()
+    planes = torch.stack([hi, mid, lo]).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.matmul(w.t().double(), gy.double())
+    bound = 2e-6 * torch.matmul(w.t().abs().double(), gy.abs().double()).max().item()
+    for cfg in (1, 2, 3, 4):
+        dx = torch.full((B, Ki, N), float("nan"), device="cuda")
+        check(lib.s2f_pgemm_dx_split(ops.pack_weight(w).data_ptr(), planes.data_ptr(), gy.numel(), dx.data_ptr(), B, Mo, Ki, N, cfg,
+                                     st), "dxs")
+        assert (dx.double() - ref).abs().max().item() <= bound, cfg
+    with pytest.raises(RuntimeError):
+        check(lib.s2f_pgemm_dx_split(ops.pack_weight(w).data_ptr(), planes.data_ptr(), gy.numel(), dx.data_ptr(), B, Mo, Ki, N + 4, 0,
+                                     st), "dxs")
+
+
+@pytest.mark.parametrize("N,C,L,training,res,lif", [(8, 16, 1024, True, True, True), (2, 7, 1052, True, False, True),
+                                                    (8, 3, 16800, True, False, True), (2, 6, 4200, False, True, True),
+                                                    (8, 8, 100, True, False, False), (2, 32, 65536, True, True, True)])
+def test_bn_backward_presplit_planes_are_the_fp32_gradient(ops, monkeypatch, N, C, L, training, res, lif):
+    """s2f_bn_act_bwd_split writes gz as hi | mid | lo bf16 planes: their sum IS the fp32 gz of s2f_bn_act_bwd (a 24-bit value
+    splits exactly into three 8-bit terms), bit for bit, in every form of the backward (single pass, row-walking, generic) --
+    and dgamma / dbeta / the residual gradient are untouched."""
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(N + C + L)
+    z = (torch.randn(N, C, L, generator=g) * 2 + 0.5).cuda().requires_grad_(True)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda().requires_grad_(True), torch.randn(C, generator=g).cuda().requires_grad_(True)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    r = torch.randn(N, C, L, generator=g).cuda().requires_grad_(True) if res else None
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    seen = {}
+    orig = lib.s2f_bn_act_bwd
+
+    def both(*a):
+        planes = torch.empty(3, N, C, L, dtype=torch.bfloat16, device="cuda")
+        a2 = list(a)
+        gz_ptr, dg_ptr, db_ptr = a2[9], a2[11], a2[12]
+        tmp = [torch.empty(C, device="cuda") for _ in range(2)]
+        gres2 = torch.empty(N, C, L, device="cuda") if a2[10] else None
+        ws = a2[8]
+        ws2 = torch.zeros(2 * C, dtype=torch.float64, device="cuda") if ws else None
+        a2[8], a2[9], a2[10], a2[11], a2[12] = (ws2.data_ptr() if ws else None, planes.data_ptr(),
+                                                gres2.data_ptr() if gres2 is not None else None, tmp[0].data_ptr(), tmp[1].data_ptr())
+        check(lib.s2f_bn_act_bwd_split(*a2), "split")
+        seen["planes"], seen["dg"], seen["db"], seen["gres"] = planes, tmp[0], tmp[1], gres2
+        return orig(*a)
+    monkeypatch.setattr(lib, "s2f_bn_act_bwd", both)
+    u, y, _ = ops.bn_act(z, None, gamma, beta, rm, rv, nbt if training else None, training, 0.1, 1e-5, residual=r, lif=lif,
+                         want_pre=True)
+    loss = (u * torch.randn(u.shape, generator=g).cuda()).sum()
+    if lif:
+        loss = loss + (y.float() * torch.randn(u.shape, generator=g).cuda()).sum()
+    loss.backward()
+    p = seen["planes"].float()
+    assert torch.equal((p[0] + p[1]) + p[2], z.grad)
+    assert torch.equal(seen["dg"], gamma.grad) and torch.equal(seen["db"], beta.grad)
+    if res:
+        assert torch.equal(seen["gres"], r.grad)
+
+
 def test_dense_gemm_groups_forward_backward(ops):
     """ops.dense_gemm (general fp32 input, G weights on consecutive channel groups -- the second 1x1 of the batched q / k / v
     chain): forward on the pack of W^T, input gradient on the pack of W, weight gradient on the 6-pass kernel; against fp64."""

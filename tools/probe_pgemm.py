@@ -117,4 +117,15 @@ if what in ("dx", "all"):
             bad = not torch.isfinite(dx).all().item()
             row += f" | c{cfg} {t1:7.1f} {err:.1e}{' NAN' if bad else ''}"
             best = min(best, t1)
+        if N % 8 == 0:
+            hi = g.bfloat16(); r1 = g - hi.float(); mid = r1.bfloat16(); lo = (r1 - mid.float()).bfloat16()
+            planes = torch.stack([hi, mid, lo]).contiguous()
+            for cfg in (1, 2, 3, 4):
+                dx = torch.full((B, Ki, N), float("nan"), device="cuda")
+                t1 = timed(lambda: check(lib.s2f_pgemm_dx_split(wp.data_ptr(), planes.data_ptr(), g.numel(), dx.data_ptr(), B, Mo, Ki, N,
+                                                                cfg, S), "dxs"))
+                err = (dx[:1].double() - ref).abs().max().item() / ref.abs().max().item()
+                bad = not torch.isfinite(dx).all().item()
+                row += f" | s{cfg} {t1:7.1f} {err:.1e}{' NAN' if bad else ''}"
+                best = min(best, t1)
         print(row + f"   best {fl / best / 1e6:6.0f} TF/s vs lib {fl / tl / 1e6:6.0f}", flush=True)
