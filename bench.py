@@ -31,6 +31,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (informational: the metric's config is B = 2)")
+    ap.add_argument("--gt", default="regions", choices=["regions", "noise"],
+                    help="--loss hungarian: synthetic semantic maps; regions = --gt-classes classes per image as rectangles "
+                         "(ADE20K averages 10.5 classes per image), noise = an independent class per pixel (all 150 present)")
+    ap.add_argument("--gt-classes", type=int, default=10)
+    ap.add_argument("--hungarian-graphs", default="tables", choices=["tables", "split"],
+                    help="tables: graph.GraphedHungarianStep (loss inside the second graph); split: graph.GraphedSplitStep (eager loss)")
     ap.add_argument("--loss", default="headline", choices=["headline", "hungarian"],
                     help="hungarian: the reference's real training loss (SURVEY 8 row f1) on a synthetic semantic map; the "
                          "matching runs on the host in the middle of the step, so the step is launched eagerly (secondary figure)")
@@ -178,13 +184,36 @@ def main():
     seg = None
     graphed_model = None
     want_split_graphs = False
+    hungarian = None
     if args.loss == "hungarian":
         args.no_cpu_baseline = args.no_kernel_events = True
-        seg = torch.randint(0, w["K"], (B, 1, w["H"], w["W"]), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+        gen = torch.Generator().manual_seed(1 + rank)
+        if args.gt == "noise":          # every pixel an independent class: all K classes present, every query matched (worst case)
+            seg = torch.randint(0, w["K"], (B, 1, w["H"], w["W"]), generator=gen)
+        else:                           # ADE20K-like: ~10.5 classes per image (Zhou et al. 2017) as axis-aligned regions
+            seg = torch.empty(B, 1, w["H"], w["W"], dtype=torch.int64)
+            for i in range(B):
+                classes = torch.randperm(w["K"], generator=gen)[:args.gt_classes]
+                ys = torch.sort(torch.randint(1, w["H"], (3,), generator=gen)).values.tolist()
+                plane = torch.empty(w["H"], w["W"], dtype=torch.int64)
+                k = 0
+                for y0, y1 in zip([0] + ys, ys + [w["H"]]):
+                    cuts = max(args.gt_classes // 4, 1)
+                    xs = torch.sort(torch.randint(1, w["W"], (cuts,), generator=gen)).values.tolist()
+                    for x0, x1 in zip([0] + xs, xs + [w["W"]]):
+                        plane[y0:y1, x0:x1] = classes[k % args.gt_classes]
+                        k += 1
+                seg[i, 0] = plane
+        seg = seg.to(dev)
         want_split_graphs = not args.no_graph
         args.no_graph = True
 
     def eager_step():
+        if hungarian is not None:
+            hungarian()                                  # graph A (forward + costs) | host assignment | graph B (loss + backward)
+            red.reduce()
+            red.wait()
+            return
         if seg is not None and graphed_model is not None:
             leaves = graphed_model.forward()            # graph A: reset + gradient clear + forward
             gts = [s2f.seg_to_instances(seg[i]) for i in range(B)]
@@ -207,9 +236,13 @@ def main():
 
     eager_step()                                    # discovers which gradients arrive through a sink ...
     red.compact()                                   # ... and moves them behind the others: packing stays one batched copy
-    if seg is not None and want_split_graphs:
-        # The assignment runs on the host between forward and backward, so the step cannot be ONE graph: forward and backward
-        # are captured as two graphs around the eager loss (graph.GraphedSplitStep).
+    if seg is not None and want_split_graphs and args.hungarian_graphs == "tables":
+        # The assignment runs on the host, so the step cannot be ONE graph: forward + matching costs are one graph, the losses (from
+        # the assignment's tables) + backward another (graph.GraphedHungarianStep).
+        from spike2former_amd.graph import GraphedHungarianStep
+        hungarian = GraphedHungarianStep(model, img, seg, red, warmup=max(args.warmup, 2))
+    elif seg is not None and want_split_graphs:
+        # forward and backward as two graphs around the EAGER loss (graph.GraphedSplitStep; generic instance masks)
         from spike2former_amd.graph import GraphedSplitStep
         graphed_model = GraphedSplitStep(model, img, red, warmup=max(args.warmup, 2))
     graphed = overlapped = None
@@ -284,12 +317,15 @@ def main():
         ms = dt / args.steps * 1e3
         out = {
             "metric": ("fwd+bwd images/sec, 512x512 T=4 ADE20K-150" if args.workload == "C2" else f"fwd+bwd images/sec ({args.workload})")
-                      + ((" [Hungarian-matched loss, " + ("forward / backward hipGraphs around the host-side matching]"
-                                                        if graphed_model is not None else "eager]")) if seg is not None else ""),
+                      + ((f" [Hungarian-matched loss, synthetic semantic maps: {'per-pixel noise, all classes present' if args.gt == 'noise' else str(args.gt_classes) + ' classes per image'}; "
+                         + ("forward+costs / losses+backward hipGraphs around the host-side assignment]" if hungarian is not None
+                            else "forward / backward hipGraphs around the eager loss]" if graphed_model is not None else "eager]"))
+                         if seg is not None else ""),
             "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "launch": ("forward / backward hipGraphs, all-reduce of step k under the forward of step k+1 (benchmark-only: no weight update fits in between)" if overlapped is not None
-                                             else "forward / backward hipGraphs around the host-side matching" if graphed_model is not None
+                                             else "forward+costs / losses+backward hipGraphs around the host-side assignment" if hungarian is not None
+                                             else "forward / backward hipGraphs around the eager loss" if graphed_model is not None
                                              else "eager" if graphed is None else "hipGraph replay"),
             "ranks_seen": (dist.get_world_size() if distributed else 1),
             "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']} "

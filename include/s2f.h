@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 15
+#define S2F_ABI_VERSION 16
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -316,6 +316,23 @@ int s2f_mask_loss_fwd(const float* pred, const uint8_t* tgt, const int64_t* gt_i
                       float alpha, float gamma, void* stream);
 int s2f_mask_loss_bwd(const float* pred, const uint8_t* tgt, const int64_t* gt_index, const float* g_sums, float* gup, int64_t P,
                       int h, int w, float alpha, float gamma, void* stream);
+
+/* ---- the same loss against SEMANTIC maps: disjoint targets "seg == class" (mmseg/models/decode_heads/maskformer_head.py:53-106) --
+ * Matching costs (mmdet task_modules/assigners/match_cost.py:289-297 FocalLossCost(binary_input), :361-371 DiceCost) as segmented
+ * sums by label instead of three [L*Q, hw] x [hw, n_gt] products: for image b, prediction row r, class id c < K
+ *   out[b][r][c] = sum_{pixels of c} (pos - neg),  out[b][r][K + c] = sum_{pixels of c} s,
+ *   out[b][r][2K] = sum_all neg,  out[b][r][2K + 1] = sum_all s        (s = sigmoid(pred), pos / neg the two focal terms)
+ * pred [B, R, hw] fp32, seg_small [B, hw] uint8 label map at the predictions' resolution (ids >= K, e.g. the ignore label 255,
+ * belong to no class), out [B, R, 2K + 2] fp32.  Sums are accumulated in 64-bit fixed point: run-to-run identical.  hw % 4 == 0.
+ * Mask losses: row = (b, r) has the target  seg[b] == row_class[row]  (seg [B, 2h, 2w] uint8; row_class int32, < 0: unmatched row,
+ * sums 0 / gradient 0): sums [B*R, 4] as s2f_mask_loss_fwd; the backward returns the gradient w.r.t. the LOW-resolution logits
+ * [B, R, h, w] directly (the adjoint of the up-sampling is applied to an LDS tile; no [rows, 2h, 2w] tensor exists). */
+int s2f_mask_cost_bins(const float* pred, const uint8_t* seg_small, float* out, int B, int R, int64_t hw, int K, float alpha,
+                       float gamma, float eps, void* stream);
+int s2f_mask_loss_seg_fwd(const float* pred, const uint8_t* seg, const int32_t* row_class, float* sums, int B, int R, int h, int w,
+                          float alpha, float gamma, void* stream);
+int s2f_mask_loss_seg_bwd(const float* pred, const uint8_t* seg, const int32_t* row_class, const float* g_sums, float* gpred, int B,
+                          int R, int h, int w, float alpha, float gamma, void* stream);
 
 /* ---- a5 / a10: spike-driven (softmax-free) attention core --------------------------------------------
  * Replaces  kv = k^T @ v ; o = (q @ kv) * scale ; o.transpose(3,4).reshape(T,B,C,N)

@@ -128,6 +128,111 @@ class GraphedSplitStep:
         self.graph_b.replay()
 
 
+class GraphedHungarianStep:
+    """The REAL training step (Hungarian-matched loss on semantic maps) as two hipGraphs around the one
+    thing that has to happen on the host, the assignment:
+        graph A : membrane reset + gradient-buffer clear + model forward + matching costs against every class id
+                  (loss.MaskFormerLoss.costs_all_classes) + their copy into pinned host memory
+        host    : scipy linear_sum_assignment per (layer, image) on the columns of the classes present -> three small tables
+                  (loss.MaskFormerLoss.match_tables), uploaded into static device buffers
+        graph B : the losses from the tables (loss_from_tables: every shape is independent of the matching) + backward of the
+                  whole model + packing of the gradients into the flat buffer
+    Between the graphs the GPU idles for the copy, the assignment and one upload -- not for ~450 eager launches of the loss and
+    its backward as with GraphedSplitStep.  `__call__` returns the loss dictionary (static tensors, valid until the next call)."""
+
+    def __init__(self, model, example_input, example_seg, grad_buffer, warmup=3, ignore_index=None):
+        head = model.decode_head
+        self.model, self.red, self.crit = model, grad_buffer, head.criterion
+        self.ignore_index = head.ignore_index if ignore_index is None else ignore_index
+        self.static_in = example_input.clone()
+        self.static_seg = self.crit.seg_as_u8(example_seg, self.ignore_index).clone()
+        params = [p for p in grad_buffer.params]
+        dev = example_input.device
+        with torch.no_grad():                                     # shapes of the outputs (and a first warm-up)
+            cls, masks = self._forward()
+        if not self.crit.semantic_ok(masks, self.static_seg):
+            raise RuntimeError("GraphedHungarianStep needs semantic maps at twice the mask predictions' resolution")
+        L, B, Q = cls.shape[:3]
+        self.tgt_labels = torch.full((L, B, Q), self.crit.num_classes, dtype=torch.int64, device=dev)
+        self.row_class = torch.full((B, L * Q), -1, dtype=torch.int32, device=dev)
+        self.num_masks = torch.ones(L, dtype=torch.float32, device=dev)
+        self.host_cost = torch.empty(L, B, Q, self.crit.num_classes, dtype=torch.float32).pin_memory()
+        self.host_count = torch.empty(B, 256, dtype=torch.float32).pin_memory()
+        self.host_tgt, self.host_rows, self.host_avg = (torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                                                        for t in (self.tgt_labels, self.row_class, self.num_masks))
+        del cls, masks
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                outs = self._forward()
+                self._costs(outs)
+                side.synchronize()
+                self._match()
+                total = sum(self._losses(outs).values())
+                torch.autograd.grad(total, params, allow_unused=True)
+                ops.wgrad_join()
+                del outs, total
+        torch.cuda.current_stream().wait_stream(side)
+        for v in ops._DW_PENDING.values():               # warm-up gradients are not packed: drop their deferred launches
+            v.clear()
+        ops.resplit_all(dev)
+        torch.cuda.synchronize()
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(self.graph_a, pool=pool, capture_error_mode=mode):
+            self.outs = self._forward()
+            self._costs(self.outs)
+        with torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode=mode):
+            losses = self._losses(self.outs)
+            grads = torch.autograd.grad(sum(losses.values()), params, allow_unused=True)
+            ops.wgrad_join()
+            self.red.pack(grads)
+            self.losses = {k: v.detach() for k, v in losses.items()}
+        torch.cuda.synchronize()
+        self._converted = ops.conversion_state()          # see GraphedStep
+
+    def _forward(self):
+        reset_net(self.model)
+        self.red.zero()
+        return tuple(self.model(self.static_in))
+
+    def _costs(self, outs):
+        with torch.no_grad():
+            cost, count = self.crit.costs_all_classes(outs[0], outs[1], self.static_seg)
+            self.host_cost.copy_(cost, non_blocking=True)
+            self.host_count.copy_(count, non_blocking=True)
+
+    def _match(self):
+        """host_cost / host_count (complete: the stream was synchronised) -> the three device tables."""
+        tgt, rows, avg = self.crit.match_tables(self.host_cost.numpy(), self.host_count.numpy())
+        self.host_tgt.copy_(torch.from_numpy(tgt))
+        self.host_rows.copy_(torch.from_numpy(rows))
+        self.host_avg.copy_(torch.from_numpy(avg))
+        self.tgt_labels.copy_(self.host_tgt, non_blocking=True)
+        self.row_class.copy_(self.host_rows, non_blocking=True)
+        self.num_masks.copy_(self.host_avg, non_blocking=True)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.num_masks.div_(dist.get_world_size()))          # reduce_mean (maskformer_head.py:459)
+
+    def _losses(self, outs):
+        return self.crit.loss_from_tables(outs[0], outs[1], self.static_seg, self.tgt_labels, self.row_class, self.num_masks)
+
+    def __call__(self, x=None, seg=None):
+        if x is not None:
+            self.static_in.copy_(x, non_blocking=True)
+        if seg is not None:
+            self.static_seg.copy_(self.crit.seg_as_u8(seg, self.ignore_index), non_blocking=True)
+        self.graph_a.replay()
+        torch.cuda.current_stream().synchronize()
+        self._match()
+        self.graph_b.replay()
+        return self.losses
+
+
 class GraphedOverlapStep:
     """BENCHMARK-ONLY (no weight update between steps): forward(k+1) replays before all-reduce(k) has finished, so an optimiser
     could not apply the averaged gradients of step k before step k+1 reads (and re-splits) the weights -- with an optimiser in the

@@ -5,7 +5,8 @@
 DiceLoss (losses/{cross_entropy_loss,focal_loss,dice_loss}.py) and mmseg's `_seg_data_to_instance_data`
 (mmseg/models/decode_heads/maskformer_head.py:53-106).
 
-Same values as the reference, organised for the GPU:
+Same values as the reference, organised for the GPU (generic instance masks: `loss_by_feat`; semantic maps, the only input
+mmseg's head ever produces: `loss_semantic`, whose device side has static shapes and no gather -- see below):
   * the reference computes a cost matrix and copies it to the host once per (decoder layer, image): 7 * B device -> host
     synchronisations per step.  Here the costs of ALL layers of an image come from three GEMMs ([L*Q, h*w] x [h*w, n_gt]) and
     every matrix of the step crosses to the host in ONE copy; scipy's linear_sum_assignment (the same solver) runs on it.
@@ -123,6 +124,120 @@ class MaskFormerLoss:
                 pq.append(r[order].astype(np.int64)); pg.append(col[order].astype(np.int64))
             out.append((pq, pg))
         return out
+
+    # ------------------------------------------------------------------------------------------------ semantic maps
+    # The targets mmseg builds from a semantic map are disjoint ("seg == class", maskformer_head.py:83-104), so
+    #   * the cost products against 0/1 columns are segmented sums by label (ops.mask_cost_bins): one pass over the logits gives the
+    #     costs against EVERY class id, the host keeps the columns of the classes present;
+    #   * a matched row's target is a class id: ops.mask_loss_seg compares the label map on the fly.
+    # Every device tensor has a shape that does not depend on the data or on the matching: the device side (costs; losses from
+    # three small tables) can be captured in hipGraphs around the host's assignment (graph.GraphedHungarianStep).
+    IGNORE_U8 = 255
+
+    def seg_as_u8(self, segs, ignore_index=255):
+        """[B, H, W] / [B, 1, H, W] integer label maps -> contiguous uint8 [B, H, W], the ignored label as 255."""
+        seg = segs.reshape(segs.shape[0], *segs.shape[-2:])
+        if seg.dtype != torch.uint8:
+            seg = torch.where(seg == ignore_index, self.IGNORE_U8, seg).to(torch.uint8) if ignore_index != self.IGNORE_U8 \
+                else seg.to(torch.uint8)
+        return seg.contiguous()
+
+    def semantic_ok(self, all_mask_preds, segs):
+        h, w = all_mask_preds.shape[-2:]
+        return (all_mask_preds.is_cuda and self.num_classes < self.IGNORE_U8 and tuple(segs.shape[-2:]) == (2 * h, 2 * w)
+                and w % 2 == 0 and (h * w) % 4 == 0 and all_mask_preds.shape[1] * all_mask_preds.shape[0] * self.num_queries < 65536)
+
+    def costs_all_classes(self, all_cls_scores, all_mask_preds, seg_u8):
+        """-> cost [L, B, Q, K] against every class id (hungarian_assigner.py:118-126 for the columns that exist) and the pixel
+        count [B, 256] of every label value in the full-resolution maps (which classes exist)."""
+        from . import ops
+        L, B, Q = all_cls_scores.shape[:3]
+        K = self.num_classes
+        h, w = all_mask_preds.shape[-2:]
+        pred = all_mask_preds.permute(1, 0, 2, 3, 4).reshape(B, L * Q, h * w).float()        # a view of the head's [B, L*Q, hw] buffer
+        small = seg_u8[:, ::2, ::2].reshape(B, h * w).contiguous()                            # nearest, maskformer_head.py:340-345
+        ones = torch.ones(1, dtype=torch.float32, device=pred.device)
+        count_small = torch.zeros(B, 256, dtype=torch.float32, device=pred.device).scatter_add_(1, small.long(), ones.expand(B, h * w))
+        count_full = torch.zeros(B, 256, dtype=torch.float32, device=pred.device).scatter_add_(
+            1, seg_u8.reshape(B, -1).long(), ones.expand(B, seg_u8[0].numel()))
+        a, gamma, eps = self.cost_focal_cfg["alpha"], self.cost_focal_cfg["gamma"], self.cost_focal_cfg["eps"]
+        bins = ops.mask_cost_bins(pred, small, K, a, gamma, eps)                              # [B, L*Q, 2K+2]
+        D, S, neg, stot = bins[..., :K], bins[..., K:2 * K], bins[..., 2 * K:2 * K + 1], bins[..., 2 * K + 1:]
+        focal = (D + neg) / (h * w)                                                           # match_cost.py:289-297
+        dice = 1 - (2 * S + self.cost_dice_eps) / (stot + count_small[:, None, :K] + self.cost_dice_eps)   # :361-371
+        mask_cost = (focal * self.cost_focal + dice * self.cost_dice).view(B, L, Q, K).permute(1, 0, 2, 3)
+        cls_cost = -all_cls_scores.float().softmax(-1)[..., :K]                               # match_cost.py:221-224
+        return cls_cost * self.cost_cls + mask_cost, count_full
+
+    def match_tables(self, cost, count_full):
+        """Host: cost [L, B, Q, K], count_full [B, 256] (numpy) -> tgt_labels [L, B, Q] int64 (K = no object), row_class [B, L*Q]
+        int32 (-1 = unmatched), avg [L] float32 (sum over images of max(#matched, 1): mask_sampling_result.py:25-28)."""
+        L, B, Q, K = cost.shape
+        if count_full[:, K:self.IGNORE_U8].any():
+            raise ValueError("semantic map holds labels >= num_classes other than the ignored one")
+        tgt = np.full((L, B, Q), K, np.int64)
+        row_class = np.full((B, L, Q), -1, np.int32)
+        avg = np.zeros(L, np.float32)
+        for b in range(B):
+            present = np.nonzero(count_full[b, :K])[0]
+            for l in range(L):
+                if present.size:
+                    r, col = linear_sum_assignment(cost[l, b][:, present])
+                    tgt[l, b, r] = present[col]
+                    row_class[b, l, r] = present[col]
+                    avg[l] += max(len(r), 1)
+                else:
+                    avg[l] += 1
+        return tgt, row_class.reshape(B, L * Q), avg
+
+    def loss_from_tables(self, all_cls_scores, all_mask_preds, seg_u8, tgt_labels, row_class, num_masks):
+        """Device: the loss dictionary from the three tables of `match_tables` (num_masks [L]: already averaged over the ranks).
+        Same formulas as `loss_by_feat`, all layers at once."""
+        from . import ops
+        L, B, Q = all_cls_scores.shape[:3]
+        h, w = all_mask_preds.shape[-2:]
+        H, W = seg_u8.shape[-2:]
+        dev = all_cls_scores.device
+        class_weight = self._class_weight(dev)
+        num_masks = num_masks.clamp(min=1.0)                                                 # maskformer_head.py:459-460
+        lab = tgt_labels.reshape(-1)
+        ce = F.cross_entropy(all_cls_scores.flatten(0, 2).float(), lab, weight=class_weight, reduction="none")   # cross_entropy_loss.py:45-50
+        loss_cls = self.cls.loss_weight * ce.view(L, -1).sum(1) / (class_weight[lab].view(L, -1).sum(1) + _EPS32)
+        pred = all_mask_preds.permute(1, 0, 2, 3, 4).reshape(B, L * Q, h, w).float()
+        sums = ops.mask_loss_seg(pred, seg_u8, row_class.reshape(-1), self.mask.alpha, self.mask.gamma).view(B, L, Q, 4)
+        a, bsum, csum, fsum = sums.unbind(-1)
+        valid = (row_class.view(B, L, Q) >= 0)
+        d = (2 * a + self.dice.eps) / (bsum + csum + self.dice.eps)                          # dice_loss.py:45-55, naive form
+        dice_terms = torch.where(valid, 1 - d, torch.zeros((), device=dev))
+        loss_dice = self.dice.loss_weight * dice_terms.sum((0, 2)) / (num_masks + _EPS32)
+        loss_mask = self.mask.loss_weight * fsum.sum((0, 2)) / (num_masks * (H * W) + _EPS32)
+        cl, ml, dl = loss_cls.unbind(0), loss_mask.unbind(0), loss_dice.unbind(0)
+        ordered = {"loss_cls": cl[L - 1], "loss_mask": ml[L - 1], "loss_dice": dl[L - 1]}    # last layer first (:396-413)
+        for l in range(L - 1):
+            ordered[f"d{l}.loss_cls"], ordered[f"d{l}.loss_mask"], ordered[f"d{l}.loss_dice"] = cl[l], ml[l], dl[l]
+        return ordered
+
+    def _class_weight(self, dev):
+        """The class weights on `dev`, uploaded once (an upload is not capturable into a hipGraph)."""
+        cache = self.__dict__.setdefault("_cw_cache", {})
+        if dev not in cache:
+            cache[dev] = torch.tensor(self.cls.class_weight, dtype=torch.float32, device=dev)
+        return cache[dev]
+
+    def loss_semantic(self, all_cls_scores, all_mask_preds, segs, ignore_index=255, reduce_fn=None):
+        """`loss_by_feat` for targets given as semantic maps [B, H, W] (what mmseg's head builds its instances from): same
+        dictionary, one device -> host copy (the costs), the assignment, one upload of the tables."""
+        seg_u8 = self.seg_as_u8(segs, ignore_index)
+        with torch.no_grad():
+            cost, count = self.costs_all_classes(all_cls_scores, all_mask_preds, seg_u8)
+            cost, count = cost.cpu().numpy(), count.cpu().numpy()
+        tgt, row_class, avg = self.match_tables(cost, count)
+        dev = all_cls_scores.device
+        num_masks = torch.from_numpy(avg).to(dev)
+        if reduce_fn is not None:
+            num_masks = reduce_fn(num_masks)
+        return self.loss_from_tables(all_cls_scores, all_mask_preds, seg_u8, torch.from_numpy(tgt).to(dev),
+                                     torch.from_numpy(row_class).to(dev), num_masks)
 
     # ------------------------------------------------------------------------------------------------ loss
     def loss_by_feat(self, all_cls_scores, all_mask_preds, batch_gt, world_size=1, reduce_fn=None):

@@ -198,21 +198,29 @@ class MaskFormerHead(nn.Module):
         """mmdet MaskFormerHead.loss_by_feat (dense_heads/maskformer_head.py:376-414); `batch_gt_instances`: per image an
         object with `.labels` / `.masks` or a (labels, masks) pair."""
         gts = [g if isinstance(g, (tuple, list)) else (g.labels, g.masks) for g in batch_gt_instances]
-        reduce_fn = None
+        return self.criterion.loss_by_feat(all_cls_scores, all_mask_preds, gts, reduce_fn=self._reduce_fn())
+
+    @staticmethod
+    def _reduce_fn():
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             def reduce_fn(t):                                  # reduce_mean of num_total_masks (:459), all layers at once
                 t = t.clone()
                 torch.distributed.all_reduce(t.div_(torch.distributed.get_world_size()))
                 return t
-        return self.criterion.loss_by_feat(all_cls_scores, all_mask_preds, gts, reduce_fn=reduce_fn)
+            return reduce_fn
+        return None
 
     def loss(self, x, batch_data_samples, train_cfg=None):
         """mmseg MaskFormerHead.loss (decode_heads/maskformer_head.py:108-136): semantic maps -> per-class binary masks ->
         forward -> Hungarian-matched loss dictionary.  `batch_data_samples`: SegDataSample-like objects
         (`.gt_sem_seg.data` [1,H,W]) or the semantic maps themselves."""
-        gts = []
-        for d in batch_data_samples:
-            seg = d if torch.is_tensor(d) else d.gt_sem_seg.data
-            gts.append(seg_to_instances(seg, self.ignore_index))
+        segs = [d if torch.is_tensor(d) else d.gt_sem_seg.data for d in batch_data_samples]
         all_cls_scores, all_mask_preds = self(x, batch_data_samples)
+        if len({tuple(s.shape[-2:]) for s in segs}) == 1:
+            seg_all = torch.stack([s.reshape(s.shape[-2:]) for s in segs])
+            if self.criterion.semantic_ok(all_mask_preds, seg_all):
+                # semantic maps at twice the predictions' resolution on the GPU (every Spike2Former config): static-shape device
+                # side, no gathers (loss.MaskFormerLoss.loss_semantic) -- same dictionary as the generic path below
+                return self.criterion.loss_semantic(all_cls_scores, all_mask_preds, seg_all, self.ignore_index, self._reduce_fn())
+        gts = [seg_to_instances(seg, self.ignore_index) for seg in segs]
         return self.loss_by_feat(all_cls_scores, all_mask_preds, gts)

@@ -1724,6 +1724,52 @@ def mask_loss_sums(pred, tgt_u8, gt_index, alpha, gamma):
     return _MaskLossSums.apply(pred, tgt_u8, gt_index, float(alpha), float(gamma))
 
 
+def mask_cost_bins(pred, seg_small, K, alpha, gamma, eps):
+    """pred [B, R, hw] fp32 logits, seg_small [B, hw] uint8 label map -> [B, R, 2K + 2]: per class id the segmented sums of
+    (pos - neg) and of s, then sum neg and sum s over all pixels (s2f.h s2f_mask_cost_bins; match_cost.py:289-297, :361-371)."""
+    _need_cuda(pred)
+    pred, seg_small = pred.contiguous(), seg_small.contiguous()
+    B, R, hw = pred.shape
+    assert seg_small.dtype == torch.uint8 and seg_small.shape == (B, hw) and pred.dtype == torch.float32
+    out = torch.empty(B, R, 2 * K + 2, dtype=torch.float32, device=pred.device)
+    check(lib.s2f_mask_cost_bins(_ptr(pred), _ptr(seg_small), _ptr(out), B, R, hw, K, alpha, gamma, eps, _stream()),
+          "s2f_mask_cost_bins")
+    return out
+
+
+class _MaskLossSeg(torch.autograd.Function):
+    """sums[(b, r)] = {sum s t, sum s, sum t, sum focal} of the 2x up-sampled logits pred[b, r] against  seg[b] == row_class[b, r]
+    (rows with row_class < 0: zeros, zero gradient); s2f.h s2f_mask_loss_seg_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, pred, seg, row_class, alpha, gamma):
+        _need_cuda(pred)
+        pred = pred.contiguous()
+        B, R, h, w = pred.shape
+        assert seg.dtype == torch.uint8 and seg.shape == (B, 2 * h, 2 * w) and seg.is_contiguous()
+        assert row_class.dtype == torch.int32 and row_class.numel() == B * R and row_class.is_contiguous()
+        sums = torch.empty(B * R, 4, dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_seg_fwd(_ptr(pred), _ptr(seg), _ptr(row_class), _ptr(sums), B, R, h, w, alpha, gamma, _stream()),
+              "s2f_mask_loss_seg_fwd")
+        ctx.save_for_backward(pred, seg, row_class)
+        ctx.cfg = (alpha, gamma)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, seg, row_class = ctx.saved_tensors
+        B, R, h, w = pred.shape
+        gp = torch.empty_like(pred)
+        check(lib.s2f_mask_loss_seg_bwd(_ptr(pred), _ptr(seg), _ptr(row_class), _ptr(g.contiguous()), _ptr(gp), B, R, h, w, *ctx.cfg,
+                                        _stream()), "s2f_mask_loss_seg_bwd")
+        return gp, None, None, None, None
+
+
+def mask_loss_seg(pred, seg_u8, row_class, alpha, gamma):
+    """pred [B, R, h, w] fp32 logits, seg_u8 [B, 2h, 2w] uint8 label map, row_class [B * R] int32 -> sums [B * R, 4]"""
+    return _MaskLossSeg.apply(pred, seg_u8, row_class, float(alpha), float(gamma))
+
+
 # ------------------------------------------------------------------------------------------------ dense k x k convolution
 class _ConvDense(torch.autograd.Function):
     """Dense k x k Conv2d lowered to GEMMs (MIOpen is not usable on this image, see conv.py).
