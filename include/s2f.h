@@ -294,6 +294,10 @@ int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_split, int64_t 
  * the weight gradient of the 1x1 convolutions whose input is not a spike map. */
 int s2f_gemm_dw_general(const float* dY, int64_t dy_batch_stride, const float* X, int64_t x_batch_stride, float* dW, int batch,
                         int M, int K, int L, int accumulate, void* stream);
+/* Many of them in ONE launch (the counterpart of s2f_spike_gemm_dw_grouped for two general operands): jobs = HOST array of
+ * njobs x {dY, dy_batch_stride, X, x_batch_stride, dW, batch, M, K, L} (int64 each; strides in elements, 0 = dense); every dW
+ * is ACCUMULATED into.  1 <= njobs <= 56; the table travels in the kernel arguments (capturable). */
+int s2f_gemm_dw_general_grouped(const int64_t* jobs, int njobs, void* stream);
 
 /* ---- exact-2x bilinear up-sampling (align_corners = False) of [planes, h, w] -> [planes, 2h, 2w] and its adjoint ------
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path

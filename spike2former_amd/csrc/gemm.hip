@@ -533,10 +533,9 @@ __global__ __launch_bounds__(128 * WM) void split_gemm_kernel(const unsigned sho
 // large maps (MS_ConvBlock1_x.conv2, the stage-1 pointwise convs: with a 128-row tile 1/2 or 3/4 of the MFMAs and of the dY
 // split work would process zero rows).  Wave layout 2 x 2 (64 x 64 each) for TM = 128, 1 x 4 (TM x 32 each) otherwise.
 template <int BKV, int XT, bool CONV, int TM>
-__global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
-                                                            float* __restrict__ dW, int B, int M, int K, int L,
-                                                            int steps_per_split, int k_tiles, Conv3 geo, int log_w,
-                                                            int64_t dy_bs, int64_t x_bs) {
+__device__ __forceinline__ void general_dw_body(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dW,
+                                                int B, int M, int K, int L, int steps_per_split, int k_tiles, Conv3 geo, int log_w,
+                                                int64_t dy_bs, int64_t x_bs, int tile, int split) {
   constexpr int LD = BKV + 8;
   constexpr int QPR = BKV / 4;                 // float4 chunks per row
   constexpr int NH = 128 * QPR / 256;          // X chunks per thread
@@ -546,11 +545,10 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
   static_assert(NHA >= 1 && MI >= 1 && NJ >= 1, "tile too small for 256 threads");
   __shared__ __attribute__((aligned(16))) unsigned short As[3][TM][LD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[XT][128][LD];      // XT = 1: X exact in bf16 (spikes); 3: general
-  const int tile = blockIdx.x;
   const int m0 = (tile / k_tiles) * TM, k0 = (tile % k_tiles) * 128;
   const int lsteps = (L + BKV - 1) / BKV;
   const int total_steps = B * lsteps;
-  const int s_begin = blockIdx.y * steps_per_split;
+  const int s_begin = split * steps_per_split;
   const int s_end = min(total_steps, s_begin + steps_per_split);
   if (s_begin >= s_end) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -660,6 +658,44 @@ __global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restr
         if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
       }
     }
+}
+
+template <int BKV, int XT, bool CONV, int TM>
+__global__ __launch_bounds__(256) void spike_gemm_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                            float* __restrict__ dW, int B, int M, int K, int L,
+                                                            int steps_per_split, int k_tiles, Conv3 geo, int log_w,
+                                                            int64_t dy_bs, int64_t x_bs) {
+  general_dw_body<BKV, XT, CONV, TM>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, dy_bs, x_bs, blockIdx.x,
+                                     blockIdx.y);
+}
+
+// MANY general weight gradients in ONE launch (the grouped form of gemm_bf16.hip's sgemm_dw_grouped_kernel for two general fp32
+// operands): the second 1x1 of every RepConv q / k / v projection and SepConv.pwconv2 owe  dW[256x256] over B*L = 8 192 -- launched
+// one by one (37 per C2 step, 24.7 us each, 44 TF/s) each splits its contraction 64 ways in front of a 256 KiB atomic tile.
+constexpr int kMaxGJobs = 56;
+struct GDwJob {
+  const float* dY;
+  const float* X;
+  float* dW;
+  int dy_bs, x_bs, B, M, K, L;
+  int first_block, steps_per_split, k_tiles, tiles;
+};
+struct GDwJobTable {
+  int njobs;
+  GDwJob job[kMaxGJobs];
+};
+
+__global__ __launch_bounds__(256) void gemm_dw_general_grouped_kernel(const GDwJobTable tab) {
+  const int id = blockIdx.x;
+  int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= id (wave-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab.job[mid].first_block <= id) lo = mid; else hi = mid - 1;
+  }
+  const GDwJob& j = tab.job[lo];
+  const int local = id - j.first_block;
+  general_dw_body<32, 3, false, 128>(j.dY, j.X, j.dW, j.B, j.M, j.K, j.L, j.steps_per_split, j.k_tiles, Conv3{0, 0, 0}, 0, j.dy_bs,
+                                     j.x_bs, local % j.tiles, local / j.tiles);
 }
 
 }  // namespace
@@ -909,6 +945,48 @@ extern "C" int s2f_gemm_dw_general(const float* dY, int64_t dy_batch_stride, con
               "s2f_gemm_dw_general: batch strides must keep 16-byte alignment");
   return spike_dw_launch(dY, X, dW, batch, M, K, L, accumulate, 3, false, Conv3{0, 0, 0}, 0, stream, dy_batch_stride,
                          x_batch_stride);
+}
+
+extern "C" int s2f_gemm_dw_general_grouped(const int64_t* jobs, int njobs, void* stream) {
+  // jobs (HOST array): njobs x {dY, dy_batch_stride, X, x_batch_stride, dW, batch, M, K, L}; every dW is accumulated into
+  S2F_REQUIRE(jobs && njobs > 0 && njobs <= kMaxGJobs, S2F_EINVAL, "s2f_gemm_dw_general_grouped: 1 .. %d jobs", kMaxGJobs);
+  GDwJobTable tab;
+  tab.njobs = njobs;
+  int64_t work = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const int64_t* r = jobs + 9 * i;
+    GDwJob& j = tab.job[i];
+    j.dY = reinterpret_cast<const float*>(r[0]);
+    j.X = reinterpret_cast<const float*>(r[2]);
+    j.dW = reinterpret_cast<float*>(r[4]);
+    S2F_REQUIRE(r[1] >= 0 && r[1] < (1ll << 31) && r[3] >= 0 && r[3] < (1ll << 31), S2F_EINVAL,
+                "s2f_gemm_dw_general_grouped: job %d: batch strides must fit 31 bits", i);
+    j.dy_bs = (int)r[1], j.x_bs = (int)r[3];
+    j.B = (int)r[5], j.M = (int)r[6], j.K = (int)r[7], j.L = (int)r[8];
+    S2F_REQUIRE(j.dY && j.X && j.dW && j.B > 0 && j.M > 0 && j.K > 0 && j.L > 0 && (j.L & 3) == 0, S2F_EINVAL,
+                "s2f_gemm_dw_general_grouped: bad job %d", i);
+    S2F_REQUIRE(s2f_aligned16(j.dY) && s2f_aligned16(j.X) && (j.dy_bs & 3) == 0 && (j.x_bs & 3) == 0, S2F_EALIGN,
+                "s2f_gemm_dw_general_grouped: job %d misaligned", i);
+    if (j.dy_bs == 0) j.dy_bs = j.M * j.L;
+    if (j.x_bs == 0) j.x_bs = j.K * j.L;
+    j.k_tiles = (j.K + 127) / 128;
+    j.tiles = ((j.M + 127) / 128) * j.k_tiles;
+    work += (int64_t)j.tiles * j.B * ((j.L + 31) / 32);
+  }
+  int sps = (int)((work + 1023) / 1024);                  // ~1024 workgroups, at least 8 steps each
+  if (sps < 8) sps = 8;
+  int64_t first = 0;
+  for (int i = 0; i < njobs; ++i) {
+    GDwJob& j = tab.job[i];
+    const int steps = j.B * ((j.L + 31) / 32);
+    j.steps_per_split = sps < steps ? sps : steps;
+    const int splits = (steps + j.steps_per_split - 1) / j.steps_per_split;
+    j.first_block = (int)first;
+    first += (int64_t)j.tiles * splits;
+  }
+  S2F_REQUIRE(first < (1ll << 31), S2F_EINVAL, "s2f_gemm_dw_general_grouped: grid too large");
+  S2F_LAUNCH(true, true, gemm_dw_general_grouped_kernel, dim3((unsigned)first), dim3(256), 0, (hipStream_t)stream, tab);
+  return s2f_check_launch("s2f_gemm_dw_general_grouped");
 }
 
 extern "C" int s2f_spike_conv3x3_dw(const float* dY, const float* X, float* dW, int batch, int M, int C, int H, int W,

@@ -149,6 +149,17 @@ def _defer_dw(gy, x, sink, B, M, K, L):
     _DW_PENDING[64 if (L % 64 == 0 or L >= 512) else 32].append((gy, x, sink, B, M, K, L))
 
 
+_DWG_PENDING = []          # general (fp32 x fp32) weight gradients: (dY ptr, dy batch stride, X ptr, x batch stride, sink, B, M, K, L, keep)
+
+
+def _defer_dw_general(gy, gy_off, dy_bs, x, x_off, x_bs, sink, B, M, K, L):
+    """-> True if the weight gradient  sink += sum_b dY[b] X[b]^T  was queued for the grouped launch of wgrad_flush()."""
+    if not (DEFER_DW and sink is not None and B * L <= DEFER_DW_MAX_CONTRACTION and WGRAD_STREAM is None and L % 4 == 0):
+        return False
+    _DWG_PENDING.append((gy.data_ptr() + 4 * gy_off, dy_bs, x.data_ptr() + 4 * x_off, x_bs, sink, B, M, K, L, (gy, x)))
+    return True
+
+
 def wgrad_drop():
     """Forget the deferred weight gradients that were never flushed (a backward that raised, an abandoned step): their sink
     views and activations must not be added into the NEXT step's freshly zeroed buffer."""
@@ -156,10 +167,21 @@ def wgrad_drop():
         return                                 # inside a capture the step's own flush follows; nothing stale can be pending
     for jobs in _DW_PENDING.values():
         jobs.clear()
+    _DWG_PENDING.clear()
 
 
 def wgrad_flush():
     import ctypes
+    while _DWG_PENDING:
+        chunk = _DWG_PENDING[:56]
+        flat = []
+        for dy, dy_bs, x, x_bs, sink, B, M, K, L, _keep in chunk:
+            flat += [dy, dy_bs, x, x_bs, sink.data_ptr(), B, M, K, L]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        _time_next("spike_gemm_dw", sum(4 * j[5] * j[8] * (j[6] + j[7]) for j in chunk),
+                   sum(2 * j[5] * j[6] * j[7] * j[8] for j in chunk))
+        check(lib.s2f_gemm_dw_general_grouped(arr, len(chunk), _stream()), "s2f_gemm_dw_general_grouped")
+        del _DWG_PENDING[:56]
     for bkv, jobs in _DW_PENDING.items():
         while jobs:
             chunk, rest = jobs[:56], jobs[56:]
@@ -501,6 +523,8 @@ class _DenseGemm(torch.autograd.Function):
                 if not ctx.needs_input_grad[1 + g]:
                     continue
                 sink = _sink_for(w)
+                if _defer_dw_general(gy, g * M * L, G * M * L, x, g * K * L, G * K * L, sink, B, M, K, L):
+                    continue
                 if sink is None:
                     gws[g] = torch.empty(M, K, dtype=torch.float32, device=gy.device)
                 check(lib.s2f_gemm_dw_general(gy.data_ptr() + 4 * g * M * L, G * M * L, x.data_ptr() + 4 * g * K * L, G * K * L,

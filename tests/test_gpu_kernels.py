@@ -772,6 +772,34 @@ def test_grouped_weight_gradients_are_the_single_launches(ops):
 
 
 @pytest.mark.gpu
+def test_grouped_general_weight_gradients_are_the_single_launches(ops):
+    """s2f_gemm_dw_general_grouped: several dW += sum_b dY[b] X[b]^T (both operands general fp32, strided groups) in one launch
+    against the single launches and fp64."""
+    import ctypes
+
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(21)
+    st = torch.cuda.current_stream().cuda_stream
+    jobs, keep, want = [], [], []
+    for (B, G, M, K, L) in [(8, 3, 256, 256, 1024), (2, 1, 100, 72, 260), (8, 1, 360, 360, 1024), (4, 2, 64, 130, 4096)]:
+        gy, x = torch.randn(B, G * M, L, generator=g).cuda(), torch.randn(B, G * K, L, generator=g).cuda()
+        for gi in range(G):
+            sink = torch.randn(M, K, generator=g).cuda()
+            ref = sink.double() + torch.einsum("bml,bkl->mk", gy[:, gi * M:(gi + 1) * M].double(), x[:, gi * K:(gi + 1) * K].double())
+            single = sink.clone()
+            check(lib.s2f_gemm_dw_general(gy.data_ptr() + 4 * gi * M * L, G * M * L, x.data_ptr() + 4 * gi * K * L, G * K * L,
+                                          single.data_ptr(), B, M, K, L, 1, st), "single")
+            jobs += [gy.data_ptr() + 4 * gi * M * L, G * M * L, x.data_ptr() + 4 * gi * K * L, G * K * L, sink.data_ptr(), B, M, K, L]
+            keep.append((gy, x, sink, single))
+            want.append(ref)
+    arr = (ctypes.c_int64 * len(jobs))(*jobs)
+    check(lib.s2f_gemm_dw_general_grouped(arr, len(want), st), "grouped")
+    for (gy, x, sink, single), ref in zip(keep, want):
+        scale = ref.abs().max().item()
+        assert (sink.double() - ref).abs().max().item() <= 2e-6 * scale * 8
+        assert (sink - single).abs().max().item() <= 1e-5 * scale
+
+
 @pytest.mark.parametrize("shape", [(8, 256, 1024), (3, 100, 256), (2, 70, 36), (1, 5, 3), (2, 64, 130)])
 def test_transpose_last2_is_the_permuted_copy(shape):
     """s2f_transpose_last2 == x.transpose(-1, -2).contiguous(), forward and adjoint, incl. ragged / unaligned tiles."""

@@ -68,6 +68,20 @@ def grouped(jobs, njobs, bkv, stream):
 
 
 lib.s2f_spike_gemm_dw_grouped = grouped
+_ggrouped = lib.s2f_gemm_dw_general_grouped
+
+
+def ggrouped(jobs, njobs, stream):
+    fl, desc = 0, collections.Counter()
+    for i in range(njobs):
+        B, M, K, L = [jobs[9 * i + j] for j in (5, 6, 7, 8)]
+        fl += 2 * B * M * K * L
+        desc[f"B{B} M{M} K{K} L{L}"] += 1
+    shape = f"{njobs} jobs: " + ", ".join(f"{n}x[{k}]" for k, n in desc.most_common())
+    return armed("s2f_gemm_dw_general_grouped", shape, fl, _ggrouped, jobs, njobs, stream)
+
+
+lib.s2f_gemm_dw_general_grouped = ggrouped
 
 
 def torch_timed(kind, shape, flops, fn):
