@@ -11,11 +11,14 @@ import collections
 import sqlite3
 import sys
 
-FAMILIES = [("spike GEMM forward (sgemm_bf16_kernel)", lambda n: "sgemm_bf16_kernel" in n),
+FAMILIES = [("spike GEMM forward, LDS-DMA pipeline (pg_nn_kernel)", lambda n: "pg_nn_kernel" in n),
+            ("input gradient / dense GEMM, 6 passes (pg_tn_f32_kernel)", lambda n: "pg_tn_f32_kernel" in n),
+            ("spike GEMM forward, round-2 kernel: 3x3 convolutions, N < 128 (sgemm_bf16_kernel)", lambda n: "sgemm_bf16_kernel" in n),
             ("spike GEMM weight gradient (sgemm_dw_bf16 / grouped)", lambda n: "sgemm_dw" in n),
-            ("general weight gradient, 6 passes (spike_gemm_dw_kernel<.., 3, ..>)", lambda n: "spike_gemm_dw_kernel" in n),
+            ("general weight gradient, 6 passes (spike_gemm_dw_kernel / gemm_dw_general_grouped)",
+             lambda n: "spike_gemm_dw_kernel" in n or "gemm_dw_general_grouped" in n),
             ("split GEMM (mask contraction backward, 3x3 input gradients)", lambda n: "split_gemm_kernel" in n),
-            ("library fp32 GEMM (rocBLAS / hipBLASLt: 1x1 input gradients)", lambda n: n.startswith("Cijk")),
+            ("library fp32 GEMM (rocBLAS / hipBLASLt)", lambda n: n.startswith("Cijk")),
             ("attention k^T v on the matrix cores (outer_mfma_kernel)", lambda n: "outer_mfma_kernel" in n)]
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
