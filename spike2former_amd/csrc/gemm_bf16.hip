@@ -286,10 +286,12 @@ __global__ __launch_bounds__(64 * WNW * WM * KG, FWD_MIN_BLOCKS(WM, KG)) void sg
 // Weight gradient with a bf16 activation:  dW[m][k] = sum_b sum_l dY[b][m][l] X[b][k][l].  The structure of
 // spike_gemm_dw_kernel (gemm.hip: 4 waves, output tile TM x 128, split-K over B*L with fp32 atomics, dY split hi+mid+lo
 // while it is staged); the X tile is copied as it lies (8-byte chunks of 4 contraction elements).
-template <int BKV, bool CONV, int TM>
+// ASPLIT: dY arrives PRE-SPLIT as three bf16 planes hi | mid | lo (`plane` elements apart, written by s2f_bn_act_bwd_split): the
+// tile is copied as it lies, like X -- no conversion arithmetic in the loop.
+template <int BKV, bool CONV, int TM, bool ASPLIT = false>
 __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const unsigned short* __restrict__ X,
                                              float* __restrict__ dW, int B, int M, int K, int L, int steps_per_split,
-                                             int k_tiles, Conv3 geo, int log_w, int tile, int split) {
+                                             int k_tiles, Conv3 geo, int log_w, int tile, int split, int64_t plane = 0) {
   constexpr int LD = BKV + 8;
   constexpr int QPR = BKV / 4;                 // 4-element chunks per row
   constexpr int NH = 128 * QPR / 256;          // X chunks per thread
@@ -316,7 +318,8 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 areg[NHA];
+  f32x4 areg[ASPLIT ? 1 : NHA];
+  u32x2 aplane[ASPLIT ? 3 : 1][NHA];
   u32x2 breg[NH];
   int crow[NH], ctap[NH];
 #pragma unroll
@@ -343,9 +346,10 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
     rok_x[h] = k0 + row < K;
     ox[h] = (unsigned int)min(row, K - 1 - k0) * (unsigned int)L;
   }
-  auto fetch = [&](int step, f32x4 (&a)[NHA], u32x2 (&bq)[NH]) {
+  auto fetch = [&](int step, f32x4 (&a)[ASPLIT ? 1 : NHA], u32x2 (&bq)[NH]) {
     const int b = step / lsteps, l0 = (step - b * lsteps) * BKV;
     const float* pa = dY + ((int64_t)b * M + m0) * L;                            // wave-uniform
+    const unsigned short* ps = reinterpret_cast<const unsigned short*>(dY) + ((int64_t)b * M + m0) * L;
     const unsigned short* px = X + ((int64_t)b * K + k0) * L;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -356,7 +360,15 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       const unsigned int col = (unsigned int)min(l, L - 4);          // L % 4 == 0, L >= 4
       // raw loads only: the out-of-range lanes are zeroed in stage(), one K step later -- with the select next to the load
       // the compiler sinks the load under the predicate and waits for it on the spot
-      if (h < NHA) a[h < NHA ? h : 0] = *reinterpret_cast<const f32x4*>(pa + (oa[h < NHA ? h : 0] + col));
+      if constexpr (ASPLIT) {
+        if (h < NHA) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            aplane[t][h < NHA ? h : 0] = *reinterpret_cast<const u32x2*>(ps + t * plane + (oa[h < NHA ? h : 0] + col));
+        }
+      } else {
+        if (h < NHA) a[h < NHA ? h : 0] = *reinterpret_cast<const f32x4*>(pa + (oa[h < NHA ? h : 0] + col));
+      }
       if constexpr (CONV) {
         const Conv3Pred pr = conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]);
         bq[h] = *reinterpret_cast<const u32x2*>(X + ((int64_t)b * geo.C + crow[h]) * L + conv3_off(l, ctap[h] / 3, ctap[h] % 3, geo, pr));
@@ -365,14 +377,21 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       }
     }
   };
-  auto stage = [&](int step, const f32x4 (&a)[NHA], const u32x2 (&bq)[NH]) __attribute__((always_inline)) {
+  auto stage = [&](int step, const f32x4 (&a)[ASPLIT ? 1 : NHA], const u32x2 (&bq)[NH]) __attribute__((always_inline)) {
     const int l0s = (step - (step / lsteps) * lsteps) * BKV;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int c = tid + h * 256;
       const int row = c / QPR, col = (c % QPR) * 4;
       const bool lok = l0s + lq[h] < L;
-      if (h < NHA) {
+      if constexpr (ASPLIT) {
+        if (h < NHA) {
+          const bool ok = lok && rok_a[h < NHA ? h : 0];
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            *reinterpret_cast<u32x2*>(&As[t][row][col]) = ok ? aplane[t][h < NHA ? h : 0] : u32x2{0u, 0u};
+        }
+      } else if (h < NHA) {
         const f32x4 av = (lok && rok_a[h < NHA ? h : 0]) ? a[h < NHA ? h : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned int h0, m0_, l0_, h1, m1, l1;
         s2f_split3x2(av.x, av.y, h0, m0_, l0_);
@@ -452,13 +471,14 @@ __device__ __forceinline__ int xcd_contiguous(int f, int total) {
 #define DW_MIN_BLOCKS(TMV, BKVV) 1
 #endif
 
-template <int BKV, bool CONV, int TM>
+template <int BKV, bool CONV, int TM, bool ASPLIT>
 __global__ __launch_bounds__(256, DW_MIN_BLOCKS(TM, BKV)) void sgemm_dw_bf16_kernel(const float* __restrict__ dY,
                                                             const unsigned short* __restrict__ X, float* __restrict__ dW,
                                                             int B, int M, int K, int L, int steps_per_split, int k_tiles,
-                                                            Conv3 geo, int log_w) {
+                                                            Conv3 geo, int log_w, int64_t plane) {
   const int id = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-  dw_tile_body<BKV, CONV, TM>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, id % (int)gridDim.x, id / (int)gridDim.x);
+  dw_tile_body<BKV, CONV, TM, ASPLIT>(dY, X, dW, B, M, K, L, steps_per_split, k_tiles, geo, log_w, id % (int)gridDim.x,
+                                      id / (int)gridDim.x, plane);
 }
 
 // MANY weight gradients in ONE launch.  The 32x32- and 64x64-stage layers (and the decoder's 100-token layers) each owe a
@@ -475,13 +495,14 @@ struct DwJob {
   float* dW;
   int B, M, K, L;
   int first_block, steps_per_split, k_tiles, tiles;
+  int64_t plane;                       // > 0: dY is three bf16 planes this many elements apart
 };
 struct DwJobTable {
   int njobs;
   DwJob job[kMaxJobs];
 };
 
-template <int BKV, int TM>
+template <int BKV, int TM, bool ASPLIT>
 __global__ __launch_bounds__(256, DW_MIN_BLOCKS(TM, BKV)) void sgemm_dw_grouped_kernel(const DwJobTable tab) {
   const int id = xcd_contiguous(blockIdx.x, gridDim.x);
   int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= id (wave-uniform)
@@ -491,8 +512,8 @@ __global__ __launch_bounds__(256, DW_MIN_BLOCKS(TM, BKV)) void sgemm_dw_grouped_
   }
   const DwJob& j = tab.job[lo];
   const int local = id - j.first_block;
-  dw_tile_body<BKV, false, TM>(j.dY, j.X, j.dW, j.B, j.M, j.K, j.L, j.steps_per_split, j.k_tiles, Conv3{0, 0, 0}, 0,
-                               local % j.tiles, local / j.tiles);
+  dw_tile_body<BKV, false, TM, ASPLIT>(j.dY, j.X, j.dW, j.B, j.M, j.K, j.L, j.steps_per_split, j.k_tiles, Conv3{0, 0, 0}, 0,
+                                       local % j.tiles, local / j.tiles, j.plane);
 }
 
 // (Two larger-tile forms of this kernel were built and measured, then removed -- tools/micro/gemm_dw_probe.hip, us on
@@ -580,7 +601,7 @@ int fwd_launch(const char* who, const uint16_t* w_split, const uint16_t* X, cons
 }
 
 int dw_launch(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate, bool conv,
-              Conv3 geo, int log_w, void* stream) {
+              Conv3 geo, int log_w, void* stream, int64_t plane = 0) {
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw_bf16: null pointer");
   S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
               "s2f_spike_gemm_dw_bf16: bad sizes (L=%d must be a positive multiple of 4)", L);
@@ -614,8 +635,14 @@ int dw_launch(const float* dY, const uint16_t* X, float* dW, int batch, int M, i
   const int steps_per_split = (total_steps + splits - 1) / splits;
   splits = (total_steps + steps_per_split - 1) / steps_per_split;
 #define S2F_DW1(BKV, CV, TMV)                                                                                            \
-  S2F_LAUNCH(true, true, (sgemm_dw_bf16_kernel<BKV, CV, TMV>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, X, dW, \
-             batch, M, K, L, steps_per_split, k_tiles, geo, log_w)
+  do {                                                                                                                   \
+    if (plane > 0)                                                                                                       \
+      S2F_LAUNCH(true, true, (sgemm_dw_bf16_kernel<BKV, CV, TMV, true>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, \
+                 X, dW, batch, M, K, L, steps_per_split, k_tiles, geo, log_w, plane);                                     \
+    else                                                                                                                 \
+      S2F_LAUNCH(true, true, (sgemm_dw_bf16_kernel<BKV, CV, TMV, false>), dim3(m_tiles * k_tiles, splits), dim3(256), 0, s, dY, \
+                 X, dW, batch, M, K, L, steps_per_split, k_tiles, geo, log_w, plane);                                     \
+  } while (0)
 #define S2F_DW(BKV, CV)             \
   do {                              \
     if (tm == 32)                   \
@@ -668,6 +695,14 @@ extern "C" int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float*
   return dw_launch(dY, X, dW, batch, M, K, L, accumulate, false, Conv3{0, 0, 0}, 0, stream);
 }
 
+extern "C" int s2f_spike_gemm_dw_bf16_split(const uint16_t* dY_split, int64_t plane_stride, const uint16_t* X, float* dW, int batch,
+                                            int M, int K, int L, int accumulate, void* stream) {
+  S2F_REQUIRE(plane_stride >= (int64_t)batch * M * L && (plane_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(dY_split) & 15u) == 0,
+              S2F_EINVAL, "s2f_spike_gemm_dw_bf16_split: plane stride must cover a plane and keep 8-byte alignment");
+  return dw_launch(reinterpret_cast<const float*>(dY_split), X, dW, batch, M, K, L, accumulate, false, Conv3{0, 0, 0}, 0, stream,
+                   plane_stride);
+}
+
 extern "C" int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,
                                          int accumulate, void* stream) {
   S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & (W - 1)) == 0, S2F_EINVAL,
@@ -677,8 +712,19 @@ extern "C" int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, flo
   return dw_launch(dY, X, dW, batch, M, C * 9, H * W, accumulate, true, Conv3{H, W, C}, log_w, stream);
 }
 
+static int dw_grouped_launch(const int64_t* jobs, int njobs, int bkv, void* stream, bool split);
+
 extern "C" int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* stream) {
-  // jobs (HOST array): njobs x {dY, X, dW (pointers), batch, M, K, L}; every dW is accumulated into (accumulate semantics)
+  return dw_grouped_launch(jobs, njobs, bkv, stream, false);
+}
+
+extern "C" int s2f_spike_gemm_dw_grouped_split(const int64_t* jobs, int njobs, int bkv, void* stream) {
+  return dw_grouped_launch(jobs, njobs, bkv, stream, true);
+}
+
+static int dw_grouped_launch(const int64_t* jobs, int njobs, int bkv, void* stream, bool split) {
+  // jobs (HOST array): njobs x {dY, X, dW (pointers), batch, M, K, L}; every dW is accumulated into (accumulate semantics);
+  // split: dY points at three bf16 planes hi | mid | lo, batch * M * L elements apart
   S2F_REQUIRE(jobs && njobs > 0 && njobs <= kMaxJobs && (bkv == 32 || bkv == 64), S2F_EINVAL,
               "s2f_spike_gemm_dw_grouped: 1 .. %d jobs, bkv 32 or 64", kMaxJobs);
   DwJobTable tab;
@@ -697,6 +743,7 @@ extern "C" int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv
                 "s2f_spike_gemm_dw_grouped: job %d misaligned", i);
     j.k_tiles = (j.K + 127) / 128;
     j.tiles = ((j.M + 63) / 64) * j.k_tiles;
+    j.plane = split ? (int64_t)j.B * j.M * j.L : 0;
     work += (int64_t)j.tiles * j.B * ((j.L + bkv - 1) / bkv);
   }
   // one contraction length per workgroup for the whole launch: ~1024 workgroups, at least 4 steps each
@@ -713,10 +760,14 @@ extern "C" int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv
   }
   S2F_REQUIRE(first < (1ll << 31), S2F_EINVAL, "s2f_spike_gemm_dw_grouped: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  if (bkv == 64)
-    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<64, 64>), dim3((unsigned)first), dim3(256), 0, s, tab);
+  if (bkv == 64 && split)
+    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<64, 64, true>), dim3((unsigned)first), dim3(256), 0, s, tab);
+  else if (bkv == 64)
+    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<64, 64, false>), dim3((unsigned)first), dim3(256), 0, s, tab);
+  else if (split)
+    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<32, 64, true>), dim3((unsigned)first), dim3(256), 0, s, tab);
   else
-    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<32, 64>), dim3((unsigned)first), dim3(256), 0, s, tab);
+    S2F_LAUNCH(true, true, (sgemm_dw_grouped_kernel<32, 64, false>), dim3((unsigned)first), dim3(256), 0, s, tab);
   return s2f_check_launch("s2f_spike_gemm_dw_grouped");
 }
 

@@ -174,8 +174,7 @@ class GraphedHungarianStep:
                 ops.wgrad_join()
                 del outs, total
         torch.cuda.current_stream().wait_stream(side)
-        for v in ops._DW_PENDING.values():               # warm-up gradients are not packed: drop their deferred launches
-            v.clear()
+        ops.wgrad_drop()                                 # warm-up gradients are not packed: drop their deferred launches
         ops.resplit_all(dev)
         torch.cuda.synchronize()
         import torch.distributed as dist
@@ -260,8 +259,7 @@ class GraphedOverlapStep:
                 torch.autograd.grad([loss], params, allow_unused=True)
                 ops.wgrad_join()
         torch.cuda.current_stream().wait_stream(side)
-        for v in ops._DW_PENDING.values():               # warm-up gradients are not packed: drop their deferred launches
-            v.clear()
+        ops.wgrad_drop()                                 # warm-up gradients are not packed: drop their deferred launches
         ops.resplit_all(self.static_in.device)
         torch.cuda.synchronize()
         import torch.distributed as dist

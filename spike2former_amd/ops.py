@@ -52,6 +52,7 @@ def begin_step(device=None):
     # a step that is being captured into a hipGraph re-splits every weight first (one launch, recorded in the graph): the
     # replays then read the live fp32 weights instead of the bf16 terms of capture time
     _TRUST_ALL[0] = False
+    _GRAD_SPLITS.clear()
     if device is not None and torch.cuda.is_current_stream_capturing():
         n = resplit_all(device, build=False)
         if n > 0:
@@ -160,14 +161,43 @@ def _defer_dw_general(gy, gy_off, dy_bs, x, x_off, x_bs, sink, B, M, K, L):
     return True
 
 
+# ---- pre-split gradients -----------------------------------------------------------------------------------------------
+# The gradient of a 1x1 convolution's output comes from a BatchNorm backward kernel and is read by two GEMMs (input and weight
+# gradient) that each split it into bf16 hi / mid / lo terms in their inner loops.  When fused.conv_bn_act pairs the two ops
+# (`split_request` around the convolution, `split_grad=` on bn_act), the BatchNorm backward writes the three bf16 planes instead
+# (s2f_bn_act_bwd_split: 6 instead of 4 bytes per element) and hands autograd a one-element stand-in expanded to z's shape;
+# _SpikeGemm.backward finds the planes under the stand-in's address and runs the all-DMA input-gradient kernel
+# (s2f_pgemm_dx_split) and the copy-only weight-gradient kernels (s2f_spike_gemm_dw_*_split).  Nothing else may read that
+# gradient -- z has exactly one consumer, the BatchNorm.
+# Measured at C2 on one box (bench.py, S2F_GRAD_SPLIT=1 vs 0): 42.95 vs 42.84 ms per step -- the input-gradient launches get 6 %
+# shorter (27.1 vs 28.9 us), the weight-gradient launches 4 % LONGER (they were not bound by the conversion arithmetic, and now
+# read 6 instead of 4 bytes per element) and so do the BatchNorm backward passes that write the planes: no net gain, so the
+# protocol is OFF by default and kept as a measured alternative (tests/test_gpu_kernels.py covers its kernels either way).
+GRAD_SPLIT = _os.environ.get("S2F_GRAD_SPLIT", "0") != "0"
+_SPLIT_STATE = {"req": False, "granted": False}
+_GRAD_SPLITS = {}
+_DW_PENDING_SPLIT = {64: [], 32: []}
+
+
+def split_request(on):
+    """fused.conv_bn_act: ask the next spike GEMM whether its backward takes the gradient as bf16 planes; -> granted?"""
+    if on:
+        _SPLIT_STATE["req"], _SPLIT_STATE["granted"] = True, False
+        return False
+    g = _SPLIT_STATE["granted"]
+    _SPLIT_STATE["req"] = _SPLIT_STATE["granted"] = False
+    return g
+
+
 def wgrad_drop():
     """Forget the deferred weight gradients that were never flushed (a backward that raised, an abandoned step): their sink
     views and activations must not be added into the NEXT step's freshly zeroed buffer."""
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return                                 # inside a capture the step's own flush follows; nothing stale can be pending
-    for jobs in _DW_PENDING.values():
+    for jobs in list(_DW_PENDING.values()) + list(_DW_PENDING_SPLIT.values()):
         jobs.clear()
     _DWG_PENDING.clear()
+    _GRAD_SPLITS.clear()
 
 
 def wgrad_flush():
@@ -182,18 +212,20 @@ def wgrad_flush():
                    sum(2 * j[5] * j[6] * j[7] * j[8] for j in chunk))
         check(lib.s2f_gemm_dw_general_grouped(arr, len(chunk), _stream()), "s2f_gemm_dw_general_grouped")
         del _DWG_PENDING[:56]
-    for bkv, jobs in _DW_PENDING.items():
-        while jobs:
-            chunk, rest = jobs[:56], jobs[56:]
-            flat = []
-            for gy, x, sink, B, M, K, L in chunk:
-                flat += [gy.data_ptr(), x.data_ptr(), sink.data_ptr(), B, M, K, L]
-            arr = (ctypes.c_int64 * len(flat))(*flat)
-            _time_next("spike_gemm_dw", sum(4 * B * L * (K + M) for _, _, _, B, M, K, L in chunk),
-                       sum(2 * B * M * L * K for _, _, _, B, M, K, L in chunk),
-                       moved=sum(B * L * (2 * K + 4 * M) for _, _, _, B, M, K, L in chunk))
-            check(lib.s2f_spike_gemm_dw_grouped(arr, len(chunk), bkv, _stream()), "s2f_spike_gemm_dw_grouped")
-            jobs[:] = rest
+    for split, pending in ((False, _DW_PENDING), (True, _DW_PENDING_SPLIT)):
+        for bkv, jobs in pending.items():
+            while jobs:
+                chunk, rest = jobs[:56], jobs[56:]
+                flat = []
+                for gy, x, sink, B, M, K, L in chunk:
+                    flat += [gy.data_ptr(), x.data_ptr(), sink.data_ptr(), B, M, K, L]
+                arr = (ctypes.c_int64 * len(flat))(*flat)
+                _time_next("spike_gemm_dw", sum(4 * B * L * (K + M) for _, _, _, B, M, K, L in chunk),
+                           sum(2 * B * M * L * K for _, _, _, B, M, K, L in chunk),
+                           moved=sum(B * L * (2 * K + (6 if split else 4) * M) for _, _, _, B, M, K, L in chunk))
+                fn = lib.s2f_spike_gemm_dw_grouped_split if split else lib.s2f_spike_gemm_dw_grouped
+                check(fn(arr, len(chunk), bkv, _stream()), "s2f_spike_gemm_dw_grouped")
+                jobs[:] = rest
 
 
 # ---- concurrency inside one step -------------------------------------------------------------------------------------
@@ -968,8 +1000,9 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
-                eps, lif_on, want_pre, keep_v, D, vth, stats, bf16):
+                eps, lif_on, want_pre, keep_v, D, vth, stats, bf16, split_grad=False):
         _need_cuda(z, conv_bias, gamma, beta, residual, v_in)
+        ctx.split_grad = bool(split_grad)
         z = z.contiguous()
         N, C = z.shape[0], z.shape[1]
         L = z.numel() // (N * C)
@@ -1022,19 +1055,27 @@ class _BNAct(torch.autograd.Function):
             return None if (g is None or g.numel() == 0) else g.contiguous()
         g_u, g_y, g_v = prep(g_u), prep(g_y), prep(g_v)
         if g_u is None and g_y is None and g_v is None:
-            return (None,) * 19
+            return (None,) * 20
         dev = z.device
-        gz = torch.empty_like(z)
+        split = ctx.split_grad and z.numel() % 4 == 0
+        planes = torch.empty((3, N, C, L), dtype=torch.bfloat16, device=dev) if split else None
+        gz = torch.empty(1, dtype=torch.float32, device=dev).expand(z.shape) if split else torch.empty_like(z)
         g_res = torch.empty_like(z) if (has_res and ctx.needs_input_grad[4]) else None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = None if (training and lib.s2f_bn_single_pass(N, C, L)) else _take_zeroed(2 * C, dev)
         # read z + incoming grads, write gz [, g_residual]
-        _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd",
-                   4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None)))
-        check(lib.s2f_bn_act_bwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
-                                 _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
-                                 int(training), vth, D, _stream()), "s2f_bn_act_bwd")
+        alg = 4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None))
+        _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd", alg, moved=alg + (2 * z.numel() if split else 0))
+        if split:
+            check(lib.s2f_bn_act_bwd_split(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
+                                           _ptr(mask), _ptr(ws), _ptr(planes), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
+                                           int(training), vth, D, _stream()), "s2f_bn_act_bwd_split")
+            _GRAD_SPLITS[gz.data_ptr()] = planes
+        else:
+            check(lib.s2f_bn_act_bwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
+                                     _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
+                                     int(training), vth, D, _stream()), "s2f_bn_act_bwd")
         g_bias = None
         if has_bias:
             # train-mode BN removes any per-channel constant: d/d(bias) == 0 exactly -> no gradient tensor at all (None, a
@@ -1042,16 +1083,16 @@ class _BNAct(torch.autograd.Function):
             g_bias = None if training else gamma * stat[C:2 * C] * dbeta
         if ctx.needs_input_grad[5]:
             raise RuntimeError("gradient w.r.t. the incoming membrane is not supported by the fused BN+LIF op")
-        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 14
+        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 15
 
 
 def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, residual=None,
-           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False):
+           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False, split_grad=False):
     """-> (u or None, y or None, v_out or None [, border]); y is a Spikes pair (bf16 when SPIKES_BF16); border [C] = BN(0)
     from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel."""
     bf16 = bool(lif) and spikes_bf16_ok(D)
     u, y, v, border, ydata = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
-                                          momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16)
+                                          momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16, split_grad)
     if lif:
         y = Spikes(ydata, y) if bf16 else Spikes(y, None)
     out = (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
@@ -1371,11 +1412,20 @@ class _SpikeGemm(torch.autograd.Function):
                   "s2f_spike_gemm_fwd")
         ctx.save_for_backward(x, w2d)
         ctx.has_bias, ctx.has_tok = bias is not None, tok is not None
+        # pre-split gradient protocol (see GRAD_SPLIT): granted when both gradient GEMMs of this layer can read planes
+        ctx.takes_split = bool(GRAD_SPLIT and _SPLIT_STATE["req"] and PGEMM and PGEMM_DX and xb and bias is None and N % 8 == 0
+                               and N >= PGEMM_MIN_N and SPIKE_GEMM_DW and M >= 16 and x.data_ptr() % 8 == 0
+                               and any(ctx.needs_input_grad[:3]))
+        if ctx.takes_split:
+            _SPLIT_STATE["granted"] = True
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w2d = ctx.saved_tensors
+        planes = _GRAD_SPLITS.pop(gy.data_ptr(), None) if ctx.takes_split else None
+        if planes is not None:
+            return _SpikeGemm._backward_split(ctx, x, w2d, planes)
         gy = gy.contiguous()
         B = x.shape[0]
         gx = gw = gb = None
@@ -1406,6 +1456,33 @@ class _SpikeGemm(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))
         return _grad_pair(ctx.has_tok, gx) + (gw, gb)
+
+
+def _spike_gemm_backward_split(ctx, x, w2d, planes):
+    """_SpikeGemm.backward from the gradient as bf16 planes [3, B, M, L] (hi | mid | lo)."""
+    _, B, M, L = planes.shape
+    K = w2d.shape[1]
+    gx = gw = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        gx = torch.empty(B, K, L, dtype=torch.float32, device=planes.device)
+        _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * (4 * K + 6 * M))
+        check(lib.s2f_pgemm_dx_split(_ptr(pack_weight(w2d)), _ptr(planes), B * M * L, _ptr(gx), B, M, K, L, 0, _stream()),
+              "s2f_pgemm_dx_split")
+    if ctx.needs_input_grad[2]:
+        sink = _sink_for(w2d)
+        if DEFER_DW and sink is not None and B * L <= DEFER_DW_MAX_CONTRACTION and WGRAD_STREAM is None:
+            _DW_PENDING_SPLIT[64 if (L % 64 == 0 or L >= 512) else 32].append((planes, x, sink, B, M, K, L))
+        else:
+            gw = torch.empty(M, K, dtype=torch.float32, device=x.device) if sink is None else None
+            _time_next("spike_gemm_dw", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * (2 * K + 6 * M))
+            side = _wgrad_stream(sink, planes, x)
+            st = side.cuda_stream if side is not None else _stream()
+            check(lib.s2f_spike_gemm_dw_bf16_split(_ptr(planes), B * M * L, _ptr(x), _ptr(gw if sink is None else sink), B, M, K, L,
+                                                   int(sink is not None), st), "s2f_spike_gemm_dw_bf16_split")
+    return _grad_pair(ctx.has_tok, gx) + (gw, None)
+
+
+_SpikeGemm._backward_split = staticmethod(_spike_gemm_backward_split)
 
 
 def dx_gemm(w2d, gy):

@@ -85,7 +85,7 @@ for p, v in zip(red.params, red.views):
     ref = want[name_of[id(p)]]
     worst = max(worst, (v - ref).abs().max().item() / (ref.abs().max().item() + 1e-3 * gscale))
 assert worst <= 2e-3, f"reduced gradients differ from the mean of the shards' gradients: {worst}"
-assert any(len(j) == 0 for j in ops._DW_PENDING.values()) and all(len(j) == 0 for j in ops._DW_PENDING.values())
+assert all(len(j) == 0 for j in list(ops._DW_PENDING.values()) + list(ops._DW_PENDING_SPLIT.values()))
 print(f"RANK {rank} OK worst {worst:.2e} ranks_seen {dist.get_world_size()}", flush=True)
 dist.barrier()
 dist.destroy_process_group()

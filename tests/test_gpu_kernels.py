@@ -1063,3 +1063,29 @@ def test_reparam_helpers_fold_like_the_reference():
         assert torch.allclose(reparam.fused_conv2d_weight_of_convbn2d(conv, bn), w2, atol=0, rtol=1e-6)
         got = reparam.fuse_convbn2d(conv, bn)(x)
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,M,K,L", [(8, 256, 256, 1024), (2, 100, 72, 260), (8, 32, 64, 4096), (4, 360, 360, 1024)])
+def test_weight_gradient_from_presplit_planes(ops, B, M, K, L):
+    """s2f_spike_gemm_dw_bf16_split / s2f_spike_gemm_dw_grouped_split: dW from dY as bf16 planes == the fp32-dY kernels (the terms
+    they form in registers are the planes), up to the order of the split-K atomics; fp64 as the yardstick."""
+    import ctypes
+
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B + M + K + L)
+    gy = torch.randn(B, M, L, generator=g).cuda()
+    x = (torch.randint(0, 9, (B, K, L), generator=g).float() / 8).cuda().bfloat16()
+    hi = gy.bfloat16(); r1 = gy - hi.float(); mid = r1.bfloat16(); lo = (r1 - mid.float()).bfloat16()
+    planes = torch.stack([hi, mid, lo]).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.einsum("bml,bkl->mk", gy.double(), x.double())
+    scale = ref.abs().max().item()
+    a, b_, c = (torch.zeros(M, K, device="cuda") for _ in range(3))
+    check(lib.s2f_spike_gemm_dw_bf16(gy.data_ptr(), x.data_ptr(), a.data_ptr(), B, M, K, L, 0, st), "fp32")
+    check(lib.s2f_spike_gemm_dw_bf16_split(planes.data_ptr(), gy.numel(), x.data_ptr(), b_.data_ptr(), B, M, K, L, 0, st), "split")
+    arr = (ctypes.c_int64 * 7)(planes.data_ptr(), x.data_ptr(), c.data_ptr(), B, M, K, L)
+    check(lib.s2f_spike_gemm_dw_grouped_split(arr, 1, 64 if (L % 64 == 0 or L >= 512) else 32, st), "grouped")
+    for got in (a, b_, c):
+        assert (got.double() - ref).abs().max().item() <= 4e-6 * scale
+    assert (a - b_).abs().max().item() <= 2e-6 * scale and (a - c).abs().max().item() <= 2e-6 * scale

@@ -209,7 +209,13 @@ def test_loss_mode_runs_the_hungarian_matched_loss(env):
     s2f, so, cfg, model = env
     state = {k: v.clone() for k, v in model.state_dict().items()}
     img = so.synthetic_image(cfg, seed=8).cuda()
-    seg = torch.randint(0, cfg.num_classes, (cfg.B, 1, cfg.H, cfg.W), generator=torch.Generator().manual_seed(2)).cuda()
+    gen = torch.Generator().manual_seed(2)
+    seg = torch.empty(cfg.B, 1, cfg.H, cfg.W, dtype=torch.int64)
+    for b in range(cfg.B):                                   # a 4 x 4 grid of rectangles, 5 classes per image
+        classes = torch.randperm(cfg.num_classes, generator=gen)[:5]
+        for i, (y0, x0) in enumerate((y, x) for y in range(0, cfg.H, cfg.H // 4) for x in range(0, cfg.W, cfg.W // 4)):
+            seg[b, 0, y0:y0 + cfg.H // 4, x0:x0 + cfg.W // 4] = classes[i % 5]
+    seg = seg.cuda()
     seg[0, :, :4] = 255
     model.train(); s2f.reset_net(model); model.zero_grad(set_to_none=True)
     losses = model(img, [seg[i] for i in range(cfg.B)], mode="loss")
@@ -222,7 +228,9 @@ def test_loss_mode_runs_the_hungarian_matched_loss(env):
     model.load_state_dict(state); s2f.reset_net(model); model.zero_grad(set_to_none=True)
     cls, masks = model(img)
     again = model.decode_head.loss_by_feat(cls, masks, [s2f.seg_to_instances(seg[i]) for i in range(cfg.B)])
-    assert all(torch.equal(again[k], losses[k]) for k in losses)
+    # mode="loss" takes the semantic-map path (label-map kernels), loss_by_feat the generic instance-mask path: fp32 round-off apart
+    assert list(again) == list(losses)
+    assert all(abs(float(again[k]) - float(losses[k])) <= 1e-5 * max(abs(float(again[k])), 1e-3) for k in losses)
     s2f.headline_loss(cls, masks).backward()
     assert got == {k for k, p in model.named_parameters() if p.grad is not None}
 
@@ -301,6 +309,45 @@ def test_cal_firing_num_tool(tmp_path):
     assert max(abs(res["t0"][k] - res2["t0"][k]) for k in res["t0"]) > 1e-3
 
 
+def test_presplit_gradient_protocol_gives_the_same_gradients(env):
+    """ops.GRAD_SPLIT (off by default): BatchNorm backward writes the gradient of a 1x1 convolution's output as bf16 hi | mid | lo
+    planes, the convolution's two gradient GEMMs read the planes.  Same parameter gradients as the fp32 hand-over -- the terms are
+    the ones the fp32 kernels form in registers -- on the 256 x 256 images (the 1x1 layers with >= 128 columns take the protocol)."""
+    s2f, so, cfg, model = env
+    from spike2former_amd import ops
+    from spike2former_amd._lib import lib
+    img = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(4)).cuda()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    s2f.set_keep_membrane(model, False)
+    model.train()
+    calls = []
+    orig = lib.s2f_pgemm_dx_split
+
+    def counted(*a):
+        calls.append(a[4:8])
+        return orig(*a)
+    lib.s2f_pgemm_dx_split = counted
+    grads = {}
+    try:
+        for flag in (False, True):
+            ops.GRAD_SPLIT = flag
+            model.load_state_dict(state); s2f.reset_net(model); model.zero_grad(set_to_none=True)
+            s2f.headline_loss(*model(img)).backward()
+            ops.wgrad_join()
+            grads[flag] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            assert (len(calls) > 10) == flag
+    finally:
+        ops.GRAD_SPLIT = False
+        lib.s2f_pgemm_dx_split = orig
+        s2f.set_keep_membrane(model, True)
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+    assert grads[True].keys() == grads[False].keys()
+    scale = max(v.abs().max().item() for v in grads[False].values())
+    for n, v in grads[False].items():
+        assert (grads[True][n] - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-6 * scale, n
+
+
 def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
     """The benchmark's gradient path -- weight-gradient kernels adding straight into the flat all-reduce buffer (sinks), the
     short-contraction ones deferred and launched as one grouped kernel (ops.DEFER_DW) -- against plain autograd gradients of
@@ -326,9 +373,10 @@ def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
         red.install_sinks()
         red.zero()
         step()
-        assert sum(len(v) for v in ops._DW_PENDING.values()) > 20          # the tiny model's layers are all short-contraction
+        pending = lambda: sum(len(v) for v in list(ops._DW_PENDING.values()) + list(ops._DW_PENDING_SPLIT.values()))
+        assert pending() > 20                                             # the tiny model's layers are all short-contraction
         red.gather()                                                      # flushes the deferred launches
-        assert sum(len(v) for v in ops._DW_PENDING.values()) == 0
+        assert pending() == 0
         names = {id(p): n for n, p in model.named_parameters()}
         gscale = max(v.abs().max().item() for v in want.values())
         for p, v in zip(red.params, red.views):
@@ -337,8 +385,7 @@ def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
             assert err <= 1e-4 * want[n].abs().max().item() + 1e-6 * gscale, (n, err)
     finally:
         ops.GRAD_SINKS = None
-        for v in ops._DW_PENDING.values():
-            v.clear()
+        ops.wgrad_drop()
         s2f.set_keep_membrane(model, True)
         model.zero_grad(set_to_none=True)
 
