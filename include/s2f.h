@@ -279,6 +279,15 @@ int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bi
                       int terms, int cfg, void* stream);
 int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
                      int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream);
+/* Implicit 3x3 convolution (stride 1, padding 1) on the same pipeline: Y[b] (M x H W) = A (M x 9 C, the TAP-MAJOR pack of the
+ * weight: s2f_pack_bf16x3 mode 1) @ im2col(X[b]), the column matrix never formed.  _bf16: X [batch][C][H][W] bf16 spikes, 3 passes
+ * (forward; replaces s2f_spike_conv3x3_fwd_bf16, bit-identical).  _f32: X fp32, split in the kernel, 6 passes -- the INPUT
+ * gradient as the convolution of dY [batch][C = conv out_channels][H][W] with the flipped, transposed weight (pack mode 2, M =
+ * conv in_channels; replaces s2f_conv3x3_general, bit-identical).  C % 32 == 0, W % 4 == 0.  cfg 0 = automatic tile. */
+int s2f_pgemm_conv3x3_bf16(const uint16_t* w_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M, int C, int H,
+                           int W, int cfg, void* stream);
+int s2f_pgemm_conv3x3_f32(const uint16_t* w_pack, const float* X, float* Y, int batch, int M, int C, int H, int W, int cfg,
+                          void* stream);
 /* The gradient of a GEMM-produced pre-activation as THREE bf16 PLANES hi | mid | lo (gz = hi + mid + lo to 2^-24; plane p at
  * gz_split + p * N C L): s2f_bn_act_bwd_split is s2f_bn_act_bwd writing that form instead of fp32 (6 instead of 4 bytes per
  * element), s2f_pgemm_dx_split the input-gradient product reading it (plane p of batch b at G_split + p * plane_stride +

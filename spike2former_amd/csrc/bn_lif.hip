@@ -1068,7 +1068,9 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
                               float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
   float* y = reinterpret_cast<float*>(y_out);
   S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
-  const bool single = training && single_pass_ok(N, C, L);
+  // sums given for a shape that could go single-pass: the caller already has the statistics (a producer's epilogue, or a probe) --
+  // take the apply path, which is not tied to one workgroup per channel
+  const bool single = training && sums == nullptr && single_pass_ok(N, C, L);
   S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
               "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");

@@ -21,6 +21,7 @@
 // (mmseg/models/backbones/sdtv2.py:121-125, 164, 222-255, 304-306; mmcv_spike/transformer.py:196-361, 758-763).
 #include "gemm_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #pragma clang fp contract(fast)
 
@@ -748,6 +749,232 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_split_kernel(const unsig
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Implicit 3x3 convolution (stride 1, padding 1) in the same pipeline:  Y[b] (M x HW) = A (M x 9C, packed TAP-MAJOR:
+// k = tap C + c, pack modes 1 / 2) @ im2col(X[b]) -- the column matrix is never formed: row k of a K step (one tap, 32
+// channels) is the channel plane shifted by (ky - 1) W + (kx - 1) pixels.
+//   A : LDS-DMA from the pack, as pg_nn_kernel (two stages).
+//   X : the shifted rows are only 2 bytes (bf16) / 4 bytes (fp32) aligned, which an LDS-DMA cannot address -- they go through
+//       registers one K step ahead (bare loads from always-valid addresses, border fix-up when staged), stored ROW-MAJOR
+//       [32 k][128 n] with the unit swizzle of pg_nn_kernel and read with ds_read_b64_tr_b16: no transposition arithmetic.
+//       BT = 1: X holds bf16 spikes (exact): 3 passes with the weight terms  (forward: sdtv2.py:86-107, 185-214).
+//       BT = 3: X is fp32 (the gradient w.r.t. the convolution's output), split hi + mid + lo while staged: 6 passes -- the
+//               INPUT gradient, as the convolution of dY with the flipped, transposed weight (pack mode 2).
+// Same products in the same order as sgemm_bf16_kernel<.., CONV> / split_gemm_kernel<.., CONV>: bit-identical results.
+struct ConvPredB {
+  bool ok, cut_l, cut_r;
+};
+__device__ __forceinline__ ConvPredB convp(int y, int x, int ky, int kx, Conv3 g, bool ok) {
+  const int yy = y + ky - 1;
+  return ConvPredB{ok && yy >= 0 && yy < g.H, kx == 0 && x == 0, kx == 2 && x + 4 == g.W};
+}
+// never addresses outside the plane: at a cut end the aligned neighbour group is loaded and shifted in registers
+__device__ __forceinline__ int convp_off(int n, int ky, int kx, Conv3 g, ConvPredB p) {
+  return p.ok ? n + (ky - 1) * g.W + (kx - 1) + (p.cut_l ? 1 : 0) - (p.cut_r ? 1 : 0) : 0;
+}
+__device__ __forceinline__ u32x2 convp_fix(u32x2 v, ConvPredB p) {
+  if (!p.ok) return u32x2{0u, 0u};
+  if (p.cut_l) return u32x2{v.x << 16, (v.y << 16) | (v.x >> 16)};          // {0, p0, p1, p2}
+  if (p.cut_r) return u32x2{(v.x >> 16) | (v.y << 16), v.y >> 16};          // {p1, p2, p3, 0}
+  return v;
+}
+__device__ __forceinline__ f32x4 convp_fix(f32x4 v, ConvPredB p) {
+  if (!p.ok) return f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.cut_l) return f32x4{0.f, v.x, v.y, v.z};
+  if (p.cut_r) return f32x4{v.y, v.z, v.w, 0.f};
+  return v;
+}
+
+template <int MI, int NJ, int WMW, int WNW, int BT>
+__global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned short* __restrict__ Ap, const void* __restrict__ Xv,
+                                                                const float* __restrict__ bias, float* __restrict__ Y, int M,
+                                                                int N, int K, int Kb, int n_tiles, int m_tiles, Conv3 geo) {
+  constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
+  static_assert(BN == 128, "the activation tile is 128 pixels wide");
+  constexpr int A_BYTES = 3 * BM * 64, B_TERM = 32 * BN * 2, B_BYTES = BT * B_TERM, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = 3 * BM / 16, NAW = (NA + NW - 1) / NW;        // 1 KiB weight copies per stage / per wavefront (padded)
+  constexpr int NQ = 32 * (BN / 4) / T;                            // 4-pixel chunks per thread and K step
+  static_assert(NQ >= 1 && (32 * (BN / 4)) % T == 0 && T % (BN / 4) == 0, "tile too small for the thread count");
+  typedef typename std::conditional<BT == 1, u32x2, f32x4>::type chunk_t;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tiles = n_tiles * m_tiles;
+  int pid = blockIdx.x;
+  if (tiles % 8 == 0) pid = (pid % 8) * (tiles / 8) + pid / 8;          // XCD-aware tile order
+  const int mt = pid % m_tiles, nt = pid / m_tiles;
+  const int b = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int64_t plane_elems = (int64_t)geo.H * geo.W;
+  const unsigned short* Xh = reinterpret_cast<const unsigned short*>(Xv) + (int64_t)b * geo.C * plane_elems;
+  const float* Xf = reinterpret_cast<const float*>(Xv) + (int64_t)b * geo.C * plane_elems;
+  float* Yb = Y + (int64_t)b * M * N;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int wm = wave / WNW, wn = wave % WNW;
+
+  auto issue_a = [&](int kb, int st) __attribute__((always_inline)) {
+    unsigned char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int q = 0; q < NAW; ++q) {
+      int idx = wave + q * NW;
+      if (NA % NW != 0 && idx >= NA) idx -= NW;                   // pad with a repeat of an earlier copy: uniform counts
+      const int t = idx / (BM / 16), R0 = (idx % (BM / 16)) * 16;
+      const int mb = min((m0 + R0) / PR, (M - 1) / PR);           // row blocks past M hold rows that are never stored
+      const unsigned short* src = Ap + ((int64_t)mb * Kb + kb) * PBLOCK + t * PTERM + ((m0 + R0) % PR) * PK + lane * 8;
+      dma16(src, sb + (t * BM + R0) * 64);
+    }
+  };
+  // this thread's 4-pixel column group is the same in every chunk and K step (T % 32 == 0)
+  const int c4 = tid % (BN / 4);
+  const int n_px = n0 + c4 * 4;
+  const bool n_ok = n_px < N;
+  const int py = n_px / geo.W, px = n_px - py * geo.W;
+  chunk_t breg[NQ];
+  auto fetch_b = [&](int kb) __attribute__((always_inline)) {
+    const int kk = kb * 32;
+    const int tap = kk / geo.C, ky = tap / 3, kx = tap - 3 * ky, c0 = kk - tap * geo.C;
+    const ConvPredB pr = convp(py, px, ky, kx, geo, n_ok && kk < K);
+    const int off = convp_off(n_px, ky, kx, geo, pr);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int kr = (tid + q * T) / (BN / 4);
+      const int64_t row = (int64_t)(pr.ok ? c0 + kr : 0) * plane_elems + off;
+      if constexpr (BT == 1)
+        breg[q] = *reinterpret_cast<const u32x2*>(Xh + row);
+      else
+        breg[q] = *reinterpret_cast<const f32x4*>(Xf + row);
+    }
+  };
+  auto stage_b = [&](int kb, int st) __attribute__((always_inline)) {
+    const int kk = kb * 32;
+    const int tap = kk / geo.C, ky = tap / 3, kx = tap - 3 * ky;
+    const ConvPredB pr = convp(py, px, ky, kx, geo, n_ok && kk < K);
+    unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + st * STAGE + A_BYTES);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int kr = (tid + q * T) / (BN / 4);
+      const int off = kr * BN + ((((c4 >> 3) ^ (kr & 3)) << 5) | ((c4 & 7) << 2));
+      const chunk_t v = convp_fix(breg[q], pr);
+      if constexpr (BT == 1) {
+        *reinterpret_cast<u32x2*>(Bs + off) = v;
+      } else {
+        unsigned int h0, m0_, l0_, h1, m1, l1;
+        s2f_split3x2(v.x, v.y, h0, m0_, l0_);
+        s2f_split3x2(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<u32x2*>(Bs + off) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(Bs + 32 * BN + off) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(Bs + 2 * 32 * BN + off) = u32x2{l0_, l1};
+      }
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kl = (lane & 15) >> 2;
+  int boff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    boff[j] = (8 * (lane >> 5) + kl) * BN + (((wn * NJ + j) ^ kl) << 5) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int a_f = ((lane & 31) >> 2) & 3, a_h = lane >> 5;
+  unsigned abyte[2][MI];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      abyte[ks][i] = (unsigned)((wm * (32 * MI) + i * 32 + (lane & 31)) * 32 + ((((ks * 2 + a_h) ^ a_f) << 3))) * 2u;
+  const unsigned smem_a = lds_addr(smem);
+  constexpr int RPS_ALL = 2 * BT * NJ + 3 * MI;      // reads per k slice
+  constexpr int RPS = RPS_ALL < 15 ? RPS_ALL : 15;   // lgkmcnt is a 4-bit counter: the wait may cover a few reads of slice 1 too
+  auto compute = [&](int st) __attribute__((always_inline)) {
+    union BF {
+      bf16x8 v;
+      s16x4 h[2];
+    } bfrag[2][BT][NJ];
+    bf16x8 afrag[2][3][MI];
+    const unsigned sb = smem_a + st * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int tb = 0; tb < BT; ++tb)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const unsigned a = sb + boff[j] * 2 + tb * B_TERM;
+          if (ks == 0) {
+            bfrag[0][tb][j].h[0] = lds_tr16_asm<A_BYTES>(a);
+            bfrag[0][tb][j].h[1] = lds_tr16_asm<A_BYTES + 4 * BN * 2>(a);
+          } else {
+            bfrag[1][tb][j].h[0] = lds_tr16_asm<A_BYTES + 16 * BN * 2>(a);
+            bfrag[1][tb][j].h[1] = lds_tr16_asm<A_BYTES + 20 * BN * 2>(a);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const unsigned a = sb + abyte[ks][i];
+        afrag[ks][0][i] = lds_b128_asm<0>(a);
+        afrag[ks][1][i] = lds_b128_asm<BM * 64>(a);
+        afrag[ks][2][i] = lds_b128_asm<2 * BM * 64>(a);
+      }
+    }
+    lds_wait<RPS>();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1) lds_wait<0>();
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int tb = 0; tb < BT; ++tb)
+            if (ta + tb < 3)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                mfma_bf16(acc[i][j], afrag[ks][ta][i], bfrag[ks][tb][j].v);
+    }
+  };
+
+  fetch_b(0);
+  issue_a(0, 0);
+  stage_b(0, 0);                                                   // the compiler waits for the loads of fetch_b(0) here
+  if (Kb > 1) fetch_b(1);
+  for (int t = 0; t < Kb; ++t) {
+    const int st = t & 1;
+    // the copies of tile t are older than the loads of tile t+1 (NQ of them): a counted wait leaves those in flight
+    if (t + 1 < Kb)
+      wait_vm_and_barrier<NQ>();
+    else
+      wait_vm_and_barrier<0>();
+    if (t + 1 < Kb) {
+      stage_b(t + 1, st ^ 1);                                      // tile t+1 from registers (loaded one step ago)
+      issue_a(t + 1, st ^ 1);
+      if (t + 2 < Kb) fetch_b(t + 2);
+    }
+    compute(st);
+  }
+
+  mfma_fence(acc);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + (wn * NJ + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[row];
+          Yb[(int64_t)row * N + col] = v;
+        }
+      }
+    }
+}
+
 int pick_cfg_nn(int M, int N, int batch, int force) {
   if (force > 0) return force;
   // measured (tools/probe_pgemm.py): 64 x 128 tiles on four wavefronts of 32 x 64 with two LDS stages (three workgroups per
@@ -857,6 +1084,54 @@ extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_spli
   }
 #undef S2F_PGS
   return s2f_check_launch("s2f_pgemm_dx_split");
+}
+
+static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, bool x_fp32, const float* bias, float* Y, int batch,
+                       int M, int C, int H, int W, int cfg, void* stream) {
+  S2F_REQUIRE(w_pack && X && Y, S2F_EINVAL, "%s: null pointer", who);
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & 3) == 0, S2F_EINVAL,
+              "%s: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", who, C, W);
+  S2F_REQUIRE((int64_t)C * 9 < (1 << 30) && (int64_t)H * W < (1 << 30), S2F_EINVAL, "%s: too large", who);
+  S2F_REQUIRE(s2f_aligned16(w_pack) && s2f_aligned16(Y) && (reinterpret_cast<uintptr_t>(X) & (x_fp32 ? 15u : 7u)) == 0, S2F_EALIGN,
+              "%s: pack / output 16-byte, activation 8-byte (bf16) or 16-byte (fp32) aligned", who);
+  hipStream_t s = (hipStream_t)stream;
+  const int N = H * W, K = 9 * C, Kb = K / PK;
+  const int n_tiles = (N + 127) / 128;
+  static const char* force = getenv("S2F_PG_CONV_CFG");
+  int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
+  // measured (tools/probe_pgemm.py conv, profiles/r03_probe_pgemm_conv.txt): rows <= 32 / <= 64 -> the 32- / 64-row tiles; otherwise
+  // 128 x 128 on eight wavefronts (two per SIMD: the staging of one runs under the MFMAs of the other)
+  if (c <= 0) c = M <= 32 ? 3 : M <= 64 ? 2 : 4;
+  const Conv3 geo{H, W, C};
+#define S2F_PGC(MI, NJ, WMW, WNW)                                                                                         \
+  do {                                                                                                                   \
+    const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                       \
+    if (x_fp32)                                                                                                          \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 3>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
+                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo);                                                 \
+    else                                                                                                                 \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
+                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo);                                                 \
+  } while (0)
+  switch (c) {
+    case 1: S2F_PGC(2, 2, 2, 2); break;          // 128 x 128, wavefront tiles 64 x 64
+    case 2: S2F_PGC(1, 2, 2, 2); break;          // 64 x 128, wavefront tiles 32 x 64
+    case 3: S2F_PGC(1, 1, 1, 4); break;          // 32 x 128, wavefront tiles 32 x 32 (the 32-channel gradients of the 256 x 256 maps)
+    case 4: S2F_PGC(1, 2, 4, 2); break;          // 128 x 128 on EIGHT wavefronts of 32 x 64: two per SIMD, staging under the MFMAs
+    default: S2F_REQUIRE(false, S2F_EINVAL, "%s: unknown cfg %d", who, c);
+  }
+#undef S2F_PGC
+  return s2f_check_launch(who);
+}
+
+extern "C" int s2f_pgemm_conv3x3_bf16(const uint16_t* w_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M, int C,
+                                      int H, int W, int cfg, void* stream) {
+  return conv_launch("s2f_pgemm_conv3x3_bf16", w_pack, X, false, bias, Y, batch, M, C, H, W, cfg, stream);
+}
+
+extern "C" int s2f_pgemm_conv3x3_f32(const uint16_t* w_pack, const float* X, float* Y, int batch, int M, int C, int H, int W,
+                                     int cfg, void* stream) {
+  return conv_launch("s2f_pgemm_conv3x3_f32", w_pack, X, true, nullptr, Y, batch, M, C, H, W, cfg, stream);
 }
 
 extern "C" int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream) {

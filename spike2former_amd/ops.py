@@ -1202,6 +1202,7 @@ SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a sp
 PGEMM = _os.environ.get("S2F_PGEMM", "1") != "0"
 PGEMM_DX = _os.environ.get("S2F_PGEMM_DX", "1") != "0"
 PGEMM_MIN_N = 128
+PGEMM_CONV = _os.environ.get("S2F_PGEMM_CONV", "1") != "0"          # implicit 3x3 convolutions on the pipelined kernels (pgemm.hip)
 
 
 def _owner(t):
@@ -1346,6 +1347,25 @@ def pack_weight(w2d, transposed=False):
     job = (src.data_ptr(), mode, 0, M, K) if src.is_contiguous() else None
     check(lib.s2f_pack_bf16x3(_ptr(src.contiguous()), _ptr(out), M, K, mode, 0, _stream()), "s2f_pack_bf16x3")
     _cache_put(key, version, out, (M, K), owner, job, kind="pack")
+    return out
+
+
+def pack_weight_conv3(weight, transposed=False):
+    """[M, C, 3, 3] -> the cached PACK (see pack_weight) of the TAP-MAJOR matrix [M, (ky, kx, c)] the implicit 3x3 kernels contract
+    over (s2f_pgemm_conv3x3_bf16), or -- `transposed` -- of the transposed-convolution matrix [C, (ky, kx, m)] with flipped taps,
+    Wt[c][(ky, kx), m] = weight[m][c][2 - ky][2 - kx]: the A operand of the input gradient (s2f_pgemm_conv3x3_f32)."""
+    key = ("pack3", bool(transposed), weight.data_ptr())
+    Mw, C = weight.shape[:2]
+    M, K, mode, cdim = (C, 9 * Mw, 2, Mw) if transposed else (Mw, 9 * C, 1, C)
+    owner = _owner(weight)
+    hit = _cache_get(key, weight._version, (Mw, C), owner)
+    if hit is not None:
+        return hit
+    out = _cache_buffer(key, (Mw, C), owner, (int(lib.s2f_pack_elems(M, K)),), weight.device)
+    src = weight.detach()
+    job = (src.data_ptr(), mode, cdim, M, K) if src.is_contiguous() else None
+    check(lib.s2f_pack_bf16x3(_ptr(src.contiguous()), _ptr(out), M, K, mode, cdim, _stream()), "s2f_pack_bf16x3")
+    _cache_put(key, weight._version, out, (Mw, C), owner, job, kind="pack")
     return out
 
 
@@ -1903,13 +1923,17 @@ class _ConvDense(torch.autograd.Function):
             x = x.contiguous()
             if SPIKE_GEMM_CHECK:
                 assert _is_spike_grid(x), "not a spike tensor"
-            ws = split_weight_conv3(weight)
             y = torch.empty(N, M, H * W, dtype=torch.float32, device=x.device)
             _time_next("spike_gemm_fwd", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9,
                        moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
-            fn = lib.s2f_spike_conv3x3_fwd_bf16 if xb else lib.s2f_spike_conv3x3_fwd
-            check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS,
-                     _stream()), "s2f_spike_conv3x3_fwd")
+            if PGEMM_CONV and xb and SPIKE_GEMM_TERMS == 3:
+                check(lib.s2f_pgemm_conv3x3_bf16(_ptr(pack_weight_conv3(weight)), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, 0,
+                                                 _stream()), "s2f_pgemm_conv3x3_bf16")
+            else:
+                ws = split_weight_conv3(weight)
+                fn = lib.s2f_spike_conv3x3_fwd_bf16 if xb else lib.s2f_spike_conv3x3_fwd
+                check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, ws.shape[1], ws.shape[2], SPIKE_GEMM_TERMS,
+                         _stream()), "s2f_spike_conv3x3_fwd")
             ctx.save_for_backward(x, weight)
             ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, True)
             ctx.implicit = True
@@ -1959,10 +1983,18 @@ class _ConvDense(torch.autograd.Function):
             if (CONV3X3_DX_IMPLICIT and kh == 3 and kw == 3 and stride == 1 and padding == 1 and M % 32 == 0 and W % 4 == 0
                     and gy.is_cuda and H * W >= CONV3X3_DX_MIN_PIXELS):
                 # transposed convolution dX = flip(W)^T (*) dY as an implicit 6-pass split GEMM: no unfold(dY), no col2im
-                wt = split_weight_tconv3(weight)
                 gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
-                check(lib.s2f_conv3x3_general(_ptr(wt), _ptr(gy), _ptr(gx), N, C, M, H, W, wt.shape[1], wt.shape[2], _stream()),
-                      "s2f_conv3x3_general")
+                _time_next("dx_gemm", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9)
+                # measured (tools/probe_pgemm.py conv): the pipelined kernel wins for <= 64 output rows (narrow tiles: 442 vs 729 us
+                # on [32 <- 128] at 256 x 256) and for long contractions (>= 256 channels); the round-2 kernel keeps a 5-10 % edge
+                # on wide outputs over short contractions
+                if PGEMM_CONV and (C <= 64 or M >= 256):
+                    check(lib.s2f_pgemm_conv3x3_f32(_ptr(pack_weight_conv3(weight, transposed=True)), _ptr(gy), _ptr(gx), N, C, M, H,
+                                                    W, 0, _stream()), "s2f_pgemm_conv3x3_f32")
+                else:
+                    wt = split_weight_tconv3(weight)
+                    check(lib.s2f_conv3x3_general(_ptr(wt), _ptr(gy), _ptr(gx), N, C, M, H, W, wt.shape[1], wt.shape[2], _stream()),
+                          "s2f_conv3x3_general")
             elif M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
                 wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
                 gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)

@@ -1089,3 +1089,48 @@ def test_weight_gradient_from_presplit_planes(ops, B, M, K, L):
     for got in (a, b_, c):
         assert (got.double() - ref).abs().max().item() <= 4e-6 * scale
     assert (a - b_).abs().max().item() <= 2e-6 * scale and (a - c).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,C,H,W", [(2, 64, 32, 32, 32), (1, 100, 64, 16, 64), (2, 32, 128, 64, 64), (1, 360, 256, 32, 32),
+                                       (2, 128, 32, 20, 36), (1, 40, 96, 8, 8)])
+def test_pgemm_conv3x3_is_the_round2_implicit_convolution(ops, N, M, C, H, W):
+    """s2f_pgemm_conv3x3_bf16 / _f32 (LDS-DMA weight panels, register-staged shifted activation rows, transpose reads) against
+    the round-2 implicit kernels -- same products in the same order: bit-identical -- and against F.conv2d in fp64, every tile
+    configuration; the input-gradient form convolves dY with the flipped transposed weight (pack mode 2)."""
+    import torch.nn.functional as F
+
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(N * 7 + M + C + H + W)
+    w = (torch.randn(M, C, 3, 3, generator=g) * (9 * C) ** -0.5).cuda()
+    xs = (torch.randint(0, 9, (N, C, H, W), generator=g).float() / 8).cuda()
+    xb = xs.bfloat16()
+    bias = torch.randn(M, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    # forward
+    ref = F.conv2d(xs.double(), w.double(), bias.double(), padding=1)
+    ws = ops.split_weight_conv3(w)
+    y0 = torch.empty(N, M, H, W, device="cuda")
+    check(lib.s2f_spike_conv3x3_fwd_bf16(ws.data_ptr(), xb.data_ptr(), bias.data_ptr(), y0.data_ptr(), N, M, C, H, W, ws.shape[1],
+                                         ws.shape[2], 3, st), "old")
+    for cfg in (1, 2, 3, 4):
+        y1 = torch.full((N, M, H, W), float("nan"), device="cuda")
+        check(lib.s2f_pgemm_conv3x3_bf16(ops.pack_weight_conv3(w).data_ptr(), xb.data_ptr(), bias.data_ptr(), y1.data_ptr(), N, M, C, H,
+                                         W, cfg, st), "new")
+        # same products; the round-2 kernel splits the contraction over wavefront groups when the grid is small, otherwise the
+        # sums are ordered alike and the results bit-identical (tools/probe_pgemm.py conv prints '=')
+        assert (y1 - y0).abs().max().item() <= 1e-6 * max(ref.abs().max().item(), 1.0), cfg
+        assert (y1.double() - ref).abs().max().item() <= 2e-6 * max(ref.abs().max().item(), 1.0)
+    # input gradient of the convolution [M <- C]: dX[C] = conv(dY[M], flip(W)^T); needs M % 32 == 0 as the contraction channels
+    if M % 32 == 0:
+        gy = torch.randn(N, M, H, W, generator=g).cuda()
+        refx = F.conv_transpose2d(gy.double(), w.double(), padding=1)
+        wt = ops.split_weight_tconv3(w)
+        g0 = torch.empty(N, C, H, W, device="cuda")
+        check(lib.s2f_conv3x3_general(wt.data_ptr(), gy.data_ptr(), g0.data_ptr(), N, C, M, H, W, wt.shape[1], wt.shape[2], st), "oldx")
+        for cfg in (1, 2, 3, 4):
+            g1 = torch.full((N, C, H, W), float("nan"), device="cuda")
+            check(lib.s2f_pgemm_conv3x3_f32(ops.pack_weight_conv3(w, transposed=True).data_ptr(), gy.data_ptr(), g1.data_ptr(), N, C, M,
+                                            H, W, cfg, st), "newx")
+            assert (g1 - g0).abs().max().item() <= 1e-6 * max(refx.abs().max().item(), 1.0), cfg
+            assert (g1.double() - refx).abs().max().item() <= 4e-6 * max(refx.abs().max().item(), 1.0)

@@ -129,3 +129,42 @@ if what in ("dx", "all"):
                 row += f" | s{cfg} {t1:7.1f} {err:.1e}{' NAN' if bad else ''}"
                 best = min(best, t1)
         print(row + f"   best {fl / best / 1e6:6.0f} TF/s vs lib {fl / tl / 1e6:6.0f}", flush=True)
+
+CONV = [(8, 128, 512, 64, 64), (8, 512, 128, 64, 64), (8, 32, 128, 256, 256), (8, 128, 32, 256, 256), (8, 64, 256, 128, 128),
+        (8, 256, 64, 128, 128), (8, 360, 256, 32, 32)]
+if what in ("conv", "all"):
+    print("# implicit 3x3 convolution (us): forward on bf16 spikes: round-2 kernel | pgemm cfg 1..3 ('=' bit-identical);"
+          "  6-pass form on fp32 (the input gradient): round-2 kernel | pgemm cfg 1..3")
+    for B, M, C, H, W in CONV:
+        w = torch.randn(M, C, 3, 3, device="cuda") * (9 * C) ** -0.5
+        x, xb = spikes(B, C, H * W)
+        xf = torch.randn(B, C, H, W, device="cuda")
+        ws = ops.split_weight_conv3(w)
+        wp = ops.pack_weight_conv3(w)
+        y0 = torch.empty(B, M, H, W, device="cuda")
+        t0 = timed(lambda: check(lib.s2f_spike_conv3x3_fwd_bf16(ws.data_ptr(), xb.data_ptr(), 0, y0.data_ptr(), B, M, C, H, W, ws.shape[1],
+                                                                ws.shape[2], 3, S), "old"))
+        fl = 2 * B * M * H * W * C * 9
+        row = f"B{B} M{M:4d} C{C:4d} {H:3d}x{W:3d}  fwd old {t0:7.1f}"
+        best = 1e9
+        for cfg in (1, 2, 3, 4):
+            y1 = torch.full((B, M, H, W), float("nan"), device="cuda")
+            t1 = timed(lambda: check(lib.s2f_pgemm_conv3x3_bf16(wp.data_ptr(), xb.data_ptr(), 0, y1.data_ptr(), B, M, C, H, W, cfg, S), "new"))
+            row += f" | c{cfg} {t1:7.1f} {'=' if torch.equal(y0, y1) else 'DIFF'}"
+            best = min(best, t1)
+        row += f"  [{fl / best / 1e6:4.0f} vs {fl / t0 / 1e6:4.0f} TF/s]"
+        # the 6-pass form: same shapes with an fp32 activation (as the input gradient of the convolution C <- M would see them)
+        wt = torch.randn(C, M, 3, 3, device="cuda") * (9 * M) ** -0.5           # a convolution M -> C whose input gradient has M rows
+        wts = ops.split_weight_tconv3(wt)
+        wtp = ops.pack_weight_conv3(wt, transposed=True)
+        g0 = torch.empty(B, M, H, W, device="cuda")
+        t0 = timed(lambda: check(lib.s2f_conv3x3_general(wts.data_ptr(), xf.data_ptr(), g0.data_ptr(), B, M, C, H, W, wts.shape[1],
+                                                         wts.shape[2], S), "oldx"))
+        row += f"   6-pass old {t0:7.1f}"
+        best = 1e9
+        for cfg in (1, 2, 3, 4):
+            g1 = torch.full((B, M, H, W), float("nan"), device="cuda")
+            t1 = timed(lambda: check(lib.s2f_pgemm_conv3x3_f32(wtp.data_ptr(), xf.data_ptr(), g1.data_ptr(), B, M, C, H, W, cfg, S), "newx"))
+            row += f" | c{cfg} {t1:7.1f} {'=' if torch.equal(g0, g1) else 'DIFF'}"
+            best = min(best, t1)
+        print(row + f"  [{fl / best / 1e6:4.0f} vs {fl / t0 / 1e6:4.0f} TF/s]", flush=True)
