@@ -785,7 +785,9 @@ __device__ __forceinline__ f32x4 convp_fix(f32x4 v, ConvPredB p) {
   return v;
 }
 
-template <int MI, int NJ, int WMW, int WNW, int BT>
+// CONV = false: the plain product  Y[b] = A @ X[b]  (X [K][N] bf16, N % 4 == 0) with the same register-staged activation rows --
+// the row lengths an LDS-DMA cannot take (N % 8 != 0: the decoder's 100-token maps, whose rows start 8-byte aligned only).
+template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned short* __restrict__ Ap, const void* __restrict__ Xv,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                                 int N, int K, int Kb, int n_tiles, int m_tiles, Conv3 geo) {
@@ -804,9 +806,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   const int mt = pid % m_tiles, nt = pid / m_tiles;
   const int b = blockIdx.y;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int64_t plane_elems = (int64_t)geo.H * geo.W;
-  const unsigned short* Xh = reinterpret_cast<const unsigned short*>(Xv) + (int64_t)b * geo.C * plane_elems;
-  const float* Xf = reinterpret_cast<const float*>(Xv) + (int64_t)b * geo.C * plane_elems;
+  const int64_t plane_elems = CONV ? (int64_t)geo.H * geo.W : (int64_t)N;
+  const unsigned short* Xh = reinterpret_cast<const unsigned short*>(Xv) + (int64_t)b * (CONV ? geo.C : K) * plane_elems;
+  const float* Xf = reinterpret_cast<const float*>(Xv) + (int64_t)b * (CONV ? geo.C : K) * plane_elems;
   float* Yb = Y + (int64_t)b * M * N;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -828,17 +830,18 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   const int c4 = tid % (BN / 4);
   const int n_px = n0 + c4 * 4;
   const bool n_ok = n_px < N;
-  const int py = n_px / geo.W, px = n_px - py * geo.W;
+  const int py = CONV ? n_px / geo.W : 0, px = CONV ? n_px - py * geo.W : 0;
   chunk_t breg[NQ];
   auto fetch_b = [&](int kb) __attribute__((always_inline)) {
     const int kk = kb * 32;
-    const int tap = kk / geo.C, ky = tap / 3, kx = tap - 3 * ky, c0 = kk - tap * geo.C;
-    const ConvPredB pr = convp(py, px, ky, kx, geo, n_ok && kk < K);
-    const int off = convp_off(n_px, ky, kx, geo, pr);
+    const int tap = CONV ? kk / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky, c0 = CONV ? kk - tap * geo.C : kk;
+    const ConvPredB pr = CONV ? convp(py, px, ky, kx, geo, n_ok && kk < K) : ConvPredB{n_ok, false, false};
+    const int off = CONV ? convp_off(n_px, ky, kx, geo, pr) : (n_ok ? n_px : 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int kr = (tid + q * T) / (BN / 4);
-      const int64_t row = (int64_t)(pr.ok ? c0 + kr : 0) * plane_elems + off;
+      // plain product: rows past K read row K - 1 (finite data) against zero weight columns of the pack
+      const int64_t row = (int64_t)(CONV ? (pr.ok ? c0 + kr : 0) : min(c0 + kr, K - 1)) * plane_elems + off;
       if constexpr (BT == 1)
         breg[q] = *reinterpret_cast<const u32x2*>(Xh + row);
       else
@@ -847,8 +850,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   };
   auto stage_b = [&](int kb, int st) __attribute__((always_inline)) {
     const int kk = kb * 32;
-    const int tap = kk / geo.C, ky = tap / 3, kx = tap - 3 * ky;
-    const ConvPredB pr = convp(py, px, ky, kx, geo, n_ok && kk < K);
+    const int tap = CONV ? kk / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky;
+    const ConvPredB pr = CONV ? convp(py, px, ky, kx, geo, n_ok && kk < K) : ConvPredB{n_ok, false, false};
     unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + st * STAGE + A_BYTES);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -975,11 +978,16 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
     }
 }
 
-int pick_cfg_nn(int M, int N, int batch, int force) {
+int pick_cfg_nn(int M, int N, int K, int batch, int force) {
   if (force > 0) return force;
-  // measured (tools/probe_pgemm.py): 64 x 128 tiles on four wavefronts of 32 x 64 with two LDS stages (three workgroups per
-  // CU) win or tie on every shape of the path; 256-row tiles tie on the M >= 512 products of the large maps
-  return 4;
+  // measured (tools/probe_pgemm.py fwd, profiles/r03_probe_pgemm.txt):
+  //   long contractions (K >= 1024): the all-DMA 64 x 128 tile on four wavefronts, two LDS stages (cfg 4);
+  //   otherwise the activation rows through registers (pg_conv_kernel<.., CONV = false>) -- 128 x 128 on eight wavefronts when
+  //   that still gives every CU a workgroup (cfg 7), else 64 x 128 on four (cfg 6): 8.7 vs 10.2 us on [256x256]@[8x256x1024],
+  //   12.0 vs 14.0 on [512x256], 18.9 vs 20.4 on [256x256]@[8x256x4096].  Rows of N % 8 != 0 elements only take cfg 6 / 7.
+  const int64_t tiles128 = (int64_t)((N + 127) / 128) * batch * ((M + 127) / 128);
+  if (K >= 1024 && (N & 7) == 0) return 4;
+  return (M > 64 && tiles128 >= 256) ? 7 : 6;
 }
 
 }  // namespace
@@ -1000,14 +1008,30 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
   S2F_REQUIRE(a_pack && X && Y, S2F_EINVAL, "s2f_pgemm_nn_bf16: null pointer");
   S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL,
               "s2f_pgemm_nn_bf16: bad sizes");
-  S2F_REQUIRE((N & 7) == 0, S2F_EINVAL, "s2f_pgemm_nn_bf16: N=%d must be a multiple of 8", N);
+  S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "s2f_pgemm_nn_bf16: N=%d must be a multiple of 4", N);
   S2F_REQUIRE(s2f_aligned16(a_pack) && s2f_aligned16(X) && s2f_aligned16(Y), S2F_EALIGN,
               "s2f_pgemm_nn_bf16: pointers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int Kb = (K + PK - 1) / PK;
   const int n_tiles = (N + 127) / 128;
   static const char* force = getenv("S2F_PG_CFG");
-  const int c = pick_cfg_nn(M, N, batch, cfg > 0 ? cfg : (force ? atoi(force) : 0));
+  const int c = terms == 3 ? pick_cfg_nn(M, N, K, batch, cfg > 0 ? cfg : (force ? atoi(force) : 0)) : (cfg > 0 ? cfg : 4);
+  S2F_REQUIRE((N & 7) == 0 || cfg == 0 || cfg == 6 || cfg == 7, S2F_EINVAL, "s2f_pgemm_nn_bf16: cfg %d needs N %% 8 == 0 (N=%d)", cfg, N);
+  if (c == 6 || c == 7 || (N & 7) != 0) {
+    // the activation rows through registers (pg_conv_kernel<.., CONV = false>): any N % 4 == 0
+    S2F_REQUIRE(terms == 3, S2F_EINVAL, "s2f_pgemm_nn_bf16: the register-staged form takes all three weight terms");
+    const bool wide = c == 7;          // (an environment-forced DMA configuration does not apply to rows of N % 8 != 0)
+    if (wide) {
+      const int m_tiles = (M + 127) / 128;
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
+                 M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
+    } else {
+      const int m_tiles = (M + 63) / 64;
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X, bias, Y,
+                 M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
+    }
+    return s2f_check_launch("s2f_pgemm_nn_bf16");
+  }
   const int64_t xbs = (int64_t)K * N;
 #define S2F_PG(MI, NJ, WMW, WNW, ATV, NSTV)                                                                            \
   do {                                                                                                                 \
@@ -1068,7 +1092,10 @@ extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_spli
   const int n_tiles = (N + 127) / 128;
   static const char* force = getenv("S2F_PG_DXS_CFG");
   int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
-  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
+  // measured (tools/probe_pgemm.py dx): 128 x 128 on eight wavefronts (two per SIMD: one stages while the other multiplies) once
+  // that gives >= 192 workgroups, else 64 x 128 on four -- 17.6 vs 19.9 us on [512 <- 256] x 1024, 65.7 vs 77.5 on [360 <- 1440],
+  // 100 vs 114 on [256 <- 256] x 16384; the four-wavefront 128 x 128 tile (cfg 1) is 3-10 % behind cfg 3 everywhere
+  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : 2;
 #define S2F_PGS(MI, NJ, WMW, WNW, NSTV)                                                                                 \
   do {                                                                                                                 \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
@@ -1163,7 +1190,8 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   {
     const int64_t wgs = (int64_t)n_tiles * batch * ((Ki + 63) / 64);
     const int steps = (Mo + 15) / 16;
-    while (beta == 0.f && wgs * zsplit < 128 && steps / (zsplit * 2) >= 8) zsplit *= 2;
+    // (a split costs a zero-fill launch and atomics: only contractions of >= 512 rows take it)
+    while (beta == 0.f && wgs * zsplit < 128 && steps / (zsplit * 2) >= 16) zsplit *= 2;
   }
   if (zsplit > 1) {
     S2F_REQUIRE(dx_batch_stride == (int64_t)Ki * N, S2F_EINVAL, "s2f_pgemm_dx_f32: the split form needs a dense DX");
@@ -1187,6 +1215,7 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   switch (c) {
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
     case 2: S2F_PGD(1, 2, 2, 2); break;          // 64 x 128
+    case 3: S2F_PGD(1, 2, 4, 2); break;          // 128 x 128 on eight wavefronts (two per SIMD)
     default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_f32: unknown cfg %d", c);
   }
 #undef S2F_PGD

@@ -1422,7 +1422,7 @@ class _SpikeGemm(torch.autograd.Function):
         y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
         xb = x.dtype == torch.bfloat16
         _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * ((2 if xb else 4) * K + 4 * M))
-        if PGEMM and xb and N % 8 == 0 and N >= PGEMM_MIN_N:
+        if PGEMM and xb and N % 4 == 0 and SPIKE_GEMM_TERMS == 3:
             check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, SPIKE_GEMM_TERMS, 0,
                                         _stream()), "s2f_pgemm_nn_bf16")
         else:
@@ -1946,7 +1946,7 @@ class _ConvDense(torch.autograd.Function):
             y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
             _time_next("spike_gemm_fwd", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1],
                        moved=N * L * ((2 if xb else 4) * cols.shape[1] + 4 * M))
-            if PGEMM and xb and L % 8 == 0 and L >= PGEMM_MIN_N:
+            if PGEMM and xb and L % 4 == 0 and SPIKE_GEMM_TERMS == 3:
                 check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1],
                                             SPIKE_GEMM_TERMS, 0, _stream()), "s2f_pgemm_nn_bf16")
             else:

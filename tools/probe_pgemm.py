@@ -63,7 +63,7 @@ def spikes(B, K, N):
     return x, xb
 
 
-FWD = [(8, 256, 256, 1024), (8, 512, 256, 1024), (8, 256, 512, 1024), (8, 1024, 256, 1024), (8, 256, 1024, 1024),
+FWD = [(8, 256, 256, 100), (8, 256, 2048, 100), (8, 2048, 256, 100), (8, 256, 256, 1024), (8, 512, 256, 1024), (8, 256, 512, 1024), (8, 1024, 256, 1024), (8, 256, 1024, 1024),
        (8, 768, 256, 1024), (8, 360, 360, 1024), (8, 1440, 360, 1024), (8, 360, 1440, 1024), (8, 256, 256, 4096),
        (8, 256, 256, 16384), (8, 256, 32, 65536), (8, 64, 32, 65536), (8, 128, 576, 4096), (8, 512, 1152, 4096),
        (2, 700, 1024, 65536)]
@@ -84,8 +84,8 @@ if what in ("fwd", "all"):
         ref = torch.matmul(w.double(), x[:1].double())
         row = f"B{B} M{M:5d} K{K:5d} N{N:6d}  old {t0:7.1f}"
         fl = 2 * B * M * N * K
-        for cfg in (1, 2, 3, 4, 5):
-            if cfg == 5 and M < 256:
+        for cfg in (1, 2, 3, 4, 5, 6, 7):
+            if (cfg == 5 and M < 256) or (cfg < 6 and N % 8):
                 continue
             y1 = torch.full((B, M, N), float("nan"), device="cuda")
             t1 = timed(lambda: check(lib.s2f_pgemm_nn_bf16(wp.data_ptr(), xb.data_ptr(), 0, y1.data_ptr(), B, M, N, K, 3, cfg, S), "new"))
@@ -108,7 +108,7 @@ if what in ("dx", "all"):
         row = f"B{B} Mo{Mo:5d} Ki{Ki:5d} N{N:6d}  lib {tl:7.1f} ({lib_err:.1e})"
         fl = 2 * B * Mo * N * Ki
         best = 1e9
-        for cfg in (1, 2):
+        for cfg in (1, 2, 3):
             if N % 4:
                 continue
             dx = torch.full((B, Ki, N), float("nan"), device="cuda")
