@@ -987,7 +987,8 @@ int pick_cfg_nn(int M, int N, int K, int batch, int force) {
   //   12.0 vs 14.0 on [512x256], 18.9 vs 20.4 on [256x256]@[8x256x4096].  Rows of N % 8 != 0 elements only take cfg 6 / 7.
   const int64_t tiles128 = (int64_t)((N + 127) / 128) * batch * ((M + 127) / 128);
   if (K >= 1024 && (N & 7) == 0) return 4;
-  return (M > 64 && tiles128 >= 256) ? 7 : 6;
+  // (cfg 8 = the 64 x 128 tile on eight wavefronts of 32 x 32: 8.1 vs 8.6 us, 11.8 vs 12.6, 19.9 vs 20.5 on the 1 024-column shapes)
+  return (M > 64 && tiles128 >= 256) ? 7 : (N >= 128 ? 8 : 6);
 }
 
 }  // namespace
@@ -1016,12 +1017,16 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
   const int n_tiles = (N + 127) / 128;
   static const char* force = getenv("S2F_PG_CFG");
   const int c = terms == 3 ? pick_cfg_nn(M, N, K, batch, cfg > 0 ? cfg : (force ? atoi(force) : 0)) : (cfg > 0 ? cfg : 4);
-  S2F_REQUIRE((N & 7) == 0 || cfg == 0 || cfg == 6 || cfg == 7, S2F_EINVAL, "s2f_pgemm_nn_bf16: cfg %d needs N %% 8 == 0 (N=%d)", cfg, N);
-  if (c == 6 || c == 7 || (N & 7) != 0) {
+  S2F_REQUIRE((N & 7) == 0 || cfg == 0 || cfg >= 6, S2F_EINVAL, "s2f_pgemm_nn_bf16: cfg %d needs N %% 8 == 0 (N=%d)", cfg, N);
+  if (c == 6 || c == 7 || c == 8 || (N & 7) != 0) {
     // the activation rows through registers (pg_conv_kernel<.., CONV = false>): any N % 4 == 0
     S2F_REQUIRE(terms == 3, S2F_EINVAL, "s2f_pgemm_nn_bf16: the register-staged form takes all three weight terms");
     const bool wide = c == 7;          // (an environment-forced DMA configuration does not apply to rows of N % 8 != 0)
-    if (wide) {
+    if (c == 8) {
+      const int m_tiles = (M + 63) / 64;
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
+                 M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
+    } else if (wide) {
       const int m_tiles = (M + 127) / 128;
       S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
                  M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
@@ -1095,7 +1100,10 @@ extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_spli
   // measured (tools/probe_pgemm.py dx): 128 x 128 on eight wavefronts (two per SIMD: one stages while the other multiplies) once
   // that gives >= 192 workgroups, else 64 x 128 on four -- 17.6 vs 19.9 us on [512 <- 256] x 1024, 65.7 vs 77.5 on [360 <- 1440],
   // 100 vs 114 on [256 <- 256] x 16384; the four-wavefront 128 x 128 tile (cfg 1) is 3-10 % behind cfg 3 everywhere
-  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : 2;
+  // and the 64 x 128 tile runs on EIGHT wavefronts of 32 x 32 (cfg 4: 13.4 vs 15.7 us on [256 <- 256] x 1024, 22.5 vs 26.0 on
+  // [256 <- 512], 38.9 vs 43.0 on [256 <- 1024]: with one workgroup per CU the four-wavefront form leaves one wavefront per SIMD,
+  // whose staging, LDS reads and MFMAs only ever run one after the other); <= 32 output rows: 32 x 128 tiles (cfg 5)
+  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : 4;
 #define S2F_PGS(MI, NJ, WMW, WNW, NSTV)                                                                                 \
   do {                                                                                                                 \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
@@ -1196,7 +1204,7 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   if (zsplit > 1) {
     S2F_REQUIRE(dx_batch_stride == (int64_t)Ki * N, S2F_EINVAL, "s2f_pgemm_dx_f32: the split form needs a dense DX");
     if (s2f_zero_async(DX, sizeof(float) * (size_t)batch * Ki * N, s) != S2F_OK) return s2f_check_launch("s2f_pgemm_dx_f32 zero");
-    c = 2;
+    c = 4;
   }
 #define S2F_PGD(MI, NJ, WMW, WNW)                                                                                       \
   do {                                                                                                                 \
@@ -1216,6 +1224,8 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
     case 2: S2F_PGD(1, 2, 2, 2); break;          // 64 x 128
     case 3: S2F_PGD(1, 2, 4, 2); break;          // 128 x 128 on eight wavefronts (two per SIMD)
+    case 4: S2F_PGD(1, 1, 2, 4); break;          // 64 x 128 on eight wavefronts of 32 x 32
+    case 5: S2F_PGD(1, 1, 1, 4); break;          // 32 x 128 on four wavefronts of 32 x 32: twice the workgroups of cfg 2
     default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_f32: unknown cfg %d", c);
   }
 #undef S2F_PGD

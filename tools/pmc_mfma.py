@@ -11,8 +11,9 @@ import collections
 import sqlite3
 import sys
 
-FAMILIES = [("spike GEMM forward, LDS-DMA pipeline (pg_nn_kernel)", lambda n: "pg_nn_kernel" in n),
-            ("input gradient / dense GEMM, 6 passes (pg_tn_f32_kernel)", lambda n: "pg_tn_f32_kernel" in n),
+FAMILIES = [("spike GEMM forward incl. 3x3, pipelined (pg_nn_kernel, pg_conv_kernel<.., 1, ..>)", lambda n: "pg_nn_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "1")),
+            ("input gradient / dense GEMM, 6 passes (pg_tn_f32_kernel, pg_conv_kernel<.., 3, ..>)",
+             lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "3")),
             ("spike GEMM forward, round-2 kernel: 3x3 convolutions, N < 128 (sgemm_bf16_kernel)", lambda n: "sgemm_bf16_kernel" in n),
             ("spike GEMM weight gradient (sgemm_dw_bf16 / grouped)", lambda n: "sgemm_dw" in n),
             ("general weight gradient, 6 passes (spike_gemm_dw_kernel / gemm_dw_general_grouped)",

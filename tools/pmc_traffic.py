@@ -12,9 +12,10 @@ FAMILIES = {          # bench.py roofline key -> predicate on the kernel name
     "bn_stats": lambda n: "bn_stats_kernel" in n,
     "lif_fwd": lambda n: "lif_fwd_kernel" in n and "sdsa" not in n,
     "lif_bwd": lambda n: "lif_bwd_kernel" in n,
-    "spike_gemm_fwd": lambda n: "spike_gemm_kernel" in n or "sgemm_bf16_kernel" in n or "pg_nn_kernel" in n,
-    "spike_gemm_fwd_pgemm": lambda n: "pg_nn_kernel" in n,
-    "dx_gemm": lambda n: "pg_tn_f32_kernel" in n,
+    "spike_gemm_fwd": lambda n: ("spike_gemm_kernel" in n or "sgemm_bf16_kernel" in n or "pg_nn_kernel" in n
+                                 or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "1")),
+    "spike_gemm_fwd_pgemm": lambda n: "pg_nn_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "1"),
+    "dx_gemm": lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "3"),
     "spike_gemm_dw": lambda n: "spike_gemm_dw_kernel" in n or "sgemm_dw" in n or "gemm_dw_general_grouped" in n,
     "sdsa_lif_fwd": lambda n: "apply_kernel<" in n and ", true>" in n,
 }

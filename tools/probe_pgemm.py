@@ -84,7 +84,7 @@ if what in ("fwd", "all"):
         ref = torch.matmul(w.double(), x[:1].double())
         row = f"B{B} M{M:5d} K{K:5d} N{N:6d}  old {t0:7.1f}"
         fl = 2 * B * M * N * K
-        for cfg in (1, 2, 3, 4, 5, 6, 7):
+        for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
             if (cfg == 5 and M < 256) or (cfg < 6 and N % 8):
                 continue
             y1 = torch.full((B, M, N), float("nan"), device="cuda")
@@ -108,7 +108,7 @@ if what in ("dx", "all"):
         row = f"B{B} Mo{Mo:5d} Ki{Ki:5d} N{N:6d}  lib {tl:7.1f} ({lib_err:.1e})"
         fl = 2 * B * Mo * N * Ki
         best = 1e9
-        for cfg in (1, 2, 3):
+        for cfg in (1, 2, 3, 4, 5):
             if N % 4:
                 continue
             dx = torch.full((B, Ki, N), float("nan"), device="cuda")
