@@ -395,6 +395,12 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // from inline asm two steps ahead (hipcc drains vmcnt(0) for its own loads next to LDS-DMA) were WRONG under register
 // pressure: the compiler spilled the in-flight destination registers to AGPRs.  What removes the stores is an operand that
 // ARRIVES split: the producer of dY writing bf16 hi / mid / lo planes -- DESIGN.md section 8.)
+// (Also built and dropped, round 3: the eight-wavefront tile with the memory work split by wavefront -- four wavefronts load /
+// split / stage G, the other four issue the weight-panel copies three or four steps ahead, vmcnt being a per-wavefront counter, so
+// that hipcc's vmcnt(0) for the register loads no longer drains the copies: 13.7 vs 12.6 us on [256 <- 256] x 8 x 1024, 48.8 vs
+// 38.0 on [256 <- 1024] -- the loop was not waiting for the panels; halving the staging wavefronts cost more.  What a 16-row step
+// costs is the SUM of its phases -- staging arithmetic, LDS writes, barrier, LDS transpose reads, MFMAs: 1 300 cycles for 384 of
+// MFMA -- because the one barrier per step keeps all wavefronts of the workgroup in the same phase.)
 // EPI: 0 = store, 1 = DX = acc + beta * DX, 2 = atomic add into a zeroed DX (gridDim.z workgroups share the contraction: the
 // decoder's 100-token products with a 2 048-long contraction have 16 output tiles).
 template <int MI, int NJ, int WMW, int WNW, int EPI>
