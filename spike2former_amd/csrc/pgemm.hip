@@ -1103,13 +1103,7 @@ extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_spli
   const int n_tiles = (N + 127) / 128;
   static const char* force = getenv("S2F_PG_DXS_CFG");
   int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
-  // measured (tools/probe_pgemm.py dx): 128 x 128 on eight wavefronts (two per SIMD: one stages while the other multiplies) once
-  // that gives >= 192 workgroups, else 64 x 128 on four -- 17.6 vs 19.9 us on [512 <- 256] x 1024, 65.7 vs 77.5 on [360 <- 1440],
-  // 100 vs 114 on [256 <- 256] x 16384; the four-wavefront 128 x 128 tile (cfg 1) is 3-10 % behind cfg 3 everywhere
-  // and the 64 x 128 tile runs on EIGHT wavefronts of 32 x 32 (cfg 4: 13.4 vs 15.7 us on [256 <- 256] x 1024, 22.5 vs 26.0 on
-  // [256 <- 512], 38.9 vs 43.0 on [256 <- 1024]: with one workgroup per CU the four-wavefront form leaves one wavefront per SIMD,
-  // whose staging, LDS reads and MFMAs only ever run one after the other); <= 32 output rows: 32 x 128 tiles (cfg 5)
-  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : 4;
+  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
 #define S2F_PGS(MI, NJ, WMW, WNW, NSTV)                                                                                 \
   do {                                                                                                                 \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
@@ -1198,7 +1192,13 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   const int n_tiles = (N + 127) / 128;
   static const char* force = getenv("S2F_PG_DX_CFG");
   int c = cfg > 0 ? cfg : (force ? atoi(force) : 0);
-  if (c <= 0) c = (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 512) ? 1 : 2;
+  // measured (tools/probe_pgemm.py dx): 128 x 128 on eight wavefronts (two per SIMD: one stages while the other multiplies) once
+  // that gives >= 192 workgroups, else 64 x 128 on four -- 17.6 vs 19.9 us on [512 <- 256] x 1024, 65.7 vs 77.5 on [360 <- 1440],
+  // 100 vs 114 on [256 <- 256] x 16384; the four-wavefront 128 x 128 tile (cfg 1) is 3-10 % behind cfg 3 everywhere
+  // and the 64 x 128 tile runs on EIGHT wavefronts of 32 x 32 (cfg 4: 13.4 vs 15.7 us on [256 <- 256] x 1024, 22.5 vs 26.0 on
+  // [256 <- 512], 38.9 vs 43.0 on [256 <- 1024]: with one workgroup per CU the four-wavefront form leaves one wavefront per SIMD,
+  // whose staging, LDS reads and MFMAs only ever run one after the other); <= 32 output rows: 32 x 128 tiles (cfg 5)
+  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : 4;
   // few output tiles and a long contraction (the decoder's 100-token products): split the contraction over gridDim.z
   int zsplit = 1;
   {
