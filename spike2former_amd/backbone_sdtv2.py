@@ -3,7 +3,7 @@
 Mirrors the registry surface of the reference backbone -- class names, constructor kwargs and state_dict keys of
 mmseg/models/backbones/sdtv2.py:48-655 -- so reference configs and checkpoints load unchanged.  Every Q_IFNode, BatchNorm, depthwise
 stencil, spike GEMM and the softmax-free attention core run in libs2f_hip.so (csrc/*.hip); spike maps travel between them
-as bf16 (`ops.Spikes`); only the input gradients of the 1x1 convolutions are library GEMMs.
+as bf16 (`ops.Spikes`); the input gradients of the 1x1 and 3x3 convolutions are this package's 6-pass kernels too (csrc/pgemm.hip).
 """
 from collections import OrderedDict
 

@@ -5,7 +5,8 @@ mode, exhaustively searches) its kernels on a fresh box: the first C2 step took 
 touches MIOpen (`torch.backends.cudnn.enabled = False`, set when the package is imported):
 
   * 1x1 Conv2d / Conv1d(k=1) (the bulk of the path's FLOPs: q/k/v, MLP, pixel-decoder and decoder projections) are
-    plain GEMMs  Y[n] = W @ X[n]  on the channel-major activations -> rocBLAS (prebuilt gfx950 kernels);
+    plain GEMMs  Y[n] = W @ X[n]  on the channel-major activations -> this package's packed-weight kernels (csrc/pgemm.hip;
+    rounds 1-2: rocBLAS);
   * dense kxk convolutions (stem 7x7, MS_ConvBlock 3x3, downsampling 3x3/s2) are lowered to im2col + the same GEMM;
   * depthwise convolutions and BatchNorm are this package's own kernels (csrc/dwconv.hip, csrc/bn_lif.hip).
 
@@ -33,7 +34,7 @@ def _gemm_nc(weight2d, x3, bias, spike_input=False):
     """x3 [N, K, L] (tensor or ops.Spikes), weight2d [M, K] -> [N, M, L]."""
     if (spike_input or isinstance(x3, ops.Spikes)) and ops.SPIKE_GEMM_ENABLED and x3.shape[2] % 4 == 0:
         return ops.spike_gemm(x3, weight2d, bias)       # bf16 matrix cores, exact for spike activations
-    # library GEMM with the weight broadcast through a zero batch stride (no operand copies), rocBLAS or hipBLASLt
+    # general fp32 input: ops.dense_gemm (6-pass packed-weight kernel; the library GEMM only for shapes it does not take)
     y = ops.dense_gemm(ops.spikes_float(x3), weight2d)
     if bias is not None:
         y = y + bias.view(1, -1, 1)

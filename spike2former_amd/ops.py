@@ -1196,7 +1196,7 @@ MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pas
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
 # Round 3: the LDS-DMA pipelined kernels (csrc/pgemm.hip).  PGEMM: forward spike GEMMs on s2f_pgemm_nn_bf16 (packed weight, bf16
-# spikes, N % 8 == 0, N >= 128); PGEMM_DX: every fp32 x fp32 product that ran on the library in rounds 1-2 -- the input
+# spikes, any N % 4 == 0 since the register-staged form); PGEMM_DX: every fp32 x fp32 product that ran on the library in rounds 1-2 -- the input
 # gradients of the 1x1 convolutions and the forward products of the convolutions whose input is not a spike map -- on
 # s2f_pgemm_dx_f32 (6 bf16 passes = fp32 accuracy), their weight gradients on s2f_gemm_dw_general.
 PGEMM = _os.environ.get("S2F_PGEMM", "1") != "0"
@@ -1409,7 +1409,7 @@ def _is_spike_grid(x):
 
 class _SpikeGemm(torch.autograd.Function):
     """Y[b] = W @ X[b] (+ bias) with X spikes (bf16 pair or fp32): forward and weight gradient on the bf16 matrix cores (W /
-    dY split hi+mid+lo), input gradient on the library (fp32)."""
+    dY split hi+mid+lo), input gradient on the transposed packed-weight kernel (dx_gemm: s2f_pgemm_dx_f32, 6 passes)."""
 
     @staticmethod
     def forward(ctx, x, tok, w2d, bias):
