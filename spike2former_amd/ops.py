@@ -1192,6 +1192,7 @@ CONV3X3_IMPLICIT_MIN_PIXELS = int(_os.environ.get("S2F_CONV3_MIN_PIXELS", 32 * 3
 # input gradient of the 3x3 convolutions as an implicit transposed convolution on the 6-pass split GEMM (no unfold / col2im)
 CONV3X3_DX_IMPLICIT = True
 CONV3X3_DX_MIN_PIXELS = 0          # measured at C2: a win on every map size (61.7 vs 62.3 ms/step)
+MASK_EINSUM_DW_GROUPED = _os.environ.get("S2F_MASK_DW_GROUPED", "1") != "0"   # the mask contraction's T*B dE products as one grouped launch
 MASK_EINSUM_DE_MFMA = True    # dE of the mask einsum on the matrix cores (6-pass split GEMM) instead of rocBLAS fp32
 SPIKE_GEMM_DW = True          # weight gradient on the bf16 matrix cores as well (dY split hi+mid+lo in-kernel)
 SPIKE_GEMM_CHECK = False      # debug: assert that the activation really is a spike tensor
@@ -1720,14 +1721,26 @@ class _MaskEinsumFolded(torch.autograd.Function):
             H = torch.empty(T, B, Q, C, dtype=torch.float32, device=dev)
             xb = sdata.dtype == torch.bfloat16
             _time_next("spike_gemm_dw", 4 * T * B * HW * (C + Q), 2 * T * B * Q * HW * C, moved=T * B * HW * ((2 if xb else 4) * C + 4 * Q))
-            for t in range(T):
-                for b in range(B):
-                    if xb:
-                        check(lib.s2f_spike_gemm_dw_bf16(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, _stream()),
-                              "s2f_spike_gemm_dw_bf16")
-                    else:
-                        check(lib.s2f_spike_gemm_dw(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, 1, _stream()),
-                              "s2f_spike_gemm_dw")
+            if xb and MASK_EINSUM_DW_GROUPED and T * B <= 56 and HW % 4 == 0:
+                # the T * B products H[t, b] = g[b] S[t, b]^T as ONE grouped launch (12 output tiles each over a 65 536-long
+                # contraction: one by one they run at 183 TF/s) into the zeroed H
+                import ctypes
+                H.zero_()
+                flat = []
+                for t in range(T):
+                    for b in range(B):
+                        flat += [g[b].data_ptr(), S[t, b].data_ptr(), H[t, b].data_ptr(), 1, Q, C, HW]
+                arr = (ctypes.c_int64 * len(flat))(*flat)
+                check(lib.s2f_spike_gemm_dw_grouped(arr, T * B, 64, _stream()), "s2f_spike_gemm_dw_grouped")
+            else:
+                for t in range(T):
+                    for b in range(B):
+                        if xb:
+                            check(lib.s2f_spike_gemm_dw_bf16(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, _stream()),
+                                  "s2f_spike_gemm_dw_bf16")
+                        else:
+                            check(lib.s2f_spike_gemm_dw(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, 1, _stream()),
+                                  "s2f_spike_gemm_dw")
             rs = g.sum(-1) if bias is not None else None                      # [B, Q]
             if ctx.needs_input_grad[0]:
                 ge = torch.matmul(H, W.t())
