@@ -1206,14 +1206,11 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
     const int steps = (Mo + 15) / 16;
     // (a split costs a zero-fill launch and atomics: only contractions of >= 512 rows take it)
     while (beta == 0.f && wgs * zsplit < 128 && steps / (zsplit * 2) >= 16) zsplit *= 2;
-    static const char* fz = getenv("S2F_PG_DX_ZSPLIT");          // probe switch: force a contraction split
-    if (fz && beta == 0.f && atoi(fz) > 0) zsplit = atoi(fz);
   }
   if (zsplit > 1) {
     S2F_REQUIRE(dx_batch_stride == (int64_t)Ki * N, S2F_EINVAL, "s2f_pgemm_dx_f32: the split form needs a dense DX");
     if (s2f_zero_async(DX, sizeof(float) * (size_t)batch * Ki * N, s) != S2F_OK) return s2f_check_launch("s2f_pgemm_dx_f32 zero");
-    static const char* fzc = getenv("S2F_PG_DX_ZCFG");
-    c = fzc ? atoi(fzc) : 4;
+    c = 4;
   }
 #define S2F_PGD(MI, NJ, WMW, WNW)                                                                                       \
   do {                                                                                                                 \

@@ -44,11 +44,13 @@ junk = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 
 
 def run(i, cfg=2):
-    check(lib.s2f_pgemm_dx_f32(wp.data_ptr(), gs[i % NB].data_ptr(), 0, dxs[i % NB].data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg, S), "dx")
+    check(lib.s2f_pgemm_dx_f32(wp.data_ptr(), gs[i % NB].data_ptr(), 0, dxs[i % NB].data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg,
+                               torch.cuda.current_stream().cuda_stream), "dx")
 
 
 def run_same(i, cfg=2):
-    check(lib.s2f_pgemm_dx_f32(wp.data_ptr(), gs[0].data_ptr(), 0, dxs[0].data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg, S), "dx")
+    check(lib.s2f_pgemm_dx_f32(wp.data_ptr(), gs[0].data_ptr(), 0, dxs[0].data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg,
+                               torch.cuda.current_stream().cuda_stream), "dx")
 
 
 for name, fn in (("same buffers", run_same), ("rotating 1 GiB of buffers", run)):
