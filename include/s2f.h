@@ -324,6 +324,13 @@ int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w,
  * Replaces the `.permute(0, 1, 3, 4, 2)` / `.permute(0, 1, 4, 2, 3)` copies around the DCNv3 sampling core
  * (ops_dcnv3/modules/dcnv3.py:198-233; mmdet/models/layers/detr_layers.py:331-337).  x != y; B < 65536. */
 int s2f_transpose_last2(const float* x, float* y, int64_t B, int R, int C, void* stream);
+/* y[b][c][r] = q[b][c][r] + g[c] * x[b][r][c]  (x [B, R, C] token-major, q / y [B, C, R] channel-major, g [C]): the pixel decoder's
+ * `query + gamma3 * ffn(query)` (detr_layers.py:336-337) with the FFN output's reinterpretation (mmcv_spike/transformer.py:829) as
+ * one pass.  Backward: gx[b][r][c] = g[c] gy[b][c][r], gg[c] += sum gy[b][c][r] x[b][r][c] (gg zeroed by the caller; d/dq = gy).
+ * R % 64 == 0, C % 64 == 0. */
+int s2f_transpose_scale_add_fwd(const float* x, const float* q, const float* g, float* y, int64_t B, int R, int C, void* stream);
+int s2f_transpose_scale_add_bwd(const float* gy, const float* x, const float* g, float* gx, float* gg_zeroed, int64_t B, int R, int C,
+                                void* stream);
 
 /* ---- mask losses of the Hungarian-matched loss on the 2x up-sampled logits -------------------
  * For matched prediction p: u = bilinear2x(pred[p]) (F.interpolate align_corners=False, dense_heads/maskformer_head.py:475-479),

@@ -48,7 +48,95 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const float* __res
   }
 }
 
+// y[b][c][r] = q[b][c][r] + g[c] * x[b][r][c]: the layer-scaled residual of the pixel decoder's FFN branch,
+//   query + gamma3 * ffn(query)  with the FFN output lying token-major in memory (mmdet/models/layers/detr_layers.py:336-337 with
+//   mmcv_spike/transformer.py:829) -- the transposition, the per-channel scale and the add in one pass (ATen: transpose copy +
+//   addcmul; backward: three mul, a sum, an add and a transpose per layer).
+__global__ __launch_bounds__(256) void transpose_scale_add_kernel(const float* __restrict__ x, const float* __restrict__ q,
+                                                                  const float* __restrict__ g, float* __restrict__ y, int R, int C) {
+  __shared__ float s[kT][kT + 1];
+  const int64_t b = blockIdx.z;
+  const int r0 = blockIdx.y * kT, c0 = blockIdx.x * kT;
+  const float* xb = x + b * (int64_t)R * C;
+  const float* qb = q + b * (int64_t)R * C;
+  float* yb = y + b * (int64_t)R * C;
+  for (int e = threadIdx.x; e < kT * (kT / 4); e += 256) {
+    const int i = e >> 4, j4 = (e & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)(r0 + i) * C + c0 + j4);
+    s[i][j4] = v.x; s[i][j4 + 1] = v.y; s[i][j4 + 2] = v.z; s[i][j4 + 3] = v.w;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kT * (kT / 4); e += 256) {
+    const int j = e >> 4, i4 = (e & 15) * 4;
+    const int64_t o = (int64_t)(c0 + j) * R + r0 + i4;
+    const float gc = g[c0 + j];
+    const float4 qv = *reinterpret_cast<const float4*>(qb + o);
+    *reinterpret_cast<float4*>(yb + o) =
+        make_float4(qv.x + gc * s[i4][j], qv.y + gc * s[i4 + 1][j], qv.z + gc * s[i4 + 2][j], qv.w + gc * s[i4 + 3][j]);
+  }
+}
+
+// backward: gx[b][r][c] = g[c] * gy[b][c][r];  gg[c] += sum_{b, r} gy[b][c][r] * x[b][r][c]   (gg zeroed by the caller; the
+// gradient w.r.t. q is gy itself).  gy tile [64 c][64 r] through LDS; every thread then owns one (r, 4 c) piece of x / gx.
+__global__ __launch_bounds__(256) void transpose_scale_add_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                      const float* __restrict__ g, float* __restrict__ gx,
+                                                                      float* __restrict__ gg, int R, int C) {
+  __shared__ float s[kT][kT + 1];
+  __shared__ float red[kT];
+  const int64_t b = blockIdx.z;
+  const int r0 = blockIdx.y * kT, c0 = blockIdx.x * kT;
+  const float* gb = gy + b * (int64_t)R * C;
+  const float* xb = x + b * (int64_t)R * C;
+  float* ob = gx + b * (int64_t)R * C;
+  if (threadIdx.x < kT) red[threadIdx.x] = 0.f;
+  for (int e = threadIdx.x; e < kT * (kT / 4); e += 256) {
+    const int j = e >> 4, i4 = (e & 15) * 4;                     // row c0 + j of gy, columns r0 + i4 ..
+    const float4 v = *reinterpret_cast<const float4*>(gb + (int64_t)(c0 + j) * R + r0 + i4);
+    s[j][i4] = v.x; s[j][i4 + 1] = v.y; s[j][i4 + 2] = v.z; s[j][i4 + 3] = v.w;
+  }
+  __syncthreads();
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  const int j4 = (threadIdx.x & 15) * 4;                         // this thread's four channels, the same in every iteration
+  for (int e = threadIdx.x; e < kT * (kT / 4); e += 256) {
+    const int i = e >> 4;
+    const int64_t o = (int64_t)(r0 + i) * C + c0 + j4;
+    const float4 xv = *reinterpret_cast<const float4*>(xb + o);
+    const float4 gv = *reinterpret_cast<const float4*>(g + c0 + j4);
+    const float t0 = s[j4][i], t1 = s[j4 + 1][i], t2 = s[j4 + 2][i], t3 = s[j4 + 3][i];
+    *reinterpret_cast<float4*>(ob + o) = make_float4(gv.x * t0, gv.y * t1, gv.z * t2, gv.w * t3);
+    part[0] += t0 * xv.x; part[1] += t1 * xv.y; part[2] += t2 * xv.z; part[3] += t3 * xv.w;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) atomicAdd(&red[j4 + u], part[u]);
+  __syncthreads();
+  if (threadIdx.x < kT) atomicAdd(gg + c0 + threadIdx.x, red[threadIdx.x]);
+}
+
 }  // namespace
+
+extern "C" int s2f_transpose_scale_add_fwd(const float* x, const float* q, const float* g, float* y, int64_t B, int R, int C,
+                                           void* stream) {
+  S2F_REQUIRE(x && q && g && y && x != y, S2F_EINVAL, "s2f_transpose_scale_add_fwd: null or aliased pointers");
+  S2F_REQUIRE(B > 0 && B < 65536 && R > 0 && C > 0 && R % 64 == 0 && C % 64 == 0, S2F_EINVAL,
+              "s2f_transpose_scale_add_fwd: need R %% 64 == 0 and C %% 64 == 0 (R=%d C=%d)", R, C);
+  S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(q) && s2f_aligned16(g) && s2f_aligned16(y), S2F_EALIGN,
+              "s2f_transpose_scale_add_fwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(transpose_scale_add_kernel, dim3(C / kT, R / kT, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, q, g, y, R,
+                     C);
+  return s2f_check_launch("s2f_transpose_scale_add_fwd");
+}
+
+extern "C" int s2f_transpose_scale_add_bwd(const float* gy, const float* x, const float* g, float* gx, float* gg_zeroed, int64_t B,
+                                           int R, int C, void* stream) {
+  S2F_REQUIRE(gy && x && g && gx && gg_zeroed, S2F_EINVAL, "s2f_transpose_scale_add_bwd: null pointer");
+  S2F_REQUIRE(B > 0 && B < 65536 && R > 0 && C > 0 && R % 64 == 0 && C % 64 == 0, S2F_EINVAL,
+              "s2f_transpose_scale_add_bwd: need R %% 64 == 0 and C %% 64 == 0 (R=%d C=%d)", R, C);
+  S2F_REQUIRE(s2f_aligned16(gy) && s2f_aligned16(x) && s2f_aligned16(g) && s2f_aligned16(gx), S2F_EALIGN,
+              "s2f_transpose_scale_add_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(transpose_scale_add_bwd_kernel, dim3(C / kT, R / kT, (unsigned)B), dim3(256), 0, (hipStream_t)stream, gy, x, g,
+                     gx, gg_zeroed, R, C);
+  return s2f_check_launch("s2f_transpose_scale_add_bwd");
+}
 
 extern "C" int s2f_transpose_last2(const float* x, float* y, int64_t B, int R, int C, void* stream) {
   if (B == 0 || R == 0 || C == 0) return S2F_OK;

@@ -214,8 +214,8 @@ class DCNDetrTransformerEncoderLayer(nn.Module):
         q = self.Conv.forward_nchw(q, scale=self.gamma1, residual=q, next_lif=self.dcn.input_proj.spike1)
         q = self.dcn.forward_nchw(q, scale=self.gamma2, residual=q, next_lif=self.ffn.fc1_spike)
         m = self.ffn.forward_nchw(q)                                     # [T*B, C, H*W] in memory == [T,B,H,W,C] semantically
-        m = ops.transpose_last2(m.view(T * B, H * W, C)).view(T, B, C, H, W)
-        return torch.addcmul(q, m, self.gamma3.view(1, 1, C, 1, 1))
+        # q + gamma3 * m^T: transposition, layer scale and residual add in one pass (forward and backward)
+        return ops.transpose_scale_add(m.view(T * B, H * W, C), q.reshape(T * B, C, H * W), self.gamma3).view(T, B, C, H, W)
 
     def forward(self, query):
         """The reference's interface: NHWC in, NHWC out (detr_layers.py:331-337)."""

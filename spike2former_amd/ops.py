@@ -1782,6 +1782,40 @@ class _TransposeLast2(torch.autograd.Function):
         return gx
 
 
+class _TransposeScaleAdd(torch.autograd.Function):
+    """q + g[c] * x^T: x [B, R, C] token-major, q [B, C, R] channel-major, g [C] (s2f.h s2f_transpose_scale_add_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, q, g):
+        _need_cuda(x, q, g)
+        x, q, g = x.contiguous(), q.contiguous(), g.contiguous()
+        B, R, C = x.shape
+        y = torch.empty_like(q)
+        check(lib.s2f_transpose_scale_add_fwd(_ptr(x), _ptr(q), _ptr(g), _ptr(y), B, R, C, _stream()), "s2f_transpose_scale_add_fwd")
+        ctx.save_for_backward(x, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, R, C = x.shape
+        gx = torch.empty_like(x)
+        gg = torch.zeros_like(g)
+        check(lib.s2f_transpose_scale_add_bwd(_ptr(gy), _ptr(x), _ptr(g), _ptr(gx), _ptr(gg), B, R, C, _stream()),
+              "s2f_transpose_scale_add_bwd")
+        return gx, gy, gg
+
+
+def transpose_scale_add(x, q, g):
+    """q [..., C, R] + g[c] * x[..., R, C]^T in one pass (the layer-scaled FFN residual of the pixel decoder); falls back to
+    transpose + addcmul for shapes the kernel does not take."""
+    R, C = x.shape[-2:]
+    if x.dtype == torch.float32 and x.is_cuda and R % 64 == 0 and C % 64 == 0 and g.data_ptr() % 16 == 0:
+        return _TransposeScaleAdd.apply(x.reshape(-1, R, C), q.reshape(-1, C, R), g).view(q.shape)
+    return torch.addcmul(q, transpose_last2(x).view(q.shape), g.view(*([1] * (q.dim() - 2)), C, 1))
+
+
 def transpose_last2(x):
     """x [..., R, C] (fp32, CUDA) -> contiguous [..., C, R]: the `.permute(...).contiguous()` copies around the DCNv3 sampling
     core as one tiled kernel (s2f_transpose_last2)."""

@@ -1134,3 +1134,25 @@ def test_pgemm_conv3x3_is_the_round2_implicit_convolution(ops, N, M, C, H, W):
                                             H, W, cfg, st), "newx")
             assert (g1 - g0).abs().max().item() <= 1e-6 * max(refx.abs().max().item(), 1.0), cfg
             assert (g1.double() - refx).abs().max().item() <= 4e-6 * max(refx.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,R,C", [(8, 1024, 256), (2, 64, 128), (3, 192, 64)])
+def test_transpose_scale_add_is_transpose_plus_addcmul(ops, B, R, C):
+    """ops.transpose_scale_add (q + gamma * x^T in one pass, pixel-decoder FFN residual) against transpose + addcmul under autograd:
+    forward bit-identical (same two roundings per element), gradients to fp32 round-off of the per-channel reduction."""
+    g = torch.Generator().manual_seed(B + R + C)
+    x = torch.randn(B, R, C, generator=g).cuda().requires_grad_(True)
+    q = torch.randn(B, C, R, generator=g).cuda().requires_grad_(True)
+    gam = (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_(True)
+    w = torch.randn(B, C, R, generator=g).cuda()
+    y = ops.transpose_scale_add(x, q, gam)
+    (y * w).sum().backward()
+    got = (y.detach().clone(), x.grad.clone(), q.grad.clone(), gam.grad.clone())
+    for t in (x, q, gam):
+        t.grad = None
+    ref = torch.addcmul(q, x.transpose(1, 2), gam.view(1, C, 1))
+    (ref * w).sum().backward()
+    assert torch.equal(got[0], ref.detach())
+    assert torch.equal(got[1], x.grad) and torch.equal(got[2], q.grad)
+    assert (got[3] - gam.grad).abs().max().item() <= 1e-5 * gam.grad.abs().max().item()
