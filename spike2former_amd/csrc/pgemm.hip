@@ -400,7 +400,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // that hipcc's vmcnt(0) for the register loads no longer drains the copies: 13.7 vs 12.6 us on [256 <- 256] x 8 x 1024, 48.8 vs
 // 38.0 on [256 <- 1024] -- the loop was not waiting for the panels; halving the staging wavefronts cost more.  What a 16-row step
 // costs is the SUM of its phases -- staging arithmetic, LDS writes, barrier, LDS transpose reads, MFMAs: 1 300 cycles for 384 of
-// MFMA -- because the one barrier per step keeps all wavefronts of the workgroup in the same phase.)
+// MFMA -- because the one barrier per step keeps all wavefronts of the workgroup in the same phase.  Putting two groups of four
+// wavefronts in OPPOSITE phase on one tile (each group half of the contraction with its own LDS stages; group 0 stages then
+// multiplies, group 1 multiplies then stages; partial tiles added through LDS) did not buy the overlap either: 16.2 vs 12.5 us on
+// the same shape, 880 vs 450 us on [256 <- 256] x 8 x 65536 (72 KiB of LDS and 512 threads per workgroup halve the occupancy).)
 // EPI: 0 = store, 1 = DX = acc + beta * DX, 2 = atomic add into a zeroed DX (gridDim.z workgroups share the contraction: the
 // decoder's 100-token products with a 2 048-long contraction have 16 output tiles).
 template <int MI, int NJ, int WMW, int WNW, int EPI>
