@@ -406,15 +406,16 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // the same shape, 880 vs 450 us on [256 <- 256] x 8 x 65536 (72 KiB of LDS and 512 threads per workgroup halve the occupancy).)
 // EPI: 0 = store, 1 = DX = acc + beta * DX, 2 = atomic add into a zeroed DX (gridDim.z workgroups share the contraction: the
 // decoder's 100-token products with a 2 048-long contraction have 16 output tiles).
-template <int MI, int NJ, int WMW, int WNW, int EPI>
+template <int MI, int NJ, int WMW, int WNW, int EPI, int KS = 1>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
                                                                   int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
                                                                   int64_t g_batch_stride, int64_t dx_batch_stride) {
   constexpr bool BETA = EPI == 1;
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
-  constexpr int KC = 16;
-  constexpr int A_BYTES = 3 * (BM / 32) * 1024, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM, STAGE = A_BYTES + B_BYTES;
+  constexpr int KC = 16 * KS;                                      // KS 16-row slices per step (one barrier per step)
+  constexpr int A_SLICE = 3 * (BM / 32) * 1024;
+  constexpr int A_BYTES = KS * A_SLICE, B_TERM = KC * BN * 2, B_BYTES = 3 * B_TERM, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = 3 * (BM / 32);                               // 1 KiB copies per stage (the waits below do not count them)
   constexpr int NQ = KC * BN / 4 / T;                             // float4 loads per thread and stage
   static_assert(NQ >= 1 && (KC * BN / 4) % T == 0, "tile too small for the thread count");
@@ -439,15 +440,18 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
 
   auto issue_a = [&](int tl, int st) __attribute__((always_inline)) {
     unsigned char* sb = smem + st * STAGE;
-    const int c0 = (t_first + tl) * KC;                           // first contraction row (a row of W)
-    const unsigned short* rows = Wp + (int64_t)(c0 / PR) * KbW * PBLOCK + (c0 % PR) * PK + lane * 8;
 #pragma unroll
-    for (int q = 0; q < (NA + NW - 1) / NW; ++q) {
-      const int idx = wave + q * NW;
-      if (NA % NW != 0 && idx >= NA) break;
-      const int term = idx / (BM / 32), p = idx % (BM / 32);
-      const int kb = min(m0 / PK + p, KbW - 1);                   // panels past Ki belong to rows that are never stored
-      dma16(rows + kb * PBLOCK + term * PTERM, sb + idx * 1024);
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c0 = (t_first + tl) * KC + 16 * ks;               // first contraction row of the slice (a row of W)
+      const unsigned short* rows = Wp + (int64_t)(c0 / PR) * KbW * PBLOCK + (c0 % PR) * PK + lane * 8;
+#pragma unroll
+      for (int q = 0; q < (NA + NW - 1) / NW; ++q) {
+        const int idx = wave + q * NW;
+        if (NA % NW != 0 && idx >= NA) break;
+        const int term = idx / (BM / 32), p = idx % (BM / 32);
+        const int kb = min(m0 / PK + p, KbW - 1);                 // panels past Ki belong to rows that are never stored
+        dma16(rows + kb * PBLOCK + term * PTERM, sb + ks * A_SLICE + idx * 1024);
+      }
     }
   };
   f32x4 breg[NQ];
@@ -509,46 +513,51 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
       bf16x8 v;
       s16x4 h[2];
     } bfrag[3][NJ], afrag[3][MI];
-    const unsigned sb = smem_a + st * STAGE;
+    const unsigned sb0 = smem_a + st * STAGE;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const unsigned a = sb + boff[j] * 2;
-      bfrag[0][j].h[0] = lds_tr16_asm<A_BYTES>(a);
-      bfrag[0][j].h[1] = lds_tr16_asm<A_BYTES + 4 * BN * 2>(a);
-      bfrag[1][j].h[0] = lds_tr16_asm<A_BYTES + B_TERM>(a);
-      bfrag[1][j].h[1] = lds_tr16_asm<A_BYTES + B_TERM + 4 * BN * 2>(a);
-      bfrag[2][j].h[0] = lds_tr16_asm<A_BYTES + 2 * B_TERM>(a);
-      bfrag[2][j].h[1] = lds_tr16_asm<A_BYTES + 2 * B_TERM + 4 * BN * 2>(a);
-    }
+    for (int ks = 0; ks < KS; ++ks) {
+      const unsigned sb = sb0 + ks * A_SLICE;                      // weight slice; the G rows of the slice lie 16 rows further
+      const unsigned sbb = sb0 + ks * (16 * BN * 2);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      afrag[0][i].h[0] = lds_tr16_asm<0>(sb + aoff[i][0] * 2);
-      afrag[0][i].h[1] = lds_tr16_asm<0>(sb + aoff[i][1] * 2);
-    }
+      for (int j = 0; j < NJ; ++j) {
+        const unsigned a = sbb + boff[j] * 2;
+        bfrag[0][j].h[0] = lds_tr16_asm<A_BYTES>(a);
+        bfrag[0][j].h[1] = lds_tr16_asm<A_BYTES + 4 * BN * 2>(a);
+        bfrag[1][j].h[0] = lds_tr16_asm<A_BYTES + B_TERM>(a);
+        bfrag[1][j].h[1] = lds_tr16_asm<A_BYTES + B_TERM + 4 * BN * 2>(a);
+        bfrag[2][j].h[0] = lds_tr16_asm<A_BYTES + 2 * B_TERM>(a);
+        bfrag[2][j].h[1] = lds_tr16_asm<A_BYTES + 2 * B_TERM + 4 * BN * 2>(a);
+      }
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      afrag[1][i].h[0] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][0] * 2);
-      afrag[1][i].h[1] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][1] * 2);
-    }
+      for (int i = 0; i < MI; ++i) {
+        afrag[0][i].h[0] = lds_tr16_asm<0>(sb + aoff[i][0] * 2);
+        afrag[0][i].h[1] = lds_tr16_asm<0>(sb + aoff[i][1] * 2);
+      }
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      afrag[2][i].h[0] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][0] * 2);
-      afrag[2][i].h[1] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][1] * 2);
-    }
+      for (int i = 0; i < MI; ++i) {
+        afrag[1][i].h[0] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][0] * 2);
+        afrag[1][i].h[1] = lds_tr16_asm<(BM / 32) * 1024>(sb + aoff[i][1] * 2);
+      }
 #pragma unroll
-    for (int ta = 0; ta < 3; ++ta) {
-      // reads were requested in the order B (all), A term 0, 1, 2 (2 MI each)
-      if (ta == 0) lds_wait<4 * MI>();
-      if (ta == 1) lds_wait<2 * MI>();
-      if (ta == 2) lds_wait<0>();
+      for (int i = 0; i < MI; ++i) {
+        afrag[2][i].h[0] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][0] * 2);
+        afrag[2][i].h[1] = lds_tr16_asm<2 * (BM / 32) * 1024>(sb + aoff[i][1] * 2);
+      }
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int ta = 0; ta < 3; ++ta) {
+        // reads were requested in the order B (all), A term 0, 1, 2 (2 MI each)
+        if (ta == 0) lds_wait<4 * MI>();
+        if (ta == 1) lds_wait<2 * MI>();
+        if (ta == 2) lds_wait<0>();
 #pragma unroll
-        for (int tb = 0; tb < 3; ++tb)
-          if (ta + tb < 3)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              mfma_bf16(acc[i][j], afrag[ta][i].v, bfrag[tb][j].v);
+          for (int tb = 0; tb < 3; ++tb)
+            if (ta + tb < 3)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                mfma_bf16(acc[i][j], afrag[ta][i].v, bfrag[tb][j].v);
+      }
     }
   };
 
@@ -1201,7 +1210,9 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   // and the 64 x 128 tile runs on EIGHT wavefronts of 32 x 32 (cfg 4: 13.4 vs 15.7 us on [256 <- 256] x 1024, 22.5 vs 26.0 on
   // [256 <- 512], 38.9 vs 43.0 on [256 <- 1024]: with one workgroup per CU the four-wavefront form leaves one wavefront per SIMD,
   // whose staging, LDS reads and MFMAs only ever run one after the other); <= 32 output rows: 32 x 128 tiles (cfg 5)
-  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : 4;
+  // cfg 7 = cfg 4 with 32-row steps (half the barriers and waits per MFMA): 11.7 vs 12.6 us, 19.0 vs 20.8, 32.6 vs 38.1 on the three
+  // shapes above; the plain-store form only (no beta, no contraction split)
+  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : (beta == 0.f ? 7 : 4);
   // few output tiles and a long contraction (the decoder's 100-token products): split the contraction over gridDim.z
   int zsplit = 1;
   {
@@ -1235,6 +1246,18 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
     case 3: S2F_PGD(1, 2, 4, 2); break;          // 128 x 128 on eight wavefronts (two per SIMD)
     case 4: S2F_PGD(1, 1, 2, 4); break;          // 64 x 128 on eight wavefronts of 32 x 32
     case 5: S2F_PGD(1, 1, 1, 4); break;          // 32 x 128 on four wavefronts of 32 x 32: twice the workgroups of cfg 2
+#define S2F_PGD2(MI, NJ, WMW, WNW)                                                                                      \
+  do {                                                                                                                 \
+    S2F_REQUIRE(zsplit == 1 && beta == 0.f, S2F_EINVAL, "s2f_pgemm_dx_f32: cfg %d is the plain store form", c);           \
+    const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
+    S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),                \
+               dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,        \
+               dx_batch_stride);                                                                                       \
+  } while (0)
+    case 7: S2F_PGD2(1, 1, 2, 4); break;         // cfg 4 with 32-row steps (half the barriers per MFMA)
+    case 8: S2F_PGD2(1, 2, 2, 2); break;         // cfg 2 with 32-row steps
+    case 9: S2F_PGD2(1, 2, 4, 2); break;         // cfg 3 with 32-row steps
+#undef S2F_PGD2
     default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_f32: unknown cfg %d", c);
   }
 #undef S2F_PGD

@@ -903,6 +903,12 @@ def test_pgemm_input_gradient_matches_fp64(ops, B, Mo, Ki, N):
     st = torch.cuda.current_stream().cuda_stream
     ref = torch.matmul(w.t().double(), gy.double())
     bound = 2e-6 * torch.matmul(w.t().abs().double(), gy.abs().double()).max().item()
+    for cfg in (3, 4, 5, 7, 8, 9):          # eight-wavefront tiles, 32-row tiles, 32-row steps: the plain-store forms
+        if Mo >= 512 and N < 128:
+            continue                         # (the launcher splits such contractions over gridDim.z with its own tile)
+        dx = torch.full((B, Ki, N), float("nan"), device="cuda")
+        check(lib.s2f_pgemm_dx_f32(ops.pack_weight(w).data_ptr(), gy.data_ptr(), 0, dx.data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg, st), "dx")
+        assert (dx.double() - ref).abs().max().item() <= bound, cfg
     for cfg in (1, 2):
         dx = torch.full((B, Ki, N), float("nan"), device="cuda")
         check(lib.s2f_pgemm_dx_f32(ops.pack_weight(w).data_ptr(), gy.data_ptr(), 0, dx.data_ptr(), 0, B, Mo, Ki, N, 0.0, cfg, st), "dx")
