@@ -86,6 +86,37 @@ for p, v in zip(red.params, red.views):
     worst = max(worst, (v - ref).abs().max().item() / (ref.abs().max().item() + 1e-3 * gscale))
 assert worst <= 2e-3, f"reduced gradients differ from the mean of the shards' gradients: {worst}"
 assert all(len(j) == 0 for j in list(ops._DW_PENDING.values()) + list(ops._DW_PENDING_SPLIT.values()))
-print(f"RANK {rank} OK worst {worst:.2e} ranks_seen {dist.get_world_size()}", flush=True)
+# the real training step under the live process group: graph.GraphedHungarianStep (the assignment's num_masks is averaged over
+# the ranks between its two graphs, maskformer_head.py:459) against the eager mode="loss" step on this rank's shard
+from spike2former_amd.graph import GraphedHungarianStep                     # noqa: E402
+del step
+gen = torch.Generator().manual_seed(17)
+seg = torch.empty(G, 1, w["H"], w["W"], dtype=torch.int64)
+for i in range(G):                                            # rank-dependent number of classes: the averaged num_masks matters
+    classes = torch.randperm(w["K"], generator=gen)[:3 + 2 * (i // per)]
+    for j, (y0, x0) in enumerate((y, x) for y in range(0, w["H"], w["H"] // 4) for x in range(0, w["W"], w["W"] // 4)):
+        seg[i, 0, y0:y0 + w["H"] // 4, x0:x0 + w["W"] // 4] = classes[j % len(classes)]
+seg = seg.to(dev)[start:start + per]
+model.load_state_dict(state)
+s2f.reset_net(model)
+red.zero()
+losses = model(mine, [seg[i] for i in range(per)], mode="loss")
+sum(losses.values()).backward()
+ops.wgrad_join()
+red.gather()
+want_loss, want_flat = {k: float(v) for k, v in losses.items()}, red.flat.clone()
+del losses
+for p in model.parameters():
+    p.grad = None
+import gc
+gc.collect()
+model.load_state_dict(state)
+hstep = GraphedHungarianStep(model, mine, seg, red, warmup=1)
+model.load_state_dict(state)
+got = hstep()
+torch.cuda.synchronize()
+assert all(abs(float(v) - want_loss[k]) <= 1e-6 * max(abs(want_loss[k]), 1e-3) for k, v in got.items()), "Hungarian graph step: losses"
+assert (red.flat - want_flat).abs().max().item() <= 1e-4 * want_flat.abs().max().item(), "Hungarian graph step: gradients"
+print(f"RANK {rank} OK worst {worst:.2e} ranks_seen {dist.get_world_size()} hungarian_graph_step OK", flush=True)
 dist.barrier()
 dist.destroy_process_group()

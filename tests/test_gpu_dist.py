@@ -1,7 +1,8 @@
 """The N > 1 bench path on the REAL model, on one GPU: two fresh child processes (torch.distributed.run, gloo, both on GPU 0)
 run tests/_dist_worker.py -- broadcast_params, gradient sinks, deferred grouped weight gradients, a GraphedStep captured with
 a process group alive, FlatGradAllReduce.reduce() -- and compare the reduced flat buffer with the mean of the two shards'
-plain-autograd gradients.  (No scaling figure can come from one GPU; this is the correctness half of SURVEY section 8e.)"""
+plain-autograd gradients; then the real training step (graph.GraphedHungarianStep: num_masks averaged over the ranks between its two
+graphs) against the eager mode="loss" step of each rank.  (No scaling figure can come from one GPU; this is the correctness half of SURVEY section 8e.)"""
 import os
 import socket
 import subprocess
@@ -26,3 +27,4 @@ def test_two_ranks_on_one_gpu_reduce_the_mean_of_their_shards():
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=850)      # children only: nothing is re-exec'ed
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "RANK 0 OK" in r.stdout and "RANK 1 OK" in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("hungarian_graph_step OK") == 2, r.stdout[-2000:]
