@@ -305,7 +305,8 @@ int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_split, int64_t 
 int s2f_spike_gemm_dw_bf16_split(const uint16_t* dY_split, int64_t plane_stride, const uint16_t* X, float* dW, int batch, int M,
                                  int K, int L, int accumulate, void* stream);
 int s2f_spike_gemm_dw_grouped_split(const int64_t* jobs, int njobs, int bkv, void* stream);
-/* dW (+)= sum_b dY[b] (M x L) X[b]^T (L x K), both operands general fp32 (6 passes), batch strides in elements (0 = dense):
+/* dW (+)= sum_b dY[b] (M x L) X[b]^T (L x K), both operands general fp32 (6 passes), batch strides in elements (0 = dense);
+ * accumulate: bit 0 = add into dW (else it is zeroed first), bit 1 = no contraction split (one add per element: run-to-run identical):
  * the weight gradient of the 1x1 convolutions whose input is not a spike map. */
 int s2f_gemm_dw_general(const float* dY, int64_t dy_batch_stride, const float* X, int64_t x_batch_stride, float* dW, int batch,
                         int M, int K, int L, int accumulate, void* stream);

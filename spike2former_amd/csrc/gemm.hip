@@ -859,6 +859,10 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
                            int x_terms, bool conv, Conv3 geo, int log_w, void* stream, int64_t dy_bs = 0, int64_t x_bs = 0) {
   if (dy_bs == 0) dy_bs = (int64_t)M * L;
   if (x_bs == 0) x_bs = (int64_t)K * L;          // conv mode: the kernel addresses X through geo, x_bs is unused there
+  // accumulate bit 1: ONE workgroup per output tile (no contraction split): every element receives a single add, so the result does
+  // not depend on the order atomics retire in -- for products used in a FORWARD pass (ops.linear_tm), which must repeat bit for bit
+  const bool one_split = (accumulate & 2) != 0;
+  accumulate &= 1;
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw: null pointer");
   S2F_REQUIRE(batch > 0 && M > 0 && K > 0 && L > 0 && (L & 3) == 0, S2F_EINVAL,
               "s2f_spike_gemm_dw: bad sizes (L=%d must be a positive multiple of 4)", L);
@@ -898,6 +902,7 @@ static int spike_dw_launch(const float* dY, const float* X, float* dW, int batch
       splits = cand;
     }
   }
+  if (one_split) splits = 1;
   if (splits > total_steps) splits = total_steps;
   if (splits > 65535) splits = 65535;
   const int steps_per_split = (total_steps + splits - 1) / splits;

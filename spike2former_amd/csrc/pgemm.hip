@@ -1219,11 +1219,13 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
     const int64_t wgs = (int64_t)n_tiles * batch * ((Ki + 63) / 64);
     const int steps = (Mo + 15) / 16;
     // (a split costs a zero-fill launch and atomics: only contractions of >= 512 rows take it)
-    while (beta == 0.f && wgs * zsplit < 128 && steps / (zsplit * 2) >= 16) zsplit *= 2;
+    // beta == 1 (accumulate into what is there, e.g. a gradient sink): the atomics of the split form ARE the accumulation
+    while ((beta == 0.f || beta == 1.f) && wgs * zsplit < 128 && steps / (zsplit * 2) >= 16) zsplit *= 2;
   }
   if (zsplit > 1) {
     S2F_REQUIRE(dx_batch_stride == (int64_t)Ki * N, S2F_EINVAL, "s2f_pgemm_dx_f32: the split form needs a dense DX");
-    if (s2f_zero_async(DX, sizeof(float) * (size_t)batch * Ki * N, s) != S2F_OK) return s2f_check_launch("s2f_pgemm_dx_f32 zero");
+    if (beta == 0.f && s2f_zero_async(DX, sizeof(float) * (size_t)batch * Ki * N, s) != S2F_OK)
+      return s2f_check_launch("s2f_pgemm_dx_f32 zero");
     c = 4;
   }
 #define S2F_PGD(MI, NJ, WMW, WNW)                                                                                       \

@@ -68,9 +68,9 @@ class MLP(nn.Module):
         nn.init.trunc_normal_(self.fc_out.weight, std=0.02)
 
     def forward(self, x):
-        x = self.spike1(self.fc1(x)) * self.quant_const
-        x = self.spike2(self.fc2(x)) * self.quant_const
-        return self.fc_out(x)
+        x = self.spike1(ops.linear_tm(x, self.fc1.weight)) * self.quant_const
+        x = self.spike2(ops.linear_tm(x, self.fc2.weight)) * self.quant_const
+        return ops.linear_tm(x, self.fc_out.weight, self.fc_out.bias)
 
 
 class DCNv3_pytorch(nn.Module):

@@ -162,7 +162,7 @@ class MaskFormerHead(nn.Module):
         # ---- SDME block (maskformer_head.py:568-582)
         z = self.decoder_post_norm(out_dec)
         a = self.alpha * self.decoder_out_spike(z)
-        all_cls_scores = self.cls_embed(a).mean(1)
+        all_cls_scores = ops.linear_tm(a, self.cls_embed.weight, self.cls_embed.bias).mean(1)
         sc = (self.alpha * self.shortcut_conv_spike(z)).reshape(ln * t * bs, nq, C)
         sc, _ = bn_act(self.shortcut_conv[0].forward_nobias(sc), None, self.shortcut_conv[1])
         e = self.mask_embed(a) + self.w * sc.view(ln, t, bs, nq, C)

@@ -1560,6 +1560,95 @@ def spike_gemm(x, w2d, bias=None):
     return _SpikeGemm.apply(data, tok, w2d, bias)
 
 
+# ------------------------------------------------------------------------------------------------ token-major linear layers
+class _LinearTM(torch.autograd.Function):
+    """nn.Linear on a TOKEN-major activation, y[n, o] = sum_c x[n, c] W[o, c] + b[o]  (the SDME block's cls_embed and mask-embedding
+    MLP, mmdet dense_heads/maskformer_head.py:568-582, SNN_core.py:95-123; ~5 600 tokens of 256 channels), on this package's kernels
+    instead of rocBLAS: both operands of y are contraction-contiguous -- the layout of the general weight-gradient kernel
+    (s2f_gemm_dw_general, 6 bf16 passes = fp32 accuracy), which also serves dX = dY W (on W^T); dW = dY^T X contracts over the
+    tokens: the transposed packed-weight kernel with dY packed on the fly (s2f_pgemm_dx_f32, contraction split over gridDim.z)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_cuda(x, w, b)
+        x = x.contiguous()
+        n, c = x.shape
+        o = w.shape[0]
+        y = b.detach().expand(n, o).contiguous() if b is not None else torch.zeros(n, o, dtype=torch.float32, device=x.device)
+        # accumulate = 3: add into y (initialised with the bias) without a contraction split -- a forward product must repeat bit for bit
+        check(lib.s2f_gemm_dw_general(_ptr(x), 0, _ptr(w.detach().contiguous()), 0, _ptr(y), 1, n, o, c, 3, _stream()), "s2f_gemm_dw_general")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, c = x.shape
+        o = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = transpose_last2(w.detach().unsqueeze(0))[0]                                # [c, o]
+            g2, op = gy, o
+            if o % 4 != 0:                                                                  # the contraction runs in groups of 4
+                op = (o + 3) // 4 * 4
+                g2 = torch.nn.functional.pad(gy, (0, op - o))
+                wt = torch.nn.functional.pad(wt, (0, op - o))
+            gx = torch.zeros(n, c, dtype=torch.float32, device=gy.device)
+            check(lib.s2f_gemm_dw_general(_ptr(g2), 0, _ptr(wt), 0, _ptr(gx), 1, n, c, op, 1, _stream()), "s2f_gemm_dw_general")
+        if ctx.needs_input_grad[1]:
+            sink = _sink_for(w)
+            if sink is not None and sink.data_ptr() % 16 != 0:
+                sink = None                  # the kernel stores / adds 16-byte aligned rows: an odd slot of the flat buffer takes p.grad
+            gp = torch.empty(int(lib.s2f_pack_elems(n, o)), dtype=torch.int16, device=gy.device)
+            check(lib.s2f_pack_bf16x3(_ptr(gy), _ptr(gp), n, o, 0, 0, _stream()), "s2f_pack_bf16x3")
+            if sink is None:
+                gw = torch.empty(o, c, dtype=torch.float32, device=gy.device)
+            check(lib.s2f_pgemm_dx_f32(_ptr(gp), _ptr(x), 0, _ptr(gw if sink is None else sink), 0, 1, n, o, c,
+                                       0.0 if sink is None else 1.0, 0, _stream()), "s2f_pgemm_dx_f32")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+def _mm_tm(x2d, w_oc):
+    """x2d [n, c] @ w_oc[o, c]^T -> [n, o] on s2f_gemm_dw_general (both operands contraction-contiguous; no contraction split:
+    repeats bit for bit); the library for c % 4 != 0."""
+    n, c = x2d.shape
+    if not (LINEAR_TM and c % 4 == 0 and x2d.is_cuda and n > 0):
+        return torch.matmul(x2d, w_oc.t())
+    y = torch.zeros(n, w_oc.shape[0], dtype=torch.float32, device=x2d.device)
+    check(lib.s2f_gemm_dw_general(_ptr(x2d.contiguous()), 0, _ptr(w_oc.contiguous()), 0, _ptr(y), 1, n, w_oc.shape[0], c, 3, _stream()),
+          "s2f_gemm_dw_general")
+    return y
+
+
+def _mtm_tm(a2d, b2d):
+    """a2d [n, o]^T @ b2d [n, c] -> [o, c]: the contraction runs over the rows of both -- the transposed packed-operand kernel with a2d
+    packed on the fly (s2f_pgemm_dx_f32, contraction split over gridDim.z); the library for c % 4 != 0."""
+    n, o = a2d.shape
+    c = b2d.shape[1]
+    if not (LINEAR_TM and c % 4 == 0 and a2d.is_cuda and n > 0):
+        return torch.matmul(a2d.t(), b2d)
+    ap = torch.empty(int(lib.s2f_pack_elems(n, o)), dtype=torch.int16, device=a2d.device)
+    check(lib.s2f_pack_bf16x3(_ptr(a2d.contiguous()), _ptr(ap), n, o, 0, 0, _stream()), "s2f_pack_bf16x3")
+    out = torch.empty(o, c, dtype=torch.float32, device=a2d.device)
+    check(lib.s2f_pgemm_dx_f32(_ptr(ap), _ptr(b2d.contiguous()), 0, _ptr(out), 0, 1, n, o, c, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
+    return out
+
+
+LINEAR_TM = _os.environ.get("S2F_LINEAR_TM", "1") != "0"
+
+
+def linear_tm(x, weight, bias=None):
+    """torch.nn.functional.linear(x, weight, bias) for x [..., c] fp32 on the GPU with c % 4 == 0 (else the library)."""
+    c = x.shape[-1]
+    if not (LINEAR_TM and x.is_cuda and x.dtype == torch.float32 and c % 4 == 0 and x.numel() > 0):
+        return torch.nn.functional.linear(x, weight, bias)
+    return _LinearTM.apply(x.reshape(-1, c), weight, bias).view(*x.shape[:-1], weight.shape[0])
+
+
 # ------------------------------------------------------------------------------------------------ mask einsum (SDME)
 def _split_rows(mat, slack_rows):
     """fp32 [R, K] -> bf16 terms [3, Rpad, Kpad] (s2f_split_bf16x3), Rpad >= R + slack_rows (zero rows: a row-block view of
@@ -1672,7 +1761,7 @@ class _MaskEinsumFolded(torch.autograd.Function):
         e = e.contiguous()
         sdata = sdata.contiguous()
         dev = e.device
-        ew = torch.matmul(e, W)                                               # [T, B, Q, C]
+        ew = _mm_tm(e.reshape(-1, Co), transpose_last2(W.detach().unsqueeze(0))[0]).view(T, B, Q, C)      # e @ W: [T, B, Q, C]
         acat = ew.permute(1, 2, 0, 3).reshape(B, Q, T * C).contiguous()       # row (b, q), column (t, c)
         Mpad = (Q + 255) // 256 * 256 if Q > 256 else (Q + 63) // 64 * 64
         Kpad = T * C
@@ -1681,7 +1770,7 @@ class _MaskEinsumFolded(torch.autograd.Function):
             check(lib.s2f_split_bf16x3(_ptr(acat[b]), _ptr(a_split[b]), Q, T * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
         rowb = None
         if bias is not None:
-            rowb = torch.matmul(e.sum(0), bias).contiguous()                  # [B, Q]: sum_t E[t, b] bias
+            rowb = (e.sum(0) * bias.view(1, 1, -1)).sum(-1).contiguous()       # [B, Q]: sum_t E[t, b] bias (a reduction, no GEMV)
         out = torch.empty(B, Q, HW, dtype=torch.float32, device=dev)
         _time_next("spike_gemm_fwd", 4 * B * HW * (T * C + Q), 2 * B * Q * HW * T * C, moved=B * HW * (2 * T * C + 4 * Q))
         check(lib.s2f_spike_gemm_fwd_bf16_ex(_ptr(a_split), 3 * Mpad * Kpad, _ptr(sdata), C * HW, C, B * C * HW, _ptr(rowb),
@@ -1743,14 +1832,14 @@ class _MaskEinsumFolded(torch.autograd.Function):
                                   "s2f_spike_gemm_dw")
             rs = g.sum(-1) if bias is not None else None                      # [B, Q]
             if ctx.needs_input_grad[0]:
-                ge = torch.matmul(H, W.t())
+                ge = _mm_tm(H.view(-1, C), W).view(T, B, Q, Co)                                   # H @ W^T
                 if bias is not None:
                     ge = ge + rs.unsqueeze(0).unsqueeze(-1) * bias.view(1, 1, 1, -1)
                 ge = ge * scale
             if ctx.needs_input_grad[3]:
-                gW = torch.einsum("tbqo,tbqc->oc", e, H) * scale
+                gW = _mtm_tm(e.reshape(-1, Co), H.view(-1, C)) * scale                             # sum_{t,b,q} e^T H
             if bias is not None and ctx.needs_input_grad[4]:
-                gb = torch.einsum("tbqo,bq->o", e, rs) * scale
+                gb = (e * rs.view(1, B, Q, 1)).sum((0, 1, 2)) * scale
         return (ge,) + _grad_pair(True, gs) + (gW, gb, None, None, None, None)
 
 

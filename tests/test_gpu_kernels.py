@@ -1162,3 +1162,32 @@ def test_transpose_scale_add_is_transpose_plus_addcmul(ops, B, R, C):
     assert torch.equal(got[0], ref.detach())
     assert torch.equal(got[1], x.grad) and torch.equal(got[2], q.grad)
     assert (got[3] - gam.grad).abs().max().item() <= 1e-5 * gam.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,o,bias", [(5600, 256, 256, False), (5600, 256, 151, True), (37, 64, 10, True), (700, 128, 96, False)])
+def test_token_major_linear_on_own_kernels(ops, n, c, o, bias):
+    """ops.linear_tm (nn.Linear on a token-major activation through s2f_gemm_dw_general / s2f_pgemm_dx_f32, no vendor GEMM) against
+    F.linear in fp64: output and all three gradients to fp32-GEMM accuracy."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n + c + o)
+    x = torch.randn(2, n // 2 if n % 2 == 0 else n, c, generator=g)[:, :n // 2 if n % 2 == 0 else n]
+    x = (x.reshape(-1, c)[:n].reshape(1, n, c)).cuda().requires_grad_(True)
+    w = (torch.randn(o, c, generator=g) * c ** -0.5).cuda().requires_grad_(True)
+    b = torch.randn(o, generator=g).cuda().requires_grad_(True) if bias else None
+    gy = torch.randn(1, n, o, generator=g).cuda()
+    y = ops.linear_tm(x, w, b)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True) if bias else None
+    yd = F.linear(xd, wd, bd)
+    yd.backward(gy.double())
+
+    def close(a, r, tol=4e-6):
+        return (a.double() - r).abs().max().item() <= tol * max(r.abs().max().item(), 1e-6) * (c if r is yd else 1) ** 0.0 + 1e-12
+    scale = lambda r: r.abs().max().item()
+    assert (y.double() - yd).abs().max().item() <= 4e-6 * scale(yd)
+    assert (x.grad.double() - xd.grad).abs().max().item() <= 4e-6 * scale(xd.grad)
+    assert (w.grad.double() - wd.grad).abs().max().item() <= 4e-6 * scale(wd.grad)
+    if bias:
+        assert (b.grad.double() - bd.grad).abs().max().item() <= 1e-5 * scale(bd.grad)
