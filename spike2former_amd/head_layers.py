@@ -280,8 +280,10 @@ class MultiHeadAttentionBlock(nn.Module):
         return k, v
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None,
-                kv_projected=None, query_channel_major=False):
-        """query [t,b,nq,dim]; key/value [t,b,nk,dim] as in the reference, or -- `kv_channel_major` -- [t,b,dim,nk], the
+                kv_projected=None, query_channel_major=False, residual_cm=None):
+        """`residual_cm` (channel-major streams only): a [t,b,dim,nq] tensor added to the result inside the output BatchNorm kernel
+        (the decoder layer's `query + attention(query)`, detr_layers.py:523-537) -- the add launch disappears.
+        query [t,b,nq,dim]; key/value [t,b,nk,dim] as in the reference, or -- `kv_channel_major` -- [t,b,dim,nk], the
         layout the pixel decoder produces them in (saves two 33 M-element transposes per projection at the 128x128 level;
         the neuron is elementwise, so the values are the same).  `kv_spikes` = (k_conv_spike(key), v_conv_spike(value))
         already formed by the caller (channel-major; the head's fused add + neuron kernel) -- key / value are then unused.
@@ -309,7 +311,8 @@ class MultiHeadAttentionBlock(nn.Module):
                 lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm)],
                 inputs=(query, key, value, fk, fv))
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)      # embed_dim**0.5, not head dim
-        o, _ = conv_bn_act(self.out_conv[0], o, self.out_conv[1])
+        res = residual_cm.reshape(t * b, dim, nq) if (residual_cm is not None and qcm) else None
+        o, _ = conv_bn_act(self.out_conv[0], o, self.out_conv[1], residual=res)
         if qcm:
             return o.view(t, b, dim, nq), None
         return o.permute(0, 2, 1).reshape(t, b, nq, dim), None
@@ -337,7 +340,8 @@ class MultiheadAttention(nn.Module):
         if kv_spikes is not None or kv_projected is not None:
             return self.attn(query=query if query_pos is None else query + query_pos, key=None, value=None,
                              attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes,
-                             kv_projected=kv_projected, query_channel_major=qcm)[0]
+                             kv_projected=kv_projected, query_channel_major=qcm,
+                             residual_cm=kwargs.get("residual_cm") if qcm else None)[0]
         if key is None:
             key = query
         if value is None:
@@ -372,10 +376,13 @@ class MSDA_FFN(nn.Module):
         spikes_in(self.fc1, self.fc2)
 
     def forward(self, x, identity=None):
+        """`identity` [t,bs,N,C]: added to the result -- elementwise in memory order, so inside bn2's kernel on the reinterpreted
+        buffer (detr_layers.py:556: query + ffn(query))."""
         t, bs, N, C = x.shape
         a = self.fc1_spike.fire(x).reshape(t * bs, C, N)
         _, a = conv_bn_act(self.fc1, a, self.bn1, lif=self.fc2_spike)
-        a, _ = conv_bn_act(self.fc2, a, self.bn2)
+        res = identity.reshape(t * bs, C, N) if identity is not None else None
+        a, _ = conv_bn_act(self.fc2, a, self.bn2, residual=res)
         return a.reshape(t, bs, N, C)
 
 
@@ -414,12 +421,17 @@ class DetrTransformerDecoderLayer(nn.Module):
         the seven projections of a layer (12 copies per layer and step, forward + backward); the projections and the
         attention core are channel-major, so only the FFN's bug-compatible reinterpretation of the token-major buffer
         (transformer.py:777,:781) needs the other layout -- one transposition in, one out."""
-        q_cm = q_cm + self.cross_attn(query=q_cm, key=key, value=value, query_pos=query_pos_cm, kv_channel_major=True,
-                                      kv_spikes=kv_spikes, kv_projected=kv_projected, query_channel_major=True)
+        # the three residual adds of the layer run inside the last BatchNorm kernel of each branch (residual=)
+        fused = kv_spikes is not None or kv_projected is not None
+        ca = self.cross_attn(query=q_cm, key=key, value=value, query_pos=query_pos_cm, kv_channel_major=True,
+                             kv_spikes=kv_spikes, kv_projected=kv_projected, query_channel_major=True,
+                             residual_cm=q_cm if fused else None)
+        q_cm = ca if fused else q_cm + ca
         qp = q_cm + query_pos_cm                       # query + query_pos == key + key_pos: formed once
-        q_cm = q_cm + self.self_attn.attn(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True)[0]
+        q_cm = self.self_attn.attn(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True,
+                                   residual_cm=q_cm)[0]
         q_tm = ops.transpose_last2(q_cm)
-        out = q_tm + self.ffn(q_tm)
+        out = self.ffn(q_tm, identity=q_tm)
         return out, (None if last else ops.transpose_last2(out))
 
 
