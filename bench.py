@@ -6,7 +6,7 @@ ResetModelHook does before each iteration) -> forward (Meta-SpikeFormer backbone
 `cls.mean() + masks.mean()` -> backward -> (N > 1) one RCCL all-reduce of the flat gradient buffer.  Optimiser excluded.
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2]      (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -63,6 +63,9 @@ def parse():
                          "step k + 1 (graph.GraphedOverlapStep) instead of ONE graph + a blocking all-reduce behind it.  "
                          "Measured in the one-rank RCCL rehearsal: 52.1 vs 49.8 ms/step -- the second graph launch and the "
                          "two stream hand-overs cost ~2.3 ms, more than the 0.2-1.6 ms collective they hide: off by default")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="N > 1 plumbing check (runs on CPU with S2F_DIST_BACKEND=gloo): launch the ranks, rendezvous, one "
+                         "all-reduce, print {\"rendezvous\": \"ok\", \"ranks_seen\": N} on rank 0 and exit -- no model, no GPU")
     ap.add_argument("--allow-eager", action="store_true",
                     help="N > 1: fall back to eager launches when the hipGraph capture fails (host-bound, ~2x slower: a curve "
                          "that mixes graph and eager points is meaningless, so the default is to fail)")
@@ -146,8 +149,27 @@ def predict_bench(args, s2f, ops, dev, w, B, rank, world):
                        "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"}}), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, the
+    way the reference's tools/dist_train.sh:5-12 does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a CHILD process, before this process has imported
+    torch or touched a GPU (nothing is re-exec'ed) -- relay its output (rank 0 prints the JSON line) and exit with its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -157,7 +179,20 @@ def main():
     from spike2former_amd.init_utils import seeded_init
 
     rank, world, local = init_process_group()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus"
+    if args.rendezvous_only:
+        seen = torch.ones(1)
+        if world > 1:
+            if dist.get_backend() == "nccl":
+                seen = seen.cuda(local)
+            dist.all_reduce(seen)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "ranks_seen": int(seen.item()), "n_gpus": args.gpus,
+                              "backend": dist.get_backend() if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)

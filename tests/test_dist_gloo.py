@@ -82,3 +82,22 @@ def test_flat_grad_allreduce_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_as_typed_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (no WORLD_SIZE): bench.py starts its two ranks itself (torch.distributed.run
+    as a child, the reference's tools/dist_train.sh:5-12), they rendezvous over gloo and rank 0 reports ranks_seen == 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["S2F_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["rendezvous"] == "ok" and out["ranks_seen"] == 2 and out["n_gpus"] == 2 and out["backend"] == "gloo"
