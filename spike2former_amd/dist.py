@@ -46,18 +46,43 @@ class FlatGradAllReduce:
     def __init__(self, params, world_size=None):
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        n = sum(p.numel() for p in self.params)
+        # every parameter's slot starts on a 16-byte boundary (slots padded to a multiple of 4 floats; the pads stay zero): the
+        # kernels that add into a slot store 16-byte rows, and whether a weight gradient goes through its sink must not depend on
+        # where compact() happens to place it
+        n = sum(self._slot(p) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self._lay_out()
         self.stream = None                     # side stream, only for gloo on device memory (see reduce())
         self.work = None
         self.sinks = False
         self._zero = None
         self._n_dense = self._dense_elems = None
+
+    @staticmethod
+    def _slot(p):
+        return (p.numel() + 3) // 4 * 4
+
+    def _lay_out(self):
+        self.views, self.offsets, off = [], [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            self.offsets.append(off)
+            off += self._slot(p)
+
+    def _pieces(self, params):
+        """flat pieces (gradient or zeros, then the slot's zero pad) of consecutive parameters, for one batched copy"""
+        out = []
+        for p in params:
+            out.append((p.grad if p.grad is not None else self._zero[:p.numel()]).reshape(-1))
+            pad = self._slot(p) - p.numel()
+            if pad:
+                out.append(self._zero[:pad])
+        return out
+
+    def _need_zero(self):
+        if self._zero is None:
+            self._zero = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.flat.device)
 
     def install_sinks(self):
         """Let the split-K weight-gradient kernels accumulate straight into this buffer (ops.GRAD_SINKS): `zero()` then
@@ -99,11 +124,9 @@ class FlatGradAllReduce:
         ops.wgrad_flush()                      # deferred weight gradients (ops.DEFER_DW) go into their sinks now
         # No gradient tensor: with sinks the parameter's slice already holds the sum (or the zeros of `zero()`) and is left
         # alone -- the packing runs over the maximal runs of parameters that do have a tensor; without sinks it is a zero.
+        self._need_zero()
         if not self.sinks:
-            if self._zero is None:
-                self._zero = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.flat.device)
-            pieces = [(p.grad if p.grad is not None else self._zero[:p.numel()]).reshape(-1) for p in self.params]
-            torch.cat(pieces, out=self.flat)
+            torch.cat(self._pieces(self.params), out=self.flat)
             return
         if self._n_dense is None:                  # not compacted yet: one batched copy per run of gradient tensors
             run, start, off = [], 0, 0
@@ -111,19 +134,29 @@ class FlatGradAllReduce:
                 if p.grad is not None:
                     if not run:
                         start = off
-                    run.append(p.grad.reshape(-1))
+                    run += self._pieces([p])
                 elif run:
                     torch.cat(run, out=self.flat[start:off])
                     run = []
-                off += p.numel()
+                off += self._slot(p)
             if run:
                 torch.cat(run, out=self.flat[start:off])
             return
-        dense = self.params[:self._n_dense]
-        if self._zero is None and any(p.grad is None for p in dense):
-            self._zero = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.flat.device)
-        pieces = [(p.grad if p.grad is not None else self._zero[:p.numel()]).reshape(-1) for p in dense]
-        torch.cat(pieces, out=self.flat[:self._dense_elems])
+        # compacted: the layout was fixed by which gradients arrived as tensors in the discovery step.  A parameter that changes
+        # sides afterwards would lose its gradient silently (a tensor in the sunk region is never packed; zeros written over a
+        # slot that a kernel added into) -- refuse instead
+        dense, sunk = self.params[:self._n_dense], self.params[self._n_dense:]
+        stray = [i for i, p in enumerate(sunk) if p.grad is not None]
+        if stray:
+            raise RuntimeError(f"FlatGradAllReduce: {len(stray)} parameter(s) placed in the sink region by compact() received a gradient "
+                               f"TENSOR in this step (first: #{self._n_dense + stray[0]}, shape {tuple(sunk[stray[0]].shape)}); their "
+                               "gradients would not be packed -- re-run compact() after the change that caused this")
+        missing = [i for i, p in enumerate(dense) if p.grad is None]
+        if missing:
+            raise RuntimeError(f"FlatGradAllReduce: {len(missing)} parameter(s) of the dense region have no gradient tensor in this step "
+                               f"(first: #{missing[0]}, shape {tuple(dense[missing[0]].shape)}): if a kernel added their gradient into "
+                               "a sink, packing would overwrite it with zeros -- re-run compact()")
+        torch.cat(self._pieces(dense), out=self.flat[:self._dense_elems])
 
     def pack(self, grads):
         """Like gather(), from an explicit gradient list aligned with `self.params` (torch.autograd.grad output; None =
@@ -145,11 +178,8 @@ class FlatGradAllReduce:
         have = [p for p in self.params if p.grad is not None]
         rest = [p for p in self.params if p.grad is None]
         self.params = have + rest
-        self._n_dense, self._dense_elems = len(have), sum(p.numel() for p in have)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self._n_dense, self._dense_elems = len(have), sum(self._slot(p) for p in have)
+        self._lay_out()
         if self.sinks:
             self.install_sinks()
 

@@ -138,6 +138,11 @@ class MaskFormerLoss:
         """[B, H, W] / [B, 1, H, W] integer label maps -> contiguous uint8 [B, H, W], the ignored label as 255."""
         seg = segs.reshape(segs.shape[0], *segs.shape[-2:])
         if seg.dtype != torch.uint8:
+            # a label outside 0..255 would wrap into a valid class id (or into 255 = ignored) in the cast below and training would
+            # go on silently on wrong targets; the reference fails loudly in its cross-entropy on such a value
+            if bool((((seg < 0) | (seg > 255)) & (seg != ignore_index)).any()):
+                raise ValueError("semantic label map holds values outside 0..255 other than ignore_index "
+                                 f"({ignore_index}): min {int(seg.min())}, max {int(seg.max())}")
             seg = torch.where(seg == ignore_index, self.IGNORE_U8, seg).to(torch.uint8) if ignore_index != self.IGNORE_U8 \
                 else seg.to(torch.uint8)
         return seg.contiguous()

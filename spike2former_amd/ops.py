@@ -1423,7 +1423,7 @@ class _SpikeGemm(torch.autograd.Function):
         y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
         xb = x.dtype == torch.bfloat16
         _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * ((2 if xb else 4) * K + 4 * M))
-        if PGEMM and xb and N % 4 == 0 and SPIKE_GEMM_TERMS == 3:
+        if PGEMM and xb and N % 4 == 0 and N >= 8 and SPIKE_GEMM_TERMS == 3:
             check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, SPIKE_GEMM_TERMS, 0,
                                         _stream()), "s2f_pgemm_nn_bf16")
         else:
@@ -1600,7 +1600,9 @@ class _LinearTM(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sink = _sink_for(w)
             if sink is not None and sink.data_ptr() % 16 != 0:
-                sink = None                  # the kernel stores / adds 16-byte aligned rows: an odd slot of the flat buffer takes p.grad
+                # the kernel adds 16-byte aligned rows.  dist.FlatGradAllReduce pads every slot to 16 bytes, so whether this weight
+                # goes through its sink never depends on where compact() placed it; a foreign sink table must do the same
+                raise RuntimeError("linear_tm: the gradient sink of this weight is not 16-byte aligned")
             gp = torch.empty(int(lib.s2f_pack_elems(n, o)), dtype=torch.int16, device=gy.device)
             check(lib.s2f_pack_bf16x3(_ptr(gy), _ptr(gp), n, o, 0, 0, _stream()), "s2f_pack_bf16x3")
             if sink is None:
@@ -2082,7 +2084,7 @@ class _ConvDense(torch.autograd.Function):
             y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
             _time_next("spike_gemm_fwd", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1],
                        moved=N * L * ((2 if xb else 4) * cols.shape[1] + 4 * M))
-            if PGEMM and xb and L % 4 == 0 and SPIKE_GEMM_TERMS == 3:
+            if PGEMM and xb and L % 4 == 0 and L >= 8 and SPIKE_GEMM_TERMS == 3:
                 check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1],
                                             SPIKE_GEMM_TERMS, 0, _stream()), "s2f_pgemm_nn_bf16")
             else:

@@ -29,14 +29,15 @@ def _worker(rank, world, port, out):
     lin(data[start:start + per]).square().mean().backward()
     red.gather()
     local = red.flat.clone()
-    want_local = torch.cat([p.grad.reshape(-1) for p in lin.parameters()])
+    pad = lambda t: torch.cat([t.reshape(-1), t.new_zeros((-t.numel()) % 4)])          # slots are padded to 16 bytes
+    want_local = torch.cat([pad(p.grad) for p in lin.parameters()])
     red.reduce(); red.wait()
     gathered = [torch.zeros_like(local) for _ in range(w)]
     dist.all_gather(gathered, local)
     want = torch.stack(gathered).mean(0)
     ok = torch.equal(local, want_local) and torch.allclose(red.flat, want, atol=1e-7) and all(
-        torch.equal(v, red.flat[o:o + v.numel()].view_as(v))
-        for v, o in zip(red.views, [0] + list(torch.tensor([v.numel() for v in red.views]).cumsum(0)[:-1])))
+        torch.equal(v, red.flat[o:o + v.numel()].view_as(v)) and o % 4 == 0
+        for v, o in zip(red.views, red.offsets))
     # ---- the benchmark's gradient path: sinks (kernels add straight into the flat buffer), compaction, bucketed all-reduce
     from spike2former_amd import ops
     params = list(lin.parameters())

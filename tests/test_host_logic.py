@@ -112,7 +112,10 @@ def test_flat_grad_buffer_sinks_and_compaction():
     red.zero()
     ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
     red.gather()
-    assert red.flat.tolist() == [1.0] * 3 + [0.0] * 5 + [2.0] * 2 + [0.0] * 4
+    # slots are padded to 16 bytes (4 floats): 3 -> 4, 5 -> 8, 2 -> 4, 4 -> 4; the pads stay zero
+    Z = [0.0]
+    assert red.offsets == [0, 4, 12, 16] and all(v.data_ptr() % 16 == 0 for v in red.views)
+    assert red.flat.tolist() == [1.0] * 3 + Z + [0.0] * 8 + [2.0] * 2 + Z * 2 + [0.0] * 4
     try:
         red.install_sinks()
         assert set(ops.GRAD_SINKS) == {p.data_ptr() for p in ps}
@@ -123,18 +126,28 @@ def test_flat_grad_buffer_sinks_and_compaction():
         ops._sink_for(ps[3]).add_(1.5)
         ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
         red.gather()                                       # not compacted yet: one copy per run
-        assert red.flat.tolist() == [1.0] * 3 + [0.0, 1.0, 2.0, 3.0, 4.0] + [2.0] * 2 + [1.5] * 4
+        assert red.flat.tolist() == [1.0] * 3 + Z + [0.0, 1.0, 2.0, 3.0, 4.0] + Z * 3 + [2.0] * 2 + Z * 2 + [1.5] * 4
         red.compact()
-        assert [p.numel() for p in red.params] == [3, 2, 5, 4] and red._dense_elems == 5
+        assert [p.numel() for p in red.params] == [3, 2, 5, 4] and red._dense_elems == 8 and red.offsets == [0, 4, 8, 16]
+        assert all(v.data_ptr() % 16 == 0 for v in red.views)
         # step 2 in the compacted layout
         red.zero()
         ops._sink_for(ps[1]).add_(torch.arange(5.0))
         ops._sink_for(ps[3]).add_(1.5)
         ps[0].grad, ps[2].grad = torch.ones(3), torch.full((2,), 2.0)
         red.gather()
-        assert red.flat.tolist() == [1.0] * 3 + [2.0] * 2 + [0.0, 1.0, 2.0, 3.0, 4.0] + [1.5] * 4
+        assert red.flat.tolist() == [1.0] * 3 + Z + [2.0] * 2 + Z * 2 + [0.0, 1.0, 2.0, 3.0, 4.0] + Z * 3 + [1.5] * 4
         for p, v in zip(red.params, red.views):
             assert v.shape == p.shape and ops._sink_for(p).data_ptr() == v.data_ptr()
+        # a parameter that changes sides after compact() would lose its gradient silently: both directions raise
+        red.zero()
+        ps[0].grad, ps[2].grad, ps[1].grad = torch.ones(3), torch.full((2,), 2.0), torch.ones(5)      # sunk parameter, tensor gradient
+        with pytest.raises(RuntimeError, match="sink region"):
+            red.gather()
+        red.zero()
+        ps[0].grad = torch.ones(3)                                                                     # dense parameter, no tensor
+        with pytest.raises(RuntimeError, match="dense region"):
+            red.gather()
         # an address is not an identity: a sink is only handed to the parameter it was registered for, and dropping the
         # buffer detaches the (process-global) table
         stale = torch.nn.Parameter(torch.zeros(5))

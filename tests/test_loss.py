@@ -69,6 +69,17 @@ def test_unsupported_variants_raise():
         MaskFormerLoss(3, 4, train_cfg=dict(assigner=dict(match_costs=[dict(type="mmdet.IoUCost")])))
 
 
+def test_label_maps_outside_the_byte_range_raise():
+    """seg_as_u8 must not wrap an out-of-range label into a valid class id (the reference fails loudly in cross-entropy)."""
+    crit = MaskFormerLoss(3, 4)
+    ok = torch.tensor([[[0, 2, 255], [1, 255, 2]]])
+    assert crit.seg_as_u8(ok).tolist() == [[[0, 2, 255], [1, 255, 2]]]
+    assert crit.seg_as_u8(torch.tensor([[[0, -100, 2]]]), ignore_index=-100).tolist() == [[[0, 255, 2]]]
+    for bad in (torch.tensor([[[0, 256, 1]]]), torch.tensor([[[0, -1, 1]]]), torch.tensor([[[0, 511, 1]]])):
+        with pytest.raises(ValueError, match="outside 0..255"):
+            crit.seg_as_u8(bad)
+
+
 # ------------------------------------------------------------------------------------------------ semantic-map path (GPU)
 def _run_semantic(g, name):
     K = int(g[f"{name}_K"])
