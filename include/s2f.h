@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 16
+#define S2F_ABI_VERSION 17
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -106,7 +106,8 @@ int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask,
 /* ---- BatchNorm fused with the conv bias, the residual add and the following Q_IFNode -------------------
  * Replaces the reference's chain  t = conv(x) + b ; u = BatchNorm(t) [+ residual] ; y = Q_IFNode(u)  (e.g. MS_ConvBlock,
  * SepConv, MS_MLP: mmseg/models/backbones/sdtv2.py:167-255; every Sequential(conv, BN) + Q_IFNode of the head), which
- * runs as ~12 ATen elementwise kernels forward and as many backward.  z: [N, C, L] channel-major, L % 4 == 0.
+ * runs as ~12 ATen elementwise kernels forward and as many backward.  z: [N, C, L] channel-major, any L >= 1 (rows of
+ * L % 4 != 0 elements take element-wise kernels: odd shapes only, e.g. a 10-query decoder; no map of the path at its real sizes).
  *
  * s2f_bn_stats (training only): per-channel sum / sum of squares of (z + conv_bias?) accumulated into sums_zeroed
  *   (double[2C], MUST be zero on entry -- the host hands out slices of one arena cleared once per step).
@@ -288,6 +289,28 @@ int s2f_pgemm_conv3x3_bf16(const uint16_t* w_pack, const uint16_t* X, const floa
                            int W, int cfg, void* stream);
 int s2f_pgemm_conv3x3_f32(const uint16_t* w_pack, const float* X, float* Y, int batch, int M, int C, int H, int W, int cfg,
                           void* stream);
+/* BatchNorm statistics from the producing GEMM's epilogue, without atomics (round 4; reference chain conv -> BatchNorm ->
+ * Q_IFNode: mmseg/models/backbones/sdtv2.py:222-255, 304-333).  The `_stats` forms of the three forward
+ * products above (no bias, all three weight terms, automatic tile) additionally store, per output row and per workgroup tile
+ * (128 columns of one batch element), the fp32 sum and sum of squares of the tile's values:
+ *   bn_partials[(p * C + row) * 2 + {0, 1}],   p = b * ceil(N / 128) + column tile,   P = s2f_bn_partials_count(batch, N) of them
+ * per row (plain stores: no atomics, nothing to zero, deterministic).  C = M, or `partials_channels` for s2f_pgemm_dx_f32_stats
+ * (a group of a grouped product writes its rows into a wider table: pass bn_partials + 2 * first_row).
+ * s2f_bn_act_fwd_partials is s2f_bn_act_fwd in training mode taking these partials instead of the sums of s2f_bn_stats: the
+ * apply kernels add the P partials of a channel in fp64 in a fixed order (the statistics are those of z; conv_bias shifts the
+ * mean).  The statistics pass over z -- one read of the tensor and one launch per BatchNorm -- disappears. */
+int64_t s2f_bn_partials_count(int batch, int N);
+int s2f_pgemm_nn_bf16_stats(const uint16_t* a_pack, const uint16_t* X, float* Y, float* bn_partials, int batch, int M, int N, int K,
+                            void* stream);
+int s2f_pgemm_conv3x3_bf16_stats(const uint16_t* w_pack, const uint16_t* X, float* Y, float* bn_partials, int batch, int M, int C,
+                                 int H, int W, void* stream);
+int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
+                           float* bn_partials, int partials_channels, int batch, int Mo, int Ki, int N, void* stream);
+int s2f_bn_act_fwd_partials(const float* z, const float* conv_bias, const float* partials, int64_t P, float* stat_out,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                            const float* beta, const float* residual, float* u_out, const float* v_in, void* y, float* v_out,
+                            uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L, float momentum, float eps,
+                            float vth, int D, int y_bf16, void* stream);
 /* The gradient of a GEMM-produced pre-activation as THREE bf16 PLANES hi | mid | lo (gz = hi + mid + lo to 2^-24; plane p at
  * gz_split + p * N C L): s2f_bn_act_bwd_split is s2f_bn_act_bwd writing that form instead of fp32 (6 instead of 4 bytes per
  * element), s2f_pgemm_dx_split the input-gradient product reading it (plane p of batch b at G_split + p * plane_stride +

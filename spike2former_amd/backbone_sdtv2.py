@@ -246,11 +246,13 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         w1 = ops.cat_params(t["w1"]).view(3 * C, C)
         w1._s2f_version = sum(p._version for p in t["w1"])              # for the cached bf16 split (ops.split_weight)
         w1._s2f_owner = t["w1"][0]
-        z = ops.spike_gemm(s.view(T * B, C, N), w1).view(T * B, 3 * C, H, W)          # the three first 1x1 convs: one GEMM
+        z = ops.spike_gemm(s.view(T * B, C, N), w1, stats=training)                    # the three first 1x1 convs: one GEMM
+        z = ops.carry_stats(z, z.view(T * B, 3 * C, H, W))
         z, _, border = bn_act(z, None, bn1, want_border=True)
         z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, border)
         # second 1x1: three products on the channel groups of z, each with its own parameter (cached pack, gradient sink)
-        z = ops.dense_gemm(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]]).view(T * B, 3 * C, H, W)
+        z = ops.dense_gemm(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]], stats=training)
+        z = ops.carry_stats(z, z.view(T * B, 3 * C, H, W))
         z, _ = bn_act(z, None, bn2)
         _, y = bn_act(z, None, bn3, lif=self.q_spike)     # q / k / v neurons: pure and identical here (checked by the caller)
         for wb in out:

@@ -30,12 +30,13 @@ def spikes_in(*convs):
         c.spike_input = True
 
 
-def _gemm_nc(weight2d, x3, bias, spike_input=False):
-    """x3 [N, K, L] (tensor or ops.Spikes), weight2d [M, K] -> [N, M, L]."""
+def _gemm_nc(weight2d, x3, bias, spike_input=False, stats=False):
+    """x3 [N, K, L] (tensor or ops.Spikes), weight2d [M, K] -> [N, M, L].  stats: the module is in training mode -- a BatchNorm
+    that follows can take its statistics from the product's epilogue (ops.BN_PARTIALS)."""
     if (spike_input or isinstance(x3, ops.Spikes)) and ops.SPIKE_GEMM_ENABLED and x3.shape[2] % 4 == 0:
-        return ops.spike_gemm(x3, weight2d, bias)       # bf16 matrix cores, exact for spike activations
+        return ops.spike_gemm(x3, weight2d, bias, stats=stats)       # bf16 matrix cores, exact for spike activations
     # general fp32 input: ops.dense_gemm (6-pass packed-weight kernel; the library GEMM only for shapes it does not take)
-    y = ops.dense_gemm(ops.spikes_float(x3), weight2d)
+    y = ops.dense_gemm(ops.spikes_float(x3), weight2d, stats=stats and bias is None)
     if bias is not None:
         y = y + bias.view(1, -1, 1)
     return y
@@ -64,10 +65,12 @@ class Conv2d(nn.Conv2d):
         N, C, H, W = x.shape
         M = self.out_channels
         kh, kw = self.kernel_size
+        stats = self.training and bias is None
         if kh == 1 and kw == 1 and self.stride == (1, 1) and self.padding == (0, 0):
-            return _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias, self.spike_input).view(N, M, H, W)
+            y = _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias, self.spike_input, stats)
+            return ops.carry_stats(y, y.view(N, M, H, W))
         if (self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.dilation == (1, 1)):
-            return ops.conv_dense(x, self.weight, bias, self.stride[0], self.padding[0], self.spike_input)
+            return ops.conv_dense(x, self.weight, bias, self.stride[0], self.padding[0], self.spike_input, stats=stats)
         Ho = (H + 2 * self.padding[0] - self.dilation[0] * (kh - 1) - 1) // self.stride[0] + 1
         Wo = (W + 2 * self.padding[1] - self.dilation[1] * (kw - 1) - 1) // self.stride[1] + 1
         cols = F.unfold(ops.spikes_float(x), (kh, kw), self.dilation, self.padding, self.stride)          # [N, C*kh*kw, Ho*Wo]
@@ -87,4 +90,4 @@ class Conv1d(nn.Conv1d):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         assert self.kernel_size == (1,) and self.stride == (1,) and self.groups == 1, "only k=1 Conv1d is on the path"
-        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias, self.spike_input)
+        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias, self.spike_input, self.training and bias is None)

@@ -78,6 +78,24 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
   block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
 }
 
+// Any row length (L % 4 != 0: rows are not 16-byte aligned): the same reduction with one element per thread and step.  Only
+// odd shapes land here (e.g. a decoder with 10 queries in the shrunken test configuration); nothing of the path at its real sizes.
+__global__ __launch_bounds__(kBlock) void bn_stats_any_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                              double* __restrict__ sums, int N, int C, int L, int slice) {
+  const int c = blockIdx.x;
+  const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
+  const float b = bias ? bias[c] : 0.0f;
+  const int len = l1 - l0, total = N * len;
+  float ps = 0.f, pq = 0.f;
+  for (int id = threadIdx.x; id < total; id += kBlock) {
+    const int n = id / len, q = id - n * len;
+    const float a = z[((int64_t)n * C + c) * L + l0 + q] + b;
+    ps += a;
+    pq += a * a;
+  }
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
+}
+
 // Per-channel statistics derived identically by every lane that needs them (deterministic: same inputs, same ops).
 // training: mean / biased variance from the fp64 sums of bn_stats_kernel -- fp64 multiplies by the precomputed 1/count,
 // no fp64 division (a wave-level fp64 divide per tile made the streaming kernel VALU-bound: 3.7 vs 5.3 TB/s);
@@ -85,22 +103,60 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
 struct ChanStat {
   float mean, rstd, var;
 };
+// (s1, s2) = sum and sum of squares of the channel; `shift` is added to the mean (statistics taken of z by a GEMM epilogue, the
+// BatchNorm input being z + conv_bias: the variance does not see the constant)
+__device__ __forceinline__ ChanStat chan_stat_of(double s1, double s2, double shift, double inv_count, float eps) {
+  ChanStat r;
+  const double m = s1 * inv_count;
+  double v = s2 * inv_count - m * m;
+  if (v < 0) v = 0;
+  r.mean = (float)(m + shift);
+  r.var = (float)v;
+  r.rstd = 1.0f / sqrtf(r.var + eps);
+  return r;
+}
 __device__ __forceinline__ ChanStat chan_stat(const double* __restrict__ sums, const float* __restrict__ running_mean,
                                               const float* __restrict__ running_var, int c, double inv_count, float eps,
                                               int training) {
+  if (training) return chan_stat_of(sums[2 * c], sums[2 * c + 1], 0.0, inv_count, eps);
   ChanStat r;
-  if (training) {
-    const double m = sums[2 * c] * inv_count;
-    double v = sums[2 * c + 1] * inv_count - m * m;
-    if (v < 0) v = 0;
-    r.mean = (float)m;
-    r.var = (float)v;
-  } else {
-    r.mean = running_mean[c];
-    r.var = running_var[c];
-  }
+  r.mean = running_mean[c];
+  r.var = running_var[c];
   r.rstd = 1.0f / sqrtf(r.var + eps);
   return r;
+}
+// Statistics handed over as per-tile PARTIALS of the producing GEMM's epilogue (pgemm.hip epi_row_partials): part[(p * C + c) * 2 +
+// {0, 1}], p < P.  The P partials of a channel are added in fp64 in a fixed order -- by one thread (few partials: consecutive
+// threads read consecutive channels), or strided over the lanes of a wavefront and folded by shuffles.
+__device__ __forceinline__ ChanStat chan_stat_partials_thread(const float* __restrict__ part, int P, int C, int c, float bias_c,
+                                                              double inv_count, float eps) {
+  double a = 0, b = 0;
+  for (int p = 0; p < P; ++p) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)p * C + c) * 2);
+    a += (double)v.x;
+    b += (double)v.y;
+  }
+  return chan_stat_of(a, b, (double)bias_c, inv_count, eps);
+}
+__device__ __forceinline__ ChanStat chan_stat_partials_wave(const float* __restrict__ part, int P, int C, int c, float bias_c,
+                                                            double inv_count, float eps, int lane) {
+  double a = 0, b = 0;
+  for (int p0 = lane; p0 < P; p0 += 4 * 64) {          // four loads in flight per lane
+    float2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 64;
+      v[u] = p < P ? *reinterpret_cast<const float2*>(part + ((int64_t)p * C + c) * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a += (double)v[u].x;
+      b += (double)v[u].y;
+    }
+  }
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  return chan_stat_of(a, b, (double)bias_c, inv_count, eps);
 }
 
 // channel of the element at flat index `base` in [N, C, L]; 32-bit division when the tensor has < 2^32 elements
@@ -156,9 +212,42 @@ __device__ __forceinline__ void st4_bf16_nt(float* p, int64_t base, const Tile4&
   __builtin_nontemporal_store(v, reinterpret_cast<u2*>(reinterpret_cast<unsigned short*>(p) + base));
 }
 
+// ANYL forms of the tile accesses: element by element, each guarded by the tensor's end (rows of L % 4 != 0 elements: a
+// lane's four elements may lie in two channel rows, and only the tensor's start is known to be aligned)
+template <bool ANYL>
+__device__ __forceinline__ Tile4 ld4g(const float* p, int64_t base, int64_t total) {
+  if (!ANYL) return ld4(p + base);
+  Tile4 t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t.a[j] = base + j < total ? p[base + j] : 0.f;
+  return t;
+}
+template <bool ANYL>
+__device__ __forceinline__ void st4g(float* p, int64_t base, int64_t total, const Tile4& t) {
+  if (!ANYL) {
+    st4(p + base, t);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < total) p[base + j] = t.a[j];
+}
+template <bool ANYL>
+__device__ __forceinline__ void st4g_bf16(float* p, int64_t base, int64_t total, const Tile4& t) {
+  if (!ANYL) {
+    st4_bf16(p, base, t);
+    return;
+  }
+  unsigned short* q = reinterpret_cast<unsigned short*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < total) q[base + j] = (unsigned short)(__float_as_uint(t.a[j]) >> 16);      // exact for spikes
+}
+
 // u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
 // YB: the spikes y are written as bf16 (2 bytes / element).
-template <bool LIF, bool HAS_V, bool YB>
+// ANYL: any row length -- the channel, the validity and the accesses are per element (see ld4g).
+template <bool LIF, bool HAS_V, bool YB, bool ANYL = false>
 __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                           const double* __restrict__ sums, float* __restrict__ stat,
                                                           float* __restrict__ running_mean,
@@ -171,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
                                                           uint64_t* __restrict__ mask,
                                                           unsigned long long* __restrict__ stats, int64_t total, int C,
                                                           int L, double inv_count, float unbias, float momentum,
-                                                          float eps, int training, float vth, float Df) {
+                                                          float eps, int training, float vth, float Df,
+                                                          const float* __restrict__ part, int P) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
@@ -187,14 +277,16 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
   auto request = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t base = tile * 256 + lane * 4;
     if (tile < ntiles && base < total) {
-      zn = ld4(z + base);
-      if (res) rn = ld4(res + base);
-      if (LIF && HAS_V) vn = ld4(v_in + base);
+      zn = ld4g<ANYL>(z, base, total);
+      if (res) rn = ld4g<ANYL>(res, base, total);
+      if (LIF && HAS_V) vn = ld4g<ANYL>(v_in, base, total);
     }
   };
   request(wave0);
   for (int c = threadIdx.x; c < C; c += kBlock) {
-    const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+    const ChanStat cs = (training && part != nullptr)
+                            ? chan_stat_partials_thread(part, P, C, c, bias ? bias[c] : 0.f, inv_count, eps)
+                            : chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
     sstat[c] = cs.mean;
     sstat[C + c] = cs.rstd;
     sstat[2 * C + c] = cs.var;
@@ -208,27 +300,38 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
     const Tile4 zv = zn, rv = rn, vv = vn;
     request(tile + nwaves);
     if (ok) {
-      const int c = channel_of(base, C, L, small);
-      const float b = bias ? bias[c] : 0.f;
-      const float mean = sstat[c], rstd = sstat[C + c], g = gamma[c], be = beta[c];
-      if (base == (int64_t)c * L) {
-        // the lane owning the first element of channel c (row n = 0) publishes the statistics for the backward pass
-        // and performs the running-statistics update (torch.nn.BatchNorm: momentum, unbiased variance)
+      // the lane owning the first element of channel c (row n = 0) publishes the statistics for the backward pass
+      // and performs the running-statistics update (torch.nn.BatchNorm: momentum, unbiased variance)
+      auto publish = [&](int c, float mean, float rstd, float g, float be) __attribute__((always_inline)) {
         stat[c] = mean;
         stat[C + c] = rstd;
-        float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+        float rm = running_mean ? running_mean[c] : 0.f, rvv = running_var ? running_var[c] : 1.f;
         if (training && running_mean != nullptr) {
           rm = (1.f - momentum) * rm + momentum * mean;
-          rv = (1.f - momentum) * rv + momentum * (sstat[2 * C + c] * unbias);
+          rvv = (1.f - momentum) * rvv + momentum * (sstat[2 * C + c] * unbias);
           running_mean[c] = rm;
-          running_var[c] = rv;
+          running_var[c] = rvv;
         }
-        stat[2 * C + c] = be - rm * g / sqrtf(rv + eps);      // BN(0) from the (updated) running statistics
+        stat[2 * C + c] = be - rm * g / sqrtf(rvv + eps);      // BN(0) from the (updated) running statistics
         if (training && c == 0 && num_batches != nullptr) *num_batches += 1;
-      }
+      };
+      int c = channel_of(base, C, L, small);
+      float b = bias ? bias[c] : 0.f;
+      float mean = sstat[c], rstd = sstat[C + c], g = gamma[c], be = beta[c];
+      if (!ANYL && base == (int64_t)c * L) publish(c, mean, rstd, g, be);
       Tile4 uo, yo, vo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (ANYL) {
+          if (base + j >= total) {
+            uo.a[j] = yo.a[j] = vo.a[j] = 0.f;
+            continue;
+          }
+          c = channel_of(base + j, C, L, small);
+          b = bias ? bias[c] : 0.f;
+          mean = sstat[c], rstd = sstat[C + c], g = gamma[c], be = beta[c];
+          if (base + j == (int64_t)c * L) publish(c, mean, rstd, g, be);
+        }
         float u = ((zv.a[j] + b) - mean) * rstd * g + be;
         if (res) u += rv.a[j];
         uo.a[j] = u;
@@ -241,13 +344,13 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
           cnz += ((uint32_t)s != 0);
         }
       }
-      if (u_out) st4(u_out + base, uo);
+      if (u_out) st4g<ANYL>(u_out, base, total, uo);
       if (LIF) {
         if (YB)
-          st4_bf16(y, base, yo);
+          st4g_bf16<ANYL>(y, base, total, yo);
         else
-          st4(y + base, yo);
-        if (v_out) st4(v_out + base, vo);
+          st4g<ANYL>(y, base, total, yo);
+        if (v_out) st4g<ANYL>(v_out, base, total, vo);
       }
     }
     if (LIF) {
@@ -346,7 +449,33 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __re
   block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
 }
 
+// any row length (see bn_stats_any_kernel): one element per thread and step; the in-range bit of flat element e is bit
+// (e & 255) >> 2 of mask word (e >> 8) * 4 + (e & 3)
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce_any_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                                   const float* __restrict__ stat, const float* __restrict__ g_u,
+                                                                   const float* __restrict__ g_y, const float* __restrict__ g_v,
+                                                                   const uint64_t* __restrict__ mask, double* __restrict__ sums,
+                                                                   int N, int C, int L, int slice, float vth, float Df) {
+  const int c = blockIdx.x;
+  const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
+  const float b = bias ? bias[c] : 0.0f, mean = stat[c], rstd = stat[C + c];
+  const int len = l1 - l0, total = N * len;
+  float ps = 0.f, pq = 0.f;
+  for (int id = threadIdx.x; id < total; id += kBlock) {
+    const int n = id / len, q = id - n * len;
+    const int64_t e = ((int64_t)n * C + c) * L + l0 + q;
+    const bool m = mask ? ((mask[(e >> 8) * 4 + (e & 3)] >> ((e & 255) >> 2)) & 1ull) : false;
+    const float gu = form_gu(g_u != nullptr, g_u ? g_u[e] : 0.f, g_y != nullptr, g_y ? g_y[e] : 0.f, g_v != nullptr,
+                             g_v ? g_v[e] : 0.f, m, vth, Df);
+    const float xhat = ((z[e] + b) - mean) * rstd;
+    ps += gu;
+    pq += gu * xhat;
+  }
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
+}
+
 // train: gz = gamma * rstd * (gu - sum_gu/cnt - xhat * sum_gux/cnt) ;  eval: gz = gamma * rstd * gu ;  g_res = gu
+template <bool ANYL>
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                               const float* __restrict__ stat,
                                                               const float* __restrict__ gamma,
@@ -368,10 +497,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
   auto request = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t base = tile * 256 + lane * 4;
     if (tile < ntiles && base < total) {
-      zn = ld4(z + base);
-      if (g_u) an = ld4(g_u + base);
-      if (g_y) bn = ld4(g_y + base);
-      if (g_v) cn = ld4(g_v + base);
+      zn = ld4g<ANYL>(z, base, total);
+      if (g_u) an = ld4g<ANYL>(g_u, base, total);
+      if (g_y) bn = ld4g<ANYL>(g_y, base, total);
+      if (g_v) cn = ld4g<ANYL>(g_v, base, total);
       if (mask) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) mn[j] = mask[tile * 4 + j];
@@ -391,24 +520,42 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
     const uint64_t mw[4] = {mn[0], mn[1], mn[2], mn[3]};
     request(tile + nwaves);
     if (base >= total) continue;
-    const int c = channel_of(base, C, L, small);
-    const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
-    const float m1 = sstat[c], m2 = sstat[C + c];
-    if (base == (int64_t)c * L) {          // dbeta = sum(gu), dgamma = sum(gu * xhat)
+    int c = channel_of(base, C, L, small);
+    float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
+    float m1 = sstat[c], m2 = sstat[C + c];
+    if (!ANYL && base == (int64_t)c * L) {          // dbeta = sum(gu), dgamma = sum(gu * xhat)
       dbeta[c] = (float)sums[2 * c];
       dgamma[c] = (float)sums[2 * c + 1];
     }
     Tile4 o, r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (ANYL) {
+        if (base + j >= total) {
+          o.a[j] = r.a[j] = 0.f;
+          continue;
+        }
+        c = channel_of(base + j, C, L, small);
+        b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g = gamma[c];
+        m1 = sstat[c], m2 = sstat[C + c];
+        if (base + j == (int64_t)c * L) {
+          dbeta[c] = (float)sums[2 * c];
+          dgamma[c] = (float)sums[2 * c + 1];
+        }
+      }
       const bool m = mask ? ((mw[j] >> lane) & 1ull) : false;
       const float gu = form_gu(g_u != nullptr, a.a[j], g_y != nullptr, bb.a[j], g_v != nullptr, cc.a[j], m, vth, Df);
       const float xhat = ((zv.a[j] + b) - mean) * rstd;
       o.a[j] = (g * rstd) * ((gu - m1) - xhat * m2);
       r.a[j] = gu;
     }
-    store_gz(gz, gzs, total, base, o);
-    if (g_res) st4(g_res + base, r);
+    if (ANYL) {
+      st4g<true>(gz, base, total, o);          // no bf16-plane form for odd rows (the pre-split protocol needs numel % 4 == 0)
+      if (g_res) st4g<true>(g_res, base, total, r);
+    } else {
+      store_gz(gz, gzs, total, base, o);
+      if (g_res) st4(g_res + base, r);
+    }
   }
 }
 
@@ -449,7 +596,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out,
     const float* __restrict__ v_in, float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask,
     unsigned long long* __restrict__ stats, int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk,
-    double inv_count, float unbias, float momentum, float eps, int training, float vth, float Df) {
+    double inv_count, float unbias, float momentum, float eps, int training, float vth, float Df,
+    const float* __restrict__ part, int P) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
   uint32_t t = wave * chunk;
@@ -467,11 +615,42 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
   };
 #pragma unroll
   for (int i = 0; i < kAhead; ++i) request(i, t + i);
-  for (int c = threadIdx.x; c < C; c += kBlock) {
-    const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
-    sstat[c] = cs.mean;
-    sstat[C + c] = cs.rstd;
-    sstat[2 * C + c] = cs.var;
+  if (training && part != nullptr) {
+    // statistics from the producer's per-tile partials: only the channels this workgroup's run of tiles touches (a few rows of
+    // a large map) -- with hundreds to thousands of partials per channel, all C channels per workgroup would re-read the whole
+    // partial buffer once per workgroup
+    const uint32_t wg_t0 = blockIdx.x * kWaves * chunk, wg_t1 = min(ntiles, wg_t0 + kWaves * chunk);
+    if (wg_t0 < wg_t1) {
+      const uint64_t e_last = min((uint64_t)total, (uint64_t)wg_t1 * 256u) - 1u;
+      const uint32_t row0 = (uint32_t)((uint64_t)wg_t0 * 256u / L), row1 = (uint32_t)(e_last / L);
+      const uint32_t nch = min((uint32_t)C, row1 - row0 + 1u), c0 = row0 % (uint32_t)C;
+      if (P <= 32) {
+        for (uint32_t k = threadIdx.x; k < nch; k += kBlock) {
+          const uint32_t c = (c0 + k) % (uint32_t)C;
+          const ChanStat cs = chan_stat_partials_thread(part, P, C, (int)c, bias ? bias[c] : 0.f, inv_count, eps);
+          sstat[c] = cs.mean;
+          sstat[C + c] = cs.rstd;
+          sstat[2 * C + c] = cs.var;
+        }
+      } else {
+        for (uint32_t k = (uint32_t)wave_id_uniform(); k < nch; k += kWaves) {
+          const uint32_t c = (c0 + k) % (uint32_t)C;
+          const ChanStat cs = chan_stat_partials_wave(part, P, C, (int)c, bias ? bias[c] : 0.f, inv_count, eps, lane);
+          if (lane == 0) {
+            sstat[c] = cs.mean;
+            sstat[C + c] = cs.rstd;
+            sstat[2 * C + c] = cs.var;
+          }
+        }
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+      const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+      sstat[c] = cs.mean;
+      sstat[C + c] = cs.rstd;
+      sstat[2 * C + c] = cs.var;
+    }
   }
   __syncthreads();
   RowWalk w = walk_begin(t, L, (uint32_t)C);
@@ -1035,10 +1214,11 @@ inline int grid_flat(int64_t total) {
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// Any L >= 1 is taken: rows of L % 4 != 0 elements run on the element-wise ANYL kernels (odd shapes only; the vector forms need
+// a lane's four elements in one 16-byte-aligned group of one channel row).
 int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
   S2F_REQUIRE(N > 0 && C > 0 && L > 0, S2F_EINVAL, "%s: bad shape N=%lld C=%lld L=%lld", who, (long long)N, (long long)C,
               (long long)L);
-  S2F_REQUIRE((L & 3) == 0, S2F_EINVAL, "%s: L=%lld must be a multiple of 4", who, (long long)L);
   S2F_REQUIRE(N * C * L < (1ll << 40) && L < (1ll << 31) && C <= 5120 && N < (1ll << 31), S2F_EINVAL,
               "%s: shape too large (C <= 5120: per-channel statistics are staged in 60 KiB of LDS)", who);
   return S2F_OK;
@@ -1053,33 +1233,41 @@ extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums
   S2F_REQUIRE(z && sums_zeroed, S2F_EINVAL, "s2f_bn_stats: null z/workspace");
   int rc = check_shape("s2f_bn_stats", N, C, L);
   if (rc) return rc;
-  S2F_REQUIRE(s2f_aligned16(z), S2F_EALIGN, "s2f_bn_stats: z must be 16-byte aligned");
   int slice;
   const int S = pick_slices((int)C, (int)L, slice);
+  if (L & 3) {
+    S2F_LAUNCH(true, true, bn_stats_any_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, (hipStream_t)stream, z, conv_bias,
+               sums_zeroed, (int)N, (int)C, (int)L, slice);
+    return s2f_check_launch("s2f_bn_stats");
+  }
+  S2F_REQUIRE(s2f_aligned16(z), S2F_EALIGN, "s2f_bn_stats: z must be 16-byte aligned");
   S2F_LAUNCH(true, true, bn_stats_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, (hipStream_t)stream, z, conv_bias,
                      sums_zeroed, (int)N, (int)C, (int)L, slice);
   return s2f_check_launch("s2f_bn_stats");
 }
 
-extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
-                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
-                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
-                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
-                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
+static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double* sums, const float* part, int64_t P,
+                           float* stat_out, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           const float* gamma, const float* beta, const float* residual, float* u_out, const float* v_in,
+                           void* y_out, float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
+                           float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
   float* y = reinterpret_cast<float*>(y_out);
   S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
-  // sums given for a shape that could go single-pass: the caller already has the statistics (a producer's epilogue, or a probe) --
+  S2F_REQUIRE(!part || (training && !sums && P > 0 && P < (1 << 24) && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
+              "s2f_bn_act_fwd_partials: training only, partials instead of sums, 0 < P < 2^24, 8-byte aligned");
+  // statistics given for a shape that could go single-pass: the caller already has them (a producer's epilogue, or a probe) --
   // take the apply path, which is not tied to one workgroup per channel
-  const bool single = training && sums == nullptr && single_pass_ok(N, C, L);
-  S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
-              "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats, eval needs the running statistics");
+  const bool single = training && sums == nullptr && part == nullptr && single_pass_ok(N, C, L);
+  S2F_REQUIRE(training ? (single || sums != nullptr || part != nullptr) : (running_mean && running_var), S2F_EINVAL,
+              "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats (or a producer's partials), eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
   S2F_REQUIRE(!(y && y_bf16) || s2f_bf16_spikes_exact(D), S2F_EINVAL,
               "s2f_bn_act_fwd: bf16 spikes need D a power of two <= 128 (D=%d)", D);
   int rc = check_shape("s2f_bn_act_fwd", N, C, L);
   if (rc) return rc;
-  S2F_REQUIRE(s2f_aligned16(z) && s2f_aligned16(residual) && s2f_aligned16(u_out) && s2f_aligned16(v_in) &&
-                  s2f_aligned16(y) && s2f_aligned16(v_out),
+  const bool anyl = (L & 3) != 0;
+  S2F_REQUIRE(anyl || (s2f_aligned16(z) && s2f_aligned16(residual) && s2f_aligned16(u_out) && s2f_aligned16(v_in) &&
+                       s2f_aligned16(y) && s2f_aligned16(v_out)),
               S2F_EALIGN, "s2f_bn_act_fwd: tensors must be 16-byte aligned");
   const int64_t total = N * C * L;
   hipStream_t s = (hipStream_t)stream;
@@ -1120,7 +1308,8 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
     const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                         \
     S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias, sums,  \
                stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, \
-               ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth, (float)D);          \
+               ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth, (float)D, part,     \
+               (int)P);                                                                                                 \
   } while (0)
 #define S2F_BN_APPLY(LIFV, HASV, YBV)                                                                                   \
   do {                                                                                                                  \
@@ -1128,10 +1317,14 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
       S2F_BN_ROWS_FWD(LIFV, HASV, YBV, true);                                                                           \
     } else if (rows) {                                                                                                  \
       S2F_BN_ROWS_FWD(LIFV, HASV, YBV, false);                                                                          \
+    } else if (anyl) {                                                                                                  \
+      S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV, true>), grid, block, lds, s, z, conv_bias, sums,         \
+                 stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
+                 total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);       \
     } else {                                                                                                            \
       S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, lds, s, z, conv_bias, sums, stat_out,      \
                  running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, \
-                 (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D);                                    \
+                 (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);                      \
     }                                                                                                                   \
   } while (0)
   if (y == nullptr)
@@ -1150,6 +1343,26 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
 #undef S2F_BN_APPLY
 #undef S2F_BN_ROWS_FWD
   return s2f_check_launch("s2f_bn_act_fwd");
+}
+
+extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
+                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
+                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
+  return bn_act_fwd_impl(z, conv_bias, sums, nullptr, 0, stat_out, running_mean, running_var, num_batches_tracked, gamma, beta,
+                         residual, u_out, v_in, y_out, v_out, mask, stats, N, C, L, momentum, eps, training, vth, D, y_bf16, stream);
+}
+
+extern "C" int s2f_bn_act_fwd_partials(const float* z, const float* conv_bias, const float* partials, int64_t P, float* stat_out,
+                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                       const float* gamma, const float* beta, const float* residual, float* u_out,
+                                       const float* v_in, void* y_out, float* v_out, uint64_t* mask, uint64_t* stats, int64_t N,
+                                       int64_t C, int64_t L, float momentum, float eps, float vth, int D, int y_bf16,
+                                       void* stream) {
+  S2F_REQUIRE(partials, S2F_EINVAL, "s2f_bn_act_fwd_partials: null partials");
+  return bn_act_fwd_impl(z, conv_bias, nullptr, partials, P, stat_out, running_mean, running_var, num_batches_tracked, gamma, beta,
+                         residual, u_out, v_in, y_out, v_out, mask, stats, N, C, L, momentum, eps, 1, vth, D, y_bf16, stream);
 }
 
 static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
@@ -1222,9 +1435,18 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
   }
   int slice;
   const int S = pick_slices((int)C, (int)L, slice);
+  if (L & 3) {
+    S2F_REQUIRE(gzs == nullptr, S2F_EINVAL, "s2f_bn_act_bwd_split: rows of L %% 4 != 0 elements have no bf16-plane form");
+    S2F_LAUNCH(true, false, bn_bwd_reduce_any_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y,
+               g_v, mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);
+    S2F_LAUNCH(false, true, bn_bwd_apply_kernel<true>, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z,
+               conv_bias, stat, gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L,
+               1.0 / ((double)N * (double)L), training, vth, (float)D, gzs);
+    return s2f_check_launch("s2f_bn_act_bwd");
+  }
   S2F_LAUNCH(true, false, bn_bwd_reduce_kernel, dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, stat, g_u, g_y, g_v,
                      mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);
-  S2F_LAUNCH(false, true, bn_bwd_apply_kernel, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z, conv_bias, stat, gamma, g_u, g_y,
+  S2F_LAUNCH(false, true, bn_bwd_apply_kernel<false>, dim3(grid_flat(total)), dim3(kBlock), 2 * C * sizeof(float), s, z, conv_bias, stat, gamma, g_u, g_y,
                      g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, (int)C, (int)L,
                      1.0 / ((double)N * (double)L), training, vth, (float)D, gzs);
   return s2f_check_launch("s2f_bn_act_bwd");

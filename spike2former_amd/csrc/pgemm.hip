@@ -163,16 +163,86 @@ struct BnLifEpi {
   float eps, vth, Df, inv_d;
 };
 
+// BatchNorm statistics from the producing GEMM's epilogue, WITHOUT atomics (reference chain conv -> BN ->
+// Q_IFNode, sdtv2.py:222-255, 304-333): per output row the sum and the sum of squares of this workgroup's tile (<= 128 columns, fp32)
+// are stored -- plain stores, one float2 per (workgroup, row) -- at  part[(slot * part_C + row) * 2 + {0, 1}],  slot = b * n_tiles +
+// nt; the BatchNorm apply kernels (bn_lif.hip) add the batch * n_tiles partials of a channel in fp64, in a fixed order (the
+// statistics pass over z -- one full read of the tensor and one launch per BatchNorm -- disappears, and with it the only
+// run-to-run variation of a forward pass: the fp64 atomics of bn_stats_kernel).  Round 3 measured the version with one fp64
+// atomic pair per (wavefront, row): a thousand same-address atomics per launch, 12 ms per step slower.
+// In-lane: sum over the NJ column blocks; across the 32 lanes of a half-wave a butterfly that halves the number of live values
+// per step (16 -> 8 -> 4 -> 2 -> 1: 16 shuffles per quantity instead of 80), which leaves row r = (lane >> 1) & 15 of the 32 x 32
+// accumulator layout in each even lane; across the WNW wavefronts of a row block through LDS (fixed order).
+template <int MI, int NJ, int WMW, int WNW>
+__device__ __forceinline__ void epi_row_partials(const f32x16 (&acc)[MI][NJ], float* __restrict__ part, int part_C,
+                                                 float* scratch, int m0, int n0, int M, int N, int slot, int wm, int wn,
+                                                 int lane, int tid) {
+  constexpr int BM = 32 * MI * WMW, T = 64 * WMW * WNW;
+  __syncthreads();                                 // every wavefront has left the K loop: its LDS stages are free
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float s[16], q[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = q[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool ok = n0 + (wn * NJ + j) * 32 + (lane & 31) < N;      // columns past N hold clamped duplicates
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ok ? acc[i][j][r] : 0.f;
+        s[r] += v;
+        q[r] += v * v;
+      }
+    }
+#define S2F_BFLY(HALF, BIT)                                            \
+  {                                                                    \
+    const bool hi = (lane & BIT) != 0;                                 \
+    _Pragma("unroll") for (int k = 0; k < HALF; ++k) {                 \
+      const float ks = hi ? s[k + HALF] : s[k], ss = hi ? s[k] : s[k + HALF]; \
+      const float kq = hi ? q[k + HALF] : q[k], sq = hi ? q[k] : q[k + HALF]; \
+      s[k] = ks + __shfl_xor(ss, BIT, 64);                             \
+      q[k] = kq + __shfl_xor(sq, BIT, 64);                             \
+    }                                                                  \
+  }
+    S2F_BFLY(8, 16)
+    S2F_BFLY(4, 8)
+    S2F_BFLY(2, 4)
+    S2F_BFLY(1, 2)
+#undef S2F_BFLY
+    s[0] += __shfl_xor(s[0], 1, 64);
+    q[0] += __shfl_xor(q[0], 1, 64);
+    if ((lane & 1) == 0) {
+      const int r = (lane >> 1) & 15;
+      const int row_l = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      *reinterpret_cast<f32x2*>(scratch + (wn * BM + row_l) * 2) = f32x2{s[0], q[0]};
+    }
+  }
+  __syncthreads();
+  for (int row_l = tid; row_l < BM; row_l += T) {
+    if (m0 + row_l < M) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WNW; ++w) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(scratch + (w * BM + row_l) * 2);
+        a += v.x;
+        b += v.y;
+      }
+      *reinterpret_cast<f32x2*>(part + ((int64_t)slot * part_C + m0 + row_l) * 2) = f32x2{a, b};
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // NN:  Y[b] (M x N) = A (M x K, packed) @ X[b] (K x N, bf16 spikes, n contiguous) [+ bias].
 // Block = WMW x WNW wavefronts, wavefront tile (32 MI) x (32 NJ), K step 32, NST LDS stages.
 // EPI = 1: the BatchNorm (+ residual) (+ neuron) epilogue above instead of the plain store.
-template <int MI, int NJ, int WMW, int WNW, int AT, int NST, int EPI = 0>
+template <int MI, int NJ, int WMW, int WNW, int AT, int NST, int EPI = 0, bool STATS = false>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned short* __restrict__ Ap,
                                                               const unsigned short* __restrict__ X,
                                                               const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                               int N, int K, int Kb, int n_tiles, int m_tiles,
-                                                              int64_t x_batch_stride, BnLifEpi ep = BnLifEpi{}) {
+                                                              int64_t x_batch_stride, BnLifEpi ep = BnLifEpi{},
+                                                              float* __restrict__ part = nullptr) {
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW;
   constexpr int A_BYTES = AT * BM * 64, B_BYTES = 32 * BN * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = AT * BM / 16, NB = B_BYTES / 1024;          // 1 KiB copies per stage
@@ -379,6 +449,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
       }
     }
   }
+  if constexpr (STATS)          // (a separate instantiation: the epilogue's registers are not charged to the plain product)
+    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, M, reinterpret_cast<float*>(smem), m0, n0, M, N, b * n_tiles + nt, wm, wn, lane,
+                                       (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -406,11 +479,12 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // the same shape, 880 vs 450 us on [256 <- 256] x 8 x 65536 (72 KiB of LDS and 512 threads per workgroup halve the occupancy).)
 // EPI: 0 = store, 1 = DX = acc + beta * DX, 2 = atomic add into a zeroed DX (gridDim.z workgroups share the contraction: the
 // decoder's 100-token products with a 2 048-long contraction have 16 output tiles).
-template <int MI, int NJ, int WMW, int WNW, int EPI, int KS = 1>
+template <int MI, int NJ, int WMW, int WNW, int EPI, int KS = 1, bool STATS = false>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
                                                                   int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
-                                                                  int64_t g_batch_stride, int64_t dx_batch_stride) {
+                                                                  int64_t g_batch_stride, int64_t dx_batch_stride,
+                                                                  float* __restrict__ part = nullptr, int part_C = 0) {
   constexpr bool BETA = EPI == 1;
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   constexpr int KC = 16 * KS;                                      // KS 16-row slices per step (one barrier per step)
@@ -605,6 +679,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
         }
       }
     }
+  if constexpr (EPI == 0 && STATS)          // the product as a FORWARD convolution of a dense input (SepConv.pwconv2, RepConv's second 1x1)
+    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, part_C, reinterpret_cast<float*>(smem), m0, n0, Ki, N, b * n_tiles + nt, wm, wn,
+                                       lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -805,10 +882,11 @@ __device__ __forceinline__ f32x4 convp_fix(f32x4 v, ConvPredB p) {
 
 // CONV = false: the plain product  Y[b] = A @ X[b]  (X [K][N] bf16, N % 4 == 0) with the same register-staged activation rows --
 // the row lengths an LDS-DMA cannot take (N % 8 != 0: the decoder's 100-token maps, whose rows start 8-byte aligned only).
-template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true>
+template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true, bool STATS = false>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned short* __restrict__ Ap, const void* __restrict__ Xv,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, int M,
-                                                                int N, int K, int Kb, int n_tiles, int m_tiles, Conv3 geo) {
+                                                                int N, int K, int Kb, int n_tiles, int m_tiles, Conv3 geo,
+                                                                float* __restrict__ part = nullptr) {
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   static_assert(BN == 128, "the activation tile is 128 pixels wide");
   constexpr int A_BYTES = 3 * BM * 64, B_TERM = 32 * BN * 2, B_BYTES = BT * B_TERM, STAGE = A_BYTES + B_BYTES;
@@ -994,6 +1072,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
         }
       }
     }
+  if constexpr (STATS)
+    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, M, reinterpret_cast<float*>(smem), m0, n0, M, N, b * n_tiles + nt, wm, wn, lane,
+                                       tid);
 }
 
 int pick_cfg_nn(int M, int N, int K, int batch, int force) {
@@ -1022,9 +1103,11 @@ extern "C" int s2f_pack_bf16x3_multi(const int64_t* jobs, int njobs, int64_t tot
   return s2f_check_launch("s2f_pack_bf16x3_multi");
 }
 
-extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M,
-                                 int N, int K, int terms, int cfg, void* stream) {
+static int pgemm_nn_impl(const uint16_t* a_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M, int N, int K,
+                         int terms, int cfg, float* part, void* stream) {
   S2F_REQUIRE(a_pack && X && Y, S2F_EINVAL, "s2f_pgemm_nn_bf16: null pointer");
+  S2F_REQUIRE(!part || (!bias && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
+              "s2f_pgemm_nn_bf16_stats: the statistics are those of the product without a bias; partials 8-byte aligned");
   S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && K > 0 && terms >= 1 && terms <= 3, S2F_EINVAL,
               "s2f_pgemm_nn_bf16: bad sizes");
   S2F_REQUIRE((N & 3) == 0, S2F_EINVAL, "s2f_pgemm_nn_bf16: N=%d must be a multiple of 4", N);
@@ -1042,16 +1125,28 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
     const bool wide = c == 7;          // (an environment-forced DMA configuration does not apply to rows of N % 8 != 0)
     if (c == 8) {
       const int m_tiles = (M + 63) / 64;
-      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
-                 M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
+      if (part)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+      else
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
     } else if (wide) {
       const int m_tiles = (M + 127) / 128;
-      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
-                 M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
+      if (part)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+      else
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
     } else {
       const int m_tiles = (M + 63) / 64;
-      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X, bias, Y,
-                 M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0});
+      if (part)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+      else
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X, bias, Y,
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
     }
     return s2f_check_launch("s2f_pgemm_nn_bf16");
   }
@@ -1059,8 +1154,13 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
 #define S2F_PG(MI, NJ, WMW, WNW, ATV, NSTV)                                                                            \
   do {                                                                                                                 \
     const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                     \
-    S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, ATV, NSTV>), dim3(n_tiles * m_tiles, batch),                 \
-               dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{});                     \
+    if (part) {                                                                                                        \
+      if constexpr (ATV == 3)          /* (the statistics entry point always runs all three weight terms) */             \
+        S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, 3, NSTV, 0, true>), dim3(n_tiles * m_tiles, batch),      \
+                   dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{}, part); \
+    } else                                                                                                             \
+      S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, ATV, NSTV>), dim3(n_tiles * m_tiles, batch),               \
+                 dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{}, part); \
   } while (0)
 #define S2F_PG_T(MI, NJ, WMW, WNW, NSTV)          \
   do {                                           \
@@ -1084,6 +1184,19 @@ extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, cons
   return s2f_check_launch("s2f_pgemm_nn_bf16");
 }
 
+extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M,
+                                 int N, int K, int terms, int cfg, void* stream) {
+  return pgemm_nn_impl(a_pack, X, bias, Y, batch, M, N, K, terms, cfg, nullptr, stream);
+}
+
+extern "C" int64_t s2f_bn_partials_count(int batch, int N) { return (int64_t)batch * ((N + 127) / 128); }
+
+extern "C" int s2f_pgemm_nn_bf16_stats(const uint16_t* a_pack, const uint16_t* X, float* Y, float* bn_partials, int batch, int M,
+                                       int N, int K, void* stream) {
+  S2F_REQUIRE(bn_partials, S2F_EINVAL, "s2f_pgemm_nn_bf16_stats: null partials");
+  return pgemm_nn_impl(a_pack, X, nullptr, Y, batch, M, N, K, 3, 0, bn_partials, stream);
+}
+
 extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, const float* conv_bias, const float* running_mean,
                                    const float* running_var, const float* gamma, const float* beta, float eps,
                                    const float* residual, float* u_out, const float* v_in, void* y_bf16, float* v_out,
@@ -1099,7 +1212,7 @@ extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, co
               reinterpret_cast<unsigned short*>(y_bf16), reinterpret_cast<unsigned long long*>(stats), eps, vth, (float)D,
               1.0f / (float)D};
   S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, (hipStream_t)stream,
-             a_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep);
+             a_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr);
   return s2f_check_launch("s2f_gemm_bn_lif_fwd");
 }
 
@@ -1134,8 +1247,10 @@ extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_spli
 }
 
 static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, bool x_fp32, const float* bias, float* Y, int batch,
-                       int M, int C, int H, int W, int cfg, void* stream) {
+                       int M, int C, int H, int W, int cfg, void* stream, float* part = nullptr) {
   S2F_REQUIRE(w_pack && X && Y, S2F_EINVAL, "%s: null pointer", who);
+  S2F_REQUIRE(!part || (!bias && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
+              "%s: the statistics are those of the product without a bias; partials 8-byte aligned", who);
   S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & 3) == 0, S2F_EINVAL,
               "%s: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", who, C, W);
   S2F_REQUIRE((int64_t)C * 9 < (1 << 30) && (int64_t)H * W < (1 << 30), S2F_EINVAL, "%s: too large", who);
@@ -1155,10 +1270,13 @@ static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, b
     const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                       \
     if (x_fp32)                                                                                                          \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 3>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
-                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo);                                                 \
+                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part);                                           \
+    else if (part)                                                                                                       \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, true>), dim3(n_tiles * m_tiles, batch),           \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part);               \
     else                                                                                                                 \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
-                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo);                                                 \
+                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part);                                           \
   } while (0)
   switch (c) {
     case 1: S2F_PGC(2, 2, 2, 2); break;          // 128 x 128, wavefront tiles 64 x 64
@@ -1176,6 +1294,12 @@ extern "C" int s2f_pgemm_conv3x3_bf16(const uint16_t* w_pack, const uint16_t* X,
   return conv_launch("s2f_pgemm_conv3x3_bf16", w_pack, X, false, bias, Y, batch, M, C, H, W, cfg, stream);
 }
 
+extern "C" int s2f_pgemm_conv3x3_bf16_stats(const uint16_t* w_pack, const uint16_t* X, float* Y, float* bn_partials, int batch,
+                                            int M, int C, int H, int W, void* stream) {
+  S2F_REQUIRE(bn_partials, S2F_EINVAL, "s2f_pgemm_conv3x3_bf16_stats: null partials");
+  return conv_launch("s2f_pgemm_conv3x3_bf16_stats", w_pack, X, false, nullptr, Y, batch, M, C, H, W, 0, stream, bn_partials);
+}
+
 extern "C" int s2f_pgemm_conv3x3_f32(const uint16_t* w_pack, const float* X, float* Y, int batch, int M, int C, int H, int W,
                                      int cfg, void* stream) {
   return conv_launch("s2f_pgemm_conv3x3_f32", w_pack, X, true, nullptr, Y, batch, M, C, H, W, cfg, stream);
@@ -1189,9 +1313,11 @@ extern "C" int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, in
   return s2f_check_launch("s2f_pack_bf16x3");
 }
 
-extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX,
-                                int64_t dx_batch_stride, int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream) {
+static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
+                         int batch, int Mo, int Ki, int N, float beta, int cfg, float* part, int part_C, void* stream) {
   if (g_batch_stride == 0) g_batch_stride = (int64_t)Mo * N;
+  S2F_REQUIRE(!part || (beta == 0.f && part_C >= Ki && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
+              "s2f_pgemm_dx_f32_stats: plain-store form only; partials 8-byte aligned, channel count >= rows");
   if (dx_batch_stride == 0) dx_batch_stride = (int64_t)Ki * N;
   S2F_REQUIRE((g_batch_stride & 3) == 0 && (dx_batch_stride & 3) == 0, S2F_EALIGN, "s2f_pgemm_dx_f32: batch strides must keep 16-byte alignment");
   S2F_REQUIRE(w_pack && G && DX, S2F_EINVAL, "s2f_pgemm_dx_f32: null pointer");
@@ -1220,7 +1346,7 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
     const int steps = (Mo + 15) / 16;
     // (a split costs a zero-fill launch and atomics: only contractions of >= 512 rows take it)
     // beta == 1 (accumulate into what is there, e.g. a gradient sink): the atomics of the split form ARE the accumulation
-    while ((beta == 0.f || beta == 1.f) && wgs * zsplit < 128 && steps / (zsplit * 2) >= 16) zsplit *= 2;
+    while ((beta == 0.f || beta == 1.f) && !part && wgs * zsplit < 128 && steps / (zsplit * 2) >= 16) zsplit *= 2;
   }
   if (zsplit > 1) {
     S2F_REQUIRE(dx_batch_stride == (int64_t)Ki * N, S2F_EINVAL, "s2f_pgemm_dx_f32: the split form needs a dense DX");
@@ -1234,13 +1360,16 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
     const dim3 grid(n_tiles * m_tiles, batch, zsplit);                                                                 \
     if (zsplit > 1)                                                                                                    \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 2>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,  \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                              \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, 0);          \
     else if (beta != 0.f)                                                                                              \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 1>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                              \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, 0);          \
+    else if (part)                                                                                                     \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 1, true>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, \
+                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, part_C);         \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride);                              \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, part_C);                \
   } while (0)
   switch (c) {
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
@@ -1252,9 +1381,14 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   do {                                                                                                                 \
     S2F_REQUIRE(zsplit == 1 && beta == 0.f, S2F_EINVAL, "s2f_pgemm_dx_f32: cfg %d is the plain store form", c);           \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
-    S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),                \
-               dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,        \
-               dx_batch_stride);                                                                                       \
+    if (part)                                                                                                          \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2, true>), dim3(n_tiles * m_tiles, batch, 1),        \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
+                 dx_batch_stride, part, part_C);                                                                       \
+    else                                                                                                               \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),              \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
+                 dx_batch_stride, part, part_C);                                                                       \
   } while (0)
     case 7: S2F_PGD2(1, 1, 2, 4); break;         // cfg 4 with 32-row steps (half the barriers per MFMA)
     case 8: S2F_PGD2(1, 2, 2, 2); break;         // cfg 2 with 32-row steps
@@ -1264,4 +1398,17 @@ extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t 
   }
 #undef S2F_PGD
   return s2f_check_launch("s2f_pgemm_dx_f32");
+}
+
+extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX,
+                                int64_t dx_batch_stride, int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream) {
+  return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, beta, cfg, nullptr, 0, stream);
+}
+
+extern "C" int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX,
+                                      int64_t dx_batch_stride, float* bn_partials, int partials_channels, int batch, int Mo, int Ki,
+                                      int N, void* stream) {
+  S2F_REQUIRE(bn_partials, S2F_EINVAL, "s2f_pgemm_dx_f32_stats: null partials");
+  return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, 0.f, 0, bn_partials, partials_channels,
+                       stream);
 }

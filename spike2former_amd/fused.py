@@ -7,9 +7,6 @@ from . import ops
 from .neuron import Q_IFNode
 
 
-_ODD_SHAPES_SEEN = set()
-
-
 def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None,
            want_border=False, scale=None, split_grad=False):
     """z: conv output WITHOUT its bias, [N, C, *].  Returns (u, y): u = BN(z + bias) [+ residual] (None unless wanted),
@@ -33,21 +30,10 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     N, C = shape[0], shape[1]
     L = z.numel() // max(N * C, 1)
     training = bn.training or (bn.running_mean is None)
-    if L % 4 != 0 or z.numel() == 0:
-        # odd row length (no map of the path has one: every level of a 4-divisible crop is 4-divisible, the decoder has 100
-        # queries): unfused ATen BatchNorm (native HIP kernels, MIOpen is disabled) + the stand-alone neuron kernel -- said
-        # out loud once per shape, so that a caller whose shapes land here knows its BatchNorms are not the fused kernels
-        if z.numel() and (C, L) not in _ODD_SHAPES_SEEN:
-            _ODD_SHAPES_SEEN.add((C, L))
-            import warnings
-            warnings.warn(f"spike2former_amd: BatchNorm over rows of {L} elements (C={C}) is not a multiple of 4 -- taking the unfused "
-                          "ATen BatchNorm + stand-alone neuron kernel for this shape", RuntimeWarning, stacklevel=2)
+    if z.numel() == 0:
+        # nothing to normalise: ATen's own handling of the empty tensor (train mode raises, as in the reference)
         t = z if conv_bias is None else z + conv_bias.view(1, -1, *([1] * (z.dim() - 2)))
         u = F.batch_norm(t, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
-        if scale is not None:
-            u = u * scale.view(1, -1, *([1] * (z.dim() - 2)))
-        if residual is not None:
-            u = u + residual.reshape(shape)
         out = (u if want_pre else None), (lif.fire(u) if lif is not None else None)
         if want_border:
             out += ((bn.bias.detach() - bn.running_mean * bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)),)

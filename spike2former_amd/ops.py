@@ -516,7 +516,7 @@ class _DenseGemm(torch.autograd.Function):
     L < 128) fall back to the library GEMM."""
 
     @staticmethod
-    def forward(ctx, x, *ws):
+    def forward(ctx, stats, x, *ws):
         _need_cuda(x, *ws)
         G = len(ws)
         M, K = ws[0].shape
@@ -526,17 +526,27 @@ class _DenseGemm(torch.autograd.Function):
         ctx.fast = PGEMM_DX and L % 4 == 0 and L >= PGEMM_MIN_N
         if ctx.fast:
             y = torch.empty(B, G * M, L, dtype=torch.float32, device=x.device)
+            P = _want_partials(stats, B, G * M, L)
+            part = torch.empty(P, G * M, 2, dtype=torch.float32, device=x.device) if P else x.new_empty(0)
+            ctx.mark_non_differentiable(part)
             for g, w in enumerate(ws):
                 _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)
-                check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w, transposed=True)), x.data_ptr() + 4 * g * K * L, G * K * L,
-                                           y.data_ptr() + 4 * g * M * L, G * M * L, B, K, M, L, 0.0, 0, _stream()),
-                      "s2f_pgemm_dx_f32")
-            return y
+                if P:
+                    check(lib.s2f_pgemm_dx_f32_stats(_ptr(pack_weight(w, transposed=True)), x.data_ptr() + 4 * g * K * L, G * K * L,
+                                                     y.data_ptr() + 4 * g * M * L, G * M * L, part.data_ptr() + 8 * g * M, G * M,
+                                                     B, K, M, L, _stream()), "s2f_pgemm_dx_f32_stats")
+                else:
+                    check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w, transposed=True)), x.data_ptr() + 4 * g * K * L, G * K * L,
+                                               y.data_ptr() + 4 * g * M * L, G * M * L, B, K, M, L, 0.0, 0, _stream()),
+                          "s2f_pgemm_dx_f32")
+            return y, part
+        part = x.new_empty(0)
+        ctx.mark_non_differentiable(part)
         wb = torch.stack(ws, 0).unsqueeze(0).expand(B, G, M, K).reshape(B * G, M, K) if G > 1 else ws[0].expand(B, M, K)
-        return bmm_tuned(wb, x.view(B * G, K, L)).view(B, G * M, L)
+        return bmm_tuned(wb, x.view(B * G, K, L)).view(B, G * M, L), part
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         x, *ws = ctx.saved_tensors
         G = len(ws)
         M, K = ws[0].shape
@@ -544,7 +554,7 @@ class _DenseGemm(torch.autograd.Function):
         gy = gy.contiguous()
         gx, gws = None, [None] * G
         if ctx.fast:
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[1]:
                 gx = torch.empty(B, G * K, L, dtype=torch.float32, device=gy.device)
                 for g, w in enumerate(ws):
                     _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)
@@ -552,7 +562,7 @@ class _DenseGemm(torch.autograd.Function):
                                                gx.data_ptr() + 4 * g * K * L, G * K * L, B, M, K, L, 0.0, 0, _stream()),
                           "s2f_pgemm_dx_f32")
             for g, w in enumerate(ws):
-                if not ctx.needs_input_grad[1 + g]:
+                if not ctx.needs_input_grad[2 + g]:
                     continue
                 sink = _sink_for(w)
                 if _defer_dw_general(gy, g * M * L, G * M * L, x, g * K * L, G * K * L, sink, B, M, K, L):
@@ -562,24 +572,25 @@ class _DenseGemm(torch.autograd.Function):
                 check(lib.s2f_gemm_dw_general(gy.data_ptr() + 4 * g * M * L, G * M * L, x.data_ptr() + 4 * g * K * L, G * K * L,
                                               _ptr(gws[g] if sink is None else sink), B, M, K, L, int(sink is not None),
                                               _stream()), "s2f_gemm_dw_general")
-            return (gx, *gws)
+            return (None, gx, *gws)
         gyv = gy.view(B * G, M, L)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[1]:
             wt = torch.stack(ws, 0).transpose(1, 2)
             wb = wt.unsqueeze(0).expand(B, G, K, M).reshape(B * G, K, M) if G > 1 else wt[0].expand(B, K, M)
             gx = bmm_tuned(wb, gyv).view(B, G * K, L)
-        if any(ctx.needs_input_grad[1:]):
+        if any(ctx.needs_input_grad[2:]):
             gw = bmm_tuned(gyv, x.view(B * G, K, L).transpose(1, 2)).view(B, G, M, K).sum(0)
             gws = [gw[g] for g in range(G)]
-        return (gx, *gws)
+        return (None, gx, *gws)
 
 
-def dense_gemm(x, w):
+def dense_gemm(x, w, stats=False):
     """x [B, G*K, L]; w: one matrix [M, K], a stack [G, M, K], or a list of G matrices (e.g. views of G parameters: each then
-    keeps its own cached pack and gradient sink) -> [B, G*M, L]"""
+    keeps its own cached pack and gradient sink) -> [B, G*M, L].  stats: as spike_gemm"""
     if torch.is_tensor(w):
         w = [w] if w.dim() == 2 else list(w.unbind(0))
-    return _DenseGemm.apply(x, *w)
+    y, part = _DenseGemm.apply(bool(stats), x, *w)
+    return _with_part(y, part)
 
 
 # ------------------------------------------------------------------------------------------------ parameter groups
@@ -1000,7 +1011,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training, momentum,
-                eps, lif_on, want_pre, keep_v, D, vth, stats, bf16, split_grad=False):
+                eps, lif_on, want_pre, keep_v, D, vth, stats, bf16, split_grad=False, partials=None):
         _need_cuda(z, conv_bias, gamma, beta, residual, v_in)
         ctx.split_grad = bool(split_grad)
         z = z.contiguous()
@@ -1011,10 +1022,17 @@ class _BNAct(torch.autograd.Function):
         s = _stream()
         ws = None
         single = bool(training) and bool(lib.s2f_bn_single_pass(N, C, L))    # small map: statistics inside s2f_bn_act_fwd
-        if training and not single:
+        if not (training and partials is not None and tuple(partials.shape[1:]) == (C, 2)
+                and partials.shape[0] == lib.s2f_bn_partials_count(N, L) and (BN_PARTIALS_SINGLE or not single)):
+            partials = None          # the statistics the producing GEMM stored with z (BN_PARTIALS), when they describe this view of it
+        if partials is not None:
+            BN_PARTIALS_USED[0] += 1
+        elif training and not single:
+            BN_PARTIALS_USED[1] += 1
             ws = _take_zeroed(2 * C, dev)
             _time_next("bn_stats", 4 * z.numel())
             check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), N, C, L, s), "s2f_bn_stats")
+            assert partials is None
         if residual is not None:
             residual = residual.contiguous()
         if v_in is not None:
@@ -1029,10 +1047,16 @@ class _BNAct(torch.autograd.Function):
         # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
         alg = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
         _time_next("bn_lif_fwd" if lif_on else "bn_fwd", alg, moved=alg - (2 * n if bf16 else 0))
-        check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
-                                 _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
-                                 _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D,
-                                 int(bf16), s), "s2f_bn_act_fwd")
+        if partials is not None:
+            check(lib.s2f_bn_act_fwd_partials(_ptr(z), _ptr(conv_bias), _ptr(partials), partials.shape[0], _ptr(stat),
+                                              _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual),
+                                              _ptr(u), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum,
+                                              eps, vth, D, int(bf16), s), "s2f_bn_act_fwd_partials")
+        else:
+            check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
+                                     _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
+                                     _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D,
+                                     int(bf16), s), "s2f_bn_act_fwd")
         buf = stat
         stat, border = buf[:2 * C], buf[2 * C:]
         ctx.save_for_backward(z, conv_bias, gamma, stat, mask)
@@ -1055,7 +1079,7 @@ class _BNAct(torch.autograd.Function):
             return None if (g is None or g.numel() == 0) else g.contiguous()
         g_u, g_y, g_v = prep(g_u), prep(g_y), prep(g_v)
         if g_u is None and g_y is None and g_v is None:
-            return (None,) * 20
+            return (None,) * 21
         dev = z.device
         split = ctx.split_grad and z.numel() % 4 == 0
         planes = torch.empty((3, N, C, L), dtype=torch.bfloat16, device=dev) if split else None
@@ -1083,16 +1107,20 @@ class _BNAct(torch.autograd.Function):
             g_bias = None if training else gamma * stat[C:2 * C] * dbeta
         if ctx.needs_input_grad[5]:
             raise RuntimeError("gradient w.r.t. the incoming membrane is not supported by the fused BN+LIF op")
-        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 15
+        return (gz, g_bias, dgamma, dbeta, g_res) + (None,) * 16
 
 
 def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, residual=None,
-           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False, split_grad=False):
+           lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None, want_border=False, split_grad=False,
+           partials=None):
     """-> (u or None, y or None, v_out or None [, border]); y is a Spikes pair (bf16 when SPIKES_BF16); border [C] = BN(0)
-    from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel."""
-    bf16 = bool(lif) and spikes_bf16_ok(D)
+    from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel.
+    partials: the [P, C, 2] per-tile sums the producing GEMM stored for z (BN_PARTIALS; default: z's `_s2f_part` attribute)."""
+    if partials is None:
+        partials = getattr(z, "_s2f_part", None)
+    bf16 = bool(lif) and spikes_bf16_ok(D) and z.numel() % 4 == 0          # as ops.lif: consumers read bf16 spikes in 8-byte groups
     u, y, v, border, ydata = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
-                                          momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16, split_grad)
+                                          momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16, split_grad, partials)
     if lif:
         y = Spikes(ydata, y) if bf16 else Spikes(y, None)
     out = (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
@@ -1204,6 +1232,32 @@ PGEMM = _os.environ.get("S2F_PGEMM", "1") != "0"
 PGEMM_DX = _os.environ.get("S2F_PGEMM_DX", "1") != "0"
 PGEMM_MIN_N = 128
 PGEMM_CONV = _os.environ.get("S2F_PGEMM_CONV", "1") != "0"          # implicit 3x3 convolutions on the pipelined kernels (pgemm.hip)
+# Round 4: BatchNorm statistics from the producing GEMM's epilogue, without atomics (s2f.h "BatchNorm statistics from the producing
+# GEMM's epilogue").  A forward convolution of a module in training mode stores per-(tile, row) partial sums next to its output
+# and hands them over as the attribute `_s2f_part` of the tensor it returns (`carry_stats` moves it across a view); fused.bn_act
+# passes them to the BatchNorm apply kernel instead of launching s2f_bn_stats.  A tensor that lost the attribute on the way simply
+# takes the statistics pass.  BN_PARTIALS_SINGLE: also for the small maps whose BatchNorm computes its statistics itself in one
+# pass (then the row-walking apply kernel runs instead of the single-pass kernel).
+BN_PARTIALS = _os.environ.get("S2F_BN_PARTIALS", "1") != "0"
+BN_PARTIALS_SINGLE = _os.environ.get("S2F_BN_PARTIALS_SINGLE", "0") != "0"
+BN_PARTIALS_USED = [0, 0]          # [BatchNorm launches fed by partials, s2f_bn_stats launches] since the last reset (tests, census)
+
+
+def _want_partials(stats, B, M, L):
+    """-> number of partials per channel (> 0) if the product [B, M, L] should store BatchNorm partials, else 0"""
+    if not (stats and BN_PARTIALS and L % 4 == 0):
+        return 0
+    if not BN_PARTIALS_SINGLE and lib.s2f_bn_single_pass(B, M, L):
+        return 0
+    return int(lib.s2f_bn_partials_count(B, L))
+
+
+def carry_stats(src, dst):
+    """dst is a view / reshape of the GEMM output src: the BatchNorm partials stored with src describe dst as well"""
+    part = getattr(src, "_s2f_part", None)
+    if part is not None:
+        dst._s2f_part = part
+    return dst
 
 
 def _owner(t):
@@ -1413,7 +1467,7 @@ class _SpikeGemm(torch.autograd.Function):
     dY split hi+mid+lo), input gradient on the transposed packed-weight kernel (dx_gemm: s2f_pgemm_dx_f32, 6 passes)."""
 
     @staticmethod
-    def forward(ctx, x, tok, w2d, bias):
+    def forward(ctx, x, tok, w2d, bias, stats=False):
         _need_cuda(w2d, bias, spikes=x)
         x = x.contiguous()
         B, K, N = x.shape
@@ -1423,7 +1477,13 @@ class _SpikeGemm(torch.autograd.Function):
         y = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
         xb = x.dtype == torch.bfloat16
         _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * ((2 if xb else 4) * K + 4 * M))
-        if PGEMM and xb and N % 4 == 0 and N >= 8 and SPIKE_GEMM_TERMS == 3:
+        pg = PGEMM and xb and N % 4 == 0 and N >= 8 and SPIKE_GEMM_TERMS == 3
+        P = _want_partials(stats and pg and bias is None, B, M, N)
+        part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device) if P else None
+        if P:
+            check(lib.s2f_pgemm_nn_bf16_stats(_ptr(pack_weight(w2d)), _ptr(x), _ptr(y), _ptr(part), B, M, N, K, _stream()),
+                  "s2f_pgemm_nn_bf16_stats")
+        elif pg:
             check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(x), _ptr(bias), _ptr(y), B, M, N, K, SPIKE_GEMM_TERMS, 0,
                                         _stream()), "s2f_pgemm_nn_bf16")
         else:
@@ -1439,14 +1499,17 @@ class _SpikeGemm(torch.autograd.Function):
                                and any(ctx.needs_input_grad[:3]))
         if ctx.takes_split:
             _SPLIT_STATE["granted"] = True
-        return y
+        if part is None:
+            part = y.new_empty(0)
+        ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         x, w2d = ctx.saved_tensors
         planes = _GRAD_SPLITS.pop(gy.data_ptr(), None) if ctx.takes_split else None
         if planes is not None:
-            return _SpikeGemm._backward_split(ctx, x, w2d, planes)
+            return _SpikeGemm._backward_split(ctx, x, w2d, planes) + (None,)
         gy = gy.contiguous()
         B = x.shape[0]
         gx = gw = gb = None
@@ -1462,7 +1525,8 @@ class _SpikeGemm(torch.autograd.Function):
                 if (DEFER_DW and sink is not None and xb and B * L <= DEFER_DW_MAX_CONTRACTION and WGRAD_STREAM is None
                         and x.data_ptr() % 8 == 0):
                     _defer_dw(gy, x, sink, B, M, K, L)
-                    return _grad_pair(ctx.has_tok, gx) + (None, gy.sum((0, 2)) if (ctx.has_bias and ctx.needs_input_grad[3]) else None)
+                    return _grad_pair(ctx.has_tok, gx) + (None, gy.sum((0, 2)) if (ctx.has_bias and ctx.needs_input_grad[3]) else None,
+                                                          None)
                 _time_next("spike_gemm_dw", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, x)
                 st = side.cuda_stream if side is not None else _stream()
@@ -1476,7 +1540,7 @@ class _SpikeGemm(torch.autograd.Function):
                 gw = torch.bmm(gy, x.float().transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))
-        return _grad_pair(ctx.has_tok, gx) + (gw, gb)
+        return _grad_pair(ctx.has_tok, gx) + (gw, gb, None)
 
 
 def _spike_gemm_backward_split(ctx, x, w2d, planes):
@@ -1554,10 +1618,17 @@ def gemm_bn_lif_eval(x, w2d, conv_bias, running_mean, running_var, gamma, beta, 
     return u, (Spikes(y, _new_tok(y)) if lif else None), v_out
 
 
-def spike_gemm(x, w2d, bias=None):
-    """x: Spikes or an fp32 spike tensor [B, K, N]"""
+def _with_part(y, part):
+    if part.numel():
+        y._s2f_part = part
+    return y
+
+
+def spike_gemm(x, w2d, bias=None, stats=False):
+    """x: Spikes or an fp32 spike tensor [B, K, N].  stats: a train-mode BatchNorm follows -- store its partial statistics with
+    the output (attribute `_s2f_part`, see BN_PARTIALS) when the kernel path can"""
     data, tok = _unpack(x)
-    return _SpikeGemm.apply(data, tok, w2d, bias)
+    return _with_part(*_SpikeGemm.apply(data, tok, w2d, bias, bool(stats)))
 
 
 # ------------------------------------------------------------------------------------------------ token-major linear layers
@@ -2044,9 +2115,10 @@ class _ConvDense(torch.autograd.Function):
               stride 1 (MS_ConvBlock.conv2: 4C -> C, sdtv2.py:202-204)."""
 
     @staticmethod
-    def forward(ctx, x, tok, weight, bias, stride, padding, spike_input):
+    def forward(ctx, x, tok, weight, bias, stride, padding, spike_input, stats=False):
         _need_cuda(weight, bias, spikes=x)
         ctx.has_tok = tok is not None
+        part = None
         xb = x.dtype == torch.bfloat16
         N, C, H, W = x.shape
         M, _, kh, kw = weight.shape
@@ -2064,7 +2136,12 @@ class _ConvDense(torch.autograd.Function):
             y = torch.empty(N, M, H * W, dtype=torch.float32, device=x.device)
             _time_next("spike_gemm_fwd", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9,
                        moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
-            if PGEMM_CONV and xb and SPIKE_GEMM_TERMS == 3:
+            P = _want_partials(stats and PGEMM_CONV and xb and SPIKE_GEMM_TERMS == 3 and bias is None, N, M, H * W)
+            if P:
+                part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+                check(lib.s2f_pgemm_conv3x3_bf16_stats(_ptr(pack_weight_conv3(weight)), _ptr(x), _ptr(y), _ptr(part), N, M, C, H, W,
+                                                       _stream()), "s2f_pgemm_conv3x3_bf16_stats")
+            elif PGEMM_CONV and xb and SPIKE_GEMM_TERMS == 3:
                 check(lib.s2f_pgemm_conv3x3_bf16(_ptr(pack_weight_conv3(weight)), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, 0,
                                                  _stream()), "s2f_pgemm_conv3x3_bf16")
             else:
@@ -2075,7 +2152,9 @@ class _ConvDense(torch.autograd.Function):
             ctx.save_for_backward(x, weight)
             ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, True)
             ctx.implicit = True
-            return y.view(N, M, Ho, Wo)
+            part = y.new_empty(0) if part is None else part
+            ctx.mark_non_differentiable(part)
+            return y.view(N, M, Ho, Wo), part
         ctx.implicit = False
         cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
         use_mfma = spike_input and SPIKE_GEMM_ENABLED and cols.shape[2] % 4 == 0
@@ -2084,7 +2163,13 @@ class _ConvDense(torch.autograd.Function):
             y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
             _time_next("spike_gemm_fwd", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1],
                        moved=N * L * ((2 if xb else 4) * cols.shape[1] + 4 * M))
-            if PGEMM and xb and L % 4 == 0 and L >= 8 and SPIKE_GEMM_TERMS == 3:
+            pg = PGEMM and xb and L % 4 == 0 and L >= 8 and SPIKE_GEMM_TERMS == 3
+            P = _want_partials(stats and pg and bias is None, N, M, L)
+            if P:
+                part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+                check(lib.s2f_pgemm_nn_bf16_stats(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(y), _ptr(part), N, M, L, cols.shape[1],
+                                                  _stream()), "s2f_pgemm_nn_bf16_stats")
+            elif pg:
                 check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1],
                                             SPIKE_GEMM_TERMS, 0, _stream()), "s2f_pgemm_nn_bf16")
             else:
@@ -2099,18 +2184,26 @@ class _ConvDense(torch.autograd.Function):
                 # general fp32 input (the stem reads the image): the transposed product on the pack of W^T, 6 passes
                 y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
                 _time_next("dx_gemm", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1])
-                check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, N, cols.shape[1], M,
-                                           L, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
+                P = _want_partials(stats and bias is None, N, M, L)
+                if P:
+                    part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+                    check(lib.s2f_pgemm_dx_f32_stats(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, _ptr(part), M, N,
+                                                     cols.shape[1], M, L, _stream()), "s2f_pgemm_dx_f32_stats")
+                else:
+                    check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, N, cols.shape[1], M,
+                                               L, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
             else:
                 y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
             if bias is not None:
                 y = y + bias.view(1, -1, 1)
         ctx.save_for_backward(cols, weight)
         ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, use_mfma)
-        return y.view(N, M, Ho, Wo)
+        part = y.new_empty(0) if part is None else part
+        ctx.mark_non_differentiable(part)
+        return y.view(N, M, Ho, Wo), part
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         cols, weight = ctx.saved_tensors
         N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, has_bias, use_mfma = ctx.geo
         gy = gy.contiguous().view(N, M, Ho * Wo)
@@ -2161,7 +2254,7 @@ class _ConvDense(torch.autograd.Function):
                 if (DEFER_DW and sink is not None and xb and N * Ho * Wo <= DEFER_DW_MAX_CONTRACTION and WGRAD_STREAM is None):
                     _defer_dw(gy, cols, sink, N, M, K, Ho * Wo)
                     return _grad_pair(ctx.has_tok, gx) + (None, gy.sum((0, 2)) if (has_bias and ctx.needs_input_grad[3]) else None,
-                                                          None, None, None)
+                                                          None, None, None, None)
                 _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K,
                            moved=N * Ho * Wo * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, cols)
@@ -2183,10 +2276,10 @@ class _ConvDense(torch.autograd.Function):
             gw = gw.view_as(weight) if gw is not None else None
         if has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))
-        return _grad_pair(ctx.has_tok, gx) + (gw, gb, None, None, None)
+        return _grad_pair(ctx.has_tok, gx) + (gw, gb, None, None, None, None)
 
 
-def conv_dense(x, weight, bias, stride, padding, spike_input):
-    """x: fp32 tensor, or Spikes (then `spike_input` is implied)"""
+def conv_dense(x, weight, bias, stride, padding, spike_input, stats=False):
+    """x: fp32 tensor, or Spikes (then `spike_input` is implied).  stats: as spike_gemm"""
     data, tok = _unpack(x)
-    return _ConvDense.apply(data, tok, weight, bias, stride, padding, spike_input or isinstance(x, Spikes))
+    return _with_part(*_ConvDense.apply(data, tok, weight, bias, stride, padding, spike_input or isinstance(x, Spikes), bool(stats)))

@@ -354,7 +354,13 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      # last tile (L % 256 != 0; C5's 1050- and 4200-pixel maps), train and eval
                                                      (3, 5, 260, True, True, True), (2, 7, 1052, True, False, True),
                                                      (1, 3, 300, True, True, False), (2, 6, 4200, False, True, True),
-                                                     (8, 3, 16800, True, False, True)])
+                                                     (8, 3, 16800, True, False, True),
+                                                     # rows of L % 4 != 0 elements (element-wise ANYL kernels): the tiny
+                                                     # configuration's 10-query decoder rows; odd totals; eval mode
+                                                     (8, 64, 10, True, False, True), (8, 256, 10, True, True, True),
+                                                     (3, 5, 7, True, True, True), (2, 3, 1, True, False, False),
+                                                     (1, 9, 333, True, True, True), (4, 6, 10, False, True, True),
+                                                     (2, 4, 1027, True, False, True)])
 @pytest.mark.parametrize("bf16", [True, False])
 def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
@@ -392,7 +398,7 @@ def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     uu, yy, _, border = ops.bn_act(zc, bc, gc, bec, rmc, rvc, nbt if training else None, training, 0.1, 1e-5, residual=rc,
                                    lif=lif, want_pre=True, stats=fstats, want_border=True)
     if lif:
-        assert yy.data.dtype == (torch.bfloat16 if bf16 else torch.float32)
+        assert yy.data.dtype == (torch.bfloat16 if (bf16 and (N * C * L) % 4 == 0) else torch.float32)
         yy = yy.float()
     # BNAndPadLayer's padding value BN(0), from the running statistics AFTER this call's update (sdtv2.py:68-78)
     bref = beta - rmo * gamma / torch.sqrt(rvo + 1e-5)
@@ -1191,3 +1197,102 @@ def test_token_major_linear_on_own_kernels(ops, n, c, o, bias):
     assert (w.grad.double() - wd.grad).abs().max().item() <= 4e-6 * scale(wd.grad)
     if bias:
         assert (b.grad.double() - bd.grad).abs().max().item() <= 1e-5 * scale(bd.grad)
+
+
+# ----------------------------------------------------------------------------------------------- BatchNorm statistics from the GEMM epilogue
+def _tile_sums(y):
+    """fp64 reference of the partials: per (batch, 128-column tile, row) the sum and the sum of squares of y [B, M, N]"""
+    B, M, N = y.shape
+    nt = (N + 127) // 128
+    yp = torch.nn.functional.pad(y.double(), (0, nt * 128 - N)).view(B, M, nt, 128)
+    return torch.stack([yp.sum(-1), (yp * yp).sum(-1)], -1).permute(0, 2, 1, 3).reshape(B * nt, M, 2)
+
+
+@pytest.mark.parametrize("B,M,K,N", [(2, 64, 32, 128), (3, 100, 72, 136), (8, 256, 256, 100), (2, 256, 256, 1024), (1, 360, 1440, 1024),
+                                     (2, 40, 96, 4096), (8, 2048, 256, 100), (1, 33, 1152, 260)])
+def test_gemm_epilogue_partials_are_the_tile_sums(ops, B, M, K, N):
+    """s2f_pgemm_nn_bf16_stats / s2f_pgemm_dx_f32_stats: the product is bit-identical to the plain entry point, and the partials
+    bn_partials[(p, row)] are the sum / sum of squares of the 128-column tile p of that row (fp32 sums of <= 128 values against
+    fp64: 1e-5 of the tile's sum of |.|), ragged M / N included -- columns past N and rows past M contribute nothing."""
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 1000 + M + K + N)
+    w = (torch.randn(M, K, generator=g) * K ** -0.5).cuda()
+    x = _spikes_bf16((B, K, N), g)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lib.s2f_bn_partials_count(B, N)
+    assert P == B * ((N + 127) // 128)
+    y0 = torch.empty(B, M, N, device="cuda")
+    check(lib.s2f_pgemm_nn_bf16(ops.pack_weight(w).data_ptr(), x.data_ptr(), None, y0.data_ptr(), B, M, N, K, 3, 0, st), "plain")
+    y1 = torch.full((B, M, N), float("nan"), device="cuda")
+    part = torch.full((P, M, 2), float("nan"), device="cuda")
+    check(lib.s2f_pgemm_nn_bf16_stats(ops.pack_weight(w).data_ptr(), x.data_ptr(), y1.data_ptr(), part.data_ptr(), B, M, N, K, st), "stats")
+    assert torch.equal(y0, y1)
+    ref = _tile_sums(y1)
+    scale = _tile_sums(y1.abs())
+    assert ((part.double() - ref).abs() <= 1e-5 * scale + 1e-30).all()
+    # the dense-input forward product (the transposed kernel on the pack of W^T), also as a group of a wider channel table
+    xf = torch.randn(B, K, N, generator=g).cuda()
+    z0 = torch.empty(B, M, N, device="cuda")
+    pk = ops.pack_weight(w, transposed=True)          # the pack of w^T [K, M]: its transposed product IS  w @ x  (ops._DenseGemm)
+    check(lib.s2f_pgemm_dx_f32(pk.data_ptr(), xf.data_ptr(), 0, z0.data_ptr(), 0, B, K, M, N, 0.0, 0, st), "dense plain")
+    z1 = torch.full((B, M, N), float("nan"), device="cuda")
+    wide = torch.full((P, M + 24, 2), float("nan"), device="cuda")
+    check(lib.s2f_pgemm_dx_f32_stats(pk.data_ptr(), xf.data_ptr(), 0, z1.data_ptr(), 0, wide.data_ptr() + 8 * 16, M + 24, B, K, M, N, st),
+          "dense stats")
+    assert torch.equal(z0, z1)
+    assert ((wide[:, 16:16 + M].double() - _tile_sums(z1)).abs() <= 1e-5 * _tile_sums(z1.abs()) + 1e-30).all()
+    assert torch.isnan(wide[:, :16]).all() and torch.isnan(wide[:, 16 + M:]).all()          # only this group's rows are written
+    assert (z1.double() - torch.matmul(w.double(), xf.double())).abs().max().item() <= 2e-6 * torch.matmul(w.abs().double(), xf.abs().double()).max().item()
+
+
+@pytest.mark.parametrize("N,M,C,H,W", [(2, 64, 32, 16, 16), (1, 128, 64, 32, 32), (2, 32, 128, 64, 64), (1, 100, 32, 8, 32)])
+def test_conv3x3_epilogue_partials_are_the_tile_sums(ops, N, M, C, H, W):
+    from spike2former_amd._lib import check, lib
+    g = torch.Generator().manual_seed(N + M + C + H)
+    w = (torch.randn(M, C, 3, 3, generator=g) * (9 * C) ** -0.5).cuda()
+    x = _spikes_bf16((N, C, H, W), g)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lib.s2f_bn_partials_count(N, H * W)
+    y0 = torch.empty(N, M, H * W, device="cuda")
+    check(lib.s2f_pgemm_conv3x3_bf16(ops.pack_weight_conv3(w).data_ptr(), x.data_ptr(), None, y0.data_ptr(), N, M, C, H, W, 0, st), "plain")
+    y1 = torch.full((N, M, H * W), float("nan"), device="cuda")
+    part = torch.full((P, M, 2), float("nan"), device="cuda")
+    check(lib.s2f_pgemm_conv3x3_bf16_stats(ops.pack_weight_conv3(w).data_ptr(), x.data_ptr(), y1.data_ptr(), part.data_ptr(), N, M, C, H, W,
+                                           st), "stats")
+    assert torch.equal(y0, y1)
+    assert ((part.double() - _tile_sums(y1)).abs() <= 1e-5 * _tile_sums(y1.abs()) + 1e-30).all()
+
+
+@pytest.mark.parametrize("N,C,L,res,lif", [(8, 256, 100, False, True), (8, 64, 4096, True, True), (2, 7, 1052, False, True),
+                                           (8, 32, 16384, False, True), (3, 20, 640, True, False), (8, 256, 1024, False, True),
+                                           (1, 8, 65536, False, True), (4, 6, 12, True, True)])
+def test_bn_from_partials_is_bn_from_the_statistics_pass(ops, spike_mode, N, C, L, res, lif):
+    """s2f_bn_act_fwd_partials == s2f_bn_stats + s2f_bn_act_fwd: the partials of a GEMM epilogue (here: exact fp64 tile sums rounded
+    to fp32, the kernel's storage format) give the same mean / rstd to fp32 round-off (1e-6), the same pre-activation to 1e-5,
+    spikes that differ in <= 1e-4 of the elements by one level, the same running statistics; every apply kernel: generic
+    (L = 100), row-walking aligned / straddling, few (<= 32: one thread per channel) and many (wave per channel) partials, the
+    conv bias shifting the mean."""
+    spike_mode(True)
+    g = torch.Generator().manual_seed(N * 31 + C + L)
+    z = (torch.randn(N, C, L, generator=g) * 2 + 0.7).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3 + 0.5).cuda()
+    r = torch.randn(N, C, L, generator=g).cuda() if res else None
+    part = _tile_sums(z).float().contiguous()
+    outs = []
+    for p in (None, part):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+        before = list(ops.BN_PARTIALS_USED)
+        u, y, _, border = ops.bn_act(z, b, gamma, beta, rm, rv, nbt, True, 0.1, 1e-5, residual=r, lif=lif, want_pre=True,
+                                     want_border=True, partials=p)
+        used = [a - c for a, c in zip(ops.BN_PARTIALS_USED, before)]
+        outs.append((u, y.float() if lif else None, rm, rv, border, int(nbt), used))
+    (u0, y0, rm0, rv0, b0, n0, used0), (u1, y1, rm1, rv1, b1, n1, used1) = outs
+    single = bool(__import__("spike2former_amd")._lib.lib.s2f_bn_single_pass(N, C, L))
+    assert used1 == ([1, 0] if (not single or ops.BN_PARTIALS_SINGLE) else [0, 0]) and used0[0] == 0
+    close = lambda a, c, tol: (a - c).abs().max().item() <= tol * max(c.abs().max().item(), 1e-6)
+    assert close(u1, u0, 1e-5) and close(rm1, rm0, 1e-6) and close(rv1, rv0, 1e-5) and close(b1, b0, 1e-5) and n0 == n1 == 1
+    if lif:
+        d = (y1 - y0) * 8
+        assert d.abs().max().item() <= 1 and (d != 0).float().mean().item() <= 1e-4
