@@ -293,9 +293,9 @@ int s2f_pgemm_conv3x3_f32(const uint16_t* w_pack, const float* X, float* Y, int 
  * Q_IFNode: mmseg/models/backbones/sdtv2.py:222-255, 304-333).  The `_stats` forms of the three forward
  * products above (no bias, all three weight terms, automatic tile) additionally store, per output row and per workgroup tile
  * (128 columns of one batch element), the fp32 sum and sum of squares of the tile's values:
- *   bn_partials[(p * C + row) * 2 + {0, 1}],   p = b * ceil(N / 128) + column tile,   P = s2f_bn_partials_count(batch, N) of them
- * per row (plain stores: no atomics, nothing to zero, deterministic).  C = M, or `partials_channels` for s2f_pgemm_dx_f32_stats
- * (a group of a grouped product writes its rows into a wider table: pass bn_partials + 2 * first_row).
+ *   bn_partials[(row * P + p) * 2 + {0, 1}],   p = b * ceil(N / 128) + column tile,   P = s2f_bn_partials_count(batch, N)
+ * (channel-major: one channel's partials are contiguous; plain stores: no atomics, nothing to zero, deterministic).  A group of a
+ * grouped product (s2f_pgemm_dx_f32_stats with batch strides) writes its rows into a wider table: pass bn_partials + 2 * first_row * P.
  * s2f_bn_act_fwd_partials is s2f_bn_act_fwd in training mode taking these partials instead of the sums of s2f_bn_stats: the
  * apply kernels add the P partials of a channel in fp64 in a fixed order (the statistics are those of z; conv_bias shifts the
  * mean).  The statistics pass over z -- one read of the tensor and one launch per BatchNorm -- disappears. */
@@ -305,7 +305,7 @@ int s2f_pgemm_nn_bf16_stats(const uint16_t* a_pack, const uint16_t* X, float* Y,
 int s2f_pgemm_conv3x3_bf16_stats(const uint16_t* w_pack, const uint16_t* X, float* Y, float* bn_partials, int batch, int M, int C,
                                  int H, int W, void* stream);
 int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
-                           float* bn_partials, int partials_channels, int batch, int Mo, int Ki, int N, void* stream);
+                           float* bn_partials, int batch, int Mo, int Ki, int N, void* stream);
 int s2f_bn_act_fwd_partials(const float* z, const float* conv_bias, const float* partials, int64_t P, float* stat_out,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
                             const float* beta, const float* residual, float* u_out, const float* v_in, void* y, float* v_out,

@@ -588,9 +588,12 @@ class OracleNet:
             query_feat = self._dec_layer(h + f"transformer_decoder.layers.{i}", query_feat, dec_in[lv],
                                          query_embed, dec_pos[lv])
             outs.append(query_feat)
-        O = torch.stack(outs)
+        return self._sdme(torch.stack(outs), mask_features)
+
+    def _sdme(self, O, mask_features):                   # SDME block + mask contraction, dense_heads/maskformer_head.py:568-586
+        p = self.p
+        h = "decode_head."
         ln, t, bs, nq, C = O.shape
-        # SDME block (:568-582)
         Z = torch.sigmoid(O)
         A = 4 * self.lif(h + "decoder_out_spike", Z)
         cls = F.linear(A, p[h + "cls_embed.weight"], p[h + "cls_embed.bias"]).mean(1)

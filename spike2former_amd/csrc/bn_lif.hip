@@ -125,38 +125,75 @@ __device__ __forceinline__ ChanStat chan_stat(const double* __restrict__ sums, c
   r.rstd = 1.0f / sqrtf(r.var + eps);
   return r;
 }
-// Statistics handed over as per-tile PARTIALS of the producing GEMM's epilogue (pgemm.hip epi_row_partials): part[(p * C + c) * 2 +
-// {0, 1}], p < P.  The P partials of a channel are added in fp64 in a fixed order -- by one thread (few partials: consecutive
+// Statistics handed over as per-tile PARTIALS of the producing GEMM's epilogue (pgemm.hip epi_row_partials): part[(c * P + p) * 2 +
+// {0, 1}], p < P (channel-major).  The P partials of a channel are added in fp64 in a fixed order -- by one thread (few partials: consecutive
 // threads read consecutive channels), or strided over the lanes of a wavefront and folded by shuffles.
 __device__ __forceinline__ ChanStat chan_stat_partials_thread(const float* __restrict__ part, int P, int C, int c, float bias_c,
                                                               double inv_count, float eps) {
   double a = 0, b = 0;
-  for (int p = 0; p < P; ++p) {
-    const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)p * C + c) * 2);
-    a += (double)v.x;
-    b += (double)v.y;
-  }
-  return chan_stat_of(a, b, (double)bias_c, inv_count, eps);
-}
-__device__ __forceinline__ ChanStat chan_stat_partials_wave(const float* __restrict__ part, int P, int C, int c, float bias_c,
-                                                            double inv_count, float eps, int lane) {
-  double a = 0, b = 0;
-  for (int p0 = lane; p0 < P; p0 += 4 * 64) {          // four loads in flight per lane
-    float2 v[4];
+  for (int p0 = 0; p0 < P; p0 += 8) {          // eight loads in flight (a plain loop waits for each load in turn)
+    float2 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + u * 64;
-      v[u] = p < P ? *reinterpret_cast<const float2*>(part + ((int64_t)p * C + c) * 2) : make_float2(0.f, 0.f);
-    }
+    for (int u = 0; u < 8; ++u)
+      v[u] = p0 + u < P ? *reinterpret_cast<const float2*>(part + ((int64_t)c * P + p0 + u) * 2) : make_float2(0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       a += (double)v[u].x;
       b += (double)v[u].y;
     }
   }
-  a = wave_sum_f64(a);
-  b = wave_sum_f64(b);
   return chan_stat_of(a, b, (double)bias_c, inv_count, eps);
+}
+// Many partials (a large map: hundreds to thousands per channel, but then a workgroup's run of tiles touches one to three
+// channels): the `nch` channels c0, c0 + 1, .. (mod C) are shared out over the workgroup's wavefronts -- all four on one channel,
+// two each on two, one each on more -- eight loads in flight per lane, folded through shuffles and LDS in a fixed order.
+// Uniform control flow (every wavefront runs every round).  red: 2 kWaves doubles of LDS.
+__device__ __forceinline__ void chan_stats_partials_block(const float* __restrict__ part, int P, int C, uint32_t c0, uint32_t nch,
+                                                          const float* __restrict__ bias, double inv_count, float eps,
+                                                          double* red, float* sstat) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wpc = nch >= (uint32_t)kWaves ? 1 : kWaves / (int)nch;          // wavefronts per channel: 4, 2, 1
+  const int groups = kWaves / wpc, g = w / wpc, wg = w % wpc;
+  for (uint32_t k0 = 0; k0 < nch; k0 += groups) {
+    const uint32_t k = k0 + g;
+    const bool live = k < nch && g < groups;
+    const uint32_t c = (c0 + (live ? k : 0u)) % (uint32_t)C;
+    double a = 0, b = 0;
+    if (live) {
+      for (int p0 = wg * 64 + lane; p0 < P; p0 += 8 * wpc * 64) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int p = p0 + u * wpc * 64;
+          v[u] = p < P ? *reinterpret_cast<const float2*>(part + ((int64_t)c * P + p) * 2) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a += (double)v[u].x;
+          b += (double)v[u].y;
+        }
+      }
+    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    __syncthreads();                                   // `red` may still be read from the previous round
+    if (lane == 0) {
+      red[2 * w] = a;
+      red[2 * w + 1] = b;
+    }
+    __syncthreads();
+    if (live && wg == 0 && lane == 0) {
+      a = 0, b = 0;
+      for (int i = 0; i < wpc; ++i) {
+        a += red[2 * (g * wpc + i)];
+        b += red[2 * (g * wpc + i) + 1];
+      }
+      const ChanStat cs = chan_stat_of(a, b, (double)(bias ? bias[c] : 0.f), inv_count, eps);
+      sstat[c] = cs.mean;
+      sstat[C + c] = cs.rstd;
+      sstat[2 * C + c] = cs.var;
+    }
+  }
 }
 
 // channel of the element at flat index `base` in [N, C, L]; 32-bit division when the tensor has < 2^32 elements
@@ -247,7 +284,9 @@ __device__ __forceinline__ void st4g_bf16(float* p, int64_t base, int64_t total,
 // u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
 // YB: the spikes y are written as bf16 (2 bytes / element).
 // ANYL: any row length -- the channel, the validity and the accesses are per element (see ld4g).
-template <bool LIF, bool HAS_V, bool YB, bool ANYL = false>
+// PART: the statistics arrive as a producer's partials (a separate instantiation: the prologue's registers are not charged to the
+// sums form).
+template <bool LIF, bool HAS_V, bool YB, bool ANYL = false, bool PART = false>
 __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                           const double* __restrict__ sums, float* __restrict__ stat,
                                                           float* __restrict__ running_mean,
@@ -284,9 +323,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
   };
   request(wave0);
   for (int c = threadIdx.x; c < C; c += kBlock) {
-    const ChanStat cs = (training && part != nullptr)
-                            ? chan_stat_partials_thread(part, P, C, c, bias ? bias[c] : 0.f, inv_count, eps)
-                            : chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+    const ChanStat cs = PART ? chan_stat_partials_thread(part, P, C, c, bias ? bias[c] : 0.f, inv_count, eps)
+                             : chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
     sstat[c] = cs.mean;
     sstat[C + c] = cs.rstd;
     sstat[2 * C + c] = cs.var;
@@ -589,7 +627,7 @@ __device__ __forceinline__ RowWalk walk_begin(uint32_t tile, uint32_t L, uint32_
   return w;
 }
 
-template <bool LIF, bool HAS_V, bool YB, bool ALIGNED>
+template <bool LIF, bool HAS_V, bool YB, bool ALIGNED, bool PART = false>
 __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const double* __restrict__ sums, float* __restrict__ stat,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ num_batches,
@@ -613,9 +651,11 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
       if (LIF && HAS_V) vn[slot] = ld4(v_in + base);
     }
   };
+  // (PART: requesting the first tiles only behind the longer prologue keeps the kernel at 61 instead of 78 VGPRs, eight instead of six
+  // wavefronts per SIMD -- and measured 0.2 ms per step SLOWER at C2 than losing the overlap: same-box A/B 39.99 / 39.76 vs 39.78 / 39.55)
 #pragma unroll
   for (int i = 0; i < kAhead; ++i) request(i, t + i);
-  if (training && part != nullptr) {
+  if constexpr (PART) {
     // statistics from the producer's per-tile partials: only the channels this workgroup's run of tiles touches (a few rows of
     // a large map) -- with hundreds to thousands of partials per channel, all C channels per workgroup would re-read the whole
     // partial buffer once per workgroup
@@ -633,15 +673,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
           sstat[2 * C + c] = cs.var;
         }
       } else {
-        for (uint32_t k = (uint32_t)wave_id_uniform(); k < nch; k += kWaves) {
-          const uint32_t c = (c0 + k) % (uint32_t)C;
-          const ChanStat cs = chan_stat_partials_wave(part, P, C, (int)c, bias ? bias[c] : 0.f, inv_count, eps, lane);
-          if (lane == 0) {
-            sstat[c] = cs.mean;
-            sstat[C + c] = cs.rstd;
-            sstat[2 * C + c] = cs.var;
-          }
-        }
+        __shared__ double pred[2 * kWaves];
+        chan_stats_partials_block(part, P, C, c0, nch, bias, inv_count, eps, pred, sstat);
       }
     }
   } else {
@@ -1266,6 +1299,7 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
   int rc = check_shape("s2f_bn_act_fwd", N, C, L);
   if (rc) return rc;
   const bool anyl = (L & 3) != 0;
+  S2F_REQUIRE(!(anyl && part), S2F_EINVAL, "s2f_bn_act_fwd_partials: rows of L %% 4 != 0 elements have no producer of partials");
   S2F_REQUIRE(anyl || (s2f_aligned16(z) && s2f_aligned16(residual) && s2f_aligned16(u_out) && s2f_aligned16(v_in) &&
                        s2f_aligned16(y) && s2f_aligned16(v_out)),
               S2F_EALIGN, "s2f_bn_act_fwd: tensors must be 16-byte aligned");
@@ -1305,11 +1339,19 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
   do {                                                                                                                  \
     uint32_t chunk;                                                                                                     \
     const uint32_t ntiles = (uint32_t)((total + 255) >> 8);                                                             \
-    const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                         \
-    S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias, sums,  \
-               stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, \
-               ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth, (float)D, part,     \
-               (int)P);                                                                                                 \
+    if (part) {                                                                                                         \
+      const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL, true>>(ntiles, lds, chunk);                 \
+      S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL, true>), dim3(rgrid), block, lds, s, z,          \
+                 conv_bias, sums, stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y,      \
+                 v_out, mask, st, total, ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps,          \
+                 training, vth, (float)D, part, (int)P);                                                                \
+    } else {                                                                                                            \
+      const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                       \
+      S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias,     \
+                 sums, stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask,    \
+                 st, total, ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth,        \
+                 (float)D, part, (int)P);                                                                               \
+    }                                                                                                                   \
   } while (0)
 #define S2F_BN_APPLY(LIFV, HASV, YBV)                                                                                   \
   do {                                                                                                                  \
@@ -1319,6 +1361,10 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
       S2F_BN_ROWS_FWD(LIFV, HASV, YBV, false);                                                                          \
     } else if (anyl) {                                                                                                  \
       S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV, true>), grid, block, lds, s, z, conv_bias, sums,         \
+                 stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
+                 total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);       \
+    } else if (part) {                                                                                                  \
+      S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV, false, true>), grid, block, lds, s, z, conv_bias, sums,  \
                  stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
                  total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);       \
     } else {                                                                                                            \

@@ -165,8 +165,10 @@ struct BnLifEpi {
 
 // BatchNorm statistics from the producing GEMM's epilogue, WITHOUT atomics (reference chain conv -> BN ->
 // Q_IFNode, sdtv2.py:222-255, 304-333): per output row the sum and the sum of squares of this workgroup's tile (<= 128 columns, fp32)
-// are stored -- plain stores, one float2 per (workgroup, row) -- at  part[(slot * part_C + row) * 2 + {0, 1}],  slot = b * n_tiles +
-// nt; the BatchNorm apply kernels (bn_lif.hip) add the batch * n_tiles partials of a channel in fp64, in a fixed order (the
+// are stored -- plain stores, one float2 per (workgroup, row) -- at  part[(row * P + slot) * 2 + {0, 1}],  slot = b * n_tiles + nt,
+// P = batch * n_tiles (CHANNEL-major: the consumer reads one channel's partials as one contiguous run; slot-major made every one
+// of its loads a separate cache line -- +19 us per BatchNorm launch on the large maps);
+// the BatchNorm apply kernels (bn_lif.hip) add the P partials of a channel in fp64, in a fixed order (the
 // statistics pass over z -- one full read of the tensor and one launch per BatchNorm -- disappears, and with it the only
 // run-to-run variation of a forward pass: the fp64 atomics of bn_stats_kernel).  Round 3 measured the version with one fp64
 // atomic pair per (wavefront, row): a thousand same-address atomics per launch, 12 ms per step slower.
@@ -174,7 +176,7 @@ struct BnLifEpi {
 // per step (16 -> 8 -> 4 -> 2 -> 1: 16 shuffles per quantity instead of 80), which leaves row r = (lane >> 1) & 15 of the 32 x 32
 // accumulator layout in each even lane; across the WNW wavefronts of a row block through LDS (fixed order).
 template <int MI, int NJ, int WMW, int WNW>
-__device__ __forceinline__ void epi_row_partials(const f32x16 (&acc)[MI][NJ], float* __restrict__ part, int part_C,
+__device__ __forceinline__ void epi_row_partials(const f32x16 (&acc)[MI][NJ], float* __restrict__ part, int P,
                                                  float* scratch, int m0, int n0, int M, int N, int slot, int wm, int wn,
                                                  int lane, int tid) {
   constexpr int BM = 32 * MI * WMW, T = 64 * WMW * WNW;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void epi_row_partials(const f32x16 (&acc)[MI][NJ], fl
         a += v.x;
         b += v.y;
       }
-      *reinterpret_cast<f32x2*>(part + ((int64_t)slot * part_C + m0 + row_l) * 2) = f32x2{a, b};
+      *reinterpret_cast<f32x2*>(part + ((int64_t)(m0 + row_l) * P + slot) * 2) = f32x2{a, b};
     }
   }
 }
@@ -450,8 +452,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
     }
   }
   if constexpr (STATS)          // (a separate instantiation: the epilogue's registers are not charged to the plain product)
-    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, M, reinterpret_cast<float*>(smem), m0, n0, M, N, b * n_tiles + nt, wm, wn, lane,
-                                       (int)threadIdx.x);
+    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, n_tiles * (int)gridDim.y, reinterpret_cast<float*>(smem), m0, n0, M, N,
+                                       b * n_tiles + nt, wm, wn, lane, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
                                                                   int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
                                                                   int64_t g_batch_stride, int64_t dx_batch_stride,
-                                                                  float* __restrict__ part = nullptr, int part_C = 0) {
+                                                                  float* __restrict__ part = nullptr) {
   constexpr bool BETA = EPI == 1;
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   constexpr int KC = 16 * KS;                                      // KS 16-row slices per step (one barrier per step)
@@ -680,8 +682,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
       }
     }
   if constexpr (EPI == 0 && STATS)          // the product as a FORWARD convolution of a dense input (SepConv.pwconv2, RepConv's second 1x1)
-    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, part_C, reinterpret_cast<float*>(smem), m0, n0, Ki, N, b * n_tiles + nt, wm, wn,
-                                       lane, tid);
+    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, n_tiles * (int)gridDim.y, reinterpret_cast<float*>(smem), m0, n0, Ki, N,
+                                       b * n_tiles + nt, wm, wn, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1073,8 +1075,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
       }
     }
   if constexpr (STATS)
-    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, M, reinterpret_cast<float*>(smem), m0, n0, M, N, b * n_tiles + nt, wm, wn, lane,
-                                       tid);
+    epi_row_partials<MI, NJ, WMW, WNW>(acc, part, n_tiles * (int)gridDim.y, reinterpret_cast<float*>(smem), m0, n0, M, N,
+                                       b * n_tiles + nt, wm, wn, lane, tid);
 }
 
 int pick_cfg_nn(int M, int N, int K, int batch, int force) {
@@ -1314,10 +1316,10 @@ extern "C" int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, in
 }
 
 static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
-                         int batch, int Mo, int Ki, int N, float beta, int cfg, float* part, int part_C, void* stream) {
+                         int batch, int Mo, int Ki, int N, float beta, int cfg, float* part, void* stream) {
   if (g_batch_stride == 0) g_batch_stride = (int64_t)Mo * N;
-  S2F_REQUIRE(!part || (beta == 0.f && part_C >= Ki && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
-              "s2f_pgemm_dx_f32_stats: plain-store form only; partials 8-byte aligned, channel count >= rows");
+  S2F_REQUIRE(!part || (beta == 0.f && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
+              "s2f_pgemm_dx_f32_stats: plain-store form only; partials 8-byte aligned");
   if (dx_batch_stride == 0) dx_batch_stride = (int64_t)Ki * N;
   S2F_REQUIRE((g_batch_stride & 3) == 0 && (dx_batch_stride & 3) == 0, S2F_EALIGN, "s2f_pgemm_dx_f32: batch strides must keep 16-byte alignment");
   S2F_REQUIRE(w_pack && G && DX, S2F_EINVAL, "s2f_pgemm_dx_f32: null pointer");
@@ -1360,16 +1362,16 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     const dim3 grid(n_tiles * m_tiles, batch, zsplit);                                                                 \
     if (zsplit > 1)                                                                                                    \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 2>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,  \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, 0);          \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr);          \
     else if (beta != 0.f)                                                                                              \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 1>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, 0);          \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr);          \
     else if (part)                                                                                                     \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 1, true>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, \
-                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, part_C);         \
+                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part);         \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, part_C);                \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part);                \
   } while (0)
   switch (c) {
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
@@ -1384,11 +1386,11 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     if (part)                                                                                                          \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2, true>), dim3(n_tiles * m_tiles, batch, 1),        \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
-                 dx_batch_stride, part, part_C);                                                                       \
+                 dx_batch_stride, part);                                                                       \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),              \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
-                 dx_batch_stride, part, part_C);                                                                       \
+                 dx_batch_stride, part);                                                                       \
   } while (0)
     case 7: S2F_PGD2(1, 1, 2, 4); break;         // cfg 4 with 32-row steps (half the barriers per MFMA)
     case 8: S2F_PGD2(1, 2, 2, 2); break;         // cfg 2 with 32-row steps
@@ -1402,13 +1404,12 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
 
 extern "C" int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX,
                                 int64_t dx_batch_stride, int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream) {
-  return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, beta, cfg, nullptr, 0, stream);
+  return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, beta, cfg, nullptr, stream);
 }
 
 extern "C" int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX,
-                                      int64_t dx_batch_stride, float* bn_partials, int partials_channels, int batch, int Mo, int Ki,
-                                      int N, void* stream) {
+                                      int64_t dx_batch_stride, float* bn_partials, int batch, int Mo, int Ki, int N,
+                                      void* stream) {
   S2F_REQUIRE(bn_partials, S2F_EINVAL, "s2f_pgemm_dx_f32_stats: null partials");
-  return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, 0.f, 0, bn_partials, partials_channels,
-                       stream);
+  return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, 0.f, 0, bn_partials, stream);
 }

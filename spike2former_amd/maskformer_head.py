@@ -101,6 +101,14 @@ class MaskFormerHead(nn.Module):
         # Keys / values stay in the channel-major layout the pixel decoder produced ([t, b, C, h*w]); the reference
         # transposes them to token-major and back around every projection (maskformer_head.py:535-540).  key + key_pos
         # depends only on the level, so it is formed once per level instead of once per decoder layer.
+        dec_in, dec_key, kv_spikes = self.decoder_inputs(msm, bs)
+        out_dec = self.run_decoder(query_feat, query_embed, dec_in, dec_key, kv_spikes)
+        return self.sdme(out_dec, mask_features)
+
+    def decoder_inputs(self, msm, bs):
+        """The three memory levels as the decoder layers read them -> (dec_in, dec_key, kv_spikes), one entry per level: the value
+        map  msm + level_embed  and the key map  ... + pos  channel-major, or -- fused -- None, None and the (key, value) spike
+        maps of the cross-attention's k / v neurons computed straight from the pixel decoder's map (ops.sum2_lif)."""
         nl = self.num_transformer_feat_level
         layers = self.transformer_decoder.layers
 
@@ -127,6 +135,13 @@ class MaskFormerHead(nn.Module):
             dec_in.append(d)
             dec_key.append(d + pos)
             kv_spikes.append(None)
+        return dec_in, dec_key, kv_spikes
+
+    def run_decoder(self, query_feat, query_embed, dec_in, dec_key, kv_spikes):
+        """The transformer decoder (detr_layers.py:491-559 per layer; level cycling maskformer_head.py:554-564) -> the stacked
+        [L + 1, T, B, Q, C] queries (initial + after every layer)."""
+        nl = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
         # Keys / values do not depend on the query: with ops.LONG_STREAMS set, the key / value chains of ALL layers (the 1 024 -
         # 16 384-token projections) are launched on a side stream ahead of the serial 100-query chain and overlap with it.
         kv_proj = [None] * self.num_transformer_decoder_layers
@@ -157,9 +172,13 @@ class MaskFormerHead(nn.Module):
                     cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv],
                     kv_projected=kv_proj[i])
                 out_dec.append(query_feat)
-        out_dec = torch.stack(out_dec)
+        return torch.stack(out_dec)
+
+    def sdme(self, out_dec, mask_features):
+        """The SDME block and the mask contraction (maskformer_head.py:568-586): out_dec [L + 1, T, B, Q, C], mask_features the fp32
+        map [T, B, C, H/2, W/2] or mask_feature_spike's bf16 spike map (ops.Spikes: the 1x1 convolution is then folded into the
+        contraction) -> (all_cls_scores, all_mask_preds)."""
         ln, t, bs, nq, C = out_dec.shape
-        # ---- SDME block (maskformer_head.py:568-582)
         z = self.decoder_post_norm(out_dec)
         a = self.alpha * self.decoder_out_spike(z)
         all_cls_scores = ops.linear_tm(a, self.cls_embed.weight, self.cls_embed.bias).mean(1)

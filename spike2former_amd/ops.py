@@ -527,13 +527,14 @@ class _DenseGemm(torch.autograd.Function):
         if ctx.fast:
             y = torch.empty(B, G * M, L, dtype=torch.float32, device=x.device)
             P = _want_partials(stats, B, G * M, L)
-            part = torch.empty(P, G * M, 2, dtype=torch.float32, device=x.device) if P else x.new_empty(0)
+            part = torch.empty(G * M, P, 2, dtype=torch.float32, device=x.device) if P else x.new_empty(0)
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
             for g, w in enumerate(ws):
                 _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)
                 if P:
                     check(lib.s2f_pgemm_dx_f32_stats(_ptr(pack_weight(w, transposed=True)), x.data_ptr() + 4 * g * K * L, G * K * L,
-                                                     y.data_ptr() + 4 * g * M * L, G * M * L, part.data_ptr() + 8 * g * M, G * M,
+                                                     y.data_ptr() + 4 * g * M * L, G * M * L, part.data_ptr() + 8 * g * M * P,
                                                      B, K, M, L, _stream()), "s2f_pgemm_dx_f32_stats")
                 else:
                     check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w, transposed=True)), x.data_ptr() + 4 * g * K * L, G * K * L,
@@ -542,6 +543,7 @@ class _DenseGemm(torch.autograd.Function):
             return y, part
         part = x.new_empty(0)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
         wb = torch.stack(ws, 0).unsqueeze(0).expand(B, G, M, K).reshape(B * G, M, K) if G > 1 else ws[0].expand(B, M, K)
         return bmm_tuned(wb, x.view(B * G, K, L)).view(B, G * M, L), part
 
@@ -549,6 +551,8 @@ class _DenseGemm(torch.autograd.Function):
     def backward(ctx, gy, _gpart=None):
         x, *ws = ctx.saved_tensors
         G = len(ws)
+        if gy is None:
+            return (None,) * (2 + G)
         M, K = ws[0].shape
         B, _, L = x.shape
         gy = gy.contiguous()
@@ -1022,8 +1026,8 @@ class _BNAct(torch.autograd.Function):
         s = _stream()
         ws = None
         single = bool(training) and bool(lib.s2f_bn_single_pass(N, C, L))    # small map: statistics inside s2f_bn_act_fwd
-        if not (training and partials is not None and tuple(partials.shape[1:]) == (C, 2)
-                and partials.shape[0] == lib.s2f_bn_partials_count(N, L) and (BN_PARTIALS_SINGLE or not single)):
+        if not (training and partials is not None and partials.dim() == 3 and partials.shape[0] == C and partials.shape[2] == 2
+                and partials.shape[1] == lib.s2f_bn_partials_count(N, L) and (BN_PARTIALS_SINGLE or not single)):
             partials = None          # the statistics the producing GEMM stored with z (BN_PARTIALS), when they describe this view of it
         if partials is not None:
             BN_PARTIALS_USED[0] += 1
@@ -1048,7 +1052,7 @@ class _BNAct(torch.autograd.Function):
         alg = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
         _time_next("bn_lif_fwd" if lif_on else "bn_fwd", alg, moved=alg - (2 * n if bf16 else 0))
         if partials is not None:
-            check(lib.s2f_bn_act_fwd_partials(_ptr(z), _ptr(conv_bias), _ptr(partials), partials.shape[0], _ptr(stat),
+            check(lib.s2f_bn_act_fwd_partials(_ptr(z), _ptr(conv_bias), _ptr(partials), partials.shape[1], _ptr(stat),
                                               _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual),
                                               _ptr(u), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum,
                                               eps, vth, D, int(bf16), s), "s2f_bn_act_fwd_partials")
@@ -1115,7 +1119,7 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
            partials=None):
     """-> (u or None, y or None, v_out or None [, border]); y is a Spikes pair (bf16 when SPIKES_BF16); border [C] = BN(0)
     from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel.
-    partials: the [P, C, 2] per-tile sums the producing GEMM stored for z (BN_PARTIALS; default: z's `_s2f_part` attribute)."""
+    partials: the [C, P, 2] per-tile sums the producing GEMM stored for z (BN_PARTIALS; default: z's `_s2f_part` attribute)."""
     if partials is None:
         partials = getattr(z, "_s2f_part", None)
     bf16 = bool(lif) and spikes_bf16_ok(D) and z.numel() % 4 == 0          # as ops.lif: consumers read bf16 spikes in 8-byte groups
@@ -1479,7 +1483,7 @@ class _SpikeGemm(torch.autograd.Function):
         _time_next("spike_gemm_fwd", 4 * B * N * (K + M), 2 * B * M * N * K, moved=B * N * ((2 if xb else 4) * K + 4 * M))
         pg = PGEMM and xb and N % 4 == 0 and N >= 8 and SPIKE_GEMM_TERMS == 3
         P = _want_partials(stats and pg and bias is None, B, M, N)
-        part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device) if P else None
+        part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device) if P else None
         if P:
             check(lib.s2f_pgemm_nn_bf16_stats(_ptr(pack_weight(w2d)), _ptr(x), _ptr(y), _ptr(part), B, M, N, K, _stream()),
                   "s2f_pgemm_nn_bf16_stats")
@@ -1502,11 +1506,14 @@ class _SpikeGemm(torch.autograd.Function):
         if part is None:
             part = y.new_empty(0)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)          # (autograd would zero-fill a [P, M, 2] "gradient" of the partials per launch)
         return y, part
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         x, w2d = ctx.saved_tensors
+        if gy is None:
+            return (None,) * 5
         planes = _GRAD_SPLITS.pop(gy.data_ptr(), None) if ctx.takes_split else None
         if planes is not None:
             return _SpikeGemm._backward_split(ctx, x, w2d, planes) + (None,)
@@ -2138,7 +2145,7 @@ class _ConvDense(torch.autograd.Function):
                        moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
             P = _want_partials(stats and PGEMM_CONV and xb and SPIKE_GEMM_TERMS == 3 and bias is None, N, M, H * W)
             if P:
-                part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+                part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device)
                 check(lib.s2f_pgemm_conv3x3_bf16_stats(_ptr(pack_weight_conv3(weight)), _ptr(x), _ptr(y), _ptr(part), N, M, C, H, W,
                                                        _stream()), "s2f_pgemm_conv3x3_bf16_stats")
             elif PGEMM_CONV and xb and SPIKE_GEMM_TERMS == 3:
@@ -2154,6 +2161,7 @@ class _ConvDense(torch.autograd.Function):
             ctx.implicit = True
             part = y.new_empty(0) if part is None else part
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
             return y.view(N, M, Ho, Wo), part
         ctx.implicit = False
         cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
@@ -2166,7 +2174,7 @@ class _ConvDense(torch.autograd.Function):
             pg = PGEMM and xb and L % 4 == 0 and L >= 8 and SPIKE_GEMM_TERMS == 3
             P = _want_partials(stats and pg and bias is None, N, M, L)
             if P:
-                part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+                part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device)
                 check(lib.s2f_pgemm_nn_bf16_stats(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(y), _ptr(part), N, M, L, cols.shape[1],
                                                   _stream()), "s2f_pgemm_nn_bf16_stats")
             elif pg:
@@ -2186,8 +2194,8 @@ class _ConvDense(torch.autograd.Function):
                 _time_next("dx_gemm", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1])
                 P = _want_partials(stats and bias is None, N, M, L)
                 if P:
-                    part = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
-                    check(lib.s2f_pgemm_dx_f32_stats(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, _ptr(part), M, N,
+                    part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device)
+                    check(lib.s2f_pgemm_dx_f32_stats(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, _ptr(part), N,
                                                      cols.shape[1], M, L, _stream()), "s2f_pgemm_dx_f32_stats")
                 else:
                     check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, N, cols.shape[1], M,
@@ -2200,11 +2208,14 @@ class _ConvDense(torch.autograd.Function):
         ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, use_mfma)
         part = y.new_empty(0) if part is None else part
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
         return y.view(N, M, Ho, Wo), part
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         cols, weight = ctx.saved_tensors
+        if gy is None:
+            return (None,) * 8
         N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, has_bias, use_mfma = ctx.geo
         gy = gy.contiguous().view(N, M, Ho * Wo)
         w2d = weight.view(M, -1)

@@ -736,3 +736,142 @@ def test_c2_stage_gradients_teacher_forced(c2):
         assert gx_l2 <= 5e-2 and p_gap <= 2e-1, (name, flipped, gx_l2, gx_off, p_gap, worst_p)
         exact += (gx_l2 <= 1e-5 and p_gap <= 1e-3)
     assert len(rows) == 17 + cfg.pd_layers and exact >= 8, [(r[0], r[2][0], r[3]) for r in rows]
+
+
+def _grad_gaps(grads, ref):
+    """-> (worst relative gap of a parameter gradient, its name); gaps relative to max|ref| + 1e-3 of the overall gradient scale"""
+    gscale = max(v.abs().max().item() for v in ref.values())
+    gaps = {n: (grads[n].cpu() - ref[n]).abs().max().item() / (ref[n].abs().max().item() + 1e-3 * gscale) for n in ref}
+    worst = max(gaps, key=gaps.get)
+    return gaps[worst], worst
+
+
+@pytest.mark.timeout(1800)
+def test_c2_decoder_layer_gradients_teacher_forced(c2):
+    """Full-size BACKWARD parity of the six transformer-decoder layers on the bench path (channel-major query stream, key / value
+    neurons fused with the level / position adds, s2f_sdsa_bwd_bf16 with the straight-through mask in its loaders, the generic
+    BatchNorm backward on 100-token rows, the decoder's grouped weight gradients): each layer is fed the oracle's query, the
+    oracle's memory level (1 024 / 4 096 / 16 384 keys) and a seeded output gradient; the gradients of the query, of the memory
+    map (key + value paths summed), of the level embedding and of every parameter of the layer are compared with the oracle's
+    autograd (detr_layers.py:491-559, mmcv_spike/transformer.py:196-361, 776-784).  A BatchNorm over 100 distinct query rows
+    turns one borderline spike into a shifted column, so a layer whose forward flips a spike is bounded loosely; a layer
+    without any flip must agree to round-off."""
+    s2f, so, cfg, st0, model, img, ref = c2
+    hd = model.decode_head
+    h = "decode_head."
+    t, bs = cfg.T, cfg.B
+    query = st0[h + "query_feat.weight"].unsqueeze(0).repeat(t, bs, 1, 1)
+    qpos = st0[h + "query_embed.weight"].unsqueeze(0).repeat(bs, 1, 1)
+    rows = []
+    for i in range(cfg.dec_layers):
+        lv = i % 3
+        lname = h + f"transformer_decoder.layers.{i}"
+        pref = lname + "."
+        lev = h + "level_embed.weight"
+        st = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k and (k.startswith(pref) or k == lev))
+                  if (k.startswith(pref) or k == lev) else v) for k, v in st0.items()}
+        net = so.OracleNet(st, cfg, training=True)
+        qo = query.clone().requires_grad_(True)
+        mo = ref["msm"][lv].clone().requires_grad_(True)
+        key = mo.flatten(3).permute(0, 1, 3, 2) + st[lev][lv].view(1, 1, -1)
+        kpos = so.sine_pos_embed(bs, mo.shape[-2], mo.shape[-1], cfg.num_feats).flatten(2).permute(0, 2, 1)
+        yo = net._dec_layer(lname, qo, key, qpos, kpos)
+        gy = torch.randn(yo.shape, generator=torch.Generator().manual_seed(300 + i)) / yo.numel() ** 0.5
+        yo.backward(gy)
+        # this build, as the head drives a layer (MaskFormerHead.decoder_inputs / run_decoder)
+        model.load_state_dict(st0, strict=True)
+        layer = hd.transformer_decoder.layers[i]
+        for p in list(layer.parameters()) + [hd.level_embed.weight]:
+            p.grad = None
+        s2f.reset_net(model)
+        msm = [m.cuda() for m in ref["msm"]]
+        msm[lv].requires_grad_(True)
+        qg = query.cuda().requires_grad_(True)
+        dec_in, dec_key, kv = hd.decoder_inputs(msm, bs)
+        assert kv[lv] is not None                      # the fused key / value neurons (s2f_sum2_lif_fwd / _bwd)
+        out, _ = layer.forward_stream(qg.transpose(2, 3).contiguous(), qpos.cuda().transpose(1, 2).contiguous(), key=dec_key[lv],
+                                      value=dec_in[lv], kv_spikes=kv[lv], kv_projected=None, last=True)
+        out.backward(gy.cuda())
+        s2f.ops.wgrad_join()
+        flipped = rel_l2(out.detach().cpu(), yo.detach()) > 1e-5
+        grads = {pref + n: p.grad for n, p in layer.named_parameters() if p.grad is not None}
+        grads[lev] = hd.level_embed.weight.grad
+        refg = {n: st[n].grad for n in grads if st[n].grad is not None}
+        assert len(refg) >= 20, (i, len(refg), len(grads))
+        p_gap, worst = _grad_gaps(grads, refg)
+        rows.append((i, flipped, rel_l2(qg.grad.cpu(), qo.grad), rel_l2(msm[lv].grad.cpu(), mo.grad), p_gap, worst))
+        query = yo.detach()                            # teacher forcing: the next layer starts from the oracle's output
+    model.load_state_dict(st0, strict=True)
+    print("decoder-layer gradient gaps (layer, flipped, gq, gmemory, worst parameter):",
+          [(r[0], r[1], f"{r[2]:.1e}", f"{r[3]:.1e}", f"{r[4]:.1e}", r[5].split("layers.")[-1]) for r in rows])
+    for i, flipped, gq, gm, p_gap, worst in rows:
+        assert gq <= 5e-2 and gm <= 5e-2 and p_gap <= 2e-1, (i, flipped, gq, gm, p_gap, worst)
+        if not flipped:
+            assert gq <= 1e-4 and gm <= 1e-4 and p_gap <= 2e-3, (i, gq, gm, p_gap, worst)
+
+
+@pytest.mark.timeout(1800)
+def test_c2_sdme_and_folded_mask_contraction_gradients(c2):
+    """Full-size BACKWARD parity of the head's tail (dense_heads/maskformer_head.py:568-586): sigmoid -> neurons -> cls_embed,
+    the mask-embedding MLP, the query-mixing shortcut Conv1d + BatchNorm1d(100), mask_embed_spike, and the mask contraction with the
+    pixel decoder's mask_feature 1x1 convolution FOLDED into it (ops.mask_einsum_folded: the T-mean inside the contraction, dE on
+    the spike operand, dS = W^T G).  Inputs: the oracle's seven decoder states and a seeded spike map in place of
+    mask_feature_spike's output (both sides apply the same neuron to the same counts); outputs weighted by seeded gradients.
+    Compared: the gradients of the decoder states, of the spike map's input, and of every parameter of the tail including the
+    folded convolution's weight and bias."""
+    s2f, so, cfg, st0, model, img, ref = c2
+    hd = model.decode_head
+    h = "decode_head."
+    t, bs = cfg.T, cfg.B
+    names = [k for k in st0 if k.startswith(h) and any(k.startswith(h + n) for n in
+             ("cls_embed.", "mask_embed.", "shortcut_conv.", "w", "pixel_decoder.mask_feature.")) and "running" not in k
+             and "num_batches" not in k and not k.startswith(h + "pixel_decoder.mask_feature_")]
+    st = {k: (v.clone().requires_grad_(k in names) if k in names else v.clone()) for k, v in st0.items()}
+    net = so.OracleNet(st, cfg, training=True)
+    # the seven decoder states: the oracle's own forward through the six layers from the oracle's memory levels
+    query = st0[h + "query_feat.weight"].unsqueeze(0).repeat(t, bs, 1, 1)
+    qpos = st0[h + "query_embed.weight"].unsqueeze(0).repeat(bs, 1, 1)
+    outs = [query]
+    with torch.no_grad():
+        for i in range(cfg.dec_layers):
+            m = ref["msm"][i % 3]
+            key = m.flatten(3).permute(0, 1, 3, 2) + st0[h + "level_embed.weight"][i % 3].view(1, 1, -1)
+            kpos = so.sine_pos_embed(bs, m.shape[-2], m.shape[-1], cfg.num_feats).flatten(2).permute(0, 2, 1)
+            query = net._dec_layer(h + f"transformer_decoder.layers.{i}", query, key, qpos, kpos)
+            outs.append(query)
+    O = torch.stack(outs)
+    C, Hm, Wm = cfg.feat_channels, cfg.H // 2, cfg.W // 2
+    g = torch.Generator().manual_seed(77)
+    counts = (torch.randn(t, bs, C, Hm, Wm, generator=g) * 1.5 + 0.5).round().clamp_(0, 8)        # the neuron's input: its own counts
+    Oo, xo = O.clone().requires_grad_(True), counts.clone().requires_grad_(True)
+    net.reset()
+    so_spk = net.lif(h + "pixel_decoder.mask_feature_spike", xo)
+    mf = net.conv2d(h + "pixel_decoder.mask_feature", so_spk.flatten(0, 1))
+    cls_o, masks_o = net._sdme(Oo, mf.reshape(t, bs, *mf.shape[1:]))
+    g_cls = torch.randn(cls_o.shape, generator=g) / cls_o.numel() ** 0.5
+    g_masks = torch.randn(masks_o.shape, generator=g) / masks_o.numel() ** 0.5
+    ((cls_o * g_cls).sum() + (masks_o * g_masks).sum()).backward()
+    # this build
+    model.load_state_dict(st0, strict=True)
+    for p in hd.parameters():
+        p.grad = None
+    s2f.reset_net(model)
+    Og, xg = O.cuda().requires_grad_(True), counts.cuda().requires_grad_(True)
+    spk = hd.pixel_decoder.mask_feature_spike.fire(xg)
+    assert isinstance(spk, s2f.ops.Spikes) and spk.tok is not None          # the bf16 pair the folded contraction takes
+    cls, masks = hd.sdme(Og, spk)
+    ((cls * g_cls.cuda()).sum() + (masks * g_masks.cuda()).sum()).backward()
+    s2f.ops.wgrad_join()
+    flipped = rel_l2(masks.detach().cpu(), masks_o.detach()) > 1e-5 or rel_l2(cls.detach().cpu(), cls_o.detach()) > 1e-5
+    params = dict(model.named_parameters())
+    grads = {n: params[n].grad for n in names if params[n].grad is not None}
+    refg = {n: st[n].grad for n in grads if st[n].grad is not None}
+    assert set(refg) == set(names), sorted(set(names) - set(refg))
+    p_gap, worst = _grad_gaps(grads, refg)
+    gO, gx = rel_l2(Og.grad.cpu(), Oo.grad), rel_l2(xg.grad.cpu(), xo.grad)
+    print("head-tail gradient gaps (flipped, g_states, g_spike_input, worst parameter):", flipped, f"{gO:.1e}", f"{gx:.1e}", f"{p_gap:.1e}", worst)
+    assert rel_l2(masks.detach().cpu(), masks_o.detach()) <= 2e-2 and rel_l2(cls.detach().cpu(), cls_o.detach()) <= 2e-2
+    assert gO <= 5e-2 and gx <= 5e-2 and p_gap <= 2e-1, (flipped, gO, gx, p_gap, worst)
+    if not flipped:
+        assert gO <= 1e-4 and gx <= 1e-4 and p_gap <= 2e-3, (gO, gx, p_gap, worst)
+    model.load_state_dict(st0, strict=True)

