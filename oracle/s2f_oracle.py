@@ -339,6 +339,7 @@ class OracleNet:
         self.firing: "OrderedDict[str, float]" = OrderedDict()
         self.keep_membrane_graph = False
         self.tap = None      # optional callable(name, tensor) for intermediate captures
+        self.tap_in = None   # optional callable(name, h): every neuron's membrane before the threshold (the STE mask is 0 <= h <= D)
         self.stages = None   # optional dict: stage name -> (input, output) of every backbone stage / encoder layer
 
     def reset(self):
@@ -346,6 +347,9 @@ class OracleNet:
 
     # ---- primitives
     def lif(self, name, x):
+        if self.tap_in is not None:
+            v = self.membranes.get(name)
+            self.tap_in(name, (x if v is None else v + x).detach())
         y, v_new, s = lif_step(x, self.membranes.get(name), self.cfg.D)
         self.membranes[name] = v_new if (self.keep_membrane_graph or not v_new.requires_grad) else v_new.detach()
         self.firing[name] = float(s.detach().mean())

@@ -670,16 +670,79 @@ _BB_STAGES = [("downsample1_1", "_down", (7, 2, 3, True)), ("ConvBlock1_1.0", "_
              [(f"block4.{i}", "_block", ()) for i in range(2)]
 
 
+class SteBits:
+    """What explains a gradient gap between two correct fp32 implementations of a stage: the neurons whose SPIKE differs by a level
+    (an input within round-off of k + 0.5) and the neurons whose straight-through MASK bit 1[0 <= h <= D] differs although the
+    spike does not (h within round-off of 0 or D).  The oracle's side is collected while it runs (OracleNet.tap / tap_in); this
+    build's side by a second, hooked forward of the stage (nn.Module forward hooks see (input, fp32 spikes) of every Q_IFNode,
+    fused ones included; that module-call path agrees with the bench path to fp32 round-off, not bit for bit, so it can meet a
+    borderline element the bench path does not and vice versa -- the caller combines it with the bench path's own output
+    comparison).  Neurons are matched by name and walked in execution order up to and including the first one whose spikes
+    differ; a map whose two layouts differ (token- vs channel-major) is transposed when that makes the shapes agree, otherwise it
+    counts as not comparable."""
+
+    def __init__(self, net, D=8, state=None):
+        self.D, self.masks, self.spikes, self.state = D, {}, {}, state
+        net.tap = lambda n, y: self.spikes.__setitem__(n, (y.detach() * D).round().to(torch.uint8))
+        net.tap_in = lambda n, h: self.masks.__setitem__(n, (h >= 0) & (h <= D))
+        self.net = net
+
+    def detach(self):
+        self.net.tap = self.net.tap_in = None
+
+    def count(self, s2f, model, mod, prefix, run):
+        """run(): one forward of `mod` on this build -> (neurons compared, not comparable, elements, differing spikes, differing mask
+        bits where the spike agrees)"""
+        mine = {}
+
+        def grab(m, inp, out, n):
+            if n not in mine:
+                u = inp[0].detach()
+                mine[n] = (((u >= 0) & (u <= self.D)).cpu(), (out.detach() * self.D).round().to(torch.uint8).cpu())
+        hooks = [m.register_forward_hook(lambda m_, i_, o_, n=n: grab(m_, i_, o_, n)) for n, m in mod.named_modules()
+                 if isinstance(m, s2f.Q_IFNode)]
+        if self.state is not None:
+            # the first forward updated the BatchNorm running statistics, which BNAndPadLayer's border value reads even in training
+            model.load_state_dict(self.state, strict=True)
+        s2f.reset_net(model)
+        with torch.no_grad():
+            run()
+        for hk in hooks:
+            hk.remove()
+        compared = skipped = elems = dspk = dmask = 0
+        for n, (mk, spk) in mine.items():          # execution order (dict order = first call)
+            key = f"{prefix}.{n}" if n else prefix
+            if key not in self.spikes or self.spikes[key].numel() != spk.numel():
+                skipped += 1
+                continue
+            rs, rm = self.spikes[key], self.masks[key]
+            if tuple(spk.shape[-2:]) != tuple(rs.shape[-2:]) and tuple(spk.shape[-2:]) == tuple(rs.shape[-2:])[::-1]:
+                spk, mk = spk.reshape(-1, *spk.shape[-2:]).transpose(1, 2), mk.reshape(-1, *mk.shape[-2:]).transpose(1, 2)
+            ds = spk.reshape(-1) != rs.reshape(-1)
+            if ds.float().mean().item() > 1e-2:          # different layouts of the same map (or a stage downstream of a flip)
+                skipped += 1
+                continue
+            compared += 1
+            elems += spk.numel()
+            dspk += int(ds.sum())
+            dmask += int(((mk.reshape(-1) != rm.reshape(-1)) & ~ds).sum())
+            if ds.any():          # downstream of a spike flip the maps legitimately diverge: the walk ends at the first one
+                break
+        return compared, skipped, elems, dspk, dmask
+
+
 def _stage_backward(s2f, so, cfg, st0, model, mod, name, fn, args, x, seed):
     """One stage, forward AND backward, on both sides from the oracle's input x and a seeded output gradient:
-    -> (flipped?, gx gap, worst parameter-gradient gap), gaps relative to the gradient scale."""
+    -> (flipped?, gx gap, worst parameter-gradient gap, its name, SteBits.count), gaps relative to the gradient scale."""
     # oracle (CPU autograd on a private copy of the parameters of this stage)
     pref = name + "."
     st = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k and k.startswith(pref)) if k.startswith(pref) else v)
           for k, v in st0.items()}
     net = so.OracleNet(st, cfg, training=True)
+    bits = SteBits(net, state=st0)
     xo = x.clone().requires_grad_(True)
     yo = getattr(net, fn)(name, xo, *args)
+    bits.detach()
     gy = torch.randn(yo.shape, generator=torch.Generator().manual_seed(seed)) / yo.numel() ** 0.5
     yo.backward(gy)
     # this build: the bench path (bf16 spike maps, fused kernels, no hooks)
@@ -698,7 +761,9 @@ def _stage_backward(s2f, so, cfg, st0, model, mod, name, fn, args, x, seed):
     gscale = max(v.abs().max().item() for v in ref.values())
     gaps = {n: (grads[n].cpu() - ref[n]).abs().max().item() / (ref[n].abs().max().item() + 1e-3 * gscale) for n in ref}
     assert len(ref) >= 2, (name, list(grads))
-    return flipped, gx_gap, max(gaps.values()), max(gaps, key=gaps.get)
+    xc = x.cuda()
+    counted = bits.count(s2f, model, mod, name, lambda: mod(xc))
+    return flipped, gx_gap, max(gaps.values()), max(gaps, key=gaps.get), counted
 
 
 @pytest.mark.timeout(1800)
@@ -714,8 +779,13 @@ def test_c2_stage_gradients_teacher_forced(c2):
     the head).  Measured (one run, 23 stages): the five down-samplings, block3.0, block3.4 and four of the six pixel-decoder
     layers meet no such boundary and agree to 2e-7 .. 1.4e-6 in relative L2 of the input gradient and <= 5e-4 of the gradient
     scale in every parameter gradient -- the kernels themselves are exact to round-off; the stages that do meet one range up to
-    3.9e-2 / 1.6e-1 (block4.0, which also has a forward spike flip).  Asserted: every stage within 5e-2 (input gradient, relative
-    L2) and 2e-1 (parameter gradients); at least 8 stages exact to 1e-5 / 1e-3."""
+    3.9e-2 / 1.6e-1 (block4.0, which also has a forward spike flip).
+    Round 4: the explanation is CHECKED, not assumed.  Every neuron of the stage is compared with the oracle's in its spike and in
+    its mask bit (SteBits: a second, hooked forward, walked in execution order up to the first spike flip).  Asserted: (1) a stage
+    whose output agrees with the oracle's and in which no spike and no mask bit differs agrees to round-off -- 1e-5 (input gradient,
+    relative L2) and 1e-3 (parameter gradients); (2) the differing bits are few: <= 1e-4 of the neuron elements walked (measured:
+    0, 4 or 8 bits -- the T = 4 replicas of one or two elements -- of 10^7..10^8); (3) a stage that does meet such a bit stays within
+    5e-2 / 2e-1; at least 8 stages exact."""
     s2f, so, cfg, st0, model, img, ref = c2
     bb, pd = model.backbone, model.decode_head.pixel_decoder
     rows = []
@@ -730,10 +800,16 @@ def test_c2_stage_gradients_teacher_forced(c2):
         rows.append((name,) + _stage_backward(s2f, so, cfg, st0, model, pd.encoder.layers[i], name, "_enc_layer", (),
                                               ref["stages"][name][0], 200 + i))
     model.load_state_dict(st0, strict=True)
-    print("stage-gradient gaps:", [(r[0].split(".", 1)[1], r[1], f"{r[2][0]:.1e}", f"{r[2][1]:.1e}", f"{r[3]:.1e}") for r in rows])
+    print("stage-gradient gaps (stage, output differs, gx rel-L2, gx fraction off, worst parameter gap, (neurons compared, not "
+          "comparable, elements, differing spikes, differing mask bits)):",
+          [(r[0].split(".", 1)[1], r[1], f"{r[2][0]:.1e}", f"{r[2][1]:.1e}", f"{r[3]:.1e}", r[5]) for r in rows])
     exact = 0
-    for name, flipped, (gx_l2, gx_off), p_gap, worst_p in rows:
+    for name, flipped, (gx_l2, gx_off), p_gap, worst_p, (compared, skipped, elems, dspk, dmask) in rows:
         assert gx_l2 <= 5e-2 and p_gap <= 2e-1, (name, flipped, gx_l2, gx_off, p_gap, worst_p)
+        assert compared >= (0 if name.endswith("downsample1_1") else 1), (name, compared, skipped)
+        assert dspk + dmask <= max(1e-4 * elems, 4), (name, elems, dspk, dmask)
+        if not flipped and skipped == 0 and dspk == 0 and dmask == 0:          # nothing that could explain a gap: there must be none
+            assert gx_l2 <= 1e-5 and p_gap <= 1e-3, (name, gx_l2, p_gap, worst_p)
         exact += (gx_l2 <= 1e-5 and p_gap <= 1e-3)
     assert len(rows) == 17 + cfg.pd_layers and exact >= 8, [(r[0], r[2][0], r[3]) for r in rows]
 
@@ -754,8 +830,9 @@ def test_c2_decoder_layer_gradients_teacher_forced(c2):
     oracle's memory level (1 024 / 4 096 / 16 384 keys) and a seeded output gradient; the gradients of the query, of the memory
     map (key + value paths summed), of the level embedding and of every parameter of the layer are compared with the oracle's
     autograd (detr_layers.py:491-559, mmcv_spike/transformer.py:196-361, 776-784).  A BatchNorm over 100 distinct query rows
-    turns one borderline spike into a shifted column, so a layer whose forward flips a spike is bounded loosely; a layer
-    without any flip must agree to round-off."""
+    turns one borderline spike into a shifted column, and one straight-through mask bit at a key neuron changes the memory gradient
+    of that token; so the layer's 15 neurons are compared with the oracle's in spike AND mask bit (SteBits): a layer in which none
+    differs must agree to round-off, the others are bounded loosely, and the differing bits must be few."""
     s2f, so, cfg, st0, model, img, ref = c2
     hd = model.decode_head
     h = "decode_head."
@@ -763,6 +840,7 @@ def test_c2_decoder_layer_gradients_teacher_forced(c2):
     query = st0[h + "query_feat.weight"].unsqueeze(0).repeat(t, bs, 1, 1)
     qpos = st0[h + "query_embed.weight"].unsqueeze(0).repeat(bs, 1, 1)
     rows = []
+    s2f.set_keep_membrane(model, False)                # as bench.py: a reset precedes every step (the fused key / value neurons need it)
     for i in range(cfg.dec_layers):
         lv = i % 3
         lname = h + f"transformer_decoder.layers.{i}"
@@ -771,11 +849,13 @@ def test_c2_decoder_layer_gradients_teacher_forced(c2):
         st = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k and (k.startswith(pref) or k == lev))
                   if (k.startswith(pref) or k == lev) else v) for k, v in st0.items()}
         net = so.OracleNet(st, cfg, training=True)
+        bits = SteBits(net, state=st0)
         qo = query.clone().requires_grad_(True)
         mo = ref["msm"][lv].clone().requires_grad_(True)
         key = mo.flatten(3).permute(0, 1, 3, 2) + st[lev][lv].view(1, 1, -1)
         kpos = so.sine_pos_embed(bs, mo.shape[-2], mo.shape[-1], cfg.num_feats).flatten(2).permute(0, 2, 1)
         yo = net._dec_layer(lname, qo, key, qpos, kpos)
+        bits.detach()
         gy = torch.randn(yo.shape, generator=torch.Generator().manual_seed(300 + i)) / yo.numel() ** 0.5
         yo.backward(gy)
         # this build, as the head drives a layer (MaskFormerHead.decoder_inputs / run_decoder)
@@ -787,10 +867,12 @@ def test_c2_decoder_layer_gradients_teacher_forced(c2):
         msm = [m.cuda() for m in ref["msm"]]
         msm[lv].requires_grad_(True)
         qg = query.cuda().requires_grad_(True)
-        dec_in, dec_key, kv = hd.decoder_inputs(msm, bs)
-        assert kv[lv] is not None                      # the fused key / value neurons (s2f_sum2_lif_fwd / _bwd)
-        out, _ = layer.forward_stream(qg.transpose(2, 3).contiguous(), qpos.cuda().transpose(1, 2).contiguous(), key=dec_key[lv],
-                                      value=dec_in[lv], kv_spikes=kv[lv], kv_projected=None, last=True)
+        def run(q):
+            dec_in, dec_key, kv = hd.decoder_inputs(msm, bs)
+            return kv[lv], layer.forward_stream(q.transpose(2, 3).contiguous(), qpos.cuda().transpose(1, 2).contiguous(), key=dec_key[lv],
+                                                value=dec_in[lv], kv_spikes=kv[lv], kv_projected=None, last=True)[0]
+        fused_kv, out = run(qg)
+        assert fused_kv is not None                    # the fused key / value neurons (s2f_sum2_lif_fwd / _bwd)
         out.backward(gy.cuda())
         s2f.ops.wgrad_join()
         flipped = rel_l2(out.detach().cpu(), yo.detach()) > 1e-5
@@ -799,14 +881,18 @@ def test_c2_decoder_layer_gradients_teacher_forced(c2):
         refg = {n: st[n].grad for n in grads if st[n].grad is not None}
         assert len(refg) >= 20, (i, len(refg), len(grads))
         p_gap, worst = _grad_gaps(grads, refg)
-        rows.append((i, flipped, rel_l2(qg.grad.cpu(), qo.grad), rel_l2(msm[lv].grad.cpu(), mo.grad), p_gap, worst))
+        counted = bits.count(s2f, model, layer, lname, lambda: run(qg.detach()))
+        rows.append((i, flipped, rel_l2(qg.grad.cpu(), qo.grad), rel_l2(msm[lv].grad.cpu(), mo.grad), p_gap, worst, counted))
         query = yo.detach()                            # teacher forcing: the next layer starts from the oracle's output
+    s2f.set_keep_membrane(model, True)
     model.load_state_dict(st0, strict=True)
-    print("decoder-layer gradient gaps (layer, flipped, gq, gmemory, worst parameter):",
-          [(r[0], r[1], f"{r[2]:.1e}", f"{r[3]:.1e}", f"{r[4]:.1e}", r[5].split("layers.")[-1]) for r in rows])
-    for i, flipped, gq, gm, p_gap, worst in rows:
+    print("decoder-layer gradient gaps (layer, output differs, gq, gmemory, worst parameter, (neurons compared, not comparable, "
+          "elements, differing spikes, differing mask bits)):",
+          [(r[0], r[1], f"{r[2]:.1e}", f"{r[3]:.1e}", f"{r[4]:.1e}", r[5].split("layers.")[-1], r[6]) for r in rows])
+    for i, flipped, gq, gm, p_gap, worst, (compared, skipped, elems, dspk, dmask) in rows:
         assert gq <= 5e-2 and gm <= 5e-2 and p_gap <= 2e-1, (i, flipped, gq, gm, p_gap, worst)
-        if not flipped:
+        assert compared >= 1 and dspk + dmask <= max(1e-4 * elems, 4), (i, compared, skipped, elems, dspk, dmask)
+        if not flipped and skipped == 0 and dspk == 0 and dmask == 0:          # nothing that could explain a gap: there must be none
             assert gq <= 1e-4 and gm <= 1e-4 and p_gap <= 2e-3, (i, gq, gm, p_gap, worst)
 
 
@@ -855,6 +941,7 @@ def test_c2_sdme_and_folded_mask_contraction_gradients(c2):
     model.load_state_dict(st0, strict=True)
     for p in hd.parameters():
         p.grad = None
+    s2f.set_keep_membrane(model, False)
     s2f.reset_net(model)
     Og, xg = O.cuda().requires_grad_(True), counts.cuda().requires_grad_(True)
     spk = hd.pixel_decoder.mask_feature_spike.fire(xg)
@@ -874,4 +961,41 @@ def test_c2_sdme_and_folded_mask_contraction_gradients(c2):
     assert gO <= 5e-2 and gx <= 5e-2 and p_gap <= 2e-1, (flipped, gO, gx, p_gap, worst)
     if not flipped:
         assert gO <= 1e-4 and gx <= 1e-4 and p_gap <= 2e-3, (gO, gx, p_gap, worst)
+    s2f.set_keep_membrane(model, True)
     model.load_state_dict(st0, strict=True)
+
+
+@pytest.mark.timeout(900)
+def test_c2_batchnorm_statistics_come_from_the_gemm_epilogues(c2):
+    """Round 4: in a C2 training step every BatchNorm whose input is produced by one of the packed-weight GEMM / implicit 3x3 kernels
+    takes its statistics from that kernel's epilogue partials (ops.BN_PARTIALS; s2f_bn_act_fwd_partials) -- the statistics pass
+    s2f_bn_stats is left only for the depthwise-convolution outputs of the large FPN levels -- and the step's outputs agree with the
+    statistics-pass form to the fp64 summation order (spikes may flip at borderline elements: compared per stage elsewhere; here the
+    first backbone stage, which has no neuron, must agree to 1e-6)."""
+    s2f, so, cfg, st0, model, img, ref = c2
+    ops = s2f.ops
+    assert ops.BN_PARTIALS
+    model.load_state_dict(st0, strict=True)
+    s2f.set_keep_membrane(model, False)
+    x = img.cuda()
+    outs = []
+    for on in (True, False):
+        ops.BN_PARTIALS = on
+        try:
+            model.load_state_dict(st0, strict=True)
+            s2f.reset_net(model)
+            before = list(ops.BN_PARTIALS_USED)
+            with torch.no_grad():
+                cls, masks = model(x)
+                x1 = model.backbone.downsample1_1(x.unsqueeze(0).repeat(cfg.T, 1, 1, 1, 1))
+            outs.append((cls, masks, x1, [a - b for a, b in zip(ops.BN_PARTIALS_USED, before)]))
+        finally:
+            ops.BN_PARTIALS = True
+    s2f.set_keep_membrane(model, True)
+    model.load_state_dict(st0, strict=True)
+    (c1, m1, d1, used_on), (c0, m0, d0, used_off) = outs
+    print("BatchNorm launches fed by partials / statistics passes:", used_on, "with the switch off:", used_off)
+    assert used_off[0] == 0 and used_off[1] >= 70
+    assert used_on[0] >= 70 and used_on[1] <= 8, used_on
+    assert rel_l2(d1.cpu(), d0.cpu()) <= 1e-6
+    assert torch.isfinite(m1).all() and m1.shape == m0.shape and c1.shape == c0.shape
