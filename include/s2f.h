@@ -296,9 +296,10 @@ int s2f_pgemm_conv3x3_f32(const uint16_t* w_pack, const float* X, float* Y, int 
  *   bn_partials[(row * P + p) * 2 + {0, 1}],   p = b * ceil(N / 128) + column tile,   P = s2f_bn_partials_count(batch, N)
  * (channel-major: one channel's partials are contiguous; plain stores: no atomics, nothing to zero, deterministic).  A group of a
  * grouped product (s2f_pgemm_dx_f32_stats with batch strides) writes its rows into a wider table: pass bn_partials + 2 * first_row * P.
- * s2f_bn_act_fwd_partials is s2f_bn_act_fwd in training mode taking these partials instead of the sums of s2f_bn_stats: the
- * apply kernels add the P partials of a channel in fp64 in a fixed order (the statistics are those of z; conv_bias shifts the
- * mean).  The statistics pass over z -- one read of the tensor and one launch per BatchNorm -- disappears. */
+ * s2f_bn_partials_finalize adds the P partials of every channel in fp64 in a fixed order into sums_out (double[2C], need not be
+ * zeroed) -- the sums s2f_bn_stats produces (of z + conv_bias?: the shift is applied to the sums), which s2f_bn_act_fwd then takes
+ * as `sums`.  The statistics pass over z -- one read of the tensor per BatchNorm, 5-47 us at C2 -- becomes a 2.5-4 us launch over
+ * P * C * 8 bytes, and the statistics no longer depend on the order of fp64 atomics. */
 int64_t s2f_bn_partials_count(int batch, int N);
 int s2f_pgemm_nn_bf16_stats(const uint16_t* a_pack, const uint16_t* X, float* Y, float* bn_partials, int batch, int M, int N, int K,
                             void* stream);
@@ -306,11 +307,8 @@ int s2f_pgemm_conv3x3_bf16_stats(const uint16_t* w_pack, const uint16_t* X, floa
                                  int H, int W, void* stream);
 int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
                            float* bn_partials, int batch, int Mo, int Ki, int N, void* stream);
-int s2f_bn_act_fwd_partials(const float* z, const float* conv_bias, const float* partials, int64_t P, float* stat_out,
-                            float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
-                            const float* beta, const float* residual, float* u_out, const float* v_in, void* y, float* v_out,
-                            uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L, float momentum, float eps,
-                            float vth, int D, int y_bf16, void* stream);
+int s2f_bn_partials_finalize(const float* partials, int64_t P, const float* conv_bias, double* sums_out, int64_t N, int64_t C,
+                             int64_t L, void* stream);
 /* The gradient of a GEMM-produced pre-activation as THREE bf16 PLANES hi | mid | lo (gz = hi + mid + lo to 2^-24; plane p at
  * gz_split + p * N C L): s2f_bn_act_bwd_split is s2f_bn_act_bwd writing that form instead of fp32 (6 instead of 4 bytes per
  * element), s2f_pgemm_dx_split the input-gradient product reading it (plane p of batch b at G_split + p * plane_stride +

@@ -71,7 +71,7 @@ SIGNATURES = {
     "s2f_pgemm_nn_bf16_stats": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "s2f_pgemm_conv3x3_bf16_stats": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "s2f_pgemm_dx_f32_stats": (_i, [_p, _p, _i64, _p, _i64, _p] + [_i] * 4 + [_p]),
-    "s2f_bn_act_fwd_partials": (_i, [_p] * 3 + [_i64] + [_p] * 13 + [_i64] * 3 + [_f, _f, _f, _i, _i, _p]),
+    "s2f_bn_partials_finalize": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "s2f_bn_act_bwd_split": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
     "s2f_mask_cost_bins": (_i, [_p, _p, _p, _i, _i, _i64, _i, _f, _f, _f, _p]),
     "s2f_mask_loss_seg_fwd": (_i, [_p] * 4 + [_i] * 4 + [_f, _f, _p]),

@@ -126,73 +126,55 @@ __device__ __forceinline__ ChanStat chan_stat(const double* __restrict__ sums, c
   return r;
 }
 // Statistics handed over as per-tile PARTIALS of the producing GEMM's epilogue (pgemm.hip epi_row_partials): part[(c * P + p) * 2 +
-// {0, 1}], p < P (channel-major).  The P partials of a channel are added in fp64 in a fixed order -- by one thread (few partials: consecutive
-// threads read consecutive channels), or strided over the lanes of a wavefront and folded by shuffles.
-__device__ __forceinline__ ChanStat chan_stat_partials_thread(const float* __restrict__ part, int P, int C, int c, float bias_c,
-                                                              double inv_count, float eps) {
-  double a = 0, b = 0;
-  for (int p0 = 0; p0 < P; p0 += 8) {          // eight loads in flight (a plain loop waits for each load in turn)
-    float2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      v[u] = p0 + u < P ? *reinterpret_cast<const float2*>(part + ((int64_t)c * P + p0 + u) * 2) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      a += (double)v[u].x;
-      b += (double)v[u].y;
-    }
-  }
-  return chan_stat_of(a, b, (double)bias_c, inv_count, eps);
-}
-// Many partials (a large map: hundreds to thousands per channel, but then a workgroup's run of tiles touches one to three
-// channels): the `nch` channels c0, c0 + 1, .. (mod C) are shared out over the workgroup's wavefronts -- all four on one channel,
-// two each on two, one each on more -- eight loads in flight per lane, folded through shuffles and LDS in a fixed order.
-// Uniform control flow (every wavefront runs every round).  red: 2 kWaves doubles of LDS.
-__device__ __forceinline__ void chan_stats_partials_block(const float* __restrict__ part, int P, int C, uint32_t c0, uint32_t nch,
-                                                          const float* __restrict__ bias, double inv_count, float eps,
-                                                          double* red, float* sstat) {
+// {0, 1}], p < P (channel-major).  bn_partials_finalize_kernel adds the P partials of every channel in fp64 in a fixed order and
+// writes the sums s2f_bn_stats would have produced (of z + bias: the shift by the conv bias is applied to the sums) -- a launch of
+// 2.5-4 us that reads P * C * 8 bytes in place of a pass over z (5-47 us at C2).  (Built and measured first, round 4: the apply
+// kernels adding the partials of the channels they touch in their own prologue, no extra launch -- +9.7 us per launch of the
+// row-walking kernel on the large maps (thousands of partials per channel behind two block-wide barriers, in front of every
+// workgroup's first tile), +2.4 us on the 100-token decoder rows: 0.41 ms per step against 0.31 for these launches, and the fused
+// BatchNorm + neuron kernel itself -- the kernel the roofline figure is quoted on -- got 10 % slower.)
+// grid: one workgroup per channel (P > 256) or one wavefront per channel (four channels per workgroup).
+__global__ __launch_bounds__(kBlock) void bn_partials_finalize_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                      double* __restrict__ sums, int P, int C, double count,
+                                                                      int per_wave) {
+  __shared__ double red[2 * kWaves];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wpc = nch >= (uint32_t)kWaves ? 1 : kWaves / (int)nch;          // wavefronts per channel: 4, 2, 1
-  const int groups = kWaves / wpc, g = w / wpc, wg = w % wpc;
-  for (uint32_t k0 = 0; k0 < nch; k0 += groups) {
-    const uint32_t k = k0 + g;
-    const bool live = k < nch && g < groups;
-    const uint32_t c = (c0 + (live ? k : 0u)) % (uint32_t)C;
-    double a = 0, b = 0;
-    if (live) {
-      for (int p0 = wg * 64 + lane; p0 < P; p0 += 8 * wpc * 64) {
-        float2 v[8];
+  const int c = per_wave ? blockIdx.x * kWaves + w : blockIdx.x;
+  const int first = per_wave ? lane : threadIdx.x, stride = per_wave ? 64 : kBlock;
+  double a = 0, b = 0;
+  if (c < C) {
+    for (int p0 = first; p0 < P; p0 += 8 * stride) {          // eight loads in flight
+      float2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int p = p0 + u * wpc * 64;
-          v[u] = p < P ? *reinterpret_cast<const float2*>(part + ((int64_t)c * P + p) * 2) : make_float2(0.f, 0.f);
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * stride;
+        v[u] = p < P ? *reinterpret_cast<const float2*>(part + ((int64_t)c * P + p) * 2) : make_float2(0.f, 0.f);
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          a += (double)v[u].x;
-          b += (double)v[u].y;
-        }
+      for (int u = 0; u < 8; ++u) {
+        a += (double)v[u].x;
+        b += (double)v[u].y;
       }
     }
-    a = wave_sum_f64(a);
-    b = wave_sum_f64(b);
-    __syncthreads();                                   // `red` may still be read from the previous round
+  }
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  if (!per_wave) {
     if (lane == 0) {
       red[2 * w] = a;
       red[2 * w + 1] = b;
     }
     __syncthreads();
-    if (live && wg == 0 && lane == 0) {
-      a = 0, b = 0;
-      for (int i = 0; i < wpc; ++i) {
-        a += red[2 * (g * wpc + i)];
-        b += red[2 * (g * wpc + i) + 1];
-      }
-      const ChanStat cs = chan_stat_of(a, b, (double)(bias ? bias[c] : 0.f), inv_count, eps);
-      sstat[c] = cs.mean;
-      sstat[C + c] = cs.rstd;
-      sstat[2 * C + c] = cs.var;
+    a = 0, b = 0;
+    for (int i = 0; i < kWaves; ++i) {
+      a += red[2 * i];
+      b += red[2 * i + 1];
     }
+  }
+  if (c < C && (per_wave ? lane == 0 : threadIdx.x == 0)) {
+    const double sh = bias ? (double)bias[c] : 0.0;          // sum(z + sh) = s1 + n sh ; sum((z + sh)^2) = s2 + 2 sh s1 + n sh^2
+    sums[2 * c] = a + count * sh;
+    sums[2 * c + 1] = b + 2.0 * sh * a + count * sh * sh;
   }
 }
 
@@ -284,9 +266,7 @@ __device__ __forceinline__ void st4g_bf16(float* p, int64_t base, int64_t total,
 // u = ((z + b) - mean) * rstd * gamma + beta [+ res] ; optional LIF on u.   Flat 256-element tiles, L % 4 == 0.
 // YB: the spikes y are written as bf16 (2 bytes / element).
 // ANYL: any row length -- the channel, the validity and the accesses are per element (see ld4g).
-// PART: the statistics arrive as a producer's partials (a separate instantiation: the prologue's registers are not charged to the
-// sums form).
-template <bool LIF, bool HAS_V, bool YB, bool ANYL = false, bool PART = false>
+template <bool LIF, bool HAS_V, bool YB, bool ANYL = false>
 __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                           const double* __restrict__ sums, float* __restrict__ stat,
                                                           float* __restrict__ running_mean,
@@ -299,8 +279,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
                                                           uint64_t* __restrict__ mask,
                                                           unsigned long long* __restrict__ stats, int64_t total, int C,
                                                           int L, double inv_count, float unbias, float momentum,
-                                                          float eps, int training, float vth, float Df,
-                                                          const float* __restrict__ part, int P) {
+                                                          float eps, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWaves;
@@ -323,8 +302,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
   };
   request(wave0);
   for (int c = threadIdx.x; c < C; c += kBlock) {
-    const ChanStat cs = PART ? chan_stat_partials_thread(part, P, C, c, bias ? bias[c] : 0.f, inv_count, eps)
-                             : chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+    const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
     sstat[c] = cs.mean;
     sstat[C + c] = cs.rstd;
     sstat[2 * C + c] = cs.var;
@@ -627,15 +605,14 @@ __device__ __forceinline__ RowWalk walk_begin(uint32_t tile, uint32_t L, uint32_
   return w;
 }
 
-template <bool LIF, bool HAS_V, bool YB, bool ALIGNED, bool PART = false>
+template <bool LIF, bool HAS_V, bool YB, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const double* __restrict__ sums, float* __restrict__ stat,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ num_batches,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out,
     const float* __restrict__ v_in, float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask,
     unsigned long long* __restrict__ stats, int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk,
-    double inv_count, float unbias, float momentum, float eps, int training, float vth, float Df,
-    const float* __restrict__ part, int P) {
+    double inv_count, float unbias, float momentum, float eps, int training, float vth, float Df) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
   uint32_t t = wave * chunk;
@@ -651,39 +628,13 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
       if (LIF && HAS_V) vn[slot] = ld4(v_in + base);
     }
   };
-  // (PART: requesting the first tiles only behind the longer prologue keeps the kernel at 61 instead of 78 VGPRs, eight instead of six
-  // wavefronts per SIMD -- and measured 0.2 ms per step SLOWER at C2 than losing the overlap: same-box A/B 39.99 / 39.76 vs 39.78 / 39.55)
 #pragma unroll
   for (int i = 0; i < kAhead; ++i) request(i, t + i);
-  if constexpr (PART) {
-    // statistics from the producer's per-tile partials: only the channels this workgroup's run of tiles touches (a few rows of
-    // a large map) -- with hundreds to thousands of partials per channel, all C channels per workgroup would re-read the whole
-    // partial buffer once per workgroup
-    const uint32_t wg_t0 = blockIdx.x * kWaves * chunk, wg_t1 = min(ntiles, wg_t0 + kWaves * chunk);
-    if (wg_t0 < wg_t1) {
-      const uint64_t e_last = min((uint64_t)total, (uint64_t)wg_t1 * 256u) - 1u;
-      const uint32_t row0 = (uint32_t)((uint64_t)wg_t0 * 256u / L), row1 = (uint32_t)(e_last / L);
-      const uint32_t nch = min((uint32_t)C, row1 - row0 + 1u), c0 = row0 % (uint32_t)C;
-      if (P <= 32) {
-        for (uint32_t k = threadIdx.x; k < nch; k += kBlock) {
-          const uint32_t c = (c0 + k) % (uint32_t)C;
-          const ChanStat cs = chan_stat_partials_thread(part, P, C, (int)c, bias ? bias[c] : 0.f, inv_count, eps);
-          sstat[c] = cs.mean;
-          sstat[C + c] = cs.rstd;
-          sstat[2 * C + c] = cs.var;
-        }
-      } else {
-        __shared__ double pred[2 * kWaves];
-        chan_stats_partials_block(part, P, C, c0, nch, bias, inv_count, eps, pred, sstat);
-      }
-    }
-  } else {
-    for (int c = threadIdx.x; c < C; c += kBlock) {
-      const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
-      sstat[c] = cs.mean;
-      sstat[C + c] = cs.rstd;
-      sstat[2 * C + c] = cs.var;
-    }
+  for (int c = threadIdx.x; c < C; c += kBlock) {
+    const ChanStat cs = chan_stat(sums, running_mean, running_var, c, inv_count, eps, training);
+    sstat[c] = cs.mean;
+    sstat[C + c] = cs.rstd;
+    sstat[2 * C + c] = cs.var;
   }
   __syncthreads();
   RowWalk w = walk_begin(t, L, (uint32_t)C);
@@ -1279,27 +1230,38 @@ extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums
   return s2f_check_launch("s2f_bn_stats");
 }
 
-static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double* sums, const float* part, int64_t P,
-                           float* stat_out, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                           const float* gamma, const float* beta, const float* residual, float* u_out, const float* v_in,
-                           void* y_out, float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
-                           float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
+extern "C" int s2f_bn_partials_finalize(const float* partials, int64_t P, const float* conv_bias, double* sums_out, int64_t N,
+                                        int64_t C, int64_t L, void* stream) {
+  S2F_REQUIRE(partials && sums_out && P > 0 && P < (1 << 24) && (reinterpret_cast<uintptr_t>(partials) & 7u) == 0, S2F_EINVAL,
+              "s2f_bn_partials_finalize: partials 8-byte aligned, 0 < P < 2^24, sums workspace given");
+  int rc = check_shape("s2f_bn_partials_finalize", N, C, L);
+  if (rc) return rc;
+  const int per_wave = P <= 256;
+  const unsigned fgrid = per_wave ? (unsigned)((C + kWaves - 1) / kWaves) : (unsigned)C;
+  S2F_LAUNCH(true, true, bn_partials_finalize_kernel, dim3(fgrid), dim3(kBlock), 0, (hipStream_t)stream, partials, conv_bias,
+             sums_out, (int)P, (int)C, (double)N * (double)L, per_wave);
+  return s2f_check_launch("s2f_bn_partials_finalize");
+}
+
+extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
+                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
+                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
   float* y = reinterpret_cast<float*>(y_out);
   S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
-  S2F_REQUIRE(!part || (training && !sums && P > 0 && P < (1 << 24) && (reinterpret_cast<uintptr_t>(part) & 7u) == 0), S2F_EINVAL,
-              "s2f_bn_act_fwd_partials: training only, partials instead of sums, 0 < P < 2^24, 8-byte aligned");
-  // statistics given for a shape that could go single-pass: the caller already has them (a producer's epilogue, or a probe) --
+  constexpr bool first_launch = true;
+  // sums given for a shape that could go single-pass: the caller already has the statistics (a producer's epilogue, or a probe) --
   // take the apply path, which is not tied to one workgroup per channel
-  const bool single = training && sums == nullptr && part == nullptr && single_pass_ok(N, C, L);
-  S2F_REQUIRE(training ? (single || sums != nullptr || part != nullptr) : (running_mean && running_var), S2F_EINVAL,
-              "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats (or a producer's partials), eval needs the running statistics");
+  const bool single = training && sums == nullptr && single_pass_ok(N, C, L);
+  S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
+              "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats / s2f_bn_partials_finalize, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
   S2F_REQUIRE(!(y && y_bf16) || s2f_bf16_spikes_exact(D), S2F_EINVAL,
               "s2f_bn_act_fwd: bf16 spikes need D a power of two <= 128 (D=%d)", D);
   int rc = check_shape("s2f_bn_act_fwd", N, C, L);
   if (rc) return rc;
   const bool anyl = (L & 3) != 0;
-  S2F_REQUIRE(!(anyl && part), S2F_EINVAL, "s2f_bn_act_fwd_partials: rows of L %% 4 != 0 elements have no producer of partials");
   S2F_REQUIRE(anyl || (s2f_aligned16(z) && s2f_aligned16(residual) && s2f_aligned16(u_out) && s2f_aligned16(v_in) &&
                        s2f_aligned16(y) && s2f_aligned16(v_out)),
               S2F_EALIGN, "s2f_bn_act_fwd: tensors must be 16-byte aligned");
@@ -1339,19 +1301,10 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
   do {                                                                                                                  \
     uint32_t chunk;                                                                                                     \
     const uint32_t ntiles = (uint32_t)((total + 255) >> 8);                                                             \
-    if (part) {                                                                                                         \
-      const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL, true>>(ntiles, lds, chunk);                 \
-      S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL, true>), dim3(rgrid), block, lds, s, z,          \
-                 conv_bias, sums, stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y,      \
-                 v_out, mask, st, total, ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps,          \
-                 training, vth, (float)D, part, (int)P);                                                                \
-    } else {                                                                                                            \
-      const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                       \
-      S2F_LAUNCH(true, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias,     \
-                 sums, stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask,    \
-                 st, total, ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth,        \
-                 (float)D, part, (int)P);                                                                               \
-    }                                                                                                                   \
+    const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                         \
+    S2F_LAUNCH(first_launch, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias, \
+               sums, stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,   \
+               total, ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth, (float)D);    \
   } while (0)
 #define S2F_BN_APPLY(LIFV, HASV, YBV)                                                                                   \
   do {                                                                                                                  \
@@ -1360,17 +1313,13 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
     } else if (rows) {                                                                                                  \
       S2F_BN_ROWS_FWD(LIFV, HASV, YBV, false);                                                                          \
     } else if (anyl) {                                                                                                  \
-      S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV, true>), grid, block, lds, s, z, conv_bias, sums,         \
+      S2F_LAUNCH(first_launch, true, (bn_apply_kernel<LIFV, HASV, YBV, true>), grid, block, lds, s, z, conv_bias, sums, \
                  stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
-                 total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);       \
-    } else if (part) {                                                                                                  \
-      S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV, false, true>), grid, block, lds, s, z, conv_bias, sums,  \
-                 stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
-                 total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);       \
+                 total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D);                     \
     } else {                                                                                                            \
-      S2F_LAUNCH(true, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, lds, s, z, conv_bias, sums, stat_out,      \
-                 running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, total, (int)C, \
-                 (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D, part, (int)P);                      \
+      S2F_LAUNCH(first_launch, true, (bn_apply_kernel<LIFV, HASV, YBV>), grid, block, lds, s, z, conv_bias, sums,        \
+                 stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,      \
+                 total, (int)C, (int)L, inv_count, unbias, momentum, eps, training, vth, (float)D);                     \
     }                                                                                                                   \
   } while (0)
   if (y == nullptr)
@@ -1389,26 +1338,6 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
 #undef S2F_BN_APPLY
 #undef S2F_BN_ROWS_FWD
   return s2f_check_launch("s2f_bn_act_fwd");
-}
-
-extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
-                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
-                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
-                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
-                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
-  return bn_act_fwd_impl(z, conv_bias, sums, nullptr, 0, stat_out, running_mean, running_var, num_batches_tracked, gamma, beta,
-                         residual, u_out, v_in, y_out, v_out, mask, stats, N, C, L, momentum, eps, training, vth, D, y_bf16, stream);
-}
-
-extern "C" int s2f_bn_act_fwd_partials(const float* z, const float* conv_bias, const float* partials, int64_t P, float* stat_out,
-                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                       const float* gamma, const float* beta, const float* residual, float* u_out,
-                                       const float* v_in, void* y_out, float* v_out, uint64_t* mask, uint64_t* stats, int64_t N,
-                                       int64_t C, int64_t L, float momentum, float eps, float vth, int D, int y_bf16,
-                                       void* stream) {
-  S2F_REQUIRE(partials, S2F_EINVAL, "s2f_bn_act_fwd_partials: null partials");
-  return bn_act_fwd_impl(z, conv_bias, nullptr, partials, P, stat_out, running_mean, running_var, num_batches_tracked, gamma, beta,
-                         residual, u_out, v_in, y_out, v_out, mask, stats, N, C, L, momentum, eps, 1, vth, D, y_bf16, stream);
 }
 
 static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,

@@ -1030,13 +1030,17 @@ class _BNAct(torch.autograd.Function):
                 and partials.shape[1] == lib.s2f_bn_partials_count(N, L) and (BN_PARTIALS_SINGLE or not single)):
             partials = None          # the statistics the producing GEMM stored with z (BN_PARTIALS), when they describe this view of it
         if partials is not None:
+            # the producer's per-tile partials -> the sums of the statistics pass: one small launch over P * C * 8 bytes
             BN_PARTIALS_USED[0] += 1
+            ws = _take_zeroed(2 * C, dev)          # (plain stores: the workspace need not be zero)
+            _time_next("bn_stats", 8 * partials.shape[1] * C)
+            check(lib.s2f_bn_partials_finalize(_ptr(partials), partials.shape[1], _ptr(conv_bias), _ptr(ws), N, C, L, s),
+                  "s2f_bn_partials_finalize")
         elif training and not single:
             BN_PARTIALS_USED[1] += 1
             ws = _take_zeroed(2 * C, dev)
             _time_next("bn_stats", 4 * z.numel())
             check(lib.s2f_bn_stats(_ptr(z), _ptr(conv_bias), _ptr(ws), N, C, L, s), "s2f_bn_stats")
-            assert partials is None
         if residual is not None:
             residual = residual.contiguous()
         if v_in is not None:
@@ -1051,16 +1055,10 @@ class _BNAct(torch.autograd.Function):
         # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
         alg = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
         _time_next("bn_lif_fwd" if lif_on else "bn_fwd", alg, moved=alg - (2 * n if bf16 else 0))
-        if partials is not None:
-            check(lib.s2f_bn_act_fwd_partials(_ptr(z), _ptr(conv_bias), _ptr(partials), partials.shape[1], _ptr(stat),
-                                              _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual),
-                                              _ptr(u), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum,
-                                              eps, vth, D, int(bf16), s), "s2f_bn_act_fwd_partials")
-        else:
-            check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
-                                     _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
-                                     _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D,
-                                     int(bf16), s), "s2f_bn_act_fwd")
+        check(lib.s2f_bn_act_fwd(_ptr(z), _ptr(conv_bias), _ptr(ws), _ptr(stat), _ptr(running_mean), _ptr(running_var),
+                                 _ptr(nbt), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
+                                 _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, momentum, eps, int(training), vth, D,
+                                 int(bf16), s), "s2f_bn_act_fwd")
         buf = stat
         stat, border = buf[:2 * C], buf[2 * C:]
         ctx.save_for_backward(z, conv_bias, gamma, stat, mask)

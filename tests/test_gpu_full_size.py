@@ -968,7 +968,7 @@ def test_c2_sdme_and_folded_mask_contraction_gradients(c2):
 @pytest.mark.timeout(900)
 def test_c2_batchnorm_statistics_come_from_the_gemm_epilogues(c2):
     """Round 4: in a C2 training step every BatchNorm whose input is produced by one of the packed-weight GEMM / implicit 3x3 kernels
-    takes its statistics from that kernel's epilogue partials (ops.BN_PARTIALS; s2f_bn_act_fwd_partials) -- the statistics pass
+    takes its statistics from that kernel's epilogue partials (ops.BN_PARTIALS; s2f_bn_partials_finalize) -- the statistics pass
     s2f_bn_stats is left only for the depthwise-convolution outputs of the large FPN levels -- and the step's outputs agree with the
     statistics-pass form to the fp64 summation order (spikes may flip at borderline elements: compared per stage elsewhere; here the
     first backbone stage, which has no neuron, must agree to 1e-6)."""

@@ -1268,7 +1268,7 @@ def test_conv3x3_epilogue_partials_are_the_tile_sums(ops, N, M, C, H, W):
                                            (8, 32, 16384, False, True), (3, 20, 640, True, False), (8, 256, 1024, False, True),
                                            (1, 8, 65536, False, True), (4, 6, 12, True, True)])
 def test_bn_from_partials_is_bn_from_the_statistics_pass(ops, spike_mode, N, C, L, res, lif):
-    """s2f_bn_act_fwd_partials == s2f_bn_stats + s2f_bn_act_fwd: the partials of a GEMM epilogue (here: exact fp64 tile sums rounded
+    """s2f_bn_partials_finalize + s2f_bn_act_fwd == s2f_bn_stats + s2f_bn_act_fwd: the partials of a GEMM epilogue (here: exact fp64 tile sums rounded
     to fp32, the kernel's storage format) give the same mean / rstd to fp32 round-off (1e-6), the same pre-activation to 1e-5,
     spikes that differ in <= 1e-4 of the elements by one level, the same running statistics; every apply kernel: generic
     (L = 100), row-walking aligned / straddling, few (<= 32: one thread per channel) and many (wave per channel) partials, the
