@@ -121,9 +121,14 @@ int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask,
  * s2f_bn_act_bwd:  gu = g_u? + STE(g_y?, g_v?, mask) ;  training: gz = gamma*rstd*(gu - mean(gu) - xhat*mean(gu*xhat)),
  *   eval: gz = gamma*rstd*gu ;  g_residual? = gu ;  dgamma = sum(gu*xhat) ; dbeta = sum(gu).  sums_zeroed as above. */
 /* 1 when, in training mode, s2f_bn_act_fwd / s2f_bn_act_bwd compute the channel statistics of this shape themselves
- * (one workgroup per channel holds the channel's N*L elements in registers: small maps with L % 256 == 0): the caller
- * then skips s2f_bn_stats and may pass sums / sums_zeroed = NULL. */
+ * (one workgroup per channel holds the channel's N*L elements in registers: small maps with L % 256 == 0; one wavefront per
+ * channel for short rows, see s2f_bn_mask_words): the caller then skips s2f_bn_stats and may pass sums / sums_zeroed = NULL. */
 int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L);
+/* uint64 words of the in-range mask that s2f_bn_act_fwd writes and s2f_bn_act_bwd reads for this shape in training mode: the flat
+ * 256-element-tile layout of s2f_lif_mask_words, except for short rows (L % 4 == 0, L % 256 != 0, N * L <= 2 048, C >= 32: the
+ * decoder's 100-token maps), whose single-pass kernels keep one wavefront per channel and a per-channel mask layout of their own
+ * (32 words per channel; private to this forward / backward pair). */
+int64_t s2f_bn_mask_words(int64_t N, int64_t C, int64_t L);
 int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
                  void* stream);
 int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out, float* running_mean,
@@ -135,6 +140,25 @@ int s2f_bn_act_bwd(const float* z, const float* conv_bias, const float* stat, co
                    const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
                    float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
                    float vth, int D, void* stream);
+
+/* Train-mode BatchNorm o BatchNorm as ONE kernel (every RepConv chain of the attention blocks ends in two: Sequential(RepConv(..,
+ * BN), BN), mmseg/models/backbones/sdtv2.py:112-132, 280-296, 304-306).  With xhat = (z + b - mean) r the first BatchNorm gives
+ * a = gamma xhat + beta, whose batch mean is beta and whose biased batch variance is gamma^2 var r^2: the second needs no pass of
+ * its own,  BN2(BN1(z)) = gamma gamma2 r2 xhat + beta2,  r2 = 1 / sqrt(gamma^2 var r^2 + eps2);  running_mean2 / running_var2 are
+ * updated with (beta, gamma^2 var r^2 n/(n-1)).  Single-pass shapes only (s2f_bn2_fused_ok; the 32x32-stage maps where these
+ * chains live); stat_out: float[4C] = mean, r, BN1(0) border, r2.  The backward returns both BatchNorms' parameter gradients:
+ * dbeta2 = sum gu, dgamma2 = gamma r2 sum(gu xhat), dbeta = 0, dgamma = gamma2 eps2 r2^3 sum(gu xhat). */
+int s2f_bn2_fused_ok(int64_t N, int64_t C, int64_t L);
+int s2f_bn2_act_fwd(const float* z, const float* conv_bias, float* stat_out, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, const float* gamma, const float* beta, float momentum, float eps,
+                    const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                    int64_t* num_batches_tracked2, float momentum2, float eps2, const float* residual, float* u_out,
+                    const float* v_in, void* y, float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
+                    float vth, int D, int y_bf16, void* stream);
+int s2f_bn2_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* gamma2, float eps2,
+                    const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask, float* gz, float* g_residual,
+                    float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, int64_t N, int64_t C, int64_t L, float vth, int D,
+                    void* stream);
 
 /* ---- depthwise KxK convolution (stride 1, dilation 1, K in {3,5,7}) on [N, C, H, W] -----------------------
  * Replaces nn.Conv2d(groups=C) as used by SepConv.dwconv (mmseg/models/backbones/sdtv2.py:156-163), RepConv's un-padded

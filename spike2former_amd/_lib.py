@@ -31,6 +31,10 @@ SIGNATURES = {
     "s2f_lif_seq_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i64, _f, _i, _p]),
     "s2f_lif_seq_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i64, _f, _i, _p]),
     "s2f_bn_single_pass": (_i, [_i64] * 3),
+    "s2f_bn_mask_words": (_i64, [_i64] * 3),
+    "s2f_bn2_fused_ok": (_i, [_i64] * 3),
+    "s2f_bn2_act_fwd": (_i, [_p] * 8 + [_f, _f] + [_p] * 5 + [_f, _f] + [_p] * 7 + [_i64] * 3 + [_f, _i, _i, _p]),
+    "s2f_bn2_act_bwd": (_i, [_p] * 5 + [_f] + [_p] * 10 + [_i64] * 3 + [_f, _i, _p]),
     "s2f_bn_stats": (_i, [_p] * 3 + [_i64] * 3 + [_p]),
     "s2f_bn_act_fwd": (_i, [_p] * 16 + [_i64] * 3 + [_f, _f, _i, _f, _i, _i, _p]),
     "s2f_bn_act_bwd": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .conv import Conv1d, Conv2d, spikes_in
-from .fused import bn_act, conv_bn_act
+from .fused import bn_act, bn_bn_act, conv_bn_act
 from .neuron import Q_IFNode, Quant
 from .registry import MODELS
 
@@ -93,8 +93,7 @@ class RepConv(nn.Module):
         x = self.body[2][1](x)
         if outer_bn is None:
             return bn_act(x, None, self.body[2][2])[0]
-        x, _ = bn_act(x, None, self.body[2][2])
-        return bn_act(x, None, outer_bn, residual=residual, lif=lif, next_lif=next_lif)
+        return bn_bn_act(x, self.body[2][2], outer_bn, residual=residual, lif=lif, next_lif=next_lif)
 
 
 class SepConv(nn.Module):
@@ -253,8 +252,7 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         # second 1x1: three products on the channel groups of z, each with its own parameter (cached pack, gradient sink)
         z = ops.dense_gemm(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]], stats=training)
         z = ops.carry_stats(z, z.view(T * B, 3 * C, H, W))
-        z, _ = bn_act(z, None, bn2)
-        _, y = bn_act(z, None, bn3, lif=self.q_spike)     # q / k / v neurons: pure and identical here (checked by the caller)
+        _, y = bn_bn_act(z, bn2, bn3, lif=self.q_spike)   # q / k / v neurons: pure and identical here (checked by the caller)
         for wb in out:
             wb()
         if training:

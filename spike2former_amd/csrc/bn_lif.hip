@@ -958,13 +958,28 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red, in
   }
 }
 
-template <bool LIF, bool HAS_V, bool YB>
+// The SECOND BatchNorm of a train-mode BatchNorm o BatchNorm pair (every RepConv chain of the attention blocks closes with two:
+// Sequential(RepConv(.. BN_b), BN_c), sdtv2.py:280-296, 304-306).  With xhat = (z - mean) r_b the first gives a = gamma_b xhat +
+// beta_b, whose batch mean is beta_b and whose (biased) batch variance is gamma_b^2 var r_b^2 -- no second pass is needed to know
+// them -- so  BN_c(BN_b(z)) = gamma_b gamma_c r_c xhat + beta_c,  r_c = 1 / sqrt(gamma_b^2 var r_b^2 + eps_c):  ONE kernel with a
+// different scale, which also updates BN_c's running statistics with (beta_b, gamma_b^2 var r_b^2 unbias).  (The reference forms
+// mean(a) numerically: beta_b + gamma_b mean(xhat), mean(xhat) ~ 1e-8.)
+struct Bn2 {
+  const float* gamma;            // gamma_c [C]; null = plain BatchNorm
+  const float* beta;             // beta_c
+  float* running_mean;           // BN_c's running statistics (or null)
+  float* running_var;
+  long long* num_batches;
+  float eps, momentum;
+};
+
+template <bool LIF, bool HAS_V, bool YB, bool DOUBLE = false>
 __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ num_batches, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out, const float* __restrict__ v_in,
     float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
-    int N, int C, int L, double inv_count, float unbias, float momentum, float eps, float vth, float Df) {
+    int N, int C, int L, double inv_count, float unbias, float momentum, float eps, float vth, float Df, Bn2 bn2) {
   __shared__ double red[2 * kFusedWaves];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = L >> 8, tiles = N * tpr;                  // tiles per row, tiles of this channel
@@ -1002,7 +1017,7 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
   if (vd < 0) vd = 0;
   const float mean = (float)md, var = (float)vd;
   const float rstd = 1.0f / sqrtf(var + eps);
-  const float g = gamma[c], be = beta[c];
+  float g = gamma[c], be = beta[c];
   if (threadIdx.x == 0) {
     stat[c] = mean;
     stat[C + c] = rstd;
@@ -1015,6 +1030,20 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
     }
     stat[2 * C + c] = be - rm * g / sqrtf(rv + eps);          // BN(0) from the (updated) running statistics
     if (c == 0 && num_batches != nullptr) *num_batches += 1;
+  }
+  if constexpr (DOUBLE) {
+    const float var_a = (g * g) * (var * (rstd * rstd));      // biased batch variance of a = gamma_b xhat + beta_b
+    const float r_c = 1.0f / sqrtf(var_a + bn2.eps);
+    if (threadIdx.x == 0) {
+      stat[3 * C + c] = r_c;
+      if (bn2.running_mean != nullptr) {
+        bn2.running_mean[c] = (1.f - bn2.momentum) * bn2.running_mean[c] + bn2.momentum * be;
+        bn2.running_var[c] = (1.f - bn2.momentum) * bn2.running_var[c] + bn2.momentum * (var_a * unbias);
+      }
+      if (c == 0 && bn2.num_batches != nullptr) *bn2.num_batches += 1;
+    }
+    g = (g * bn2.gamma[c]) * r_c;
+    be = bn2.beta[c];
   }
   uint32_t csum = 0, cnz = 0;
 #pragma unroll
@@ -1061,13 +1090,24 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
   }
 }
 
-template <bool GU, bool GY, bool GV>
+// DOUBLE (the backward of the pair above): with S1 = sum gu, S2 = sum gu xhat,
+//   dbeta_c = S1 ; dgamma_c = gamma_b r_c S2 ; dbeta_b = 0 ; dgamma_b = gamma_c eps_c r_c^3 S2 ;
+//   gz = gamma_b r_b gamma_c r_c (gu - S1/n - kappa xhat S2/n),  kappa = r_c^2 (gamma_b^2 + eps_c)
+// (BN_c's backward into a, then BN_b's: sum xhat = 0, sum xhat^2 = n var r_b^2 = n (1 / r_c^2 - eps_c) / gamma_b^2).
+struct Bn2Bwd {
+  const float* gamma;            // gamma_c; null = plain
+  float* dgamma;                 // d gamma_c, d beta_c
+  float* dbeta;
+  float eps;
+};
+
+template <bool GU, bool GY, bool GV, bool DOUBLE = false>
 __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
     const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df,
-    unsigned short* __restrict__ gzs) {
+    unsigned short* __restrict__ gzs, Bn2Bwd bn2) {
   __shared__ double red[2 * kFusedWaves];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = L >> 8, tiles = N * tpr;
@@ -1113,11 +1153,22 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
   }
   double s1 = (double)ps, s2 = (double)pq;
   block_sum2(s1, s2, red, nwaves);
-  if (threadIdx.x == 0) {
+  float scale = g * rstd;
+  float m1 = (float)(s1 * inv_count), m2 = (float)(s2 * inv_count);
+  if constexpr (DOUBLE) {
+    const float r_c = stat[3 * C + c], g_c = bn2.gamma[c];
+    if (threadIdx.x == 0) {
+      bn2.dbeta[c] = (float)s1;
+      bn2.dgamma[c] = (g * r_c) * (float)s2;
+      dbeta[c] = 0.f;
+      dgamma[c] = (g_c * bn2.eps) * (r_c * r_c * r_c) * (float)s2;
+    }
+    scale = (g * rstd) * (g_c * r_c);
+    m2 *= (r_c * r_c) * (g * g + bn2.eps);
+  } else if (threadIdx.x == 0) {
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
   }
-  const float m1 = (float)(s1 * inv_count), m2 = (float)(s2 * inv_count);
 #pragma unroll
   for (int i = 0; i < kTpw; ++i) {
     if (tix[i] < 0) continue;
@@ -1125,9 +1176,184 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     const int64_t base = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
     Tile4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o.a[j] = (g * rstd) * ((gu[i].a[j] - m1) - xh[i].a[j] * m2);
+    for (int j = 0; j < 4; ++j) o.a[j] = scale * ((gu[i].a[j] - m1) - xh[i].a[j] * m2);
     store_gz(gz, gzs, (int64_t)N * C * L, base, o);
     if (g_res) st4(g_res + base, gu[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-pass forms for SHORT rows (round 4): the decoder's 100-token maps [T*B, C, 100] (and any L % 4 == 0 map with N * L <= 2 048
+// whose rows are not whole 256-element tiles).  The two-kernel forms cost four launches of 5-7 us per BatchNorm and step there
+// (statistics or partials-finalize + apply forward, reduce + apply backward; ~50 such BatchNorms per C2 step); round 3's one-launch
+// attempt was tied to the flat 256-element mask tiles -- 64 channels per workgroup, FOUR workgroups for 256 channels -- and lost.
+// The in-range mask of these maps is written by this forward and read by this backward only, so it gets its own layout: ONE
+// WAVEFRONT PER CHANNEL holds the channel's N * L / 4 four-element groups (group g = n * (L / 4) + q of row n at lane g & 63,
+// round g >> 6, at most kSmallIters rounds), and mask word [(c * kSmallIters + round) * 4 + j] is the ballot of component j of
+// that round.  Statistics by shuffles inside the wavefront (fp64), everything else as the single-pass kernels above.
+constexpr int kSmallIters = 8;          // rounds of 64 four-element groups per channel: N * L <= 2 048
+
+inline bool small_rows_ok(int64_t N, int64_t C, int64_t L) {
+  return (L & 3) == 0 && (L & 255) != 0 && N * L <= 64 * 4 * kSmallIters && N * L >= 8 && C >= 32;
+}
+
+template <bool LIF, bool HAS_V, bool YB>
+__global__ __launch_bounds__(64) void bn_small_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out, const float* __restrict__ v_in,
+    float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
+    int N, int C, int L, double inv_count, float unbias, float momentum, float eps, float vth, float Df) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int per_row = L >> 2, groups = N * per_row;
+  const float b = bias ? bias[c] : 0.f;
+  Tile4 zv[kSmallIters], rvp[kSmallIters];
+  int64_t base[kSmallIters];
+  bool ok[kSmallIters];
+#pragma unroll
+  for (int i = 0; i < kSmallIters; ++i) {                   // all loads in flight before the first use
+    const int g = i * 64 + lane;
+    ok[i] = g < groups;
+    const int n = ok[i] ? g / per_row : 0, q = ok[i] ? g - n * per_row : 0;
+    base[i] = ((int64_t)n * C + c) * L + q * 4;
+    if (i * 64 < groups) {                                  // wave-uniform: rounds past the channel's groups issue nothing
+      zv[i] = ld4(z + base[i]);
+      if (res) rvp[i] = ld4(res + base[i]);
+    }
+  }
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kSmallIters; ++i) {
+    if (!ok[i]) continue;
+    const float a0 = zv[i].a[0] + b, a1 = zv[i].a[1] + b, a2 = zv[i].a[2] + b, a3 = zv[i].a[3] + b;
+    ps += (a0 + a1) + (a2 + a3);
+    pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  const double s1 = wave_sum_f64((double)ps), s2 = wave_sum_f64((double)pq);
+  const double md = s1 * inv_count;
+  double vd = s2 * inv_count - md * md;
+  if (vd < 0) vd = 0;
+  const float mean = (float)md, var = (float)vd;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float g_ = gamma[c], be = beta[c];
+  if (lane == 0) {
+    stat[c] = mean;
+    stat[C + c] = rstd;
+    float rm = 0.f, rv = 1.f;
+    if (running_mean != nullptr) {
+      rm = (1.f - momentum) * running_mean[c] + momentum * mean;
+      rv = (1.f - momentum) * running_var[c] + momentum * (var * unbias);
+      running_mean[c] = rm;
+      running_var[c] = rv;
+    }
+    stat[2 * C + c] = be - rm * g_ / sqrtf(rv + eps);         // BN(0) from the (updated) running statistics
+    if (c == 0 && num_batches != nullptr) *num_batches += 1;
+  }
+  uint32_t csum = 0, cnz = 0;
+#pragma unroll
+  for (int i = 0; i < kSmallIters; ++i) {
+    if (i * 64 >= groups) break;                            // wave-uniform
+    bool inr[4] = {false, false, false, false};
+    if (ok[i]) {
+      Tile4 vv, uo, yo, vo;
+      if (LIF && HAS_V) vv = ld4(v_in + base[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = ((zv[i].a[j] + b) - mean) * rstd * g_ + be;
+        if (res) u += rvp[i].a[j];
+        uo.a[j] = u;
+        if (LIF) {
+          const float h = HAS_V ? (vv.a[j] + u) : u;
+          float sp, yy;
+          s2f_lif_update(h, Df, 1.0f, vth, sp, yy, vo.a[j], inr[j]);
+          yo.a[j] = sp / Df;
+          csum += (uint32_t)sp;
+          cnz += ((uint32_t)sp != 0);
+        }
+      }
+      if (u_out) st4(u_out + base[i], uo);
+      if (LIF) {
+        if (YB)
+          st4_bf16(y, base[i], yo);
+        else
+          st4(y + base[i], yo);
+        if (v_out) st4(v_out + base[i], vo);
+      }
+    }
+    if (LIF && mask != nullptr) {
+      const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+      if (lane < 4) mask[((int64_t)c * kSmallIters + i) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    }
+  }
+  if (LIF && stats != nullptr) {
+    for (int o = 32; o > 0; o >>= 1) {
+      csum += __shfl_xor(csum, o, 64);
+      cnz += __shfl_xor(cnz, o, 64);
+    }
+    if (lane == 0) {
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+      if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+    }
+  }
+}
+
+template <bool GU, bool GY, bool GV>
+__global__ __launch_bounds__(64) void bn_small_bwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
+    const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
+    const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int per_row = L >> 2, groups = N * per_row;
+  const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g_ = gamma[c];
+  Tile4 xh[kSmallIters], gu[kSmallIters];
+  int64_t base[kSmallIters];
+  bool ok[kSmallIters];
+#pragma unroll
+  for (int i = 0; i < kSmallIters; ++i) {
+    const int g = i * 64 + lane;
+    ok[i] = g < groups;
+    const int n = ok[i] ? g / per_row : 0, q = ok[i] ? g - n * per_row : 0;
+    base[i] = ((int64_t)n * C + c) * L + q * 4;
+    if (i * 64 >= groups) continue;                         // wave-uniform
+    xh[i] = ld4(z + base[i]);
+    if (GU) gu[i] = ld4(g_u + base[i]);
+    Tile4 bb, cc;
+    if (GY) bb = ld4(g_y + base[i]);
+    if (GV) cc = ld4(g_v + base[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool m = false;
+      if (GY || GV) m = (mask[((int64_t)c * kSmallIters + i) * 4 + j] >> lane) & 1ull;
+      gu[i].a[j] = form_gu(GU, GU ? gu[i].a[j] : 0.f, GY, GY ? bb.a[j] : 0.f, GV, GV ? cc.a[j] : 0.f, m, vth, Df);
+      xh[i].a[j] = ((xh[i].a[j] + b) - mean) * rstd;
+    }
+  }
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kSmallIters; ++i) {
+    if (!ok[i]) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ps += gu[i].a[j];
+      pq += gu[i].a[j] * xh[i].a[j];
+    }
+  }
+  const double s1 = wave_sum_f64((double)ps), s2 = wave_sum_f64((double)pq);
+  if (lane == 0) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+  }
+  const float m1 = (float)(s1 * inv_count), m2 = (float)(s2 * inv_count);
+#pragma unroll
+  for (int i = 0; i < kSmallIters; ++i) {
+    if (!ok[i]) continue;
+    Tile4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.a[j] = (g_ * rstd) * ((gu[i].a[j] - m1) - xh[i].a[j] * m2);
+    st4(gz + base[i], o);
+    if (g_res) st4(g_res + base[i], gu[i]);
   }
 }
 
@@ -1210,7 +1436,14 @@ int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
 
 }  // namespace
 
-extern "C" int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L) { return single_pass_ok(N, C, L) ? 1 : 0; }
+extern "C" int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L) { return (single_pass_ok(N, C, L) || small_rows_ok(N, C, L)) ? 1 : 0; }
+
+// uint64 words of the in-range mask s2f_bn_act_fwd writes / s2f_bn_act_bwd reads for this shape: the flat-tile layout of
+// s2f_lif_mask_words, or the per-channel layout of the short-row single-pass kernels (private to this fwd / bwd pair)
+extern "C" int64_t s2f_bn_mask_words(int64_t N, int64_t C, int64_t L) {
+  if (small_rows_ok(N, C, L)) return C * kSmallIters * 4;
+  return ((N * C * L + 255) >> 8) * 4;
+}
 
 extern "C" int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
                             void* stream) {
@@ -1243,18 +1476,20 @@ extern "C" int s2f_bn_partials_finalize(const float* partials, int64_t P, const 
   return s2f_check_launch("s2f_bn_partials_finalize");
 }
 
-extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
-                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
-                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
-                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
-                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
+static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double* sums, float* stat_out, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
+                           const float* residual, float* u_out, const float* v_in, void* y_out, float* v_out, uint64_t* mask,
+                           uint64_t* stats, int64_t N, int64_t C, int64_t L, float momentum, float eps, int training, float vth,
+                           int D, int y_bf16, void* stream, Bn2 bn2) {
   float* y = reinterpret_cast<float*>(y_out);
   S2F_REQUIRE(z && stat_out && gamma && beta, S2F_EINVAL, "s2f_bn_act_fwd: null z/stat/gamma/beta");
+  S2F_REQUIRE(!bn2.gamma || (training && sums == nullptr && single_pass_ok(N, C, L) && bn2.beta), S2F_EINVAL,
+              "s2f_bn2_act_fwd: the BatchNorm pair runs on the single-pass kernels only (training mode, s2f_bn2_fused_ok)");
   constexpr bool first_launch = true;
   // sums given for a shape that could go single-pass: the caller already has the statistics (a producer's epilogue, or a probe) --
   // take the apply path, which is not tied to one workgroup per channel
   const bool single = training && sums == nullptr && single_pass_ok(N, C, L);
-  S2F_REQUIRE(training ? (single || sums != nullptr) : (running_mean && running_var), S2F_EINVAL,
+  S2F_REQUIRE(training ? (single || sums != nullptr || small_rows_ok(N, C, L)) : (running_mean && running_var), S2F_EINVAL,
               "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats / s2f_bn_partials_finalize, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
   S2F_REQUIRE(!(y && y_bf16) || s2f_bf16_spikes_exact(D), S2F_EINVAL,
@@ -1273,12 +1508,41 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   const double count = (double)N * (double)L;
   const double inv_count = 1.0 / count;
   const float unbias = count > 1 ? (float)(count / (count - 1.0)) : 1.0f;
+  if (training && small_rows_ok(N, C, L)) {
+    // (always, given statistics or not: the mask layout of this shape is the short-row one, which the backward reads)
+#define S2F_BN_SMALL(LIFV, HASV, YBV)                                                                                    \
+  S2F_LAUNCH(true, true, (bn_small_fwd_kernel<LIFV, HASV, YBV>), dim3((unsigned)C), dim3(64), 0, s, z, conv_bias, stat_out, \
+             running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C,      \
+             (int)L, inv_count, unbias, momentum, eps, vth, (float)D)
+    if (y == nullptr)
+      S2F_BN_SMALL(false, false, false);
+    else if (v_in == nullptr) {
+      if (y_bf16)
+        S2F_BN_SMALL(true, false, true);
+      else
+        S2F_BN_SMALL(true, false, false);
+    } else {
+      if (y_bf16)
+        S2F_BN_SMALL(true, true, true);
+      else
+        S2F_BN_SMALL(true, true, false);
+    }
+#undef S2F_BN_SMALL
+    return s2f_check_launch("s2f_bn_act_fwd");
+  }
   if (single) {
     const dim3 fgrid((unsigned)C), fblock(single_pass_threads(N, L));
 #define S2F_BN_FUSED(LIFV, HASV, YBV)                                                                                    \
-  S2F_LAUNCH(true, true, (bn_fused_fwd_kernel<LIFV, HASV, YBV>), fgrid, fblock, 0, s, z, conv_bias, stat_out,             \
-             running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C,      \
-             (int)L, inv_count, unbias, momentum, eps, vth, (float)D)
+  do {                                                                                                                   \
+    if (bn2.gamma)                                                                                                       \
+      S2F_LAUNCH(true, true, (bn_fused_fwd_kernel<LIFV, HASV, YBV, true>), fgrid, fblock, 0, s, z, conv_bias, stat_out,    \
+                 running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C,  \
+                 (int)L, inv_count, unbias, momentum, eps, vth, (float)D, bn2);                                          \
+    else                                                                                                                 \
+      S2F_LAUNCH(true, true, (bn_fused_fwd_kernel<LIFV, HASV, YBV>), fgrid, fblock, 0, s, z, conv_bias, stat_out,          \
+                 running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C,  \
+                 (int)L, inv_count, unbias, momentum, eps, vth, (float)D, bn2);                                          \
+  } while (0)
     if (y == nullptr)
       S2F_BN_FUSED(false, false, false);
     else if (v_in == nullptr) {
@@ -1340,11 +1604,37 @@ extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const doub
   return s2f_check_launch("s2f_bn_act_fwd");
 }
 
+extern "C" int s2f_bn_act_fwd(const float* z, const float* conv_bias, const double* sums, float* stat_out,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                              const float* beta, const float* residual, float* u_out, const float* v_in, void* y_out,
+                              float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C, int64_t L,
+                              float momentum, float eps, int training, float vth, int D, int y_bf16, void* stream) {
+  return bn_act_fwd_impl(z, conv_bias, sums, stat_out, running_mean, running_var, num_batches_tracked, gamma, beta, residual, u_out,
+                         v_in, y_out, v_out, mask, stats, N, C, L, momentum, eps, training, vth, D, y_bf16, stream, Bn2{});
+}
+
+extern "C" int s2f_bn2_fused_ok(int64_t N, int64_t C, int64_t L) { return single_pass_ok(N, C, L) ? 1 : 0; }
+
+extern "C" int s2f_bn2_act_fwd(const float* z, const float* conv_bias, float* stat_out, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, const float* gamma, const float* beta, float momentum, float eps,
+                               const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                               int64_t* num_batches_tracked2, float momentum2, float eps2, const float* residual, float* u_out,
+                               const float* v_in, void* y_out, float* v_out, uint64_t* mask, uint64_t* stats, int64_t N, int64_t C,
+                               int64_t L, float vth, int D, int y_bf16, void* stream) {
+  S2F_REQUIRE(gamma2 && beta2, S2F_EINVAL, "s2f_bn2_act_fwd: null second BatchNorm");
+  return bn_act_fwd_impl(z, conv_bias, nullptr, stat_out, running_mean, running_var, num_batches_tracked, gamma, beta, residual, u_out,
+                         v_in, y_out, v_out, mask, stats, N, C, L, momentum, eps, 1, vth, D, y_bf16, stream,
+                         Bn2{gamma2, beta2, running_mean2, running_var2, reinterpret_cast<long long*>(num_batches_tracked2), eps2,
+                             momentum2});
+}
+
 static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
                            const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
                            float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
-                           float vth, int D, void* stream, unsigned short* gzs) {
-  const bool single = training && single_pass_ok(N, C, L);
+                           float vth, int D, void* stream, unsigned short* gzs, Bn2Bwd bn2 = Bn2Bwd{}) {
+  S2F_REQUIRE(!bn2.gamma || (training && single_pass_ok(N, C, L) && bn2.dgamma && bn2.dbeta && !gzs), S2F_EINVAL,
+              "s2f_bn2_act_bwd: the BatchNorm pair runs on the single-pass kernels only");
+  const bool single = training && (single_pass_ok(N, C, L) || small_rows_ok(N, C, L));
   S2F_REQUIRE(z && stat && gamma && (single || sums_zeroed) && (gz || gzs) && dgamma && dbeta, S2F_EINVAL,
               "s2f_bn_act_bwd: null pointer");
   S2F_REQUIRE(!gzs || (reinterpret_cast<uintptr_t>(gzs) & 7u) == 0, S2F_EALIGN, "s2f_bn_act_bwd_split: gz_split must be 8-byte aligned");
@@ -1354,11 +1644,36 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = N * C * L;
+  if (training && small_rows_ok(N, C, L)) {
+    S2F_REQUIRE(gzs == nullptr && gz, S2F_EINVAL, "s2f_bn_act_bwd_split: short rows (N * L <= 2048) have no bf16-plane form");
+#define S2F_BN_SB(A, B, Cc)                                                                                               \
+  S2F_LAUNCH(true, true, (bn_small_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(64), 0, s, z, conv_bias, stat, gamma, g_u, \
+             g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L, 1.0 / ((double)N * (double)L), vth,    \
+             (float)D)
+    switch ((g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0)) {
+      case 1: S2F_BN_SB(false, false, true); break;
+      case 2: S2F_BN_SB(false, true, false); break;
+      case 3: S2F_BN_SB(false, true, true); break;
+      case 4: S2F_BN_SB(true, false, false); break;
+      case 5: S2F_BN_SB(true, false, true); break;
+      case 6: S2F_BN_SB(true, true, false); break;
+      default: S2F_BN_SB(true, true, true); break;
+    }
+#undef S2F_BN_SB
+    return s2f_check_launch("s2f_bn_act_bwd");
+  }
   if (single) {
 #define S2F_BN_FB(A, B, Cc)                                                                                               \
-  S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0, s, z,      \
-             conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L,          \
-             1.0 / ((double)N * (double)L), vth, (float)D, gzs)
+  do {                                                                                                                    \
+    if (bn2.gamma)                                                                                                        \
+      S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc, true>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0,  \
+                 s, z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C,        \
+                 (int)L, 1.0 / ((double)N * (double)L), vth, (float)D, gzs, bn2);                                         \
+    else                                                                                                                  \
+      S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0, s, z,  \
+                 conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L,      \
+                 1.0 / ((double)N * (double)L), vth, (float)D, gzs, bn2);                                                 \
+  } while (0)
     const int combo = (g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0);
     switch (combo) {
       case 1: S2F_BN_FB(false, false, true); break;
@@ -1443,4 +1758,13 @@ extern "C" int s2f_bn_act_bwd_split(const float* z, const float* conv_bias, cons
   S2F_REQUIRE(gz_split, S2F_EINVAL, "s2f_bn_act_bwd_split: null gz_split");
   return bn_act_bwd_impl(z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, sums_zeroed, nullptr, g_residual, dgamma, dbeta, N, C,
                          L, training, vth, D, stream, gz_split);
+}
+
+extern "C" int s2f_bn2_act_bwd(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* gamma2,
+                               float eps2, const float* g_u, const float* g_y, const float* g_v, const uint64_t* mask, float* gz,
+                               float* g_residual, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, int64_t N, int64_t C,
+                               int64_t L, float vth, int D, void* stream) {
+  S2F_REQUIRE(gz && gamma2, S2F_EINVAL, "s2f_bn2_act_bwd: null gz / second BatchNorm");
+  return bn_act_bwd_impl(z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, nullptr, gz, g_residual, dgamma, dbeta, N, C, L, 1, vth, D,
+                         stream, nullptr, Bn2Bwd{gamma2, dgamma2, dbeta2, eps2});
 }

@@ -66,6 +66,43 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     return (u, y, border) if want_border else (u, y)
 
 
+def bn_bn_act(z, bn1, bn2, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
+    """bn2(bn1(z)) [+ residual] [-> neuron]: the BatchNorm pair that closes a RepConv chain (Sequential(RepConv(.., BN), BN),
+    sdtv2.py:280-296).  In training mode on the single-pass shapes (the 32x32-stage maps, where these chains live) the pair is ONE
+    kernel forward and one backward (ops.bn2_act: the second BatchNorm's batch statistics follow from the first's); otherwise two
+    bn_act calls.  Returns (u, y) as bn_act."""
+    training = (bn1.training or bn1.running_mean is None) and (bn2.training or bn2.running_mean is None)
+    momentum_ok = bn1.momentum is not None and bn2.momentum is not None
+    if not (training and momentum_ok and ops.bn2_act_ok(z) and bn1.weight is not None and bn2.weight is not None
+            and bn1.running_mean is not None and bn2.running_mean is not None):
+        x, _ = bn_act(z, None, bn1)
+        return bn_act(x, None, bn2, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
+    if next_lif is not None and lif is None:
+        u, y = bn_bn_act(z, bn1, bn2, residual=residual, lif=next_lif, want_pre=True)
+        next_lif.prefire(u, y)
+        return u, None
+    if want_pre is None:
+        want_pre = lif is None
+    wanted_pre = want_pre
+    if lif is not None and lif._forward_hooks:
+        want_pre = True
+    v_in = None
+    if lif is not None and not isinstance(lif.v, float):
+        v_in = lif.v.detach()
+    if lif is not None and lif.stats is not None:
+        lif.stats_elems += z.numel()
+    u, y, v_out = ops.bn2_act(z, bn1, bn2, residual=residual, lif=lif is not None, want_pre=want_pre, v_in=v_in,
+                              keep_v=(lif is not None and lif.keep_membrane), D=(lif.D if lif is not None else 8),
+                              vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None))
+    if lif is not None:
+        lif.v = v_out if lif.keep_membrane else 0.0
+        if lif._forward_hooks:
+            yf = y.float().detach()
+            for hook in list(lif._forward_hooks.values()):
+                hook(lif, (u,), yf)
+    return (u if wanted_pre else None), y
+
+
 def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
     """1x1 convolution (Conv2d / Conv1d of this package, fed by a neuron) -> BatchNorm [+ residual] [-> neuron]; x [N, K, *].
     In eval mode on bf16 spikes this is ONE launch -- the packed-weight GEMM with the BatchNorm (running statistics), the

@@ -1050,7 +1050,9 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty(z.shape, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev) if lif_on else None
         v_out = torch.empty_like(z) if (lif_on and keep_v) else None
         need_grad = any(ctx.needs_input_grad[:5])
-        mask = torch.empty(mask_words(z.numel()), dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
+        # (training-mode short rows keep a per-channel mask layout of their own: s2f_bn_mask_words)
+        nmask = int(lib.s2f_bn_mask_words(N, C, L)) if training else mask_words(z.numel())
+        mask = torch.empty(nmask, dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
         n = z.numel()
         # algorithmic bytes: read z, [read residual], [write u], [write y]  (SURVEY 8d per-element figures)
         alg = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
@@ -1127,6 +1129,89 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
         y = Spikes(ydata, y) if bf16 else Spikes(y, None)
     out = (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
     return out + (border,) if want_border else out
+
+
+BN2_FUSED = _os.environ.get("S2F_BN2_FUSED", "1") != "0"          # train-mode BatchNorm o BatchNorm pairs as one kernel (s2f_bn2_act_fwd / _bwd)
+
+
+class _BN2Act(torch.autograd.Function):
+    """u = BN2(BN1(z)) [+ residual] ; y = Q_IFNode(u)  in ONE single-pass kernel forward and one backward (s2f.h "BatchNorm o
+    BatchNorm": the pair that closes every RepConv chain, sdtv2.py:280-296, 304-306).  Training mode, single-pass shapes."""
+
+    @staticmethod
+    def forward(ctx, z, g1, b1, g2, b2, residual, v_in, rm1, rv1, nbt1, mom1, eps1, rm2, rv2, nbt2, mom2, eps2, lif_on, want_pre,
+                keep_v, D, vth, stats, bf16):
+        _need_cuda(z, g1, b1, g2, b2, residual, v_in)
+        z = z.contiguous()
+        N, C = z.shape[0], z.shape[1]
+        L = z.numel() // (N * C)
+        dev = z.device
+        stat = torch.empty(4 * C, dtype=torch.float32, device=dev)      # mean, r1, BN1(0) border, r2
+        if residual is not None:
+            residual = residual.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        bf16 = bool(bf16) and lif_on
+        u = torch.empty_like(z) if want_pre else None
+        y = torch.empty(z.shape, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev) if lif_on else None
+        v_out = torch.empty_like(z) if (lif_on and keep_v) else None
+        need_grad = any(ctx.needs_input_grad[:6])
+        mask = torch.empty(mask_words(z.numel()), dtype=torch.int64, device=dev) if (lif_on and need_grad) else None
+        n = z.numel()
+        alg = 4 * n * (1 + (residual is not None) + bool(want_pre) + bool(lif_on))
+        _time_next("bn_lif_fwd" if lif_on else "bn_fwd", alg, moved=alg - (2 * n if bf16 else 0))
+        check(lib.s2f_bn2_act_fwd(_ptr(z), 0, _ptr(stat), _ptr(rm1), _ptr(rv1), _ptr(nbt1), _ptr(g1), _ptr(b1), mom1, eps1, _ptr(g2),
+                                  _ptr(b2), _ptr(rm2), _ptr(rv2), _ptr(nbt2), mom2, eps2, _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y),
+                                  _ptr(v_out), _ptr(mask), _ptr(stats), N, C, L, vth, D, int(bf16), _stream()), "s2f_bn2_act_fwd")
+        ctx.save_for_backward(z, g1, g2, stat, mask)
+        ctx.cfg = (N, C, L, D, vth, residual is not None, eps2)
+        ctx.set_materialize_grads(False)
+        ydata = z.new_empty(0)
+        if bf16:
+            ydata, y = y, _new_tok(z)
+        outs = [t if t is not None else z.new_empty(0) for t in (u, y, v_out)]
+        ctx.mark_non_differentiable(ydata, *[o for o, t in zip(outs, (u, y, v_out)) if t is None])
+        return tuple(outs) + (ydata,)
+
+    @staticmethod
+    def backward(ctx, g_u, g_y, g_v, _g_ydata):
+        z, g1, g2, stat, mask = ctx.saved_tensors
+        N, C, L, D, vth, has_res, eps2 = ctx.cfg
+
+        def prep(g):
+            return None if (g is None or g.numel() == 0) else g.contiguous()
+        g_u, g_y, g_v = prep(g_u), prep(g_y), prep(g_v)
+        if g_u is None and g_y is None and g_v is None:
+            return (None,) * 24
+        dev = z.device
+        gz = torch.empty_like(z)
+        g_res = torch.empty_like(z) if (has_res and ctx.needs_input_grad[5]) else None
+        d = torch.empty(4, C, dtype=torch.float32, device=dev)          # dgamma1, dbeta1, dgamma2, dbeta2
+        alg = 4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None))
+        _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd", alg)
+        check(lib.s2f_bn2_act_bwd(_ptr(z), 0, _ptr(stat), _ptr(g1), _ptr(g2), eps2, _ptr(g_u), _ptr(g_y), _ptr(g_v), _ptr(mask), _ptr(gz),
+                                  _ptr(g_res), _ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(d[3]), N, C, L, vth, D, _stream()),
+              "s2f_bn2_act_bwd")
+        if ctx.needs_input_grad[6]:
+            raise RuntimeError("gradient w.r.t. the incoming membrane is not supported by the fused BN+LIF op")
+        return (gz, d[0], d[1], d[2], d[3], g_res) + (None,) * 18
+
+
+def bn2_act_ok(z):
+    N, C = z.shape[0], z.shape[1]
+    return bool(BN2_FUSED and z.is_cuda and z.numel() and lib.s2f_bn2_fused_ok(N, C, z.numel() // (N * C)))
+
+
+def bn2_act(z, bn1, bn2, residual=None, lif=False, want_pre=True, v_in=None, keep_v=False, D=8, vth=1.0, stats=None):
+    """bn1 / bn2: objects with weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps (nn.BatchNorm or the
+    concatenated twins of the batched q / k / v chain) -> (u or None, y (Spikes) or None, v_out or None)"""
+    bf16 = bool(lif) and spikes_bf16_ok(D) and z.numel() % 4 == 0
+    u, y, v, ydata = _BN2Act.apply(z, bn1.weight, bn1.bias, bn2.weight, bn2.bias, residual, v_in, bn1.running_mean, bn1.running_var,
+                                   bn1.num_batches_tracked, bn1.momentum, bn1.eps, bn2.running_mean, bn2.running_var,
+                                   bn2.num_batches_tracked, bn2.momentum, bn2.eps, lif, want_pre, keep_v, D, vth, stats, bf16)
+    if lif:
+        y = Spikes(ydata, y) if bf16 else Spikes(y, None)
+    return (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
 
 
 class _ScaleAffine(torch.autograd.Function):

@@ -360,7 +360,12 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      (8, 64, 10, True, False, True), (8, 256, 10, True, True, True),
                                                      (3, 5, 7, True, True, True), (2, 3, 5, True, False, False),
                                                      (1, 9, 333, True, True, True), (4, 6, 10, False, True, True),
-                                                     (2, 4, 1027, True, False, True)])
+                                                     (2, 4, 1027, True, False, True),
+                                                     # short rows, one wavefront per channel (s2f_bn_mask_words): the decoder's
+                                                     # 100-token maps; one / several / all eight rounds of 64 groups
+                                                     (8, 256, 100, True, False, True), (8, 64, 100, True, True, True),
+                                                     (8, 2048, 100, True, False, False), (2, 32, 1000, True, True, True),
+                                                     (3, 40, 36, True, True, True), (2, 33, 4, True, False, True)])
 @pytest.mark.parametrize("bf16", [True, False])
 def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
@@ -1297,3 +1302,64 @@ def test_bn_from_partials_is_bn_from_the_statistics_pass(ops, spike_mode, N, C, 
     if lif:
         d = (y1 - y0) * 8
         assert d.abs().max().item() <= 1 and (d != 0).float().mean().item() <= 1e-4
+
+
+@pytest.mark.parametrize("N,C,L,res,lif", [(8, 256, 1024, False, True), (8, 768, 1024, False, True), (8, 360, 1024, True, False),
+                                           (4, 64, 512, True, True), (8, 256, 1024, True, True)])
+def test_batchnorm_pair_as_one_kernel_is_two_batchnorms(ops, spike_mode, N, C, L, res, lif):
+    """s2f_bn2_act_fwd / _bwd (train-mode BN2(BN1(z)) [+ residual] [-> neuron] in one single-pass kernel each way: the pair closing
+    every RepConv chain, sdtv2.py:280-296) against two s2f_bn_act calls: pre-activation 1e-5, spikes <= 1e-4 of the elements by one
+    level, both BatchNorms' running statistics 1e-5, gz / g_residual / dgamma2 / dbeta2 1e-4 of their scale, and the first
+    BatchNorm's parameter gradients -- dbeta1 = 0 exactly (round-off noise in the two-kernel form) and dgamma1 = O(eps) -- to 1e-4
+    of the scale of dgamma2."""
+    import types
+    spike_mode(True)
+    g = torch.Generator().manual_seed(N + C + L)
+    z = (torch.randn(N, C, L, generator=g) * 1.7 + 0.3).cuda()
+    r = torch.randn(N, C, L, generator=g).cuda() if res else None
+    gu_w, gy_w = torch.randn(N, C, L, generator=g).cuda(), torch.randn(N, C, L, generator=g).cuda()
+
+    def bns():
+        out = []
+        for k in range(2):
+            gg = torch.Generator().manual_seed(100 + k)
+            out.append(types.SimpleNamespace(weight=(torch.rand(C, generator=gg) + 0.5).cuda().requires_grad_(True),
+                                             bias=(torch.randn(C, generator=gg) * 0.3 + 0.4).cuda().requires_grad_(True),
+                                             running_mean=torch.zeros(C, device="cuda"), running_var=torch.ones(C, device="cuda"),
+                                             num_batches_tracked=torch.zeros((), dtype=torch.int64, device="cuda"), momentum=0.1,
+                                             eps=1e-5, training=True))
+        return out
+    outs = []
+    for fusedv in (False, True):
+        b1, b2 = bns()
+        zc = z.clone().requires_grad_(True)
+        rc = r.clone().requires_grad_(True) if res else None
+        if fusedv:
+            assert ops.bn2_act_ok(zc)
+            u, y, _ = ops.bn2_act(zc, b1, b2, residual=rc, lif=lif, want_pre=True)
+        else:
+            x, _, _ = ops.bn_act(zc, None, b1.weight, b1.bias, b1.running_mean, b1.running_var, b1.num_batches_tracked, True, 0.1, 1e-5)
+            u, y, _ = ops.bn_act(x, None, b2.weight, b2.bias, b2.running_mean, b2.running_var, b2.num_batches_tracked, True, 0.1, 1e-5,
+                                 residual=rc, lif=lif, want_pre=True)
+        loss = (u * gu_w).sum()
+        if lif:
+            loss = loss + (y.float() * gy_w).sum()
+        loss.backward()
+        outs.append((u.detach(), y.float().detach() if lif else None, zc.grad, rc.grad if res else None, b1, b2))
+    (u0, y0, gz0, gr0, a1, a2), (u1, y1, gz1, gr1, c1, c2) = outs
+    close = lambda a, b, tol, scale=None: (a - b).abs().max().item() <= tol * max((b.abs().max().item() if scale is None else scale), 1e-6)
+    assert close(u1, u0, 1e-5)
+    flips = False
+    if lif:
+        d = (y1 - y0) * 8
+        assert d.abs().max().item() <= 1 and (d != 0).float().mean().item() <= 1e-4
+        flips = bool((d != 0).any())
+    for x, y_ in ((c1, a1), (c2, a2)):
+        assert close(x.running_mean, y_.running_mean, 1e-5, 1.0) and close(x.running_var, y_.running_var, 1e-5) and int(x.num_batches_tracked) == 1
+    tol = 5e-3 if flips else 1e-4
+    assert close(gz1, gz0, tol) and close(c2.weight.grad, a2.weight.grad, tol) and close(c2.bias.grad, a2.bias.grad, tol)
+    if res:
+        assert close(gr1, gr0, tol)
+    s2 = a2.weight.grad.abs().max().item()
+    assert close(c1.weight.grad, a1.weight.grad, tol, s2) and close(c1.bias.grad, a1.bias.grad, tol, s2)
+    assert float(c1.bias.grad.abs().max()) == 0.0
