@@ -178,6 +178,8 @@ def main():
     from spike2former_amd.dist import FlatGradAllReduce, broadcast_params, init_process_group
     from spike2former_amd.init_utils import seeded_init
 
+    # a shape that leaves the package's kernels for a vendor library / ATen path is an error here, not a slower number
+    ops.STRICT = os.environ.get("S2F_STRICT", "1") != "0"
     rank, world, local = init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus"
     if args.rendezvous_only:

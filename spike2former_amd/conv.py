@@ -61,6 +61,7 @@ class Conv2d(nn.Conv2d):
                     and self.stride == (1, 1) and self.dilation == (1, 1) and self.padding[0] == self.padding[1]):
                 return ops.dwconv(x, self.weight, self.padding[0], border)      # hand-written depthwise stencil
             assert border is None
+            ops.fallback("grouped Conv2d", f"groups={self.groups} k={self.kernel_size}")
             return F.conv2d(ops.spikes_float(x), self.weight, bias, self.stride, self.padding, self.dilation, self.groups)
         N, C, H, W = x.shape
         M = self.out_channels

@@ -8,7 +8,7 @@ from .neuron import Q_IFNode
 
 
 def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None,
-           want_border=False, scale=None, split_grad=False):
+           want_border=False, scale=None):
     """z: conv output WITHOUT its bias, [N, C, *].  Returns (u, y): u = BN(z + bias) [+ residual] (None unless wanted),
     y = lif(u) as an ops.Spikes pair (None without lif).  Shapes follow z.  want_border: also return BN(0) from the running statistics as
     updated by this call (BNAndPadLayer's padding value, sdtv2.py:68-78) -- written by the same kernel.
@@ -18,7 +18,7 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     scale: per-channel factor on the BatchNorm output, u = scale * BN(z + bias) [+ residual] (the layer-scale `gamma` of the
     pixel decoder's encoder layers, detr_layers.py:331-337), folded into the affine pair: two [C] products, no pass over u."""
     if next_lif is not None and lif is None:
-        u, y = bn_act(z, conv_bias, bn, residual=residual, lif=next_lif, want_pre=True, scale=scale, split_grad=split_grad)
+        u, y = bn_act(z, conv_bias, bn, residual=residual, lif=next_lif, want_pre=True, scale=scale)
         next_lif.prefire(u, y)
         return u, None
     if want_pre is None:
@@ -51,8 +51,7 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         bn.num_batches_tracked if training else None, training, bn.momentum, bn.eps,
         residual=residual, lif=lif is not None, want_pre=want_pre, v_in=v_in,
         keep_v=(lif is not None and lif.keep_membrane), D=(lif.D if lif is not None else 8),
-        vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None), want_border=True,
-        split_grad=split_grad)
+        vth=(lif.v_threshold if lif is not None else 1.0), stats=(lif.stats if lif is not None else None), want_border=True)
     if lif is not None:
         lif.v = v_out if lif.keep_membrane else 0.0
         if lif._forward_hooks:
@@ -122,16 +121,8 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     eval_bn = (not bn.training) and bn.running_mean is not None and bn.affine
     if not (pure_conv and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
             and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
-        # the gradient of z is written by the BatchNorm backward and read only by this convolution's two gradient GEMMs: when
-        # they can take it as bf16 planes (ops.GRAD_SPLIT), the BatchNorm backward writes planes
-        ops.split_request(pure_conv and torch.is_grad_enabled())
-        try:
-            z = conv.forward_nobias(x)
-        finally:
-            split = ops.split_request(False)
-        if split and (z.numel() // max(z.shape[0] * z.shape[1], 1)) % 4 != 0:
-            raise RuntimeError("pre-split gradient granted for a row length the fused BatchNorm does not take")
-        return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif, split_grad=split)
+        z = conv.forward_nobias(x)
+        return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
     M = conv.out_channels
     v_in = None
     if fire is not None and not isinstance(fire.v, float):

@@ -19,6 +19,16 @@ from . import ops
 from .neuron import reset_net
 
 
+def _check_settings(captured):
+    """A captured hipGraph bakes in the launch structure the op-layer switches selected at capture time (ops.cfg): replaying it
+    under different settings would mix two configurations silently -- e.g. eager steps of a comparison running with a switch
+    flipped while the graph still replays the old kernels."""
+    now = ops.cfg.snapshot()
+    if now != captured:
+        diff = {k: (captured[k], now[k]) for k in now if now[k] != captured.get(k)}
+        raise RuntimeError(f"this hipGraph was captured under different op-layer settings (captured, now): {diff}; re-capture")
+
+
 class GraphedStep:
     def __init__(self, model, loss_fn, example_input, grad_buffer=None, warmup=3):
         self.model, self.loss_fn = model, loss_fn
@@ -44,6 +54,7 @@ class GraphedStep:
         # the graph bakes in the addresses of the conversion job tables and of every cached split / pack buffer: hold them (an
         # eager forward after an optimiser step re-converts INTO the same buffers, ops._cache_buffer, and replaces tables)
         self._converted = ops.conversion_state()
+        self._settings = ops.cfg.snapshot()
 
     def _eager_step(self):
         reset_net(self.model)
@@ -61,6 +72,7 @@ class GraphedStep:
         return loss.detach()
 
     def __call__(self, x=None):
+        _check_settings(self._settings)
         if x is not None:
             self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
@@ -104,7 +116,8 @@ class GraphedSplitStep:
             ops.wgrad_join()
             self.red.pack(grads)
         torch.cuda.synchronize()
-        self._converted = ops.conversion_state()          # see GraphedStep
+        self._converted = ops.conversion_state()
+        self._settings = ops.cfg.snapshot()          # see GraphedStep
 
     def _forward(self):
         reset_net(self.model)
@@ -113,6 +126,7 @@ class GraphedSplitStep:
 
     def forward(self, x=None):
         """-> the model outputs (static tensors, valid until the next forward), detached leaves that require grad."""
+        _check_settings(self._settings)
         if x is not None:
             self.static_in.copy_(x, non_blocking=True)
         self.graph_a.replay()
@@ -191,7 +205,8 @@ class GraphedHungarianStep:
             self.red.pack(grads)
             self.losses = {k: v.detach() for k, v in losses.items()}
         torch.cuda.synchronize()
-        self._converted = ops.conversion_state()          # see GraphedStep
+        self._converted = ops.conversion_state()
+        self._settings = ops.cfg.snapshot()          # see GraphedStep
 
     def _forward(self):
         reset_net(self.model)
@@ -221,6 +236,7 @@ class GraphedHungarianStep:
         return self.crit.loss_from_tables(outs[0], outs[1], self.static_seg, self.tgt_labels, self.row_class, self.num_masks)
 
     def __call__(self, x=None, seg=None):
+        _check_settings(self._settings)
         if x is not None:
             self.static_in.copy_(x, non_blocking=True)
         if seg is not None:
@@ -274,13 +290,15 @@ class GraphedOverlapStep:
             ops.wgrad_join()
             self.red.pack(grads)
         torch.cuda.synchronize()
-        self._converted = ops.conversion_state()          # see GraphedStep
+        self._converted = ops.conversion_state()
+        self._settings = ops.cfg.snapshot()          # see GraphedStep
 
     def _forward(self):
         reset_net(self.model)
         return self.loss_fn(*self.model(self.static_in))
 
     def __call__(self, x=None):
+        _check_settings(self._settings)
         if x is not None:
             self.static_in.copy_(x, non_blocking=True)
         self.graph_f.replay()                 # runs under the previous step's all-reduce

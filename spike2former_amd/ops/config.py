@@ -1,0 +1,48 @@
+"""Every process-global switch of the op layer in ONE object (`ops.cfg`; `ops.X` reads and writes forward to it for the names
+below).  A captured step bakes the launch structure these select into its hipGraph: graph.py snapshots the scalar ones at capture
+(`cfg.snapshot()`) and refuses to replay under a different setting."""
+import os
+
+
+class Config:
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "SPIKE_GEMM_DW", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "STRICT")
+    RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
+
+    def __init__(self):
+        self.KERNEL_EVENTS = None
+        self.GRAD_SINKS = None
+        self.WGRAD_STREAM = None
+        self.DEFER_DW = True
+        self.DEFER_DW_MAX_CONTRACTION = int(os.environ.get("S2F_DEFER_DW_MAX", "32768"))
+        self.BRANCH_STREAMS = None
+        self.LONG_STREAMS = None
+        self.LONG_WHAT = ("lat", "mf", "kv")
+        self.BLAS_AUTOTUNE = True
+        self.SPIKES_BF16 = True
+        self.SPIKE_GEMM_TERMS = 3
+        self.SPIKE_GEMM_ENABLED = True
+        self.CONV3X3_IMPLICIT = True
+        self.CONV3X3_IMPLICIT_MIN_PIXELS = int(os.environ.get("S2F_CONV3_MIN_PIXELS", 32 * 32))
+        self.CONV3X3_DX_IMPLICIT = True
+        self.CONV3X3_DX_MIN_PIXELS = 0
+        self.MASK_EINSUM_DW_GROUPED = os.environ.get("S2F_MASK_DW_GROUPED", "1") != "0"
+        self.MASK_EINSUM_DE_MFMA = True
+        self.SPIKE_GEMM_DW = True
+        self.SPIKE_GEMM_CHECK = False
+        self.PGEMM = os.environ.get("S2F_PGEMM", "1") != "0"
+        self.PGEMM_DX = os.environ.get("S2F_PGEMM_DX", "1") != "0"
+        self.PGEMM_MIN_N = 128
+        self.PGEMM_CONV = os.environ.get("S2F_PGEMM_CONV", "1") != "0"
+        self.BN_PARTIALS = os.environ.get("S2F_BN_PARTIALS", "1") != "0"
+        self.BN_PARTIALS_SINGLE = os.environ.get("S2F_BN_PARTIALS_SINGLE", "0") != "0"
+        self.BN2_FUSED = os.environ.get("S2F_BN2_FUSED", "1") != "0"
+        self.LINEAR_TM = os.environ.get("S2F_LINEAR_TM", "1") != "0"
+        # STRICT: a shape that leaves this package's kernels for a library / ATen path is an error, not a slower number
+        self.STRICT = os.environ.get("S2F_STRICT", "0") != "0"
+
+    def snapshot(self):
+        """the settings a captured hipGraph depends on (scalars only)"""
+        return {n: getattr(self, n) for n in self.FIELDS if n not in self.RUNTIME}
+
+
+cfg = Config()

@@ -1,0 +1,250 @@
+"""Depthwise stencils (csrc/dwconv.hip) and dense k x k convolutions lowered to the GEMM kernels."""
+import torch
+
+from .config import cfg
+from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _stream, check, lib, Spikes, ...)
+from .gemm import *          # noqa: F401,F403
+
+
+# ------------------------------------------------------------------------------------------------ depthwise conv
+class _DWConv(torch.autograd.Function):
+    """Depthwise KxK, stride 1 (nn.Conv2d(groups=C)); `border` = per-channel constant padding value (detached).
+    x: fp32, or a bf16 spike map with its autograd handle `tok`."""
+
+    @staticmethod
+    def forward(ctx, x, tok, w, border, pad):
+        _need_cuda(w, border, spikes=x)
+        x, w = x.contiguous(), w.contiguous()
+        N, C, H, W = x.shape
+        K = w.shape[-1]
+        Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+        y = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=x.device)
+        if border is not None:
+            border = border.contiguous()
+        xb = int(x.dtype == torch.bfloat16)
+        check(lib.s2f_dwconv_fwd(_ptr(x), _ptr(w), _ptr(border), _ptr(y), N, C, H, W, K, pad, xb, _stream()),
+              "s2f_dwconv_fwd")
+        ctx.save_for_backward(x, w, border)
+        ctx.pad, ctx.has_tok = pad, tok is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, border = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, H, W = x.shape
+        K = w.shape[-1]
+        gx = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+            check(lib.s2f_dwconv_bwd_input(_ptr(gy), _ptr(w), _ptr(gx), N, C, H, W, K, ctx.pad, _stream()),
+                  "s2f_dwconv_bwd_input")
+        if ctx.needs_input_grad[2]:
+            sink = _sink_for(w)
+            gw = torch.empty_like(w) if sink is None else None
+            side = _wgrad_stream(sink, gy, x, border)
+            check(lib.s2f_dwconv_bwd_weight(_ptr(x), _ptr(border), _ptr(gy), _ptr(gw if sink is None else sink), N, C, H, W,
+                                            K, ctx.pad, int(sink is not None), int(x.dtype == torch.bfloat16),
+                                            side.cuda_stream if side is not None else _stream()), "s2f_dwconv_bwd_weight")
+        return _grad_pair(ctx.has_tok, gx) + (gw, None, None)
+
+
+def dwconv(x, w, pad, border=None):
+    """x: fp32 tensor or Spikes"""
+    data, tok = _unpack(x)
+    return _DWConv.apply(data, tok, w, border, pad)
+
+
+
+
+# ------------------------------------------------------------------------------------------------ dense k x k convolution
+class _ConvDense(torch.autograd.Function):
+    """Dense k x k Conv2d lowered to GEMMs (MIOpen is not usable on this image, see conv.py).
+
+    forward : cols = im2col(x) ; y = W2d @ cols                       (spike GEMM when x is a neuron output)
+    dW      : dY @ cols^T                                              (bf16-MFMA batch-reduce kernel for spike inputs)
+              3x3 / stride 1 / padding 1 on spikes: both as IMPLICIT GEMMs -- the kernels' loaders read x itself, `cols`
+              (9x the activation: 2.4 GB for MS_ConvBlock1_1.conv2 at C2) is neither written, read nor saved
+    dX      : the cheaper of two equivalent lowerings --
+                M >= C : dcols = W2d^T @ dY ; dX = col2im(dcols)       (the adjoint of im2col; C*k*k rows)
+                M <  C : dX = flip(W)^T (*) dY = W_t2d @ im2col(dY)     (transposed convolution; M*k*k rows)
+              the second form moves k*k*M instead of k*k*C rows through HBM and needs no col2im scatter; it applies to
+              stride 1 (MS_ConvBlock.conv2: 4C -> C, sdtv2.py:202-204)."""
+
+    @staticmethod
+    def forward(ctx, x, tok, weight, bias, stride, padding, spike_input, stats=False):
+        _need_cuda(weight, bias, spikes=x)
+        ctx.has_tok = tok is not None
+        part = None
+        xb = x.dtype == torch.bfloat16
+        N, C, H, W = x.shape
+        M, _, kh, kw = weight.shape
+        Ho = (H + 2 * padding - kh) // stride + 1
+        Wo = (W + 2 * padding - kw) // stride + 1
+        w2d = weight.view(M, -1)
+        # implicit GEMM: 3x3, stride 1, padding 1 on spikes -- the kernels' loaders read the activation itself
+        implicit = (spike_input and cfg.SPIKE_GEMM_ENABLED and cfg.CONV3X3_IMPLICIT and kh == 3 and kw == 3 and stride == 1
+                    and padding == 1 and C % 32 == 0 and W % 4 == 0 and (W & (W - 1)) == 0
+                    and H * W >= cfg.CONV3X3_IMPLICIT_MIN_PIXELS)
+        if implicit:
+            x = x.contiguous()
+            if cfg.SPIKE_GEMM_CHECK:
+                assert _is_spike_grid(x), "not a spike tensor"
+            y = torch.empty(N, M, H * W, dtype=torch.float32, device=x.device)
+            _time_next("spike_gemm_fwd", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9,
+                       moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
+            P = _want_partials(stats and cfg.PGEMM_CONV and xb and cfg.SPIKE_GEMM_TERMS == 3 and bias is None, N, M, H * W)
+            if P:
+                part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device)
+                check(lib.s2f_pgemm_conv3x3_bf16_stats(_ptr(pack_weight_conv3(weight)), _ptr(x), _ptr(y), _ptr(part), N, M, C, H, W,
+                                                       _stream()), "s2f_pgemm_conv3x3_bf16_stats")
+            elif cfg.PGEMM_CONV and xb and cfg.SPIKE_GEMM_TERMS == 3:
+                check(lib.s2f_pgemm_conv3x3_bf16(_ptr(pack_weight_conv3(weight)), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, 0,
+                                                 _stream()), "s2f_pgemm_conv3x3_bf16")
+            else:
+                ws = split_weight_conv3(weight)
+                fn = lib.s2f_spike_conv3x3_fwd_bf16 if xb else lib.s2f_spike_conv3x3_fwd
+                check(fn(_ptr(ws), _ptr(x), _ptr(bias), _ptr(y), N, M, C, H, W, ws.shape[1], ws.shape[2], cfg.SPIKE_GEMM_TERMS,
+                         _stream()), "s2f_spike_conv3x3_fwd")
+            ctx.save_for_backward(x, weight)
+            ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, True)
+            ctx.implicit = True
+            part = y.new_empty(0) if part is None else part
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
+            return y.view(N, M, Ho, Wo), part
+        ctx.implicit = False
+        cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
+        use_mfma = spike_input and cfg.SPIKE_GEMM_ENABLED and cols.shape[2] % 4 == 0
+        L = Ho * Wo
+        if use_mfma:
+            y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
+            _time_next("spike_gemm_fwd", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1],
+                       moved=N * L * ((2 if xb else 4) * cols.shape[1] + 4 * M))
+            pg = cfg.PGEMM and xb and L % 4 == 0 and L >= 8 and cfg.SPIKE_GEMM_TERMS == 3
+            P = _want_partials(stats and pg and bias is None, N, M, L)
+            if P:
+                part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device)
+                check(lib.s2f_pgemm_nn_bf16_stats(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(y), _ptr(part), N, M, L, cols.shape[1],
+                                                  _stream()), "s2f_pgemm_nn_bf16_stats")
+            elif pg:
+                check(lib.s2f_pgemm_nn_bf16(_ptr(pack_weight(w2d)), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1],
+                                            cfg.SPIKE_GEMM_TERMS, 0, _stream()), "s2f_pgemm_nn_bf16")
+            else:
+                ws = split_weight(w2d)
+                fn = lib.s2f_spike_gemm_fwd_bf16 if xb else lib.s2f_spike_gemm_fwd
+                check(fn(_ptr(ws), _ptr(cols), _ptr(bias), _ptr(y), N, M, L, cols.shape[1], ws.shape[1], ws.shape[2],
+                         cfg.SPIKE_GEMM_TERMS, _stream()), "s2f_spike_gemm_fwd")
+        else:
+            if xb:
+                cols = cols.float()
+            if cfg.PGEMM_DX and L % 4 == 0 and L >= cfg.PGEMM_MIN_N:
+                # general fp32 input (the stem reads the image): the transposed product on the pack of W^T, 6 passes
+                y = torch.empty(N, M, L, dtype=torch.float32, device=x.device)
+                _time_next("dx_gemm", 4 * N * L * (cols.shape[1] + M), 2 * N * M * L * cols.shape[1])
+                P = _want_partials(stats and bias is None, N, M, L)
+                if P:
+                    part = torch.empty(M, P, 2, dtype=torch.float32, device=x.device)
+                    check(lib.s2f_pgemm_dx_f32_stats(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, _ptr(part), N,
+                                                     cols.shape[1], M, L, _stream()), "s2f_pgemm_dx_f32_stats")
+                else:
+                    check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, N, cols.shape[1], M,
+                                               L, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
+            else:
+                y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
+            if bias is not None:
+                y = y + bias.view(1, -1, 1)
+        ctx.save_for_backward(cols, weight)
+        ctx.geo = (N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, bias is not None, use_mfma)
+        part = y.new_empty(0) if part is None else part
+        ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
+        return y.view(N, M, Ho, Wo), part
+
+    @staticmethod
+    def backward(ctx, gy, _gpart=None):
+        cols, weight = ctx.saved_tensors
+        if gy is None:
+            return (None,) * 8
+        N, C, H, W, M, kh, kw, Ho, Wo, stride, padding, has_bias, use_mfma = ctx.geo
+        gy = gy.contiguous().view(N, M, Ho * Wo)
+        w2d = weight.view(M, -1)
+        gx = gw = gb = None
+        xb = cols.dtype == torch.bfloat16
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if (cfg.CONV3X3_DX_IMPLICIT and kh == 3 and kw == 3 and stride == 1 and padding == 1 and M % 32 == 0 and W % 4 == 0
+                    and gy.is_cuda and H * W >= cfg.CONV3X3_DX_MIN_PIXELS):
+                # transposed convolution dX = flip(W)^T (*) dY as an implicit 6-pass split GEMM: no unfold(dY), no col2im
+                gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+                _time_next("dx_gemm", 4 * N * H * W * (C + M), 2 * N * M * H * W * C * 9)
+                # measured (tools/probe_pgemm.py conv): the pipelined kernel wins for <= 64 output rows (narrow tiles: 442 vs 729 us
+                # on [32 <- 128] at 256 x 256) and for long contractions (>= 256 channels); the round-2 kernel keeps a 5-10 % edge
+                # on wide outputs over short contractions
+                if cfg.PGEMM_CONV and (C <= 64 or M >= 256):
+                    check(lib.s2f_pgemm_conv3x3_f32(_ptr(pack_weight_conv3(weight, transposed=True)), _ptr(gy), _ptr(gx), N, C, M, H,
+                                                    W, 0, _stream()), "s2f_pgemm_conv3x3_f32")
+                else:
+                    wt = split_weight_tconv3(weight)
+                    check(lib.s2f_conv3x3_general(_ptr(wt), _ptr(gy), _ptr(gx), N, C, M, H, W, wt.shape[1], wt.shape[2], _stream()),
+                          "s2f_conv3x3_general")
+            elif M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
+                wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
+                gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)
+                gx = bmm_tuned(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
+            else:
+                dcols = dx_gemm(w2d, gy)
+                gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
+        if ctx.needs_input_grad[2]:
+            K = w2d.shape[1]
+            if ctx.implicit:
+                x = cols                                                  # the saved tensor is the activation itself
+                gt = torch.empty(M, 3, 3, C, dtype=torch.float32, device=gy.device)        # tap-major, as the kernel contracts
+                _time_next("spike_gemm_dw", 4 * N * H * W * (C + M), 2 * N * M * H * W * K,
+                           moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
+                fn = lib.s2f_spike_conv3x3_dw_bf16 if xb else lib.s2f_spike_conv3x3_dw
+                check(fn(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")
+                sink = _sink_for(weight)
+                if sink is not None:
+                    sink.view(M, C, 3, 3).add_(gt.permute(0, 3, 1, 2))
+                    gw = None
+                else:
+                    gw = gt.permute(0, 3, 1, 2).contiguous()
+            elif use_mfma and cfg.SPIKE_GEMM_DW and M >= 16:
+                sink = _sink_for(weight)
+                gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
+                if (cfg.DEFER_DW and sink is not None and xb and N * Ho * Wo <= cfg.DEFER_DW_MAX_CONTRACTION and cfg.WGRAD_STREAM is None):
+                    _defer_dw(gy, cols, sink, N, M, K, Ho * Wo)
+                    return _grad_pair(ctx.has_tok, gx) + (None, gy.sum((0, 2)) if (has_bias and ctx.needs_input_grad[3]) else None,
+                                                          None, None, None, None)
+                _time_next("spike_gemm_dw", 4 * N * Ho * Wo * (K + M), 2 * N * M * Ho * Wo * K,
+                           moved=N * Ho * Wo * ((2 if xb else 4) * K + 4 * M))
+                side = _wgrad_stream(sink, gy, cols)
+                st = side.cuda_stream if side is not None else _stream()
+                if xb:
+                    check(lib.s2f_spike_gemm_dw_bf16(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                                     int(sink is not None), st), "s2f_spike_gemm_dw_bf16")
+                else:
+                    check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(cols), _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                                int(sink is not None), 1, st), "s2f_spike_gemm_dw")
+            elif cfg.PGEMM_DX and (Ho * Wo) % 4 == 0 and cols.dtype == torch.float32:
+                # both operands general fp32 (the stem): 6-pass weight-gradient kernel, straight into the sink when there is one
+                sink = _sink_for(weight)
+                gw = torch.empty(M, K, dtype=torch.float32, device=gy.device) if sink is None else None
+                check(lib.s2f_gemm_dw_general(_ptr(gy), 0, _ptr(cols), 0, _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
+                                              int(sink is not None), _stream()), "s2f_gemm_dw_general")
+            else:
+                fallback("conv_dense dW", f"M={M} L={Ho * Wo}")
+                gw = torch.bmm(gy, cols.float().transpose(1, 2)).sum(0)
+            gw = gw.view_as(weight) if gw is not None else None
+        if has_bias and ctx.needs_input_grad[3]:
+            gb = gy.sum((0, 2))
+        return _grad_pair(ctx.has_tok, gx) + (gw, gb, None, None, None, None)
+
+
+def conv_dense(x, weight, bias, stride, padding, spike_input, stats=False):
+    """x: fp32 tensor, or Spikes (then `spike_input` is implied).  stats: as spike_gemm"""
+    data, tok = _unpack(x)
+    return _with_part(*_ConvDense.apply(data, tok, weight, bias, stride, padding, spike_input or isinstance(x, Spikes), bool(stats)))
+
+
+__all__ = [n for n in dir() if not n.startswith('__')]

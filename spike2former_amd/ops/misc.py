@@ -1,0 +1,188 @@
+"""Tiled transposes, exact-2x bilinear up-sampling, the mask-loss kernels of the Hungarian-matched loss."""
+import torch
+
+from .config import cfg
+from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _stream, check, lib, Spikes, ...)
+
+
+# ------------------------------------------------------------------------------------------------ transposition
+class _TransposeLast2(torch.autograd.Function):
+    """x [B, R, C] -> [B, C, R], contiguous (the adjoint is the same kernel the other way round)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, R, C = x.shape
+        y = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+        check(lib.s2f_transpose_last2(_ptr(x), _ptr(y), B, R, C, _stream()), "s2f_transpose_last2")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B, C, R = gy.shape
+        gx = torch.empty(B, R, C, dtype=torch.float32, device=gy.device)
+        check(lib.s2f_transpose_last2(_ptr(gy), _ptr(gx), B, C, R, _stream()), "s2f_transpose_last2")
+        return gx
+
+
+class _TransposeScaleAdd(torch.autograd.Function):
+    """q + g[c] * x^T: x [B, R, C] token-major, q [B, C, R] channel-major, g [C] (s2f.h s2f_transpose_scale_add_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, q, g):
+        _need_cuda(x, q, g)
+        x, q, g = x.contiguous(), q.contiguous(), g.contiguous()
+        B, R, C = x.shape
+        y = torch.empty_like(q)
+        check(lib.s2f_transpose_scale_add_fwd(_ptr(x), _ptr(q), _ptr(g), _ptr(y), B, R, C, _stream()), "s2f_transpose_scale_add_fwd")
+        ctx.save_for_backward(x, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, R, C = x.shape
+        gx = torch.empty_like(x)
+        gg = torch.zeros_like(g)
+        check(lib.s2f_transpose_scale_add_bwd(_ptr(gy), _ptr(x), _ptr(g), _ptr(gx), _ptr(gg), B, R, C, _stream()),
+              "s2f_transpose_scale_add_bwd")
+        return gx, gy, gg
+
+
+def transpose_scale_add(x, q, g):
+    """q [..., C, R] + g[c] * x[..., R, C]^T in one pass (the layer-scaled FFN residual of the pixel decoder); falls back to
+    transpose + addcmul for shapes the kernel does not take."""
+    R, C = x.shape[-2:]
+    if x.dtype == torch.float32 and x.is_cuda and R % 64 == 0 and C % 64 == 0 and g.data_ptr() % 16 == 0:
+        return _TransposeScaleAdd.apply(x.reshape(-1, R, C), q.reshape(-1, C, R), g).view(q.shape)
+    return torch.addcmul(q, transpose_last2(x).view(q.shape), g.view(*([1] * (q.dim() - 2)), C, 1))
+
+
+def transpose_last2(x):
+    """x [..., R, C] (fp32, CUDA) -> contiguous [..., C, R]: the `.permute(...).contiguous()` copies around the DCNv3 sampling
+    core as one tiled kernel (s2f_transpose_last2)."""
+    lead = x.shape[:-2]
+    R, C = x.shape[-2:]
+    if x.dtype != torch.float32 or x.numel() == 0:
+        return x.transpose(-1, -2).contiguous()
+    return _TransposeLast2.apply(x.reshape(-1, R, C)).view(*lead, C, R)
+
+
+# ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
+class _Up2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, C, h, w = x.shape
+        y = torch.empty(N, C, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+        check(lib.s2f_upsample2x_fwd(_ptr(x), _ptr(y), N * C, h, w, _stream()), "s2f_upsample2x_fwd")
+        ctx.shape = (N, C, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, h, w = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(N, C, h, w, dtype=torch.float32, device=gy.device)
+        check(lib.s2f_upsample2x_bwd(_ptr(gy), _ptr(gx), N * C, h, w, _stream()), "s2f_upsample2x_bwd")
+        return gx
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False); the exact-2x case runs the HIP kernel."""
+    h, w = x.shape[-2:]
+    if tuple(size) == (2 * h, 2 * w) and w % 2 == 0:
+        return _Up2x.apply(x)
+    fallback("upsample_bilinear", f"{(h, w)} -> {tuple(size)}")
+    return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+
+
+# ------------------------------------------------------------------------------------------------ mask losses (row f1)
+class _MaskLossSums(torch.autograd.Function):
+    """sums[p] = {sum s t, sum s, sum t, sum focal} over the 2x up-sampled logits of matched prediction p against its binary
+    target (s2f.h s2f_mask_loss_fwd/bwd); nothing of size [P, 2h, 2w] exists forward, one such buffer backward."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt, gt_index, alpha, gamma):
+        _need_cuda(pred)
+        pred = pred.contiguous()
+        tgt = tgt.contiguous()
+        P, h, w = pred.shape
+        assert tgt.dtype == torch.uint8 and tgt.shape[1:] == (2 * h, 2 * w) and gt_index.dtype == torch.int64
+        sums = torch.empty(P, 4, dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_fwd(_ptr(pred), _ptr(tgt), _ptr(gt_index), _ptr(sums), P, h, w, alpha, gamma, _stream()),
+              "s2f_mask_loss_fwd")
+        ctx.save_for_backward(pred, tgt, gt_index)
+        ctx.cfg = (alpha, gamma)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt, gt_index = ctx.saved_tensors
+        P, h, w = pred.shape
+        g = g.contiguous()
+        gup = torch.empty(P, 2 * h, 2 * w, dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_bwd(_ptr(pred), _ptr(tgt), _ptr(gt_index), _ptr(g), _ptr(gup), P, h, w, *ctx.cfg, _stream()),
+              "s2f_mask_loss_bwd")
+        gp = torch.empty_like(pred)
+        check(lib.s2f_upsample2x_bwd(_ptr(gup), _ptr(gp), P, h, w, _stream()), "s2f_upsample2x_bwd")
+        return gp, None, None, None, None
+
+
+def mask_loss_sums(pred, tgt_u8, gt_index, alpha, gamma):
+    """pred [P, h, w] fp32 logits, tgt_u8 [G, 2h, 2w] uint8 0/1, gt_index [P] int64 -> [P, 4]"""
+    return _MaskLossSums.apply(pred, tgt_u8, gt_index, float(alpha), float(gamma))
+
+
+def mask_cost_bins(pred, seg_small, K, alpha, gamma, eps):
+    """pred [B, R, hw] fp32 logits, seg_small [B, hw] uint8 label map -> [B, R, 2K + 2]: per class id the segmented sums of
+    (pos - neg) and of s, then sum neg and sum s over all pixels (s2f.h s2f_mask_cost_bins; match_cost.py:289-297, :361-371)."""
+    _need_cuda(pred)
+    pred, seg_small = pred.contiguous(), seg_small.contiguous()
+    B, R, hw = pred.shape
+    assert seg_small.dtype == torch.uint8 and seg_small.shape == (B, hw) and pred.dtype == torch.float32
+    out = torch.empty(B, R, 2 * K + 2, dtype=torch.float32, device=pred.device)
+    check(lib.s2f_mask_cost_bins(_ptr(pred), _ptr(seg_small), _ptr(out), B, R, hw, K, alpha, gamma, eps, _stream()),
+          "s2f_mask_cost_bins")
+    return out
+
+
+class _MaskLossSeg(torch.autograd.Function):
+    """sums[(b, r)] = {sum s t, sum s, sum t, sum focal} of the 2x up-sampled logits pred[b, r] against  seg[b] == row_class[b, r]
+    (rows with row_class < 0: zeros, zero gradient); s2f.h s2f_mask_loss_seg_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, pred, seg, row_class, alpha, gamma):
+        _need_cuda(pred)
+        pred = pred.contiguous()
+        B, R, h, w = pred.shape
+        assert seg.dtype == torch.uint8 and seg.shape == (B, 2 * h, 2 * w) and seg.is_contiguous()
+        assert row_class.dtype == torch.int32 and row_class.numel() == B * R and row_class.is_contiguous()
+        sums = torch.empty(B * R, 4, dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_seg_fwd(_ptr(pred), _ptr(seg), _ptr(row_class), _ptr(sums), B, R, h, w, alpha, gamma, _stream()),
+              "s2f_mask_loss_seg_fwd")
+        ctx.save_for_backward(pred, seg, row_class)
+        ctx.cfg = (alpha, gamma)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, seg, row_class = ctx.saved_tensors
+        B, R, h, w = pred.shape
+        gp = torch.empty_like(pred)
+        check(lib.s2f_mask_loss_seg_bwd(_ptr(pred), _ptr(seg), _ptr(row_class), _ptr(g.contiguous()), _ptr(gp), B, R, h, w, *ctx.cfg,
+                                        _stream()), "s2f_mask_loss_seg_bwd")
+        return gp, None, None, None, None
+
+
+def mask_loss_seg(pred, seg_u8, row_class, alpha, gamma):
+    """pred [B, R, h, w] fp32 logits, seg_u8 [B, 2h, 2w] uint8 label map, row_class [B * R] int32 -> sums [B * R, 4]"""
+    return _MaskLossSeg.apply(pred, seg_u8, row_class, float(alpha), float(gamma))
+
+
+
+__all__ = [n for n in dir() if not n.startswith('__')]

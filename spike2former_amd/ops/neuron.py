@@ -1,0 +1,151 @@
+"""Q_IFNode as autograd ops (csrc/lif.hip): one call, the fused two-neuron form of the decoder's keys / values, T chained calls."""
+import torch
+
+from .config import cfg
+from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _stream, check, lib, Spikes, ...)
+
+
+# ------------------------------------------------------------------------------------------------ LIF
+class _LIF(torch.autograd.Function):
+    """One Q_IFNode call (neuron.py:166-197 + surrogate.py:522-538).  Saves 1 bit/element for backward."""
+
+    @staticmethod
+    def forward(ctx, x, v_in, D, vth, keep_v, stats, bf16):
+        _need_cuda(x, v_in)
+        x = x.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        n = x.numel()
+        y = torch.empty(x.shape, dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device)
+        v_out = torch.empty_like(x) if keep_v else None
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
+        _time_next("lif_fwd", 8 * n, moved=(6 if bf16 else 8) * n)
+        check(lib.s2f_lif_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), 0, _ptr(stats), n, vth, D, int(bf16),
+                              _stream()), "s2f_lif_fwd")
+        ctx.save_for_backward(mask)
+        ctx.D, ctx.vth, ctx.has_v = D, vth, v_in is not None
+        ctx.set_materialize_grads(False)          # no zero-filled stand-ins for the gradients of unused / bf16 outputs
+        if v_out is None:
+            v_out = x.new_empty(0)
+            ctx.mark_non_differentiable(v_out)
+        if bf16:                       # (autograd handle, membrane, bf16 spikes)
+            ctx.mark_non_differentiable(y)
+            return _new_tok(x), v_out, y
+        aux = x.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return y, v_out, aux
+
+    @staticmethod
+    def backward(ctx, gy, gv, _g2):
+        (mask,) = ctx.saved_tensors
+        if gy is None and gv is None:
+            return (None,) * 7
+        if gy is None:                              # only the membrane carries a gradient
+            gy = torch.zeros_like(gv)
+        gy = gy.contiguous()
+        if gv is not None and gv.numel() != gy.numel():
+            gv = None
+        if gv is not None:
+            gv = gv.contiguous()
+        gx = torch.empty_like(gy)
+        _time_next("lif_bwd", 12 * gy.numel())
+        check(lib.s2f_lif_bwd(_ptr(gy), _ptr(gv), _ptr(mask), _ptr(gx), gy.numel(), ctx.vth, ctx.D, _stream()),
+              "s2f_lif_bwd")
+        return gx, (gx if ctx.has_v else None), None, None, None, None, None
+
+
+def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None, spikes=False):
+    """-> (y, v_out or None); `spikes`: y as a Spikes pair (bf16 when cfg.SPIKES_BF16 and the size allows 8-byte stores)"""
+    bf16 = bool(spikes) and spikes_bf16_ok(D) and x.numel() % 4 == 0 and x.numel() > 0
+    y, v, data = _LIF.apply(x, v_in, D, vth, keep_v, stats, bf16)
+    if spikes:
+        y = Spikes(data, y) if bf16 else Spikes(y, None)
+    return y, (v if keep_v else None)
+
+
+class _Sum2LIF(torch.autograd.Function):
+    """The decoder's value / key neurons on  a = x + e[c]  and  a + pos[b]  in one pass, neither sum materialised
+    (maskformer_head.py:535-540 + transformer.py:626-629; s2f.h s2f_sum2_lif_fwd).  Reset, stateless neurons only."""
+
+    @staticmethod
+    def forward(ctx, x, e, pos, B, D, vth, bf16):
+        _need_cuda(x, e, pos)
+        x, e, pos = x.contiguous(), e.contiguous(), pos.contiguous()
+        TB, C, L = x.shape
+        n = x.numel()
+        dt = torch.bfloat16 if bf16 else torch.float32
+        yk, yv = torch.empty(x.shape, dtype=dt, device=x.device), torch.empty(x.shape, dtype=dt, device=x.device)
+        mk = torch.empty(mask_words(n), dtype=torch.int64, device=x.device)
+        mv = torch.empty_like(mk)
+        _time_next("lif_fwd", 12 * n, moved=(8 if bf16 else 12) * n)          # read x, write two spike maps (pos is 1/T of a map)
+        check(lib.s2f_sum2_lif_fwd(_ptr(x), _ptr(e), _ptr(pos), _ptr(yk), _ptr(yv), _ptr(mk), _ptr(mv), TB, B, C, L, vth, D,
+                                   int(bf16), _stream()), "s2f_sum2_lif_fwd")
+        ctx.save_for_backward(mk, mv)
+        ctx.D = D
+        ctx.set_materialize_grads(False)
+        if bf16:
+            ctx.mark_non_differentiable(yk, yv)
+            return _new_tok(x), _new_tok(x), yk, yv
+        aux = x.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return yk, yv, aux, aux
+
+    @staticmethod
+    def backward(ctx, gk, gv, _a, _b):
+        mk, mv = ctx.saved_tensors
+        if gk is None and gv is None:
+            return (None,) * 7
+        gk = torch.zeros_like(gv) if gk is None else gk
+        gv = torch.zeros_like(gk) if gv is None else gv
+        gk, gv = gk.contiguous(), gv.contiguous()
+        gx = torch.empty_like(gk)
+        _time_next("lif_bwd", 12 * gk.numel())
+        check(lib.s2f_sum2_lif_bwd(_ptr(gk), _ptr(gv), _ptr(mk), _ptr(mv), _ptr(gx), gk.numel(), ctx.D, _stream()),
+              "s2f_sum2_lif_bwd")
+        ge = gx.sum((0, 2)) if ctx.needs_input_grad[1] else None
+        return gx, ge, None, None, None, None, None
+
+
+def sum2_lif(x, e, pos, B, D=8, vth=1.0):
+    """x [T*B, C, L], e [C], pos [B, C, L] -> (Q_IFNode(x + e + pos), Q_IFNode(x + e))  (key spikes, value spikes), as Spikes."""
+    bf16 = spikes_bf16_ok(D)
+    hk, hv, dk, dv = _Sum2LIF.apply(x, e, pos, B, D, vth, bf16)
+    return (Spikes(dk, hk), Spikes(dv, hv)) if bf16 else (Spikes(hk), Spikes(hv))
+
+
+class _LIFSeq(torch.autograd.Function):
+    """T chained stateful calls on one neuron, membrane in registers (cal_firing_num.py:203-225 across images)."""
+
+    @staticmethod
+    def forward(ctx, x_seq, v0, D, vth, stats):
+        _need_cuda(x_seq, v0)
+        x_seq = x_seq.contiguous()
+        T = x_seq.shape[0]
+        n = x_seq[0].numel()
+        y = torch.empty_like(x_seq)
+        vT = torch.empty_like(x_seq[0])
+        mask = torch.empty(T * mask_words(n), dtype=torch.int64, device=x_seq.device)
+        check(lib.s2f_lif_seq_fwd(_ptr(x_seq), _ptr(None if v0 is None else v0.contiguous()), _ptr(y), _ptr(vT),
+                                  _ptr(mask), _ptr(stats), T, n, vth, D, _stream()), "s2f_lif_seq_fwd")
+        ctx.save_for_backward(mask)
+        ctx.D, ctx.vth, ctx.has_v0, ctx.T, ctx.n = D, vth, v0 is not None, T, n
+        return y, vT
+
+    @staticmethod
+    def backward(ctx, gy, gvT):
+        (mask,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        gv0 = torch.empty_like(gy[0]) if ctx.has_v0 else None
+        check(lib.s2f_lif_seq_bwd(_ptr(gy), _ptr(None if gvT is None else gvT.contiguous()), _ptr(mask), _ptr(gx),
+                                  _ptr(gv0), ctx.T, ctx.n, ctx.vth, ctx.D, _stream()), "s2f_lif_seq_bwd")
+        return gx, gv0, None, None, None
+
+
+def lif_seq(x_seq, v0=None, D=8, vth=1.0, stats=None):
+    return _LIFSeq.apply(x_seq, v0, D, vth, stats)
+
+
+
+__all__ = [n for n in dir() if not n.startswith('__')]

@@ -17,6 +17,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _strict():
+    """S2F_STRICT for every full-size test: at the BASELINE configs no shape may leave the package's kernels for a vendor library
+    (rocBLAS / hipBLASLt through torch.bmm / matmul / einsum) or an ATen convolution -- ops.fallback raises."""
+    from spike2former_amd import ops
+    before, ops.STRICT = ops.STRICT, True
+    yield
+    ops.STRICT = before
+
+
 @pytest.fixture(scope="module")
 def c2():
     import spike2former_amd as s2f

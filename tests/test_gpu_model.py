@@ -309,45 +309,6 @@ def test_cal_firing_num_tool(tmp_path):
     assert max(abs(res["t0"][k] - res2["t0"][k]) for k in res["t0"]) > 1e-3
 
 
-def test_presplit_gradient_protocol_gives_the_same_gradients(env):
-    """ops.GRAD_SPLIT (off by default): BatchNorm backward writes the gradient of a 1x1 convolution's output as bf16 hi | mid | lo
-    planes, the convolution's two gradient GEMMs read the planes.  Same parameter gradients as the fp32 hand-over -- the terms are
-    the ones the fp32 kernels form in registers -- on the 256 x 256 images (the 1x1 layers with >= 128 columns take the protocol)."""
-    s2f, so, cfg, model = env
-    from spike2former_amd import ops
-    from spike2former_amd._lib import lib
-    img = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(4)).cuda()
-    state = {k: v.clone() for k, v in model.state_dict().items()}
-    s2f.set_keep_membrane(model, False)
-    model.train()
-    calls = []
-    orig = lib.s2f_pgemm_dx_split
-
-    def counted(*a):
-        calls.append(a[4:8])
-        return orig(*a)
-    lib.s2f_pgemm_dx_split = counted
-    grads = {}
-    try:
-        for flag in (False, True):
-            ops.GRAD_SPLIT = flag
-            model.load_state_dict(state); s2f.reset_net(model); model.zero_grad(set_to_none=True)
-            s2f.headline_loss(*model(img)).backward()
-            ops.wgrad_join()
-            grads[flag] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-            assert (len(calls) > 10) == flag
-    finally:
-        ops.GRAD_SPLIT = False
-        lib.s2f_pgemm_dx_split = orig
-        s2f.set_keep_membrane(model, True)
-        model.load_state_dict(state)
-        model.zero_grad(set_to_none=True)
-    assert grads[True].keys() == grads[False].keys()
-    scale = max(v.abs().max().item() for v in grads[False].values())
-    for n, v in grads[False].items():
-        assert (grads[True][n] - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-6 * scale, n
-
-
 def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
     """The benchmark's gradient path -- weight-gradient kernels adding straight into the flat all-reduce buffer (sinks), the
     short-contraction ones deferred and launched as one grouped kernel (ops.DEFER_DW) -- against plain autograd gradients of
@@ -373,7 +334,7 @@ def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
         red.install_sinks()
         red.zero()
         step()
-        pending = lambda: sum(len(v) for v in list(ops._DW_PENDING.values()) + list(ops._DW_PENDING_SPLIT.values()))
+        pending = lambda: sum(len(v) for v in list(ops._DW_PENDING.values()))
         assert pending() > 20                                             # the tiny model's layers are all short-contraction
         red.gather()                                                      # flushes the deferred launches
         assert pending() == 0

@@ -103,7 +103,7 @@ def bmm_tuned(a, b):
                        lambda: _bmm(a, b))
 
 
-ops.bmm_tuned = bmm_tuned
+ops.bmm_tuned = ops.gemm.bmm_tuned = ops.conv.bmm_tuned = bmm_tuned
 _einsum = torch.einsum
 
 
