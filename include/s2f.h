@@ -292,11 +292,19 @@ int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* str
  *   y = Q_IFNode( BatchNorm_running( W @ X + conv_bias ) [+ residual] )   as ONE launch -- the GEMM above with bn_apply's and
  * the neuron's arithmetic in its epilogue (same per-element expressions: bit-identical to s2f_pgemm_nn_bf16 + s2f_bn_act_fwd in
  * eval mode).  u_out? = the fp32 pre-activation, y_bf16? = the spikes (bf16), v_in? / v_out? = carried membrane, stats? = firing
- * counters as in s2f_lif_fwd.  No backward (inference path). */
+ * counters as in s2f_lif_fwd.  N % 4 == 0, N >= 8; the tile follows the plain product's rule (round 4: the eight-wavefront
+ * register-staged tiles too).  No backward (inference path). */
 int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, const float* conv_bias, const float* running_mean,
                         const float* running_var, const float* gamma, const float* beta, float eps, const float* residual,
                         float* u_out, const float* v_in, void* y_bf16, float* v_out, uint64_t* stats, int batch, int M, int N,
                         int K, float vth, int D, void* stream);
+/* The same epilogue on the implicit 3x3 convolution (stride 1, padding 1; w_pack = the tap-major pack, s2f_pack_bf16x3 mode 1; X
+ * [batch][C][H][W] bf16 spikes): eval-mode conv3x3 -> BatchNorm [+ residual] [-> Q_IFNode] as one launch (MS_ConvBlock's two
+ * convolutions in inference, mmseg/models/backbones/sdtv2.py:183-219). */
+int s2f_conv3x3_bn_lif_fwd(const uint16_t* w_pack, const uint16_t* X, const float* conv_bias, const float* running_mean,
+                           const float* running_var, const float* gamma, const float* beta, float eps, const float* residual,
+                           float* u_out, const float* v_in, void* y_bf16, float* v_out, uint64_t* stats, int batch, int M, int C,
+                           int H, int W, float vth, int D, void* stream);
 int64_t s2f_pack_elems(int M, int K);
 int s2f_pack_bf16x3(const float* src, uint16_t* dst, int M, int K, int mode, int C, void* stream);
 int s2f_pack_bf16x3_multi(const int64_t* jobs, int njobs, int64_t total_workgroups, void* stream);

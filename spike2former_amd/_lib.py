@@ -62,6 +62,7 @@ SIGNATURES = {
     "s2f_spike_gemm_dw_grouped": (_i, [_p, _i, _i, _p]),
     "s2f_spike_conv3x3_dw_bf16": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "s2f_gemm_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 6 + [_i] * 4 + [_f, _i, _p]),
+    "s2f_conv3x3_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 6 + [_i] * 5 + [_f, _i, _p]),
     "s2f_pack_elems": (_i64, [_i, _i]),
     "s2f_pack_bf16x3_multi": (_i, [_p, _i, _i64, _p]),
     "s2f_pgemm_nn_bf16": (_i, [_p] * 4 + [_i] * 6 + [_p]),

@@ -146,8 +146,9 @@ class MS_ConvBlock(nn.Module):
         T, B, C, H, W = x.shape
         feat = self.Conv(x, residual=x, next_lif=self.spike1)            # x + SepConv(x)
         s = self.spike1.fire(feat)
-        _, s = bn_act(self.conv1(s.flatten(0, 1)), None, self.bn1, lif=self.spike2)
-        u, _ = bn_act(self.conv2(s), None, self.bn2, residual=feat.flatten(0, 1), next_lif=next_lif)   # feat + BN(conv2(.))
+        # (conv_bn_act: in eval mode conv3x3 + BatchNorm + neuron are one launch; in training conv.forward_nobias + bn_act)
+        _, s = conv_bn_act(self.conv1, s.flatten(0, 1), self.bn1, lif=self.spike2)
+        u, _ = conv_bn_act(self.conv2, s, self.bn2, residual=feat.flatten(0, 1), next_lif=next_lif)   # feat + BN(conv2(.))
         return u.reshape(T, B, C, H, W)
 
 

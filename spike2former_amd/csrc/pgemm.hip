@@ -234,6 +234,75 @@ __device__ __forceinline__ void epi_row_partials(const f32x16 (&acc)[MI][NJ], fl
   }
 }
 
+// (shared by pg_nn_kernel and pg_conv_kernel: per-element expressions of bn_lif.hip / lif.hip, contraction off)
+// The accumulator tile goes through LDS (the K loop's stages are free by then): in the 32 x 32 MFMA layout a lane holds 16 rows of
+// ONE column, so storing from the accumulators writes 2 bytes (bf16 spikes) per lane and instruction -- round 3's form, which made
+// the fused launch slower than GEMM + BatchNorm kernel (46 vs 21 + 17 us on [256 x 256] @ [8 x 256 x 1024]).  From the row-major LDS
+// tile each thread owns four consecutive columns of a row: 16-byte residual / pre-activation accesses and 8-byte spike stores, the
+// access pattern of bn_apply_kernel.
+template <int MI, int NJ, int WMW, int WNW>
+__device__ __forceinline__ void epi_bn_lif(const f32x16 (&acc)[MI][NJ], const BnLifEpi& ep, unsigned char* smem, int m0, int n0,
+                                           int M, int N, int b, int wm, int wn, int lane, int wave) {
+#pragma clang fp contract(off)
+  constexpr int NW = WMW * WNW, BM = 32 * MI * WMW, BN = 32 * NJ * WNW, T = 64 * NW;
+  float* tile = reinterpret_cast<float*>(smem);          // [BM][BN] fp32
+  __syncthreads();                                      // every wavefront has left the K loop
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[((wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + (wn * NJ + j) * 32 + (lane & 31)] = acc[i][j][r];
+  __syncthreads();
+  unsigned int csum = 0, cnz = 0;
+  const int64_t boff_ = (int64_t)b * M * N;
+  const int tid = wave * 64 + lane;
+  for (int idx = tid; idx < BM * (BN / 4); idx += T) {
+    const int row_l = idx / (BN / 4), c4 = idx - row_l * (BN / 4);
+    const int row = m0 + row_l, col = n0 + c4 * 4;
+    if (row >= M || col >= N) continue;                 // N % 4 == 0: a group of four is in range or not
+    const float pb = ep.conv_bias ? ep.conv_bias[row] : 0.f, pm = ep.mean[row], pr = 1.0f / sqrtf(ep.var[row] + ep.eps),
+                pg = ep.gamma[row], pe = ep.beta[row];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row_l * BN + c4 * 4);
+    const int64_t o = boff_ + (int64_t)row * N + col;
+    f32x4 rs = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
+    if (ep.residual) rs = *reinterpret_cast<const f32x4*>(ep.residual + o);
+    if (ep.y && ep.v_in) vi = *reinterpret_cast<const f32x4*>(ep.v_in + o);
+    float u[4], yy[4], vn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u[e] = ((a[e] + pb) - pm) * pr * pg + pe;
+      if (ep.residual) u[e] += rs[e];
+      if (ep.y) {
+        const float h = ep.v_in ? (vi[e] + u[e]) : u[e];
+        float sp;
+        bool inr;
+        s2f_lif_update(h, ep.Df, ep.inv_d, ep.vth, sp, yy[e], vn[e], inr);
+        csum += (unsigned int)sp;
+        cnz += ((unsigned int)sp != 0);
+      }
+    }
+    if (ep.u_out) *reinterpret_cast<f32x4*>(ep.u_out + o) = f32x4{u[0], u[1], u[2], u[3]};
+    if (ep.y) {
+      const uint2 w = s2f_spikes_to_bf16x4(yy[0], yy[1], yy[2], yy[3]);          // exact: a spike has <= 8 significant bits
+      *reinterpret_cast<u32x2*>(ep.y + o) = u32x2{w.x, w.y};
+      if (ep.v_out) *reinterpret_cast<f32x4*>(ep.v_out + o) = f32x4{vn[0], vn[1], vn[2], vn[3]};
+    }
+  }
+  if (ep.y && ep.stats) {
+    for (int o = 32; o > 0; o >>= 1) {
+      csum += __shfl_xor(csum, o, 64);
+      cnz += __shfl_xor(cnz, o, 64);
+    }
+    if (lane == 0) {
+      unsigned long long* slot = ep.stats + 2 * ((blockIdx.x * NW + wave) % S2F_STAT_SLOTS);
+      if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+      if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // NN:  Y[b] (M x N) = A (M x K, packed) @ X[b] (K x N, bf16 spikes, n contiguous) [+ bias].
 // Block = WMW x WNW wavefronts, wavefront tile (32 MI) x (32 NJ), K step 32, NST LDS stages.
@@ -380,57 +449,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
   // epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   mfma_fence(acc);
   if constexpr (EPI == 1) {
-#pragma clang fp contract(off)
-    unsigned int csum = 0, cnz = 0;
-    const int64_t boff_ = (int64_t)b * M * N;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      float pb[16], pm[16], pr[16], pg[16], pe[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {            // per-row parameters first (clamped addresses), one wait
-        const int row = min(m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
-        pb[r] = ep.conv_bias ? ep.conv_bias[row] : 0.f;
-        pm[r] = ep.mean[row];
-        pr[r] = 1.0f / sqrtf(ep.var[row] + ep.eps);
-        pg[r] = ep.gamma[row];
-        pe[r] = ep.beta[row];
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + (wn * NJ + j) * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < M && col < N) {
-            const int64_t o = boff_ + (int64_t)row * N + col;
-            float u = ((acc[i][j][r] + pb[r]) - pm[r]) * pr[r] * pg[r] + pe[r];
-            if (ep.residual) u += ep.residual[o];
-            if (ep.u_out) ep.u_out[o] = u;
-            if (ep.y) {
-              const float h = ep.v_in ? (ep.v_in[o] + u) : u;
-              float sp, yy, vn;
-              bool inr;
-              s2f_lif_update(h, ep.Df, ep.inv_d, ep.vth, sp, yy, vn, inr);
-              ep.y[o] = (unsigned short)(__float_as_uint(yy) >> 16);        // exact: a spike has <= 8 significant bits
-              if (ep.v_out) ep.v_out[o] = vn;
-              csum += (unsigned int)sp;
-              cnz += ((unsigned int)sp != 0);
-            }
-          }
-        }
-      }
-    }
-    if (ep.y && ep.stats) {
-      for (int o = 32; o > 0; o >>= 1) {
-        csum += __shfl_xor(csum, o, 64);
-        cnz += __shfl_xor(cnz, o, 64);
-      }
-      if (lane == 0) {
-        unsigned long long* slot = ep.stats + 2 * ((blockIdx.x * NW + wave) % S2F_STAT_SLOTS);
-        if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
-        if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
-      }
-    }
+    epi_bn_lif<MI, NJ, WMW, WNW>(acc, ep, smem, m0, n0, M, N, b, wm, wn, lane, wave);
     return;
   }
 #pragma unroll
@@ -884,11 +903,13 @@ __device__ __forceinline__ f32x4 convp_fix(f32x4 v, ConvPredB p) {
 
 // CONV = false: the plain product  Y[b] = A @ X[b]  (X [K][N] bf16, N % 4 == 0) with the same register-staged activation rows --
 // the row lengths an LDS-DMA cannot take (N % 8 != 0: the decoder's 100-token maps, whose rows start 8-byte aligned only).
-template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true, bool STATS = false>
+// EPI = 1: the eval-mode BatchNorm (+ residual) (+ neuron) epilogue of s2f_gemm_bn_lif_fwd / s2f_conv3x3_bn_lif_fwd (epi_bn_lif)
+// instead of the plain store.
+template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true, bool STATS = false, int EPI = 0>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned short* __restrict__ Ap, const void* __restrict__ Xv,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                                 int N, int K, int Kb, int n_tiles, int m_tiles, Conv3 geo,
-                                                                float* __restrict__ part = nullptr) {
+                                                                float* __restrict__ part = nullptr, BnLifEpi ep = BnLifEpi{}) {
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   static_assert(BN == 128, "the activation tile is 128 pixels wide");
   constexpr int A_BYTES = 3 * BM * 64, B_TERM = 32 * BN * 2, B_BYTES = BT * B_TERM, STAGE = A_BYTES + B_BYTES;
@@ -1059,6 +1080,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   }
 
   mfma_fence(acc);
+  if constexpr (EPI == 1) {
+    epi_bn_lif<MI, NJ, WMW, WNW>(acc, ep, smem, m0, n0, M, N, b, wm, wn, lane, wave);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1129,26 +1154,26 @@ static int pgemm_nn_impl(const uint16_t* a_pack, const uint16_t* X, const float*
       const int m_tiles = (M + 63) / 64;
       if (part)
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
-                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
       else
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
-                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
     } else if (wide) {
       const int m_tiles = (M + 127) / 128;
       if (part)
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
-                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
       else
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
-                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
     } else {
       const int m_tiles = (M + 63) / 64;
       if (part)
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
-                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
       else
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X, bias, Y,
-                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part);
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
     }
     return s2f_check_launch("s2f_pgemm_nn_bf16");
   }
@@ -1205,17 +1230,72 @@ extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, co
                                    uint64_t* stats, int batch, int M, int N, int K, float vth, int D, void* stream) {
   S2F_REQUIRE(a_pack && X && running_mean && running_var && gamma && beta, S2F_EINVAL, "s2f_gemm_bn_lif_fwd: null pointer");
   S2F_REQUIRE(u_out || y_bf16, S2F_EINVAL, "s2f_gemm_bn_lif_fwd: neither u_out nor y requested");
-  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && (N & 7) == 0 && K > 0, S2F_EINVAL,
-              "s2f_gemm_bn_lif_fwd: bad sizes (N=%d must be a positive multiple of 8)", N);
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && (N & 3) == 0 && K > 0, S2F_EINVAL,
+              "s2f_gemm_bn_lif_fwd: bad sizes (N=%d must be a multiple of 4, >= 8)", N);
   S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_gemm_bn_lif_fwd: bf16 spikes need D a power of two <= 128");
   S2F_REQUIRE(s2f_aligned16(a_pack) && s2f_aligned16(X), S2F_EALIGN, "s2f_gemm_bn_lif_fwd: operands must be 16-byte aligned");
-  const int Kb = (K + PK - 1) / PK, n_tiles = (N + 127) / 128, m_tiles = (M + 63) / 64;
+  const int Kb = (K + PK - 1) / PK, n_tiles = (N + 127) / 128;
   BnLifEpi ep{conv_bias, running_mean, running_var, gamma, beta, residual, u_out, v_in, v_out,
               reinterpret_cast<unsigned short*>(y_bf16), reinterpret_cast<unsigned long long*>(stats), eps, vth, (float)D,
               1.0f / (float)D};
-  S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, (hipStream_t)stream,
-             a_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr);
+  hipStream_t s = (hipStream_t)stream;
+  // the tile rule of the plain product (pick_cfg_nn): round 3 ran every fused launch on the four-wavefront DMA tile, 36 us on average
+  // in the C2 inference step where the plain products of the same shapes take 14-21 us
+  const int c = pick_cfg_nn(M, N, K, batch, 0);
+  if (c == 4) {
+    const int m_tiles = (M + 63) / 64;
+    S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
+               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr);
+  } else if (c == 8) {
+    const int m_tiles = (M + 63) / 64;
+    S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+  } else if (c == 7) {
+    const int m_tiles = (M + 127) / 128;
+    S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+  } else {
+    const int m_tiles = (M + 63) / 64;
+    S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
+               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+  }
   return s2f_check_launch("s2f_gemm_bn_lif_fwd");
+}
+
+// The same epilogue on the implicit 3x3 convolution (stride 1, padding 1): eval-mode conv3x3 -> BatchNorm [+ residual] [-> neuron]
+// as one launch (MS_ConvBlock's two convolutions in inference, sdtv2.py:183-219).
+extern "C" int s2f_conv3x3_bn_lif_fwd(const uint16_t* w_pack, const uint16_t* X, const float* conv_bias, const float* running_mean,
+                                      const float* running_var, const float* gamma, const float* beta, float eps,
+                                      const float* residual, float* u_out, const float* v_in, void* y_bf16, float* v_out,
+                                      uint64_t* stats, int batch, int M, int C, int H, int W, float vth, int D, void* stream) {
+  S2F_REQUIRE(w_pack && X && running_mean && running_var && gamma && beta, S2F_EINVAL, "s2f_conv3x3_bn_lif_fwd: null pointer");
+  S2F_REQUIRE(u_out || y_bf16, S2F_EINVAL, "s2f_conv3x3_bn_lif_fwd: neither u_out nor y requested");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & 3) == 0, S2F_EINVAL,
+              "s2f_conv3x3_bn_lif_fwd: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_conv3x3_bn_lif_fwd: bf16 spikes need D a power of two <= 128");
+  S2F_REQUIRE(s2f_aligned16(w_pack) && (reinterpret_cast<uintptr_t>(X) & 7u) == 0, S2F_EALIGN,
+              "s2f_conv3x3_bn_lif_fwd: pack 16-byte, activation 8-byte aligned");
+  const int N = H * W, K = 9 * C, Kb = K / PK, n_tiles = (N + 127) / 128;
+  BnLifEpi ep{conv_bias, running_mean, running_var, gamma, beta, residual, u_out, v_in, v_out,
+              reinterpret_cast<unsigned short*>(y_bf16), reinterpret_cast<unsigned long long*>(stats), eps, vth, (float)D,
+              1.0f / (float)D};
+  hipStream_t s = (hipStream_t)stream;
+  const Conv3 geo{H, W, C};
+#define S2F_PGCE(MI, NJ, WMW, WNW)                                                                                        \
+  do {                                                                                                                   \
+    const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                       \
+    S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, false, 1>), dim3(n_tiles * m_tiles, batch),         \
+               dim3(64 * WMW * WNW), 0, s, w_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, \
+               geo, (float*)nullptr, ep);                                                                                \
+  } while (0)
+  if (M <= 32)
+    S2F_PGCE(1, 1, 1, 4);
+  else if (M <= 64)
+    S2F_PGCE(1, 2, 2, 2);
+  else
+    S2F_PGCE(1, 2, 4, 2);
+#undef S2F_PGCE
+  return s2f_check_launch("s2f_conv3x3_bn_lif_fwd");
 }
 
 extern "C" int s2f_pgemm_dx_split(const uint16_t* w_pack, const uint16_t* G_split, int64_t plane_stride, float* DX, int batch,
@@ -1272,13 +1352,13 @@ static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, b
     const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                       \
     if (x_fp32)                                                                                                          \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 3>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
-                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part);                                           \
+                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});                                           \
     else if (part)                                                                                                       \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, true>), dim3(n_tiles * m_tiles, batch),           \
-                 dim3(64 * WMW * WNW), 0, s, w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part);               \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});               \
     else                                                                                                                 \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
-                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part);                                           \
+                 w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});                                           \
   } while (0)
   switch (c) {
     case 1: S2F_PGC(2, 2, 2, 2); break;          // 128 x 128, wavefront tiles 64 x 64

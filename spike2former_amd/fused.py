@@ -65,11 +65,45 @@ def bn_act(z, conv_bias, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     return (u, y, border) if want_border else (u, y)
 
 
+class _EvalBN:
+    """what bn_act reads of an eval-mode BatchNorm"""
+    training, affine, momentum, num_batches_tracked = False, True, 0.0, None
+
+
+def _composed_eval_pair(bn1, bn2):
+    ts = (bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in ts) + (bn1.eps, bn2.eps)
+    hit = getattr(bn2, "_s2f_eval_pair", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        r2g2 = bn2.weight / torch.sqrt(bn2.running_var + bn2.eps)
+        out = _EvalBN()
+        out.weight = (bn1.weight * r2g2).contiguous()
+        out.bias = ((bn1.bias - bn2.running_mean) * r2g2 + bn2.bias).contiguous()
+        out.running_mean, out.running_var, out.eps = bn1.running_mean, bn1.running_var, bn1.eps
+    try:
+        bn2._s2f_eval_pair = (key, out)
+    except AttributeError:          # (an object without a __dict__)
+        pass
+    return out
+
+
 def bn_bn_act(z, bn1, bn2, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
     """bn2(bn1(z)) [+ residual] [-> neuron]: the BatchNorm pair that closes a RepConv chain (Sequential(RepConv(.., BN), BN),
     sdtv2.py:280-296).  In training mode on the single-pass shapes (the 32x32-stage maps, where these chains live) the pair is ONE
     kernel forward and one backward (ops.bn2_act: the second BatchNorm's batch statistics follow from the first's); otherwise two
     bn_act calls.  Returns (u, y) as bn_act."""
+    # (real modules only: the composed pair is cached on them by parameter version; the batched q / k / v chain hands in transient
+    # concatenations of its twins' parameters, whose version counters say nothing)
+    eval_both = (isinstance(bn1, torch.nn.Module) and isinstance(bn2, torch.nn.Module) and not bn1.training and not bn2.training
+                 and bn1.running_mean is not None and bn2.running_mean is not None and bn1.weight is not None
+                 and bn2.weight is not None and not torch.is_grad_enabled())
+    if eval_both:
+        # inference: two affine maps are one.  BN2(BN1(z)) = (z - m1) r1 [g1 r2 g2] + [(b1 - m2) r2 g2 + b2]: BN1's running statistics
+        # with a composed (gamma, beta) -- one BatchNorm launch (the fold the reference ships for inference,
+        # clock_driven/functional.py:574-692).  The composed pair is cached per module pair and parameter version.
+        return bn_act(z, None, _composed_eval_pair(bn1, bn2), residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
     training = (bn1.training or bn1.running_mean is None) and (bn2.training or bn2.running_mean is None)
     momentum_ok = bn1.momentum is not None and bn2.momentum is not None
     if not (training and momentum_ok and ops.bn2_act_ok(z) and bn1.weight is not None and bn2.weight is not None
@@ -118,8 +152,12 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         want_pre = lif is None
     pure_conv = (conv.kernel_size in ((1, 1), (1,)) and conv.groups == 1 and tuple(conv.stride) in ((1, 1), (1,))
                  and tuple(conv.padding) in ((0, 0), (0,)))
+    # 3x3 / stride 1 / padding 1 without a bias on a map the implicit kernel takes (MS_ConvBlock's convolutions)
+    conv3 = (conv.kernel_size == (3, 3) and conv.groups == 1 and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+             and tuple(conv.dilation) == (1, 1) and conv.bias is None and x.dim() == 4 and conv.in_channels % 32 == 0
+             and x.shape[-1] % 4 == 0 and (x.shape[-1] & (x.shape[-1] - 1)) == 0 and ops.cfg.PGEMM_CONV)
     eval_bn = (not bn.training) and bn.running_mean is not None and bn.affine
-    if not (pure_conv and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
+    if not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
             and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
         z = conv.forward_nobias(x)
         return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
@@ -129,13 +167,16 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         v_in = fire.v.detach()
     if fire is not None and fire.stats is not None:
         fire.stats_elems += shape_in[0] * M * L
-    u, y, v_out = ops.gemm_bn_lif_eval(
-        x.reshape(shape_in[0], shape_in[1], L), conv.weight.view(M, -1), conv.bias, bn.running_mean, bn.running_var, bn.weight,
-        bn.bias, bn.eps, residual=None if residual is None else residual.reshape(shape_in[0], M, L),
-        want_pre=bool(want_pre or (next_lif is not None and lif is None) or (fire is not None and bool(fire._forward_hooks))),
-        lif=fire is not None, v_in=v_in,
-        keep_v=(fire is not None and fire.keep_membrane), D=(fire.D if fire is not None else 8),
-        vth=(fire.v_threshold if fire is not None else 1.0), stats=(fire.stats if fire is not None else None))
+    kw = dict(want_pre=bool(want_pre or (next_lif is not None and lif is None) or (fire is not None and bool(fire._forward_hooks))),
+              lif=fire is not None, v_in=v_in, keep_v=(fire is not None and fire.keep_membrane), D=(fire.D if fire is not None else 8),
+              vth=(fire.v_threshold if fire is not None else 1.0), stats=(fire.stats if fire is not None else None))
+    if conv3:
+        u, y, v_out = ops.conv3x3_bn_lif_eval(x, conv.weight, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps,
+                                              residual=None if residual is None else residual.reshape(shape_in[0], M, *shape_in[2:]), **kw)
+    else:
+        u, y, v_out = ops.gemm_bn_lif_eval(
+            x.reshape(shape_in[0], shape_in[1], L), conv.weight.view(M, -1), conv.bias, bn.running_mean, bn.running_var, bn.weight,
+            bn.bias, bn.eps, residual=None if residual is None else residual.reshape(shape_in[0], M, L), **kw)
     out_shape = (shape_in[0], M) + tuple(shape_in[2:])
     if u is not None:
         u = u.view(out_shape)

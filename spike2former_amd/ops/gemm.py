@@ -485,9 +485,10 @@ def dx_gemm(w2d, gy):
 
 
 def gemm_bn_lif_eval_ok(x, N):
-    """The eval-mode fusion takes bf16 spikes with N % 8 == 0, N >= cfg.PGEMM_MIN_N, and builds no autograd graph."""
-    return (cfg.PGEMM and isinstance(x, Spikes) and x.data.dtype == torch.bfloat16 and x.data.is_cuda and N % 8 == 0
-            and N >= cfg.PGEMM_MIN_N and not (torch.is_grad_enabled() and x.requires_grad))
+    """The eval-mode fusion takes bf16 spikes with N % 4 == 0, N >= 8 (the decoder's 100-token maps too), and builds no autograd
+    graph."""
+    return (cfg.PGEMM and isinstance(x, Spikes) and x.data.dtype == torch.bfloat16 and x.data.is_cuda and N % 4 == 0
+            and N >= 8 and x.data.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and x.requires_grad))
 
 
 def gemm_bn_lif_eval(x, w2d, conv_bias, running_mean, running_var, gamma, beta, eps, residual=None, want_pre=False, lif=False,
@@ -511,6 +512,30 @@ def gemm_bn_lif_eval(x, w2d, conv_bias, running_mean, running_var, gamma, beta, 
         check(lib.s2f_gemm_bn_lif_fwd(_ptr(pack_weight(w2d)), _ptr(data), _ptr(conv_bias), _ptr(running_mean), _ptr(running_var),
                                       _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y), _ptr(v_out),
                                       _ptr(stats), B, M, N, K, float(vth), int(D), _stream()), "s2f_gemm_bn_lif_fwd")
+    return u, (Spikes(y, _new_tok(y)) if lif else None), v_out
+
+
+def conv3x3_bn_lif_eval(x, weight, running_mean, running_var, gamma, beta, eps, residual=None, want_pre=False, lif=False, v_in=None,
+                        keep_v=False, D=8, vth=1.0, stats=None):
+    """Eval-mode  conv3x3 (stride 1, padding 1, no bias) -> BatchNorm(running statistics) [+ residual] [-> Q_IFNode]  as ONE launch
+    (s2f_conv3x3_bn_lif_fwd; row f4).  x: bf16 Spikes [B, C, H, W]; weight [M, C, 3, 3].  -> (u, spikes, v_out), [B, M, H, W]."""
+    data = x.data.contiguous()
+    B, C, H, W = data.shape
+    M = weight.shape[0]
+    dev = data.device
+    with torch.no_grad():
+        u = torch.empty(B, M, H, W, dtype=torch.float32, device=dev) if want_pre else None
+        y = torch.empty(B, M, H, W, dtype=torch.bfloat16, device=dev) if lif else None
+        v_out = torch.empty(B, M, H, W, dtype=torch.float32, device=dev) if (lif and keep_v) else None
+        if residual is not None:
+            residual = residual.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        n = B * H * W
+        _time_next("gemm_bn_lif", 4 * n * (C + M), 2 * n * M * C * 9, moved=n * (2 * C + (4 if want_pre else 0) + (2 if lif else 0)))
+        check(lib.s2f_conv3x3_bn_lif_fwd(_ptr(pack_weight_conv3(weight)), _ptr(data), 0, _ptr(running_mean), _ptr(running_var),
+                                         _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), _ptr(u), _ptr(v_in), _ptr(y), _ptr(v_out),
+                                         _ptr(stats), B, M, C, H, W, float(vth), int(D), _stream()), "s2f_conv3x3_bn_lif_fwd")
     return u, (Spikes(y, _new_tok(y)) if lif else None), v_out
 
 
@@ -814,6 +839,19 @@ class _MaskEinsumFolded(torch.autograd.Function):
             if bias is not None and ctx.needs_input_grad[4]:
                 gb = (e * rs.view(1, B, Q, 1)).sum((0, 1, 2)) * scale
         return (ge,) + _grad_pair(True, gs) + (gW, gb, None, None, None, None)
+
+
+def class_mask_product(cls_score, mask_probs):
+    """einsum('bqc,bqhw->bchw') of the inference post-processing (mmseg decode_heads/maskformer_head.py:176-178): per image the
+    [K x Q] x [Q x HW] product of two general fp32 operands on the transposed packed-operand kernel (6 bf16 passes = fp32 accuracy;
+    the class scores packed on the fly) instead of the vendor GEMM the einsum lowers to.  No autograd (inference glue)."""
+    B, Q, K = cls_score.shape
+    h, w = mask_probs.shape[-2:]
+    if not (cfg.LINEAR_TM and cls_score.is_cuda and (h * w) % 4 == 0 and cls_score.dtype == torch.float32
+            and not (torch.is_grad_enabled() and (cls_score.requires_grad or mask_probs.requires_grad))):
+        fallback("class_mask_product", f"hw={h * w}")
+        return torch.einsum("bqc,bqhw->bchw", cls_score, mask_probs)
+    return torch.stack([_mtm_tm(cls_score[b], mask_probs[b].reshape(Q, h * w)).view(K, h, w) for b in range(B)])
 
 
 def mask_einsum_folded(e, spikes, W, bias, scale, T, B, e_exact=False):

@@ -93,7 +93,9 @@ def test_model_predict_is_head_forward_plus_the_pinned_postprocessing():
         want = model.postprocess_result(logits, [SegDataSample(metainfo=dict(m)) for m in metas])
     assert len(res) == 2 and res[0].seg_logits.data.shape == (w["K"], 50, 70) and res[0].pred_sem_seg.data.shape == (1, 50, 70)
     for a, b in zip(res, want):
-        assert torch.equal(a.seg_logits.data, b.seg_logits.data) and torch.equal(a.pred_sem_seg.data, b.pred_sem_seg.data)
+        # (the class x mask product runs on this package's 6-pass kernel, the hand composition on the vendor GEMM: fp32 round-off)
+        assert (a.seg_logits.data - b.seg_logits.data).abs().max().item() <= 1e-5 * b.seg_logits.data.abs().max().item()
+        assert (a.pred_sem_seg.data != b.pred_sem_seg.data).float().mean().item() <= 1e-3
 
 
 @pytest.mark.gpu

@@ -1363,3 +1363,31 @@ def test_batchnorm_pair_as_one_kernel_is_two_batchnorms(ops, spike_mode, N, C, L
     s2 = a2.weight.grad.abs().max().item()
     assert close(c1.weight.grad, a1.weight.grad, tol, s2) and close(c1.bias.grad, a1.bias.grad, tol, s2)
     assert float(c1.bias.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,M,C,H,W,res,lif", [(2, 64, 32, 16, 16, False, True), (1, 128, 64, 32, 32, True, True), (2, 32, 128, 64, 64, True, False),
+                                               (8, 512, 128, 64, 64, False, True), (1, 100, 32, 8, 32, True, True)])
+def test_eval_conv3x3_bn_lif_fusion_is_the_unfused_path(ops, spike_mode, N, M, C, H, W, res, lif):
+    """s2f_conv3x3_bn_lif_fwd (eval-mode conv3x3 -> BatchNorm -> [+ residual] -> neuron in the implicit convolution's epilogue) against
+    s2f_pgemm_conv3x3_bf16 + s2f_bn_act_fwd in eval mode: same accumulator, same per-element expressions -> identical spikes,
+    pre-activation and firing counters."""
+    spike_mode(True)
+    g = torch.Generator().manual_seed(N + M + C + H)
+    w = (torch.randn(M, C, 3, 3, generator=g) * (9 * C) ** -0.5).cuda()
+    x = ops.Spikes(_spikes_bf16((N, C, H, W), g), None)
+    x.tok = ops._new_tok(x.data)
+    gamma, beta = (torch.rand(M, generator=g) + 0.5).cuda(), (torch.randn(M, generator=g) * 0.3 + 0.5).cuda()
+    rm, rv = (torch.randn(M, generator=g) * 0.1).cuda(), (torch.rand(M, generator=g) + 0.5).cuda()
+    r = torch.randn(N, M, H, W, generator=g).cuda() if res else None
+    st1, st0 = ops.new_stats("cuda"), ops.new_stats("cuda")
+    with torch.no_grad():
+        u1, y1, _ = ops.conv3x3_bn_lif_eval(x, w, rm, rv, gamma, beta, 1e-5, residual=r, want_pre=True, lif=lif, stats=st1 if lif else None)
+        from spike2former_amd._lib import check, lib
+        z = torch.empty(N, M, H, W, device="cuda")          # the implicit kernel itself (ops.conv_dense takes im2col below 32 x 32)
+        check(lib.s2f_pgemm_conv3x3_bf16(ops.pack_weight_conv3(w).data_ptr(), x.data.data_ptr(), None, z.data_ptr(), N, M, C, H, W, 0,
+                                         torch.cuda.current_stream().cuda_stream), "conv")
+        u0, y0, _ = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, residual=r, lif=lif, want_pre=True,
+                               stats=st0 if lif else None)
+    assert torch.equal(u1, u0)
+    if lif:
+        assert torch.equal(y1.data, y0.data) and ops.read_stats(st1).tolist() == ops.read_stats(st0).tolist()

@@ -41,7 +41,9 @@ def main():
     replays = int(sys.argv[2])
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
     # the last `replays` occurrences of the step are graph replays; one step has 6 dcn backward launches at C2 (pd layers)
-    marks = [i for i, r in enumerate(rows) if 'dcn_bwd' in r[0]]
+    import os
+    marker = os.environ.get("S2F_STEP_MARKER", "dcn_bwd")          # a kernel launched exactly 6 times per step (predict: dcn_fwd)
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
     per_step = len([1 for r in rows if 'dcn_fwd' in r[0]]) // max(len(marks) // 6, 1) or 6
     first = marks[-6 * replays]
     # step boundary: walk back from the first dcn_bwd of that replay to the preceding step's end is fuzzy; use whole replays

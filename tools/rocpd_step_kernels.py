@@ -18,7 +18,9 @@ def short(name):
 def table(path, replays):
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if 'dcn_bwd' in r[0]]
+    import os
+    marker = os.environ.get("S2F_STEP_MARKER", "dcn_bwd")          # a kernel launched exactly 6 times per step (predict: dcn_fwd)
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
     starts = [marks[-6 * k] for k in range(replays, 0, -1)]
     sel = rows[starts[0]:starts[-1]]
     n = replays - 1
