@@ -376,7 +376,7 @@ def main():
             # separate runs, gfx950 corrections applied there); null when no such profile exists for a kernel
             traffic, traffic_src = {}, None
             try:
-                for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest profile wins
+                for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json", "r04_pmc_traffic.json"):          # the newest profile wins
                     path = os.path.join(ROOT, "profiles", name)
                     if os.path.exists(path):
                         with open(path) as f:

@@ -4,20 +4,36 @@ runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE in KiB x2
     python tools/pmc_traffic.py <fetch.db> <write.db> > profiles/rNN_pmc_traffic.json"""
 import collections, json, sqlite3, sys
 
+def _targs(n):
+    return [a.strip() for a in n.split("<", 1)[1].split(">")[0].split(",")] if "<" in n else []
+
+
+def _bn_bwd(n, with_spike_grad):
+    """the BatchNorm backward kernels whose template arguments say whether a spike gradient (g_y) comes in: <GU, GY, GV, ..>"""
+    if not any(k in n for k in ("bn_bwd_apply_rows_kernel", "bn_bwd_reduce_rows_kernel", "bn_fused_bwd_kernel", "bn_small_bwd_kernel")):
+        return False
+    a = _targs(n)
+    return len(a) >= 2 and (a[1] == "true") == with_spike_grad
+
+
 FAMILIES = {          # bench.py roofline key -> predicate on the kernel name
-    "bn_lif_fwd": lambda n: "bn_apply_kernel<true" in n or "bn_apply_rows_kernel<true" in n or "bn_fused_fwd_kernel<true" in n,
-    "bn_fwd": lambda n: "bn_apply_kernel<false" in n or "bn_apply_rows_kernel<false" in n or "bn_fused_fwd_kernel<false" in n,
+    "bn_lif_fwd": lambda n: any(k in n for k in ("bn_apply_kernel<true", "bn_apply_rows_kernel<true", "bn_fused_fwd_kernel<true",
+                                                 "bn_small_fwd_kernel<true")),
+    "bn_fwd": lambda n: any(k in n for k in ("bn_apply_kernel<false", "bn_apply_rows_kernel<false", "bn_fused_fwd_kernel<false",
+                                             "bn_small_fwd_kernel<false")),
+    "bn_lif_bwd": lambda n: _bn_bwd(n, True),
+    "bn_bwd": lambda n: _bn_bwd(n, False),
     "bn_lif_bwd+bn_bwd": lambda n: ("bn_bwd_apply_kernel" in n or "bn_bwd_reduce_kernel" in n or "bn_bwd_apply_rows_kernel" in n
-                                    or "bn_bwd_reduce_rows_kernel" in n or "bn_fused_bwd_kernel" in n),
-    "bn_stats": lambda n: "bn_stats_kernel" in n,
+                                    or "bn_bwd_reduce_rows_kernel" in n or "bn_fused_bwd_kernel" in n or "bn_small_bwd_kernel" in n),
+    "bn_stats": lambda n: "bn_stats_kernel" in n or "bn_partials_finalize_kernel" in n,
     "lif_fwd": lambda n: "lif_fwd_kernel" in n and "sdsa" not in n,
     "lif_bwd": lambda n: "lif_bwd_kernel" in n,
     "spike_gemm_fwd": lambda n: ("spike_gemm_kernel" in n or "sgemm_bf16_kernel" in n or "pg_nn_kernel" in n
-                                 or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "1")),
-    "spike_gemm_fwd_pgemm": lambda n: "pg_nn_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "1"),
-    "dx_gemm": lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "3"),
+                                 or ("pg_conv_kernel" in n and _targs(n)[4] == "1")),
+    "spike_gemm_fwd_pgemm": lambda n: "pg_nn_kernel" in n or ("pg_conv_kernel" in n and _targs(n)[4] == "1"),
+    "dx_gemm": lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and _targs(n)[4] == "3"),
     "spike_gemm_dw": lambda n: "spike_gemm_dw_kernel" in n or "sgemm_dw" in n or "gemm_dw_general_grouped" in n,
-    "sdsa_lif_fwd": lambda n: "apply_kernel<" in n and ", true>" in n,
+    "sdsa_lif_fwd": lambda n: "apply_kernel<" in n and ", true>" in n and "bn_" not in n,
 }
 
 
