@@ -312,6 +312,13 @@ int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bi
                       int terms, int cfg, void* stream);
 int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
                      int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream);
+/* Up to four independent products of s2f_pgemm_dx_f32's plain-store form in ONE launch (blockIdx.z = group): w_packs is a HOST
+ * array of `groups` device pointers (copied into the kernel arguments); group g reads G + g * g_group_stride and writes DX + g *
+ * dx_group_stride (and bn_partials? + g * partials_group_stride: the _stats form).  The channel groups of a grouped 1x1
+ * convolution -- the second 1x1 of the stacked q | k | v projection chain (sdtv2.py:304-306), forward and input gradient. */
+int s2f_pgemm_dx_f32_grouped(const uint16_t* const* w_packs, int groups, const float* G, int64_t g_batch_stride,
+                             int64_t g_group_stride, float* DX, int64_t dx_batch_stride, int64_t dx_group_stride, float* bn_partials,
+                             int64_t partials_group_stride, int batch, int Mo, int Ki, int N, void* stream);
 /* Implicit 3x3 convolution (stride 1, padding 1) on the same pipeline: Y[b] (M x H W) = A (M x 9 C, the TAP-MAJOR pack of the
  * weight: s2f_pack_bf16x3 mode 1) @ im2col(X[b]), the column matrix never formed.  _bf16: X [batch][C][H][W] bf16 spikes, 3 passes
  * (forward; replaces s2f_spike_conv3x3_fwd_bf16, bit-identical).  _f32: X fp32, split in the kernel, 6 passes -- the INPUT

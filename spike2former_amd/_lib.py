@@ -75,6 +75,7 @@ SIGNATURES = {
     "s2f_bn_partials_count": (_i64, [_i, _i]),
     "s2f_pgemm_nn_bf16_stats": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "s2f_pgemm_conv3x3_bf16_stats": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "s2f_pgemm_dx_f32_grouped": (_i, [_p, _i, _p, _i64, _i64, _p, _i64, _i64, _p, _i64] + [_i] * 4 + [_p]),
     "s2f_pgemm_dx_f32_stats": (_i, [_p, _p, _i64, _p, _i64, _p] + [_i] * 4 + [_p]),
     "s2f_bn_partials_finalize": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "s2f_bn_act_bwd_split": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),

@@ -500,12 +500,28 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 // the same shape, 880 vs 450 us on [256 <- 256] x 8 x 65536 (72 KiB of LDS and 512 threads per workgroup halve the occupancy).)
 // EPI: 0 = store, 1 = DX = acc + beta * DX, 2 = atomic add into a zeroed DX (gridDim.z workgroups share the contraction: the
 // decoder's 100-token products with a 2 048-long contraction have 16 output tiles).
-template <int MI, int NJ, int WMW, int WNW, int EPI, int KS = 1, bool STATS = false>
+// GROUPED (EPI 0): blockIdx.z selects one of up to four independent products of the same shape -- the channel groups of a grouped
+// 1x1 convolution (the second 1x1 of the stacked q | k | v chain, sdtv2.py:304-306): its own packed weight, its own channel range of
+// G / DX (and of the BatchNorm partials).  Three 256-workgroup launches become one of 768: three workgroups per CU instead of one.
+struct TnGroups {
+  const unsigned short* wp[4];
+  int64_t g_stride, dx_stride, part_stride;          // element offsets between consecutive groups
+};
+
+template <int MI, int NJ, int WMW, int WNW, int EPI, int KS = 1, bool STATS = false, bool GROUPED = false>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
                                                                   int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
                                                                   int64_t g_batch_stride, int64_t dx_batch_stride,
-                                                                  float* __restrict__ part = nullptr) {
+                                                                  float* __restrict__ part = nullptr, TnGroups grp = TnGroups{}) {
+  if constexpr (GROUPED) {
+    static_assert(EPI == 0, "grouped form: plain store only");
+    const int g = blockIdx.z;
+    Wp = grp.wp[g];
+    G += g * grp.g_stride;
+    DX += g * grp.dx_stride;
+    if (STATS) part += g * grp.part_stride;
+  }
   constexpr bool BETA = EPI == 1;
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
   constexpr int KC = 16 * KS;                                      // KS 16-row slices per step (one barrier per step)
@@ -1442,16 +1458,16 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     const dim3 grid(n_tiles * m_tiles, batch, zsplit);                                                                 \
     if (zsplit > 1)                                                                                                    \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 2>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,  \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr);          \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, TnGroups{});          \
     else if (beta != 0.f)                                                                                              \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 1>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr);          \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, TnGroups{});          \
     else if (part)                                                                                                     \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 1, true>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, \
-                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part);         \
+                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, TnGroups{});         \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part);                \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, TnGroups{});                \
   } while (0)
   switch (c) {
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
@@ -1466,11 +1482,11 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     if (part)                                                                                                          \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2, true>), dim3(n_tiles * m_tiles, batch, 1),        \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
-                 dx_batch_stride, part);                                                                       \
+                 dx_batch_stride, part, TnGroups{});                                                                       \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),              \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
-                 dx_batch_stride, part);                                                                       \
+                 dx_batch_stride, part, TnGroups{});                                                                       \
   } while (0)
     case 7: S2F_PGD2(1, 1, 2, 4); break;         // cfg 4 with 32-row steps (half the barriers per MFMA)
     case 8: S2F_PGD2(1, 2, 2, 2); break;         // cfg 2 with 32-row steps
@@ -1492,4 +1508,47 @@ extern "C" int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, in
                                       void* stream) {
   S2F_REQUIRE(bn_partials, S2F_EINVAL, "s2f_pgemm_dx_f32_stats: null partials");
   return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, 0.f, 0, bn_partials, stream);
+}
+
+extern "C" int s2f_pgemm_dx_f32_grouped(const uint16_t* const* w_packs, int groups, const float* G, int64_t g_batch_stride,
+                                        int64_t g_group_stride, float* DX, int64_t dx_batch_stride, int64_t dx_group_stride,
+                                        float* bn_partials, int64_t partials_group_stride, int batch, int Mo, int Ki, int N,
+                                        void* stream) {
+  S2F_REQUIRE(w_packs && G && DX && groups >= 1 && groups <= 4, S2F_EINVAL, "s2f_pgemm_dx_f32_grouped: null pointer / 1..4 groups");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && Mo > 0 && Ki > 0 && N >= 4 && (N & 3) == 0, S2F_EINVAL,
+              "s2f_pgemm_dx_f32_grouped: bad sizes (N=%d must be a positive multiple of 4)", N);
+  S2F_REQUIRE((g_batch_stride & 3) == 0 && (dx_batch_stride & 3) == 0 && (g_group_stride & 3) == 0 && (dx_group_stride & 3) == 0 &&
+                  s2f_aligned16(G) && s2f_aligned16(DX) && (reinterpret_cast<uintptr_t>(bn_partials) & 7u) == 0,
+              S2F_EALIGN, "s2f_pgemm_dx_f32_grouped: strides / pointers must keep 16-byte alignment");
+  TnGroups grp{};
+  for (int g = 0; g < groups; ++g) {
+    S2F_REQUIRE(w_packs[g] && s2f_aligned16(w_packs[g]), S2F_EINVAL, "s2f_pgemm_dx_f32_grouped: null / unaligned pack %d", g);
+    grp.wp[g] = w_packs[g];
+  }
+  grp.g_stride = g_group_stride;
+  grp.dx_stride = dx_group_stride;
+  grp.part_stride = partials_group_stride;
+  hipStream_t s = (hipStream_t)stream;
+  const int KbW = (Ki + PK - 1) / PK, n_tiles = (N + 127) / 128;
+  // the tile rule of the single product (s2f_pgemm_dx_f32), per group
+  const bool wide = Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192;
+#define S2F_PGG(MI, NJ, WMW, WNW, KSV)                                                                                   \
+  do {                                                                                                                  \
+    const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                     \
+    const dim3 grid(n_tiles * m_tiles, batch, groups);                                                                  \
+    if (bn_partials)                                                                                                    \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, KSV, true, true>), grid, dim3(64 * WMW * WNW), 0, s,  \
+                 grp.wp[0], G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, 0.f, g_batch_stride, dx_batch_stride, bn_partials, grp); \
+    else                                                                                                                \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, KSV, false, true>), grid, dim3(64 * WMW * WNW), 0, s, \
+                 grp.wp[0], G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, 0.f, g_batch_stride, dx_batch_stride, bn_partials, grp); \
+  } while (0)
+  if (Ki <= 32)
+    S2F_PGG(1, 1, 1, 4, 1);
+  else if (wide)
+    S2F_PGG(1, 2, 4, 2, 1);
+  else
+    S2F_PGG(1, 1, 2, 4, 2);
+#undef S2F_PGG
+  return s2f_check_launch("s2f_pgemm_dx_f32_grouped");
 }

@@ -81,6 +81,14 @@ class _DenseGemm(torch.autograd.Function):
             part = torch.empty(G * M, P, 2, dtype=torch.float32, device=x.device) if P else x.new_empty(0)
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)
+            if 1 < G <= 4 and cfg.DENSE_GROUPED:
+                # the G products as ONE launch (blockIdx.z = group): three workgroups per CU instead of one on the 32x32-stage maps
+                import ctypes
+                packs = (ctypes.c_void_p * G)(*[pack_weight(w, transposed=True).data_ptr() for w in ws])
+                _time_next("dx_gemm", 4 * B * L * G * (K + M), 2 * B * G * M * L * K)
+                check(lib.s2f_pgemm_dx_f32_grouped(packs, G, _ptr(x), G * K * L, K * L, _ptr(y), G * M * L, M * L, _ptr(part) if P else 0,
+                                                   2 * M * P, B, K, M, L, _stream()), "s2f_pgemm_dx_f32_grouped")
+                return y, part
             for g, w in enumerate(ws):
                 _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)
                 if P:
@@ -109,7 +117,14 @@ class _DenseGemm(torch.autograd.Function):
         gy = gy.contiguous()
         gx, gws = None, [None] * G
         if ctx.fast:
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and 1 < G <= 4 and cfg.DENSE_GROUPED:
+                import ctypes
+                gx = torch.empty(B, G * K, L, dtype=torch.float32, device=gy.device)
+                packs = (ctypes.c_void_p * G)(*[pack_weight(w).data_ptr() for w in ws])
+                _time_next("dx_gemm", 4 * B * L * G * (K + M), 2 * B * G * M * L * K)
+                check(lib.s2f_pgemm_dx_f32_grouped(packs, G, _ptr(gy), G * M * L, M * L, _ptr(gx), G * K * L, K * L, 0, 0, B, M, K, L,
+                                                   _stream()), "s2f_pgemm_dx_f32_grouped")
+            elif ctx.needs_input_grad[1]:
                 gx = torch.empty(B, G * K, L, dtype=torch.float32, device=gy.device)
                 for g, w in enumerate(ws):
                     _time_next("dx_gemm", 4 * B * L * (K + M), 2 * B * M * L * K)

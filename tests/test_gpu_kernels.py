@@ -997,16 +997,40 @@ def test_bn_backward_presplit_planes_are_the_fp32_gradient(ops, monkeypatch, N, 
         assert torch.equal(seen["gres"], r.grad)
 
 
-def test_dense_gemm_groups_forward_backward(ops):
+@pytest.mark.parametrize("B,G,M,K,L", [(3, 3, 72, 40, 256), (8, 3, 256, 256, 1024), (8, 3, 360, 360, 1024), (2, 2, 32, 96, 512),
+                                       (1, 4, 64, 24, 132)])
+def test_dense_gemm_groups_forward_backward(ops, B, G, M, K, L):
     """ops.dense_gemm (general fp32 input, G weights on consecutive channel groups -- the second 1x1 of the batched q / k / v
-    chain): forward on the pack of W^T, input gradient on the pack of W, weight gradient on the 6-pass kernel; against fp64."""
+    chain): forward on the pack of W^T, input gradient on the pack of W, weight gradient on the 6-pass kernel; against fp64.  The
+    G products run as ONE grouped launch each way (s2f_pgemm_dx_f32_grouped): bit-identical to the G separate launches, and its
+    BatchNorm partials are the tile sums of every group's rows."""
     g = torch.Generator().manual_seed(5)
-    B, G, M, K, L = 3, 3, 72, 40, 256
     x = torch.randn(B, G * K, L, generator=g).cuda().requires_grad_(True)
     ws = [(torch.randn(M, K, generator=g) * K ** -0.5).cuda().requires_grad_(True) for _ in range(G)]
-    y = ops.dense_gemm(x, ws)
     gy = torch.randn(B, G * M, L, generator=g).cuda()
+    assert ops.DENSE_GROUPED
+    ops.DENSE_GROUPED = False
+    try:
+        y0 = ops.dense_gemm(x, ws)
+        y0.backward(gy)
+        gx0 = x.grad.clone()
+        x.grad = None
+        for w in ws:
+            w.grad = None
+    finally:
+        ops.DENSE_GROUPED = True
+    single = ops.lib.s2f_bn_single_pass(B, G * M, L)
+    ops.BN_PARTIALS_SINGLE = True
+    try:
+        y = ops.dense_gemm(x, ws, stats=True)
+    finally:
+        ops.BN_PARTIALS_SINGLE = False
+    assert torch.equal(y, y0)
+    part = getattr(y, "_s2f_part", None)
+    assert part is not None and tuple(part.shape) == (G * M, B * ((L + 127) // 128), 2), single
+    assert ((part.double() - _tile_sums(y.detach())).abs() <= 1e-5 * _tile_sums(y.detach().abs()) + 1e-30).all()
     y.backward(gy)
+    assert torch.equal(x.grad, gx0)
     xd, gyd = x.detach().double().view(B, G, K, L), gy.double().view(B, G, M, L)
     for i, w in enumerate(ws):
         wd = w.detach().double()
