@@ -170,6 +170,12 @@ int s2f_bn2_act_bwd(const float* z, const float* conv_bias, const float* stat, c
  * output convolutions and DCNv3's dw_conv all read a neuron output); the arithmetic stays fp32. */
 int s2f_dwconv_fwd(const void* x, const float* w, const float* border, float* y, int N, int C, int H, int W, int K,
                    int pad, int x_bf16, void* stream);
+/* Eval mode (row f4): the stencil with the BatchNorm (running statistics) and the Q_IFNode that follow every depthwise convolution of
+ * the path in its store -- u_out? = fp32 pre-activation, y_bf16? = bf16 spikes, stats? = firing counters; the fp32 convolution
+ * output is never written.  Per-element expressions of s2f_bn_act_fwd in eval mode (bit-identical spikes). */
+int s2f_dwconv_bn_lif_fwd(const void* x, const float* w, const float* border, const float* running_mean, const float* running_var,
+                          const float* gamma, const float* beta, float eps, float* u_out, void* y_bf16, uint64_t* stats, int N,
+                          int C, int H, int W, int K, int pad, int x_bf16, float vth, int D, void* stream);
 int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, int N, int C, int H, int W, int K, int pad,
                          void* stream);
 int s2f_dwconv_bwd_weight(const void* x, const float* border, const float* gy, float* gw, int N, int C, int H, int W,

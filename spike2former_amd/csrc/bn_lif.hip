@@ -934,8 +934,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
 // channel c loads its slice ONCE, reduces the statistics through LDS and applies them from registers: z is read once instead
 // of twice and one launch replaces two.  At the 32x32 / 64x64 stages of the path the two-kernel form is launch-bound
 // (measured floors: bn_stats 4.3 us + bn_apply 5.5 us for <= 16 MB), which is where ~2/3 of the BatchNorm launches live.
+// (round 4, same-box A/B of the C2 step: 4 tiles per wavefront on eight wavefronts 38.53 / 38.43 ms against 38.73 / 38.63 with 8 on four --
+// two wavefronts per SIMD instead of one hide the load round trip of these launch-bound kernels; 2 on sixteen loses again, 39.09 / 38.99)
 #ifndef S2F_BN_TPW
-#define S2F_BN_TPW 8
+#define S2F_BN_TPW 4
 #endif
 constexpr int kTpw = S2F_BN_TPW;              // tiles per wave held in registers
 constexpr int kFusedWaves = 32 / kTpw;        // wavefronts of a single-pass workgroup (a channel has at most 32 tiles)

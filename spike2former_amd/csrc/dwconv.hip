@@ -75,12 +75,70 @@ __device__ __forceinline__ void stage_halo(float (&s)[TS + K - 1][TS + K], const
   }
 }
 
+// Eval-mode epilogue of s2f_dwconv_bn_lif_fwd (row f4): the BatchNorm that follows a depthwise convolution everywhere on the path
+// (SepConv_Spike.dwconv, DCNv3.dw_conv, the pixel decoder's output convolutions: SNN_core.py:36-45, dcnv3.py:161-169,
+// pixel_decoder.py:374-378) with its running statistics, and the Q_IFNode after it, applied to the stencil's four outputs before
+// they are stored: u = (acc - mean) rstd gamma + beta ; spikes as bf16.  Per-element expressions of bn_lif.hip / lif.hip.
+struct DwEpi {
+  const float* mean;             // running_mean [C]; null = plain stencil
+  const float* var;
+  const float* gamma;
+  const float* beta;
+  float* u_out;                  // fp32 pre-activation [N][C][Ho][Wo] or null
+  unsigned short* y;             // bf16 spikes or null (no neuron)
+  unsigned long long* stats;     // firing counters or null
+  float eps, vth, Df, inv_d;
+};
+
+// four consecutive outputs of channel c at flat offset `off` (16-byte aligned when `vec`), `nvalid` of them inside the row
+__device__ __forceinline__ void dw_epi_store(const DwEpi& ep, int c, int64_t off, const float (&acc)[4], int nvalid, bool vec,
+                                             uint32_t& csum, uint32_t& cnz) {
+#pragma clang fp contract(off)
+  const float mean = ep.mean[c], rstd = 1.0f / sqrtf(ep.var[c] + ep.eps), g = ep.gamma[c], be = ep.beta[c];
+  float u[4], yy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    u[o] = (acc[o] - mean) * rstd * g + be;
+    if (ep.y && o < nvalid) {
+      float sp, vn;
+      bool inr;
+      s2f_lif_update(u[o], ep.Df, ep.inv_d, ep.vth, sp, yy[o], vn, inr);
+      csum += (uint32_t)sp;
+      cnz += ((uint32_t)sp != 0);
+    }
+  }
+  if (vec && nvalid == 4) {
+    if (ep.u_out) *reinterpret_cast<float4*>(ep.u_out + off) = make_float4(u[0], u[1], u[2], u[3]);
+    if (ep.y) *reinterpret_cast<uint2*>(ep.y + off) = s2f_spikes_to_bf16x4(yy[0], yy[1], yy[2], yy[3]);
+  } else {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o >= nvalid) continue;
+      if (ep.u_out) ep.u_out[off + o] = u[o];
+      if (ep.y) ep.y[off + o] = (unsigned short)(__float_as_uint(yy[o]) >> 16);
+    }
+  }
+}
+
+__device__ __forceinline__ void dw_epi_counters(const DwEpi& ep, uint32_t csum, uint32_t cnz) {
+  if (ep.y == nullptr || ep.stats == nullptr) return;
+  for (int o = 32; o > 0; o >>= 1) {
+    csum += __shfl_xor(csum, o, 64);
+    cnz += __shfl_xor(cnz, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* slot = ep.stats + 2 * ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y * 7) % S2F_STAT_SLOTS);
+    if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+    if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+  }
+}
+
 // FLIP = false: y[oy][ox] = sum_{i,j} w[i][j] * x[oy + i - pad][ox + j - pad]           (x: H x W, y: Ho x Wo)
 // FLIP = true : y[oy][ox] = sum_{i,j} w[i][j] * x[oy - i + pad][ox - j + pad]           (input gradient: x = gy)
-template <int K, bool FLIP, typename TX>
+template <int K, bool FLIP, typename TX, bool EPI = false>
 __global__ __launch_bounds__(256) void dw_stencil_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ border, float* __restrict__ y, int C,
-                                                         int H, int W, int Ho, int Wo, int pad, int tiles_x) {
+                                                         int H, int W, int Ho, int Wo, int pad, int tiles_x, DwEpi ep = DwEpi{}) {
   constexpr int HS = TS + K - 1;
   __shared__ float s[HS][HS + 1];
   const int plane = blockIdx.y;
@@ -112,6 +170,15 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const TX* __restrict__ 
     }
   }
   const int oy = ty + r;
+  if constexpr (EPI) {
+    uint32_t csum = 0, cnz = 0;
+    if (oy < Ho && tx + q0 < Wo) {
+      const int64_t off = (int64_t)plane * Ho * Wo + (int64_t)oy * Wo + tx + q0;
+      dw_epi_store(ep, c, off, acc, min(4, Wo - tx - q0), (Wo & 3) == 0 && (off & 3) == 0, csum, cnz);
+    }
+    dw_epi_counters(ep, csum, cnz);
+    return;
+  }
   if (oy < Ho) {
     float* yp = y + (int64_t)plane * Ho * Wo + (int64_t)oy * Wo + tx + q0;
     if ((Wo & 3) == 0 && tx + q0 + 3 < Wo && (reinterpret_cast<uintptr_t>(yp) & 15u) == 0) {
@@ -132,10 +199,11 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const TX* __restrict__ 
 // 1.5 LDS reads of 16 bytes instead of 17.5 of 4 bytes.  'Same' padding (pad == (K - 1) / 2) only.
 constexpr int WT = 64, HT = 32, WS = WT + 8;           // tile and staged row length (floats)
 
-template <int K, bool FLIP, typename TX>
+template <int K, bool FLIP, typename TX, bool EPI = false>
 __global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ border, float* __restrict__ y,
-                                                              int C, int H, int W, int Ho, int Wo, int pad, int tiles_x) {
+                                                              int C, int H, int W, int Ho, int Wo, int pad, int tiles_x,
+                                                              DwEpi ep = DwEpi{}) {
   constexpr int HR = HT + K - 1;                       // staged rows
   __shared__ __attribute__((aligned(16))) float s[HR][WS];
   const int plane = blockIdx.y;
@@ -181,6 +249,18 @@ __global__ __launch_bounds__(256) void dw_stencil_wide_kernel(const TX* __restri
         for (int o = 0; o < 4; ++o) acc[a][o] += wv * row[j + o + SH];
       }
     }
+  }
+  if constexpr (EPI) {
+    uint32_t csum = 0, cnz = 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int oy = ty + r2 + a, ox = tx + q0;
+      if (oy >= Ho || ox >= Wo) continue;
+      const int64_t off = (int64_t)plane * Ho * Wo + (int64_t)oy * Wo + ox;
+      dw_epi_store(ep, c, off, acc[a], min(4, Wo - ox), (Wo & 3) == 0 && (off & 3) == 0, csum, cnz);
+    }
+    dw_epi_counters(ep, csum, cnz);
+    return;
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -273,6 +353,26 @@ int check(const char* who, int N, int C, int H, int W, int K, int pad, int& Ho, 
   return S2F_OK;
 }
 
+template <typename TX>
+void launch_stencil_epi(int K, dim3 grid, hipStream_t s, const TX* x, const float* w, const float* border, int C, int H, int W, int Ho,
+                        int Wo, int pad, int tiles_x, DwEpi ep) {
+  if (K == 3 && (W & 3) == 0 && W >= 2 * WT && H >= HT && pad == 1 && (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(TX) - 1)) == 0) {
+    const int wx = (Wo + WT - 1) / WT, wy = (Ho + HT - 1) / HT;
+    hipLaunchKernelGGL((dw_stencil_wide_kernel<3, false, TX, true>), dim3(wx * wy, grid.y), dim3(256), 0, s, x, w, border,
+                       (float*)nullptr, C, H, W, Ho, Wo, pad, wx, ep);
+    return;
+  }
+  if (K == 3)
+    hipLaunchKernelGGL((dw_stencil_kernel<3, false, TX, true>), grid, dim3(256), 0, s, x, w, border, (float*)nullptr, C, H, W, Ho, Wo,
+                       pad, tiles_x, ep);
+  else if (K == 5)
+    hipLaunchKernelGGL((dw_stencil_kernel<5, false, TX, true>), grid, dim3(256), 0, s, x, w, border, (float*)nullptr, C, H, W, Ho, Wo,
+                       pad, tiles_x, ep);
+  else
+    hipLaunchKernelGGL((dw_stencil_kernel<7, false, TX, true>), grid, dim3(256), 0, s, x, w, border, (float*)nullptr, C, H, W, Ho, Wo,
+                       pad, tiles_x, ep);
+}
+
 template <bool FLIP, typename TX>
 void launch_stencil(int K, dim3 grid, hipStream_t s, const TX* x, const float* w, const float* border, float* y, int C,
                     int H, int W, int Ho, int Wo, int pad, int tiles_x) {
@@ -284,15 +384,15 @@ void launch_stencil(int K, dim3 grid, hipStream_t s, const TX* x, const float* w
   if (wide_on && K == 3 && (W & 3) == 0 && W >= 2 * WT && H >= HT && pad == 1 && (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(TX) - 1)) == 0) {
     const int wx = (Wo + WT - 1) / WT, wy = (Ho + HT - 1) / HT;
     hipLaunchKernelGGL((dw_stencil_wide_kernel<3, FLIP, TX>), dim3(wx * wy, grid.y), dim3(256), 0, s, x, w, border, y, C, H, W, Ho,
-                       Wo, pad, wx);
+                       Wo, pad, wx, DwEpi{});
     return;
   }
   if (K == 3)
-    hipLaunchKernelGGL((dw_stencil_kernel<3, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL((dw_stencil_kernel<3, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x, DwEpi{});
   else if (K == 5)
-    hipLaunchKernelGGL((dw_stencil_kernel<5, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL((dw_stencil_kernel<5, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x, DwEpi{});
   else
-    hipLaunchKernelGGL((dw_stencil_kernel<7, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x);
+    hipLaunchKernelGGL((dw_stencil_kernel<7, FLIP, TX>), grid, dim3(256), 0, s, x, w, border, y, C, H, W, Ho, Wo, pad, tiles_x, DwEpi{});
 }
 
 }  // namespace
@@ -311,6 +411,28 @@ extern "C" int s2f_dwconv_fwd(const void* x, const float* w, const float* border
     launch_stencil<false>(K, dim3(tiles_x * tiles_y, N * C), (hipStream_t)stream, reinterpret_cast<const float*>(x), w, border,
                           y, C, H, W, Ho, Wo, pad, tiles_x);
   return s2f_check_launch("s2f_dwconv_fwd");
+}
+
+extern "C" int s2f_dwconv_bn_lif_fwd(const void* x, const float* w, const float* border, const float* running_mean,
+                                     const float* running_var, const float* gamma, const float* beta, float eps, float* u_out,
+                                     void* y_bf16, uint64_t* stats, int N, int C, int H, int W, int K, int pad, int x_bf16, float vth,
+                                     int D, void* stream) {
+  S2F_REQUIRE(x && w && running_mean && running_var && gamma && beta && (u_out || y_bf16), S2F_EINVAL,
+              "s2f_dwconv_bn_lif_fwd: null pointer / neither output requested");
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_dwconv_bn_lif_fwd: bf16 spikes need D a power of two <= 128");
+  int Ho, Wo;
+  int rc = check("s2f_dwconv_bn_lif_fwd", N, C, H, W, K, pad, Ho, Wo);
+  if (rc) return rc;
+  const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
+  DwEpi ep{running_mean, running_var, gamma, beta, u_out, reinterpret_cast<unsigned short*>(y_bf16),
+           reinterpret_cast<unsigned long long*>(stats), eps, vth, (float)D, 1.0f / (float)D};
+  if (x_bf16)
+    launch_stencil_epi(K, dim3(tiles_x * tiles_y, N * C), (hipStream_t)stream, reinterpret_cast<const unsigned short*>(x), w, border, C,
+                       H, W, Ho, Wo, pad, tiles_x, ep);
+  else
+    launch_stencil_epi(K, dim3(tiles_x * tiles_y, N * C), (hipStream_t)stream, reinterpret_cast<const float*>(x), w, border, C, H, W,
+                       Ho, Wo, pad, tiles_x, ep);
+  return s2f_check_launch("s2f_dwconv_bn_lif_fwd");
 }
 
 extern "C" int s2f_dwconv_bwd_input(const float* gy, const float* w, float* gx, int N, int C, int H, int W, int K, int pad,

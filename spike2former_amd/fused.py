@@ -150,6 +150,30 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     fire = next_lif if (next_lif is not None and lif is None) else lif
     if want_pre is None:
         want_pre = lif is None
+    # eval mode, depthwise stencil -> BatchNorm -> [neuron]: the BatchNorm and the neuron run in the stencil's store (row f4)
+    if (x.dim() == 4 and getattr(conv, "groups", 1) == conv.in_channels == conv.out_channels and conv.groups > 1
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] in (3, 5, 7) and conv.bias is None
+            and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.padding[0] == conv.padding[1]
+            and (not bn.training) and bn.running_mean is not None and bn.affine and EVAL_FUSION and residual is None and x.is_cuda
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))
+            and (fire is None or (ops.spikes_bf16_ok(fire.D) and isinstance(fire.v, float) and not fire.keep_membrane
+                                  and not fire._forward_pre_hooks and (L % 4 == 0)))):
+        if fire is not None and fire.stats is not None:
+            fire.stats_elems += shape_in[0] * conv.out_channels * L
+        pre = bool(want_pre or (next_lif is not None and lif is None) or (fire is not None and bool(fire._forward_hooks)))
+        u, y = ops.dwconv_bn_lif_eval(x, conv.weight, conv.padding[0], bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps,
+                                      want_pre=pre or fire is None, lif=fire is not None, D=(fire.D if fire is not None else 8),
+                                      vth=(fire.v_threshold if fire is not None else 1.0), stats=(fire.stats if fire is not None else None))
+        if fire is not None:
+            fire.v = 0.0
+            if fire._forward_hooks:
+                yf = y.float().detach()
+                for hook in list(fire._forward_hooks.values()):
+                    hook(fire, (u,), yf)
+        if next_lif is not None and lif is None:
+            next_lif.prefire(u, y)
+            return u, None
+        return (u if (want_pre or fire is None) else None), y
     pure_conv = (conv.kernel_size in ((1, 1), (1,)) and conv.groups == 1 and tuple(conv.stride) in ((1, 1), (1,))
                  and tuple(conv.padding) in ((0, 0), (0,)))
     # 3x3 / stride 1 / padding 1 without a bias on a map the implicit kernel takes (MS_ConvBlock's convolutions)

@@ -41,8 +41,8 @@ class SepConv_Spike(nn.Module):
         residual add and the next neuron on the stream are folded into the last BatchNorm kernel (fused.bn_act)."""
         T, B, C, H, W = x.shape
         x = self.spike1.fire(x).flatten(0, 1)
-        _, x = bn_act(self.pwconv1[0](x), None, self.pwconv1[1], lif=self.spike2)
-        _, x = bn_act(self.dwconv[0](x), None, self.dwconv[1], lif=self.spike3)
+        _, x = conv_bn_act(self.pwconv1[0], x, self.pwconv1[1], lif=self.spike2)
+        _, x = conv_bn_act(self.dwconv[0], x, self.dwconv[1], lif=self.spike3)          # (eval: stencil + BatchNorm + neuron, one launch)
         x, _ = bn_act(self.pwconv2[0](x), None, self.pwconv2[1], scale=scale, next_lif=next_lif,
                       residual=None if residual is None else residual.flatten(0, 1))
         return x.reshape(T, B, C, H, W)
@@ -129,7 +129,7 @@ class DCNv3_pytorch(nn.Module):
         def offset_and_mask():
             x1 = self.dw_spike.fire(inp).flatten(0, 1)
             ops.use_here(x1)
-            _, x1 = bn_act(self.dw_conv[0](x1), None, self.dw_conv[1], lif=self.offset_spike)
+            _, x1 = conv_bn_act(self.dw_conv[0], x1, self.dw_conv[1], lif=self.offset_spike)
             # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
             offset, _ = conv_bn_act(self.offset[0], x1, self.offset[1])
             _, mask = conv_bn_act(self.mask[0], x1, self.mask[1], lif=self.mask_spike)

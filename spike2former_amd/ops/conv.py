@@ -49,6 +49,26 @@ class _DWConv(torch.autograd.Function):
         return _grad_pair(ctx.has_tok, gx) + (gw, None, None)
 
 
+def dwconv_bn_lif_eval(x, w, pad, running_mean, running_var, gamma, beta, eps, border=None, want_pre=False, lif=False, D=8, vth=1.0,
+                       stats=None):
+    """Eval-mode  depthwise conv -> BatchNorm(running statistics) [-> Q_IFNode (reset, no membrane kept)]  as ONE launch
+    (s2f_dwconv_bn_lif_fwd; row f4).  x: fp32 tensor or Spikes [N, C, H, W]; w [C, 1, K, K] -> (u fp32 or None, Spikes or None)."""
+    data, _ = _unpack(x)
+    data = data.contiguous()
+    N, C, H, W = data.shape
+    K = w.shape[-1]
+    Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+    dev = data.device
+    with torch.no_grad():
+        u = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=dev) if want_pre else None
+        y = torch.empty(N, C, Ho, Wo, dtype=torch.bfloat16, device=dev) if lif else None
+        check(lib.s2f_dwconv_bn_lif_fwd(_ptr(data), _ptr(w.detach().contiguous()), _ptr(None if border is None else border.contiguous()),
+                                        _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta), float(eps), _ptr(u), _ptr(y),
+                                        _ptr(stats), N, C, H, W, K, pad, int(data.dtype == torch.bfloat16), float(vth), int(D), _stream()),
+              "s2f_dwconv_bn_lif_fwd")
+    return u, (Spikes(y, _new_tok(y)) if lif else None)
+
+
 def dwconv(x, w, pad, border=None):
     """x: fp32 tensor or Spikes"""
     data, tok = _unpack(x)

@@ -1415,3 +1415,25 @@ def test_eval_conv3x3_bn_lif_fusion_is_the_unfused_path(ops, spike_mode, N, M, C
     assert torch.equal(u1, u0)
     if lif:
         assert torch.equal(y1.data, y0.data) and ops.read_stats(st1).tolist() == ops.read_stats(st0).tolist()
+
+
+@pytest.mark.parametrize("N,C,H,W,K,lif,xbf", [(2, 64, 32, 32, 3, True, True), (1, 32, 64, 64, 5, True, True), (2, 16, 32, 32, 7, True, False),
+                                               (1, 8, 128, 128, 3, True, True), (2, 24, 20, 36, 5, False, True), (1, 8, 256, 256, 3, True, False)])
+def test_eval_dwconv_bn_lif_fusion_is_the_unfused_path(ops, spike_mode, N, C, H, W, K, lif, xbf):
+    """s2f_dwconv_bn_lif_fwd (eval mode: depthwise stencil with the BatchNorm and the neuron in its store, both stencil forms) against
+    s2f_dwconv_fwd + s2f_bn_act_fwd in eval mode: identical pre-activation, spikes and firing counters."""
+    spike_mode(True)
+    g = torch.Generator().manual_seed(N + C + H + K)
+    w = (torch.randn(C, 1, K, K, generator=g) * K ** -1.0).cuda()
+    xs = _spikes_bf16((N, C, H, W), g)
+    x = ops.Spikes(xs, ops._new_tok(xs)) if xbf else xs.float()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3 + 0.5).cuda()
+    rm, rv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    st1, st0 = ops.new_stats("cuda"), ops.new_stats("cuda")
+    with torch.no_grad():
+        u1, y1 = ops.dwconv_bn_lif_eval(x, w, K // 2, rm, rv, gamma, beta, 1e-5, want_pre=True, lif=lif, stats=st1 if lif else None)
+        z = ops.dwconv(x, w, K // 2)
+        u0, y0, _ = ops.bn_act(z, None, gamma, beta, rm, rv, None, False, 0.1, 1e-5, lif=lif, want_pre=True, stats=st0 if lif else None)
+    assert torch.equal(u1, u0)
+    if lif:
+        assert torch.equal(y1.data, y0.data) and ops.read_stats(st1).tolist() == ops.read_stats(st0).tolist()
