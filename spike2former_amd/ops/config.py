@@ -5,7 +5,7 @@ import os
 
 
 class Config:
-    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "SPIKE_GEMM_DW", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "STRICT")
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "SPIKE_GEMM_DW", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
     RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
 
     def __init__(self):
@@ -38,6 +38,10 @@ class Config:
         self.BN2_FUSED = os.environ.get("S2F_BN2_FUSED", "1") != "0"
         self.LINEAR_TM = os.environ.get("S2F_LINEAR_TM", "1") != "0"
         self.DENSE_GROUPED = os.environ.get("S2F_DENSE_GROUPED", "1") != "0"          # the groups of a grouped 1x1 as one launch
+        # a captured step re-converts every weight (bf16 splits / packs) from the live fp32 values inside the graph, so that a replay after
+        # an optimiser step multiplies by the current weights.  False: frozen weights (an inference graph) -- the conversions of capture
+        # time are replayed against; a weight update then needs a new capture
+        self.RESPLIT_IN_GRAPH = True
         # STRICT: a shape that leaves this package's kernels for a library / ATen path is an error, not a slower number
         self.STRICT = os.environ.get("S2F_STRICT", "0") != "0"
 

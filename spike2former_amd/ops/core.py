@@ -53,7 +53,7 @@ def begin_step(device=None):
     # replays then read the live fp32 weights instead of the bf16 terms of capture time
     from . import gemm as _g          # (the weight-conversion caches live with the GEMM ops)
     _g._TRUST_ALL[0] = False
-    if device is not None and torch.cuda.is_current_stream_capturing():
+    if device is not None and torch.cuda.is_current_stream_capturing() and cfg.RESPLIT_IN_GRAPH:
         n = _g.resplit_all(device, build=False)
         if n > 0:
             _g._TRUST_ALL[0] = True

@@ -1,5 +1,6 @@
 """DCN pixel decoder, registry type 'mmdet.DCNTransformerEncoderPixelDecoder'
 (mmdet/models/layers/pixel_decoder.py:316-472; the base-class neuron it inherits and uses is :80)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -85,7 +86,11 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
                 ops.use_here(x)
                 return self.lateral_convs[i][0].forward_nobias(x)
             return run
-        lat = {i: ops.fork(0, lateral(i), inputs=(feats[i],), what="lat") for i in range(self.num_inputs - 2, -1, -1)}
+        # (inference: the lateral convolution, its BatchNorm, the top-down add and the output neuron are ONE launch below --
+        # conv_bn_act's eval fusion -- so nothing is started ahead)
+        lat_eval = (not self.training) and not torch.is_grad_enabled()
+        lat = {} if lat_eval else {i: ops.fork(0, lateral(i), inputs=(feats[i],), what="lat")
+                                   for i in range(self.num_inputs - 2, -1, -1)}
 
         y = self.last_feat_conv_spike.fire(x4)
         y = conv_bn(self.encoder_in_proj, y.flatten(0, 1))[0].reshape(t, bs, E, h, w)
@@ -95,11 +100,15 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         out = [y.reshape(t, bs, E, h, w)]
 
         def level(i, y):
-            z, handle = lat[i]
-            ops.join(handle, (z,))
             up = ops.upsample_bilinear(y, feats[i].shape[-2:])
-            # cur + upsample(y), then the output neuron: residual add and neuron fused into the BatchNorm kernel
-            _, s = bn_act(z, self.lateral_convs[i][0].bias, self.lateral_convs[i][1], residual=up, lif=self.output_convs_spike[i])
+            if lat_eval:
+                x = self.lateral_convs_spike[i].fire(feats[i]).flatten(0, 1)
+                _, s = conv_bn_act(self.lateral_convs[i][0], x, self.lateral_convs[i][1], residual=up, lif=self.output_convs_spike[i])
+            else:
+                z, handle = lat[i]
+                ops.join(handle, (z,))
+                # cur + upsample(y), then the output neuron: residual add and neuron fused into the BatchNorm kernel
+                _, s = bn_act(z, self.lateral_convs[i][0].bias, self.lateral_convs[i][1], residual=up, lif=self.output_convs_spike[i])
             # the last level feeds only mask_feature_spike: that neuron is applied by the same BatchNorm kernel (prefire)
             # instead of a separate pass over the [T*B, C, H/2, W/2] map (537 MB at C2)
             return conv_bn(self.output_convs[i], s, next_lif=self.mask_feature_spike if i == 0 else None)[0]
