@@ -160,6 +160,13 @@ int s2f_bn2_act_bwd(const float* z, const float* conv_bias, const float* stat, c
                     float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, int64_t N, int64_t C, int64_t L, float vth, int D,
                     void* stream);
 
+/* ---- im2col / col2im of the dense k x k convolutions that do not take the implicit 3x3 kernels: the stride-2 down-samplings and
+ * the 7x7 stem (MS_DownSampling, mmseg/models/backbones/sdtv2.py:386-421).  cols [N][C kh kw][Ho Wo] (same dtype as x: fp32, or
+ * bf16 spikes with x_bf16), row (c kh + ky) kw + kx, zero outside the plane, dilation 1 -- torch.nn.functional.unfold's layout.
+ * s2f_col2im is its adjoint as a gather (no atomics, no zero fill): gx[n][c][y][x] = sum of the column entries that cover it. */
+int s2f_im2col(const void* x, void* cols, int N, int C, int H, int W, int kh, int kw, int stride, int pad, int x_bf16, void* stream);
+int s2f_col2im(const float* cols, float* gx, int N, int C, int H, int W, int kh, int kw, int stride, int pad, void* stream);
+
 /* ---- depthwise KxK convolution (stride 1, dilation 1, K in {3,5,7}) on [N, C, H, W] -----------------------
  * Replaces nn.Conv2d(groups=C) as used by SepConv.dwconv (mmseg/models/backbones/sdtv2.py:156-163), RepConv's un-padded
  * 3x3 on the BNAndPadLayer output (sdtv2.py:48-89, 123-127), SepConv_Spike.dwconv (mmcv_spike/SNN_core.py:36-40),

@@ -38,6 +38,8 @@ SIGNATURES = {
     "s2f_bn_stats": (_i, [_p] * 3 + [_i64] * 3 + [_p]),
     "s2f_bn_act_fwd": (_i, [_p] * 16 + [_i64] * 3 + [_f, _f, _i, _f, _i, _i, _p]),
     "s2f_bn_act_bwd": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
+    "s2f_im2col": (_i, [_p, _p] + [_i] * 9 + [_p]),
+    "s2f_col2im": (_i, [_p, _p] + [_i] * 8 + [_p]),
     "s2f_dwconv_fwd": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_dwconv_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 3 + [_i] * 7 + [_f, _i, _p]),
     "s2f_dwconv_bwd_input": (_i, [_p] * 3 + [_i] * 6 + [_p]),

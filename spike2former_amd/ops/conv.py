@@ -78,6 +78,34 @@ def dwconv(x, w, pad, border=None):
 
 
 # ------------------------------------------------------------------------------------------------ dense k x k convolution
+def im2col(x, kh, kw, stride, padding):
+    """torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride) for fp32 maps and bf16 spike maps, as one gather kernel
+    (csrc/im2col.hip): [N, C, H, W] -> [N, C kh kw, Ho Wo], the column matrix of the reference's stride-2 / 7x7 nn.Conv2d
+    (mmseg/models/backbones/sdtv2.py:386-421)."""
+    N, C, H, W = x.shape
+    Ho = (H + 2 * padding - kh) // stride + 1
+    Wo = (W + 2 * padding - kw) // stride + 1
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("im2col: needs an fp32 or bf16 map in device memory (there is no host path)")
+    x = x.contiguous()
+    cols = torch.empty(N, C * kh * kw, Ho * Wo, dtype=x.dtype, device=x.device)
+    check(lib.s2f_im2col(_ptr(x), _ptr(cols), N, C, H, W, kh, kw, stride, padding, int(x.dtype == torch.bfloat16), _stream()),
+          "s2f_im2col")
+    return cols
+
+
+def col2im(dcols, C, H, W, kh, kw, stride, padding):
+    """torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride) as a gather: every input pixel sums the column entries
+    that cover it, in a fixed order, with no zero fill (csrc/im2col.hip)."""
+    N = dcols.shape[0]
+    if not dcols.is_cuda or dcols.dtype != torch.float32:
+        raise RuntimeError("col2im: needs fp32 columns in device memory (there is no host path)")
+    dcols = dcols.contiguous()
+    gx = torch.empty(N, C, H, W, dtype=torch.float32, device=dcols.device)
+    check(lib.s2f_col2im(_ptr(dcols), _ptr(gx), N, C, H, W, kh, kw, stride, padding, _stream()), "s2f_col2im")
+    return gx
+
+
 class _ConvDense(torch.autograd.Function):
     """Dense k x k Conv2d lowered to GEMMs (MIOpen is not usable on this image, see conv.py).
 
@@ -134,7 +162,7 @@ class _ConvDense(torch.autograd.Function):
             ctx.set_materialize_grads(False)
             return y.view(N, M, Ho, Wo), part
         ctx.implicit = False
-        cols = torch.nn.functional.unfold(x, (kh, kw), 1, padding, stride)              # [N, C*kh*kw, Ho*Wo]
+        cols = im2col(x, kh, kw, stride, padding)                                       # [N, C*kh*kw, Ho*Wo]
         use_mfma = spike_input and cfg.SPIKE_GEMM_ENABLED and cols.shape[2] % 4 == 0
         L = Ho * Wo
         if use_mfma:
@@ -209,11 +237,11 @@ class _ConvDense(torch.autograd.Function):
                           "s2f_conv3x3_general")
             elif M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
                 wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
-                gcols = torch.nn.functional.unfold(gy.view(N, M, Ho, Wo), (kh, kw), 1, kh - 1 - padding, 1)
+                gcols = im2col(gy.view(N, M, Ho, Wo), kh, kw, 1, kh - 1 - padding)
                 gx = bmm_tuned(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
             else:
                 dcols = dx_gemm(w2d, gy)
-                gx = torch.nn.functional.fold(dcols, (H, W), (kh, kw), 1, padding, stride)
+                gx = col2im(dcols, C, H, W, kh, kw, stride, padding)
         if ctx.needs_input_grad[2]:
             K = w2d.shape[1]
             if ctx.implicit:

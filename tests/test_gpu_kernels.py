@@ -1437,3 +1437,24 @@ def test_eval_dwconv_bn_lif_fusion_is_the_unfused_path(ops, spike_mode, N, C, H,
     assert torch.equal(u1, u0)
     if lif:
         assert torch.equal(y1.data, y0.data) and ops.read_stats(st1).tolist() == ops.read_stats(st0).tolist()
+
+
+@pytest.mark.parametrize("N,C,H,W,k,s,p,bf", [(2, 3, 64, 64, 7, 2, 3, False), (2, 32, 32, 32, 3, 2, 1, True), (1, 64, 16, 16, 3, 1, 1, True),
+                                              (2, 5, 13, 22, 3, 2, 1, False), (1, 8, 9, 7, 3, 1, 1, True), (1, 4, 31, 30, 5, 3, 2, False),
+                                              (2, 16, 128, 128, 3, 2, 1, True)])
+def test_im2col_and_col2im_are_unfold_and_fold(ops, N, C, H, W, k, s, p, bf):
+    """s2f_im2col is torch.nn.functional.unfold bit for bit (a gather); s2f_col2im is fold up to the order of its <= k*k additions per
+    pixel (fold scatters with atomics), and exactly the adjoint of im2col."""
+    g = torch.Generator().manual_seed(N * 7 + C + H + k)
+    x = (_spikes_bf16((N, C, H, W), g) if bf else torch.randn(N, C, H, W, generator=g).cuda())
+    cols = ops.im2col(x, k, k, s, p)
+    want = torch.nn.functional.unfold(x.float(), (k, k), 1, p, s)
+    assert cols.dtype == x.dtype and torch.equal(cols.float(), want)
+    d = torch.randn(want.shape, generator=g).cuda()
+    gx = ops.col2im(d, C, H, W, k, k, s, p)
+    ref = torch.nn.functional.fold(d.double(), (H, W), (k, k), 1, p, s)
+    assert (gx.double() - ref).abs().max().item() <= 1e-6 * k * k
+    # adjoint: <im2col(x), d> == <x, col2im(d)>
+    a = (want.double() * d.double()).sum().item()
+    b = (x.double() * gx.double()).sum().item()
+    assert abs(a - b) <= 1e-9 * max(1.0, abs(a)) + 1e-6 * want.abs().sum().item() * 1e-3
