@@ -11,6 +11,7 @@
 // elements (one 16-byte access; L % 4 == 0 keeps them inside one channel row), the in-range bits are wave ballots as in
 // lif.hip.  Per-channel parameters are 2-3 floats per lane served from L1/L2.
 #include "gemm_common.h"
+#include <cstring>
 
 namespace {
 
@@ -1408,11 +1409,22 @@ int resident_blocks(size_t lds) {
   }
   return cus * per_cu;
 }
-// -> grid; chunk = contiguous tiles per wave
+// -> grid; chunk = contiguous tiles per wave.  `want` tiles per wave in as many workgroups as that takes -- NOT one resident
+// workgroup per equal share of the tensor: equal static shares finish with the slowest CU, short workgroups handed out by the
+// dispatcher as others retire balance themselves (round 4, tools/probe_bn_stream.py, [8, 512, 16384] BatchNorm + neuron
+// forward: 93 us on a resident grid, 73 us with 8 tiles per wave; [8, 256, 65536] 191 -> 164 us; the backward pair 525 -> 472 us
+// with 4.  A resident grid that strides over the same 8-tile runs is as slow as the equal shares, 187 us; twice the resident
+// grid is as fast as the full one: it is the balancing, not the address pattern).  S2F_BN_ROWS_CHUNK=<forward>,<backward> overrides
+// `want` (0: the resident grid) for that probe.
 template <auto Kern>
-int grid_rows(uint32_t ntiles, size_t lds, uint32_t& chunk) {
-  const int64_t cap = resident_blocks<Kern>(lds);
+int grid_rows(uint32_t ntiles, size_t lds, uint32_t& chunk, int want) {
+  static const char* env = getenv("S2F_BN_ROWS_CHUNK");              // "<forward>,<backward>"
+  if (env != nullptr) {
+    const int fwd_want = atoi(env), bwd_want = strchr(env, ',') ? atoi(strchr(env, ',') + 1) : fwd_want;
+    want = want == 8 ? fwd_want : bwd_want;
+  }
   int64_t blocks = ((int64_t)ntiles + 4 * kWaves - 1) / (4 * kWaves);      // >= 4 tiles per wave amortise the prologue
+  const int64_t cap = want > 0 ? ((int64_t)ntiles + (int64_t)want * kWaves - 1) / ((int64_t)want * kWaves) : resident_blocks<Kern>(lds);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   chunk = (uint32_t)(((int64_t)ntiles + blocks * kWaves - 1) / (blocks * kWaves));
@@ -1567,7 +1579,7 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
   do {                                                                                                                  \
     uint32_t chunk;                                                                                                     \
     const uint32_t ntiles = (uint32_t)((total + 255) >> 8);                                                             \
-    const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk);                         \
+    const int rgrid = grid_rows<bn_apply_rows_kernel<LIFV, HASV, YBV, AL>>(ntiles, lds, chunk, 8);                         \
     S2F_LAUNCH(first_launch, true, (bn_apply_rows_kernel<LIFV, HASV, YBV, AL>), dim3(rgrid), block, lds, s, z, conv_bias, \
                sums, stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st,   \
                total, ntiles, (int)C, (uint32_t)L, chunk, inv_count, unbias, momentum, eps, training, vth, (float)D);    \
@@ -1698,7 +1710,7 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
 #define S2F_BN_ROWS_APPLY(A, B, Cc, AL)                                                                                  \
   do {                                                                                                                   \
     uint32_t chunk;                                                                                                      \
-    const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc, AL>>(ntiles, 0, chunk);                               \
+    const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc, AL>>(ntiles, 0, chunk, 4);                               \
     S2F_LAUNCH(false, true, (bn_bwd_apply_rows_kernel<A, B, Cc, AL>), dim3(rgrid), dim3(kBlock), 0, s, z, conv_bias, stat, \
                gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, ntiles, (int)C, (uint32_t)L, \
                chunk, inv_count, training, vth, (float)D, gzs);                                                          \
