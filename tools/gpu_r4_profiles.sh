@@ -46,3 +46,8 @@ cd $R
 bash tools/prof_ab_env.sh r04_partials S2F_BN_PARTIALS=0 S2F_BN_PARTIALS=1 > /dev/null 2>&1
 cd $R
 bash tools/prof_ab_env.sh r04_bn2 S2F_BN2_FUSED=0 S2F_BN2_FUSED=1 > /dev/null 2>&1
+cd $R
+bash tools/prof_ab_env.sh r04_rows S2F_BN_ROWS_CHUNK=0 S2F_BN_ROWS_CHUNK=8,4 > /dev/null 2>&1
+cd $R
+python tools/probe_bn_stream.py > gpurun_out/r04_bn_stream_probe.txt 2>&1
+S2F_BN_ROWS_CHUNK=0 python tools/probe_bn_stream.py > gpurun_out/r04_bn_stream_probe_resident_grid.txt 2>&1

@@ -27,7 +27,7 @@ def cat(name):
     if 's2f_zero' in name: return 'fill/memset'
     if 'depthwise' in name: return 'depthwise conv (ATen)'
     if 'batch_norm' in name: return 'batch_norm (ATen)'
-    if 'im2col' in name or 'col2im' in name: return 'im2col/col2im (ATen)'
+    if 'im2col' in name or 'col2im' in name: return 'im2col/col2im (ATen)' if 'at::' in name else 'im2col/col2im (ours)'
     if 'upsample' in name: return 'upsample (ATen)'
     if 'direct_copy' in name or 'copyBuffer' in name or 'CatArray' in name: return 'copies'
     if 'CUDAFunctor_add' in name or 'CUDAFunctorOnSelf_add' in name: return 'add (ATen)'
