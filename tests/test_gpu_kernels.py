@@ -1458,3 +1458,23 @@ def test_im2col_and_col2im_are_unfold_and_fold(ops, N, C, H, W, k, s, p, bf):
     a = (want.double() * d.double()).sum().item()
     b = (x.double() * gx.double()).sum().item()
     assert abs(a - b) <= 1e-9 * max(1.0, abs(a)) + 1e-6 * want.abs().sum().item() * 1e-3
+
+
+@pytest.mark.parametrize("B,M,K,N", [(2, 64, 32, 4), (3, 40, 72, 4), (1, 256, 256, 4)])
+def test_spike_gemm_on_a_2x2_map(ops, spike_mode, B, M, K, N):
+    """N = 4 (a 2 x 2 map: a 32 x 32 crop at stride 16) is below the packed-weight kernels' N >= 8: ops.spike_gemm takes the round-2
+    kernel there (forward, weight gradient) and the input gradient whatever path it picks -- all against fp64."""
+    spike_mode(True)
+    g = torch.Generator().manual_seed(B + M + K)
+    xs = _spikes_bf16((B, K, N), g)
+    w = (torch.randn(M, K, generator=g) * K ** -0.5).cuda().requires_grad_()
+    tok = ops._new_tok(xs).clone().requires_grad_()
+    y = ops.spike_gemm(ops.Spikes(xs, tok), w)
+    gy = torch.randn(B, M, N, generator=g).cuda()
+    y.backward(gy)
+    xd, wd = xs.double(), w.detach().double()
+    assert (y.double() - wd @ xd).abs().max().item() <= 2e-6 * (wd.abs() @ xd).max().item()
+    gx = torch.einsum("mk,bmn->bkn", wd, gy.double())
+    gw = torch.einsum("bmn,bkn->mk", gy.double(), xd)
+    assert (tok.grad.double() - gx).abs().max().item() <= 4e-6 * torch.einsum("mk,bmn->bkn", wd.abs(), gy.double().abs()).max().item()
+    assert (w.grad.double() - gw).abs().max().item() <= 4e-6 * torch.einsum("bmn,bkn->mk", gy.double().abs(), xd).max().item()
