@@ -156,3 +156,46 @@ def test_flat_grad_buffer_sinks_and_compaction():
         assert ops.GRAD_SINKS is None and ops._sink_for(ps[1]) is None
     finally:
         ops.GRAD_SINKS = None
+
+
+def test_register_upstream_fills_the_reference_registries(monkeypatch):
+    """register_upstream() (registry level): with mmseg / mmdet importable, the classes of this package take the
+    reference's type names in THEIR registries (`register_module(name=, module=, force=True)`, the mmengine Registry call the
+    reference's own modules use: mmseg/models/backbones/sdtv2.py:424, mmdet/models/layers/pixel_decoder.py:316).  mmengine is not
+    in this image, so stand-ins with that one method are put on sys.modules; the names must also build through them."""
+    import sys
+    import types
+    import spike2former_amd as s2f
+
+    class FakeRegistry:
+        def __init__(self):
+            self.modules, self.forced = {}, []
+
+        def register_module(self, name=None, force=False, module=None):
+            assert module is not None and isinstance(name, str)
+            if name in self.modules and not force:
+                raise KeyError(name)
+            self.modules[name] = module
+            self.forced.append(force)
+
+    regs = {}
+    for pkg in ("mmseg", "mmdet"):
+        root, reg = types.ModuleType(pkg), types.ModuleType(pkg + ".registry")
+        reg.MODELS = regs[pkg] = FakeRegistry()
+        root.registry = reg
+        monkeypatch.setitem(sys.modules, pkg, root)
+        monkeypatch.setitem(sys.modules, pkg + ".registry", reg)
+    regs["mmseg"].modules["MaskFormerHead"] = object          # the reference's own class is replaced (force=True), not an error
+    done = s2f.register_upstream()
+    assert set(regs["mmseg"].modules) == {"Spiking_vit_MetaFormer", "Spiking_vit_MetaFormerv2", "MaskFormerHead", "EncoderDecoder",
+                                          "SegDataPreProcessor"}
+    assert set(regs["mmdet"].modules) == {"DCNTransformerEncoderPixelDecoder"}
+    assert all(regs["mmseg"].forced) and all(regs["mmdet"].forced) and len(done) == 6
+    for reg in regs.values():
+        for name, cls in reg.modules.items():
+            assert cls is s2f.MODELS.get(name) and cls.__module__.startswith("spike2former_amd")
+    # without the packages: nothing to do, no error
+    for pkg in ("mmseg", "mmdet"):
+        monkeypatch.setitem(sys.modules, pkg, None)
+        monkeypatch.setitem(sys.modules, pkg + ".registry", None)
+    assert s2f.register_upstream() == []
