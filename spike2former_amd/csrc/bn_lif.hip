@@ -1379,7 +1379,7 @@ inline int pick_slices(int C, int L, int& slice) {
   return S;
 }
 
-// Row-walking forms: eligibility, slice picker (in tiles) and the persistent grid.
+// Row-walking forms: eligibility, slice picker (in tiles) and the grid (grid_rows below).
 inline bool rows_ok(int64_t N, int64_t C, int64_t L, int D) {
   return (L & 3) == 0 && L >= 256 && N * C * L < ((int64_t)1 << 39) && N * C < ((int64_t)1 << 31) && D >= 1 && (D & (D - 1)) == 0;
 }
@@ -1390,8 +1390,9 @@ inline int pick_slices_rows(int C, int L, int& slice) {
   slice = ((L + S - 1) / S + 255) / 256 * 256;                      // whole tiles when the rows are tile-aligned
   return (L + slice - 1) / slice;
 }
-// Workgroups of `Kern` that can be resident on the whole chip at once: a persistent kernel launched with more than that
-// runs a second, partly filled round (2 048 workgroups on 1 792 slots cost 14 %).
+// Workgroups of `Kern` that can be resident on the whole chip at once (the round-2 grid of the row kernels, kept as the `want = 0`
+// form of grid_rows for the probe: 2 048 equal shares on 1 792 slots ran a second, 14 %-full round -- and, round 4, equal shares
+// on exactly the resident slots still lose 13-28 % to the slowest CU, see grid_rows).
 template <auto Kern>
 int resident_blocks(size_t lds) {
   static int cus = 0, per_cu_small = 0;
