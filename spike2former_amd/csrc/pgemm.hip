@@ -1155,7 +1155,9 @@ int pick_cfg_nn(int M, int N, int K, int batch, int force) {
   const int64_t tiles128 = (int64_t)((N + 127) / 128) * batch * ((M + 127) / 128);
   if (K >= 1024 && (N & 7) == 0) return 4;
   // (cfg 8 = the 64 x 128 tile on eight wavefronts of 32 x 32: 8.1 vs 8.6 us, 11.8 vs 12.6, 19.9 vs 20.5 on the 1 024-column shapes)
-  return (M > 64 && tiles128 >= 256) ? 7 : (N >= 128 ? 8 : 6);
+  // (round 4, tools/probe_small_n.py: the eight-wavefront tile also wins on the decoder's 100-token maps -- 31.0 vs 33.4 us on
+  //  [256x2048], 6.4 vs 7.1 on [256x256], 8.4 vs 8.9 on [2048x256] -- so cfg 6 is left with the outputs of fewer than 64 rows)
+  return (M > 64 && tiles128 >= 256) ? 7 : ((N >= 128 || M >= 64) ? 8 : 6);
 }
 
 }  // namespace
