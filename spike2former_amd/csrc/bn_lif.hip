@@ -219,6 +219,24 @@ __device__ __forceinline__ void st4_bf16(float* p, int64_t base, const Tile4& t)
   *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + base) = s2f_spikes_to_bf16x4(t.a[0], t.a[1], t.a[2], t.a[3]);
 }
 
+// Non-temporal loads for operands at their LAST use: bit 0 = z in the row-walking forward, bit 1 = z and the incoming gradients in
+// the row-walking backward apply (the reduce pass before it reads them normally: this pass re-reads them), bit 2 = non-temporal
+// mask stores, bit 3 / 4 = the single-pass forward / backward.  Same-box A/B of the C2 step through S2F_LIB (round 4, two
+// alternations): 0: 37.23 / 37.22 ms, HBM-resident forward fraction 0.697 / 0.681;  1: 37.17 / 37.25, 0.728 / 0.713;
+// 3: 37.04 / 37.05, 0.717 / 0.719;  7: 37.05 / 37.11, 0.701 / 0.698 (the mask words are read back by the backward: keep them cached).
+// On another box, against 3 (37.63 / 37.61): 3 + 8: 37.55 / 37.56;  3 + 16: 37.53 / 37.46;  3 + 8 + 16: 37.46 / 37.40.
+// The kernels' own durations barely move -- what improves is everybody else: a streamed-through operand no longer evicts what the
+// next kernel is about to read (the gradient just written for the input- and weight-gradient products).
+#ifndef S2F_BN_NT
+#define S2F_BN_NT 27
+#endif
+__device__ __forceinline__ Tile4 ld4_nt(const float* p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+  Tile4 t;
+  t.a[0] = v.x, t.a[1] = v.y, t.a[2] = v.z, t.a[3] = v.w;
+  return t;
+}
 // streaming (non-temporal) forms of the two stores
 __device__ __forceinline__ void st4_nt(float* p, const Tile4& t) {
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -624,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
   auto request = [&](int slot, uint32_t tile) __attribute__((always_inline)) {
     if (tile < t_end && (ALIGNED || tile + 1 < ntiles || (uint32_t)lane * 4 < tail)) {
       const int64_t base = (int64_t)tile * 256 + lane * 4;
-      zn[slot] = ld4(z + base);
+      zn[slot] = (S2F_BN_NT & 1) ? ld4_nt(z + base) : ld4(z + base);
       if (res) rn[slot] = ld4(res + base);
       if (LIF && HAS_V) vn[slot] = ld4(v_in + base);
     }
@@ -713,7 +731,13 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     }
     if (LIF) {
       const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
-      if (mask != nullptr && lane < 4) mask[(int64_t)tile * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+      if (mask != nullptr && lane < 4) {
+        const uint64_t word = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        if (S2F_BN_NT & 4)
+          __builtin_nontemporal_store(word, mask + (int64_t)tile * 4 + lane);
+        else
+          mask[(int64_t)tile * 4 + lane] = word;
+      }
     }
     w.off += 256u;
     if (w.off >= L) {
@@ -855,9 +879,9 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
     if (tile < t_end) {
       if (ALIGNED || tile + 1 < ntiles || (uint32_t)lane * 4 < tail) {
         const int64_t base = (int64_t)tile * 256 + lane * 4;
-        zn = ld4(z + base);
-        if (GU) an = ld4(g_u + base);
-        if (GY) bn = ld4(g_y + base);
+        zn = (S2F_BN_NT & 2) ? ld4_nt(z + base) : ld4(z + base);
+        if (GU) an = (S2F_BN_NT & 2) ? ld4_nt(g_u + base) : ld4(g_u + base);
+        if (GY) bn = (S2F_BN_NT & 2) ? ld4_nt(g_y + base) : ld4(g_y + base);
         if (GV) cn = ld4(g_v + base);
       }
       if (GY || GV) {
@@ -996,7 +1020,7 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
     ok[i] = t < tiles;
     const int n = ok[i] ? t / tpr : 0, q = ok[i] ? t - n * tpr : 0;
     base[i] = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
-    zv[i] = ld4(z + base[i]);
+    zv[i] = (S2F_BN_NT & 8) ? ld4_nt(z + base[i]) : ld4(z + base[i]);
   }
   // the residual is independent of the statistics: its loads ride with z's instead of forming a second dependent round trip
   // after the block reduction (~1.5 us of a 9 us kernel)
@@ -1126,11 +1150,11 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     const int tt = t < tiles ? t : 0;
     const int n = tt / tpr, q = tt - n * tpr;
     const int64_t base = ((int64_t)n * C + c) * L + q * 256 + lane * 4;
-    xh[i] = ld4(z + base);
-    if (GU) gu[i] = ld4(g_u + base);
+    xh[i] = (S2F_BN_NT & 16) ? ld4_nt(z + base) : ld4(z + base);
+    if (GU) gu[i] = (S2F_BN_NT & 16) ? ld4_nt(g_u + base) : ld4(g_u + base);
     Tile4 bb, cc;
     uint64_t word = 0;
-    if (GY) bb = ld4(g_y + base);
+    if (GY) bb = (S2F_BN_NT & 16) ? ld4_nt(g_y + base) : ld4(g_y + base);
     if (GV) cc = ld4(g_v + base);
     if (GY || GV) word = mask[(base >> 8) * 4 + (lane & 3)];
 #pragma unroll
