@@ -226,7 +226,9 @@ __device__ __forceinline__ void st4_bf16(float* p, int64_t base, const Tile4& t)
 // 3: 37.04 / 37.05, 0.717 / 0.719;  7: 37.05 / 37.11, 0.701 / 0.698 (the mask words are read back by the backward: keep them cached).
 // On another box, against 3 (37.63 / 37.61): 3 + 8: 37.55 / 37.56;  3 + 16: 37.53 / 37.46;  3 + 8 + 16: 37.46 / 37.40.
 // The kernels' own durations barely move -- what improves is everybody else: a streamed-through operand no longer evicts what the
-// next kernel is about to read (the gradient just written for the input- and weight-gradient products).
+// next kernel is about to read (the gradient just written for the input- and weight-gradient products).  The same hint on the other
+// last-use streams of the step (incoming gradients of the stand-alone neuron backward, the column matrix in col2im, the output
+// gradient in the depthwise weight gradient) measured nothing: 37.16 / 37.07 without, 37.03 / 37.12 with all three.
 #ifndef S2F_BN_NT
 #define S2F_BN_NT 27
 #endif
