@@ -221,7 +221,7 @@ __device__ __forceinline__ void st4_bf16(float* p, int64_t base, const Tile4& t)
 
 // Non-temporal loads for operands at their LAST use: bit 0 = z in the row-walking forward, bit 1 = z and the incoming gradients in
 // the row-walking backward apply (the reduce pass before it reads them normally: this pass re-reads them), bit 2 = non-temporal
-// mask stores, bit 3 / 4 = the single-pass forward / backward.  Same-box A/B of the C2 step through S2F_LIB (round 4, two
+// mask stores, bit 3 / 4 = the single-pass forward / backward, bit 5 = the residual operand (below).  Same-box A/B of the C2 step through S2F_LIB (round 4, two
 // alternations): 0: 37.23 / 37.22 ms, HBM-resident forward fraction 0.697 / 0.681;  1: 37.17 / 37.25, 0.728 / 0.713;
 // 3: 37.04 / 37.05, 0.717 / 0.719;  7: 37.05 / 37.11, 0.701 / 0.698 (the mask words are read back by the backward: keep them cached).
 // On another box, against 3 (37.63 / 37.61): 3 + 8: 37.55 / 37.56;  3 + 16: 37.53 / 37.46;  3 + 8 + 16: 37.46 / 37.40.
@@ -229,8 +229,10 @@ __device__ __forceinline__ void st4_bf16(float* p, int64_t base, const Tile4& t)
 // next kernel is about to read (the gradient just written for the input- and weight-gradient products).  The same hint on the other
 // last-use streams of the step (incoming gradients of the stand-alone neuron backward, the column matrix in col2im, the output
 // gradient in the depthwise weight gradient) measured nothing: 37.16 / 37.07 without, 37.03 / 37.12 with all three.
+// bit 5 = the residual operand of the forward kernels (the previous block's stream: its last reader): 27 -> 59 on a third box
+// 37.28 / 37.38 / 37.28 -> 37.28 / 37.27 / 37.20, HBM-resident fraction 0.712 / 0.707 / 0.712 -> 0.729 / 0.734 / 0.732.
 #ifndef S2F_BN_NT
-#define S2F_BN_NT 27
+#define S2F_BN_NT 59
 #endif
 __device__ __forceinline__ Tile4 ld4_nt(const float* p) {
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_rows_kernel(
     if (tile < t_end && (ALIGNED || tile + 1 < ntiles || (uint32_t)lane * 4 < tail)) {
       const int64_t base = (int64_t)tile * 256 + lane * 4;
       zn[slot] = (S2F_BN_NT & 1) ? ld4_nt(z + base) : ld4(z + base);
-      if (res) rn[slot] = ld4(res + base);
+      if (res) rn[slot] = (S2F_BN_NT & 32) ? ld4_nt(res + base) : ld4(res + base);
       if (LIF && HAS_V) vn[slot] = ld4(v_in + base);
     }
   };
@@ -1029,7 +1031,7 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
   Tile4 rvp[kTpw];
   if (res) {
 #pragma unroll
-    for (int i = 0; i < kTpw; ++i) rvp[i] = ld4(res + base[i]);
+    for (int i = 0; i < kTpw; ++i) rvp[i] = (S2F_BN_NT & 32) ? ld4_nt(res + base[i]) : ld4(res + base[i]);
   }
   float ps = 0.f, pq = 0.f;
 #pragma unroll
