@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 17
+#define S2F_ABI_VERSION 18
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
