@@ -1478,3 +1478,55 @@ def test_spike_gemm_on_a_2x2_map(ops, spike_mode, B, M, K, N):
     gw = torch.einsum("bmn,bkn->mk", gy.double(), xd)
     assert (tok.grad.double() - gx).abs().max().item() <= 4e-6 * torch.einsum("mk,bmn->bkn", wd.abs(), gy.double().abs()).max().item()
     assert (w.grad.double() - gw).abs().max().item() <= 4e-6 * torch.einsum("bmn,bkn->mk", gy.double().abs(), xd).max().item()
+
+
+@pytest.mark.parametrize("bands", [2, 3, 7])
+def test_dcnv3_backward_in_bands_is_the_one_workgroup_backward(ops, bands):
+    """Maps whose (n, group) slice does not fit in one CU's LDS (C3: 64 x 32, C5: 50 x 84) run the DCNv3 backward in bands of input
+    rows (dcn_bwd_lds_kernel<true>): forced on the C2 geometry, all three gradients are bit-identical to the one-workgroup kernel
+    (same fixed-point scale, integer accumulation; the offset / mask gradients are formed by exactly one band each)."""
+    import os
+    from spike2former_amd._lib import lib
+    g = torch.Generator().manual_seed(40 + bands)
+    N, H, W, G, Cg = 2, 32, 32, 32, 8
+    x = torch.randn(N, H, W, G * Cg, generator=g).cuda()
+    off = (torch.randn(N, H, W, G * 18, generator=g) * 3).cuda()
+    m = torch.rand(N, H, W, G * 9, generator=g).cuda()
+    gy = torch.randn(N, H, W, G * Cg, generator=g).cuda()
+
+    def bwd():
+        gx, goff, gm = torch.full_like(x, float("nan")), torch.full_like(off, float("nan")), torch.full_like(m, float("nan"))
+        rc = lib.s2f_dcnv3_bwd(x.data_ptr(), off.data_ptr(), m.data_ptr(), gy.data_ptr(), gx.data_ptr(), goff.data_ptr(), gm.data_ptr(),
+                               N, H, W, G, Cg, 3, 3, 1, 1, 1, 1, 1, 1, 1.0, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return gx, goff, gm
+    want = bwd()
+    os.environ["S2F_DCN_FORCE_BANDS"] = str(bands)
+    try:
+        got = bwd()
+    finally:
+        del os.environ["S2F_DCN_FORCE_BANDS"]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 50, 84), (2, 64, 32), (1, 37, 20)])
+def test_dcnv3_on_maps_larger_than_one_cu_vs_oracle(ops, so, N, H, W):
+    """C5's 50 x 84 and C3's 64 x 32 pixel-decoder maps (G = 32, Cg = 8): forward and banded backward against the oracle's gather
+    restatement, tolerances of the C2-geometry test."""
+    g = torch.Generator().manual_seed(H * W)
+    G, Cg = 32, 8
+    x = torch.randn(N, H, W, G * Cg, generator=g)
+    off = torch.randn(N, H, W, G * 18, generator=g) * 2
+    m = torch.clamp(torch.round(torch.randn(N, H, W, G * 9, generator=g) + 1), 0, 8) / 8
+    gy = torch.randn(N, H, W, G * Cg, generator=g)
+    xo, oo, mo = (t.clone().requires_grad_(True) for t in (x, off, m))
+    yo = so.dcnv3_core(xo, oo, mo, G, Cg)
+    yo.backward(gy)
+    xc, oc, mc = (t.cuda().requires_grad_(True) for t in (x, off, m))
+    y = ops.dcnv3_core(xc, oc, mc, 3, 3, 1, 1, 1, 1, 1, 1, G, Cg, 1.0)
+    y.backward(gy.cuda())
+    for a, b, tol, name in ((y, yo.detach(), 1e-5, "y"), (xc.grad, xo.grad, 1e-5, "gx"), (mc.grad, mo.grad, 1e-5, "gm"),
+                            (oc.grad, oo.grad, 1e-4, "goff")):
+        assert (a.detach().cpu() - b).abs().max().item() <= tol * b.abs().max().item(), name
