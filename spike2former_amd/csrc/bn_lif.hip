@@ -969,7 +969,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
 #define S2F_BN_TPW 4
 #endif
 constexpr int kTpw = S2F_BN_TPW;              // tiles per wave held in registers
-constexpr int kFusedWaves = 32 / kTpw;        // wavefronts of a single-pass workgroup (a channel has at most 32 tiles)
+// wavefronts of a single-pass workgroup: up to 16 (a channel of at most 64 tiles = 16 384 elements: round 4 -- the 64 x 32 stage of C3
+// and the T = 8 batch of C4 are 16 384 elements per channel and ran the two-pass kernels for every BatchNorm of their deep stages)
+#ifndef S2F_BN_MAX_TILES
+#define S2F_BN_MAX_TILES 64
+#endif
+constexpr int kFusedWaves = S2F_BN_MAX_TILES / kTpw;
 constexpr int kFusedBlock = 64 * kFusedWaves;
 
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red, int nwaves) {

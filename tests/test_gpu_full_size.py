@@ -1012,7 +1012,8 @@ def test_c2_batchnorm_statistics_come_from_the_gemm_epilogues(c2):
     (c1, m1, d1, used_on), (c0, m0, d0, used_off) = outs
     print("BatchNorm launches fed by partials / statistics passes:", used_on, "with the switch off:", used_off)
     # (the 32x32-stage maps and the decoder's 100-token maps compute their statistics inside their single-pass kernels either way)
-    assert used_off[0] == 0 and used_off[1] >= 20, used_off
-    assert used_on[0] >= 20 and used_on[1] <= 8 and used_on[0] + used_on[1] == used_off[1], (used_on, used_off)
+    # (and, with sixteen-wavefront single-pass workgroups, every map of up to 16 384 elements per channel: the SDME block's too)
+    assert used_off[0] == 0 and used_off[1] >= 15, used_off
+    assert used_on[0] >= 15 and used_on[1] <= 8 and used_on[0] + used_on[1] == used_off[1], (used_on, used_off)
     assert rel_l2(d1.cpu(), d0.cpu()) <= 1e-6
     assert torch.isfinite(m1).all() and m1.shape == m0.shape and c1.shape == c0.shape

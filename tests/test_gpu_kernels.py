@@ -365,7 +365,11 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      # 100-token maps; one / several / all eight rounds of 64 groups
                                                      (8, 256, 100, True, False, True), (8, 64, 100, True, True, True),
                                                      (8, 2048, 100, True, False, False), (2, 32, 1000, True, True, True),
-                                                     (3, 40, 36, True, True, True), (2, 33, 4, True, False, True)])
+                                                     (3, 40, 36, True, True, True), (2, 33, 4, True, False, True),
+                                                     # 33 .. 64 tiles per channel: the sixteen-wavefront single-pass form (C3's 64 x 32
+                                                     # stage, C4's T = 8 batch)
+                                                     (8, 64, 2048, True, True, True), (16, 96, 1024, True, False, True),
+                                                     (5, 64, 3072, True, True, False)])
 @pytest.mark.parametrize("bf16", [True, False])
 def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
@@ -1329,7 +1333,8 @@ def test_bn_from_partials_is_bn_from_the_statistics_pass(ops, spike_mode, N, C, 
 
 
 @pytest.mark.parametrize("N,C,L,res,lif", [(8, 256, 1024, False, True), (8, 768, 1024, False, True), (8, 360, 1024, True, False),
-                                           (4, 64, 512, True, True), (8, 256, 1024, True, True)])
+                                           (4, 64, 512, True, True), (8, 256, 1024, True, True), (8, 128, 2048, True, True),
+                                           (16, 64, 1024, False, True)])
 def test_batchnorm_pair_as_one_kernel_is_two_batchnorms(ops, spike_mode, N, C, L, res, lif):
     """s2f_bn2_act_fwd / _bwd (train-mode BN2(BN1(z)) [+ residual] [-> neuron] in one single-pass kernel each way: the pair closing
     every RepConv chain, sdtv2.py:280-296) against two s2f_bn_act calls: pre-activation 1e-5, spikes <= 1e-4 of the elements by one
