@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 18
+#define S2F_ABI_VERSION 19
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -281,6 +281,19 @@ int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int
  * over all (job, tile, split) triples with a launch-wide contraction length per workgroup; the job table travels in the
  * kernel arguments.  bkv = contraction elements per step: 64 (rows with L % 64 == 0 or L >= 512) or 32. */
 int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* stream);
+/* The same weight gradients on the LDS-DMA pipeline (csrc/dwp.hip, round 5): tile 128 (dY rows) x 256 (X rows), contraction step
+ * 32, eight wavefronts in two halves that alternate a multiply segment with a staging segment (X by global_load_lds into a
+ * three-slot ring, dY split hi + mid + lo through registers into two stages), one barrier per segment.  Needs L % 32 == 0,
+ * M L < 2^30, K L < 2^31 (s2f_spike_gemm_dw_pipe_ok says whether a shape qualifies; the host falls back to
+ * s2f_spike_gemm_dw_bf16 otherwise).  cfg: 0 = the two-halves schedule, 1 = every wavefront in the same phase (probe);
+ * target_wgs <= 0: default split of the contraction.  Replaces the autograd weight gradient of the 1x1 convolutions fed by a
+ * Q_IFNode (mmseg/models/backbones/sdtv2.py:222-255, 304-306; mmcv_spike/transformer.py:213-236, 758-763;
+ * mmdet/models/layers/pixel_decoder.py:368-404; mmdet/models/dense_heads/maskformer_head.py:581-582 for the mask contraction's
+ * embedding gradient). */
+int s2f_spike_gemm_dw_pipe_ok(int batch, int M, int K, int L);
+int s2f_spike_gemm_dw_pipe(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate, int cfg,
+                           int target_wgs, void* stream);
+int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, int cfg, int target_wgs, void* stream);
 
 /* ---- pipelined GEMMs fed by LDS-DMA (csrc/pgemm.hip, round 3) ------------------------------------------------------------
  * The same products as s2f_spike_gemm_fwd_bf16 and as the autograd input gradient of a 1x1 convolution
@@ -496,6 +509,29 @@ int s2f_dcnv3_bwd(const float* input, const float* offset, const float* mask, co
                   float* grad_input, float* grad_offset, float* grad_mask, int N, int H, int W, int G, int Cg, int Kh,
                   int Kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float offset_scale,
                   void* stream);
+
+/* ---- f2: one training iteration's parameter update (csrc/optim.hip, round 5) -------------------------------------------
+ * Replaces mmengine OptimWrapper.update_params for the Spike2Former configs
+ * (configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:137-155): torch.nn.utils.clip_grad_norm_(max_norm = 0.01,
+ * norm_type = 2) + torch.optim.AdamW.step() with one (lr, weight_decay) pair per parameter (`custom_keys` multipliers), over
+ * the flat gradient buffer of the data-parallel step (dist.FlatGradAllReduce: 16-byte-aligned slots, zero pads).
+ *   s2f_grad_sqnorm_parts(n)   number of fp64 partials s2f_grad_sqnorm writes for n elements
+ *   s2f_grad_sqnorm            partials[i] = sum of g^2 over the i-th run of 16 384 elements (plain stores: bit-repeatable)
+ *   s2f_adamw_prepare          state[0] = clip coefficient min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: 1), [1] = norm,
+ *                              [4] += 1 (the step count t), [2] = 1 - beta1^t, [3] = sqrt(1 - beta2^t); state = float[8], zeroed
+ *                              by the caller before the first iteration
+ *   s2f_adamw_step             slots int64 [nslots][3] = {parameter pointer, slot offset in g / m / v (elements, % 4 == 0),
+ *                              numel}; hyper float [nslots][2] = {lr, weight_decay} of THIS iteration; chunks int32 [nchunks][2]
+ *                              = {slot, first element} covering every slot in runs of s2f_adamw_chunk_elems();
+ *                              g' = g * state[0]; p *= 1 - lr wd; m += (g' - m)(1 - beta1); v = beta2 v + (1 - beta2) g'^2;
+ *                              p -= lr / state[2] * m / (sqrt(v) / state[3] + eps)      (torch/optim/adamw.py, single-tensor form)
+ * All tables are DEVICE memory; nothing synchronises, so the three launches can be captured behind the step's hipGraph. */
+int64_t s2f_grad_sqnorm_parts(int64_t n);
+int s2f_grad_sqnorm(const float* g, int64_t n, double* partials, void* stream);
+int s2f_adamw_prepare(const double* partials, int nparts, float max_norm, float beta1, float beta2, float* state, void* stream);
+int s2f_adamw_chunk_elems(void);
+int s2f_adamw_step(const int64_t* slots, const float* hyper, const int32_t* chunks, int nchunks, const float* g, float* m, float* v,
+                   const float* state, float beta1, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,9 @@ SIGNATURES = {
     "s2f_spike_gemm_dw_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_fwd_bf16_ex": (_i, [_p, _i64, _p, _i64, _i, _i64, _p, _i64, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_dw_grouped": (_i, [_p, _i, _i, _p]),
+    "s2f_spike_gemm_dw_pipe_ok": (_i, [_i] * 4),
+    "s2f_spike_gemm_dw_pipe": (_i, [_p, _p, _p] + [_i] * 7 + [_p]),
+    "s2f_spike_gemm_dw_pipe_grouped": (_i, [_p, _i, _i, _i, _p]),
     "s2f_spike_conv3x3_dw_bf16": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "s2f_gemm_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 6 + [_i] * 4 + [_f, _i, _p]),
     "s2f_conv3x3_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 6 + [_i] * 5 + [_f, _i, _p]),
@@ -97,6 +100,11 @@ SIGNATURES = {
     "s2f_sdsa_apply": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "s2f_dcnv3_fwd": (_i, [_p] * 4 + [_i] * 13 + [_f, _p]),
     "s2f_dcnv3_bwd": (_i, [_p] * 7 + [_i] * 13 + [_f, _p]),
+    "s2f_grad_sqnorm_parts": (_i64, [_i64]),
+    "s2f_grad_sqnorm": (_i, [_p, _i64, _p, _p]),
+    "s2f_adamw_prepare": (_i, [_p, _i, _f, _f, _f, _p, _p]),
+    "s2f_adamw_chunk_elems": (_i, []),
+    "s2f_adamw_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _p]),
 }
 
 

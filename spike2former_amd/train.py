@@ -6,7 +6,9 @@ the Spike2Former configs (configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_
 
 mmengine itself is not part of the reference tree (third-party, mmengine 0.8.4 per Seg/README.md:25): `parse_losses`,
 the `custom_keys` rule of DefaultOptimWrapperConstructor and the two schedulers are restated from its published behaviour;
-parity is pinned by the config's own values only.  The optimiser is torch.optim.AdamW, which is what the reference runs."""
+parity is pinned by the config's own values only.  The reference's optimiser is torch.optim.AdamW behind clip_grad_norm_;
+`OptimWrapper` runs exactly that (eager, one group per parameter), `FlatAdamW` is the same update as three HIP launches over
+the flat gradient buffer of the data-parallel step (csrc/optim.hip), pinned against the former in tests/test_gpu_optim.py."""
 import torch
 
 from .neuron import reset_net
@@ -47,6 +49,138 @@ def param_groups(model, lr, weight_decay, paramwise_cfg=None):
     return groups
 
 
+def _multipliers(names, paramwise_cfg):
+    """DefaultOptimWrapperConstructor's `custom_keys` rule per parameter name -> [(lr_mult, decay_mult)]"""
+    custom = dict((paramwise_cfg or {}).get("custom_keys", {}))
+    keys = sorted(sorted(custom.keys()), key=len, reverse=True)
+    out = []
+    for name in names:
+        lm, dm = 1.0, 1.0
+        for k in keys:
+            if k in name:
+                lm, dm = custom[k].get("lr_mult", 1.0), custom[k].get("decay_mult", 1.0)
+                break
+        out.append((lm, dm))
+    return out
+
+
+class FlatAdamW:
+    """clip_grad_norm_(max_norm) + AdamW over `dist.FlatGradAllReduce`'s flat gradient buffer: three HIP launches per iteration
+    (s2f_grad_sqnorm -> s2f_adamw_prepare -> s2f_adamw_step), no host synchronisation -- `step()` can be captured behind the
+    step's hipGraph (graph.GraphedStep(optimizer=...)) or called eagerly after the all-reduce when N > 1.
+
+    What mmengine's OptimWrapper does for the config (configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:137-155) with
+    ~1 000 single-parameter groups: gradients are read where the step packed (and the all-reduce averaged) them, both moments
+    are flat buffers of the same layout, parameters are addressed through a pointer table (they stay where their modules own
+    them).  `param_groups` is a list of {'lr', 'weight_decay', 'name'} dictionaries, one per parameter, that a scheduler
+    (LinearThenPoly) may rewrite between iterations; the table goes to the device at the start of `step()`.
+    Build it AFTER `grad_buffer.compact()`: the tables follow the buffer's layout (checked at every step)."""
+
+    def __init__(self, model, grad_buffer, lr=0.001, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.005, paramwise_cfg=None,
+                 clip_grad=None):
+        from ._lib import lib
+        self.red, self.betas, self.eps = grad_buffer, (float(betas[0]), float(betas[1])), float(eps)
+        self.max_norm = float((clip_grad or {}).get("max_norm", 0.0)) if clip_grad else 0.0
+        if clip_grad and clip_grad.get("norm_type", 2) != 2:
+            raise NotImplementedError("FlatAdamW clips by the 2-norm (the Spike2Former configs' norm_type)")
+        names = {id(p): n for n, p in model.named_parameters()}
+        self.params = list(grad_buffer.params)
+        mult = _multipliers([names.get(id(p), "") for p in self.params], paramwise_cfg)
+        self.param_groups = [{"params": [p], "lr": lr * lm, "weight_decay": weight_decay * dm, "name": names.get(id(p), "")}
+                             for p, (lm, dm) in zip(self.params, mult)]
+        dev = grad_buffer.flat.device
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(grad_buffer.flat), torch.zeros_like(grad_buffer.flat)
+        n = grad_buffer.flat.numel()
+        self.partials = torch.zeros(int(lib.s2f_grad_sqnorm_parts(n)), dtype=torch.float64, device=dev)
+        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.empty(len(self.params), 2, dtype=torch.float32)
+        if dev.type == "cuda":
+            self._hyper_host = self._hyper_host.pin_memory()
+        self.hyper = torch.zeros(len(self.params), 2, dtype=torch.float32, device=dev)
+        self._build_tables()
+
+    def _build_tables(self):
+        from ._lib import lib
+        chunk = int(lib.s2f_adamw_chunk_elems())
+        dev = self.red.flat.device
+        self._layout = (tuple(self.red.offsets), tuple(p.data_ptr() for p in self.params))
+        slots, chunks = [], []
+        for i, (p, off) in enumerate(zip(self.params, self.red.offsets)):
+            if not p.is_contiguous():
+                raise RuntimeError("FlatAdamW: parameters must be contiguous")
+            slots.append((p.data_ptr(), off, p.numel()))
+            chunks += [(i, s) for s in range(0, p.numel(), chunk)]
+        self.slots = torch.tensor(slots, dtype=torch.int64).to(dev)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+
+    def sync_hyper(self):
+        """the per-parameter (lr, weight_decay) table of this iteration -> device (one small copy)"""
+        for i, g in enumerate(self.param_groups):
+            self._hyper_host[i, 0], self._hyper_host[i, 1] = g["lr"], g["weight_decay"]
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def step(self, sync_hyper=True):
+        """Gradients: `grad_buffer.flat` as the step left it (packed, averaged).  -> the gradient norm (device scalar)."""
+        from ._lib import check, lib
+        from .ops.core import _stream
+        if (tuple(self.red.offsets), tuple(p.data_ptr() for p in self.params)) != self._layout or self.red.params != self.params:
+            raise RuntimeError("FlatAdamW: the gradient buffer's layout (compact()) or a parameter's storage changed since the tables "
+                               "were built; call rebuild()")
+        if sync_hyper:
+            self.sync_hyper()
+        flat, b1, b2 = self.red.flat, self.betas[0], self.betas[1]
+        s = _stream()
+        check(lib.s2f_grad_sqnorm(flat.data_ptr(), flat.numel(), self.partials.data_ptr(), s), "s2f_grad_sqnorm")
+        check(lib.s2f_adamw_prepare(self.partials.data_ptr(), self.partials.numel(), self.max_norm, b1, b2, self.state.data_ptr(), s),
+              "s2f_adamw_prepare")
+        check(lib.s2f_adamw_step(self.slots.data_ptr(), self.hyper.data_ptr(), self.chunks.data_ptr(), self.chunks.shape[0],
+                                 flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.state.data_ptr(),
+                                 b1, b2, self.eps, s), "s2f_adamw_step")
+        # the kernels wrote the parameters behind autograd's back: bump their version counters so that every cache keyed on a
+        # weight's version (the bf16 term splits / packs of ops.gemm) re-converts in eager use; a captured step re-converts inside
+        # the graph anyway (ops.resplit_all)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.autograd.graph.increment_version(self.params)
+        return self.state[1]
+
+    def rebuild(self):
+        """after grad_buffer.compact(): re-lay the moments out with the buffer (values kept per parameter)"""
+        old_off = dict(zip((id(p) for p in self.params), self._layout[0]))
+        m, v = torch.zeros_like(self.red.flat), torch.zeros_like(self.red.flat)
+        groups = {id(g["params"][0]): g for g in self.param_groups}
+        for p, off in zip(self.red.params, self.red.offsets):
+            o = old_off[id(p)]
+            m[off:off + p.numel()] = self.exp_avg[o:o + p.numel()]
+            v[off:off + p.numel()] = self.exp_avg_sq[o:o + p.numel()]
+        self.exp_avg, self.exp_avg_sq = m, v
+        self.params = list(self.red.params)
+        self.param_groups = [groups[id(p)] for p in self.params]
+        self._build_tables()
+
+    @property
+    def grad_norm(self):
+        return self.state[1]
+
+    @property
+    def clip_coef(self):
+        return self.state[0]
+
+    def state_dict(self):
+        """per-parameter moments by name + the step count (what torch.optim.AdamW.state_dict carries, keyed by name)"""
+        out = {"step": int(self.state[4].item()), "state": {}}
+        for g, p, off in zip(self.param_groups, self.params, self.red.offsets):
+            out["state"][g["name"]] = {"exp_avg": self.exp_avg[off:off + p.numel()].view_as(p).clone(),
+                                       "exp_avg_sq": self.exp_avg_sq[off:off + p.numel()].view_as(p).clone()}
+        return out
+
+    def load_state_dict(self, sd):
+        self.state[4] = float(sd["step"])
+        for g, p, off in zip(self.param_groups, self.params, self.red.offsets):
+            st = sd["state"][g["name"]]
+            self.exp_avg[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+
+
 class LinearThenPoly:
     """LinearLR(start_factor, begin=0, end=warmup) followed by PolyLR(eta_min, power, begin=warmup, end=total), by iteration:
     factor(t) multiplies every group's base lr."""
@@ -61,8 +195,11 @@ class LinearThenPoly:
     def factor(self, t):
         if t < self.warmup:
             return self.start_factor + (1.0 - self.start_factor) * t / max(self.warmup - 1, 1) if self.warmup > 1 else 1.0
-        span = max(self.total - self.warmup, 1)
-        return max(1.0 - (t - self.warmup) / span, 0.0) ** self.power
+        # mmengine 0.8.4 PolyLR.__init__: total_iters = end - begin - 1; its recursive rule
+        #   lr_t = (lr_{t-1} - eta_min) * (1 - 1 / (total_iters - s + 1))^power + eta_min,  s = t - begin = 1 .. total_iters
+        # telescopes to (1 - s / total_iters)^power: the floor eta_min is reached at t = end - 1 and held
+        span = max(self.total - self.warmup - 1, 1)
+        return max(1.0 - min(t - self.warmup, span) / span, 0.0) ** self.power
 
     def _apply(self):
         f = self.factor(self.t)

@@ -1,31 +1,13 @@
 #!/bin/bash
-# tools/isa.sh <file.hip> [kernel-name-substring]: gfx950 ISA of one translation unit -> /tmp/t/<file>.s, resource summary,
-# and (with a substring) the compact instruction stream of the matching kernels.
-set -e
-F=$1; B=$(basename $F .hip); mkdir -p /tmp/t
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function --cuda-device-only -S /root/repo/spike2former_amd/csrc/$B.hip -o /tmp/t/$B.s 2>&1 | grep -E "error|warning: [^a]" || true
-grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count|group_segment_fixed_size):" /tmp/t/$B.s | paste - - - - | awk '{print $4, "vgpr", $6, "spill", $8, "lds", $2}' | sed 's/_ZN12_GLOBAL__N_1//' | { [ -n "$2" ] && grep "$2" || cat; }
-if [ -n "$2" ]; then python3 - "$B" "$2" <<'PY'
-import sys, itertools, re
-s = open(f'/tmp/t/{sys.argv[1]}.s').read()
-for m in re.finditer(r'^(_Z\S*' + re.escape(sys.argv[2]) + r'\S*):', s, flags=re.M):
-    name = m.group(1); i = m.start(); j = s.index('.Lfunc_end', i)
-    seq = []
-    for l in s[i:j].split('\n')[1:]:
-        t = l.strip()
-        if not t or t.startswith(';'): continue
-        if t.startswith('.LBB'): seq.append('\n ' + t.split()[0]); continue
-        if t.startswith('.'): continue
-        op = t.split()[0]
-        if op == 's_waitcnt': op = t.split(';')[0].strip().replace('s_waitcnt ', 'W:')
-        elif 'mfma' in op: op = 'MFMA'
-        elif op.startswith('v_mov'): op = 'vmov'
-        elif op.startswith('v_'): op = 'V'
-        elif op.startswith('s_') and not re.match(r's_(barrier|cbranch|branch|endpgm)', op): op = 'S'
-        seq.append(op)
-    out = []
-    for k, g in itertools.groupby(seq):
-        n = len(list(g)); out.append(f"{k}x{n}" if n > 1 else k)
-    print(name[:110]); print(' '.join(out)[:int(sys.argv[3]) if len(sys.argv) > 3 else 3500])
-PY
+# Instruction-stream skeleton of one kernel of a csrc/*.hip file:  bash tools/isa.sh <file.hip> <kernel-name-regex> [full]
+# (barriers, waits, memory instructions, MFMAs and LDS reads counted in runs; `full` prints the whole stream)
+cd "$(dirname "$0")/../spike2former_amd/csrc"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics --cuda-device-only -S "$1" -o /tmp/isa_$$.s 2>/dev/null
+L=$(grep -nE "^_Z.*($2).*:" /tmp/isa_$$.s | head -1 | cut -d: -f1)
+[ -z "$L" ] && { echo "no kernel matches $2"; grep -nE "^_Z.*:" /tmp/isa_$$.s | cut -c1-160; exit 1; }
+tail -n +"$L" /tmp/isa_$$.s | awk '/s_endpgm/{print; exit} {print}' > /tmp/isa_$$.k
+if [ "$3" = full ]; then cat /tmp/isa_$$.k; else
+grep -nE "s_barrier|s_waitcnt|v_mfma|ds_read|ds_write|global_load|buffer_load|global_store|s_setprio|^\.LBB|global_atomic|s_endpgm" /tmp/isa_$$.k |
+  awk '{ if ($0 ~ /v_mfma/) {m++; next} if ($0 ~ /ds_read/) {r++; next} if (m>0) {print "   ... " m " mfma"; m=0} if (r>0) {print "   ... " r " ds_read"; r=0} print }'
 fi
+rm -f /tmp/isa_$$.s /tmp/isa_$$.k
