@@ -528,10 +528,10 @@ int s2f_dcnv3_bwd(const float* input, const float* offset, const float* mask, co
  * All tables are DEVICE memory; nothing synchronises, so the three launches can be captured behind the step's hipGraph. */
 int64_t s2f_grad_sqnorm_parts(int64_t n);
 int s2f_grad_sqnorm(const float* g, int64_t n, double* partials, void* stream);
-int s2f_adamw_prepare(const double* partials, int nparts, float max_norm, float beta1, float beta2, float* state, void* stream);
+int s2f_adamw_prepare(const double* partials, int nparts, float max_norm, double beta1, double beta2, float* state, void* stream);
 int s2f_adamw_chunk_elems(void);
 int s2f_adamw_step(const int64_t* slots, const float* hyper, const int32_t* chunks, int nchunks, const float* g, float* m, float* v,
-                   const float* state, float beta1, float beta2, float eps, void* stream);
+                   const float* state, double beta1, double beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

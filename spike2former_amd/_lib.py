@@ -102,9 +102,9 @@ SIGNATURES = {
     "s2f_dcnv3_bwd": (_i, [_p] * 7 + [_i] * 13 + [_f, _p]),
     "s2f_grad_sqnorm_parts": (_i64, [_i64]),
     "s2f_grad_sqnorm": (_i, [_p, _i64, _p, _p]),
-    "s2f_adamw_prepare": (_i, [_p, _i, _f, _f, _f, _p, _p]),
+    "s2f_adamw_prepare": (_i, [_p, _i, _f, ctypes.c_double, ctypes.c_double, _p, _p]),
     "s2f_adamw_chunk_elems": (_i, []),
-    "s2f_adamw_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _p]),
+    "s2f_adamw_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, ctypes.c_double, ctypes.c_double, _f, _p]),
 }
 
 

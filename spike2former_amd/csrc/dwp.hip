@@ -61,43 +61,38 @@ constexpr int TM = 128, TK = 256, BL = 32;
 constexpr int A_PLANE = TM * 64;                 // one term plane: 128 rows x 64 bytes
 constexpr int A_STAGE = 3 * A_PLANE;             // 24 KiB
 constexpr int B_STAGE = TK * 64;                 // 16 KiB
-constexpr int NA = 2, NB = 4;
-constexpr int LDS_BYTES = NA * A_STAGE + NB * B_STAGE;          // 112 KiB: one workgroup per CU
+constexpr int RAW_SLOT = TM * BL * 4;            // fp32 dY tile as it arrives: 16 KiB (2 KiB per wavefront)
+constexpr int NRAW = 3;
 
-// SYM = true: the symmetric schedule for comparison (all eight wavefronts stage, barrier, multiply, barrier)
-// KO (probe builds only, S2F_DWP_PROBE): 1 = no MFMAs, 2 = no fragment reads, 4 = no loads / copies after the prologue, 8 = no staging
+// SYM = false: two halves in opposite phase (planes double-buffered, four ring slots: 160 KiB of LDS);
+// SYM = true : every wavefront in the same phase  stage | barrier | multiply | barrier  (one plane stage, three ring slots: 120 KiB)
+// KO (probe builds only, S2F_DWP_PROBE): 1 = no MFMAs, 2 = no fragment reads, 4 = no copies after the prologue, 8 = no staging
 template <bool SYM, int KO = 0>
 __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const unsigned short* __restrict__ X,
-                                         float* __restrict__ dW, int M, int K, int L, int total_steps, int sps, int k_tiles,
-                                         int tile, int split) {
-  // two OBJECTS: hipcc orders an LDS store behind every LDS-DMA in flight that it cannot prove disjoint (s_waitcnt vmcnt(0) in front
-  // of the ds_write of the dY planes, i.e. the X copies of the next tile drained every step when both lived in one array)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NA * A_STAGE];
-  __shared__ __attribute__((aligned(1024))) unsigned char smem_ring[NB * B_STAGE];
-  const int s_begin = split * sps;
-  const int n = min(total_steps, s_begin + sps) - s_begin;
+                                         float* __restrict__ dW, int M, int K, int L, int k_tiles, int tile, int s_begin,
+                                         int n) {
+  constexpr int NA = SYM ? 1 : 2, NB = SYM ? 3 : 4;
+  // separate OBJECTS: hipcc orders an LDS store behind every LDS-DMA in flight that it cannot prove disjoint
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NA * A_STAGE];          // dY planes hi | mid | lo
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_ring[NB * B_STAGE];     // X tiles
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[NRAW * RAW_SLOT];   // dY tiles as fp32, one 16-byte mailbox per lane
   if (n <= 0) return;
   const int m0 = (tile / k_tiles) * TM, k0 = (tile % k_tiles) * TK;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, wn = wave & 3, wm = half;
 
-  // ---- staging shares: each half stages 64 rows of dY (2 float4 per thread) and 8 of the 16 X copies (2 per wavefront)
-  const int ht = tid & 255;
-  unsigned oa[2], aw[2];
+  // ---- this wavefront's share of a tile: 16 rows of dY (two copies of 8 rows x 128 bytes: lane -> row lane >> 3, float4
+  // lane & 7, landing in mailbox `lane` of the copy) and 32 rows of X (two copies of 16 rows x 64 bytes)
+  unsigned oa[2], aw[2], ob[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = ht + i * 256;
-    const int row = half * 64 + (c >> 3), q4 = c & 7;
+    const int row = wave * 16 + i * 8 + (lane >> 3), q4 = lane & 7;
     oa[i] = ((unsigned)min(m0 + row, M - 1) * (unsigned)L + (unsigned)(q4 * 4)) * 4u;          // BYTES (M L < 2^30)
     aw[i] = (unsigned)(row * 64 + ((((q4 >> 1) ^ ((row >> 2) & 3))) << 4) + (q4 & 1) * 8);
-  }
-  unsigned ob[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int r = (wave * 2 + q) * 16 + (lane >> 2);
+    const int r = (wave * 2 + i) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((r >> 2) & 3);
-    ob[q] = ((unsigned)min(k0 + r, K - 1) * (unsigned)L + (unsigned)(c * 8)) * 2u;          // BYTES (K L < 2^31)
+    ob[i] = ((unsigned)min(k0 + r, K - 1) * (unsigned)L + (unsigned)(c * 8)) * 2u;             // BYTES (K L < 2^31)
   }
   // ---- fragment addresses (bytes inside a stage)
   unsigned aoff[2][2], boff[2][2];
@@ -111,6 +106,7 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
       boff[ks][i] = (unsigned)(rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4));
     }
   const unsigned smem_a = lds_addr(smem), smem_b = lds_addr(smem_ring);
+  const unsigned raw_mine = lds_addr(smem_raw) + wave * 2048 + lane * 16;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -120,23 +116,22 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // cursor of the next tile to LOAD (wave-uniform): batch element, contraction offset
+  // cursor of the next tile to REQUEST (wave-uniform): batch element, contraction offset, ring positions
   const int lsteps = L >> 5;
   int cb = s_begin / lsteps, cl = (s_begin - cb * lsteps) << 5;
-  int next_slot = 0, loaded = 0;
-  f32x4 areg0[2], areg1[2];                    // dY shares of the even / odd tiles in flight (two tiles ahead)
-  auto load_next = [&](f32x4 (&areg)[2]) __attribute__((always_inline)) {
-    // wave-uniform base + loop-invariant 32-bit byte offset per lane
+  int next_slot = 0, next_raw = 0, loaded = 0;
+  // one group = 4 copies per wavefront: {dY rows 0-7, dY rows 8-15, X rows 0-15, X rows 16-31} of its share
+  auto request = [&]() __attribute__((always_inline)) {
     const char* pa = reinterpret_cast<const char*>(dY + (int64_t)cb * M * L + cl);
     const char* px = reinterpret_cast<const char*>(X + (int64_t)cb * K * L + cl);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) areg[i] = *reinterpret_cast<const f32x4*>(pa + oa[i]);
+    for (int i = 0; i < 2; ++i) dma16(pa, oa[i], smem_raw + next_raw * RAW_SLOT + wave * 2048 + i * 1024);
 #pragma unroll
     for (int q = 0; q < 2; ++q) dma16(px, ob[q], smem_ring + next_slot * B_STAGE + (wave * 2 + q) * 1024);
     next_slot = next_slot == NB - 1 ? 0 : next_slot + 1;
-    // Past the last tile the cursor stays where it is: the requests are issued UNCONDITIONALLY (a re-read of the last tile into
-    // registers nobody consumes and a ring slot nobody reads again) -- a conditional request makes hipcc count the outstanding
-    // operations of the path WITHOUT it, i.e. wait for part of the newest group in the steady state.
+    next_raw = next_raw == NRAW - 1 ? 0 : next_raw + 1;
+    // past the last tile the cursor stays: the requests are issued unconditionally (into slots nobody reads again), so that the
+    // number of copies in flight at any point of the loop does not depend on the path taken
     if (++loaded < n) {
       cl += BL;
       if (cl == L) {
@@ -145,29 +140,42 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
       }
     }
   };
-  // S(u): this thread's share of dY tile u (held in `areg`) goes into stage u & 1; then tile u + 2 is requested into the same
-  // registers and ring slot (u + 2) % 4.  In flight at the head of S(u): the group {2 loads, 2 copies} of tile u + 1 (allowed to
-  // stay in flight: vmcnt(4)) behind the group of tile u, which must have landed -- it was issued two steps ago.
-  auto stage = [&](int u, f32x4 (&areg)[2]) __attribute__((always_inline)) {
+  // S(u): this wavefront's 16 rows of dY tile u -- landed in its own mailboxes, so no barrier is needed between the copy and the
+  // conversion -- are split hi + mid + lo into plane stage u % NA; then tile u + 2 is requested.  In flight at the head of S(u):
+  // group u + 1 (4 copies: may stay in flight) behind group u.
+  int raw_slot = 0;
+  auto stage = [&](int u) __attribute__((always_inline)) {
     if (u >= n || (KO & 8)) return;
-    if (u + 1 < n && !(KO & 4)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned char* as = smem + (u & 1) * A_STAGE;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const unsigned rb_ = raw_mine + raw_slot * RAW_SLOT;
+    raw_slot = raw_slot == NRAW - 1 ? 0 : raw_slot + 1;
+    f32x4 v[2];
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(rb_));
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v[1]) : "v"(rb_));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+    unsigned char* as = smem + (NA == 1 ? 0 : (u & 1)) * A_STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const f32x4 v = areg[i];
       unsigned h0, m0_, l0_, h1, m1, l1;
-      s2f_split3x2(v.x, v.y, h0, m0_, l0_);
-      s2f_split3x2(v.z, v.w, h1, m1, l1);
-      *reinterpret_cast<u32x2*>(as + aw[i]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(as + A_PLANE + aw[i]) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(as + 2 * A_PLANE + aw[i]) = u32x2{l0_, l1};
+      if (KO & 16) {
+        h0 = __float_as_uint(v[i].x), h1 = __float_as_uint(v[i].y), m0_ = __float_as_uint(v[i].z), m1 = __float_as_uint(v[i].w), l0_ = h0, l1 = m1;
+      } else {
+        s2f_split3x2(v[i].x, v[i].y, h0, m0_, l0_);
+        s2f_split3x2(v[i].z, v[i].w, h1, m1, l1);
+      }
+      if (KO & 32) {
+        asm volatile("" ::"v"(h0), "v"(h1), "v"(m0_), "v"(m1), "v"(l0_), "v"(l1));
+      } else {
+        *reinterpret_cast<u32x2*>(as + aw[i]) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(as + A_PLANE + aw[i]) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(as + 2 * A_PLANE + aw[i]) = u32x2{l0_, l1};
+      }
     }
-    if (!(KO & 4)) load_next(areg);
+    if (!(KO & 4)) request();
   };
   // C(t): 16 fragment reads requested at once, the MFMAs of k slice 0 run under the landing of slice 1's fragments
   auto compute = [&](int t, int slot) __attribute__((always_inline)) {
-    const unsigned ab = smem_a + (t & 1) * A_STAGE, bb = smem_b + slot * B_STAGE;
+    const unsigned ab = smem_a + (NA == 1 ? 0 : (t & 1)) * A_STAGE, bb = smem_b + slot * B_STAGE;
     bf16x8 bf[2][2], af[2][3][2];
     if (KO & 2) {
 #pragma unroll
@@ -207,48 +215,41 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
   };
 
   // prologue: tiles 0 and 1 requested, tile 0 staged by everybody (which requests tile 2)
-  load_next(areg0);
-  load_next(areg1);
-  stage(0, areg0);
+  request();
+  request();
+  stage(0);
   if (half == 1 && !SYM) asm volatile("s_setprio 1");
   phase_barrier();
   int slot = 0;
 #define S2F_NEXT_SLOT slot = slot == NB - 1 ? 0 : slot + 1
-  // Both loops START with the staging segment: hipcc waits for the dY registers at the loop header, which must be the point
-  // where they are consumed -- two steps after their loads were issued -- not the head of a multiply segment.  Unrolled by two:
-  // the register set of a tile is chosen by its parity.
-  if (SYM || half == 0) {
+  if (SYM) {
+    // the planes have ONE stage: S(k + 1) follows the barrier behind C(k)
+    for (int k = 0; k < n; ++k) {
+      compute(k, slot);
+      S2F_NEXT_SLOT;
+      phase_barrier();
+      stage(k + 1);
+      phase_barrier();
+    }
+  } else if (half == 0) {
+    // half 0:  C(0) | S(1) | C(1) | S(2) | ...          half 1:  S(1) | C(0) | S(2) | C(1) | ...
     compute(0, 0);
     slot = 1;
     phase_barrier();
-    for (int k = 1; k < n; k += 2) {
-      stage(k, areg1);
+    for (int k = 1; k < n; ++k) {
+      stage(k);
       phase_barrier();
       compute(k, slot);
       S2F_NEXT_SLOT;
       phase_barrier();
-      if (k + 1 < n) {
-        stage(k + 1, areg0);
-        phase_barrier();
-        compute(k + 1, slot);
-        S2F_NEXT_SLOT;
-        phase_barrier();
-      }
     }
   } else {
-    for (int k = 0; k < n; k += 2) {
-      stage(k + 1, areg1);
+    for (int k = 0; k < n; ++k) {
+      stage(k + 1);
       phase_barrier();
       compute(k, slot);
       S2F_NEXT_SLOT;
-      if (k < n - 1) {
-        phase_barrier();
-        stage(k + 2, areg0);
-        phase_barrier();
-        compute(k + 1, slot);
-        S2F_NEXT_SLOT;
-        if (k + 1 < n - 1) phase_barrier();
-      }
+      if (k < n - 1) phase_barrier();
     }
   }
 #undef S2F_NEXT_SLOT
@@ -271,46 +272,52 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     }
 }
 
-// workgroup f runs on XCD f % 8: give each XCD a contiguous range of (split, tile) ids, tile fastest -- the tiles of one
-// contraction split stream the same dY / X slices at the same time and share them through that XCD's L2 (see gemm_bf16.hip)
+// workgroup f runs on XCD f % 8: give each XCD a contiguous range of the linearised work, so that the workgroups of one XCD stream
+// neighbouring tiles of the same job (shared dY rows / X rows) through that XCD's L2 (see gemm_bf16.hip)
 __device__ __forceinline__ int xcd_contiguous(int f, int total) {
   const int chunk = total >> 3, rem = total & 7;
   const int xcd = f & 7, idx = f >> 3;
   return xcd * chunk + min(xcd, rem) + idx;
 }
 
-template <bool SYM, int KO = 0>
-__global__ __launch_bounds__(512, 1) void dwp_kernel(const float* __restrict__ dY, const unsigned short* __restrict__ X,
-                                                     float* __restrict__ dW, int M, int K, int L, int total_steps, int sps,
-                                                     int k_tiles, int tiles) {
-  const int id = xcd_contiguous(blockIdx.x, gridDim.x);
-  dwp_body<SYM, KO>(dY, X, dW, M, K, L, total_steps, sps, k_tiles, id % tiles, id / tiles);
-}
-
+// Work decomposition ("stream-K"): the (tile, contraction step) pairs of all jobs are laid out in one line -- job by job, tile by
+// tile, a tile's steps consecutive -- and workgroup w takes the w-th of gridDim.x EQUAL pieces of it.  A piece is at most a tail
+// of one tile, some whole tiles, a head of another: the accumulators are flushed (fp32 atomics) when the tile changes, i.e. one
+// flush per (workgroup, tile touched) instead of one per fixed-length contraction split -- the 128 KiB atomic tile of a
+// 768-workgroup split cost 88 us of a 400 us launch (tools/probe_dwp_ko.py: "barriers + epilogue only"); every CU gets the same
+// amount of work, there is no second, partly filled round.
 constexpr int kMaxJobs = 56;
 struct DwpJob {
   const float* dY;
   const unsigned short* X;
   float* dW;
-  int M, K, L, total_steps;
-  int first_block, sps, k_tiles, tiles;
+  int M, K, L, steps;          // steps = batch * L / 32 contraction steps per tile
+  int first_work, k_tiles;     // first_work: index of this job's first (tile, step) pair in the line
 };
 struct DwpJobTable {
-  int njobs;
+  int njobs, work, quota;      // work: total (tile, step) pairs; quota: pairs per workgroup
   DwpJob job[kMaxJobs];
 };
 
 template <bool SYM, int KO = 0>
 __global__ __launch_bounds__(512, 1) void dwp_grouped_kernel(const DwpJobTable tab) {
   const int id = xcd_contiguous(blockIdx.x, gridDim.x);
-  int lo = 0, hi = tab.njobs - 1;                         // last job whose first block <= id (wave-uniform)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tab.job[mid].first_block <= id) lo = mid; else hi = mid - 1;
+  int w0 = id * tab.quota;
+  const int w1 = min(tab.work, w0 + tab.quota);
+  while (w0 < w1) {
+    int lo = 0, hi = tab.njobs - 1;                       // last job whose first pair <= w0 (wave-uniform)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab.job[mid].first_work <= w0) lo = mid; else hi = mid - 1;
+    }
+    const DwpJob& j = tab.job[lo];
+    const int local = w0 - j.first_work;
+    const int tile = local / j.steps, s = local - tile * j.steps;
+    const int n = min(j.steps - s, w1 - w0);
+    dwp_body<SYM, KO>(j.dY, j.X, j.dW, j.M, j.K, j.L, j.k_tiles, tile, s, n);
+    w0 += n;
+    __syncthreads();                                      // the next piece re-uses the LDS stages
   }
-  const DwpJob& j = tab.job[lo];
-  const int local = id - j.first_block;
-  dwp_body<SYM, KO>(j.dY, j.X, j.dW, j.M, j.K, j.L, j.total_steps, j.sps, j.k_tiles, local % j.tiles, local / j.tiles);
 }
 
 bool dwp_shape_ok(int batch, int M, int K, int L) {
@@ -323,30 +330,49 @@ bool dwp_shape_ok(int batch, int M, int K, int L) {
 // 1 when the pipelined kernel takes this shape (the host's dispatch asks before choosing it)
 extern "C" int s2f_spike_gemm_dw_pipe_ok(int batch, int M, int K, int L) { return dwp_shape_ok(batch, M, K, L) ? 1 : 0; }
 
-// dW (+)= sum_b dY[b] X[b]^T on the pipelined kernel.  cfg: 0 = two-halves schedule, 1 = symmetric schedule (probe);
-// target_wgs <= 0: the default number of workgroups the contraction is split for.
+static int dwp_launch_table(DwpJobTable& tab, int cfg, int target_wgs, void* stream, const char* who) {
+  int64_t work = 0;
+  for (int i = 0; i < tab.njobs; ++i) {
+    DwpJob& j = tab.job[i];
+    j.k_tiles = (j.K + TK - 1) / TK;
+    j.first_work = (int)work;
+    work += (int64_t)((j.M + TM - 1) / TM) * j.k_tiles * j.steps;
+    S2F_REQUIRE(work < (1ll << 30), S2F_EINVAL, "%s: too much work for one launch", who);
+  }
+  // one workgroup per CU (256 on MI355X); at least 8 steps per workgroup
+  if (target_wgs <= 0) target_wgs = 256;
+  int quota = (int)((work + target_wgs - 1) / target_wgs);
+  if (quota < 8) quota = 8;
+  const int wgs = (int)((work + quota - 1) / quota);
+  tab.work = (int)work, tab.quota = quota;
+  hipStream_t s = (hipStream_t)stream;
+#ifdef S2F_DWP_PROBE
+#define S2F_KO(N) if (cfg == 2 * N + 1) { S2F_LAUNCH(true, true, (dwp_grouped_kernel<true, N>), dim3((unsigned)wgs), dim3(512), 0, s, tab); return s2f_check_launch("ko"); } \
+                  if (cfg == 2 * N) { S2F_LAUNCH(true, true, (dwp_grouped_kernel<false, N>), dim3((unsigned)wgs), dim3(512), 0, s, tab); return s2f_check_launch("ko"); }
+  S2F_KO(1) S2F_KO(3) S2F_KO(4) S2F_KO(12) S2F_KO(15) S2F_KO(20) S2F_KO(36) S2F_KO(52) S2F_KO(48)
+#undef S2F_KO
+#endif
+  if (cfg == 1)
+    S2F_LAUNCH(true, true, (dwp_grouped_kernel<true>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
+  else
+    S2F_LAUNCH(true, true, (dwp_grouped_kernel<false>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
+  return s2f_check_launch(who);
+}
+
+// dW (+)= sum_b dY[b] X[b]^T on the pipelined kernel.  cfg: 0 = two-halves schedule, 1 = symmetric schedule;
+// target_wgs <= 0: one workgroup per CU.
 extern "C" int s2f_spike_gemm_dw_pipe(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L,
                                       int accumulate, int cfg, int target_wgs, void* stream) {
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw_pipe: null pointer");
   S2F_REQUIRE(dwp_shape_ok(batch, M, K, L), S2F_EINVAL, "s2f_spike_gemm_dw_pipe: needs L %% 32 == 0, M L < 2^30, K L < 2^31 (M=%d K=%d L=%d)",
               M, K, L);
   S2F_REQUIRE(s2f_aligned16(dY) && s2f_aligned16(X), S2F_EALIGN, "s2f_spike_gemm_dw_pipe: operands must be 16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, s) != S2F_OK)
+  if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, (hipStream_t)stream) != S2F_OK)
     return s2f_check_launch("s2f_spike_gemm_dw_pipe memset");
-  const int k_tiles = (K + TK - 1) / TK, tiles = ((M + TM - 1) / TM) * k_tiles;
-  const int total = batch * (L >> 5);
-  if (target_wgs <= 0) target_wgs = 768;
-  int sps = (int)(((int64_t)total * tiles + target_wgs - 1) / target_wgs);
-  if (sps < 8) sps = 8;
-  if (sps > total) sps = total;
-  const int splits = (total + sps - 1) / sps;
-  const dim3 grid((unsigned)(tiles * splits));
-  if (cfg == 1)
-    S2F_LAUNCH(true, true, (dwp_kernel<true>), grid, dim3(512), 0, s, dY, X, dW, M, K, L, total, sps, k_tiles, tiles);
-  else
-    S2F_LAUNCH(true, true, (dwp_kernel<false>), grid, dim3(512), 0, s, dY, X, dW, M, K, L, total, sps, k_tiles, tiles);
-  return s2f_check_launch("s2f_spike_gemm_dw_pipe");
+  DwpJobTable tab;
+  tab.njobs = 1;
+  tab.job[0] = DwpJob{dY, X, dW, M, K, L, batch * (L >> 5), 0, 0};
+  return dwp_launch_table(tab, cfg, target_wgs, stream, "s2f_spike_gemm_dw_pipe");
 }
 
 // MANY weight gradients in one launch (what s2f_spike_gemm_dw_grouped is to the round-2 kernel).  jobs (HOST array):
@@ -355,7 +381,6 @@ extern "C" int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, in
   S2F_REQUIRE(jobs && njobs > 0 && njobs <= kMaxJobs, S2F_EINVAL, "s2f_spike_gemm_dw_pipe_grouped: 1 .. %d jobs", kMaxJobs);
   DwpJobTable tab;
   tab.njobs = njobs;
-  int64_t work = 0;
   for (int i = 0; i < njobs; ++i) {
     const int64_t* r = jobs + 7 * i;
     DwpJob& j = tab.job[i];
@@ -366,33 +391,7 @@ extern "C" int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, in
     j.M = (int)r[4], j.K = (int)r[5], j.L = (int)r[6];
     S2F_REQUIRE(j.dY && j.X && j.dW && dwp_shape_ok(B, j.M, j.K, j.L), S2F_EINVAL, "s2f_spike_gemm_dw_pipe_grouped: bad job %d", i);
     S2F_REQUIRE(s2f_aligned16(j.dY) && s2f_aligned16(j.X), S2F_EALIGN, "s2f_spike_gemm_dw_pipe_grouped: job %d misaligned", i);
-    j.k_tiles = (j.K + TK - 1) / TK;
-    j.tiles = ((j.M + TM - 1) / TM) * j.k_tiles;
-    j.total_steps = B * (j.L >> 5);
-    work += (int64_t)j.tiles * j.total_steps;
+    j.steps = B * (j.L >> 5);
   }
-  if (target_wgs <= 0) target_wgs = 768;
-  int sps = (int)((work + target_wgs - 1) / target_wgs);
-  if (sps < 8) sps = 8;
-  int64_t first = 0;
-  for (int i = 0; i < njobs; ++i) {
-    DwpJob& j = tab.job[i];
-    j.sps = sps < j.total_steps ? sps : j.total_steps;
-    const int splits = (j.total_steps + j.sps - 1) / j.sps;
-    j.first_block = (int)first;
-    first += (int64_t)j.tiles * splits;
-  }
-  S2F_REQUIRE(first < (1ll << 31), S2F_EINVAL, "s2f_spike_gemm_dw_pipe_grouped: grid too large");
-  hipStream_t s = (hipStream_t)stream;
-#ifdef S2F_DWP_PROBE
-#define S2F_KO(N) if (cfg == 2 * N + 1) { S2F_LAUNCH(true, true, (dwp_grouped_kernel<true, N>), dim3((unsigned)first), dim3(512), 0, s, tab); return s2f_check_launch("ko"); } \
-                  if (cfg == 2 * N) { S2F_LAUNCH(true, true, (dwp_grouped_kernel<false, N>), dim3((unsigned)first), dim3(512), 0, s, tab); return s2f_check_launch("ko"); }
-  S2F_KO(1) S2F_KO(2) S2F_KO(3) S2F_KO(4) S2F_KO(8) S2F_KO(12) S2F_KO(13) S2F_KO(15)
-#undef S2F_KO
-#endif
-  if (cfg == 1)
-    S2F_LAUNCH(true, true, (dwp_grouped_kernel<true>), dim3((unsigned)first), dim3(512), 0, s, tab);
-  else
-    S2F_LAUNCH(true, true, (dwp_grouped_kernel<false>), dim3((unsigned)first), dim3(512), 0, s, tab);
-  return s2f_check_launch("s2f_spike_gemm_dw_pipe_grouped");
+  return dwp_launch_table(tab, cfg, target_wgs, stream, "s2f_spike_gemm_dw_pipe_grouped");
 }

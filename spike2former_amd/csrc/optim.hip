@@ -51,8 +51,8 @@ __global__ __launch_bounds__(kNormBlock) void grad_sqnorm_kernel(const float* __
 }
 
 // state[0] clip coefficient, [1] gradient norm, [2] 1 - beta1^t, [3] sqrt(1 - beta2^t), [4] t (after the increment)
-__global__ __launch_bounds__(256) void adamw_prepare_kernel(const double* __restrict__ part, int nparts, float max_norm, float beta1,
-                                                            float beta2, float* __restrict__ state) {
+__global__ __launch_bounds__(256) void adamw_prepare_kernel(const double* __restrict__ part, int nparts, float max_norm, double beta1,
+                                                            double beta2, float* __restrict__ state) {
   __shared__ double red[256];
   // fixed order: thread i owns the contiguous run [i * per, (i + 1) * per) of partials, then a tree over the 256 run sums
   const int per = (nparts + 255) / 256;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void adamw_prepare_kernel(const double* __rest
     const double t = (double)state[4] + 1.0;
     state[0] = (float)coef;
     state[1] = (float)norm;
-    state[2] = (float)(1.0 - pow((double)beta1, t));
-    state[3] = (float)sqrt(1.0 - pow((double)beta2, t));
+    state[2] = (float)(1.0 - pow(beta1, t));
+    state[3] = (float)sqrt(1.0 - pow(beta2, t));
     state[4] = (float)t;
   }
 }
@@ -86,14 +86,14 @@ constexpr int kChunk = 4096;          // elements per workgroup: 256 threads x 4
 __global__ __launch_bounds__(256) void adamw_step_kernel(const long long* __restrict__ slots, const float* __restrict__ hyper,
                                                          const int* __restrict__ chunks, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
-                                                         const float* __restrict__ state, float beta1, float beta2, float eps) {
+                                                         const float* __restrict__ state, float beta2, float omb1, float omb2, float eps) {
   const int slot = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
   float* __restrict__ p = reinterpret_cast<float*>(slots[3 * slot]);
   const long long off = slots[3 * slot + 1];
   const int numel = (int)slots[3 * slot + 2];
   const float lr = hyper[2 * slot], wd = hyper[2 * slot + 1];
   const float clip = state[0], bc1 = state[2], bc2s = state[3];
-  const float step_size = lr / bc1, decay = 1.f - lr * wd, omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  const float step_size = lr / bc1, decay = 1.f - lr * wd;
   const int end = min(numel, start + kChunk);
   const bool vec = ((reinterpret_cast<uintptr_t>(p) & 15u) == 0);          // slot offsets are multiples of 4 elements, `start` too
 #pragma unroll
@@ -155,10 +155,10 @@ extern "C" int s2f_grad_sqnorm(const float* g, int64_t n, double* partials, void
   return s2f_check_launch("s2f_grad_sqnorm");
 }
 
-extern "C" int s2f_adamw_prepare(const double* partials, int nparts, float max_norm, float beta1, float beta2, float* state,
+extern "C" int s2f_adamw_prepare(const double* partials, int nparts, float max_norm, double beta1, double beta2, float* state,
                                  void* stream) {
   S2F_REQUIRE(partials && state && nparts > 0, S2F_EINVAL, "s2f_adamw_prepare: null pointer or no partials");
-  S2F_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, S2F_EINVAL, "s2f_adamw_prepare: betas must lie in [0, 1)");
+  S2F_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., S2F_EINVAL, "s2f_adamw_prepare: betas must lie in [0, 1)");
   hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nparts, max_norm, beta1, beta2, state);
   return s2f_check_launch("s2f_adamw_prepare");
 }
@@ -166,11 +166,12 @@ extern "C" int s2f_adamw_prepare(const double* partials, int nparts, float max_n
 extern "C" int s2f_adamw_chunk_elems(void) { return kChunk; }
 
 extern "C" int s2f_adamw_step(const int64_t* slots, const float* hyper, const int32_t* chunks, int nchunks, const float* g, float* m,
-                              float* v, const float* state, float beta1, float beta2, float eps, void* stream) {
+                              float* v, const float* state, double beta1, double beta2, float eps, void* stream) {
   S2F_REQUIRE(slots && hyper && chunks && g && m && v && state, S2F_EINVAL, "s2f_adamw_step: null pointer");
   S2F_REQUIRE(nchunks > 0, S2F_EINVAL, "s2f_adamw_step: no chunks");
   S2F_REQUIRE(s2f_aligned16(g) && s2f_aligned16(m) && s2f_aligned16(v), S2F_EALIGN, "s2f_adamw_step: flat buffers must be 16-byte aligned");
   hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const long long*>(slots), hyper, chunks, g, m, v, state, beta1, beta2, eps);
+                     reinterpret_cast<const long long*>(slots), hyper, chunks, g, m, v, state, (float)beta2, (float)(1.0 - beta1),
+                     (float)(1.0 - beta2), eps);          // 1 - beta formed in double, as the Python scalars torch hands its kernels
   return s2f_check_launch("s2f_adamw_step");
 }

@@ -191,6 +191,25 @@ def wgrad_flush():
                    sum(2 * j[5] * j[6] * j[7] * j[8] for j in chunk))
         check(lib.s2f_gemm_dw_general_grouped(arr, len(chunk), _stream()), "s2f_gemm_dw_general_grouped")
         del _DWG_PENDING[:56]
+    if cfg.DW_PIPE:
+        # the jobs the pipelined kernel takes (L % 32 == 0) leave their step classes for ONE list: a grouped launch spreads equal
+        # shares of all its jobs over the CUs, so the more it holds the better
+        pipe = []
+        for bkv, jobs in _DW_PENDING.items():
+            rest = []
+            for j in jobs:
+                (pipe if lib.s2f_spike_gemm_dw_pipe_ok(j[3], j[4], j[5], j[6]) else rest).append(j)
+            jobs[:] = rest
+        while pipe:
+            chunk, pipe = pipe[:56], pipe[56:]
+            flat = []
+            for gy, x, sink, B, M, K, L in chunk:
+                flat += [gy.data_ptr(), x.data_ptr(), sink.data_ptr(), B, M, K, L]
+            arr = (ctypes.c_int64 * len(flat))(*flat)
+            _time_next("spike_gemm_dw", sum(4 * B * L * (K + M) for _, _, _, B, M, K, L in chunk),
+                       sum(2 * B * M * L * K for _, _, _, B, M, K, L in chunk),
+                       moved=sum(B * L * (2 * K + 4 * M) for _, _, _, B, M, K, L in chunk))
+            check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, len(chunk), 0, 0, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
     for bkv, jobs in _DW_PENDING.items():
         while jobs:
             chunk, rest = jobs[:56], jobs[56:]

@@ -833,7 +833,10 @@ class _MaskEinsumFolded(torch.autograd.Function):
                     for b in range(B):
                         flat += [g[b].data_ptr(), S[t, b].data_ptr(), H[t, b].data_ptr(), 1, Q, C, HW]
                 arr = (ctypes.c_int64 * len(flat))(*flat)
-                check(lib.s2f_spike_gemm_dw_grouped(arr, T * B, 64, _stream()), "s2f_spike_gemm_dw_grouped")
+                if cfg.DW_PIPE and lib.s2f_spike_gemm_dw_pipe_ok(1, Q, C, HW):
+                    check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, T * B, 0, 0, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
+                else:
+                    check(lib.s2f_spike_gemm_dw_grouped(arr, T * B, 64, _stream()), "s2f_spike_gemm_dw_grouped")
             else:
                 for t in range(T):
                     for b in range(B):

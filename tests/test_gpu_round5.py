@@ -1,0 +1,181 @@
+"""GPU parity tests of the round-5 kernels, through the C ABI: the pipelined weight gradient (csrc/dwp.hip) against fp64 and
+against the round-2 kernel it replaces; the fused clip + AdamW update (csrc/optim.hip) against torch.optim.AdamW behind
+torch.nn.utils.clip_grad_norm_ (what the reference's OptimWrapper runs,
+configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:137-155)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _operands(B, M, K, L, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    gy = torch.randn(B, M, L, device="cuda", generator=g) * torch.rand(B, M, 1, device="cuda", generator=g) * 1e-3
+    x = (torch.randint(0, 9, (B, K, L), device="cuda", generator=g).float() / 8).to(torch.bfloat16)
+    return gy, x
+
+
+# ragged M / K (tile 128 x 256), contraction lengths from one step to many batches, both schedules
+@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("B,M,K,L", [(8, 256, 256, 1024), (2, 700, 256, 4096), (3, 130, 300, 96), (1, 64, 32, 32), (5, 360, 1440, 64),
+                                     (2, 1024, 256, 1024), (1, 5, 7, 2048)])
+def test_pipelined_weight_gradient_matches_fp64(cfg, B, M, K, L):
+    from spike2former_amd._lib import check, lib
+    assert lib.s2f_spike_gemm_dw_pipe_ok(B, M, K, L) == 1
+    gy, x = _operands(B, M, K, L, 3)
+    want = torch.einsum("bml,bkl->mk", gy.double(), x.double())
+    scale = torch.einsum("bml,bkl->mk", gy.abs().double(), x.double()).clamp_min(1e-30)
+    for wgs in (0, 7, 1000):                     # default (one workgroup per CU), few long pieces, many short ones
+        out = torch.full((M, K), float("nan"), device="cuda")
+        check(lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), out.data_ptr(), B, M, K, L, 0, cfg, wgs, _stream()), "dw_pipe")
+        torch.cuda.synchronize()
+        # fp32-equivalent: three exact bf16 terms of dY (24 bits), exact spikes, fp32 accumulation
+        assert ((out.double() - want).abs() / scale).max().item() <= 2e-6
+    # accumulate != 0 adds into the destination
+    base = torch.randn(M, K, device="cuda")
+    acc = base.clone()
+    check(lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), acc.data_ptr(), B, M, K, L, 1, cfg, 0, _stream()), "dw_pipe")
+    torch.cuda.synchronize()
+    assert torch.allclose(acc.double(), base.double() + want, rtol=0, atol=2e-6 * scale.max().item() + 1e-6 * base.abs().max().item())
+
+
+def test_pipelined_weight_gradient_refuses_what_it_cannot_take():
+    from spike2former_amd._lib import lib
+    assert lib.s2f_spike_gemm_dw_pipe_ok(8, 256, 256, 100) == 0            # L % 32 != 0: the decoder's 100-token maps stay on the old kernel
+    assert lib.s2f_spike_gemm_dw_pipe_ok(1, 1 << 16, 64, 1 << 15) == 0     # M L >= 2^30
+    gy, x = _operands(1, 32, 32, 36, 0)
+    out = torch.zeros(32, 32, device="cuda")
+    assert lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), out.data_ptr(), 1, 32, 32, 36, 0, 0, 0, _stream()) == -1
+    assert b"L %% 32" in lib.s2f_last_error() or b"L % 32" in lib.s2f_last_error()
+
+
+def test_pipelined_grouped_launch_is_the_single_launches():
+    from spike2former_amd._lib import check, lib
+    spec = [(8, 256, 256, 1024), (8, 1024, 256, 1024), (2, 700, 256, 4096), (3, 130, 300, 96), (8, 288, 256, 1024), (1, 40, 520, 64)]
+    keep, flat, want = [], [], []
+    for i, (B, M, K, L) in enumerate(spec):
+        gy, x = _operands(B, M, K, L, 10 + i)
+        pre = torch.randn(M, K, device="cuda")
+        out = pre.clone()
+        keep.append((gy, x, out))
+        flat += [gy.data_ptr(), x.data_ptr(), out.data_ptr(), B, M, K, L]
+        want.append((pre.double() + torch.einsum("bml,bkl->mk", gy.double(), x.double()),
+                     torch.einsum("bml,bkl->mk", gy.abs().double(), x.double()).max().item() + pre.abs().max().item()))
+    arr = (ctypes.c_int64 * len(flat))(*flat)
+    check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, len(spec), 0, 0, _stream()), "dw_pipe_grouped")
+    torch.cuda.synchronize()
+    for (gy, x, out), (w, sc) in zip(keep, want):
+        assert (out.double() - w).abs().max().item() <= 2e-6 * sc
+
+
+def test_deferred_weight_gradients_take_the_pipelined_kernel(monkeypatch):
+    """ops.wgrad_flush routes the jobs the pipelined kernel takes to ONE grouped launch and leaves the others (L = 100) where they
+    were; the sums in the sinks are those of the round-2 grouped kernel to fp32 round-off."""
+    from spike2former_amd import ops
+    from spike2former_amd.ops import core
+    res = {}
+    for pipe in (True, False):
+        monkeypatch.setattr(ops.cfg, "DW_PIPE", pipe)
+        sinks = []
+        for i, (B, M, K, L) in enumerate([(8, 256, 256, 1024), (8, 256, 2048, 100), (8, 512, 256, 1024), (2, 64, 96, 4096)]):
+            gy, x = _operands(B, M, K, L, 20 + i)
+            sink = torch.zeros(M, K, device="cuda")
+            core._defer_dw(gy, x, sink, B, M, K, L)
+            sinks.append(sink)
+        core.wgrad_flush()
+        torch.cuda.synchronize()
+        res[pipe] = sinks
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ clip + AdamW
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.backbone = torch.nn.ModuleDict({"a": torch.nn.Linear(37, 19), "b": torch.nn.Conv2d(5, 7, 3)})
+        self.head = torch.nn.Linear(130, 66, bias=False)
+        self.query_embed = torch.nn.Embedding(10, 6)
+        self.big = torch.nn.Parameter(torch.randn(3, 4099, generator=g))        # > one 4 096-element chunk, ragged
+        self.scalar = torch.nn.Parameter(torch.randn(1, generator=g))
+
+
+CUSTOM = {"custom_keys": {"backbone": dict(lr_mult=0.1, decay_mult=1.0), "query_embed": dict(lr_mult=1.0, decay_mult=0.0)}}
+
+
+@pytest.mark.parametrize("max_norm", [0.01, 1e9, None])
+def test_flat_adamw_is_clip_grad_norm_plus_torch_adamw(max_norm):
+    from spike2former_amd.dist import FlatGradAllReduce
+    from spike2former_amd.train import FlatAdamW, LinearThenPoly, OptimWrapper
+    torch.manual_seed(1)
+    ours, ref = _Toy().cuda(), _Toy().cuda()
+    ref.load_state_dict(ours.state_dict())
+    clip = dict(max_norm=max_norm, norm_type=2) if max_norm else None
+    red = FlatGradAllReduce(ours.parameters(), 1)
+    opt = FlatAdamW(ours, red, lr=0.001, betas=(0.9, 0.999), weight_decay=0.005, paramwise_cfg=CUSTOM, clip_grad=clip)
+    sched = LinearThenPoly(opt, warmup=2, total=10, start_factor=0.1)
+    wrap = OptimWrapper(ref, dict(type="AdamW", lr=0.001, betas=(0.9, 0.999), weight_decay=0.005), clip_grad=clip, paramwise_cfg=CUSTOM)
+    rsched = LinearThenPoly(wrap.optimizer, warmup=2, total=10, start_factor=0.1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for it in range(4):
+        grads = [torch.randn(p.shape, device="cuda", generator=g) * (10.0 ** (it - 2)) for p in ours.parameters()]
+        for p, q, gr in zip(ours.parameters(), ref.parameters(), grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        red.gather()
+        norm = opt.step()
+        sched.step()
+        want = torch.nn.utils.clip_grad_norm_(list(ref.parameters()), max_norm, 2) if max_norm else None
+        wrap.optimizer.step()
+        rsched.step()
+        if want is not None:
+            assert abs(norm.item() - want.item()) <= 1e-6 * want.item()
+        for (n, p), q in zip(ours.named_parameters(), ref.parameters()):
+            assert (p - q).abs().max().item() <= 1e-6 * max(q.abs().max().item(), 1e-3), (it, n)
+    # versions were bumped (eager use): caches keyed on a weight's version re-convert
+    assert all(p._version > 0 for p in ours.parameters())
+    sd = opt.state_dict()
+    assert sd["step"] == 4 and set(sd["state"]) == {n for n, _ in ours.named_parameters()}
+    ref_state = wrap.optimizer.state_dict()["state"]
+    for i, (n, _) in enumerate(ref.named_parameters()):
+        assert (sd["state"][n]["exp_avg_sq"] - ref_state[i]["exp_avg_sq"]).abs().max().item() <= 1e-6 * ref_state[i]["exp_avg_sq"].abs().max().item() + 1e-30
+
+
+def test_flat_adamw_follows_compact_and_is_capturable():
+    from spike2former_amd.dist import FlatGradAllReduce
+    from spike2former_amd.train import FlatAdamW
+    m = _Toy().cuda()
+    red = FlatGradAllReduce(m.parameters(), 1)
+    opt = FlatAdamW(m, red, clip_grad=dict(max_norm=0.01))
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    m.head.weight.grad = None                    # as if its gradient had arrived through a sink
+    red.gather()
+    red.compact()
+    with pytest.raises(RuntimeError, match="rebuild"):
+        opt.step()
+    opt.rebuild()
+    before = [p.detach().clone() for p in m.parameters()]
+    red.gather()
+    opt.sync_hyper()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step(sync_hyper=False)               # warm-up (step 1)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        opt.step(sync_hyper=False)               # captured, not executed
+    graph.replay()                               # step 2
+    graph.replay()                               # step 3
+    torch.cuda.synchronize()
+    assert int(opt.state[4].item()) == 3
+    moved = [(p.detach() - b).abs().max().item() for p, b in zip(m.parameters(), before)]
+    assert all(d > 0 for d in moved)

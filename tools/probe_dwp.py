@@ -60,7 +60,7 @@ def single(B, M, K, L, sets):
                        ("pipe", lambda gy, x, o: lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), o.data_ptr(), B, M, K, L, 1, 0, 0, S())),
                        ("sym", lambda gy, x, o: lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), o.data_ptr(), B, M, K, L, 1, 1, 0, S())),
                        ("pipe512", lambda gy, x, o: lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), o.data_ptr(), B, M, K, L, 1, 0, 512, S())),
-                       ("pipe1536", lambda gy, x, o: lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), o.data_ptr(), B, M, K, L, 1, 0, 1536, S()))):
+                       ("pipe768", lambda gy, x, o: lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), o.data_ptr(), B, M, K, L, 1, 0, 768, S()))):
         fns = [(lambda a=a, b=b, o=o: call(a, b, o)) for (a, b), o in zip(ops, outs)]
         us = timeit(fns)
         res[name] = (us, fl / us / 1e6)
@@ -89,8 +89,8 @@ def grouped(jobs_spec, sets, label):
     for name, call in (("old", lambda t: lib.s2f_spike_gemm_dw_grouped(t, n, bkv, S())),
                        ("pipe", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 0, 0, S())),
                        ("sym", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 1, 0, S())),
-                       ("pipe512", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 0, 512, S())),
-                       ("pipe1536", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 0, 1536, S()))):
+                       ("sym512", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 1, 512, S())), ("pipe512", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 0, 512, S())),
+                       ("pipe768", lambda t: lib.s2f_spike_gemm_dw_pipe_grouped(t, n, 0, 768, S()))):
         us = timeit([(lambda t=t: check(call(t), name)) for t in tabs], reps=10)
         print(f"  {name:9s} {us:9.1f} us  {fl / us / 1e6:7.1f} TF/s")
     del keep

@@ -26,11 +26,19 @@ for s in range(2):
                 fl += 2.0 * B * M * K * L
     tabs.append((ctypes.c_int64 * len(flat))(*flat))
 n = sum(c for c, *_ in spec)
-names = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no loads / copies", 8: "no staging (no loads)",
-         12: "no staging", 13: "no staging, no MFMA", 15: "barriers + epilogue only"}
+names = {0: "full", 1: "no MFMA", 3: "no MFMA, no fragment reads", 4: "no copies", 12: "no staging", 15: "barriers + epilogue only",
+         20: "no copies, no split arithmetic", 36: "no copies, no plane writes", 52: "no copies: mailbox reads only", 48: "copies + mailbox reads only"}
+import statistics
+res = {}
+for rnd in range(4):
+    for sym in (1, 0):
+        for ko, name in names.items():
+            cfg = 2 * ko + sym
+            us = timeit([(lambda t=t: check(lib.s2f_spike_gemm_dw_pipe_grouped(t, n, cfg, 0, S()), name)) for t in tabs], reps=10)
+            if rnd:
+                res.setdefault((sym, ko), []).append(us)
 for sym in (1, 0):
-    print(f"# {'symmetric' if sym else 'two halves'}: grouped 43 jobs, {fl / 1e9:.1f} GFLOP")
+    print(f"# {'symmetric' if sym else 'two halves'}: grouped 43 jobs, {fl / 1e9:.1f} GFLOP; median of 3 rounds (min .. max)")
     for ko, name in names.items():
-        cfg = 2 * ko + sym
-        us = timeit([(lambda t=t: check(lib.s2f_spike_gemm_dw_pipe_grouped(t, n, cfg, 0, S()), name)) for t in tabs], reps=10)
-        print(f"  KO {ko:2d} {name:32s} {us:8.1f} us")
+        v = res[(sym, ko)]
+        print(f"  KO {ko:2d} {name:32s} {statistics.median(v):8.1f} us  ({min(v):.1f} .. {max(v):.1f})")
