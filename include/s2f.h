@@ -270,6 +270,11 @@ int s2f_spike_conv3x3_fwd_bf16(const uint16_t* w_split, const uint16_t* X, const
 int s2f_spike_gemm_fwd_bf16_ex(const uint16_t* a_split, int64_t a_batch_stride, const uint16_t* X, int64_t x_batch_stride,
                                int k_inner, int64_t x_outer_stride, const float* bias, int64_t bias_batch_stride,
                                float out_scale, float* Y, int batch, int M, int N, int K, int Mpad, int Kpad, void* stream);
+/* The same general product on the LDS-DMA pipeline (csrc/pgemm.hip, round 5): a_pack holds one s2f_pack_bf16x3 pack of [M][K] per
+ * batch element, a_batch_stride elements apart; N % 8 == 0. */
+int s2f_pgemm_nn_bf16_ex(const uint16_t* a_pack, int64_t a_batch_stride, const uint16_t* X, int64_t x_batch_stride, int k_inner,
+                         int64_t x_outer_stride, const float* bias, int64_t bias_batch_stride, float out_scale, float* Y, int batch,
+                         int M, int N, int K, void* stream);
 int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate,
                            void* stream);
 int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "s2f_spike_conv3x3_fwd_bf16": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),
     "s2f_spike_gemm_dw_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_fwd_bf16_ex": (_i, [_p, _i64, _p, _i64, _i, _i64, _p, _i64, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "s2f_pgemm_nn_bf16_ex": (_i, [_p, _i64, _p, _i64, _i, _i64, _p, _i64, _f, _p, _i, _i, _i, _i, _p]),
     "s2f_spike_gemm_dw_grouped": (_i, [_p, _i, _i, _p]),
     "s2f_spike_gemm_dw_pipe_ok": (_i, [_i] * 4),
     "s2f_spike_gemm_dw_pipe": (_i, [_p, _p, _p] + [_i] * 7 + [_p]),

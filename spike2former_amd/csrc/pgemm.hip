@@ -332,13 +332,22 @@ __device__ __forceinline__ void epi_bn_lif(const f32x16 (&acc)[MI][NJ], const Bn
 // NN:  Y[b] (M x N) = A (M x K, packed) @ X[b] (K x N, bf16 spikes, n contiguous) [+ bias].
 // Block = WMW x WNW wavefronts, wavefront tile (32 MI) x (32 NJ), K step 32, NST LDS stages.
 // EPI = 1: the BatchNorm (+ residual) (+ neuron) epilogue above instead of the plain store.
-template <int MI, int NJ, int WMW, int WNW, int AT, int NST, int EPI = 0, bool STATS = false>
+// EX: the general form of the mask contraction with the mask_feature convolution folded into it (ops.mask_einsum_folded): a packed
+// weight per batch element (a_batch_stride elements apart), the contraction running over K / k_inner slabs of the activation that
+// lie x_outer_stride elements apart (the T time slices of a [T, B, C, HW] spike map as ONE contraction of length T C; k_inner % 32
+// == 0, so a step never straddles two slabs), a per-batch row bias, an output scale:  Y = scale (A_b X_b + bias_b 1^T).
+struct NnEx {
+  int k_inner;
+  int64_t a_batch_stride, x_outer_stride, bias_batch_stride;
+  float out_scale;
+};
+template <int MI, int NJ, int WMW, int WNW, int AT, int NST, int EPI = 0, bool STATS = false, bool EX = false>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned short* __restrict__ Ap,
                                                               const unsigned short* __restrict__ X,
                                                               const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                               int N, int K, int Kb, int n_tiles, int m_tiles,
                                                               int64_t x_batch_stride, BnLifEpi ep = BnLifEpi{},
-                                                              float* __restrict__ part = nullptr) {
+                                                              float* __restrict__ part = nullptr, NnEx ex = NnEx{}) {
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW;
   constexpr int A_BYTES = AT * BM * 64, B_BYTES = 32 * BN * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = AT * BM / 16, NB = B_BYTES / 1024;          // 1 KiB copies per stage
@@ -355,6 +364,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
   const int m0 = mt * BM, n0 = nt * BN;
   const unsigned short* Xb = X + (int64_t)b * x_batch_stride;
   float* Yb = Y + (int64_t)b * M * N;
+  if constexpr (EX) {
+    Ap += (int64_t)b * ex.a_batch_stride;
+    if (bias) bias += (int64_t)b * ex.bias_batch_stride;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wm = wave / WNW, wn = wave % WNW;
@@ -379,7 +392,11 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
       const int lc = (((b_pc >> 2) ^ (k & 3)) << 2) | (b_pc & 3);
       const int kr = min(kb * 32 + k, K - 1);                     // rows past K meet zero weight columns
       const int col = min(n0 + lc * 8, N - 8);                    // columns past N are never stored
-      dma16(Xb + (int64_t)kr * N + col, sb + A_BYTES + idx * 1024);
+      if constexpr (EX) {
+        const int slab = (kb * 32) / ex.k_inner;                  // wave-uniform
+        dma16(Xb + (int64_t)slab * ex.x_outer_stride + (int64_t)(kr - slab * ex.k_inner) * N + col, sb + A_BYTES + idx * 1024);
+      } else
+        dma16(Xb + (int64_t)kr * N + col, sb + A_BYTES + idx * 1024);
     }
   };
 
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_nn_kernel(const unsigned sh
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) Yb[(int64_t)row * N + col] = acc[i][j][r] + bv[r];
+        if (row < M && col < N) Yb[(int64_t)row * N + col] = EX ? (acc[i][j][r] + bv[r]) * ex.out_scale : acc[i][j][r] + bv[r];
       }
     }
   }
@@ -1227,10 +1244,10 @@ static int pgemm_nn_impl(const uint16_t* a_pack, const uint16_t* X, const float*
     if (part) {                                                                                                        \
       if constexpr (ATV == 3)          /* (the statistics entry point always runs all three weight terms) */             \
         S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, 3, NSTV, 0, true>), dim3(n_tiles * m_tiles, batch),      \
-                   dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{}, part); \
+                   dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{}, part, NnEx{}); \
     } else                                                                                                             \
       S2F_LAUNCH(true, true, (pg_nn_kernel<MI, NJ, WMW, WNW, ATV, NSTV>), dim3(n_tiles * m_tiles, batch),               \
-                 dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{}, part); \
+                 dim3(64 * WMW * WNW), 0, s, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, xbs, BnLifEpi{}, part, NnEx{}); \
   } while (0)
 #define S2F_PG_T(MI, NJ, WMW, WNW, NSTV)          \
   do {                                           \
@@ -1252,6 +1269,28 @@ static int pgemm_nn_impl(const uint16_t* a_pack, const uint16_t* X, const float*
 #undef S2F_PG_T
 #undef S2F_PG
   return s2f_check_launch("s2f_pgemm_nn_bf16");
+}
+
+// The general form (see NnEx): Y[b] = out_scale (A_b X_b + bias_b 1^T), A_b = a_pack + b a_batch_stride (each packed by
+// s2f_pack_bf16x3 as [M][K]), row k of X_b at X + b x_batch_stride + (k / k_inner) x_outer_stride + (k % k_inner) N.
+extern "C" int s2f_pgemm_nn_bf16_ex(const uint16_t* a_pack, int64_t a_batch_stride, const uint16_t* X, int64_t x_batch_stride,
+                                    int k_inner, int64_t x_outer_stride, const float* bias, int64_t bias_batch_stride,
+                                    float out_scale, float* Y, int batch, int M, int N, int K, void* stream) {
+  S2F_REQUIRE(a_pack && X && Y, S2F_EINVAL, "s2f_pgemm_nn_bf16_ex: null pointer");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && N >= 8 && (N & 7) == 0 && K > 0, S2F_EINVAL,
+              "s2f_pgemm_nn_bf16_ex: bad sizes (N %% 8 == 0 needed, N=%d)", N);
+  S2F_REQUIRE(k_inner > 0 && k_inner % 32 == 0 && K % k_inner == 0, S2F_EINVAL,
+              "s2f_pgemm_nn_bf16_ex: k_inner must be a multiple of 32 that divides K");
+  S2F_REQUIRE((a_batch_stride & 7) == 0 && (x_batch_stride & 7) == 0 && (x_outer_stride & 7) == 0, S2F_EALIGN,
+              "s2f_pgemm_nn_bf16_ex: strides must keep 16-byte alignment");
+  S2F_REQUIRE(s2f_aligned16(a_pack) && s2f_aligned16(X) && s2f_aligned16(Y), S2F_EALIGN, "s2f_pgemm_nn_bf16_ex: pointers must be 16-byte aligned");
+  const int Kb = (K + PK - 1) / PK, n_tiles = (N + 127) / 128, m_tiles = (M + 63) / 64;
+  // 64 x 128 on four wavefronts, two LDS stages, three workgroups per CU (cfg 4 of s2f_pgemm_nn_bf16): 603 us on the C2 mask contraction
+  // [700 x 1024] @ [2 x 1024 x 65536] against 834 for the round-2 kernel and 659 for the 256 x 128 eight-wavefront tile (tools/probe_mask_fwd.py)
+  S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 0, false, true>), dim3(n_tiles * m_tiles, batch), dim3(256), 0,
+             (hipStream_t)stream, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, x_batch_stride, BnLifEpi{}, nullptr,
+             NnEx{k_inner, a_batch_stride, x_outer_stride, bias_batch_stride, out_scale});
+  return s2f_check_launch("s2f_pgemm_nn_bf16_ex");
 }
 
 extern "C" int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bias, float* Y, int batch, int M,
@@ -1288,7 +1327,7 @@ extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, co
   if (c == 4) {
     const int m_tiles = (M + 63) / 64;
     S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
-               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr);
+               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr, NnEx{});
   } else if (c == 8) {
     const int m_tiles = (M + 63) / 64;
     S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,

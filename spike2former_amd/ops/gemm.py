@@ -775,19 +775,29 @@ class _MaskEinsumFolded(torch.autograd.Function):
         dev = e.device
         ew = _mm_tm(e.reshape(-1, Co), transpose_last2(W.detach().unsqueeze(0))[0]).view(T, B, Q, C)      # e @ W: [T, B, Q, C]
         acat = ew.permute(1, 2, 0, 3).reshape(B, Q, T * C).contiguous()       # row (b, q), column (t, c)
-        Mpad = (Q + 255) // 256 * 256 if Q > 256 else (Q + 63) // 64 * 64
-        Kpad = T * C
-        a_split = torch.empty(B, 3, Mpad, Kpad, dtype=torch.int16, device=dev)
-        for b in range(B):
-            check(lib.s2f_split_bf16x3(_ptr(acat[b]), _ptr(a_split[b]), Q, T * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
         rowb = None
         if bias is not None:
             rowb = (e.sum(0) * bias.view(1, 1, -1)).sum(-1).contiguous()       # [B, Q]: sum_t E[t, b] bias (a reduction, no GEMV)
         out = torch.empty(B, Q, HW, dtype=torch.float32, device=dev)
-        _time_next("spike_gemm_fwd", 4 * B * HW * (T * C + Q), 2 * B * Q * HW * T * C, moved=B * HW * (2 * T * C + 4 * Q))
-        check(lib.s2f_spike_gemm_fwd_bf16_ex(_ptr(a_split), 3 * Mpad * Kpad, _ptr(sdata), C * HW, C, B * C * HW, _ptr(rowb),
-                                             Q if rowb is not None else 0, scale, _ptr(out), B, Q, HW, T * C, Mpad, Kpad, _stream()),
-              "s2f_spike_gemm_fwd_bf16_ex")
+        if cfg.PGEMM and cfg.MASK_FWD_PGEMM and HW % 8 == 0 and C % 32 == 0:
+            # the pipelined NN kernel (LDS-DMA fed, csrc/pgemm.hip): one pack of (E W)[b] per batch element
+            pe = int(lib.s2f_pack_elems(Q, T * C))
+            a_pack = torch.empty(B, pe, dtype=torch.int16, device=dev)
+            for b in range(B):
+                check(lib.s2f_pack_bf16x3(_ptr(acat[b]), _ptr(a_pack[b]), Q, T * C, 0, 0, _stream()), "s2f_pack_bf16x3")
+            _time_next("spike_gemm_fwd", 4 * B * HW * (T * C + Q), 2 * B * Q * HW * T * C, moved=B * HW * (2 * T * C + 4 * Q))
+            check(lib.s2f_pgemm_nn_bf16_ex(_ptr(a_pack), pe, _ptr(sdata), C * HW, C, B * C * HW, _ptr(rowb), Q if rowb is not None else 0,
+                                           scale, _ptr(out), B, Q, HW, T * C, _stream()), "s2f_pgemm_nn_bf16_ex")
+        else:
+            Mpad = (Q + 255) // 256 * 256 if Q > 256 else (Q + 63) // 64 * 64
+            Kpad = T * C
+            a_split = torch.empty(B, 3, Mpad, Kpad, dtype=torch.int16, device=dev)
+            for b in range(B):
+                check(lib.s2f_split_bf16x3(_ptr(acat[b]), _ptr(a_split[b]), Q, T * C, Mpad, Kpad, _stream()), "s2f_split_bf16x3")
+            _time_next("spike_gemm_fwd", 4 * B * HW * (T * C + Q), 2 * B * Q * HW * T * C, moved=B * HW * (2 * T * C + 4 * Q))
+            check(lib.s2f_spike_gemm_fwd_bf16_ex(_ptr(a_split), 3 * Mpad * Kpad, _ptr(sdata), C * HW, C, B * C * HW, _ptr(rowb),
+                                                 Q if rowb is not None else 0, scale, _ptr(out), B, Q, HW, T * C, Mpad, Kpad, _stream()),
+                  "s2f_spike_gemm_fwd_bf16_ex")
         ctx.save_for_backward(e, sdata, W, bias)
         ctx.cfg = (scale, T, B, bool(e_exact))
         return out
