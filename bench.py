@@ -45,6 +45,11 @@ def parse():
                          "(reset -> backbone -> head -> whole-image seg logits), hipGraph replay; --no-eval-fusion runs it on the "
                          "two-kernel conv -> BatchNorm+neuron path for comparison")
     ap.add_argument("--no-eval-fusion", action="store_true")
+    ap.add_argument("--optimizer", action="store_true",
+                    help="SECONDARY figure (SURVEY section 8 row f2): one full training ITERATION per step -- the step above + (N > 1: "
+                         "all-reduce) + clip_grad_norm_(0.01) + AdamW with the config's per-parameter multipliers, as three HIP "
+                         "launches over the flat gradient buffer (train.FlatAdamW), captured behind the step when N = 1.  The "
+                         "headline metric excludes the optimiser (BASELINE.md section 3); this line includes it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP-event pass on the LIF kernels")
     ap.add_argument("--dump-events", default=None, help="write (kernel, algorithmic bytes, us) of every timed launch here")
@@ -276,11 +281,22 @@ def main():
 
     eager_step()                                    # discovers which gradients arrive through a sink ...
     red.compact()                                   # ... and moves them behind the others: packing stays one batched copy
+    optim = sched = None
+    if args.optimizer:
+        # configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:137-167
+        from spike2former_amd.train import FlatAdamW, LinearThenPoly
+        args.no_cpu_baseline = args.no_kernel_events = True
+        optim = FlatAdamW(model, red, lr=0.001, betas=(0.9, 0.999), weight_decay=0.005, clip_grad=dict(max_norm=0.01, norm_type=2),
+                          paramwise_cfg=dict(custom_keys={"backbone": dict(lr_mult=0.1, decay_mult=1.0),
+                                                          "query_embed": dict(lr_mult=1.0, decay_mult=0.0),
+                                                          "query_feat": dict(lr_mult=1.0, decay_mult=0.0),
+                                                          "level_embed": dict(lr_mult=1.0, decay_mult=0.0)}))
+        sched = LinearThenPoly(optim, warmup=1500, total=160000, start_factor=1e-6, eta_min=0.0, power=1.0)
     if seg is not None and want_split_graphs and args.hungarian_graphs == "tables":
         # The assignment runs on the host, so the step cannot be ONE graph: forward + matching costs are one graph, the losses (from
         # the assignment's tables) + backward another (graph.GraphedHungarianStep).
         from spike2former_amd.graph import GraphedHungarianStep
-        hungarian = GraphedHungarianStep(model, img, seg, red, warmup=max(args.warmup, 2))
+        hungarian = GraphedHungarianStep(model, img, seg, red, warmup=max(args.warmup, 2), optimizer=optim if world == 1 else None)
     elif seg is not None and want_split_graphs:
         # forward and backward as two graphs around the EAGER loss (graph.GraphedSplitStep; generic instance masks)
         from spike2former_amd.graph import GraphedSplitStep
@@ -301,7 +317,8 @@ def main():
         # reset + grad clear + forward + loss + backward captured once as a hipGraph; the RCCL all-reduce stays eager
         from spike2former_amd.graph import GraphedStep
         try:
-            graphed = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=max(args.warmup, 2))
+            graphed = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=max(args.warmup, 2),
+                                  optimizer=optim if world == 1 else None)
         except RuntimeError as e:                   # N > 1 with --allow-eager only: eager launches, labelled as such
             if world == 1 or not args.allow_eager:
                 raise
@@ -313,10 +330,15 @@ def main():
         if overlapped is not None:
             return overlapped()
         if graphed is None:
-            return eager_step()
-        graphed()
-        red.reduce()
-        red.wait()
+            eager_step()
+        else:
+            graphed()
+            red.reduce()
+            red.wait()
+        if optim is not None:
+            if world > 1 or (graphed is None and hungarian is None):
+                optim.step()                          # N > 1: behind the all-reduce (eager: three launches); eager steps likewise
+            sched.step()
 
     def fence():
         torch.cuda.synchronize()
@@ -356,7 +378,8 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": ("fwd+bwd images/sec, 512x512 T=4 ADE20K-150" if args.workload == "C2" else f"fwd+bwd images/sec ({args.workload})")
+            "metric": (("training iteration (fwd+bwd+clip+AdamW) images/sec [secondary], " if optim is not None else "") +
+                       ("fwd+bwd images/sec, 512x512 T=4 ADE20K-150" if args.workload == "C2" else f"fwd+bwd images/sec ({args.workload})"))
                       + ((f" [Hungarian-matched loss, synthetic semantic maps: {'per-pixel noise, all classes present' if args.gt == 'noise' else str(args.gt_classes) + ' classes per image'}; "
                          + ("forward+costs / losses+backward hipGraphs around the host-side assignment]" if hungarian is not None
                             else "forward / backward hipGraphs around the eager loss]" if graphed_model is not None else "eager]"))

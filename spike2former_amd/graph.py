@@ -30,10 +30,18 @@ def _check_settings(captured):
 
 
 class GraphedStep:
-    def __init__(self, model, loss_fn, example_input, grad_buffer=None, warmup=3):
+    """`optimizer` (train.FlatAdamW over `grad_buffer`): the parameter update -- clip + AdamW, three launches -- is captured behind
+    the gradient packing, so one replay is one training ITERATION (single process; with N > 1 the all-reduce sits between the step
+    and the update, which the caller then runs eagerly: `step(); grad_buffer.reduce(); optimizer.step()`).  Its per-parameter
+    (lr, weight_decay) table is uploaded before every replay (a scheduler may have rewritten it)."""
+
+    def __init__(self, model, loss_fn, example_input, grad_buffer=None, warmup=3, optimizer=None):
         self.model, self.loss_fn = model, loss_fn
         self.static_in = example_input.clone()
         self.grad_buffer = grad_buffer
+        self.optimizer = optimizer
+        if optimizer is not None:
+            optimizer.sync_hyper()
         self.graph = torch.cuda.CUDAGraph()
         self.static_loss = None
         side = torch.cuda.Stream()
@@ -69,12 +77,16 @@ class GraphedStep:
         ops.wgrad_join()                  # side-stream weight gradients (ops.WGRAD_STREAM) rejoin before packing
         if self.grad_buffer is not None:
             self.grad_buffer.gather()
+        if self.optimizer is not None:
+            self.optimizer.step(sync_hyper=False)
         return loss.detach()
 
     def __call__(self, x=None):
         _check_settings(self._settings)
         if x is not None:
             self.static_in.copy_(x, non_blocking=True)
+        if self.optimizer is not None:
+            self.optimizer.sync_hyper()
         self.graph.replay()
         return self.static_loss
 
@@ -154,8 +166,11 @@ class GraphedHungarianStep:
     Between the graphs the GPU idles for the copy, the assignment and one upload -- not for ~450 eager launches of the loss and
     its backward as with GraphedSplitStep.  `__call__` returns the loss dictionary (static tensors, valid until the next call)."""
 
-    def __init__(self, model, example_input, example_seg, grad_buffer, warmup=3, ignore_index=None):
+    def __init__(self, model, example_input, example_seg, grad_buffer, warmup=3, ignore_index=None, optimizer=None):
         head = model.decode_head
+        self.optimizer = optimizer          # train.FlatAdamW: captured at the end of graph B (single process; see GraphedStep)
+        if optimizer is not None:
+            optimizer.sync_hyper()
         self.model, self.red, self.crit = model, grad_buffer, head.criterion
         self.ignore_index = head.ignore_index if ignore_index is None else ignore_index
         self.static_in = example_input.clone()
@@ -203,6 +218,8 @@ class GraphedHungarianStep:
             grads = torch.autograd.grad(sum(losses.values()), params, allow_unused=True)
             ops.wgrad_join()
             self.red.pack(grads)
+            if self.optimizer is not None:
+                self.optimizer.step(sync_hyper=False)
             self.losses = {k: v.detach() for k, v in losses.items()}
         torch.cuda.synchronize()
         self._converted = ops.conversion_state()
@@ -241,6 +258,8 @@ class GraphedHungarianStep:
             self.static_in.copy_(x, non_blocking=True)
         if seg is not None:
             self.static_seg.copy_(self.crit.seg_as_u8(seg, self.ignore_index), non_blocking=True)
+        if self.optimizer is not None:
+            self.optimizer.sync_hyper()
         self.graph_a.replay()
         torch.cuda.current_stream().synchronize()
         self._match()

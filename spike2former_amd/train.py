@@ -123,7 +123,8 @@ class FlatAdamW:
         """Gradients: `grad_buffer.flat` as the step left it (packed, averaged).  -> the gradient norm (device scalar)."""
         from ._lib import check, lib
         from .ops.core import _stream
-        if (tuple(self.red.offsets), tuple(p.data_ptr() for p in self.params)) != self._layout or self.red.params != self.params:
+        if ((tuple(self.red.offsets), tuple(p.data_ptr() for p in self.params)) != self._layout
+                or [id(p) for p in self.red.params] != [id(p) for p in self.params]):
             raise RuntimeError("FlatAdamW: the gradient buffer's layout (compact()) or a parameter's storage changed since the tables "
                                "were built; call rebuild()")
         if sync_hyper:

@@ -117,6 +117,33 @@ got = hstep()
 torch.cuda.synchronize()
 assert all(abs(float(v) - want_loss[k]) <= 1e-6 * max(abs(want_loss[k]), 1e-3) for k, v in got.items()), "Hungarian graph step: losses"
 assert (red.flat - want_flat).abs().max().item() <= 1e-4 * want_flat.abs().max().item(), "Hungarian graph step: gradients"
-print(f"RANK {rank} OK worst {worst:.2e} ranks_seen {dist.get_world_size()} hungarian_graph_step OK", flush=True)
+# the parameter update behind the all-reduce: train.FlatAdamW on the averaged flat buffer against
+# clip_grad_norm_ + torch.optim.AdamW on the same gradients; both ranks must end with identical parameters
+from spike2former_amd.train import FlatAdamW                                 # noqa: E402
+del hstep
+model.load_state_dict(state)
+CUSTOM = dict(custom_keys={"backbone": dict(lr_mult=0.1, decay_mult=1.0), "query_embed": dict(lr_mult=1.0, decay_mult=0.0),
+                           "query_feat": dict(lr_mult=1.0, decay_mult=0.0), "level_embed": dict(lr_mult=1.0, decay_mult=0.0)})
+opt = FlatAdamW(model, red, lr=0.001, weight_decay=0.005, paramwise_cfg=CUSTOM, clip_grad=dict(max_norm=0.01, norm_type=2))
+ref = [p.detach().clone().requires_grad_(True) for p in red.params]
+ref_opt = torch.optim.AdamW([{"params": [r], "lr": g["lr"], "weight_decay": g["weight_decay"]} for r, g in zip(ref, opt.param_groups)],
+                            lr=0.001, betas=(0.9, 0.999), weight_decay=0.005)
+for it in range(2):
+    eager()
+    red.reduce()
+    red.wait()
+    for r, v in zip(ref, red.views):
+        r.grad = v.clone()
+    torch.nn.utils.clip_grad_norm_(ref, 0.01, 2)
+    ref_opt.step()
+    opt.step()
+    torch.cuda.synchronize()
+    for p, r in zip(red.params, ref):
+        assert (p - r).abs().max().item() <= 1e-6 * max(r.abs().max().item(), 1e-3), f"FlatAdamW vs torch.optim.AdamW, iteration {it}"
+chk = torch.cat([p.detach().flatten() for p in red.params])
+both = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(both, chk)
+assert torch.equal(both[0], both[1]), "parameters differ between the ranks after two iterations"
+print(f"RANK {rank} OK worst {worst:.2e} ranks_seen {dist.get_world_size()} hungarian_graph_step OK flat_adamw OK", flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -28,3 +28,28 @@ def test_two_ranks_on_one_gpu_reduce_the_mean_of_their_shards():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "RANK 0 OK" in r.stdout and "RANK 1 OK" in r.stdout, r.stdout[-2000:]
     assert r.stdout.count("hungarian_graph_step OK") == 2, r.stdout[-2000:]
+    assert r.stdout.count("flat_adamw OK") == 2, r.stdout[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_rccl_communicator_and_hipgraph_capture_coexist(tmp_path):
+    """RCCL readiness on the box the driver uses (one GPU): ONE fresh child with S2F_FORCE_DIST=1 (backend nccl = RCCL, world 1:
+    communicator, watchdog thread) captures the step as a hipGraph, replays it twice and runs FlatGradAllReduce.reduce() -- the
+    N > 1 bench path minus the second rank -- and a second child does the same without a process group.  The forward is
+    deterministic: the losses must agree bitwise; the gradients contain split-K fp32 atomics: 1e-5 of their scale."""
+    import torch
+    outs = {}
+    for tag, extra in (("rccl", {"S2F_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())}), ("plain", {})):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        env.pop("S2F_DIST_BACKEND", None)
+        if tag == "plain":
+            env.pop("S2F_FORCE_DIST", None)
+        out = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), out], env=env, cwd=ROOT,
+                           capture_output=True, text=True, timeout=400)          # a child process: nothing is re-exec'ed
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert f"backend {'nccl' if tag == 'rccl' else 'none'}" in r.stdout, r.stdout[-1000:]
+        outs[tag] = torch.load(out)
+    assert torch.equal(outs["rccl"]["loss"], outs["plain"]["loss"])
+    a, b = outs["rccl"]["flat"], outs["plain"]["flat"]
+    assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
