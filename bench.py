@@ -116,7 +116,7 @@ def predict_bench(args, s2f, ops, dev, w, B, rank, world):
     fused.EVAL_FUSION = not args.no_eval_fusion
     # inference: the weights are frozen, so the graph does not re-convert them (bf16 packs) on every replay as a training step must
     # (0.23 ms per replay at C2); they are converted once below, before the capture
-    ops.RESPLIT_IN_GRAPH = False
+    resplit_was, ops.RESPLIT_IN_GRAPH = ops.RESPLIT_IN_GRAPH, False
     model = seeded_init(s2f.MODELS.build(s2f.model_cfg(args.workload))).to(dev).eval()
     s2f.set_keep_membrane(model, False)
     img = torch.randn(B, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
@@ -155,6 +155,7 @@ def predict_bench(args, s2f, ops, dev, w, B, rank, world):
             "eval_fusion": bool(fused.EVAL_FUSION), "logits_shape": list(out.shape),
             "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']}, per-GPU batch {B}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"}}), flush=True)
+    ops.RESPLIT_IN_GRAPH = resplit_was          # (process-global: a training graph captured later must re-convert its weights)
 
 
 def self_launch(args):

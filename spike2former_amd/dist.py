@@ -128,35 +128,27 @@ class FlatGradAllReduce:
         if not self.sinks:
             torch.cat(self._pieces(self.params), out=self.flat)
             return
-        if self._n_dense is None:                  # not compacted yet: one batched copy per run of gradient tensors
-            run, start, off = [], 0, 0
-            for p in self.params:
-                if p.grad is not None:
-                    if not run:
-                        start = off
-                    run += self._pieces([p])
-                elif run:
-                    torch.cat(run, out=self.flat[start:off])
-                    run = []
-                off += self._slot(p)
-            if run:
-                torch.cat(run, out=self.flat[start:off])
+        dense = self.params[:self._n_dense] if self._n_dense is not None else []
+        if (self._n_dense is not None and all(p.grad is not None for p in dense)
+                and all(p.grad is None for p in self.params[self._n_dense:])):
+            # compacted and this step's gradients arrived as in the discovery step: ONE batched copy over the leading region
+            torch.cat(self._pieces(dense), out=self.flat[:self._dense_elems])
             return
-        # compacted: the layout was fixed by which gradients arrived as tensors in the discovery step.  A parameter that changes
-        # sides afterwards would lose its gradient silently (a tensor in the sunk region is never packed; zeros written over a
-        # slot that a kernel added into) -- refuse instead
-        dense, sunk = self.params[:self._n_dense], self.params[self._n_dense:]
-        stray = [i for i, p in enumerate(sunk) if p.grad is not None]
-        if stray:
-            raise RuntimeError(f"FlatGradAllReduce: {len(stray)} parameter(s) placed in the sink region by compact() received a gradient "
-                               f"TENSOR in this step (first: #{self._n_dense + stray[0]}, shape {tuple(sunk[stray[0]].shape)}); their "
-                               "gradients would not be packed -- re-run compact() after the change that caused this")
-        missing = [i for i, p in enumerate(dense) if p.grad is None]
-        if missing:
-            raise RuntimeError(f"FlatGradAllReduce: {len(missing)} parameter(s) of the dense region have no gradient tensor in this step "
-                               f"(first: #{missing[0]}, shape {tuple(dense[missing[0]].shape)}): if a kernel added their gradient into "
-                               "a sink, packing would overwrite it with zeros -- re-run compact()")
-        torch.cat(self._pieces(dense), out=self.flat[:self._dense_elems])
+        # not compacted, or a parameter changed sides since compact() (unused on this iteration: no tensor although it lies in the
+        # dense region; a gradient tensor for a parameter placed in the sink region): one batched copy per run of gradient tensors.
+        # A slot without a tensor is left alone -- it holds the zeros of zero() or the sum a kernel added through the sink.
+        run, start, off = [], 0, 0
+        for p in self.params:
+            if p.grad is not None:
+                if not run:
+                    start = off
+                run += self._pieces([p])
+            elif run:
+                torch.cat(run, out=self.flat[start:off])
+                run = []
+            off += self._slot(p)
+        if run:
+            torch.cat(run, out=self.flat[start:off])
 
     def pack(self, grads):
         """Like gather(), from an explicit gradient list aligned with `self.params` (torch.autograd.grad output; None =

@@ -155,7 +155,7 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
             and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] in (3, 5, 7) and conv.bias is None
             and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.padding[0] == conv.padding[1]
             and (not bn.training) and bn.running_mean is not None and bn.affine and EVAL_FUSION and residual is None and x.is_cuda
-            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))
+            and _no_grad_needed(x, conv, bn)
             and (fire is None or (ops.spikes_bf16_ok(fire.D) and isinstance(fire.v, float) and not fire.keep_membrane
                                   and not fire._forward_pre_hooks and (L % 4 == 0)))):
         if fire is not None and fire.stats is not None:
@@ -181,7 +181,7 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
              and tuple(conv.dilation) == (1, 1) and conv.bias is None and x.dim() == 4 and conv.in_channels % 32 == 0
              and x.shape[-1] % 4 == 0 and (x.shape[-1] & (x.shape[-1] - 1)) == 0 and ops.cfg.PGEMM_CONV)
     eval_bn = (not bn.training) and bn.running_mean is not None and bn.affine
-    if not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
+    if not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L) and _no_grad_needed(x, conv, bn, residual)
             and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
         z = conv.forward_nobias(x)
         return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
@@ -216,6 +216,17 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
         next_lif.prefire(u, y)
         return u, None
     return (u if want_pre else None), y
+
+
+def _no_grad_needed(x, conv, bn, residual=None):
+    """The eval-mode fusions build no autograd graph: they are only legal when nothing that feeds them wants a gradient -- the
+    input, the residual, AND the trainable parameters (a frozen backbone feeding a trainable head under bn.eval(), norm_eval
+    fine-tuning: the convolution's weight and the BatchNorm affine must still receive gradients)."""
+    if not torch.is_grad_enabled():
+        return True
+    if x.requires_grad:                      # a tensor or ops.Spikes (its token carries the flag)
+        return False
+    return not any(t is not None and t.requires_grad for t in (residual, conv.weight, conv.bias, bn.weight, bn.bias))
 
 
 EVAL_FUSION = True          # eval-mode conv + BatchNorm + neuron as one GEMM launch (False: the two-kernel path, for A/B and tests)

@@ -108,7 +108,8 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
     from the updated running statistics (BNAndPadLayer's padding value), produced by the same kernel.
     partials: the [C, P, 2] per-tile sums the producing GEMM stored for z (cfg.BN_PARTIALS; default: z's `_s2f_part` attribute)."""
     if partials is None:
-        partials = getattr(z, "_s2f_part", None)
+        from .gemm import stats_of
+        partials = stats_of(z)
     bf16 = bool(lif) and spikes_bf16_ok(D) and z.numel() % 4 == 0          # as ops.lif: consumers read bf16 spikes in 8-byte groups
     u, y, v, border, ydata = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
                                           momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16, partials)

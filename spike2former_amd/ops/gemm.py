@@ -196,10 +196,21 @@ def _want_partials(stats, B, M, L):
 
 def carry_stats(src, dst):
     """dst is a view / reshape of the GEMM output src: the BatchNorm partials stored with src describe dst as well"""
-    part = getattr(src, "_s2f_part", None)
+    part = stats_of(src)
     if part is not None:
-        dst._s2f_part = part
+        dst._s2f_part = (part, dst._version, dst.data_ptr())
     return dst
+
+
+def stats_of(z):
+    """The BatchNorm partials the producing GEMM stored with z, IF z still holds what the GEMM wrote: the attribute carries the
+    tensor's version counter and address at hand-over; an in-place change since (add_, mul_, a hook) or a carry onto another
+    tensor invalidates them and the BatchNorm takes its statistics pass instead."""
+    hit = getattr(z, "_s2f_part", None)
+    if hit is None:
+        return None
+    part, version, ptr = hit
+    return part if (z._version == version and z.data_ptr() == ptr) else None
 
 
 def _owner(t):
@@ -556,7 +567,7 @@ def conv3x3_bn_lif_eval(x, weight, running_mean, running_var, gamma, beta, eps, 
 
 def _with_part(y, part):
     if part.numel():
-        y._s2f_part = part
+        y._s2f_part = (part, y._version, y.data_ptr())
     return y
 
 

@@ -1030,7 +1030,7 @@ def test_dense_gemm_groups_forward_backward(ops, B, G, M, K, L):
     finally:
         ops.BN_PARTIALS_SINGLE = False
     assert torch.equal(y, y0)
-    part = getattr(y, "_s2f_part", None)
+    part = ops.stats_of(y)
     assert part is not None and tuple(part.shape) == (G * M, B * ((L + 127) // 128), 2), single
     assert ((part.double() - _tile_sums(y.detach())).abs() <= 1e-5 * _tile_sums(y.detach().abs()) + 1e-30).all()
     y.backward(gy)

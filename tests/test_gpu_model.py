@@ -35,6 +35,27 @@ def rel(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
+# The full-size rule (tests/test_gpu_full_size.py) at the tiny configuration: what separates two correct fp32 implementations is the
+# neurons that flipped a level.  Every Q_IFNode launch counts {sum of spike counts, non-zero counts} exactly (integers); when both
+# agree with the oracle's for EVERY neuron, no spike differs and the outputs must agree to fp32 round-off -- logits 1e-5, gradients
+# 1e-4 of their scale; only a step with a flipped neuron gets the loose bounds of the tolerance statement above.
+TIGHT_OUT, TIGHT_GRAD, LOOSE_OUT, LOOSE_GRAD = 1e-5, 1e-4, 2e-2, 5e-2
+
+
+def spike_census(s2f, model, fwd):
+    """-> (fwd(), {neuron name: (sum of counts, non-zero counts)}) from the kernels' own counters"""
+    from spike2former_amd import ops
+    nodes = {n: m for n, m in model.named_modules() if isinstance(m, s2f.Q_IFNode)}
+    dev = next(model.parameters()).device
+    for m in nodes.values():
+        m.stats, m.stats_elems = ops.new_stats(dev), 0
+    out = fwd()
+    res = {n: tuple(int(v) for v in ops.read_stats(m.stats).cpu()) for n, m in nodes.items() if m.stats_elems > 0}
+    for m in nodes.values():
+        m.stats = None
+    return out, res
+
+
 def test_end_to_end_train_step_vs_reference(env, golden):
     s2f, so, cfg, model = env
     g = golden("e2e_C1_64.npz")
@@ -62,8 +83,14 @@ def test_end_to_end_train_step_vs_reference(env, golden):
     table = rec.result()["t0"]
     assert list(table) == list(g["lif_names"])
     assert np.abs(np.array(list(table.values())) - g["firing"]).max() <= 2e-3
-    assert rel(cls.cpu(), torch.from_numpy(g["cls"])) <= 2e-2
-    assert rel(masks.cpu(), torch.from_numpy(g["masks"])) <= 2e-2
+    # a flipped spike moves a neuron's rate by >= 1 / elements >= 7.6e-6 at this size; the reference's fp32 mean is good to ~1e-7
+    flipped = any(np.abs(d).max() > 0 for d in
+                  (spikes[n].reshape(-1).astype(int) - (g["tap__" + n].reshape(-1) if "transformer_decoder" not in n else
+                   g["tap__" + n].transpose(0, 1, 3, 2).reshape(-1)).astype(int) for n in spikes)) or \
+        np.abs(np.array(list(table.values())) - g["firing"]).max() > 2e-6
+    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD)
+    assert rel(cls.cpu(), torch.from_numpy(g["cls"])) <= tol_out, flipped
+    assert rel(masks.cpu(), torch.from_numpy(g["masks"])) <= tol_out, flipped
     grads = dict(model.named_parameters())
     gscale = g["grad_absmax"].max()
     for i, k in enumerate(g["sel_keys"]):
@@ -71,7 +98,7 @@ def test_end_to_end_train_step_vs_reference(env, golden):
         mine = grads[str(k)].grad
         mine = torch.zeros_like(ref) if mine is None else mine.cpu()      # conv bias under train-mode BN: exactly zero
         err = (mine - ref).abs().max().item()
-        assert err <= 5e-2 * ref.abs().max().item() + 1e-5 * gscale, (k, err, ref.abs().max().item())
+        assert err <= tol_grad * ref.abs().max().item() + (1e-5 if flipped else 1e-6) * gscale, (k, err, ref.abs().max().item(), flipped)
     sd = model.state_dict()
     for k, ssum in zip(g["stat_keys"], g["stat_sum"]):
         assert abs(sd[str(k)].double().sum().item() - ssum) <= 1e-3 * max(1.0, abs(ssum)), k
@@ -136,18 +163,24 @@ def test_train_step_vs_oracle_on_fresh_input(env):
     model.train(); s2f.reset_net(model); model.zero_grad(set_to_none=True)
     img = so.synthetic_image(cfg, seed=42)
     net = so.OracleNet(st, cfg, training=True)
+    want = {}
+    net.tap = lambda n, y: want.__setitem__(n, (int((y.detach() * 8).round().sum().item()), int((y.detach() != 0).sum().item())))
     ocls, omasks = net.forward(img)
+    net.tap = None
     so.headline_loss(ocls, omasks).backward()
-    cls, masks = model(img.cuda())
+    (cls, masks), got = spike_census(s2f, model, lambda: model(img.cuda()))
     s2f.headline_loss(cls, masks).backward()
-    assert rel(cls.detach().cpu(), ocls.detach()) <= 2e-2 and rel(masks.detach().cpu(), omasks.detach()) <= 2e-2
+    assert set(got) == set(want), set(got) ^ set(want)
+    flipped = sorted(n for n in got if got[n] != want[n])
+    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD)
+    assert rel(cls.detach().cpu(), ocls.detach()) <= tol_out and rel(masks.detach().cpu(), omasks.detach()) <= tol_out, flipped
     gscale = max(v.grad.abs().max().item() for v in st.values() if v.grad is not None)
     worst = 0.0
     for k, p in model.named_parameters():
         ref = st[k].grad
         mine = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
         worst = max(worst, (mine - ref).abs().max().item() / (ref.abs().max().item() + 1e-3 * gscale))
-    assert worst <= 5e-2, worst
+    assert worst <= tol_grad, (worst, flipped)
 
 
 def test_fused_key_value_neurons_do_not_change_the_step(env):

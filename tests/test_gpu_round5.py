@@ -179,3 +179,29 @@ def test_flat_adamw_follows_compact_and_is_capturable():
     assert int(opt.state[4].item()) == 3
     moved = [(p.detach() - b).abs().max().item() for p, b in zip(m.parameters(), before)]
     assert all(d > 0 for d in moved)
+
+
+# ------------------------------------------------------------------------------------------------ eval fusion gates
+def test_eval_fusion_is_not_taken_when_a_parameter_wants_a_gradient():
+    """Frozen input, trainable convolution and BatchNorm affine under bn.eval() (norm_eval fine-tuning): the fused eval kernels
+    build no autograd graph, so they must step aside -- the weight and the affine still receive gradients."""
+    import spike2former_amd as s2f
+    from spike2former_amd import fused, ops
+    from spike2former_amd.conv import Conv2d
+    torch.manual_seed(0)
+    conv = Conv2d(64, 32, 1, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(32).cuda().eval()
+    lif = s2f.Q_IFNode().cuda()
+    x = ops.Spikes((torch.randint(0, 9, (4, 64, 16, 16), device="cuda").float() / 8).to(torch.bfloat16))
+    s2f.reset_net(lif)
+    u, y = fused.conv_bn_act(conv, x, bn, lif=lif, want_pre=True)
+    u.square().mean().backward()
+    assert conv.weight.grad is not None and bn.weight.grad is not None and bn.bias.grad is not None
+    assert conv.weight.grad.abs().max().item() > 0
+    # with everything frozen the fused kernel IS taken, and gives the same pre-activation
+    for p in list(conv.parameters()) + list(bn.parameters()):
+        p.requires_grad_(False)
+    s2f.reset_net(lif)
+    u2, y2 = fused.conv_bn_act(conv, x, bn, lif=lif, want_pre=True)
+    assert not u2.requires_grad
+    assert torch.allclose(u2, u.detach(), rtol=1e-5, atol=1e-5)
