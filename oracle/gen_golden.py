@@ -144,9 +144,14 @@ def gen_e2e(R, cfg_name="C1_64"):
 
             def hook(mod, i, o, n=n):
                 fr[n] = float((o.detach() * 8).mean())
+                # exact integer census of the reference's spike map: {sum of counts, non-zero counts, elements with 0 <= h <= 8}
+                h = i[0].detach()
+                census[n] = (int((o.detach() * 8).round().sum().item()), int((o.detach() != 0).sum().item()),
+                             int(((h >= 0) & (h <= 8)).sum().item()))
                 if n in want_taps:
                     taps[n] = _np(o * 8).astype(np.uint8)
             m.register_forward_hook(hook)
+    census = {}
     img = so.synthetic_image(cfg)
     metas = [rs.Meta(cfg.H, cfg.W)] * cfg.B
     R.functional.reset_net(bb); R.functional.reset_net(hd)
@@ -198,6 +203,7 @@ def gen_e2e(R, cfg_name="C1_64"):
         feat_x4=_np(feats[3]), feat_absmean=np.array([float(f.abs().mean()) for f in feats], dtype=np.float64),
         lif_names=np.array(lif_names), lif_names_all=np.array(lif_names_all),
         firing=np.array([fr[n] for n in lif_names], dtype=np.float64),
+        census=np.array([census[n] for n in lif_names], dtype=np.int64),
         grad_keys=np.array(keys), grad_absmax=np.array([rg[k].abs().max().item() for k in keys], dtype=np.float64),
         grad_sum=np.array([rg[k].double().sum().item() for k in keys], dtype=np.float64),
         sel_keys=np.array(sel), stat_keys=np.array(sorted(rstats)),

@@ -36,23 +36,31 @@ def rel(a, b):
 
 
 # The full-size rule (tests/test_gpu_full_size.py) at the tiny configuration: what separates two correct fp32 implementations is the
-# neurons that flipped a level.  Every Q_IFNode launch counts {sum of spike counts, non-zero counts} exactly (integers); when both
-# agree with the oracle's for EVERY neuron, no spike differs and the outputs must agree to fp32 round-off -- logits 1e-5, gradients
-# 1e-4 of their scale; only a step with a flipped neuron gets the loose bounds of the tolerance statement above.
-TIGHT_OUT, TIGHT_GRAD, LOOSE_OUT, LOOSE_GRAD = 1e-5, 1e-4, 2e-2, 5e-2
+# neurons that flipped a spike level (an input within round-off of k + 0.5) or a straight-through mask bit 1[0 <= h <= 8] (h within
+# round-off of 0 or 8).  Per neuron the exact integer census {sum of spike counts, non-zero counts, elements in range} is compared
+# with the reference's (tests/golden/e2e_C1_64.npz `census`, written by oracle/gen_golden.py from the reference's own hooks) or the
+# oracle's; when EVERY neuron agrees, the logits must agree to fp32 round-off (1e-5).  Gradients: this configuration (B = 1,
+# train-mode BatchNorm over a few hundred positions) is ill-conditioned -- the generator measures 2e-3 between the reference's and
+# the oracle's gradients on BIT-IDENTICAL forwards (oracle/gen_golden.py gen_e2e `worst`), so 1e-2 of a tensor's scale is what a
+# flip-free step is held to, 5e-2 one with a flip.
+TIGHT_OUT, TIGHT_GRAD, LOOSE_OUT, LOOSE_GRAD = 1e-5, 1e-2, 2e-2, 5e-2
 
 
 def spike_census(s2f, model, fwd):
-    """-> (fwd(), {neuron name: (sum of counts, non-zero counts)}) from the kernels' own counters"""
-    from spike2former_amd import ops
-    nodes = {n: m for n, m in model.named_modules() if isinstance(m, s2f.Q_IFNode)}
-    dev = next(model.parameters()).device
-    for m in nodes.values():
-        m.stats, m.stats_elems = ops.new_stats(dev), 0
+    """-> (fwd(), {neuron name: (sum of counts, non-zero counts, elements with 0 <= h <= D)}) through forward hooks on every
+    Q_IFNode (fused neurons report (input, fp32 spikes) through them as well)"""
+    res = {}
+
+    def grab(mod, inp, out, n):
+        if n not in res:
+            u = inp[0].detach()
+            res[n] = (int((out.detach() * mod.D).round().sum().item()), int((out.detach() != 0).sum().item()),
+                      int(((u >= 0) & (u <= mod.D)).sum().item()))
+    hooks = [m.register_forward_hook(lambda m_, i_, o_, n=n: grab(m_, i_, o_, n)) for n, m in model.named_modules()
+             if isinstance(m, s2f.Q_IFNode)]
     out = fwd()
-    res = {n: tuple(int(v) for v in ops.read_stats(m.stats).cpu()) for n, m in nodes.items() if m.stats_elems > 0}
-    for m in nodes.values():
-        m.stats = None
+    for h in hooks:
+        h.remove()
     return out, res
 
 
@@ -66,7 +74,7 @@ def test_end_to_end_train_step_vs_reference(env, golden):
     hooks = [m.register_forward_hook(lambda mod, i, o, n=n: spikes.__setitem__(n, (o.detach() * 8).round().to(torch.uint8).cpu().numpy()))
              for n, m in model.named_modules() if ("tap__" + n) in g.files]
     with s2f.FiringRecorder(model) as rec:
-        cls, masks = model(torch.from_numpy(g["img"]).cuda())
+        (cls, masks), census = spike_census(s2f, model, lambda: model(torch.from_numpy(g["img"]).cuda()))
         rec.collect()
     for h in hooks:
         h.remove()
@@ -83,11 +91,9 @@ def test_end_to_end_train_step_vs_reference(env, golden):
     table = rec.result()["t0"]
     assert list(table) == list(g["lif_names"])
     assert np.abs(np.array(list(table.values())) - g["firing"]).max() <= 2e-3
-    # a flipped spike moves a neuron's rate by >= 1 / elements >= 7.6e-6 at this size; the reference's fp32 mean is good to ~1e-7
-    flipped = any(np.abs(d).max() > 0 for d in
-                  (spikes[n].reshape(-1).astype(int) - (g["tap__" + n].reshape(-1) if "transformer_decoder" not in n else
-                   g["tap__" + n].transpose(0, 1, 3, 2).reshape(-1)).astype(int) for n in spikes)) or \
-        np.abs(np.array(list(table.values())) - g["firing"]).max() > 2e-6
+    want = {str(n): tuple(int(v) for v in c) for n, c in zip(g["lif_names"], g["census"])}
+    assert set(census) == set(want)
+    flipped = sorted(n for n in want if census[n] != want[n])
     tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD)
     assert rel(cls.cpu(), torch.from_numpy(g["cls"])) <= tol_out, flipped
     assert rel(masks.cpu(), torch.from_numpy(g["masks"])) <= tol_out, flipped
@@ -98,7 +104,7 @@ def test_end_to_end_train_step_vs_reference(env, golden):
         mine = grads[str(k)].grad
         mine = torch.zeros_like(ref) if mine is None else mine.cpu()      # conv bias under train-mode BN: exactly zero
         err = (mine - ref).abs().max().item()
-        assert err <= tol_grad * ref.abs().max().item() + (1e-5 if flipped else 1e-6) * gscale, (k, err, ref.abs().max().item(), flipped)
+        assert err <= tol_grad * ref.abs().max().item() + 1e-5 * gscale, (k, err, ref.abs().max().item(), flipped)
     sd = model.state_dict()
     for k, ssum in zip(g["stat_keys"], g["stat_sum"]):
         assert abs(sd[str(k)].double().sum().item() - ssum) <= 1e-3 * max(1.0, abs(ssum)), k
@@ -163,10 +169,12 @@ def test_train_step_vs_oracle_on_fresh_input(env):
     model.train(); s2f.reset_net(model); model.zero_grad(set_to_none=True)
     img = so.synthetic_image(cfg, seed=42)
     net = so.OracleNet(st, cfg, training=True)
-    want = {}
+    want, inr = {}, {}
     net.tap = lambda n, y: want.__setitem__(n, (int((y.detach() * 8).round().sum().item()), int((y.detach() != 0).sum().item())))
+    net.tap_in = lambda n, h: inr.__setitem__(n, int(((h >= 0) & (h <= 8)).sum().item()))
     ocls, omasks = net.forward(img)
-    net.tap = None
+    net.tap = net.tap_in = None
+    want = {n: v + (inr[n],) for n, v in want.items()}
     so.headline_loss(ocls, omasks).backward()
     (cls, masks), got = spike_census(s2f, model, lambda: model(img.cuda()))
     s2f.headline_loss(cls, masks).backward()
