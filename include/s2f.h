@@ -212,7 +212,7 @@ int s2f_spike_gemm_fwd(const uint16_t* w_split, const float* X, const float* bia
  * inflated column matrix of F.unfold is never materialised (MS_ConvBlock.conv1 / conv2,
  * mmseg/models/backbones/sdtv2.py:197-204).  The contraction runs TAP-MAJOR, k = (3 ky + kx) C + c (C % 32 == 0: a 32-wide
  * step lies in one tap): w_split = s2f_split_bf16x3 of weight.permute(0,2,3,1) viewed [M, 9C].  Y: [batch, M, H*W].
- * s2f_spike_conv3x3_fwd needs W % 4 == 0; s2f_spike_conv3x3_dw needs W a power of two and writes dW in the same tap-major
+ * s2f_spike_conv3x3_fwd needs W % 4 == 0; s2f_spike_conv3x3_dw needs W % 4 == 0 (round 5: any such width; a power of two decodes the pixel index with a shift) and writes dW in the same tap-major
  * order, [M, 3, 3, C] (dY [batch, M, H*W]); the caller permutes it back to the weight's [M, C, 3, 3]. */
 int s2f_spike_conv3x3_fwd(const uint16_t* w_split, const float* X, const float* bias, float* Y, int batch, int M, int C,
                           int H, int W, int Mpad, int Kpad, int terms, void* stream);
@@ -447,8 +447,11 @@ int s2f_mask_loss_bwd(const float* pred, const uint8_t* tgt, const int64_t* gt_i
  * [B, R, h, w] directly (the adjoint of the up-sampling is applied to an LDS tile; no [rows, 2h, 2w] tensor exists). */
 int s2f_mask_cost_bins(const float* pred, const uint8_t* seg_small, float* out, int B, int R, int64_t hw, int K, float alpha,
                        float gamma, float eps, void* stream);
-int s2f_mask_loss_seg_fwd(const float* pred, const uint8_t* seg, const int32_t* row_class, float* sums, int B, int R, int h, int w,
-                          float alpha, float gamma, void* stream);
+/* partials: workspace of s2f_mask_loss_seg_partials(B, R, h, w) floats (need not be zeroed): a row's pixels are cut into chunks whose
+ * partial sums are stored there and added in chunk order -- the loss is bit-repeatable (rounds 2-4: fp32 atomics in arrival order). */
+int64_t s2f_mask_loss_seg_partials(int B, int R, int h, int w);
+int s2f_mask_loss_seg_fwd(const float* pred, const uint8_t* seg, const int32_t* row_class, float* sums, float* partials, int B, int R,
+                          int h, int w, float alpha, float gamma, void* stream);
 int s2f_mask_loss_seg_bwd(const float* pred, const uint8_t* seg, const int32_t* row_class, const float* g_sums, float* gpred, int B,
                           int R, int h, int w, float alpha, float gamma, void* stream);
 

@@ -341,6 +341,8 @@ class OracleNet:
         self.tap = None      # optional callable(name, tensor) for intermediate captures
         self.tap_in = None   # optional callable(name, h): every neuron's membrane before the threshold (the STE mask is 0 <= h <= D)
         self.stages = None   # optional dict: stage name -> (input, output) of every backbone stage / encoder layer
+        self.force = None    # optional dict: neuron name -> spike COUNTS (uint8, this net's layout) to emit instead of the neuron's own:
+        #                      re-seeds a teacher-forced comparison behind a neuron that legitimately flipped a level (tests only)
 
     def reset(self):
         self.membranes.clear()
@@ -351,6 +353,10 @@ class OracleNet:
             v = self.membranes.get(name)
             self.tap_in(name, (x if v is None else v + x).detach())
         y, v_new, s = lif_step(x, self.membranes.get(name), self.cfg.D)
+        if self.force is not None and name in self.force:
+            v_in = self.membranes.get(name)
+            s = self.force[name].to(x.dtype).reshape(x.shape)
+            y, v_new = s / self.cfg.D, (x if v_in is None else v_in + x) - s
         self.membranes[name] = v_new if (self.keep_membrane_graph or not v_new.requires_grad) else v_new.detach()
         self.firing[name] = float(s.detach().mean())
         if self.tap is not None:
@@ -447,6 +453,14 @@ class OracleNet:
         if self.stages is not None:
             self.stages[name] = (x.detach(), y.detach())
         return y
+
+    def run_backbone_stage(self, name, x):
+        """one stage of `backbone()` on its own (name as in `stages`): the teacher-forced re-runs of the full-size tests"""
+        short = name[len("backbone."):]
+        if short.startswith("downsample"):
+            k, s, pad, first = {"downsample1_1": (7, 2, 3, True), "downsample4": (3, 1, 1, False)}.get(short, (3, 2, 1, False))
+            return self._down(name, x, k, s, pad, first)
+        return (self._convblock if short.startswith("ConvBlock") else self._block)(name, x)
 
     def backbone(self, img):                             # Spiking_vit_MetaFormer.forward_features :614-651
         b = "backbone."

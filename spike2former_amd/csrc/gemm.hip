@@ -135,6 +135,9 @@ __device__ __forceinline__ void split3x2(float v0, float v1, unsigned int& h, un
 struct Conv3 {
   int H, W, C;
 };
+// pixel index -> (row, column) of a W-wide map; log_w >= 0: W = 2^log_w (shift / mask), log_w < 0: any width (one division)
+__device__ __forceinline__ int conv3_row(int l, int W, int log_w) { return log_w >= 0 ? l >> log_w : l / W; }
+__device__ __forceinline__ int conv3_col(int l, int W, int log_w) { return log_w >= 0 ? l & (W - 1) : l - (l / W) * W; }
 
 // 4 consecutive pixels n .. n+3 of one plane, shifted by the tap: ONE (generally unaligned) 16-byte load; the pixel that
 // falls off the row at its left / right end is zeroed, a row outside the plane reads as zeros.  `plane` = channel plane base.
@@ -582,10 +585,10 @@ __device__ __forceinline__ void general_dw_body(const float* __restrict__ dY, co
         a[h < NHA ? h : 0] = (lok && m0 + row < M) ? *reinterpret_cast<const f32x4*>(dY + (int64_t)b * dy_bs + (int64_t)(m0 + row) * L + l)
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
       if (CONV) {
-        // X is the activation [B][K/9][H][W]; row k0 + row of the virtual im2col matrix, pixels l .. l+3 (W a power of two)
+        // X is the activation [B][K/9][H][W]; row k0 + row of the virtual im2col matrix, pixels l .. l+3
         // (channel, ky, kx) of this thread's row were decoded once, before the step loop
         const bool ok = lok && k0 + row < K;
-        bq[h] = conv3_load(X + ((int64_t)b * geo.C + crow[h]) * L, l, l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo,
+        bq[h] = conv3_load(X + ((int64_t)b * geo.C + crow[h]) * L, l, conv3_row(l, geo.W, log_w), conv3_col(l, geo.W, log_w), ctap[h] / 3, ctap[h] % 3, geo,
                            ok);
       } else {
         bq[h] = (lok && k0 + row < K) ? *reinterpret_cast<const f32x4*>(X + (int64_t)b * x_bs + (int64_t)(k0 + row) * L + l)
@@ -996,9 +999,10 @@ extern "C" int s2f_gemm_dw_general_grouped(const int64_t* jobs, int njobs, void*
 
 extern "C" int s2f_spike_conv3x3_dw(const float* dY, const float* X, float* dW, int batch, int M, int C, int H, int W,
                                     int accumulate, void* stream) {
-  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & (W - 1)) == 0, S2F_EINVAL,
-              "s2f_spike_conv3x3_dw: need C %% 32 == 0 and W a power of two >= 4 (C=%d, W=%d)", C, W);
-  int log_w = 0;
-  while ((1 << log_w) < W) ++log_w;
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & 3) == 0, S2F_EINVAL,
+              "s2f_spike_conv3x3_dw: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  int log_w = -1;
+  if ((W & (W - 1)) == 0)
+    for (log_w = 0; (1 << log_w) < W;) ++log_w;
   return spike_dw_launch(dY, X, dW, batch, M, C * 9, H * W, accumulate, 1, true, Conv3{H, W, C}, log_w, stream);
 }

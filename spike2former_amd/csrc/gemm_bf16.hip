@@ -370,7 +370,7 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
         if (h < NHA) a[h < NHA ? h : 0] = *reinterpret_cast<const f32x4*>(pa + (oa[h < NHA ? h : 0] + col));
       }
       if constexpr (CONV) {
-        const Conv3Pred pr = conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]);
+        const Conv3Pred pr = conv3_pred(conv3_row(l, geo.W, log_w), conv3_col(l, geo.W, log_w), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]);
         bq[h] = *reinterpret_cast<const u32x2*>(X + ((int64_t)b * geo.C + crow[h]) * L + conv3_off(l, ctap[h] / 3, ctap[h] % 3, geo, pr));
       } else {
         bq[h] = *reinterpret_cast<const u32x2*>(px + (ox[h] + col));
@@ -403,7 +403,7 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
       if constexpr (CONV) {
         const int l = l0s + lq[h];
         *reinterpret_cast<u32x2*>(&Bs[row][col]) =
-            conv3_fix(bq[h], conv3_pred(l >> log_w, l & (geo.W - 1), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]));
+            conv3_fix(bq[h], conv3_pred(conv3_row(l, geo.W, log_w), conv3_col(l, geo.W, log_w), ctap[h] / 3, ctap[h] % 3, geo, lok && rok_x[h]));
       } else {
         *reinterpret_cast<u32x2*>(&Bs[row][col]) = (lok && rok_x[h]) ? bq[h] : u32x2{0u, 0u};
       }
@@ -705,10 +705,11 @@ extern "C" int s2f_spike_gemm_dw_bf16_split(const uint16_t* dY_split, int64_t pl
 
 extern "C" int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,
                                          int accumulate, void* stream) {
-  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & (W - 1)) == 0, S2F_EINVAL,
-              "s2f_spike_conv3x3_dw_bf16: need C %% 32 == 0 and W a power of two >= 4 (C=%d, W=%d)", C, W);
-  int log_w = 0;
-  while ((1 << log_w) < W) ++log_w;
+  S2F_REQUIRE(C > 0 && C % 32 == 0 && H > 0 && W >= 4 && (W & 3) == 0, S2F_EINVAL,
+              "s2f_spike_conv3x3_dw_bf16: need C %% 32 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  int log_w = -1;                                // any width: the kernel divides (C5's maps are 672 / 336 / 168 / 84 wide)
+  if ((W & (W - 1)) == 0)
+    for (log_w = 0; (1 << log_w) < W;) ++log_w;
   return dw_launch(dY, X, dW, batch, M, C * 9, H * W, accumulate, true, Conv3{H, W, C}, log_w, stream);
 }
 

@@ -39,6 +39,9 @@ __device__ __forceinline__ void s2f_split3x2(float v0, float v1, unsigned int& h
 struct Conv3 {
   int H, W, C;
 };
+// pixel index -> (row, column) of a W-wide map; log_w >= 0: W = 2^log_w (shift / mask), log_w < 0: any width (one division)
+__device__ __forceinline__ int conv3_row(int l, int W, int log_w) { return log_w >= 0 ? l >> log_w : l / W; }
+__device__ __forceinline__ int conv3_col(int l, int W, int log_w) { return log_w >= 0 ? l & (W - 1) : l - (l / W) * W; }
 
 // LDS transpose read (gfx950 ds_read_b64_tr_b16): within a 16-lane group lane i supplies the 8-byte-aligned address of
 // 4 consecutive 16-bit elements -- row (i >> 2), columns 4 (i & 3) .. +3 of a 4 x 16 block when addressed as below -- and

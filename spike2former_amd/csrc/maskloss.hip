@@ -14,10 +14,10 @@
 // All shapes are independent of the matching, so the whole loss replays inside a hipGraph (graph.GraphedHungarianStep).
 //
 // Repeatability.  The matching costs are 64-bit fixed-point sums (integer adds: the assignment is identical from run to run).  The
-// four loss sums of a row (mask_loss_seg_fwd_kernel) are NOT bit-repeatable: a row is cut into `chunks` (8 at C2) pieces whose
-// partial sums are added to sums[row] with fp32 atomics in arrival order -- run-to-run differences of a few ulps of a sum over
-// 262 144 pixels; the graph-versus-eager and golden-vector tests hold at their 1e-6 / 1e-5 bounds.  (The same holds for the
-// layer-scale gradient of transpose_scale_add_bwd_kernel, transpose.hip.)
+// four loss sums of a row (mask_loss_seg_fwd_kernel) are bit-repeatable since round 5: a row is cut into `chunks` (32 at C2) pieces
+// whose partial sums are STORED to partials[row][chunk][4] and added in chunk order by mask_loss_seg_finalize_kernel (which also
+// writes the zeros of the rows without a match: the clearing launch it replaces) -- rounds 2-4 added them to sums[row] with fp32
+// atomics in arrival order.  (The layer-scale gradient of transpose_scale_add_bwd_kernel, transpose.hip, still uses atomics.)
 #include "s2f_common.h"
 
 #pragma clang fp contract(off)
@@ -144,11 +144,11 @@ __device__ __forceinline__ void up4(const float* __restrict__ r0, const float* _
 }
 
 __global__ __launch_bounds__(256) void mask_loss_seg_fwd_kernel(const float* __restrict__ pred, const unsigned char* __restrict__ seg,
-                                                                const int* __restrict__ row_class, float* __restrict__ sums, int R,
+                                                                const int* __restrict__ row_class, float* __restrict__ part, int R,
                                                                 int h, int w, float alpha, float gamma, int chunks) {
   const int row = blockIdx.y;
   const int cls = row_class[row];
-  if (cls < 0) return;                                   // sums[row] stays zero
+  if (cls < 0) return;                                   // (the finalize kernel writes this row's zeros)
   const int W = 2 * w, H = 2 * h;
   const float* pp = pred + (int64_t)row * h * w;
   const unsigned char* sp = seg + (int64_t)(row / R) * H * W;
@@ -185,8 +185,20 @@ __global__ __launch_bounds__(256) void mask_loss_seg_fwd_kernel(const float* __r
   }
   __syncthreads();
   if (threadIdx.x < 4)
-    atomicAdd(sums + (int64_t)row * 4 + threadIdx.x,
-              (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    part[((int64_t)row * chunks + blockIdx.x) * 4 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// sums[row][k] = partials of the row's chunks added in chunk order (rows without a match: zero)
+__global__ __launch_bounds__(256) void mask_loss_seg_finalize_kernel(const float* __restrict__ part, const int* __restrict__ row_class,
+                                                                     float* __restrict__ sums, int rows, int chunks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 4) return;
+  const int row = i >> 2, k = i & 3;
+  float a = 0.f;
+  if (row_class[row] >= 0)
+    for (int c = 0; c < chunks; ++c) a += part[((int64_t)row * chunks + c) * 4 + k];
+  sums[i] = a;
 }
 
 // Backward: gpred[row] = adjoint of the 2x up-sampling applied to  d(sum_k g[row][k] sums[row][k]) / du.  A workgroup owns a
@@ -280,20 +292,27 @@ extern "C" int s2f_mask_cost_bins(const float* pred, const uint8_t* seg_small, f
   return s2f_check_launch("s2f_mask_cost_bins");
 }
 
-extern "C" int s2f_mask_loss_seg_fwd(const float* pred, const uint8_t* seg, const int32_t* row_class, float* sums, int B, int R,
-                                     int h, int w, float alpha, float gamma, void* stream) {
-  S2F_REQUIRE(pred && seg && row_class && sums, S2F_EINVAL, "s2f_mask_loss_seg_fwd: null pointer");
+static int seg_chunks(int h, int w) {
+  const int64_t total = (int64_t)2 * h * (2 * w / 4);
+  const int chunks = (int)((total + 256 * 8 - 1) / (256 * 8));       // >= 8 iterations per thread
+  return chunks < 1 ? 1 : chunks;
+}
+
+extern "C" int64_t s2f_mask_loss_seg_partials(int B, int R, int h, int w) { return (int64_t)B * R * seg_chunks(h, w) * 4; }
+
+extern "C" int s2f_mask_loss_seg_fwd(const float* pred, const uint8_t* seg, const int32_t* row_class, float* sums, float* partials,
+                                     int B, int R, int h, int w, float alpha, float gamma, void* stream) {
+  S2F_REQUIRE(pred && seg && row_class && sums && partials, S2F_EINVAL, "s2f_mask_loss_seg_fwd: null pointer");
   S2F_REQUIRE(B > 0 && R > 0 && (int64_t)B * R < 65536 && h > 0 && w > 0 && (w % 2) == 0, S2F_EINVAL,
               "s2f_mask_loss_seg_fwd: need B * R < 65536 and an even width");
   S2F_REQUIRE((reinterpret_cast<uintptr_t>(seg) & 3u) == 0 && (reinterpret_cast<uintptr_t>(pred) & 7u) == 0, S2F_EALIGN,
               "s2f_mask_loss_seg_fwd: label map 4-byte, logits 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (s2f_zero_async(sums, sizeof(float) * 4 * (size_t)B * R, s) != S2F_OK) return s2f_check_launch("s2f_mask_loss_seg_fwd memset");
-  const int64_t total = (int64_t)2 * h * (2 * w / 4);
-  int chunks = (int)((total + 256 * 8 - 1) / (256 * 8));       // >= 8 iterations per thread: few atomics per mask
-  if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(mask_loss_seg_fwd_kernel, dim3(chunks, (unsigned)(B * R)), dim3(256), 0, s, pred, seg, row_class, sums, R, h, w,
-                     alpha, gamma, chunks);
+  const int chunks = seg_chunks(h, w);
+  hipLaunchKernelGGL(mask_loss_seg_fwd_kernel, dim3(chunks, (unsigned)(B * R)), dim3(256), 0, s, pred, seg, row_class, partials, R, h,
+                     w, alpha, gamma, chunks);
+  hipLaunchKernelGGL(mask_loss_seg_finalize_kernel, dim3((unsigned)((B * R * 4 + 255) / 256)), dim3(256), 0, s, partials, row_class,
+                     sums, B * R, chunks);
   return s2f_check_launch("s2f_mask_loss_seg_fwd");
 }
 

@@ -179,7 +179,7 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     # 3x3 / stride 1 / padding 1 without a bias on a map the implicit kernel takes (MS_ConvBlock's convolutions)
     conv3 = (conv.kernel_size == (3, 3) and conv.groups == 1 and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
              and tuple(conv.dilation) == (1, 1) and conv.bias is None and x.dim() == 4 and conv.in_channels % 32 == 0
-             and x.shape[-1] % 4 == 0 and (x.shape[-1] & (x.shape[-1] - 1)) == 0 and ops.cfg.PGEMM_CONV)
+             and x.shape[-1] % 4 == 0 and ops.cfg.PGEMM_CONV)
     eval_bn = (not bn.training) and bn.running_mean is not None and bn.affine
     if not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L) and _no_grad_needed(x, conv, bn, residual)
             and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):

@@ -132,7 +132,7 @@ class _ConvDense(torch.autograd.Function):
         w2d = weight.view(M, -1)
         # implicit GEMM: 3x3, stride 1, padding 1 on spikes -- the kernels' loaders read the activation itself
         implicit = (spike_input and cfg.SPIKE_GEMM_ENABLED and cfg.CONV3X3_IMPLICIT and kh == 3 and kw == 3 and stride == 1
-                    and padding == 1 and C % 32 == 0 and W % 4 == 0 and (W & (W - 1)) == 0
+                    and padding == 1 and C % 32 == 0 and W % 4 == 0
                     and H * W >= cfg.CONV3X3_IMPLICIT_MIN_PIXELS)
         if implicit:
             x = x.contiguous()

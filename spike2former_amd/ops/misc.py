@@ -163,8 +163,9 @@ class _MaskLossSeg(torch.autograd.Function):
         assert seg.dtype == torch.uint8 and seg.shape == (B, 2 * h, 2 * w) and seg.is_contiguous()
         assert row_class.dtype == torch.int32 and row_class.numel() == B * R and row_class.is_contiguous()
         sums = torch.empty(B * R, 4, dtype=torch.float32, device=pred.device)
-        check(lib.s2f_mask_loss_seg_fwd(_ptr(pred), _ptr(seg), _ptr(row_class), _ptr(sums), B, R, h, w, alpha, gamma, _stream()),
-              "s2f_mask_loss_seg_fwd")
+        part = torch.empty(int(lib.s2f_mask_loss_seg_partials(B, R, h, w)), dtype=torch.float32, device=pred.device)
+        check(lib.s2f_mask_loss_seg_fwd(_ptr(pred), _ptr(seg), _ptr(row_class), _ptr(sums), _ptr(part), B, R, h, w, alpha, gamma,
+                                        _stream()), "s2f_mask_loss_seg_fwd")
         ctx.save_for_backward(pred, seg, row_class)
         ctx.cfg = (alpha, gamma)
         return sums

@@ -57,7 +57,7 @@ def c2():
         mf, memory, msm = net.pixel_decoder(feats)
         net.tap = None
     ref = dict(feats=feats, mask_features=mf, memory=memory, msm=msm, firing=dict(net.firing), fire_bb=fire_bb,
-               stages=net.stages, pd_taps=pd_taps, bb_taps=bb_taps)
+               stages=net.stages, pd_taps=pd_taps, bb_taps=bb_taps, net=net)
     return s2f, so, cfg, st0, model, img, ref
 
 
@@ -90,11 +90,20 @@ class NeuronWalk:
         for h in self.hooks:
             h.remove()
 
-    def check(self, taps, frac=1e-4, channel_major=False):
-        """-> (neurons compared, name of the first differing neuron or None)"""
+    def counts_for(self, full_name, like):
+        """this build's spike counts of neuron `full_name` (uint8) in the oracle's layout `like` -- what OracleNet.force takes"""
+        n = full_name[len(self.prefix) + 1:] if full_name != self.prefix else ""
+        return self.mine[n].reshape(like.shape)
+
+    def check(self, taps, frac=1e-4, channel_major=False, forced=()):
+        """-> (neurons compared, name of the first differing neuron or None); `forced`: full names of neurons whose oracle output was
+        replaced by this build's map (OracleNet.force) -- equal by construction, the walk continues behind them"""
         checked = 0
         for n in self.order:
-            r = taps.get(f"{self.prefix}.{n}" if n else self.prefix)
+            full = f"{self.prefix}.{n}" if n else self.prefix
+            if full in forced:
+                continue
+            r = taps.get(full)
             if r is None or r.numel() != self.mine[n].numel():
                 continue
             m = self.mine[n]
@@ -104,7 +113,7 @@ class NeuronWalk:
             checked += 1
             if (d != 0).any():
                 assert d.abs().max().item() == 1 and (d != 0).float().mean().item() <= frac, (self.prefix, n, (d != 0).float().mean().item())
-                return checked, n
+                return checked, full
         return checked, None
 
 
@@ -121,7 +130,7 @@ def test_c2_backbone_stages_teacher_forced(c2):
     s2f, so, cfg, st0, model, img, ref = c2
     model.load_state_dict(st0, strict=True)
     bb = model.backbone
-    worst, walked = {}, {}
+    worst, walked, reseeded = {}, {}, {}
     for name, (x, y) in ref["stages"].items():
         if not name.startswith("backbone."):
             continue
@@ -140,9 +149,33 @@ def test_c2_backbone_stages_teacher_forced(c2):
         assert first is not None or checked >= (0 if name.endswith("downsample1_1") else 1 if "downsample" in name else 3), (name, walk.order)
         if first is None:                                 # no neuron flipped anywhere in the stage: round-off only
             assert worst[name] <= 1e-5, (name, worst[name])
+            continue
+        # RE-SEED behind every flipped neuron (round 5): the oracle re-runs THIS stage emitting this build's spike map for the neuron
+        # that flipped (OracleNet.force), so the neurons downstream see identical inputs again and are walked exactly as well; repeated
+        # until no unforced neuron differs.  Every neuron of the stage is then either bit-identical to the oracle's or one of the few
+        # that flipped <= 1e-4 of their elements by one level, and the stage output must agree to round-off.
+        net, forced = ref["net"], {}
+        for _ in range(12):
+            forced[first] = walk.counts_for(first, ref["bb_taps"][first])
+            for k, v in st0.items():                      # the stage's BatchNorm statistics as before its first oracle run
+                if k.startswith(name + ".") and ("running_" in k or "num_batches" in k):
+                    net.p[k].copy_(v)
+            taps = {}
+            net.reset()
+            net.force, net.tap = forced, lambda nm, yy: taps.__setitem__(nm, (yy * 8).round().to(torch.uint8))
+            with torch.no_grad():
+                y2 = net.run_backbone_stage(name, x)
+            net.force = net.tap = None
+            _, first = walk.check(taps, forced=forced)
+            if first is None:
+                break
+        assert first is None, (name, sorted(forced))
+        reseeded[name] = (len(forced), rel_l2(out.cpu(), y2))
+        assert reseeded[name][1] <= 1e-5, (name, reseeded[name])
     assert len(worst) == 17
     assert max(worst.values()) <= 6e-2, worst
     assert sorted(worst.values())[len(worst) // 2] <= 1e-5, worst
+    print("re-seeded stages (flipped neurons, rel L2 after re-seeding):", reseeded)
 
 
 @pytest.mark.timeout(900)

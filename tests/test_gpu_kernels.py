@@ -645,7 +645,11 @@ def test_spike_gemm_weight_gradient_matches_fp64(ops, B, M, K, L):
                                                      (1, 128, 32, 8, 8, 3, 1, 1, True),
                                                      # implicit-GEMM 3x3 (W a power of two): ragged M / C / H, several tiles
                                                      (2, 32, 72, 19, 32, 3, 1, 1, True), (3, 160, 40, 5, 64, 3, 1, 1, True),
-                                                     (1, 64, 200, 33, 4, 3, 1, 1, True)])
+                                                     (1, 64, 200, 33, 4, 3, 1, 1, True),
+                                                     # widths that are not a power of two (C5's maps are 672 / 336 / 168 / 84 wide): the
+                                                     # implicit weight-gradient kernels divide instead of shifting (round 5)
+                                                     (2, 32, 72, 11, 84, 3, 1, 1, True), (1, 64, 40, 7, 168, 3, 1, 1, True),
+                                                     (2, 96, 32, 9, 12, 3, 1, 1, True)])
 def test_conv_dense_vs_aten_cpu(ops, N, C, M, H, W, k, s, p, spike):
     """The GEMM lowerings of the dense convolution (incl. the transposed-convolution form of dX used when M < C) against
     F.conv2d on CPU: 2e-5 of the max for outputs and all three gradients."""

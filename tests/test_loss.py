@@ -191,3 +191,19 @@ def test_label_map_mask_loss_is_the_gathered_mask_loss(h, w):
     gp = pred.grad.reshape(B * R, h, w)
     assert gp[inval].abs().max().item() == 0.0
     assert (gp[valid.cuda()] - p2.grad).abs().max().item() <= 1e-5 * p2.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_label_map_mask_loss_is_bit_repeatable():
+    """Round 5: the chunk partials of a row are stored and added in chunk order (csrc/maskloss.hip) -- the four sums of every row
+    are identical from launch to launch, at the C2 size (h = w = 256: 32 chunks per row) where rounds 2-4 used fp32 atomics."""
+    from spike2former_amd import ops
+    B, R, K, h, w = 2, 40, 150, 256, 256
+    g = torch.Generator().manual_seed(3)
+    pred = (torch.randn(B, R, h, w, generator=g) * 3).cuda()
+    seg = _regions(B, 2 * h, 2 * w, K, 10, 4).cuda()
+    seg_u8 = MaskFormerLoss(K, R).seg_as_u8(seg)
+    rc = torch.randint(-1, K, (B * R,), generator=g).to(torch.int32).cuda()
+    first = ops.mask_loss_seg(pred, seg_u8, rc, 0.25, 2.0).clone()
+    for _ in range(5):
+        assert torch.equal(ops.mask_loss_seg(pred, seg_u8, rc, 0.25, 2.0), first)
