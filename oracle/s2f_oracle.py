@@ -341,6 +341,7 @@ class OracleNet:
         self.tap = None      # optional callable(name, tensor) for intermediate captures
         self.tap_in = None   # optional callable(name, h): every neuron's membrane before the threshold (the STE mask is 0 <= h <= D)
         self.stages = None   # optional dict: stage name -> (input, output) of every backbone stage / encoder layer
+        self.force_diffs = {}   # per forced neuron: (elements whose own count differs, largest difference in levels, elements)
         self.force = None    # optional dict: neuron name -> spike COUNTS (uint8, this net's layout) to emit instead of the neuron's own:
         #                      re-seeds a teacher-forced comparison behind a neuron that legitimately flipped a level (tests only)
 
@@ -354,9 +355,14 @@ class OracleNet:
             self.tap_in(name, (x if v is None else v + x).detach())
         y, v_new, s = lif_step(x, self.membranes.get(name), self.cfg.D)
         if self.force is not None and name in self.force:
+            # emit the given counts; the straight-through gradient still flows through this neuron's own quantiser (same h)
             v_in = self.membranes.get(name)
-            s = self.force[name].to(x.dtype).reshape(x.shape)
-            y, v_new = s / self.cfg.D, (x if v_in is None else v_in + x) - s
+            sf = self.force[name].to(x.dtype).reshape(x.shape)
+            d = (sf - s.detach()).abs()
+            self.force_diffs[name] = (int((d != 0).sum()), float(d.max()) if d.numel() else 0.0, d.numel())
+            y = y + (sf / self.cfg.D - y).detach()
+            v_new = v_new + (((x if v_in is None else v_in + x) - sf) - v_new).detach()
+            s = sf
         self.membranes[name] = v_new if (self.keep_membrane_graph or not v_new.requires_grad) else v_new.detach()
         self.firing[name] = float(s.detach().mean())
         if self.tap is not None:
