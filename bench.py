@@ -403,12 +403,23 @@ def main():
             # separate runs, gfx950 corrections applied there); null when no such profile exists for a kernel
             traffic, traffic_src = {}, None
             try:
-                for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json", "r04_pmc_traffic.json"):          # the newest profile wins
-                    path = os.path.join(ROOT, "profiles", name)
-                    if os.path.exists(path):
-                        with open(path) as f:
-                            traffic.update({k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()})
-                        traffic_src = f"profiles/{name} (rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
+                # the newest committed profile, and only if it was taken on THESE streaming kernels: the profile records a hash of
+                # csrc/bn_lif.hip + lif.hip (tools/pmc_traffic.py); after a change to them it is stale and `traffic` is null
+                import hashlib
+                h = hashlib.sha256()
+                for f_ in ("bn_lif.hip", "lif.hip"):
+                    h.update(open(os.path.join(ROOT, "spike2former_amd", "csrc", f_), "rb").read())
+                sha = h.hexdigest()[:16]
+                path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+                if os.path.exists(path):
+                    with open(path) as f:
+                        prof = json.load(f)
+                    if prof.get("streaming_kernel_sources_sha16") == sha:
+                        traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["kernels"].items()}
+                        traffic_src = ("profiles/r05_pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command on the "
+                                       "same kernel sources, not measured in this run)")
+                    else:
+                        traffic_src = "profiles/r05_pmc_traffic.json is STALE (the streaming kernels changed since): traffic not reported"
             except (OSError, KeyError, ValueError):
                 pass
             if args.dump_events:
@@ -436,7 +447,7 @@ def main():
                     out[key] = {"kernel": name, "bound": "hbm", "achieved": round(mgbs, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(mgbs / HBM_PEAK_GBS, 4),
                                 "traffic": traffic.get(name) if args.workload == "C2" else None,
-                                "traffic_source": (traffic_src if (args.workload == "C2" and name in traffic) else None),
+                                "traffic_source": (traffic_src if args.workload == "C2" else None),
                                 "launches": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
                                 "moved_bytes_per_launch": moved // launches,
                                 "algorithmic_bytes_per_launch": nbytes // launches,

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import fused, ops
 from .conv import Conv1d, Conv2d, spikes_in
 from .fused import bn_act, bn_bn_act, conv_bn_act
 from .neuron import Q_IFNode, Quant
@@ -246,7 +246,19 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         w1 = ops.cat_params(t["w1"]).view(3 * C, C)
         w1._s2f_version = sum(p._version for p in t["w1"])              # for the cached bf16 split (ops.split_weight)
         w1._s2f_owner = t["w1"][0]
-        z = ops.spike_gemm(s.view(T * B, C, N), w1, stats=training)                    # the three first 1x1 convs: one GEMM
+        sv = s.view(T * B, C, N)
+        if (not training) and fused.EVAL_FUSION and not torch.is_grad_enabled() and ops.gemm_bn_lif_eval_ok(sv, N):
+            # inference: BatchNorm_1 (running statistics) rides in the first GEMM's epilogue, and the
+            # BatchNorm pair that closes the chain is ONE affine map (composed on the host, cached per parameter version):
+            # five launches -> three  (GEMM+BN | stencil | grouped GEMM | BN+neuron)
+            ev = self._eval_affines(t, bn1, bn2, bn3)
+            z = ops.gemm_bn_lif_eval(sv, w1, None, bn1.running_mean, bn1.running_var, bn1.weight, bn1.bias, bn1.eps, want_pre=True,
+                                     lif=False)[0].view(T * B, 3 * C, H, W)
+            z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, ev["border"])
+            z = ops.dense_gemm(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]], stats=False).view(T * B, 3 * C, H, W)
+            _, y = bn_act(z, None, ev["pair"], lif=self.q_spike)
+            return y.view(T * B, 3 * C, N)
+        z = ops.spike_gemm(sv, w1, stats=training)                    # the three first 1x1 convs: one GEMM
         z = ops.carry_stats(z, z.view(T * B, 3 * C, H, W))
         z, _, border = bn_act(z, None, bn1, want_border=True)
         z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, border)
@@ -259,6 +271,24 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         if training:
             torch._foreach_add_([b.num_batches_tracked for bns in t["bns"] for b in bns], 1)
         return y.view(T * B, 3 * C, N)          # q | k | v spikes, channel-stacked: the attention core reads the ranges in place
+
+    def _eval_affines(self, t, bn1, bn2, bn3):
+        """eval mode: BN_1(0) (the stencil's border value) and BN_3 o BN_2 as one affine pair on BN_2's running statistics, cached on
+        the versions of the 27 parameter / buffer tensors involved"""
+        key = tuple((x.data_ptr(), x._version) for bns in t["bns"] for b in bns for x in (b.weight, b.bias, b.running_mean, b.running_var))
+        hit = getattr(self, "_s2f_eval_affines", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            border = (bn1.bias - bn1.running_mean * bn1.weight / torch.sqrt(bn1.running_var + bn1.eps)).contiguous()
+            r3g3 = bn3.weight / torch.sqrt(bn3.running_var + bn3.eps)
+            pair = fused._EvalBN()
+            pair.weight = (bn2.weight * r3g3).contiguous()
+            pair.bias = ((bn2.bias - bn3.running_mean) * r3g3 + bn3.bias).contiguous()
+            pair.running_mean, pair.running_var, pair.eps = bn2.running_mean.clone(), bn2.running_var.clone(), bn2.eps
+        out = dict(border=border, pair=pair)
+        self._s2f_eval_affines = (key, out)
+        return out
 
     def _can_batch(self):
         lifs = (self.q_spike, self.k_spike, self.v_spike)

@@ -38,3 +38,31 @@ def fuse_convbn2d(conv2d: nn.Conv2d, bn2d: nn.BatchNorm2d, k=None, b=None):
     if getattr(conv2d, "spike_input", False):
         fused.spike_input = True
     return fused
+
+
+@torch.no_grad()
+def merge_repconv(rep, outer_bn=None):
+    """The dense 3x3 convolution (zero padding 1) + bias that equals an eval-mode RepConv [+ the BatchNorm behind it]
+    (sdtv2.py:112-132 with 48-89: conv1x1 -> BNAndPad -> depthwise 3x3 -> conv1x1 -> BatchNorm [-> BatchNorm]).  Everything between
+    the two neurons is linear, and BNAndPadLayer pads with BN_1(0), i.e. with what BN_1 gives where the ZERO-padded input's 1x1
+    image is zero -- so the chain is a zero-padded 3x3 convolution:
+        K[m, c, ky, kx] = sum_j W2'[m, j] Wd[j, ky, kx] W1'[j, c],      bias[m] = sum_j W2'[m, j] b1[j] sum_taps Wd[j] + b2[m]
+    with W1' = diag(s1) W1, b1 = BN_1's shift, W2' / b2 = the second 1x1 with the closing BatchNorm(s) folded in.  Formed in fp64.
+    -> (weight [M, C, 3, 3] fp32, bias [M] fp32).  NINE times the multiply-adds of a 1x1: measured 4x slower than the three-launch
+    chain on the C2 maps (tools/probe_repconv_merge.py) -- an export helper, not used on the product path."""
+    c1, bnp, (dw, c2, bn2) = rep.body[0], rep.body[1].bn, rep.body[2]
+    d = torch.float64
+    s1 = (bnp.weight.to(d) / (bnp.running_var.to(d) + bnp.eps).sqrt())
+    b1 = bnp.bias.to(d) - bnp.running_mean.to(d) * s1
+    w1 = c1.weight.to(d).flatten(1) * s1.view(-1, 1)                                     # [J, C]
+    s2 = bn2.weight.to(d) / (bn2.running_var.to(d) + bn2.eps).sqrt()
+    b2 = bn2.bias.to(d) - bn2.running_mean.to(d) * s2
+    if outer_bn is not None:
+        s3 = outer_bn.weight.to(d) / (outer_bn.running_var.to(d) + outer_bn.eps).sqrt()
+        b2 = (b2 - outer_bn.running_mean.to(d)) * s3 + outer_bn.bias.to(d)
+        s2 = s2 * s3
+    w2 = c2.weight.to(d).flatten(1) * s2.view(-1, 1)                                     # [M, J]
+    wd = dw.weight.to(d).view(-1, 3, 3)                                                  # [J, 3, 3]
+    k = torch.einsum("mj,jyx,jc->mcyx", w2, wd, w1)
+    bias = w2 @ (b1 * wd.sum((1, 2))) + b2
+    return k.float().contiguous(), bias.float().contiguous()

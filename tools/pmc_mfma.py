@@ -15,7 +15,8 @@ FAMILIES = [("spike GEMM forward incl. 3x3, pipelined (pg_nn_kernel, pg_conv_ker
             ("input gradient / dense GEMM, 6 passes (pg_tn_f32_kernel, pg_conv_kernel<.., 3, ..>)",
              lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "3")),
             ("spike GEMM forward, round-2 kernel: 3x3 convolutions, N < 128 (sgemm_bf16_kernel)", lambda n: "sgemm_bf16_kernel" in n),
-            ("spike GEMM weight gradient (sgemm_dw_bf16 / grouped)", lambda n: "sgemm_dw" in n),
+            ("spike GEMM weight gradient, pipelined (dwp_grouped_kernel: 1x1 layers, mask-contraction embedding gradient)", lambda n: "dwp_" in n),
+            ("spike GEMM weight gradient, round-2 kernel (sgemm_dw_bf16: implicit 3x3, L % 32 != 0)", lambda n: "sgemm_dw" in n),
             ("general weight gradient, 6 passes (spike_gemm_dw_kernel / gemm_dw_general_grouped)",
              lambda n: "spike_gemm_dw_kernel" in n or "gemm_dw_general_grouped" in n),
             ("split GEMM (mask contraction backward, 3x3 input gradients)", lambda n: "split_gemm_kernel" in n),

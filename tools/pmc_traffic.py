@@ -32,7 +32,8 @@ FAMILIES = {          # bench.py roofline key -> predicate on the kernel name
                                  or ("pg_conv_kernel" in n and _targs(n)[4] == "1")),
     "spike_gemm_fwd_pgemm": lambda n: "pg_nn_kernel" in n or ("pg_conv_kernel" in n and _targs(n)[4] == "1"),
     "dx_gemm": lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and _targs(n)[4] == "3"),
-    "spike_gemm_dw": lambda n: "spike_gemm_dw_kernel" in n or "sgemm_dw" in n or "gemm_dw_general_grouped" in n,
+    "spike_gemm_dw": lambda n: "spike_gemm_dw_kernel" in n or "sgemm_dw" in n or "gemm_dw_general_grouped" in n or "dwp_" in n,
+    "spike_gemm_dw_pipe": lambda n: "dwp_" in n,
     "sdsa_lif_fwd": lambda n: "apply_kernel<" in n and ", true>" in n and "bn_" not in n,
 }
 
@@ -52,15 +53,30 @@ def per_family(db, counter):
         vals = [v for d, v in per.items() if pred(name[d])]
         if vals:
             out[fam] = (len(vals), sum(vals) / len(vals))
+            KERNELS[fam] |= {name[d].split("(")[0] for d in per if pred(name[d])}
     return out
+
+
+KERNELS = collections.defaultdict(set)
+
+
+def source_sha():
+    """what bench.py compares at run time: the streaming kernels' sources -- a profile taken before a change to them is stale"""
+    import hashlib, os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spike2former_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("bn_lif.hip", "lif.hip"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 f, w = per_family(sys.argv[1], "FETCH_SIZE"), per_family(sys.argv[2], "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-graph "
                  "--no-kernel-events --no-cpu-baseline` at C2; correction: FETCH_SIZE x2 (gfx950, 16 B/lane streams), KiB -> bytes",
-       "kernels": {}}
+       "streaming_kernel_sources_sha16": source_sha(), "kernels": {}}
 for fam in FAMILIES:
     if fam in f and fam in w:
         res["kernels"][fam] = {"launches_in_profile": f[fam][0], "fetch_kib_raw": round(f[fam][1], 1), "write_kib_raw": round(w[fam][1], 1),
-                               "hbm_bytes_per_launch": int(f[fam][1] * 1024 * 2 + w[fam][1] * 1024)}
+                               "hbm_bytes_per_launch": int(f[fam][1] * 1024 * 2 + w[fam][1] * 1024),
+                               "kernel_names": sorted(KERNELS[fam])}
 print(json.dumps(res, indent=1))

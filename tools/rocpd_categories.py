@@ -10,7 +10,8 @@ def cat(name):
     if name.startswith('Cijk'): return 'GEMM (rocBLAS/Tensile)'
     if 'split_gemm' in name: return 'split GEMM (mask einsum), bf16 MFMA (ours)'
     if 'split_multi' in name: return 'weight re-split (ours)'
-    if 'spike_gemm_dw' in name or 'sgemm_dw' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
+    if 'spike_gemm_dw' in name or 'sgemm_dw' in name or 'dwp_' in name: return 'spike GEMM dW, bf16 MFMA (ours)'
+    if 'adamw_' in name or 'grad_sqnorm' in name: return 'optimizer (ours)'
     if 'pg_conv_kernel' in name:            # <MI, NJ, WMW, WNW, BT, CONV>: BT = 3 is the 6-pass form (3x3 input gradient)
         bt = name.split('<')[1].split('>')[0].split(',')[4].strip()
         return 'dX / dense GEMM, 6-pass bf16 MFMA (ours)' if bt == '3' else 'spike GEMM fwd, bf16 MFMA (ours)'
