@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 19
+#define S2F_ABI_VERSION 20
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -299,6 +299,17 @@ int s2f_spike_gemm_dw_pipe_ok(int batch, int M, int K, int L);
 int s2f_spike_gemm_dw_pipe(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate, int cfg,
                            int target_wgs, void* stream);
 int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, int cfg, int target_wgs, void* stream);
+/* The implicit 3x3 weight gradient (stride 1, padding 1; what s2f_spike_conv3x3_dw_bf16 computes: dW [M][3][3][C] tap-major) on the same
+ * kernel, up to 16 convolutions per launch.  The shifted rows of a tap are 2-byte aligned, which an LDS-DMA cannot fetch: the kernel
+ * reads the horizontal taps from Xs, a copy of the activation shifted by one element behind an 8-element front pad (s2f_shift1_bf16:
+ * Xs holds n + 16 elements, Xs[8 + i] = X[i + 1] for i = -1 .. n - 2, zeros elsewhere; n % 8 == 0),
+ * and zeroes in the fragments what the zero padding would have supplied.  jobs (HOST array): njobs x {dY, X, Xs, dW (pointers),
+ * batch, M, C, H, W} as int64; every dW is accumulated into.  Needs C % 32 == 0, W % 32 == 0, B C H W 2 < 2^31
+ * (s2f_spike_conv3x3_dw_pipe_ok).  Replaces the autograd weight gradient of MS_ConvBlock's dense 3x3 convolutions and of the stride-1
+ * down-sampling (mmseg/models/backbones/sdtv2.py:183-219, 540-548). */
+int s2f_spike_conv3x3_dw_pipe_ok(int batch, int M, int C, int H, int W);
+int s2f_shift1_bf16(const uint16_t* X, uint16_t* Xs, int64_t n, void* stream);
+int s2f_spike_conv3x3_dw_pipe(const int64_t* jobs, int njobs, int cfg, int target_wgs, void* stream);
 
 /* ---- pipelined GEMMs fed by LDS-DMA (csrc/pgemm.hip, round 3) ------------------------------------------------------------
  * The same products as s2f_spike_gemm_fwd_bf16 and as the autograd input gradient of a 1x1 convolution

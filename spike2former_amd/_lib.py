@@ -67,6 +67,9 @@ SIGNATURES = {
     "s2f_spike_gemm_dw_pipe_ok": (_i, [_i] * 4),
     "s2f_spike_gemm_dw_pipe": (_i, [_p, _p, _p] + [_i] * 7 + [_p]),
     "s2f_spike_gemm_dw_pipe_grouped": (_i, [_p, _i, _i, _i, _p]),
+    "s2f_spike_conv3x3_dw_pipe_ok": (_i, [_i] * 5),
+    "s2f_shift1_bf16": (_i, [_p, _p, _i64, _p]),
+    "s2f_spike_conv3x3_dw_pipe": (_i, [_p, _i, _i, _i, _p]),
     "s2f_spike_conv3x3_dw_bf16": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "s2f_gemm_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 6 + [_i] * 4 + [_f, _i, _p]),
     "s2f_conv3x3_bn_lif_fwd": (_i, [_p] * 7 + [_f] + [_p] * 6 + [_i] * 5 + [_f, _i, _p]),

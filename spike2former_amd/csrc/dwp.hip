@@ -41,6 +41,13 @@ __device__ __forceinline__ void dma16(const void* base, unsigned off, void* lds_
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, off, 0, 0, 0);
 }
+// the same with the hardware's range check: `off` is the byte offset from the START of a tensor of `bytes` bytes; a lane whose
+// offset falls outside (a tap above the first / below the last image row of the first / last plane: the unsigned offset wraps)
+// lands zeros instead of touching memory
+__device__ __forceinline__ void dma16_checked(const void* tensor, unsigned bytes, unsigned off, void* lds_dst) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tensor), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, off, 0, 0, 0);
+}
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_b128_asm(unsigned byte_addr) {
   bf16x8 r;
@@ -67,10 +74,21 @@ constexpr int NRAW = 3;
 // SYM = false: two halves in opposite phase (planes double-buffered, four ring slots: 160 KiB of LDS);
 // SYM = true : every wavefront in the same phase  stage | barrier | multiply | barrier  (one plane stage, three ring slots: 120 KiB)
 // KO (probe builds only, S2F_DWP_PROBE): 1 = no MFMAs, 2 = no fragment reads, 4 = no copies after the prologue, 8 = no staging
-template <bool SYM, int KO = 0>
+// CONV: the implicit 3x3 convolution (stride 1, padding 1).  Row k = tap * C + c of the virtual im2col matrix is channel plane c
+// shifted by the tap; X is the activation [B][C][H][W] itself and Xs a copy shifted by ONE element (Xs[i] = X[i + 1]), so that
+// the horizontal taps are dword-aligned copy sources too: kx = 1 reads X at l + (ky - 1) W, kx = 2 reads Xs at the same place,
+// kx = 0 reads Xs two elements earlier.  What the zero padding would have supplied is zeroed in the X fragments: a tap above /
+// below the image (whole 8-pixel chunk: W % 32 == 0 keeps a 32-pixel step inside one image row), the first pixel of a row for
+// kx = 0, the last for kx = 2.  A copy instruction covers 16 rows of one tap (C % 16 == 0).
+struct DwpConv {
+  const unsigned short* Xs;
+  int C, H, W;
+  unsigned x_bytes;          // bytes of X (= of Xs): B C H W 2 < 2^31
+};
+template <bool SYM, int KO = 0, bool CONV = false>
 __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const unsigned short* __restrict__ X,
                                          float* __restrict__ dW, int M, int K, int L, int k_tiles, int tile, int s_begin,
-                                         int n) {
+                                         int n, DwpConv cv = DwpConv{}) {
   constexpr int NA = SYM ? 1 : 2, NB = SYM ? 3 : 4;
   // separate OBJECTS: hipcc orders an LDS store behind every LDS-DMA in flight that it cannot prove disjoint
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NA * A_STAGE];          // dY planes hi | mid | lo
@@ -92,7 +110,27 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     aw[i] = (unsigned)(row * 64 + ((((q4 >> 1) ^ ((row >> 2) & 3))) << 4) + (q4 & 1) * 8);
     const int r = (wave * 2 + i) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((r >> 2) & 3);
-    ob[i] = ((unsigned)min(k0 + r, K - 1) * (unsigned)L + (unsigned)(c * 8)) * 2u;             // BYTES (K L < 2^31)
+    if constexpr (CONV) {
+      const int k = min(k0 + r, K - 1), tap = k / cv.C, ch = k - tap * cv.C, ky = tap / 3, kx = tap - 3 * ky;
+      // byte offset from the start of the tensor, without the batch element and the step (added per request); may be negative
+      ob[i] = (unsigned)((ch * L + (ky - 1) * cv.W + (kx == 0 ? -2 : 0) + c * 8) * 2);
+    } else {
+      ob[i] = ((unsigned)min(k0 + r, K - 1) * (unsigned)L + (unsigned)(c * 8)) * 2u;             // BYTES (K L < 2^31)
+    }
+  }
+  // CONV: which tensor each of this wavefront's two copy instructions reads (wave-uniform), and per X-fragment row block the tap
+  bool shifted[2] = {false, false};
+  int fky[2] = {1, 1}, fkx[2] = {1, 1};
+  unsigned x_bytes = 0;
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tap = min(k0 + (wave * 2 + i) * 16, K - 1) / cv.C;
+      shifted[i] = (tap % 3) != 1;
+      const int kf = min(k0 + wn * 64 + i * 32 + (lane & 31), K - 1), tf = kf / cv.C;
+      fky[i] = tf / 3, fkx[i] = tf - 3 * fky[i];
+    }
+    x_bytes = cv.x_bytes;
   }
   // ---- fragment addresses (bytes inside a stage)
   unsigned aoff[2][2], boff[2][2];
@@ -123,11 +161,19 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
   // one group = 4 copies per wavefront: {dY rows 0-7, dY rows 8-15, X rows 0-15, X rows 16-31} of its share
   auto request = [&]() __attribute__((always_inline)) {
     const char* pa = reinterpret_cast<const char*>(dY + (int64_t)cb * M * L + cl);
-    const char* px = reinterpret_cast<const char*>(X + (int64_t)cb * K * L + cl);
 #pragma unroll
     for (int i = 0; i < 2; ++i) dma16(pa, oa[i], smem_raw + next_raw * RAW_SLOT + wave * 2048 + i * 1024);
+    if constexpr (CONV) {
+      const unsigned uni = (unsigned)((cb * cv.C * L + cl) * 2);          // batch element + step, bytes (x_bytes < 2^31)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) dma16(px, ob[q], smem_ring + next_slot * B_STAGE + (wave * 2 + q) * 1024);
+      for (int q = 0; q < 2; ++q)
+        dma16_checked(shifted[q] ? cv.Xs : X, shifted[q] ? x_bytes + 32u : x_bytes, ob[q] + uni + (shifted[q] ? 16u : 0u),
+                      smem_ring + next_slot * B_STAGE + (wave * 2 + q) * 1024);          // (Xs: 8 elements of front pad)
+    } else {
+      const char* px = reinterpret_cast<const char*>(X + (int64_t)cb * K * L + cl);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) dma16(px, ob[q], smem_ring + next_slot * B_STAGE + (wave * 2 + q) * 1024);
+    }
     next_slot = next_slot == NB - 1 ? 0 : next_slot + 1;
     next_raw = next_raw == NRAW - 1 ? 0 : next_raw + 1;
     // past the last tile the cursor stays: the requests are issued unconditionally (into slots nobody reads again), so that the
@@ -173,6 +219,12 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     }
     if (!(KO & 4)) request();
   };
+  // CONV: image row / first column of the tile being MULTIPLIED (wave-uniform; a step never straddles image rows: W % 32 == 0)
+  int cy = 0, cx = 0;
+  if constexpr (CONV) {
+    const int l_first = (s_begin % lsteps) << 5;
+    cy = l_first / cv.W, cx = l_first - cy * cv.W;
+  }
   // C(t): 16 fragment reads requested at once, the MFMAs of k slice 0 run under the landing of slice 1's fragments
   auto compute = [&](int t, int slot) __attribute__((always_inline)) {
     const unsigned ab = smem_a + (NA == 1 ? 0 : (t & 1)) * A_STAGE, bb = smem_b + slot * B_STAGE;
@@ -198,10 +250,32 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
         af[ks][2][i] = lds_b128_asm<2 * A_PLANE>(ab + aoff[ks][i]);
       }
     }
-    lds_wait<8>();
+    if constexpr (CONV) {
+      // the waits take the X fragments as in / out operands: the zeroing below must not be scheduled above them
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[0][0]), "+v"(bf[0][1])::"memory");
+    } else {
+      lds_wait<8>();
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 1) lds_wait<0>();
+      if (ks == 1) {
+        if constexpr (CONV) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1])::"memory");
+        else lds_wait<0>();
+      }
+      if constexpr (CONV) {
+        const int xc = cx + (ks * 2 + (lane >> 5)) * 8;          // first column of this lane's 8-pixel chunk
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int yy = cy + fky[j] - 1;
+          u32x4 v = *reinterpret_cast<u32x4*>(&bf[ks][j]);
+          const bool vok = yy >= 0 && yy < cv.H;
+          v.x = (vok && !(fkx[j] == 0 && xc == 0)) ? v.x : (vok ? (v.x & 0xffff0000u) : 0u);
+          v.y = vok ? v.y : 0u;
+          v.z = vok ? v.z : 0u;
+          v.w = (vok && !(fkx[j] == 2 && xc + 8 == cv.W)) ? v.w : (vok ? (v.w & 0x0000ffffu) : 0u);
+          *reinterpret_cast<u32x4*>(&bf[ks][j]) = v;
+        }
+      }
 #pragma unroll
       for (int t3 = 0; t3 < 3; ++t3)
 #pragma unroll
@@ -211,6 +285,13 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
             if (KO & 1) asm volatile("" ::"v"(af[ks][t3][i]), "v"(bf[ks][j]));
             else mfma_bf16(acc[i][j], af[ks][t3][i], bf[ks][j]);
           }
+    }
+    if constexpr (CONV) {
+      cx += BL;
+      if (cx == cv.W) {
+        cx = 0;
+        cy = cy + 1 == cv.H ? 0 : cy + 1;
+      }
     }
   };
 
@@ -320,6 +401,61 @@ __global__ __launch_bounds__(512, 1) void dwp_grouped_kernel(const DwpJobTable t
   }
 }
 
+// the implicit 3x3 weight gradients of up to 16 convolutions in one launch (the same decomposition)
+constexpr int kMaxConvJobs = 16;
+struct DwpConvJob {
+  DwpJob j;
+  DwpConv cv;
+};
+struct DwpConvTable {
+  int njobs, work, quota;
+  DwpConvJob job[kMaxConvJobs];
+};
+template <bool SYM>
+__global__ __launch_bounds__(512, 1) void dwp_conv_kernel(const DwpConvTable tab) {
+  const int id = xcd_contiguous(blockIdx.x, gridDim.x);
+  int w0 = id * tab.quota;
+  const int w1 = min(tab.work, w0 + tab.quota);
+  while (w0 < w1) {
+    int lo = 0, hi = tab.njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab.job[mid].j.first_work <= w0) lo = mid; else hi = mid - 1;
+    }
+    const DwpJob& j = tab.job[lo].j;
+    const int local = w0 - j.first_work;
+    const int tile = local / j.steps, s = local - tile * j.steps;
+    const int n = min(j.steps - s, w1 - w0);
+    dwp_body<SYM, 0, true>(j.dY, j.X, j.dW, j.M, j.K, j.L, j.k_tiles, tile, s, n, tab.job[lo].cv);
+    w0 += n;
+    __syncthreads();
+  }
+}
+
+// Xs[8 + i] = X[i + 1] for i = -1 .. n - 2, zeros elsewhere (Xs holds n + 16 elements): the copy that makes the horizontal taps
+// dword-aligned sources.  The 8-element front pad keeps the chunk that starts one or two elements BEFORE the tensor (kx = 0 at the
+// first pixels of the first plane) inside the buffer -- the hardware's range check drops a copy whose first byte is out of range as a
+// whole, valid elements included.  8 elements per thread.
+__global__ __launch_bounds__(256) void shift1_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ xs,
+                                                          int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n8; i += (int64_t)gridDim.x * 256) {
+    if (i == n8) {          // the pads: X[0] is the last element of the front pad, the tail is zero
+      const unsigned x0 = x[0];
+      *reinterpret_cast<u32x4*>(xs) = u32x4{0u, 0u, 0u, x0 << 16};
+      *reinterpret_cast<u32x4*>(xs + 8 + 8 * n8) = u32x4{0u, 0u, 0u, 0u};
+      continue;
+    }
+    const u32x4 a = *reinterpret_cast<const u32x4*>(x + 8 * i);
+    const unsigned nxt = i + 1 < n8 ? *reinterpret_cast<const unsigned*>(x + 8 * i + 8) : 0u;
+    u32x4 o;
+    o.x = (a.x >> 16) | (a.y << 16);
+    o.y = (a.y >> 16) | (a.z << 16);
+    o.z = (a.z >> 16) | (a.w << 16);
+    o.w = (a.w >> 16) | (nxt << 16);
+    *reinterpret_cast<u32x4*>(xs + 8 + 8 * i) = o;
+  }
+}
+
 bool dwp_shape_ok(int batch, int M, int K, int L) {
   return batch > 0 && M > 0 && K > 0 && L >= 32 && (L & 31) == 0 && (int64_t)M * L < (1ll << 30) && (int64_t)K * L < (1ll << 31) &&
          (int64_t)batch * (L >> 5) < (1ll << 30);
@@ -394,4 +530,63 @@ extern "C" int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, in
     j.steps = B * (j.L >> 5);
   }
   return dwp_launch_table(tab, cfg, target_wgs, stream, "s2f_spike_gemm_dw_pipe_grouped");
+}
+
+// 1 when the pipelined kernel takes the implicit 3x3 weight gradient of this shape
+extern "C" int s2f_spike_conv3x3_dw_pipe_ok(int batch, int M, int C, int H, int W) {
+  return (C > 0 && C % 32 == 0 && H > 0 && W >= 32 && W % 32 == 0 && dwp_shape_ok(batch, M, 9 * C, H * W) &&
+          (int64_t)batch * C * H * W * 2 < (1ll << 31)) ? 1 : 0;
+}
+
+// Xs (n + 16 elements): Xs[8 + i] = X[i + 1], i = -1 .. n - 2, zeros elsewhere (n % 8 == 0; both 16-byte aligned): the shifted copy
+// s2f_spike_conv3x3_dw_pipe reads the horizontal taps from
+extern "C" int s2f_shift1_bf16(const uint16_t* X, uint16_t* Xs, int64_t n, void* stream) {
+  S2F_REQUIRE(X && Xs && n > 0 && (n & 7) == 0, S2F_EINVAL, "s2f_shift1_bf16: null pointer or n %% 8 != 0");
+  S2F_REQUIRE(s2f_aligned16(X) && s2f_aligned16(Xs), S2F_EALIGN, "s2f_shift1_bf16: 16-byte alignment");
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks + 1;          // (+1: the thread that writes the pads)
+  hipLaunchKernelGGL(shift1_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, Xs, n / 8);
+  return s2f_check_launch("s2f_shift1_bf16");
+}
+
+// Implicit 3x3 weight gradients (stride 1, padding 1) on the pipelined kernel, many convolutions per launch: jobs (HOST array):
+// njobs x {dY, X, Xs, dW (pointers), batch, M, C, H, W}; dW [M][3][3][C] tap-major (as s2f_spike_conv3x3_dw_bf16), accumulated
+// into.  Xs = s2f_shift1_bf16(X).  Replaces the autograd weight gradient of MS_ConvBlock's dense 3x3 convolutions
+// (mmseg/models/backbones/sdtv2.py:183-219) and of the stride-1 down-sampling (sdtv2.py:540-548).
+extern "C" int s2f_spike_conv3x3_dw_pipe(const int64_t* jobs, int njobs, int cfg, int target_wgs, void* stream) {
+  S2F_REQUIRE(jobs && njobs > 0 && njobs <= kMaxConvJobs, S2F_EINVAL, "s2f_spike_conv3x3_dw_pipe: 1 .. %d jobs", kMaxConvJobs);
+  DwpConvTable tab;
+  tab.njobs = njobs;
+  int64_t work = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const int64_t* r = jobs + 9 * i;
+    DwpConvJob& cj = tab.job[i];
+    cj.j.dY = reinterpret_cast<const float*>(r[0]);
+    cj.j.X = reinterpret_cast<const unsigned short*>(r[1]);
+    cj.cv.Xs = reinterpret_cast<const unsigned short*>(r[2]);
+    cj.j.dW = reinterpret_cast<float*>(r[3]);
+    const int B = (int)r[4], C = (int)r[6], H = (int)r[7], W = (int)r[8];
+    cj.j.M = (int)r[5];
+    S2F_REQUIRE(cj.j.dY && cj.j.X && cj.cv.Xs && cj.j.dW && s2f_spike_conv3x3_dw_pipe_ok(B, cj.j.M, C, H, W), S2F_EINVAL,
+                "s2f_spike_conv3x3_dw_pipe: bad job %d (needs C %% 32 == 0, W %% 32 == 0)", i);
+    S2F_REQUIRE(s2f_aligned16(cj.j.dY) && s2f_aligned16(cj.j.X) && s2f_aligned16(cj.cv.Xs), S2F_EALIGN,
+                "s2f_spike_conv3x3_dw_pipe: job %d misaligned", i);
+    cj.j.K = 9 * C, cj.j.L = H * W, cj.j.steps = B * (cj.j.L >> 5);
+    cj.cv.C = C, cj.cv.H = H, cj.cv.W = W, cj.cv.x_bytes = (unsigned)((int64_t)B * C * H * W * 2);
+    cj.j.k_tiles = (cj.j.K + TK - 1) / TK;
+    cj.j.first_work = (int)work;
+    work += (int64_t)((cj.j.M + TM - 1) / TM) * cj.j.k_tiles * cj.j.steps;
+    S2F_REQUIRE(work < (1ll << 30), S2F_EINVAL, "s2f_spike_conv3x3_dw_pipe: too much work for one launch");
+  }
+  if (target_wgs <= 0) target_wgs = 256;
+  int quota = (int)((work + target_wgs - 1) / target_wgs);
+  if (quota < 8) quota = 8;
+  const int wgs = (int)((work + quota - 1) / quota);
+  tab.work = (int)work, tab.quota = quota;
+  hipStream_t s = (hipStream_t)stream;
+  if (cfg == 1)
+    S2F_LAUNCH(true, true, (dwp_conv_kernel<true>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
+  else
+    S2F_LAUNCH(true, true, (dwp_conv_kernel<false>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
+  return s2f_check_launch("s2f_spike_conv3x3_dw_pipe");
 }

@@ -249,8 +249,19 @@ class _ConvDense(torch.autograd.Function):
                 gt = torch.empty(M, 3, 3, C, dtype=torch.float32, device=gy.device)        # tap-major, as the kernel contracts
                 _time_next("spike_gemm_dw", 4 * N * H * W * (C + M), 2 * N * M * H * W * K,
                            moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
-                fn = lib.s2f_spike_conv3x3_dw_bf16 if xb else lib.s2f_spike_conv3x3_dw
-                check(fn(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")
+                if xb and cfg.DW_PIPE_CONV and M >= 128 and C >= 64 and lib.s2f_spike_conv3x3_dw_pipe_ok(N, M, C, H, W):
+                    # the LDS-DMA pipelined kernel (csrc/dwp.hip): the horizontal taps come from a copy shifted by one element.
+                    # Its tile is 128 output channels x 256 (tap, input channel) rows: narrower layers stay on the round-2 kernel
+                    # (measured, tools/probe_dwp_conv.py: M = 32 / 64 lose 10-70 %, C = 32 ties)
+                    import ctypes
+                    xs = torch.empty(x.numel() + 16, dtype=x.dtype, device=x.device)
+                    check(lib.s2f_shift1_bf16(_ptr(x), _ptr(xs), x.numel(), _stream()), "s2f_shift1_bf16")
+                    gt.zero_()
+                    arr = (ctypes.c_int64 * 9)(_ptr(gy), _ptr(x), _ptr(xs), _ptr(gt), N, M, C, H, W)
+                    check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, 0, 0, _stream()), "s2f_spike_conv3x3_dw_pipe")
+                else:
+                    fn = lib.s2f_spike_conv3x3_dw_bf16 if xb else lib.s2f_spike_conv3x3_dw
+                    check(fn(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")
                 sink = _sink_for(weight)
                 if sink is not None:
                     sink.view(M, C, 3, 3).add_(gt.permute(0, 3, 1, 2))

@@ -205,3 +205,34 @@ def test_eval_fusion_is_not_taken_when_a_parameter_wants_a_gradient():
     u2, y2 = fused.conv_bn_act(conv, x, bn, lif=lif, want_pre=True)
     assert not u2.requires_grad
     assert torch.allclose(u2, u.detach(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ implicit 3x3 weight gradient, pipelined
+@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("B,M,C,H,W", [(2, 128, 32, 64, 64), (1, 40, 64, 5, 32), (2, 300, 96, 9, 64), (3, 64, 256, 4, 32), (1, 512, 128, 64, 64)])
+def test_pipelined_conv3x3_weight_gradient_matches_conv2d(cfg, B, M, C, H, W):
+    """s2f_spike_conv3x3_dw_pipe (tap-major dW [M, 3, 3, C]) against the weight gradient of F.conv2d in fp64: every border (first /
+    last row, first / last column), tiles that span several taps (C < 256), ragged M, batch boundaries inside a workgroup's piece."""
+    import ctypes
+    import torch.nn.functional as F
+    from spike2former_amd._lib import check, lib
+    assert lib.s2f_spike_conv3x3_dw_pipe_ok(B, M, C, H, W) == 1
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C)
+    x = (torch.randint(0, 9, (B, C, H, W), device="cuda", generator=g).float() / 8).to(torch.bfloat16)
+    gy = torch.randn(B, M, H, W, device="cuda", generator=g)
+    w = torch.zeros(M, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(gy.double())
+    want = w.grad.permute(0, 2, 3, 1).contiguous()                       # [M, ky, kx, C]
+    wabs = torch.zeros(M, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wabs, None, 1, 1).backward(gy.abs().double())
+    scale = wabs.grad.permute(0, 2, 3, 1).clamp_min(1e-30)
+    xs = torch.empty(x.numel() + 16, dtype=x.dtype, device=x.device)
+    check(lib.s2f_shift1_bf16(x.data_ptr(), xs.data_ptr(), x.numel(), _stream()), "shift1")
+    assert torch.equal(xs[7:7 + x.numel()], x.view(-1)) and float(xs[:7].abs().sum()) == 0.0 and float(xs[7 + x.numel():].abs().sum()) == 0.0
+    for wgs in (0, 5, 700):
+        out = torch.zeros(M, 3, 3, C, device="cuda")
+        arr = (ctypes.c_int64 * 9)(gy.data_ptr(), x.data_ptr(), xs.data_ptr(), out.data_ptr(), B, M, C, H, W)
+        check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, cfg, wgs, _stream()), "conv3x3_dw_pipe")
+        torch.cuda.synchronize()
+        assert ((out.double() - want).abs() / scale).max().item() <= 2e-6, wgs
+    assert lib.s2f_spike_conv3x3_dw_pipe_ok(2, 64, 32, 8, 84) == 0          # W % 32 != 0 (C5's maps): stays on the round-2 kernel
