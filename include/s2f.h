@@ -288,8 +288,9 @@ int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int
 int s2f_spike_gemm_dw_grouped(const int64_t* jobs, int njobs, int bkv, void* stream);
 /* The same weight gradients on the LDS-DMA pipeline (csrc/dwp.hip, round 5): tile 128 (dY rows) x 256 (X rows), contraction step
  * 32, eight wavefronts in two halves that alternate a multiply segment with a staging segment (X by global_load_lds into a
- * three-slot ring, dY split hi + mid + lo through registers into two stages), one barrier per segment.  Needs L % 32 == 0,
- * M L < 2^30, K L < 2^31 (s2f_spike_gemm_dw_pipe_ok says whether a shape qualifies; the host falls back to
+ * three-slot ring, dY split hi + mid + lo through registers into two stages), one barrier per segment.  Needs L % 4 == 0,
+ * L >= 32, M L < 2^30, K L < 2^31; with L % 32 != 0 the last step of a batch element is masked while dY is split and the copies
+ * are range-checked against the whole tensors: batch M L < 2^30, batch K L < 2^31 (s2f_spike_gemm_dw_pipe_ok says whether a shape qualifies; the host falls back to
  * s2f_spike_gemm_dw_bf16 otherwise).  cfg: 0 = the two-halves schedule, 1 = every wavefront in the same phase (probe);
  * target_wgs <= 0: default split of the contraction.  Replaces the autograd weight gradient of the 1x1 convolutions fed by a
  * Q_IFNode (mmseg/models/backbones/sdtv2.py:222-255, 304-306; mmcv_spike/transformer.py:213-236, 758-763;
@@ -304,7 +305,7 @@ int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, int cfg, int 
  * reads the horizontal taps from Xs, a copy of the activation shifted by one element behind an 8-element front pad (s2f_shift1_bf16:
  * Xs holds n + 16 elements, Xs[8 + i] = X[i + 1] for i = -1 .. n - 2, zeros elsewhere; n % 8 == 0),
  * and zeroes in the fragments what the zero padding would have supplied.  jobs (HOST array): njobs x {dY, X, Xs, dW (pointers),
- * batch, M, C, H, W} as int64; every dW is accumulated into.  Needs C % 32 == 0, W % 32 == 0, B C H W 2 < 2^31
+ * batch, M, C, H, W} as int64; every dW is accumulated into.  Needs C % 32 == 0, W % 8 == 0, W >= 32, H W % 32 == 0, B C H W 2 < 2^31
  * (s2f_spike_conv3x3_dw_pipe_ok).  Replaces the autograd weight gradient of MS_ConvBlock's dense 3x3 convolutions and of the stride-1
  * down-sampling (mmseg/models/backbones/sdtv2.py:183-219, 540-548). */
 int s2f_spike_conv3x3_dw_pipe_ok(int batch, int M, int C, int H, int W);

@@ -137,10 +137,16 @@ class MS_Attention_linear(nn.Module):
         s = self.head_spike.fire(x).flatten(0, 1)
         q = bn_act(self.q_conv[0](s), None, self.q_conv[1], lif=self.q_spike)[1].view(T * B, C, N)
         k = bn_act(self.k_conv[0](s), None, self.k_conv[1], lif=self.k_spike)[1].view(T * B, C, N)
-        v = bn_act(self.v_conv[0](s), None, self.v_conv[1], lif=self.v_spike)[1].float()         # [TB, r*C, H, W]
+        v = bn_act(self.v_conv[0](s), None, self.v_conv[1], lif=self.v_spike)[1]                 # [TB, r*C, H, W]
         # value channel c_v = head * (r d) + j * d + jj: the j-th d-wide slice of every head is one ordinary attention problem
-        vj = v.view(T * B, h, r, d, N).permute(2, 0, 1, 3, 4).contiguous()                      # [r, TB, h, d, N]
-        o = torch.stack([ops.sdsa(q, k, vj[j].reshape(T * B, C, N), h, self.scale * 2) for j in range(r)], 0)
+        if isinstance(v, ops.Spikes) and v.tok is not None:
+            # bf16 spikes stay bf16 (the regrouping copy moves half the bytes, the attention core runs its bf16 kernels)
+            vj = v.view(T * B, h, r, d, N).permute(2, 0, 1, 3, 4).contiguous()                  # [r, TB, h, d, N]
+            vs = [ops.Spikes(vj.data[j].view(T * B, C, N), vj.tok[j].reshape(T * B, C, N)) for j in range(r)]
+        else:
+            vj = ops.spikes_float(v).view(T * B, h, r, d, N).permute(2, 0, 1, 3, 4).contiguous()
+            vs = [vj[j].reshape(T * B, C, N) for j in range(r)]
+        o = torch.stack([ops.sdsa(q, k, vs[j], h, self.scale * 2) for j in range(r)], 0)
         o = o.view(r, T * B, h, d, N).permute(1, 2, 0, 3, 4).reshape(T * B, r * C, H, W)        # back to c_v order
         o = self.attn_spike.fire(o)
         res = None if residual is None else residual.flatten(0, 1)

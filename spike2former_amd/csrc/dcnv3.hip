@@ -371,6 +371,10 @@ __global__ __launch_bounds__(1024) void dcn_bwd_lds_kernel(const float* __restri
       const bool in0 = !BANDED || (t.y0 >= y_lo && t.y0 < y_hi), in1 = !BANDED || (t.y0 + 1 >= y_lo && t.y0 + 1 < y_hi);
       const bool s00 = b00 && in0, s01 = b01 && in0, s10 = b10 && in1, s11 = b11 && in1;
       const bool mine = !BANDED || min(nb - 1, ho / rows_ob) == band;
+      // BANDED: an item whose corners lie in other bands and whose offset / mask gradients another band forms costs this workgroup
+      // its tap arithmetic only (neighbouring pixels share their band: whole wavefronts skip the channel loop; without the test
+      // every band repeated the channel loop of every item, nb times the work)
+      if (BANDED && !(mine || s00 || s01 || s10 || s11)) continue;
       const int a00 = ((t.y0 - y_lo) * g.W + t.x0) * CA;
       float am = 0.f, ax = 0.f, ay = 0.f;
       // channels four at a time: 16-byte LDS reads of the grad_output row and the four corner rows (scalar reads put the
@@ -525,6 +529,16 @@ extern "C" int s2f_dcnv3_bwd(const float* input, const float* offset, const floa
     int nb = force_bands > 1 ? force_bands : 2;
     auto band_lds = [&](int b) { return (size_t)((H + b - 1) / b) * W * 8 * (Cg + 1) + staging; };
     while (force_bands <= 1 && nb < H && nb < 64 && band_lds(nb) > kMaxDynLds) ++nb;
+    if (force_bands <= 1) {
+      // A workgroup pays ~57 us per 256-pixel chunk whose rows are its own (LDS atomics) and ~7 us for every other chunk it walks
+      // (tools/probe_dcn.py, fitted over 3 .. 10 bands at 50 x 84); one workgroup per CU.  Among the next few band counts take
+      // the one with the least  (8 / nb + 1) x rounds:  4 bands instead of 3 at C5 (512 workgroups = two full rounds, 853 -> 729 us)
+      auto cost = [&](int b) { return (8.0 / b + 1.0) * (double)(((int64_t)N * G * b + 255) / 256); };
+      int best = nb;
+      for (int b = nb + 1; b <= nb + 3 && b <= H && b < 64; ++b)
+        if (cost(b) < cost(best) - 1e-9) best = b;
+      nb = best;
+    }
     if (nb <= H && band_lds(nb) <= kMaxDynLds && (int64_t)N * G * nb < ((int64_t)1 << 31)) {
       static bool raised_b = false;
       if (!raised_b) {

@@ -1,6 +1,6 @@
 // Weight gradient of a spike-fed convolution on the LDS-DMA pipeline, 8 wavefronts in two halves (gfx950, round 5).
 //
-//   dW[m][k] += sum_b sum_l dY[b][m][l] X[b][k][l]        dY fp32 [B][M][L],  X bf16 spikes [B][K][L],  L % 32 == 0
+//   dW[m][k] += sum_b sum_l dY[b][m][l] X[b][k][l]        dY fp32 [B][M][L],  X bf16 spikes [B][K][L],  L % 4 == 0
 //
 // The round-2 kernel (gemm_bf16.hip: dw_tile_body) stages BOTH operands through registers into a 64 x 128 tile and its four
 // wavefronts run  stage -> barrier -> fragment reads -> MFMA -> barrier  one after the other: per step a workgroup moves
@@ -78,17 +78,21 @@ constexpr int NRAW = 3;
 // shifted by the tap; X is the activation [B][C][H][W] itself and Xs a copy shifted by ONE element (Xs[i] = X[i + 1]), so that
 // the horizontal taps are dword-aligned copy sources too: kx = 1 reads X at l + (ky - 1) W, kx = 2 reads Xs at the same place,
 // kx = 0 reads Xs two elements earlier.  What the zero padding would have supplied is zeroed in the X fragments: a tap above /
-// below the image (whole 8-pixel chunk: W % 32 == 0 keeps a 32-pixel step inside one image row), the first pixel of a row for
-// kx = 0, the last for kx = 2.  A copy instruction covers 16 rows of one tap (C % 16 == 0).
+// below the image (whole 8-pixel chunk: W % 8 == 0), the first pixel of a row for kx = 0, the last for kx = 2.  A copy instruction covers 16 rows of one tap (C % 16 == 0).
 struct DwpConv {
   const unsigned short* Xs;
   int C, H, W;
   unsigned x_bytes;          // bytes of X (= of Xs): B C H W 2 < 2^31
 };
-template <bool SYM, int KO = 0, bool CONV = false>
+// RAG ("ragged"): L % 32 != 0 (L % 4 == 0) -- the 100-token layers of the decoder, the 50 x 84 maps of C5.  The last step of a batch
+// element runs past the end of the rows: the copies are range-checked against the whole tensors (B M L < 2^30, B K L < 2^31: the
+// offsets count from the start of the tensor), dY is zeroed past l = L while it is split -- whatever X holds there (the head of
+// the next row: finite spikes, or the zeros of the range check) is multiplied by zero.
+template <bool SYM, int KO = 0, bool CONV = false, bool RAG = false>
 __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const unsigned short* __restrict__ X,
                                          float* __restrict__ dW, int M, int K, int L, int k_tiles, int tile, int s_begin,
-                                         int n, DwpConv cv = DwpConv{}) {
+                                         int n, DwpConv cv = DwpConv{}, int B = 0) {
+  static_assert(!(CONV && RAG), "the ragged form is for the plain products");
   constexpr int NA = SYM ? 1 : 2, NB = SYM ? 3 : 4;
   // separate OBJECTS: hipcc orders an LDS store behind every LDS-DMA in flight that it cannot prove disjoint
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NA * A_STAGE];          // dY planes hi | mid | lo
@@ -155,15 +159,27 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // cursor of the next tile to REQUEST (wave-uniform): batch element, contraction offset, ring positions
-  const int lsteps = L >> 5;
+  const int lsteps = RAG ? (L + 31) >> 5 : L >> 5;
   int cb = s_begin / lsteps, cl = (s_begin - cb * lsteps) << 5;
+  const unsigned dy_bytes = RAG ? (unsigned)B * (unsigned)M * (unsigned)L * 4u : 0u;
+  const unsigned xr_bytes = RAG ? (unsigned)B * (unsigned)K * (unsigned)L * 2u : 0u;
   int next_slot = 0, next_raw = 0, loaded = 0;
   // one group = 4 copies per wavefront: {dY rows 0-7, dY rows 8-15, X rows 0-15, X rows 16-31} of its share
   auto request = [&]() __attribute__((always_inline)) {
-    const char* pa = reinterpret_cast<const char*>(dY + (int64_t)cb * M * L + cl);
+    if constexpr (RAG) {
+      const unsigned ua = (unsigned)(cb * M * L + cl) * 4u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(pa, oa[i], smem_raw + next_raw * RAW_SLOT + wave * 2048 + i * 1024);
-    if constexpr (CONV) {
+      for (int i = 0; i < 2; ++i) dma16_checked(dY, dy_bytes, oa[i] + ua, smem_raw + next_raw * RAW_SLOT + wave * 2048 + i * 1024);
+    } else {
+      const char* pa = reinterpret_cast<const char*>(dY + (int64_t)cb * M * L + cl);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16(pa, oa[i], smem_raw + next_raw * RAW_SLOT + wave * 2048 + i * 1024);
+    }
+    if constexpr (RAG) {
+      const unsigned ux = (unsigned)(cb * K * L + cl) * 2u;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) dma16_checked(X, xr_bytes, ob[q] + ux, smem_ring + next_slot * B_STAGE + (wave * 2 + q) * 1024);
+    } else if constexpr (CONV) {
       const unsigned uni = (unsigned)((cb * cv.C * L + cl) * 2);          // batch element + step, bytes (x_bytes < 2^31)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -180,7 +196,7 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     // number of copies in flight at any point of the loop does not depend on the path taken
     if (++loaded < n) {
       cl += BL;
-      if (cl == L) {
+      if (cl >= L) {
         cl = 0;
         ++cb;
       }
@@ -190,6 +206,7 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
   // conversion -- are split hi + mid + lo into plane stage u % NA; then tile u + 2 is requested.  In flight at the head of S(u):
   // group u + 1 (4 copies: may stay in flight) behind group u.
   int raw_slot = 0;
+  int sl = cl + (lane & 7) * 4;          // RAG: contraction offset of this lane's float4 in the tile being staged
   auto stage = [&](int u) __attribute__((always_inline)) {
     if (u >= n || (KO & 8)) return;
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -199,6 +216,11 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(rb_));
     asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v[1]) : "v"(rb_));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+    if constexpr (RAG) {
+      if (sl >= L) v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sl += BL;
+      if (sl - (int)(lane & 7) * 4 >= L) sl = (lane & 7) * 4;
+    }
     unsigned char* as = smem + (NA == 1 ? 0 : (u & 1)) * A_STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -219,7 +241,7 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     }
     if (!(KO & 4)) request();
   };
-  // CONV: image row / first column of the tile being MULTIPLIED (wave-uniform; a step never straddles image rows: W % 32 == 0)
+  // CONV: image row / first column of the tile being MULTIPLIED (wave-uniform)
   int cy = 0, cx = 0;
   if constexpr (CONV) {
     const int l_first = (s_begin % lsteps) << 5;
@@ -263,10 +285,13 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
         else lds_wait<0>();
       }
       if constexpr (CONV) {
-        const int xc = cx + (ks * 2 + (lane >> 5)) * 8;          // first column of this lane's 8-pixel chunk
+        // first column / image row of this lane's 8-pixel chunk: a 32-pixel step may run into the next image row (W % 8 == 0 keeps a
+        // chunk inside one row, H W % 32 == 0 a step inside one image)
+        int xc = cx + (ks * 2 + (lane >> 5)) * 8, yc = cy;
+        if (xc >= cv.W) xc -= cv.W, ++yc;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int yy = cy + fky[j] - 1;
+          const int yy = yc + fky[j] - 1;
           u32x4 v = *reinterpret_cast<u32x4*>(&bf[ks][j]);
           const bool vok = yy >= 0 && yy < cv.H;
           v.x = (vok && !(fkx[j] == 0 && xc == 0)) ? v.x : (vok ? (v.x & 0xffff0000u) : 0u);
@@ -288,8 +313,8 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
     }
     if constexpr (CONV) {
       cx += BL;
-      if (cx == cv.W) {
-        cx = 0;
+      if (cx >= cv.W) {
+        cx -= cv.W;
         cy = cy + 1 == cv.H ? 0 : cy + 1;
       }
     }
@@ -372,7 +397,7 @@ struct DwpJob {
   const float* dY;
   const unsigned short* X;
   float* dW;
-  int M, K, L, steps;          // steps = batch * L / 32 contraction steps per tile
+  int M, K, L, steps;          // steps = batch * ceil(L / 32) contraction steps per tile
   int first_work, k_tiles;     // first_work: index of this job's first (tile, step) pair in the line
 };
 struct DwpJobTable {
@@ -380,7 +405,7 @@ struct DwpJobTable {
   DwpJob job[kMaxJobs];
 };
 
-template <bool SYM, int KO = 0>
+template <bool SYM, int KO = 0, bool RAG = false>
 __global__ __launch_bounds__(512, 1) void dwp_grouped_kernel(const DwpJobTable tab) {
   const int id = xcd_contiguous(blockIdx.x, gridDim.x);
   int w0 = id * tab.quota;
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void dwp_grouped_kernel(const DwpJobTable t
     const int local = w0 - j.first_work;
     const int tile = local / j.steps, s = local - tile * j.steps;
     const int n = min(j.steps - s, w1 - w0);
-    dwp_body<SYM, KO>(j.dY, j.X, j.dW, j.M, j.K, j.L, j.k_tiles, tile, s, n);
+    dwp_body<SYM, KO, false, RAG>(j.dY, j.X, j.dW, j.M, j.K, j.L, j.k_tiles, tile, s, n, DwpConv{}, RAG ? j.steps / ((j.L + 31) >> 5) : 0);
     w0 += n;
     __syncthreads();                                      // the next piece re-uses the LDS stages
   }
@@ -457,8 +482,9 @@ __global__ __launch_bounds__(256) void shift1_bf16_kernel(const unsigned short* 
 }
 
 bool dwp_shape_ok(int batch, int M, int K, int L) {
-  return batch > 0 && M > 0 && K > 0 && L >= 32 && (L & 31) == 0 && (int64_t)M * L < (1ll << 30) && (int64_t)K * L < (1ll << 31) &&
-         (int64_t)batch * (L >> 5) < (1ll << 30);
+  if (!(batch > 0 && M > 0 && K > 0 && L >= 32 && (L & 3) == 0 && (int64_t)batch * ((L + 31) >> 5) < (1ll << 30))) return false;
+  if (L & 31) return (int64_t)batch * M * L < (1ll << 30) && (int64_t)batch * K * L < (1ll << 31);          // ragged: whole-tensor offsets
+  return (int64_t)M * L < (1ll << 30) && (int64_t)K * L < (1ll << 31);
 }
 
 }  // namespace
@@ -488,8 +514,13 @@ static int dwp_launch_table(DwpJobTable& tab, int cfg, int target_wgs, void* str
   S2F_KO(1) S2F_KO(3) S2F_KO(4) S2F_KO(12) S2F_KO(15) S2F_KO(20) S2F_KO(36) S2F_KO(52) S2F_KO(48)
 #undef S2F_KO
 #endif
+  bool ragged = false;
+  for (int i = 0; i < tab.njobs; ++i) ragged = ragged || (tab.job[i].L & 31) != 0;
+  S2F_REQUIRE(!ragged || cfg == 0, S2F_EINVAL, "%s: L %% 32 != 0 runs on the two-halves schedule only (cfg 0)", who);
   if (cfg == 1)
     S2F_LAUNCH(true, true, (dwp_grouped_kernel<true>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
+  else if (ragged)
+    S2F_LAUNCH(true, true, (dwp_grouped_kernel<false, 0, true>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
   else
     S2F_LAUNCH(true, true, (dwp_grouped_kernel<false>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
   return s2f_check_launch(who);
@@ -500,14 +531,14 @@ static int dwp_launch_table(DwpJobTable& tab, int cfg, int target_wgs, void* str
 extern "C" int s2f_spike_gemm_dw_pipe(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L,
                                       int accumulate, int cfg, int target_wgs, void* stream) {
   S2F_REQUIRE(dY && X && dW, S2F_EINVAL, "s2f_spike_gemm_dw_pipe: null pointer");
-  S2F_REQUIRE(dwp_shape_ok(batch, M, K, L), S2F_EINVAL, "s2f_spike_gemm_dw_pipe: needs L %% 32 == 0, M L < 2^30, K L < 2^31 (M=%d K=%d L=%d)",
+  S2F_REQUIRE(dwp_shape_ok(batch, M, K, L), S2F_EINVAL, "s2f_spike_gemm_dw_pipe: needs L %% 4 == 0, L >= 32, M L < 2^30, K L < 2^31 (M=%d K=%d L=%d)",
               M, K, L);
   S2F_REQUIRE(s2f_aligned16(dY) && s2f_aligned16(X), S2F_EALIGN, "s2f_spike_gemm_dw_pipe: operands must be 16-byte aligned");
   if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, (hipStream_t)stream) != S2F_OK)
     return s2f_check_launch("s2f_spike_gemm_dw_pipe memset");
   DwpJobTable tab;
   tab.njobs = 1;
-  tab.job[0] = DwpJob{dY, X, dW, M, K, L, batch * (L >> 5), 0, 0};
+  tab.job[0] = DwpJob{dY, X, dW, M, K, L, batch * ((L + 31) >> 5), 0, 0};
   return dwp_launch_table(tab, cfg, target_wgs, stream, "s2f_spike_gemm_dw_pipe");
 }
 
@@ -527,14 +558,14 @@ extern "C" int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, in
     j.M = (int)r[4], j.K = (int)r[5], j.L = (int)r[6];
     S2F_REQUIRE(j.dY && j.X && j.dW && dwp_shape_ok(B, j.M, j.K, j.L), S2F_EINVAL, "s2f_spike_gemm_dw_pipe_grouped: bad job %d", i);
     S2F_REQUIRE(s2f_aligned16(j.dY) && s2f_aligned16(j.X), S2F_EALIGN, "s2f_spike_gemm_dw_pipe_grouped: job %d misaligned", i);
-    j.steps = B * (j.L >> 5);
+    j.steps = B * ((j.L + 31) >> 5);
   }
   return dwp_launch_table(tab, cfg, target_wgs, stream, "s2f_spike_gemm_dw_pipe_grouped");
 }
 
 // 1 when the pipelined kernel takes the implicit 3x3 weight gradient of this shape
 extern "C" int s2f_spike_conv3x3_dw_pipe_ok(int batch, int M, int C, int H, int W) {
-  return (C > 0 && C % 32 == 0 && H > 0 && W >= 32 && W % 32 == 0 && dwp_shape_ok(batch, M, 9 * C, H * W) &&
+  return (C > 0 && C % 32 == 0 && H > 0 && W >= 32 && W % 8 == 0 && (H * W) % 32 == 0 && dwp_shape_ok(batch, M, 9 * C, H * W) &&
           (int64_t)batch * C * H * W * 2 < (1ll << 31)) ? 1 : 0;
 }
 
@@ -568,7 +599,7 @@ extern "C" int s2f_spike_conv3x3_dw_pipe(const int64_t* jobs, int njobs, int cfg
     const int B = (int)r[4], C = (int)r[6], H = (int)r[7], W = (int)r[8];
     cj.j.M = (int)r[5];
     S2F_REQUIRE(cj.j.dY && cj.j.X && cj.cv.Xs && cj.j.dW && s2f_spike_conv3x3_dw_pipe_ok(B, cj.j.M, C, H, W), S2F_EINVAL,
-                "s2f_spike_conv3x3_dw_pipe: bad job %d (needs C %% 32 == 0, W %% 32 == 0)", i);
+                "s2f_spike_conv3x3_dw_pipe: bad job %d (needs C %% 32 == 0, W %% 8 == 0, W >= 32, H W %% 32 == 0)", i);
     S2F_REQUIRE(s2f_aligned16(cj.j.dY) && s2f_aligned16(cj.j.X) && s2f_aligned16(cj.cv.Xs), S2F_EALIGN,
                 "s2f_spike_conv3x3_dw_pipe: job %d misaligned", i);
     cj.j.K = 9 * C, cj.j.L = H * W, cj.j.steps = B * (cj.j.L >> 5);

@@ -12,7 +12,8 @@
 // Spike operands are multiples of 1/D, so every product and every partial sum is exactly representable in fp32
 // while it stays below 2^24 ulps: the result is independent of summation order (atomics included) and identical to
 // the reference's fp32 matmuls.  The tests assert that bound instead of a tolerance.
-#include "s2f_common.h"
+#include "gemm_common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(fast)
 
@@ -359,7 +360,7 @@ int launch_outer(Operand<TA> a, Operand<TB> b, float* kv, int TB_, int heads, in
 // file header), so neither the four waves' interleaved 16-column slices (added through LDS) nor the split-N atomics depend
 // on the order of the additions.  The VALU form (outer_kernel) spent 17 us on the 1 024-token maps of the backbone, most
 // of it in 2 M fp32 atomics of its 16-way split, and 51 us on the decoder's 16 384-token keys.
-// grid (nsplit, TB*heads); N % 64 == 0, 16-byte aligned rows.  DT = ceil(d / 32) tiles per side.
+// grid (nsplit, TB*heads); N % 8 == 0 (16-byte aligned rows; C5's 4 200-token maps end in a partly filled step).  DT = ceil(d / 32) tiles per side.
 typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
 typedef __attribute__((ext_vector_type(16))) float ff32x16;
 
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const unsigned short* _
       for (int a = 0; a < DT; ++a) {
         const int i = a * 32 + row, n = n0 + u * 64;
         ka[u][a] = vb[u][a] = make_uint4(0u, 0u, 0u, 0u);
-        if (i < d && n < n_end) {
+        if (i < d && n + ksub < n_end) {          // (N % 8 == 0: a lane's 8 columns are inside the row or past it)
           ka[u][a] = *reinterpret_cast<const uint4*>(ar + (int64_t)i * N + n + ksub);
           vb[u][a] = *reinterpret_cast<const uint4*>(br + (int64_t)i * N + n + ksub);
         }
@@ -439,10 +440,126 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const unsigned short* _
   }
 }
 
+// The same product with a GENERAL fp32 second operand (the gradient of kv: q^T (scale go), go with or without the straight-through
+// mask of the fused neuron): b is split hi + mid + lo into three bf16 terms in registers -- the terms of the weight-gradient kernels
+// (gemm_common.h s2f_split3x2: 24 bits) -- three MFMAs per tile pair against the exact spike operand, fp32 accumulation as the
+// VALU form it replaces (outer_kernel<unsigned short, float>: 12 us at the 1 024-token maps of C2, 29 us at C5's 4 200).
+template <int DT>
+__global__ __launch_bounds__(256) void outer_mfma_sg_kernel(const unsigned short* __restrict__ A, int64_t a_bs, Operand<float> OB,
+                                                            float* __restrict__ KV, int heads, int d, int N, float alpha) {
+  __shared__ __attribute__((aligned(16))) float red[3][DT * DT][16][64];
+  const int bh = blockIdx.y;
+  const int tb = bh / heads, h = bh % heads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned short* ar = A + (int64_t)tb * a_bs + (int64_t)h * d * N;
+  const float* br = OB.base + (int64_t)tb * OB.batch_stride + (int64_t)h * d * N;
+  const int64_t e0 = ((int64_t)tb * heads * d + h * d) * N;
+  const int nsplit = gridDim.x;
+  const int chunk = ((N + nsplit - 1) / nsplit + 63) / 64 * 64;
+  const int n_begin = blockIdx.x * chunk, n_end = min(N, n_begin + chunk);
+  ff32x16 acc[DT][DT];
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int row = lane & 31, ksub = 8 * (lane >> 5);
+  constexpr int U = 2;
+  for (int n0 = n_begin + wave * 16; n0 < n_end; n0 += 64 * U) {
+    uint4 ka[U][DT];
+    float4 g0[U][DT], g1[U][DT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int a = 0; a < DT; ++a) {
+        const int i = a * 32 + row, n = n0 + u * 64;
+        ka[u][a] = make_uint4(0u, 0u, 0u, 0u);
+        g0[u][a] = g1[u][a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < d && n + ksub < n_end) {
+          ka[u][a] = *reinterpret_cast<const uint4*>(ar + (int64_t)i * N + n + ksub);
+          g0[u][a] = opnd_ld4(OB, br + (int64_t)i * N, e0 + (int64_t)i * N, n + ksub);
+          g1[u][a] = opnd_ld4(OB, br + (int64_t)i * N, e0 + (int64_t)i * N, n + ksub + 4);
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (n0 + u * 64 >= n_end) continue;            // wave-uniform
+      u32x4 t3[3][DT];
+#pragma unroll
+      for (int b = 0; b < DT; ++b) {
+        unsigned int hh[4], mm[4], ll[4];
+        s2f_split3x2(g0[u][b].x, g0[u][b].y, hh[0], mm[0], ll[0]);
+        s2f_split3x2(g0[u][b].z, g0[u][b].w, hh[1], mm[1], ll[1]);
+        s2f_split3x2(g1[u][b].x, g1[u][b].y, hh[2], mm[2], ll[2]);
+        s2f_split3x2(g1[u][b].z, g1[u][b].w, hh[3], mm[3], ll[3]);
+        t3[0][b] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        t3[1][b] = u32x4{mm[0], mm[1], mm[2], mm[3]};
+        t3[2][b] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      }
+#pragma unroll
+      for (int a = 0; a < DT; ++a)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int t = 2; t >= 0; --t)          // small terms first
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<fbf16x8*>(&ka[u][a]),
+                                                                *reinterpret_cast<fbf16x8*>(&t3[t][b]), acc[a][b], 0, 0, 0);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < DT; ++a)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][a * DT + b][r][lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* kvg = KV + (int64_t)bh * d * d;
+#pragma unroll
+    for (int a = 0; a < DT; ++a)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[a][b][r] + red[0][a * DT + b][r][lane] + red[1][a * DT + b][r][lane] + red[2][a * DT + b][r][lane];
+          const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = b * 32 + (lane & 31);
+          if (i < d && j < d) {
+            if (nsplit > 1)
+              atomicAdd(&kvg[i * d + j], v * alpha);
+            else
+              kvg[i * d + j] = v * alpha;
+          }
+        }
+  }
+}
+
+// spike x general outer product: the matrix-core form when the rows allow 16-byte loads, else the VALU form
+int launch_outer_spikes_general(const unsigned short* a, int64_t a_bs, Operand<float> b, float* kv, int TB_, int heads, int d, int N,
+                                float alpha, hipStream_t s) {
+  static const char* off = getenv("S2F_SDSA_OUTER_SG_VALU");          // A/B switch: "1" keeps the VALU form
+  const bool mfma = !(off && off[0] == '1') && (N & 7) == 0 && (a_bs & 7) == 0 && (b.batch_stride & 3) == 0 && s2f_aligned16(a) &&
+                    s2f_aligned16(b.base);
+  if (!mfma) return launch_outer(Operand<unsigned short>{a, a_bs, nullptr, 0.f}, b, kv, TB_, heads, d, N, alpha, s);
+  int ns = N / 128;                                  // two 16-column steps per wave and workgroup
+  const int cap = 2048 / (TB_ * heads) > 1 ? 2048 / (TB_ * heads) : 1;
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  if (ns > 1 && s2f_zero_async(kv, sizeof(float) * (size_t)TB_ * heads * d * d, s) != S2F_OK)
+    return s2f_check_launch("s2f_sdsa_kv clear");
+  if (d <= 32)
+    hipLaunchKernelGGL((outer_mfma_sg_kernel<1>), dim3(ns, TB_ * heads), dim3(256), 0, s, a, a_bs, b, kv, heads, d, N, alpha);
+  else
+    hipLaunchKernelGGL((outer_mfma_sg_kernel<2>), dim3(ns, TB_ * heads), dim3(256), 0, s, a, a_bs, b, kv, heads, d, N, alpha);
+  return s2f_check_launch("s2f_sdsa_kv");
+}
+
 // spike x spike outer product: the matrix-core form when the rows allow 16-byte loads
 int launch_outer_spikes(const unsigned short* a, int64_t a_bs, const unsigned short* b, int64_t b_bs, float* kv, int TB_, int heads,
                         int d, int N, float alpha, hipStream_t s) {
-  const bool mfma = (N & 63) == 0 && ((a_bs | b_bs) & 7) == 0 && s2f_aligned16(a) && s2f_aligned16(b);
+  const bool mfma = (N & 7) == 0 && ((a_bs | b_bs) & 7) == 0 && s2f_aligned16(a) && s2f_aligned16(b);
   if (!mfma)
     return launch_outer(Operand<unsigned short>{a, a_bs, nullptr, 0.f}, Operand<unsigned short>{b, b_bs, nullptr, 0.f}, kv, TB_,
                         heads, d, N, alpha, s);
@@ -553,7 +670,7 @@ extern "C" int s2f_sdsa_bwd_bf16(const uint16_t* q, const uint16_t* k, const uin
   // the incoming gradient: of o, or -- with go_mask -- of the spikes y = Q_IFNode(o): straight-through inside the loaders
   const Operand<float> G{go, obs, go_mask, go_mask ? 1.0f / (float)D : 0.f};
   launch_apply<true>(G, kv_save, gq, gq_batch_stride, TB, heads, d, Nq, scale, s);
-  rc = launch_outer(Operand<unsigned short>{q, q_batch_stride, nullptr, 0.f}, G, gkv_ws, TB, heads, d, Nq, scale, s);
+  rc = launch_outer_spikes_general(q, q_batch_stride, G, gkv_ws, TB, heads, d, Nq, scale, s);
   if (rc) return rc;
   launch_apply<true>(Operand<unsigned short>{v, v_batch_stride, nullptr, 0.f}, gkv_ws, gk, gk_batch_stride, TB, heads, d, Nk, 1.0f, s);
   launch_apply<false>(Operand<unsigned short>{k, k_batch_stride, nullptr, 0.f}, gkv_ws, gv, gv_batch_stride, TB, heads, d, Nk, 1.0f, s);

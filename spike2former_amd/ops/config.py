@@ -29,9 +29,9 @@ class Config:
         self.MASK_EINSUM_DE_MFMA = True
         self.MASK_FWD_PGEMM = os.environ.get("S2F_MASK_FWD_PGEMM", "1") != "0"          # folded mask contraction forward on the LDS-DMA pipeline
         self.SPIKE_GEMM_DW = True
-        # deferred / grouped weight gradients on the LDS-DMA pipeline (csrc/dwp.hip) where the shape qualifies (L % 32 == 0)
+        # deferred / grouped weight gradients on the LDS-DMA pipeline (csrc/dwp.hip) where the shape qualifies (L % 4 == 0, L >= 32)
         self.DW_PIPE = os.environ.get("S2F_DW_PIPE", "1") != "0"
-        self.DW_PIPE_CONV = os.environ.get("S2F_DW_PIPE_CONV", "1") != "0"          # ... and the implicit 3x3 weight gradients (W % 32 == 0)
+        self.DW_PIPE_CONV = os.environ.get("S2F_DW_PIPE_CONV", "1") != "0"          # ... and the implicit 3x3 weight gradients (W % 8 == 0)
         self.SPIKE_GEMM_CHECK = False
         self.PGEMM = os.environ.get("S2F_PGEMM", "1") != "0"
         self.PGEMM_DX = os.environ.get("S2F_PGEMM_DX", "1") != "0"

@@ -192,7 +192,7 @@ def wgrad_flush():
         check(lib.s2f_gemm_dw_general_grouped(arr, len(chunk), _stream()), "s2f_gemm_dw_general_grouped")
         del _DWG_PENDING[:56]
     if cfg.DW_PIPE:
-        # the jobs the pipelined kernel takes (L % 32 == 0) leave their step classes for ONE list: a grouped launch spreads equal
+        # the jobs the pipelined kernel takes (L % 4 == 0, L >= 32) leave their step classes for ONE list: a grouped launch spreads equal
         # shares of all its jobs over the CUs, so the more it holds the better
         pipe = []
         for bkv, jobs in _DW_PENDING.items():

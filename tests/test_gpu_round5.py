@@ -21,13 +21,20 @@ def _operands(B, M, K, L, seed):
     return gy, x
 
 
-# ragged M / K (tile 128 x 256), contraction lengths from one step to many batches, both schedules
+# ragged M / K (tile 128 x 256), contraction lengths from one step to many batches, both schedules; L % 32 != 0 (the decoder's
+# 100-token maps, C5's 50 x 84 maps, one and a bit steps) on the two-halves schedule
 @pytest.mark.parametrize("cfg", [0, 1])
 @pytest.mark.parametrize("B,M,K,L", [(8, 256, 256, 1024), (2, 700, 256, 4096), (3, 130, 300, 96), (1, 64, 32, 32), (5, 360, 1440, 64),
-                                     (2, 1024, 256, 1024), (1, 5, 7, 2048)])
+                                     (2, 1024, 256, 1024), (1, 5, 7, 2048), (8, 256, 256, 100), (4, 360, 256, 4200), (3, 130, 300, 36),
+                                     (8, 2048, 256, 100), (1, 64, 520, 1052)])
 def test_pipelined_weight_gradient_matches_fp64(cfg, B, M, K, L):
     from spike2former_amd._lib import check, lib
     assert lib.s2f_spike_gemm_dw_pipe_ok(B, M, K, L) == 1
+    if L % 32 and cfg == 1:
+        gy, x = _operands(B, M, K, L, 3)
+        out = torch.zeros(M, K, device="cuda")
+        assert lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), out.data_ptr(), B, M, K, L, 0, 1, 0, _stream()) == -1
+        return
     gy, x = _operands(B, M, K, L, 3)
     want = torch.einsum("bml,bkl->mk", gy.double(), x.double())
     scale = torch.einsum("bml,bkl->mk", gy.abs().double(), x.double()).clamp_min(1e-30)
@@ -47,17 +54,20 @@ def test_pipelined_weight_gradient_matches_fp64(cfg, B, M, K, L):
 
 def test_pipelined_weight_gradient_refuses_what_it_cannot_take():
     from spike2former_amd._lib import lib
-    assert lib.s2f_spike_gemm_dw_pipe_ok(8, 256, 256, 100) == 0            # L % 32 != 0: the decoder's 100-token maps stay on the old kernel
+    assert lib.s2f_spike_gemm_dw_pipe_ok(8, 256, 256, 1050) == 0           # L % 4 != 0 (C5's 25 x 42 maps): rows are not float4-aligned
+    assert lib.s2f_spike_gemm_dw_pipe_ok(8, 256, 256, 28) == 0             # less than one step
     assert lib.s2f_spike_gemm_dw_pipe_ok(1, 1 << 16, 64, 1 << 15) == 0     # M L >= 2^30
-    gy, x = _operands(1, 32, 32, 36, 0)
+    assert lib.s2f_spike_gemm_dw_pipe_ok(64, 1 << 10, 64, (1 << 14) + 4) == 0     # ragged: batch M L >= 2^30
+    gy, x = _operands(1, 32, 32, 38, 0)
     out = torch.zeros(32, 32, device="cuda")
-    assert lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), out.data_ptr(), 1, 32, 32, 36, 0, 0, 0, _stream()) == -1
-    assert b"L %% 32" in lib.s2f_last_error() or b"L % 32" in lib.s2f_last_error()
+    assert lib.s2f_spike_gemm_dw_pipe(gy.data_ptr(), x.data_ptr(), out.data_ptr(), 1, 32, 32, 38, 0, 0, 0, _stream()) == -1
+    assert b"L % 4" in lib.s2f_last_error()
 
 
 def test_pipelined_grouped_launch_is_the_single_launches():
     from spike2former_amd._lib import check, lib
-    spec = [(8, 256, 256, 1024), (8, 1024, 256, 1024), (2, 700, 256, 4096), (3, 130, 300, 96), (8, 288, 256, 1024), (1, 40, 520, 64)]
+    spec = [(8, 256, 256, 1024), (8, 1024, 256, 1024), (2, 700, 256, 4096), (3, 130, 300, 96), (8, 288, 256, 1024), (1, 40, 520, 64),
+            (8, 256, 2048, 100), (4, 256, 360, 4200)]          # (the last two: L % 32 != 0 -- the whole launch takes the ragged form)
     keep, flat, want = [], [], []
     for i, (B, M, K, L) in enumerate(spec):
         gy, x = _operands(B, M, K, L, 10 + i)
@@ -75,7 +85,7 @@ def test_pipelined_grouped_launch_is_the_single_launches():
 
 
 def test_deferred_weight_gradients_take_the_pipelined_kernel(monkeypatch):
-    """ops.wgrad_flush routes the jobs the pipelined kernel takes to ONE grouped launch and leaves the others (L = 100) where they
+    """ops.wgrad_flush routes the jobs the pipelined kernel takes to ONE grouped launch and leaves the others (L < 32) where they
     were; the sums in the sinks are those of the round-2 grouped kernel to fp32 round-off."""
     from spike2former_amd import ops
     from spike2former_amd.ops import core
@@ -83,7 +93,7 @@ def test_deferred_weight_gradients_take_the_pipelined_kernel(monkeypatch):
     for pipe in (True, False):
         monkeypatch.setattr(ops.cfg, "DW_PIPE", pipe)
         sinks = []
-        for i, (B, M, K, L) in enumerate([(8, 256, 256, 1024), (8, 256, 2048, 100), (8, 512, 256, 1024), (2, 64, 96, 4096)]):
+        for i, (B, M, K, L) in enumerate([(8, 256, 256, 1024), (8, 256, 2048, 100), (8, 512, 256, 1024), (2, 64, 96, 4096), (4, 128, 128, 28)]):
             gy, x = _operands(B, M, K, L, 20 + i)
             sink = torch.zeros(M, K, device="cuda")
             core._defer_dw(gy, x, sink, B, M, K, L)
@@ -209,10 +219,12 @@ def test_eval_fusion_is_not_taken_when_a_parameter_wants_a_gradient():
 
 # ------------------------------------------------------------------------------------------------ implicit 3x3 weight gradient, pipelined
 @pytest.mark.parametrize("cfg", [0, 1])
-@pytest.mark.parametrize("B,M,C,H,W", [(2, 128, 32, 64, 64), (1, 40, 64, 5, 32), (2, 300, 96, 9, 64), (3, 64, 256, 4, 32), (1, 512, 128, 64, 64)])
+@pytest.mark.parametrize("B,M,C,H,W", [(2, 128, 32, 64, 64), (1, 40, 64, 5, 32), (2, 300, 96, 9, 64), (3, 64, 256, 4, 32), (1, 512, 128, 64, 64),
+                                       (2, 128, 64, 12, 40), (1, 256, 32, 20, 168), (3, 130, 64, 4, 56), (1, 128, 64, 50, 336)])
 def test_pipelined_conv3x3_weight_gradient_matches_conv2d(cfg, B, M, C, H, W):
     """s2f_spike_conv3x3_dw_pipe (tap-major dW [M, 3, 3, C]) against the weight gradient of F.conv2d in fp64: every border (first /
-    last row, first / last column), tiles that span several taps (C < 256), ragged M, batch boundaries inside a workgroup's piece."""
+    last row, first / last column), tiles that span several taps (C < 256), ragged M, batch boundaries inside a workgroup's piece,
+    widths that are no multiple of the 32-pixel step (a step then spans two image rows: C5's 336- and 168-wide maps)."""
     import ctypes
     import torch.nn.functional as F
     from spike2former_amd._lib import check, lib
@@ -235,4 +247,5 @@ def test_pipelined_conv3x3_weight_gradient_matches_conv2d(cfg, B, M, C, H, W):
         check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, cfg, wgs, _stream()), "conv3x3_dw_pipe")
         torch.cuda.synchronize()
         assert ((out.double() - want).abs() / scale).max().item() <= 2e-6, wgs
-    assert lib.s2f_spike_conv3x3_dw_pipe_ok(2, 64, 32, 8, 84) == 0          # W % 32 != 0 (C5's maps): stays on the round-2 kernel
+    assert lib.s2f_spike_conv3x3_dw_pipe_ok(2, 64, 32, 8, 84) == 0          # W % 8 != 0 (C5's 84-wide maps): stays on the round-2 kernel
+    assert lib.s2f_spike_conv3x3_dw_pipe_ok(2, 64, 32, 5, 40) == 0          # H W % 32 != 0: a step would span two images
