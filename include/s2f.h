@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 20
+#define S2F_ABI_VERSION 21
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -355,6 +355,16 @@ int s2f_pgemm_nn_bf16(const uint16_t* a_pack, const uint16_t* X, const float* bi
                       int terms, int cfg, void* stream);
 int s2f_pgemm_dx_f32(const uint16_t* w_pack, const float* G, int64_t g_batch_stride, float* DX, int64_t dx_batch_stride,
                      int batch, int Mo, int Ki, int N, float beta, int cfg, void* stream);
+/* Inference: 1x1 convolution of a DENSE fp32 input -> BatchNorm (running statistics) [+ residual] [-> Q_IFNode from a reset
+ * membrane] as ONE launch, `groups` (1..4) independent weights on consecutive channel groups: SepConv.pwconv2 behind the depthwise
+ * convolution (sdtv2.py:135-180), the second 1x1 of the RepConv chains with their composed BatchNorm pair (sdtv2.py:112-132,
+ * 304-306; the fold helpers of clock_driven/functional.py:574-692), the stem's column matrix (sdtv2.py:386-421).
+ * X [batch][groups K][N] fp32 (strides in elements), per-channel vectors [groups M], residual / u_out / y_bf16
+ * [batch][groups M][N]; w_packs[g] = s2f_pack_bf16x3 (mode 3) of W_g [M][K].  Six bf16 passes (fp32 accuracy).  N % 4 == 0. */
+int s2f_dense_gemm_bn_lif_fwd(const uint16_t* const* w_packs, int groups, const float* X, int64_t x_batch_stride, int64_t x_group_stride,
+                              const float* conv_bias, const float* running_mean, const float* running_var, const float* gamma,
+                              const float* beta, float eps, const float* residual, float* u_out, void* y_bf16, uint64_t* stats,
+                              int batch, int K, int M, int N, float vth, int D, void* stream);
 /* Up to four independent products of s2f_pgemm_dx_f32's plain-store form in ONE launch (blockIdx.z = group): w_packs is a HOST
  * array of `groups` device pointers (copied into the kernel arguments); group g reads G + g * g_group_stride and writes DX + g *
  * dx_group_stride (and bn_partials? + g * partials_group_stride: the _stats form).  The channel groups of a grouped 1x1
@@ -422,6 +432,10 @@ int s2f_gemm_dw_general_grouped(const int64_t* jobs, int njobs, void* stream);
  * Replaces F.interpolate(y, size=2x, mode='bilinear', align_corners=False) in the pixel decoder's FPN path
  * (mmdet/models/layers/pixel_decoder.py:456-460).  w must be even (16-byte output stores). */
 int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream);
+/* y = sigmoid(up2x(x)) in one pass (w % 4 == 0, x and y 16-byte aligned): the inference post-processing's
+ * F.interpolate(mask_pred, size = img_shape) followed by mask_pred.sigmoid() (mmseg/models/decode_heads/maskformer_head.py:170-176)
+ * where the masks are predicted at half the image resolution (every Spike2Former config).  No adjoint: inference only. */
+int s2f_upsample2x_sigmoid_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream);
 int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream);
 
 /* ---- batched transposition of the last two dimensions: x [B, R, C] -> y [B, C, R] (fp32) -----------------------------------
@@ -513,6 +527,11 @@ int s2f_sdsa_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, i
 int s2f_sdsa_lif_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
                           int64_t k_batch_stride, int64_t v_batch_stride, uint16_t* y_spikes, uint64_t* mask, uint64_t* stats,
                           float* kv_save, int TB, int heads, int d, int N, float scale, float vth, int D, void* stream);
+/* The same without the in-range mask -- inference, where nothing is back-propagated -- for any Nq % 4 == 0 and separate key length
+ * Nk: the decoder's 100-query attention blocks (mmcv_spike/transformer.py:238-300).  kv_ws [TB, heads, d, d] is scratch. */
+int s2f_sdsa_lif_fwd_bf16_nomask(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                                 int64_t k_batch_stride, int64_t v_batch_stride, uint16_t* y_spikes, uint64_t* stats, float* kv_ws,
+                                 int TB, int heads, int d, int Nq, int Nk, float scale, float vth, int D, void* stream);
 
 /* ---- a9: DCNv3 core ---------------------------------------------------------------------------------
  * Replaces dcnv3_core_pytorch (ops_dcnv3/functions/dcnv3_func.py:147-189; = the dormant CUDA op

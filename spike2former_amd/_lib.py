@@ -48,6 +48,7 @@ SIGNATURES = {
     "s2f_split_bf16x3_multi": (_i, [_p, _i, _i64, _p]),
     "s2f_spike_gemm_fwd": (_i, [_p] * 4 + [_i] * 7 + [_p]),
     "s2f_upsample2x_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "s2f_upsample2x_sigmoid_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_upsample2x_bwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_last2": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_scale_add_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "s2f_pgemm_nn_bf16_stats": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "s2f_pgemm_conv3x3_bf16_stats": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "s2f_pgemm_dx_f32_grouped": (_i, [_p, _i, _p, _i64, _i64, _p, _i64, _i64, _p, _i64] + [_i] * 4 + [_p]),
+    "s2f_dense_gemm_bn_lif_fwd": (_i, [_p, _i, _p, _i64, _i64, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "s2f_pgemm_dx_f32_stats": (_i, [_p, _p, _i64, _p, _i64, _p] + [_i] * 4 + [_p]),
     "s2f_bn_partials_finalize": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "s2f_bn_act_bwd_split": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
@@ -101,6 +103,7 @@ SIGNATURES = {
     "s2f_sdsa_fwd_bf16": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_bwd_bf16": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _i, _p, _p, _p, _i64, _i64, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_lif_fwd_bf16": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "s2f_sdsa_lif_fwd_bf16_nomask": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "s2f_sdsa_kv": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_apply": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "s2f_dcnv3_fwd": (_i, [_p] * 4 + [_i] * 13 + [_f, _p]),

@@ -86,14 +86,40 @@ class RepConv(nn.Module):
     def forward(self, x, outer_bn=None, lif=None, residual=None, next_lif=None):
         """conv1x1 -> BN+pad -> dw3x3 -> conv1x1 -> BN [-> outer BN [+ residual] [-> neuron]].
         Returns (pre-activation or None, spikes or None) when `outer_bn` is given, else the tensor."""
+        dw = self.body[2][0]
+        bn1 = self.body[1].bn
+        if (outer_bn is not None and dw.kernel_size == (3, 3) and self.body[1].pad_pixels == 1 and not bn1.training
+                and bn1.running_mean is not None and bn1.affine and isinstance(outer_bn, nn.Module) and not outer_bn.training
+                and not self.body[2][2].training and outer_bn.running_mean is not None and self.body[2][2].running_mean is not None
+                and fused.EVAL_FUSION and not torch.is_grad_enabled() and x.dim() == 4
+                and ops.gemm_bn_lif_eval_ok(x, x.shape[2] * x.shape[3])):
+            # inference (row f4): BatchNorm_1 rides in the first GEMM's epilogue, its border value BN_1(0) is cached, and the
+            # BatchNorm pair that closes the chain [+ residual] [-> neuron] rides in the second (dense) GEMM's: six launches -> three
+            N_, C_, H_, W_ = x.shape
+            z = ops.gemm_bn_lif_eval(x.reshape(N_, C_, H_ * W_), self.body[0].weight.view(self.body[0].out_channels, -1), None,
+                                     bn1.running_mean, bn1.running_var, bn1.weight, bn1.bias, bn1.eps, want_pre=True, lif=False)[0]
+            z = ops.dwconv(z.view(N_, -1, H_, W_), dw.weight, 1, self._eval_border())
+            return conv_bn_act(self.body[2][1], z, fused._composed_eval_pair(self.body[2][2], outer_bn), residual=residual, lif=lif,
+                               next_lif=next_lif)
         x, border = self.body[1](self.body[0](x), return_border=True)
         # un-padded depthwise 3x3 over the constant-bordered map == pad-1 stencil reading `border` outside the plane
-        dw = self.body[2][0]
         x = ops.dwconv(x, dw.weight, dw.kernel_size[0] // 2, border) if dw.kernel_size == (3, 3) else dw(self.body[1].pad(x, border))
         x = self.body[2][1](x)
         if outer_bn is None:
             return bn_act(x, None, self.body[2][2])[0]
         return bn_bn_act(x, self.body[2][2], outer_bn, residual=residual, lif=lif, next_lif=next_lif)
+
+    def _eval_border(self):
+        """BN_1(0) from the running statistics (the value the depthwise stencil reads outside the plane), cached by parameter version"""
+        bn = self.body[1].bn
+        key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        hit = getattr(self, "_s2f_eval_border", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            border = (bn.bias - bn.running_mean * bn.weight / torch.sqrt(bn.running_var + bn.eps)).contiguous()
+        self._s2f_eval_border = (key, border)
+        return border
 
 
 class SepConv(nn.Module):
@@ -117,8 +143,9 @@ class SepConv(nn.Module):
         T, B, C, H, W = x.shape
         s = self.spike1.fire(x)
         _, s = conv_bn_act(self.pwconv1, s.flatten(0, 1), self.bn1, lif=self.spike2)
-        z = self.pwconv2(self.dwconv(s))
-        u, _ = bn_act(z, None, self.bn2, residual=None if residual is None else residual.flatten(0, 1), next_lif=next_lif)
+        # (conv_bn_act: in eval mode the dense 1x1 + BatchNorm + residual + next neuron are one launch; training: forward_nobias + bn_act)
+        u, _ = conv_bn_act(self.pwconv2, self.dwconv(s), self.bn2, residual=None if residual is None else residual.flatten(0, 1),
+                           next_lif=next_lif)
         return u.reshape(T, B, C, H, W)
 
 
@@ -250,13 +277,19 @@ class MS_Attention_RepConv_qkv_id(nn.Module):
         if (not training) and fused.EVAL_FUSION and not torch.is_grad_enabled() and ops.gemm_bn_lif_eval_ok(sv, N):
             # inference: BatchNorm_1 (running statistics) rides in the first GEMM's epilogue, and the
             # BatchNorm pair that closes the chain is ONE affine map (composed on the host, cached per parameter version):
-            # five launches -> three  (GEMM+BN | stencil | grouped GEMM | BN+neuron)
+            # five launches -> three  (GEMM+BN | stencil | grouped GEMM+BN+neuron)
             ev = self._eval_affines(t, bn1, bn2, bn3)
             z = ops.gemm_bn_lif_eval(sv, w1, None, bn1.running_mean, bn1.running_var, bn1.weight, bn1.bias, bn1.eps, want_pre=True,
                                      lif=False)[0].view(T * B, 3 * C, H, W)
             z = ops.dwconv(z, ops.cat_params(t["dw"]), 1, ev["border"])
+            pair, n = ev["pair"], self.q_spike
+            if ops.dense_gemm_bn_lif_eval_ok(z, N) and ops.spikes_bf16_ok(n.D):
+                _, y = ops.dense_gemm_bn_lif_eval(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]], None, pair.running_mean,
+                                                  pair.running_var, pair.weight, pair.bias, pair.eps, lif=True, D=n.D, vth=n.v_threshold)
+                n.v = 0.0
+                return y.view(T * B, 3 * C, N)
             z = ops.dense_gemm(z.view(T * B, 3 * C, N), [p.view(C, C) for p in t["w2"]], stats=False).view(T * B, 3 * C, H, W)
-            _, y = bn_act(z, None, ev["pair"], lif=self.q_spike)
+            _, y = bn_act(z, None, pair, lif=self.q_spike)
             return y.view(T * B, 3 * C, N)
         z = ops.spike_gemm(sv, w1, stats=training)                    # the three first 1x1 convs: one GEMM
         z = ops.carry_stats(z, z.view(T * B, 3 * C, H, W))
@@ -358,9 +391,46 @@ class MS_DownSampling(nn.Module):
         T, B = x.shape[:2]
         if hasattr(self, "encode_spike"):
             x = self.encode_spike.fire(x)
-        x, _ = bn_act(self.encode_conv.forward_nobias(x.flatten(0, 1)), self.encode_conv.bias, self.encode_bn,
-                      next_lif=next_lif)
-        return x.reshape(T, B, *x.shape[1:])
+        x = x.flatten(0, 1)
+        u = self._eval_fused(x, next_lif)
+        if u is None:
+            u, _ = bn_act(self.encode_conv.forward_nobias(x), self.encode_conv.bias, self.encode_bn, next_lif=next_lif)
+        return u.reshape(T, B, *u.shape[1:])
+
+    def _eval_fused(self, x, next_lif):
+        """Inference (row f4): the convolution as its column matrix times the weight with the BatchNorm (running statistics) and the
+        next block's first neuron in the GEMM's epilogue -- bf16 spike columns on the 3-pass kernel, the stem's fp32 image columns on the
+        6-pass one.  None when the fusion does not apply (training, gradients, a stateful / observed neuron, odd shapes)."""
+        conv, bn, n = self.encode_conv, self.encode_bn, next_lif
+        if (bn.training or bn.running_mean is None or not bn.affine or torch.is_grad_enabled() or not fused.EVAL_FUSION
+                or not x.is_cuda or conv.groups != 1 or conv.dilation != (1, 1) or conv.stride[0] != conv.stride[1]
+                or conv.padding[0] != conv.padding[1] or conv.kernel_size[0] != conv.kernel_size[1]):
+            return None
+        if n is not None and not (ops.spikes_bf16_ok(n.D) and isinstance(n.v, float) and not n.keep_membrane and n.stats is None
+                                  and not n._forward_hooks and not n._forward_pre_hooks):
+            return None
+        k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        N_, C_, H_, W_ = x.shape
+        Ho, Wo = (H_ + 2 * pd - k) // st + 1, (W_ + 2 * pd - k) // st + 1
+        L, M = Ho * Wo, conv.out_channels
+        spikes = isinstance(x, ops.Spikes)
+        if spikes and (x.tok is None or x.data.dtype != torch.bfloat16):
+            return None
+        if L % 4 or L < 128:
+            return None
+        kw = dict(want_pre=True, lif=n is not None, D=(n.D if n is not None else 8), vth=(n.v_threshold if n is not None else 1.0))
+        bnargs = (conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps)
+        w2d = conv.weight.view(M, -1)
+        if spikes:
+            cols = ops.im2col(x.data, k, k, st, pd)
+            u, y, _ = ops.gemm_bn_lif_eval(ops.Spikes(cols, ops.core._new_tok(cols)), w2d, *bnargs, **kw)
+        else:
+            u, y = ops.dense_gemm_bn_lif_eval(ops.im2col(x, k, k, st, pd), w2d, *bnargs, **kw)
+        u = u.view(N_, M, Ho, Wo)
+        if n is not None:
+            n.v = 0.0
+            n.prefire(u, y.view(N_, M, Ho, Wo))
+        return u
 
 
 @MODELS.register_module()

@@ -267,7 +267,7 @@ __device__ __forceinline__ void epi_row_partials(const f32x16 (&acc)[MI][NJ], fl
 // access pattern of bn_apply_kernel.
 template <int MI, int NJ, int WMW, int WNW>
 __device__ __forceinline__ void epi_bn_lif(const f32x16 (&acc)[MI][NJ], const BnLifEpi& ep, unsigned char* smem, int m0, int n0,
-                                           int M, int N, int b, int wm, int wn, int lane, int wave) {
+                                           int M, int N, int b, int wm, int wn, int lane, int wave, int64_t batch_stride = -1) {
 #pragma clang fp contract(off)
   constexpr int NW = WMW * WNW, BM = 32 * MI * WMW, BN = 32 * NJ * WNW, T = 64 * NW;
   float* tile = reinterpret_cast<float*>(smem);          // [BM][BN] fp32
@@ -281,7 +281,7 @@ __device__ __forceinline__ void epi_bn_lif(const f32x16 (&acc)[MI][NJ], const Bn
         tile[((wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + (wn * NJ + j) * 32 + (lane & 31)] = acc[i][j][r];
   __syncthreads();
   unsigned int csum = 0, cnz = 0;
-  const int64_t boff_ = (int64_t)b * M * N;
+  const int64_t boff_ = (int64_t)b * (batch_stride >= 0 ? batch_stride : (int64_t)M * N);
   const int tid = wave * 64 + lane;
   for (int idx = tid; idx < BM * (BN / 4); idx += T) {
     const int row_l = idx / (BN / 4), c4 = idx - row_l * (BN / 4);
@@ -555,14 +555,22 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
                                                                   int Ki, int N, int KbW, int n_tiles, int m_tiles, float beta,
                                                                   int64_t g_batch_stride, int64_t dx_batch_stride,
-                                                                  float* __restrict__ part = nullptr, TnGroups grp = TnGroups{}) {
+                                                                  float* __restrict__ part = nullptr, TnGroups grp = TnGroups{},
+                                                                  BnLifEpi ep = BnLifEpi{}) {
   if constexpr (GROUPED) {
-    static_assert(EPI == 0, "grouped form: plain store only");
+    static_assert(EPI == 0 || EPI == 3, "grouped form: plain store or the eval-mode BatchNorm epilogue");
     const int g = blockIdx.z;
     Wp = grp.wp[g];
     G += g * grp.g_stride;
-    DX += g * grp.dx_stride;
+    if (EPI == 0) DX += g * grp.dx_stride;
     if (STATS) part += g * grp.part_stride;
+    if constexpr (EPI == 3) {          // per-channel vectors [groups * Ki]; tensors [batch][groups * Ki][N]
+      if (ep.conv_bias) ep.conv_bias += g * Ki;
+      ep.mean += g * Ki, ep.var += g * Ki, ep.gamma += g * Ki, ep.beta += g * Ki;
+      if (ep.residual) ep.residual += g * grp.dx_stride;
+      if (ep.u_out) ep.u_out += g * grp.dx_stride;
+      if (ep.y) ep.y += g * grp.dx_stride;
+    }
   }
   constexpr bool BETA = EPI == 1;
   constexpr int BM = 32 * MI * WMW, BN = 32 * NJ * WNW, NW = WMW * WNW, T = 64 * NW;
@@ -734,6 +742,13 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigne
   }
 
   mfma_fence(acc);
+  if constexpr (EPI == 3) {
+    // the product as the FORWARD 1x1 convolution of a dense input in inference: BatchNorm (running statistics) [+ residual]
+    // [-> neuron] on the tile while it is in LDS -- the fp32 convolution output never reaches HBM (s2f_dense_gemm_bn_lif_fwd)
+    static_assert(2 * STAGE >= BM * BN * 4, "the output tile must fit the stages it is transposed through");
+    epi_bn_lif<MI, NJ, WMW, WNW>(acc, ep, smem, m0, n0, Ki, N, b, wm, wn, lane, wave, dx_batch_stride);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1524,16 +1539,16 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     const dim3 grid(n_tiles * m_tiles, batch, zsplit);                                                                 \
     if (zsplit > 1)                                                                                                    \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 2>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,  \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, TnGroups{});          \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, TnGroups{}, BnLifEpi{});          \
     else if (beta != 0.f)                                                                                              \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 1>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, TnGroups{});          \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, (float*)nullptr, TnGroups{}, BnLifEpi{});          \
     else if (part)                                                                                                     \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 1, true>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, \
-                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, TnGroups{});         \
+                 G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, TnGroups{}, BnLifEpi{});         \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0>), grid, dim3(64 * WMW * WNW), 0, s, w_pack, G, DX,   \
-                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, TnGroups{});                \
+                 Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride, dx_batch_stride, part, TnGroups{}, BnLifEpi{});                \
   } while (0)
   switch (c) {
     case 1: S2F_PGD(2, 2, 2, 2); break;          // 128 x 128
@@ -1548,11 +1563,11 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     if (part)                                                                                                          \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2, true>), dim3(n_tiles * m_tiles, batch, 1),        \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
-                 dx_batch_stride, part, TnGroups{});                                                                       \
+                 dx_batch_stride, part, TnGroups{}, BnLifEpi{});                                                                       \
     else                                                                                                               \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),              \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
-                 dx_batch_stride, part, TnGroups{});                                                                       \
+                 dx_batch_stride, part, TnGroups{}, BnLifEpi{});                                                                       \
   } while (0)
     case 7: S2F_PGD2(1, 1, 2, 4); break;         // cfg 4 with 32-row steps (half the barriers per MFMA)
     case 8: S2F_PGD2(1, 2, 2, 2); break;         // cfg 2 with 32-row steps
@@ -1574,6 +1589,57 @@ extern "C" int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, in
                                       void* stream) {
   S2F_REQUIRE(bn_partials, S2F_EINVAL, "s2f_pgemm_dx_f32_stats: null partials");
   return pgemm_dx_impl(w_pack, G, g_batch_stride, DX, dx_batch_stride, batch, Mo, Ki, N, 0.f, 0, bn_partials, stream);
+}
+
+// Inference: 1x1 convolution of a DENSE fp32 input (not a spike map) -> BatchNorm (running statistics) [+ residual] [-> Q_IFNode] as
+// ONE launch, for `groups` (1..4) independent weights on consecutive channel groups: SepConv.pwconv2 behind the depthwise
+// convolution, the second 1x1 of the (stacked q | k | v) RepConv chains with their composed BatchNorm pair, the stem convolution's
+// column matrix (sdtv2.py:112-132, 135-180, 304-306, 386-421).  X [batch][groups K][N] (group stride x_group_stride), per-channel
+// vectors [groups M], residual / u_out / y [batch][groups M][N].  w_packs[g] = s2f_pack_bf16x3 of W_g^T ([K][M], mode 3), the pack
+// the dense forward product reads.  Six bf16 passes (both operands general).  Reset neurons only (no membrane in or out).
+extern "C" int s2f_dense_gemm_bn_lif_fwd(const uint16_t* const* w_packs, int groups, const float* X, int64_t x_batch_stride,
+                                         int64_t x_group_stride, const float* conv_bias, const float* running_mean,
+                                         const float* running_var, const float* gamma, const float* beta, float eps,
+                                         const float* residual, float* u_out, void* y_bf16, uint64_t* stats, int batch, int K,
+                                         int M, int N, float vth, int D, void* stream) {
+  S2F_REQUIRE(w_packs && X && running_mean && running_var && gamma && beta && groups >= 1 && groups <= 4, S2F_EINVAL,
+              "s2f_dense_gemm_bn_lif_fwd: null pointer / 1..4 groups");
+  S2F_REQUIRE(u_out || y_bf16, S2F_EINVAL, "s2f_dense_gemm_bn_lif_fwd: neither u_out nor y requested");
+  S2F_REQUIRE(batch > 0 && batch < 65536 && M > 0 && K > 0 && N >= 4 && (N & 3) == 0, S2F_EINVAL,
+              "s2f_dense_gemm_bn_lif_fwd: bad sizes (N=%d must be a positive multiple of 4)", N);
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_dense_gemm_bn_lif_fwd: bf16 spikes need D a power of two <= 128");
+  S2F_REQUIRE((x_batch_stride & 3) == 0 && (x_group_stride & 3) == 0 && s2f_aligned16(X) && (!residual || s2f_aligned16(residual)) &&
+                  (!u_out || s2f_aligned16(u_out)) && (reinterpret_cast<uintptr_t>(y_bf16) & 7u) == 0,
+              S2F_EALIGN, "s2f_dense_gemm_bn_lif_fwd: strides / pointers must keep 16-byte alignment");
+  TnGroups grp{};
+  for (int g = 0; g < groups; ++g) {
+    S2F_REQUIRE(w_packs[g] && s2f_aligned16(w_packs[g]), S2F_EINVAL, "s2f_dense_gemm_bn_lif_fwd: null / unaligned pack %d", g);
+    grp.wp[g] = w_packs[g];
+  }
+  grp.g_stride = x_group_stride;
+  grp.dx_stride = (int64_t)M * N;
+  BnLifEpi ep{conv_bias, running_mean, running_var, gamma, beta, residual, u_out, nullptr, nullptr,
+              reinterpret_cast<unsigned short*>(y_bf16), reinterpret_cast<unsigned long long*>(stats), eps, vth, (float)D,
+              1.0f / (float)D};
+  hipStream_t s = (hipStream_t)stream;
+  const int KbW = (M + PK - 1) / PK, n_tiles = (N + 127) / 128;
+  const int64_t out_bs = (int64_t)groups * M * N;
+  const bool wide = M > 64 && (int64_t)n_tiles * batch * ((M + 127) / 128) >= 192;
+#define S2F_PGE(MI, NJ, WMW, WNW, KSV)                                                                                   \
+  do {                                                                                                                  \
+    const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                      \
+    S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 3, KSV, false, true>), dim3(n_tiles * m_tiles, batch, groups),    \
+               dim3(64 * WMW * WNW), 0, s, grp.wp[0], X, (float*)nullptr, K, M, N, KbW, n_tiles, m_tiles, 0.f, x_batch_stride,  \
+               out_bs, (float*)nullptr, grp, ep);                                                                       \
+  } while (0)
+  if (M <= 32)
+    S2F_PGE(1, 1, 1, 4, 1);
+  else if (wide)
+    S2F_PGE(1, 2, 4, 2, 2);
+  else
+    S2F_PGE(1, 1, 2, 4, 2);
+#undef S2F_PGE
+  return s2f_check_launch("s2f_dense_gemm_bn_lif_fwd");
 }
 
 extern "C" int s2f_pgemm_dx_f32_grouped(const uint16_t* const* w_packs, int groups, const float* G, int64_t g_batch_stride,
@@ -1604,10 +1670,10 @@ extern "C" int s2f_pgemm_dx_f32_grouped(const uint16_t* const* w_packs, int grou
     const dim3 grid(n_tiles * m_tiles, batch, groups);                                                                  \
     if (bn_partials)                                                                                                    \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, KSV, true, true>), grid, dim3(64 * WMW * WNW), 0, s,  \
-                 grp.wp[0], G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, 0.f, g_batch_stride, dx_batch_stride, bn_partials, grp); \
+                 grp.wp[0], G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, 0.f, g_batch_stride, dx_batch_stride, bn_partials, grp, BnLifEpi{}); \
     else                                                                                                                \
       S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, KSV, false, true>), grid, dim3(64 * WMW * WNW), 0, s, \
-                 grp.wp[0], G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, 0.f, g_batch_stride, dx_batch_stride, bn_partials, grp); \
+                 grp.wp[0], G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, 0.f, g_batch_stride, dx_batch_stride, bn_partials, grp, BnLifEpi{}); \
   } while (0)
   if (Ki <= 32)
     S2F_PGG(1, 1, 1, 4, 1);

@@ -677,6 +677,32 @@ extern "C" int s2f_sdsa_bwd_bf16(const uint16_t* q, const uint16_t* k, const uin
   return s2f_check_launch("s2f_sdsa_bwd_bf16");
 }
 
+// The same pair WITHOUT the in-range mask (inference: no backward) for any token counts Nq, Nk % 4 == 0 -- the decoder's 100-query
+// maps against 100 / 1 024 / 4 096 / 16 384 keys (mmcv_spike/transformer.py:238-300: attn_lif((q k^T) v * scale)).  The mask layout
+// is what ties s2f_sdsa_lif_fwd_bf16 to N % 256 == 0; without it a lane's four columns only have to be in range together.
+extern "C" int s2f_sdsa_lif_fwd_bf16_nomask(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
+                                            int64_t k_batch_stride, int64_t v_batch_stride, uint16_t* y_spikes, uint64_t* stats,
+                                            float* kv_ws, int TB, int heads, int d, int Nq, int Nk, float scale, float vth, int D,
+                                            void* stream) {
+  S2F_REQUIRE(y_spikes && kv_ws, S2F_EINVAL, "s2f_sdsa_lif_fwd_bf16_nomask: null pointer");
+  int rc = check("s2f_sdsa_lif_fwd_bf16_nomask", TB, heads, d, Nq);
+  if (rc) return rc;
+  rc = check_bf16("s2f_sdsa_lif_fwd_bf16_nomask", q, k, v, q_batch_stride, k_batch_stride, v_batch_stride, Nq, Nk);
+  if (rc) return rc;
+  S2F_REQUIRE((Nq & 3) == 0 && (q_batch_stride & 3) == 0 && s2f_bf16_spikes_exact(D), S2F_EINVAL,
+              "s2f_sdsa_lif_fwd_bf16_nomask: needs Nq %% 4 == 0, a q batch stride that is a multiple of 4 and D a power of two <= 128");
+  S2F_REQUIRE((reinterpret_cast<uintptr_t>(q) & 7u) == 0 && (reinterpret_cast<uintptr_t>(y_spikes) & 7u) == 0, S2F_EALIGN,
+              "s2f_sdsa_lif_fwd_bf16_nomask: q and y must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  rc = launch_outer_spikes(k, k_batch_stride, v, v_batch_stride, kv_ws, TB, heads, d, Nk, 1.0f, s);
+  if (rc) return rc;
+  launch_apply<false, unsigned short, true>(Operand<unsigned short>{q, q_batch_stride, nullptr, 0.f}, kv_ws, nullptr,
+                                            (int64_t)heads * d * Nq, TB, heads, d, Nq, scale, s,
+                                            LifOut{y_spikes, nullptr, reinterpret_cast<unsigned long long*>(stats), vth, (float)D,
+                                                   1.0f / (float)D});
+  return s2f_check_launch("s2f_sdsa_lif_fwd_bf16_nomask");
+}
+
 extern "C" int s2f_sdsa_lif_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_batch_stride,
                                      int64_t k_batch_stride, int64_t v_batch_stride, uint16_t* y_spikes, uint64_t* mask,
                                      uint64_t* stats, float* kv_save, int TB, int heads, int d, int N, float scale, float vth,

@@ -79,6 +79,9 @@ inline dim3 plane_grid(int64_t cells, int64_t planes) {
 // w % 4 == 0: one thread produces a 2 x 8 block of outputs (rows 2i, 2i+1; columns 8k .. 8k+7) from input rows i-1, i, i+1
 // and columns 4k-1 .. 4k+4 -- one 16-byte load and two edge scalars per row (9 load instructions for 16 outputs instead of 32
 // scalar loads), same tap arithmetic as the kernel above ((1 - l) a + l b with l = 0.75 / 0.25 / 0 at the clamped edge).
+// SIGMOID: y = sigmoid(up(x)) -- the inference post-processing's `mask_pred.sigmoid()` (mmseg decode_heads/maskformer_head.py:176)
+// inside the up-sampling pass: the 4x larger map is written once instead of written, read and written again.
+template <bool SIGMOID>
 __global__ __launch_bounds__(256) void up2x_fwd_block_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes,
                                                              int h, int w) {
   // grid (ceil(h * w/4 / 256), planes): 32-bit index arithmetic only -- with one flat 64-bit index the four 64-bit
@@ -118,6 +121,10 @@ __global__ __launch_bounds__(256) void up2x_fwd_block_kernel(const float* __rest
     for (int j = 0; j < 8; ++j) {
       ev[j] = i == 0 ? (1.f - 0.f) * hx[1][j] + 0.f * hx[2][j] : (1.f - 0.75f) * hx[0][j] + 0.75f * hx[1][j];   // output row 2i
       od[j] = (1.f - 0.25f) * hx[1][j] + 0.25f * hx[2][j];                                                       // output row 2i + 1
+      if (SIGMOID) {
+        ev[j] = 1.f / (1.f + expf(-ev[j]));
+        od[j] = 1.f / (1.f + expf(-od[j]));
+      }
     }
     *reinterpret_cast<float4*>(o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
     *reinterpret_cast<float4*>(o + 4) = make_float4(ev[4], ev[5], ev[6], ev[7]);
@@ -345,12 +352,21 @@ extern "C" int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int 
   S2F_REQUIRE(planes > 0 && h > 0 && w > 0 && (w % 2) == 0, S2F_EINVAL, "s2f_upsample2x_fwd: need even input width");
   S2F_REQUIRE(s2f_aligned16(y), S2F_EALIGN, "s2f_upsample2x_fwd: output must be 16-byte aligned");
   if ((w & 3) == 0 && s2f_aligned16(x))
-    hipLaunchKernelGGL(up2x_fwd_block_kernel, plane_grid((int64_t)h * (w / 4), planes), dim3(256), 0, (hipStream_t)stream, x, y,
+    hipLaunchKernelGGL(up2x_fwd_block_kernel<false>, plane_grid((int64_t)h * (w / 4), planes), dim3(256), 0, (hipStream_t)stream, x, y,
                        planes, h, w);
   else
     hipLaunchKernelGGL(up2x_fwd_kernel, dim3(grid_for(planes * 2 * h * (2 * w / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
                        planes, h, w);
   return s2f_check_launch("s2f_upsample2x_fwd");
+}
+
+extern "C" int s2f_upsample2x_sigmoid_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream) {
+  S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_upsample2x_sigmoid_fwd: null pointer");
+  S2F_REQUIRE(planes > 0 && h > 0 && w > 0 && (w % 4) == 0, S2F_EINVAL, "s2f_upsample2x_sigmoid_fwd: needs w %% 4 == 0");
+  S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y), S2F_EALIGN, "s2f_upsample2x_sigmoid_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(up2x_fwd_block_kernel<true>, plane_grid((int64_t)h * (w / 4), planes), dim3(256), 0, (hipStream_t)stream, x, y,
+                     planes, h, w);
+  return s2f_check_launch("s2f_upsample2x_sigmoid_fwd");
 }
 
 extern "C" int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream) {

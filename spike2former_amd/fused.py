@@ -89,6 +89,26 @@ def _composed_eval_pair(bn1, bn2):
     return out
 
 
+def _scaled_eval_bn(bn, scale):
+    """scale * BN(.) of an eval-mode BatchNorm as ONE affine map: its running statistics with (scale gamma, scale beta) -- cached on
+    the module by parameter version (inference: the parameters do not change between calls)."""
+    ts = (bn.weight, bn.bias, scale)
+    key = tuple((t.data_ptr(), t._version) for t in ts)
+    hit = getattr(bn, "_s2f_eval_scaled", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        out = _EvalBN()
+        out.weight = (bn.weight * scale).contiguous()
+        out.bias = (bn.bias * scale).contiguous()
+        out.running_mean, out.running_var, out.eps = bn.running_mean, bn.running_var, bn.eps
+    try:
+        bn._s2f_eval_scaled = (key, out)
+    except AttributeError:
+        pass
+    return out
+
+
 def bn_bn_act(z, bn1, bn2, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
     """bn2(bn1(z)) [+ residual] [-> neuron]: the BatchNorm pair that closes a RepConv chain (Sequential(RepConv(.., BN), BN),
     sdtv2.py:280-296).  In training mode on the single-pass shapes (the 32x32-stage maps, where these chains live) the pair is ONE
@@ -136,17 +156,25 @@ def bn_bn_act(z, bn1, bn2, residual=None, lif: Q_IFNode = None, want_pre=None, n
     return (u if wanted_pre else None), y
 
 
-def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None):
+def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None, next_lif: Q_IFNode = None, scale=None):
     """1x1 convolution (Conv2d / Conv1d of this package, fed by a neuron) -> BatchNorm [+ residual] [-> neuron]; x [N, K, *].
     In eval mode on bf16 spikes this is ONE launch -- the packed-weight GEMM with the BatchNorm (running statistics), the
     residual add and the neuron in its epilogue (ops.gemm_bn_lif_eval; the inference-time fold of SURVEY section 8 row f4,
     reference helpers clock_driven/functional.py:574-692): the fp32 convolution output never reaches HBM.  Everything else
     (training, fp32 inputs, shapes the kernel does not take, someone recording gradients) is conv.forward_nobias + bn_act.
-    Returns (u, y) as bn_act."""
+    `scale`: per-channel factor on the BatchNorm output as in bn_act (the pixel decoder's layer scale): in eval mode folded into the
+    affine pair once (cached), so that the layer stays one launch.  Returns (u, y) as bn_act."""
     shape_in = x.shape
     L = 1
     for d in shape_in[2:]:
         L *= d
+    if scale is not None:
+        if ((not bn.training) and bn.running_mean is not None and bn.affine and EVAL_FUSION
+                and _no_grad_needed(x, conv, bn, residual) and not (torch.is_grad_enabled() and scale.requires_grad)):
+            bn = _scaled_eval_bn(bn, scale)
+        else:
+            z = conv.forward_nobias(x)
+            return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif, scale=scale)
     fire = next_lif if (next_lif is not None and lif is None) else lif
     if want_pre is None:
         want_pre = lif is None
@@ -181,8 +209,14 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
              and tuple(conv.dilation) == (1, 1) and conv.bias is None and x.dim() == 4 and conv.in_channels % 32 == 0
              and x.shape[-1] % 4 == 0 and ops.cfg.PGEMM_CONV)
     eval_bn = (not bn.training) and bn.running_mean is not None and bn.affine
-    if not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L) and _no_grad_needed(x, conv, bn, residual)
-            and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
+    # a 1x1 convolution of a DENSE fp32 map (SepConv.pwconv2 behind the depthwise stencil, the stem's column matrix): the 6-pass
+    # product with the same epilogue (ops.dense_gemm_bn_lif_eval); reset neurons only
+    dense = (pure_conv and eval_bn and EVAL_FUSION and ops.dense_gemm_bn_lif_eval_ok(x, L) and _no_grad_needed(x, conv, bn, residual)
+             and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks and isinstance(fire.v, float)
+                                   and not fire.keep_membrane)))
+    if not dense and not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
+                          and _no_grad_needed(x, conv, bn, residual)
+                          and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
         z = conv.forward_nobias(x)
         return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
     M = conv.out_channels
@@ -194,7 +228,13 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     kw = dict(want_pre=bool(want_pre or (next_lif is not None and lif is None) or (fire is not None and bool(fire._forward_hooks))),
               lif=fire is not None, v_in=v_in, keep_v=(fire is not None and fire.keep_membrane), D=(fire.D if fire is not None else 8),
               vth=(fire.v_threshold if fire is not None else 1.0), stats=(fire.stats if fire is not None else None))
-    if conv3:
+    if dense:
+        u, y = ops.dense_gemm_bn_lif_eval(
+            x.reshape(shape_in[0], shape_in[1], L), conv.weight.view(M, -1), conv.bias, bn.running_mean, bn.running_var, bn.weight,
+            bn.bias, bn.eps, residual=None if residual is None else residual.reshape(shape_in[0], M, L), want_pre=kw["want_pre"],
+            lif=kw["lif"], D=kw["D"], vth=kw["vth"], stats=kw["stats"])
+        v_out = None
+    elif conv3:
         u, y, v_out = ops.conv3x3_bn_lif_eval(x, conv.weight, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps,
                                               residual=None if residual is None else residual.reshape(shape_in[0], M, *shape_in[2:]), **kw)
     else:

@@ -43,8 +43,8 @@ class SepConv_Spike(nn.Module):
         x = self.spike1.fire(x).flatten(0, 1)
         _, x = conv_bn_act(self.pwconv1[0], x, self.pwconv1[1], lif=self.spike2)
         _, x = conv_bn_act(self.dwconv[0], x, self.dwconv[1], lif=self.spike3)          # (eval: stencil + BatchNorm + neuron, one launch)
-        x, _ = bn_act(self.pwconv2[0](x), None, self.pwconv2[1], scale=scale, next_lif=next_lif,
-                      residual=None if residual is None else residual.flatten(0, 1))
+        x, _ = conv_bn_act(self.pwconv2[0], x, self.pwconv2[1], scale=scale, next_lif=next_lif,          # (eval: one launch)
+                           residual=None if residual is None else residual.flatten(0, 1))
         return x.reshape(T, B, C, H, W)
 
     def forward(self, x):

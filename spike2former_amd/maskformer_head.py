@@ -209,10 +209,10 @@ class MaskFormerHead(nn.Module):
             metainfo["batch_input_shape"] = metainfo["img_shape"]
         cls, masks = self(x, None)
         img_shape = batch_img_metas[0]["batch_input_shape"]
-        mp = ops.upsample_bilinear(masks[-1], tuple(img_shape)) if masks.is_cuda else \
-            F.interpolate(masks[-1], size=tuple(img_shape), mode="bilinear", align_corners=False)
+        mp = ops.upsample_bilinear(masks[-1], tuple(img_shape), sigmoid=True) if masks.is_cuda else \
+            F.interpolate(masks[-1], size=tuple(img_shape), mode="bilinear", align_corners=False).sigmoid()
         cls_score = F.softmax(cls[-1], dim=-1)[..., :-1]
-        return ops.class_mask_product(cls_score.contiguous(), mp.sigmoid())
+        return ops.class_mask_product(cls_score.contiguous(), mp)
 
     def loss_by_feat(self, all_cls_scores, all_mask_preds, batch_gt_instances, batch_img_metas=None):
         """mmdet MaskFormerHead.loss_by_feat (dense_heads/maskformer_head.py:376-414); `batch_gt_instances`: per image an

@@ -140,6 +140,23 @@ def _sdsa_spikes(qd, kd, vd, qt, kt, vt, heads, scale, packed, lif):
     pure = (lif is not None and isinstance(lif.v, float) and not lif.keep_membrane
             and not lif._forward_hooks and not lif._forward_pre_hooks)          # hooks want the module call
     fuse = pure and Nq == Nk and Nq % 256 == 0 and (C * Nq) % 8 == 0 and spikes_bf16_ok(lif.D)
+    no_grad = not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (qt, kt, vt)))
+    if (pure and no_grad and not packed and Nq % 4 == 0 and Nk % 4 == 0 and spikes_bf16_ok(lif.D) and C // heads <= 64
+            and not (Nq == Nk and Nq % 256 == 0)):
+        # inference on maps the masked kernel does not take (the decoder's 100 queries): attention core + neuron as one launch pair,
+        # o never written (s2f_sdsa_lif_fwd_bf16_nomask)
+        qd, kd, vd = qd.contiguous(), kd.contiguous(), vd.contiguous()
+        TB = qd.shape[0]
+        d = C // heads
+        y = torch.empty(TB, C, Nq, dtype=torch.bfloat16, device=qd.device)
+        kv = torch.empty(TB, heads, d, d, dtype=torch.float32, device=qd.device)
+        if lif.stats is not None:
+            lif.stats_elems += TB * C * Nq
+        check(lib.s2f_sdsa_lif_fwd_bf16_nomask(_ptr(qd), _ptr(kd), _ptr(vd), C * Nq, C * Nk, C * Nk, _ptr(y), _ptr(lif.stats),
+                                               _ptr(kv), TB, heads, d, Nq, Nk, scale, lif.v_threshold, lif.D, _stream()),
+              "s2f_sdsa_lif_fwd_bf16_nomask")
+        lif.v = 0.0
+        return Spikes(y, _new_tok(y))
     if fuse and lif.stats is not None:
         lif.stats_elems += qd.shape[0] * C * Nq
     o, ydata = _SDSASpikes.apply(qd, kd, vd, qt, kt, vt, heads, scale, packed, fuse, lif.D if fuse else 8,

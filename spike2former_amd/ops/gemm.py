@@ -545,6 +545,40 @@ def gemm_bn_lif_eval(x, w2d, conv_bias, running_mean, running_var, gamma, beta, 
     return u, (Spikes(y, _new_tok(y)) if lif else None), v_out
 
 
+def dense_gemm_bn_lif_eval_ok(x, N):
+    """The eval-mode fusion of a 1x1 convolution whose input is a general fp32 map (not spikes): N % 4 == 0, at least one 128-column
+    tile, no autograd graph."""
+    return (cfg.PGEMM_DX and torch.is_tensor(x) and x.dtype == torch.float32 and x.is_cuda and N % 4 == 0 and N >= cfg.PGEMM_MIN_N
+            and x.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and x.requires_grad))
+
+
+def dense_gemm_bn_lif_eval(x, ws, conv_bias, running_mean, running_var, gamma, beta, eps, residual=None, want_pre=False, lif=False,
+                           D=8, vth=1.0, stats=None):
+    """Eval-mode  conv1x1 (dense fp32 input; G = len(ws) weights [M, K] on consecutive channel groups) -> BatchNorm(running
+    statistics) [+ residual] [-> Q_IFNode, reset]  as ONE launch (s2f_dense_gemm_bn_lif_fwd; row f4).  x [B, G K, N] fp32; the
+    per-channel vectors [G M].  -> (u fp32 [B, G M, N] or None, Spikes or None).  No backward: inference only."""
+    import ctypes
+    if torch.is_tensor(ws):
+        ws = [ws] if ws.dim() == 2 else list(ws.unbind(0))
+    G = len(ws)
+    M, K = ws[0].shape
+    x = x.contiguous()
+    B, GK, N = x.shape
+    assert GK == G * K and 1 <= G <= 4
+    dev = x.device
+    with torch.no_grad():
+        u = torch.empty(B, G * M, N, dtype=torch.float32, device=dev) if want_pre else None
+        y = torch.empty(B, G * M, N, dtype=torch.bfloat16, device=dev) if lif else None
+        if residual is not None:
+            residual = residual.contiguous()
+        packs = (ctypes.c_void_p * G)(*[pack_weight(w, transposed=True).data_ptr() for w in ws])
+        _time_next("dx_gemm", 4 * B * N * G * (K + M), 2 * B * G * M * N * K)
+        check(lib.s2f_dense_gemm_bn_lif_fwd(packs, G, _ptr(x), G * K * N, K * N, _ptr(conv_bias), _ptr(running_mean), _ptr(running_var),
+                                            _ptr(gamma), _ptr(beta), float(eps), _ptr(residual), _ptr(u), _ptr(y), _ptr(stats),
+                                            B, K, M, N, float(vth), int(D), _stream()), "s2f_dense_gemm_bn_lif_fwd")
+    return u, (Spikes(y, _new_tok(y)) if lif else None)
+
+
 def conv3x3_bn_lif_eval(x, weight, running_mean, running_var, gamma, beta, eps, residual=None, want_pre=False, lif=False, v_in=None,
                         keep_v=False, D=8, vth=1.0, stats=None):
     """Eval-mode  conv3x3 (stride 1, padding 1, no bias) -> BatchNorm(running statistics) [+ residual] [-> Q_IFNode]  as ONE launch
@@ -649,17 +683,20 @@ def _mm_tm(x2d, w_oc):
     return y
 
 
-def _mtm_tm(a2d, b2d):
+def _mtm_tm(a2d, b2d, out=None):
     """a2d [n, o]^T @ b2d [n, c] -> [o, c]: the contraction runs over the rows of both -- the transposed packed-operand kernel with a2d
-    packed on the fly (s2f_pgemm_dx_f32, contraction split over gridDim.z); the library for c % 4 != 0."""
+    packed on the fly (s2f_pgemm_dx_f32, contraction split over gridDim.z); the library for c % 4 != 0.  `out`: a contiguous
+    [o, c] fp32 destination (16-byte aligned)."""
     n, o = a2d.shape
     c = b2d.shape[1]
     if not (cfg.LINEAR_TM and c % 4 == 0 and a2d.is_cuda and n > 0):
         fallback("mtm_tm", f"c={c}")
-        return torch.matmul(a2d.t(), b2d)
+        return torch.matmul(a2d.t(), b2d) if out is None else torch.matmul(a2d.t(), b2d, out=out)
     ap = torch.empty(int(lib.s2f_pack_elems(n, o)), dtype=torch.int16, device=a2d.device)
     check(lib.s2f_pack_bf16x3(_ptr(a2d.contiguous()), _ptr(ap), n, o, 0, 0, _stream()), "s2f_pack_bf16x3")
-    out = torch.empty(o, c, dtype=torch.float32, device=a2d.device)
+    if out is None:
+        out = torch.empty(o, c, dtype=torch.float32, device=a2d.device)
+    assert out.is_contiguous() and out.shape == (o, c) and out.dtype == torch.float32
     check(lib.s2f_pgemm_dx_f32(_ptr(ap), _ptr(b2d.contiguous()), 0, _ptr(out), 0, 1, n, o, c, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
     return out
 
@@ -894,7 +931,10 @@ def class_mask_product(cls_score, mask_probs):
             and not (torch.is_grad_enabled() and (cls_score.requires_grad or mask_probs.requires_grad))):
         fallback("class_mask_product", f"hw={h * w}")
         return torch.einsum("bqc,bqhw->bchw", cls_score, mask_probs)
-    return torch.stack([_mtm_tm(cls_score[b], mask_probs[b].reshape(Q, h * w)).view(K, h, w) for b in range(B)])
+    out = torch.empty(B, K, h, w, dtype=torch.float32, device=cls_score.device)          # every image's product lands in its slice
+    for b in range(B):
+        _mtm_tm(cls_score[b], mask_probs[b].reshape(Q, h * w), out=out[b].view(K, h * w))
+    return out
 
 
 def mask_einsum_folded(e, spikes, W, bias, scale, T, B, e_exact=False):

@@ -92,13 +92,23 @@ class _Up2x(torch.autograd.Function):
         return gx
 
 
-def upsample_bilinear(x, size):
-    """F.interpolate(x, size, mode='bilinear', align_corners=False); the exact-2x case runs the HIP kernel."""
+def upsample_bilinear(x, size, sigmoid=False):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False); the exact-2x case runs the HIP kernel.  `sigmoid`: followed by
+    .sigmoid() -- inside the same pass where no gradient is wanted (the inference post-processing)."""
     h, w = x.shape[-2:]
     if tuple(size) == (2 * h, 2 * w) and w % 2 == 0:
-        return _Up2x.apply(x)
+        if sigmoid and w % 4 == 0 and x.dim() == 4 and not (torch.is_grad_enabled() and x.requires_grad):
+            _need_cuda(x)
+            x = x.contiguous()
+            N, C = x.shape[:2]
+            y = torch.empty(N, C, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+            check(lib.s2f_upsample2x_sigmoid_fwd(_ptr(x), _ptr(y), N * C, h, w, _stream()), "s2f_upsample2x_sigmoid_fwd")
+            return y
+        y = _Up2x.apply(x)
+        return y.sigmoid() if sigmoid else y
     fallback("upsample_bilinear", f"{(h, w)} -> {tuple(size)}")
-    return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+    y = torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+    return y.sigmoid() if sigmoid else y
 
 
 # ------------------------------------------------------------------------------------------------ mask losses (row f1)

@@ -249,3 +249,92 @@ def test_pipelined_conv3x3_weight_gradient_matches_conv2d(cfg, B, M, C, H, W):
         assert ((out.double() - want).abs() / scale).max().item() <= 2e-6, wgs
     assert lib.s2f_spike_conv3x3_dw_pipe_ok(2, 64, 32, 8, 84) == 0          # W % 8 != 0 (C5's 84-wide maps): stays on the round-2 kernel
     assert lib.s2f_spike_conv3x3_dw_pipe_ok(2, 64, 32, 5, 40) == 0          # H W % 32 != 0: a step would span two images
+
+
+# ------------------------------------------------------------------------------------------------ inference post-processing
+@pytest.mark.parametrize("shape", [(2, 5, 16, 32), (1, 3, 7, 4), (1, 100, 64, 64)])
+def test_upsample2x_sigmoid_is_interpolate_then_sigmoid(shape):
+    """ops.upsample_bilinear(.., sigmoid=True) (s2f_upsample2x_sigmoid_fwd) against F.interpolate(..).sigmoid(): the same taps as the
+    plain kernel (bit-identical up-sampled logits), expf's last bits on top."""
+    import torch.nn.functional as F
+    from spike2former_amd import ops
+    x = torch.randn(*shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 6
+    size = (2 * shape[2], 2 * shape[3])
+    with torch.no_grad():
+        got = ops.upsample_bilinear(x, size, sigmoid=True)
+        plain = ops.upsample_bilinear(x, size)
+    want = F.interpolate(x.double(), size=size, mode="bilinear", align_corners=False).sigmoid()
+    assert (got.double() - want).abs().max().item() <= 3e-7
+    assert (got - plain.sigmoid()).abs().max().item() <= 2e-7
+    # with a gradient wanted the two-kernel form (autograd) is taken
+    xg = x.clone().requires_grad_(True)
+    y = ops.upsample_bilinear(xg, size, sigmoid=True)
+    assert y.requires_grad and torch.allclose(y, got, atol=2e-7, rtol=0)
+
+
+def test_class_mask_product_writes_every_image_into_its_slice():
+    from spike2former_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cls = torch.rand(3, 100, 19, device="cuda", generator=g)
+    mp = torch.rand(3, 100, 24, 40, device="cuda", generator=g)
+    with torch.no_grad():
+        got = ops.class_mask_product(cls, mp)
+    want = torch.einsum("bqc,bqhw->bchw", cls.double(), mp.double())
+    assert got.shape == (3, 19, 24, 40) and (got.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("Nq,Nk", [(100, 100), (100, 1024), (100, 16384), (36, 4096)])
+def test_inference_attention_and_its_neuron_as_one_launch_pair(Nq, Nk):
+    """Under no_grad ops.sdsa(.., lif=) on the decoder's 100-query maps takes s2f_sdsa_lif_fwd_bf16_nomask (attention core + neuron,
+    o never written): the same spikes, bit for bit, as the core followed by the neuron's own kernel."""
+    from spike2former_amd import ops
+    from spike2former_amd.neuron import Q_IFNode, Quant
+    from spike2former_amd.ops.core import _new_tok
+    TB, C, heads = 8, 256, 8
+    g = torch.Generator(device="cuda").manual_seed(Nq + Nk)
+
+    def spikes(n):
+        d = (torch.randint(0, 9, (TB, C, n), device="cuda", generator=g).float() / 8).to(torch.bfloat16)
+        return ops.Spikes(d, _new_tok(d))
+    q, k, v = spikes(Nq), spikes(Nk), spikes(Nk)
+    scale = 1.0 / 16
+    a, b = Q_IFNode(surrogate_function=Quant()).cuda(), Q_IFNode(surrogate_function=Quant()).cuda()
+    with torch.no_grad():
+        fused = ops.sdsa(q, k, v, heads, scale, lif=a)
+        o = ops.sdsa(q, k, v, heads, scale)
+        two = b.fire(o)
+    assert isinstance(fused, ops.Spikes) and fused.data.dtype == torch.bfloat16
+    assert torch.equal(fused.data, two.data if isinstance(two, ops.Spikes) else two.to(torch.bfloat16))
+    assert fused.data.float().abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("G,B,K,M,N", [(1, 8, 512, 256, 1024), (3, 8, 256, 256, 1024), (1, 2, 147, 32, 4096), (2, 3, 96, 72, 260)])
+def test_dense_gemm_bn_lif_eval_is_gemm_then_batchnorm_then_neuron(G, B, K, M, N):
+    """s2f_dense_gemm_bn_lif_fwd (dense fp32 input, G weights on channel groups, eval BatchNorm + residual + neuron in the epilogue)
+    against the fp64 composition; the pre-activation to fp32 round-off, the spikes equal wherever the membrane is not within round-off
+    of a rounding boundary."""
+    from spike2former_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(G * 100 + K)
+    x = torch.randn(B, G * K, N, device="cuda", generator=g)
+    ws = [torch.randn(M, K, device="cuda", generator=g) / K ** 0.5 for _ in range(G)]
+    C = G * M
+    bias = torch.randn(C, device="cuda", generator=g) * 0.1
+    mean, var = torch.randn(C, device="cuda", generator=g) * 0.2, torch.rand(C, device="cuda", generator=g) + 0.5
+    gamma, beta = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g) * 0.3
+    res = torch.randn(B, C, N, device="cuda", generator=g)
+    D, eps = 8, 1e-5
+    with torch.no_grad():
+        u, y = ops.dense_gemm_bn_lif_eval(x, ws, bias, mean, var, gamma, beta, eps, residual=res, want_pre=True, lif=True, D=D, vth=1.0)
+        u_only, none = ops.dense_gemm_bn_lif_eval(x, ws, None, mean, var, gamma, beta, eps, want_pre=True, lif=False)
+    assert none is None
+    z = torch.cat([torch.einsum("mk,bkn->bmn", w.double(), x[:, i * K:(i + 1) * K].double()) for i, w in enumerate(ws)], 1)
+    aff = lambda t: (t - mean.double().view(1, -1, 1)) / torch.sqrt(var.double().view(1, -1, 1) + eps) * gamma.double().view(1, -1, 1) \
+        + beta.double().view(1, -1, 1)          # noqa: E731
+    want_u = aff(z + bias.double().view(1, -1, 1)) + res.double()
+    assert (u.double() - want_u).abs().max().item() <= 2e-5 * want_u.abs().max().item()
+    assert (u_only.double() - aff(z)).abs().max().item() <= 2e-5 * aff(z).abs().max().item()
+    h = want_u.clamp(0, D)
+    want_y = torch.round(h) / D
+    near = ((h - torch.floor(h)) - 0.5).abs() < 1e-3                      # within round-off of a rounding boundary: either neighbour
+    bad = (y.data.double() != want_y) & ~near
+    assert int(bad.sum()) == 0 and y.data.dtype == torch.bfloat16

@@ -1,7 +1,7 @@
 """Which lines of the package call the ATen ops that launch the glue kernels of one eager C2 step (copies, adds, reductions,
 fills, im2col, library GEMMs ...): a TorchDispatchMode records every non-view aten op with the innermost Python frame inside
 spike2former_amd/ (forward and backward: the mode travels with autograd's thread-local state).
-    python tools/glue_sites.py [workload] > gpurun_out/glue_sites.txt"""
+    python tools/glue_sites.py [workload [predict]] > gpurun_out/glue_sites.txt"""
 import collections
 import os
 import sys
@@ -17,22 +17,35 @@ from spike2former_amd.dist import FlatGradAllReduce
 from spike2former_amd.init_utils import seeded_init
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "C2"
+PREDICT = len(sys.argv) > 2 and sys.argv[2] == "predict"          # the inference step (eval mode, mode="logits") instead
 dev = torch.device("cuda", 0)
 w = s2f.WORKLOADS[workload]
-model = seeded_init(s2f.MODELS.build(s2f.model_cfg(workload))).to(dev).train()
+model = seeded_init(s2f.MODELS.build(s2f.model_cfg(workload))).to(dev)
+model = model.eval() if PREDICT else model.train()
 s2f.set_keep_membrane(model, False)
-red = FlatGradAllReduce(model.parameters(), 1)
-red.install_sinks()
 img = torch.randn(w["B"], 3, w["H"], w["W"], generator=torch.Generator().manual_seed(1000)).to(dev)
+if PREDICT:
+    ops.RESPLIT_IN_GRAPH = False
 
+    class _NoRed:
+        compact = staticmethod(lambda: None)
+    red = _NoRed()
 
-def step():
-    s2f.reset_net(model)
-    red.zero()
-    cls, masks = model(img)
-    s2f.headline_loss(cls, masks).backward()
-    ops.wgrad_join()
-    red.gather()
+    def step():
+        s2f.reset_net(model)
+        with torch.no_grad():
+            model(img, mode="logits")
+else:
+    red = FlatGradAllReduce(model.parameters(), 1)
+    red.install_sinks()
+
+    def step():
+        s2f.reset_net(model)
+        red.zero()
+        cls, masks = model(img)
+        s2f.headline_loss(cls, masks).backward()
+        ops.wgrad_join()
+        red.gather()
 
 
 VIEWS = {"view", "_unsafe_view", "reshape", "expand", "permute", "transpose", "t", "select", "slice", "unbind", "detach", "alias",
@@ -41,6 +54,7 @@ VIEWS = {"view", "_unsafe_view", "reshape", "expand", "permute", "transpose", "t
          "unsafe_split", "chunk", "narrow", "movedim", "contiguous", "result_type", "size", "stride", "is_contiguous", "numel",
          "storage_offset", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "dim", "_to_copy" if False else "__x"}
 agg = collections.defaultdict(lambda: [0, 0])
+LAST = ["-"]
 
 
 class Watch(TorchDispatchMode):
@@ -64,8 +78,12 @@ class Watch(TorchDispatchMode):
                 site = f"step():{fr.lineno}"
                 break
         if site == "?":
+            # no package frame: the autograd engine itself (a gradient accumulated where two consumers meet, a view's backward):
+            # name the last package line that ran before it -- the backward whose result is being added
             big = max((t for t in list(args) + ([out] if torch.is_tensor(out) else []) if torch.is_tensor(t)), key=lambda t: t.numel())
-            site = "? " + str(tuple(big.shape))
+            site = "? " + str(tuple(big.shape)) + " after " + LAST[0]
+        else:
+            LAST[0] = site
         a = agg[(site, name)]
         a[0] += 1
         a[1] += numel
