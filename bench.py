@@ -45,6 +45,9 @@ def parse():
                          "(reset -> backbone -> head -> whole-image seg logits), hipGraph replay; --no-eval-fusion runs it on the "
                          "two-kernel conv -> BatchNorm+neuron path for comparison")
     ap.add_argument("--no-eval-fusion", action="store_true")
+    ap.add_argument("--predict-all-layers", action="store_true",
+                    help="predict: evaluate the SDME block and the mask contraction for all L + 1 decoder layers as `forward` does "
+                         "(default: only the last layer's predictions, the ones the segmentation logits are formed from)")
     ap.add_argument("--optimizer", action="store_true",
                     help="SECONDARY figure (SURVEY section 8 row f2): one full training ITERATION per step -- the step above + (N > 1: "
                          "all-reduce) + clip_grad_norm_(0.01) + AdamW with the config's per-parameter multipliers, as three HIP "
@@ -114,6 +117,8 @@ def predict_bench(args, s2f, ops, dev, w, B, rank, world):
     from spike2former_amd import fused
     from spike2former_amd.init_utils import seeded_init
     fused.EVAL_FUSION = not args.no_eval_fusion
+    from spike2former_amd import maskformer_head
+    maskformer_head.PREDICT_LAST_ONLY = not args.predict_all_layers
     # inference: the weights are frozen, so the graph does not re-convert them (bf16 packs) on every replay as a training step must
     # (0.23 ms per replay at C2); they are converted once below, before the capture
     resplit_was, ops.RESPLIT_IN_GRAPH = ops.RESPLIT_IN_GRAPH, False
@@ -153,6 +158,7 @@ def predict_bench(args, s2f, ops, dev, w, B, rank, world):
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "launch": "hipGraph replay",
             "eval_fusion": bool(fused.EVAL_FUSION), "logits_shape": list(out.shape),
+            "sdme_layers_evaluated": ("last (the one the logits are formed from)" if maskformer_head.PREDICT_LAST_ONLY else "all L + 1"),
             "config": {"workload": f"{args.workload}: {w['H']}x{w['W']} T={w['T']} K={w['K']}, per-GPU batch {B}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "weights": "random-init (name-seeded)"}}), flush=True)
     ops.RESPLIT_IN_GRAPH = resplit_was          # (process-global: a training graph captured later must re-convert its weights)

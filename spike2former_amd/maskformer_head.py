@@ -22,6 +22,7 @@ from .registry import MODELS, ConfigDict
 FUSED_KV_NEURONS = True
 # the pixel decoder's mask_feature 1x1 convolution folded into the mask contraction (ops.mask_einsum_folded)
 FOLD_MASK_FEATURE = True
+PREDICT_LAST_ONLY = True          # predict(): SDME block and mask contraction for the last decoder layer only (False: all L + 1, as `forward`)
 QUERY_STREAM_CHANNEL_MAJOR = True     # decoder queries channel-major between the layers (no transposes around the projections)
 
 
@@ -92,8 +93,9 @@ class MaskFormerHead(nn.Module):
             self._pe_cache[key] = self.decoder_pe(m).flatten(2).contiguous()
         return self._pe_cache[key]
 
-    def forward(self, x, batch_data_samples=None):
-        """x: the 4 backbone maps.  -> all_cls_scores [L+1,B,Q,K+1], all_mask_preds [L+1,B,Q,H/2,W/2]."""
+    def forward(self, x, batch_data_samples=None, last_only=False):
+        """x: the 4 backbone maps.  -> all_cls_scores [L+1,B,Q,K+1], all_mask_preds [L+1,B,Q,H/2,W/2].  `last_only` (inference): the
+        predictions of the last decoder layer alone ([1, ...]) -- the only ones `predict` reads; the decoder itself runs in full."""
         mask_features, memory, msm = self.pixel_decoder(x, None, spike_memory=True, fold_mask_feature=FOLD_MASK_FEATURE)
         t, bs = memory.shape[:2]
         query_feat = self.query_feat.weight.unsqueeze(0).repeat((t, bs, 1, 1))
@@ -103,7 +105,7 @@ class MaskFormerHead(nn.Module):
         # depends only on the level, so it is formed once per level instead of once per decoder layer.
         dec_in, dec_key, kv_spikes = self.decoder_inputs(msm, bs)
         out_dec = self.run_decoder(query_feat, query_embed, dec_in, dec_key, kv_spikes)
-        return self.sdme(out_dec, mask_features)
+        return self.sdme(out_dec[-1:] if last_only else out_dec, mask_features)
 
     def decoder_inputs(self, msm, bs):
         """The three memory levels as the decoder layers read them -> (dec_in, dec_key, kv_spikes), one entry per level: the value
@@ -207,7 +209,12 @@ class MaskFormerHead(nn.Module):
         """mmseg MaskFormerHead.predict (decode_heads/maskformer_head.py:138-180) -> seg logits [B,K,H,W]."""
         for metainfo in batch_img_metas:                     # as the reference: the patch shape becomes the batch input shape
             metainfo["batch_input_shape"] = metainfo["img_shape"]
-        cls, masks = self(x, None)
+        # The segmentation logits depend on the LAST layer's class scores and masks only (cls[-1], masks[-1] below).  In eval mode every
+        # op of the SDME block is per sample (BatchNorm on its running statistics), so the other L layers' predictions -- 6/7 of the
+        # mask contraction, 0.5 ms of the C2 inference step -- are dead outputs and are not computed.  (Train-mode BatchNorm statistics
+        # run over all layers' rows: there the block is evaluated in full.)
+        last = PREDICT_LAST_ONLY and not getattr(self, "training", True)
+        cls, masks = self(x, None, last_only=True) if last else self(x, None)
         img_shape = batch_img_metas[0]["batch_input_shape"]
         mp = ops.upsample_bilinear(masks[-1], tuple(img_shape), sigmoid=True) if masks.is_cuda else \
             F.interpolate(masks[-1], size=tuple(img_shape), mode="bilinear", align_corners=False).sigmoid()

@@ -338,3 +338,27 @@ def test_dense_gemm_bn_lif_eval_is_gemm_then_batchnorm_then_neuron(G, B, K, M, N
     near = ((h - torch.floor(h)) - 0.5).abs() < 1e-3                      # within round-off of a rounding boundary: either neighbour
     bad = (y.data.double() != want_y) & ~near
     assert int(bad.sum()) == 0 and y.data.dtype == torch.bfloat16
+
+
+def test_predict_on_the_last_layer_alone_gives_the_logits_of_the_full_head():
+    """maskformer_head.PREDICT_LAST_ONLY: the SDME block and the mask contraction for the last decoder layer only -- the same
+    segmentation logits as with all L + 1 layers evaluated (eval mode: every op of the block is per sample)."""
+    import spike2former_amd as s2f
+    from spike2former_amd import maskformer_head
+    from spike2former_amd.init_utils import seeded_init
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1"))).cuda().eval()
+    s2f.set_keep_membrane(model, False)
+    w = s2f.WORKLOADS["C1"]
+    img = torch.randn(2, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(3)).cuda()
+    outs = {}
+    was = maskformer_head.PREDICT_LAST_ONLY
+    try:
+        for flag in (True, False):
+            maskformer_head.PREDICT_LAST_ONLY = flag
+            s2f.reset_net(model)
+            with torch.no_grad():
+                outs[flag] = model(img, mode="logits").clone()
+    finally:
+        maskformer_head.PREDICT_LAST_ONLY = was
+    assert outs[True].shape == outs[False].shape
+    assert (outs[True] - outs[False]).abs().max().item() <= 1e-6 * outs[False].abs().max().item()
