@@ -121,13 +121,14 @@ int s2f_lif_seq_bwd(const float* gy_seq, const float* gvT, const uint64_t* mask,
  * s2f_bn_act_bwd:  gu = g_u? + STE(g_y?, g_v?, mask) ;  training: gz = gamma*rstd*(gu - mean(gu) - xhat*mean(gu*xhat)),
  *   eval: gz = gamma*rstd*gu ;  g_residual? = gu ;  dgamma = sum(gu*xhat) ; dbeta = sum(gu).  sums_zeroed as above. */
 /* 1 when, in training mode, s2f_bn_act_fwd / s2f_bn_act_bwd compute the channel statistics of this shape themselves
- * (one workgroup per channel holds the channel's N*L elements in registers: small maps with L % 256 == 0; one wavefront per
- * channel for short rows, see s2f_bn_mask_words): the caller then skips s2f_bn_stats and may pass sums / sums_zeroed = NULL. */
+ * (one workgroup per channel holds the channel's N*L elements in registers: small maps with L % 256 == 0; one to sixteen wavefronts
+ * per channel for rows that are not whole tiles, see s2f_bn_mask_words): the caller then skips s2f_bn_stats and may pass sums / sums_zeroed = NULL. */
 int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L);
 /* uint64 words of the in-range mask that s2f_bn_act_fwd writes and s2f_bn_act_bwd reads for this shape in training mode: the flat
- * 256-element-tile layout of s2f_lif_mask_words, except for short rows (L % 4 == 0, L % 256 != 0, N * L <= 2 048, C >= 32: the
- * decoder's 100-token maps), whose single-pass kernels keep one wavefront per channel and a per-channel mask layout of their own
- * (32 words per channel; private to this forward / backward pair). */
+ * 256-element-tile layout of s2f_lif_mask_words, except for rows that are not whole tiles (L % 4 == 0, L % 256 != 0, C >= 32) with
+ * N * L <= 20 480 -- the decoder's 100-token maps (N * L <= 2 048: one wavefront per channel, 32 words per channel) and C5's 50 x 84
+ * maps (up to sixteen wavefronts per channel, 320 words per channel) -- whose single-pass kernels keep a per-channel mask layout of
+ * their own (private to this forward / backward pair). */
 int64_t s2f_bn_mask_words(int64_t N, int64_t C, int64_t L);
 int s2f_bn_stats(const float* z, const float* conv_bias, double* sums_zeroed, int64_t N, int64_t C, int64_t L,
                  void* stream);

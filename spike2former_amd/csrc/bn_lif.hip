@@ -1393,6 +1393,192 @@ __global__ __launch_bounds__(64) void bn_small_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-pass forms for rows that are NOT whole 256-element tiles but too long for one wavefront (round 5): C5's 50 x 84 maps,
+// [4, C, 4 200] -- 16 800 elements per channel, 2.5 % past the 64 whole tiles of the single-pass kernels above and not tile-aligned, so
+// every BatchNorm of that stage ran statistics / finalize / apply forward and reduce + apply backward (20 + 21 us against 8 + 13 us at
+// [4, 256, 4 096], tools/probe_bn_stream.py; ~300 launches per C5 step).  The short-row idea on up to sixteen wavefronts: the
+// channel's N * L / 4 four-element groups are dealt out 64 per wavefront and round -- group g = (round * W + wave) * 64 + lane, at
+// most kMidIters rounds -- and the in-range mask keeps a per-channel layout of its own (written by this forward, read by this
+// backward only): word [((c * kMidIters + round) * kMidWaves + wave) * 4 + j] is the ballot of component j.
+constexpr int kMidIters = 5;
+constexpr int kMidWaves = 16;
+
+inline bool mid_rows_ok(int64_t N, int64_t C, int64_t L) {
+  static const char* off = getenv("S2F_BN_MID");          // A/B switch: "0" keeps these shapes on the row-walking kernels
+  if (off && off[0] == '0') return false;
+  return (L & 3) == 0 && (L & 255) != 0 && N * L > 64 * 4 * kSmallIters && N * L <= (int64_t)64 * 4 * kMidIters * kMidWaves && C >= 32;
+}
+inline int mid_rows_threads(int64_t N, int64_t L) {
+  const int64_t groups = N * (L >> 2);
+  return 64 * (int)((groups + 64 * kMidIters - 1) / (64 * kMidIters));
+}
+
+template <bool LIF, bool HAS_V, bool YB>
+__global__ __launch_bounds__(64 * kMidWaves) void bn_mid_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ u_out, const float* __restrict__ v_in,
+    float* __restrict__ y, float* __restrict__ v_out, uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
+    int N, int C, int L, double inv_count, float unbias, float momentum, float eps, float vth, float Df) {
+  __shared__ double red[2 * kMidWaves];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int per_row = L >> 2, groups = N * per_row;
+  const float b = bias ? bias[c] : 0.f;
+  Tile4 zv[kMidIters], rvp[kMidIters];
+  int64_t base[kMidIters];
+  bool ok[kMidIters];
+#pragma unroll
+  for (int i = 0; i < kMidIters; ++i) {                     // all loads in flight before the first use
+    const int g0 = (i * W + w) * 64, g = g0 + lane;
+    ok[i] = g < groups;
+    const int n = ok[i] ? g / per_row : 0, q = ok[i] ? g - n * per_row : 0;
+    base[i] = ((int64_t)n * C + c) * L + q * 4;
+    if (g0 < groups) {                                      // wave-uniform
+      zv[i] = ld4(z + base[i]);
+      if (res) rvp[i] = ld4(res + base[i]);
+    }
+  }
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMidIters; ++i) {
+    if (!ok[i]) continue;
+    const float a0 = zv[i].a[0] + b, a1 = zv[i].a[1] + b, a2 = zv[i].a[2] + b, a3 = zv[i].a[3] + b;
+    ps += (a0 + a1) + (a2 + a3);
+    pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  double s1 = (double)ps, s2 = (double)pq;
+  block_sum2(s1, s2, red, W);
+  const double md = s1 * inv_count;
+  double vd = s2 * inv_count - md * md;
+  if (vd < 0) vd = 0;
+  const float mean = (float)md, var = (float)vd;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float g_ = gamma[c], be = beta[c];
+  if (threadIdx.x == 0) {
+    stat[c] = mean;
+    stat[C + c] = rstd;
+    float rm = 0.f, rv = 1.f;
+    if (running_mean != nullptr) {
+      rm = (1.f - momentum) * running_mean[c] + momentum * mean;
+      rv = (1.f - momentum) * running_var[c] + momentum * (var * unbias);
+      running_mean[c] = rm;
+      running_var[c] = rv;
+    }
+    stat[2 * C + c] = be - rm * g_ / sqrtf(rv + eps);         // BN(0) from the (updated) running statistics
+    if (c == 0 && num_batches != nullptr) *num_batches += 1;
+  }
+  uint32_t csum = 0, cnz = 0;
+#pragma unroll
+  for (int i = 0; i < kMidIters; ++i) {
+    if ((i * W + w) * 64 >= groups) break;                  // wave-uniform
+    bool inr[4] = {false, false, false, false};
+    if (ok[i]) {
+      Tile4 vv, uo, yo, vo;
+      if (LIF && HAS_V) vv = ld4(v_in + base[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = ((zv[i].a[j] + b) - mean) * rstd * g_ + be;
+        if (res) u += rvp[i].a[j];
+        uo.a[j] = u;
+        if (LIF) {
+          const float h = HAS_V ? (vv.a[j] + u) : u;
+          float sp, yy;
+          s2f_lif_update(h, Df, 1.0f, vth, sp, yy, vo.a[j], inr[j]);
+          yo.a[j] = sp / Df;
+          csum += (uint32_t)sp;
+          cnz += ((uint32_t)sp != 0);
+        }
+      }
+      if (u_out) st4(u_out + base[i], uo);
+      if (LIF) {
+        if (YB)
+          st4_bf16(y, base[i], yo);
+        else
+          st4(y + base[i], yo);
+        if (v_out) st4(v_out + base[i], vo);
+      }
+    }
+    if (LIF && mask != nullptr) {
+      const uint64_t b0 = __ballot(inr[0]), b1 = __ballot(inr[1]), b2 = __ballot(inr[2]), b3 = __ballot(inr[3]);
+      if (lane < 4)
+        mask[(((int64_t)c * kMidIters + i) * kMidWaves + w) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    }
+  }
+  if (LIF && stats != nullptr) {
+    for (int o = 32; o > 0; o >>= 1) {
+      csum += __shfl_xor(csum, o, 64);
+      cnz += __shfl_xor(cnz, o, 64);
+    }
+    if (lane == 0) {
+      unsigned long long* slot = stats + 2 * ((blockIdx.x * kMidWaves + w) % S2F_STAT_SLOTS);
+      if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+      if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+    }
+  }
+}
+
+template <bool GU, bool GY, bool GV>
+__global__ __launch_bounds__(64 * kMidWaves) void bn_mid_bwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
+    const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
+    const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df) {
+  __shared__ double red[2 * kMidWaves];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int per_row = L >> 2, groups = N * per_row;
+  const float b = bias ? bias[c] : 0.f, mean = stat[c], rstd = stat[C + c], g_ = gamma[c];
+  Tile4 xh[kMidIters], gu[kMidIters];
+  int64_t base[kMidIters];
+  bool ok[kMidIters];
+#pragma unroll
+  for (int i = 0; i < kMidIters; ++i) {
+    const int g0 = (i * W + w) * 64, g = g0 + lane;
+    ok[i] = g < groups;
+    const int n = ok[i] ? g / per_row : 0, q = ok[i] ? g - n * per_row : 0;
+    base[i] = ((int64_t)n * C + c) * L + q * 4;
+    if (g0 >= groups) continue;                             // wave-uniform
+    xh[i] = ld4(z + base[i]);
+    if (GU) gu[i] = ld4(g_u + base[i]);
+    Tile4 bb, cc;
+    if (GY) bb = ld4(g_y + base[i]);
+    if (GV) cc = ld4(g_v + base[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool m = false;
+      if (GY || GV) m = (mask[(((int64_t)c * kMidIters + i) * kMidWaves + w) * 4 + j] >> lane) & 1ull;
+      gu[i].a[j] = form_gu(GU, GU ? gu[i].a[j] : 0.f, GY, GY ? bb.a[j] : 0.f, GV, GV ? cc.a[j] : 0.f, m, vth, Df);
+      xh[i].a[j] = ((xh[i].a[j] + b) - mean) * rstd;
+    }
+  }
+  float ps = 0.f, pq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMidIters; ++i) {
+    if (!ok[i]) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ps += gu[i].a[j];
+      pq += gu[i].a[j] * xh[i].a[j];
+    }
+  }
+  double s1 = (double)ps, s2 = (double)pq;
+  block_sum2(s1, s2, red, W);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+  }
+  const float m1 = (float)(s1 * inv_count), m2 = (float)(s2 * inv_count);
+#pragma unroll
+  for (int i = 0; i < kMidIters; ++i) {
+    if (!ok[i]) continue;
+    Tile4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.a[j] = (g_ * rstd) * ((gu[i].a[j] - m1) - xh[i].a[j] * m2);
+    st4(gz + base[i], o);
+    if (g_res) st4(g_res + base[i], gu[i]);
+  }
+}
+
 // single-pass eligibility: whole 256-element tiles per row, one channel's tiles fit kWaves x kTpw, and enough channels
 // to occupy the chip with one workgroup per channel
 inline bool single_pass_ok(int64_t N, int64_t C, int64_t L) {
@@ -1484,12 +1670,15 @@ int check_shape(const char* who, int64_t N, int64_t C, int64_t L) {
 
 }  // namespace
 
-extern "C" int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L) { return (single_pass_ok(N, C, L) || small_rows_ok(N, C, L)) ? 1 : 0; }
+extern "C" int s2f_bn_single_pass(int64_t N, int64_t C, int64_t L) {
+  return (single_pass_ok(N, C, L) || small_rows_ok(N, C, L) || mid_rows_ok(N, C, L)) ? 1 : 0;
+}
 
 // uint64 words of the in-range mask s2f_bn_act_fwd writes / s2f_bn_act_bwd reads for this shape: the flat-tile layout of
 // s2f_lif_mask_words, or the per-channel layout of the short-row single-pass kernels (private to this fwd / bwd pair)
 extern "C" int64_t s2f_bn_mask_words(int64_t N, int64_t C, int64_t L) {
   if (small_rows_ok(N, C, L)) return C * kSmallIters * 4;
+  if (mid_rows_ok(N, C, L)) return C * kMidIters * kMidWaves * 4;
   return ((N * C * L + 255) >> 8) * 4;
 }
 
@@ -1537,7 +1726,7 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
   // sums given for a shape that could go single-pass: the caller already has the statistics (a producer's epilogue, or a probe) --
   // take the apply path, which is not tied to one workgroup per channel
   const bool single = training && sums == nullptr && single_pass_ok(N, C, L);
-  S2F_REQUIRE(training ? (single || sums != nullptr || small_rows_ok(N, C, L)) : (running_mean && running_var), S2F_EINVAL,
+  S2F_REQUIRE(training ? (single || sums != nullptr || small_rows_ok(N, C, L) || mid_rows_ok(N, C, L)) : (running_mean && running_var), S2F_EINVAL,
               "s2f_bn_act_fwd: training needs the sums of s2f_bn_stats / s2f_bn_partials_finalize, eval needs the running statistics");
   S2F_REQUIRE(u_out || y, S2F_EINVAL, "s2f_bn_act_fwd: neither u_out nor y requested");
   S2F_REQUIRE(!(y && y_bf16) || s2f_bf16_spikes_exact(D), S2F_EINVAL,
@@ -1556,6 +1745,28 @@ static int bn_act_fwd_impl(const float* z, const float* conv_bias, const double*
   const double count = (double)N * (double)L;
   const double inv_count = 1.0 / count;
   const float unbias = count > 1 ? (float)(count / (count - 1.0)) : 1.0f;
+  if (training && mid_rows_ok(N, C, L)) {
+    // (always, given statistics or not: the mask layout of this shape is the per-channel one, which the backward reads)
+#define S2F_BN_MID(LIFV, HASV, YBV)                                                                                      \
+  S2F_LAUNCH(true, true, (bn_mid_fwd_kernel<LIFV, HASV, YBV>), dim3((unsigned)C), dim3(mid_rows_threads(N, L)), 0, s, z, conv_bias, \
+             stat_out, running_mean, running_var, nbt, gamma, beta, residual, u_out, v_in, y, v_out, mask, st, (int)N, (int)C,   \
+             (int)L, inv_count, unbias, momentum, eps, vth, (float)D)
+    if (y == nullptr)
+      S2F_BN_MID(false, false, false);
+    else if (v_in == nullptr) {
+      if (y_bf16)
+        S2F_BN_MID(true, false, true);
+      else
+        S2F_BN_MID(true, false, false);
+    } else {
+      if (y_bf16)
+        S2F_BN_MID(true, true, true);
+      else
+        S2F_BN_MID(true, true, false);
+    }
+#undef S2F_BN_MID
+    return s2f_check_launch("s2f_bn_act_fwd");
+  }
   if (training && small_rows_ok(N, C, L)) {
     // (always, given statistics or not: the mask layout of this shape is the short-row one, which the backward reads)
 #define S2F_BN_SMALL(LIFV, HASV, YBV)                                                                                    \
@@ -1682,7 +1893,7 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
                            float vth, int D, void* stream, unsigned short* gzs, Bn2Bwd bn2 = Bn2Bwd{}) {
   S2F_REQUIRE(!bn2.gamma || (training && single_pass_ok(N, C, L) && bn2.dgamma && bn2.dbeta && !gzs), S2F_EINVAL,
               "s2f_bn2_act_bwd: the BatchNorm pair runs on the single-pass kernels only");
-  const bool single = training && (single_pass_ok(N, C, L) || small_rows_ok(N, C, L));
+  const bool single = training && (single_pass_ok(N, C, L) || small_rows_ok(N, C, L) || mid_rows_ok(N, C, L));
   S2F_REQUIRE(z && stat && gamma && (single || sums_zeroed) && (gz || gzs) && dgamma && dbeta, S2F_EINVAL,
               "s2f_bn_act_bwd: null pointer");
   S2F_REQUIRE(!gzs || (reinterpret_cast<uintptr_t>(gzs) & 7u) == 0, S2F_EALIGN, "s2f_bn_act_bwd_split: gz_split must be 8-byte aligned");
@@ -1692,6 +1903,24 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = N * C * L;
+  if (training && mid_rows_ok(N, C, L)) {
+    S2F_REQUIRE(gzs == nullptr && gz, S2F_EINVAL, "s2f_bn_act_bwd_split: rows that are not whole tiles have no bf16-plane form");
+#define S2F_BN_MB(A, B, Cc)                                                                                               \
+  S2F_LAUNCH(true, true, (bn_mid_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(mid_rows_threads(N, L)), 0, s, z, conv_bias, stat, \
+             gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L, 1.0 / ((double)N * (double)L), vth, \
+             (float)D)
+    switch ((g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0)) {
+      case 1: S2F_BN_MB(false, false, true); break;
+      case 2: S2F_BN_MB(false, true, false); break;
+      case 3: S2F_BN_MB(false, true, true); break;
+      case 4: S2F_BN_MB(true, false, false); break;
+      case 5: S2F_BN_MB(true, false, true); break;
+      case 6: S2F_BN_MB(true, true, false); break;
+      default: S2F_BN_MB(true, true, true); break;
+    }
+#undef S2F_BN_MB
+    return s2f_check_launch("s2f_bn_act_bwd");
+  }
   if (training && small_rows_ok(N, C, L)) {
     S2F_REQUIRE(gzs == nullptr && gz, S2F_EINVAL, "s2f_bn_act_bwd_split: short rows (N * L <= 2048) have no bf16-plane form");
 #define S2F_BN_SB(A, B, Cc)                                                                                               \

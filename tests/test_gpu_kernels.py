@@ -369,7 +369,12 @@ def test_errors_are_raised_not_swallowed(ops):
                                                      # 33 .. 64 tiles per channel: the sixteen-wavefront single-pass form (C3's 64 x 32
                                                      # stage, C4's T = 8 batch)
                                                      (8, 64, 2048, True, True, True), (16, 96, 1024, True, False, True),
-                                                     (5, 64, 3072, True, True, False)])
+                                                     (5, 64, 3072, True, True, False),
+                                                     # rows that are not whole tiles, 2 049 .. 20 480 elements per channel: the per-channel
+                                                     # single-pass form on 2 .. 16 wavefronts (C5's 50 x 84 maps: [4, C, 4 200])
+                                                     (4, 64, 4200, True, True, True), (4, 32, 4200, True, False, True),
+                                                     (2, 40, 1052, True, True, True), (5, 33, 4092, True, True, False),
+                                                     (3, 64, 1000, True, False, True)])
 @pytest.mark.parametrize("bf16", [True, False])
 def test_bn_act_vs_oracle(so, spike_mode, bf16, N, C, L, training, res, lif):
     """The fused kernels against the oracle's chain  BN(z + b) [+ r] -> Q_IFNode  on CPU (F.batch_norm + lif_step).
