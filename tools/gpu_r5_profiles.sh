@@ -12,9 +12,17 @@ cut -c1-260 gpurun_out/${T}_bench_iteration.json
 timeout 600 python bench.py --mode predict > gpurun_out/${T}_bench_predict.json 2> gpurun_out/${T}_bench_predict.err
 cut -c1-260 gpurun_out/${T}_bench_predict.json
 timeout 600 python bench.py --mode predict --no-eval-fusion > gpurun_out/${T}_bench_predict_unfused.json 2>> gpurun_out/${T}_bench_predict.err
+timeout 600 python bench.py --mode predict --predict-all-layers > gpurun_out/${T}_bench_predict_all_layers.json 2>> gpurun_out/${T}_bench_predict.err
+cut -c1-260 gpurun_out/${T}_bench_predict_all_layers.json
 for wl in C3 C4 C5; do
   timeout 600 python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > gpurun_out/${T}_bench_$wl.json 2> gpurun_out/${T}_bench_$wl.err
   cut -c1-200 gpurun_out/${T}_bench_$wl.json
+done
+for wl in C3 C5; do          # category + per-kernel tables of the other configurations
+  bash tools/prof_workload.sh ${T}_$wl --workload $wl > /dev/null 2>&1
+  cd $R
+  cp gpurun_out/prof_${T}_${wl}_categories.txt gpurun_out/${T}_categories_$wl.txt
+  cp gpurun_out/prof_${T}_${wl}_kernels.txt gpurun_out/${T}_step_kernels_$wl.txt
 done
 timeout 600 python bench.py --loss hungarian > gpurun_out/${T}_bench_hungarian_loss.json 2> gpurun_out/${T}_bench_hungarian.err
 timeout 600 python bench.py --loss hungarian --optimizer > gpurun_out/${T}_bench_iteration_hungarian_loss.json 2>> gpurun_out/${T}_bench_hungarian.err
@@ -56,6 +64,12 @@ timeout 300 python tools/probe_dwp.py > gpurun_out/${T}_probe_dwp.txt 2>&1
 S2F_LIB=spike2former_amd/libs2f_probe.so timeout 300 python tools/probe_dwp_ko.py > gpurun_out/${T}_probe_dwp_knockouts.txt 2>&1
 timeout 300 python tools/probe_mask_fwd.py > gpurun_out/${T}_probe_mask_fwd.txt 2>&1
 timeout 300 python tools/probe_repconv_merge.py > gpurun_out/${T}_probe_repconv_merge.txt 2>&1
+timeout 300 python tools/probe_dwp_conv.py > gpurun_out/${T}_probe_dwp_conv.txt 2>&1
+timeout 300 python tools/probe_dwp_ragged.py > gpurun_out/${T}_probe_dwp_ragged.txt 2>&1
+timeout 300 python tools/probe_dcn.py > gpurun_out/${T}_probe_dcn.txt 2>&1
+timeout 300 python tools/probe_bn_stream.py 4,256,4200 4,256,4096 4,1024,4200 4,1024,4096 8,256,1024 8,256,4096 8,256,65536 > gpurun_out/${T}_probe_bn_stream.txt 2>&1
+timeout 300 python tools/predict_census.py > gpurun_out/${T}_predict_census.txt 2>&1
+timeout 300 python tools/glue_sites.py C2 predict > gpurun_out/${T}_glue_sites_predict.txt 2> /dev/null
 bash tools/prof_predict.sh ${T}p > /dev/null 2>&1
 cp gpurun_out/prof_${T}p_categories.txt gpurun_out/${T}_categories_predict.txt
 cp gpurun_out/prof_${T}p_kernels.txt gpurun_out/${T}_step_kernels_predict.txt
@@ -63,3 +77,5 @@ cd $R
 bash tools/prof_ab_env.sh ${T}_dwpipe S2F_DW_PIPE=0 S2F_DW_PIPE=1 > /dev/null 2>&1
 cd $R
 bash tools/prof_ab_env.sh ${T}_maskfwd S2F_MASK_FWD_PGEMM=0 S2F_MASK_FWD_PGEMM=1 > /dev/null 2>&1
+cd $R
+bash tools/prof_ab_env.sh ${T}_dwpipe_conv S2F_DW_PIPE_CONV=0 S2F_DW_PIPE_CONV=1 > /dev/null 2>&1
