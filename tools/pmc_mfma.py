@@ -15,13 +15,13 @@ FAMILIES = [("spike GEMM forward incl. 3x3, pipelined (pg_nn_kernel, pg_conv_ker
             ("input gradient / dense GEMM, 6 passes (pg_tn_f32_kernel, pg_conv_kernel<.., 3, ..>)",
              lambda n: "pg_tn_f32_kernel" in n or ("pg_conv_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "3")),
             ("spike GEMM forward, round-2 kernel: 3x3 convolutions, N < 128 (sgemm_bf16_kernel)", lambda n: "sgemm_bf16_kernel" in n),
-            ("spike GEMM weight gradient, pipelined (dwp_grouped_kernel: 1x1 layers, mask-contraction embedding gradient)", lambda n: "dwp_" in n),
-            ("spike GEMM weight gradient, round-2 kernel (sgemm_dw_bf16: implicit 3x3, L % 32 != 0)", lambda n: "sgemm_dw" in n),
+            ("spike GEMM weight gradient, pipelined (dwp_grouped_kernel / dwp_conv_kernel: 1x1 and wide 3x3 layers, mask-contraction embedding gradient)", lambda n: "dwp_" in n),
+            ("spike GEMM weight gradient, round-2 kernel (sgemm_dw_bf16: narrow implicit 3x3 layers, L % 4 != 0)", lambda n: "sgemm_dw" in n),
             ("general weight gradient, 6 passes (spike_gemm_dw_kernel / gemm_dw_general_grouped)",
              lambda n: "spike_gemm_dw_kernel" in n or "gemm_dw_general_grouped" in n),
             ("split GEMM (mask contraction backward, 3x3 input gradients)", lambda n: "split_gemm_kernel" in n),
             ("library fp32 GEMM (rocBLAS / hipBLASLt)", lambda n: n.startswith("Cijk")),
-            ("attention k^T v on the matrix cores (outer_mfma_kernel)", lambda n: "outer_mfma_kernel" in n)]
+            ("attention outer products on the matrix cores (outer_mfma_kernel, outer_mfma_sg_kernel)", lambda n: "outer_mfma" in n)]
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
 namecol = "kernel_name" if "kernel_name" in cols else "name"
