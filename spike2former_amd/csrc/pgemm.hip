@@ -550,6 +550,9 @@ struct TnGroups {
   int64_t g_stride, dx_stride, part_stride;          // element offsets between consecutive groups
 };
 
+// (Round 5 tried the gradient rows TWO steps ahead in two register sets, loop unrolled by two, weight copies as buffer loads: hipcc
+// answers the loop-carried loads with s_waitcnt vmcnt(0) at the loop header and in front of the next loads -- 36.29 vs 36.11 ms per C2
+// step.  Registers cannot be the target of loads in flight across a back edge; dwp.hip's LDS mailboxes are the form that works.)
 template <int MI, int NJ, int WMW, int WNW, int EPI, int KS = 1, bool STATS = false, bool GROUPED = false>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_tn_f32_kernel(const unsigned short* __restrict__ Wp,
                                                                   const float* __restrict__ G, float* __restrict__ DX, int Mo,
@@ -978,7 +981,10 @@ __device__ __forceinline__ f32x4 convp_fix(f32x4 v, ConvPredB p) {
 // the row lengths an LDS-DMA cannot take (N % 8 != 0: the decoder's 100-token maps, whose rows start 8-byte aligned only).
 // EPI = 1: the eval-mode BatchNorm (+ residual) (+ neuron) epilogue of s2f_gemm_bn_lif_fwd / s2f_conv3x3_bn_lif_fwd (epi_bn_lif)
 // instead of the plain store.
-template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true, bool STATS = false, int EPI = 0>
+// G: K steps per barrier ("super-step": G consecutive 32-wide steps staged, waited for and multiplied together; Kb % G == 0).  The
+// short products of the 32x32 stage (K = 256 .. 1 024, one workgroup per CU) spend each step waiting for the activation rows loaded
+// ONE step earlier: half as many, twice as long steps halve the exposed round trips (the input-gradient kernel's KS, round 5).
+template <int MI, int NJ, int WMW, int WNW, int BT, bool CONV = true, bool STATS = false, int EPI = 0, int G = 1>
 __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned short* __restrict__ Ap, const void* __restrict__ Xv,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                                 int N, int K, int Kb, int n_tiles, int m_tiles, Conv3 geo,
@@ -990,7 +996,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   constexpr int NQ = 32 * (BN / 4) / T;                            // 4-pixel chunks per thread and K step
   static_assert(NQ >= 1 && (32 * (BN / 4)) % T == 0 && T % (BN / 4) == 0, "tile too small for the thread count");
   typedef typename std::conditional<BT == 1, u32x2, f32x4>::type chunk_t;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G * STAGE];
 
   const int tiles = n_tiles * m_tiles;
   int pid = blockIdx.x;
@@ -1023,8 +1029,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   const int n_px = n0 + c4 * 4;
   const bool n_ok = n_px < N;
   const int py = CONV ? n_px / geo.W : 0, px = CONV ? n_px - py * geo.W : 0;
-  chunk_t breg[NQ];
-  auto fetch_b = [&](int kb) __attribute__((always_inline)) {
+  chunk_t breg_[G][NQ];
+  auto fetch_b = [&](int kb, int g = 0) __attribute__((always_inline)) {
+    chunk_t (&breg)[NQ] = breg_[g];
     const int kk = kb * 32;
     const int tap = CONV ? kk / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky, c0 = CONV ? kk - tap * geo.C : kk;
     const ConvPredB pr = CONV ? convp(py, px, ky, kx, geo, n_ok && kk < K) : ConvPredB{n_ok, false, false};
@@ -1040,7 +1047,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
         breg[q] = *reinterpret_cast<const f32x4*>(Xf + row);
     }
   };
-  auto stage_b = [&](int kb, int st) __attribute__((always_inline)) {
+  auto stage_b = [&](int kb, int st, int g = 0) __attribute__((always_inline)) {
+    chunk_t (&breg)[NQ] = breg_[g];
     const int kk = kb * 32;
     const int tap = CONV ? kk / geo.C : 0, ky = tap / 3, kx = tap - 3 * ky;
     const ConvPredB pr = CONV ? convp(py, px, ky, kx, geo, n_ok && kk < K) : ConvPredB{n_ok, false, false};
@@ -1133,23 +1141,57 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
     }
   };
 
-  fetch_b(0);
-  issue_a(0, 0);
-  stage_b(0, 0);                                                   // the compiler waits for the loads of fetch_b(0) here
-  if (Kb > 1) fetch_b(1);
-  for (int t = 0; t < Kb; ++t) {
-    const int st = t & 1;
-    // the copies of tile t are older than the loads of tile t+1 (NQ of them): a counted wait leaves those in flight
-    if (t + 1 < Kb)
-      wait_vm_and_barrier<NQ>();
-    else
-      wait_vm_and_barrier<0>();
-    if (t + 1 < Kb) {
-      stage_b(t + 1, st ^ 1);                                      // tile t+1 from registers (loaded one step ago)
-      issue_a(t + 1, st ^ 1);
-      if (t + 2 < Kb) fetch_b(t + 2);
+  if constexpr (G == 1) {
+    fetch_b(0);
+    issue_a(0, 0);
+    stage_b(0, 0);                                                   // the compiler waits for the loads of fetch_b(0) here
+    if (Kb > 1) fetch_b(1);
+    for (int t = 0; t < Kb; ++t) {
+      const int st = t & 1;
+      // the copies of tile t are older than the loads of tile t+1 (NQ of them): a counted wait leaves those in flight
+      if (t + 1 < Kb)
+        wait_vm_and_barrier<NQ>();
+      else
+        wait_vm_and_barrier<0>();
+      if (t + 1 < Kb) {
+        stage_b(t + 1, st ^ 1);                                      // tile t+1 from registers (loaded one step ago)
+        issue_a(t + 1, st ^ 1);
+        if (t + 2 < Kb) fetch_b(t + 2);
+      }
+      compute(st);
     }
-    compute(st);
+  } else {
+    // super-steps of G tiles (Kb % G == 0): slot (parity, g) = parity * G + g
+    const int ns = Kb / G;
+#pragma unroll
+    for (int g = 0; g < G; ++g) fetch_b(g, g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) issue_a(g, g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) stage_b(g, g, g);
+    if (ns > 1) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) fetch_b(G + g, g);
+    }
+    for (int t = 0; t < ns; ++t) {
+      const int par = t & 1;
+      if (t + 1 < ns)
+        wait_vm_and_barrier<G * NQ>();
+      else
+        wait_vm_and_barrier<0>();
+      if (t + 1 < ns) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) stage_b((t + 1) * G + g, (par ^ 1) * G + g, g);
+#pragma unroll
+        for (int g = 0; g < G; ++g) issue_a((t + 1) * G + g, (par ^ 1) * G + g);
+        if (t + 2 < ns) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) fetch_b((t + 2) * G + g, g);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) compute(par * G + g);
+    }
   }
 
   mfma_fence(acc);
@@ -1175,6 +1217,13 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
   if constexpr (STATS)
     epi_row_partials<MI, NJ, WMW, WNW>(acc, part, n_tiles * (int)gridDim.y, reinterpret_cast<float*>(smem), m0, n0, M, N,
                                        b * n_tiles + nt, wm, wn, lane, tid);
+}
+
+// two K steps per barrier (pg_conv_kernel<.., G = 2>) for the short products that run one workgroup per CU or less: the 32x32 stage
+bool nn_super_steps(int Kb, int64_t workgroups) {
+  static const char* e = getenv("S2F_PG_NN_G");          // A/B switch: "1" keeps one step per barrier
+  if (e && e[0] == '1') return false;
+  return (Kb & 1) == 0 && Kb >= 4 && workgroups <= 512;
 }
 
 int pick_cfg_nn(int M, int N, int K, int batch, int force) {
@@ -1227,7 +1276,14 @@ static int pgemm_nn_impl(const uint16_t* a_pack, const uint16_t* X, const float*
     const bool wide = c == 7;          // (an environment-forced DMA configuration does not apply to rows of N % 8 != 0)
     if (c == 8) {
       const int m_tiles = (M + 63) / 64;
-      if (part)
+      const bool g2 = nn_super_steps(Kb, (int64_t)n_tiles * m_tiles * batch);
+      if (part && g2)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, true, 0, 2>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
+      else if (g2)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, false, 0, 2>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
+      else if (part)
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
                    bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
       else
@@ -1235,7 +1291,14 @@ static int pgemm_nn_impl(const uint16_t* a_pack, const uint16_t* X, const float*
                    M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
     } else if (wide) {
       const int m_tiles = (M + 127) / 128;
-      if (part)
+      const bool g2 = nn_super_steps(Kb, (int64_t)n_tiles * m_tiles * batch);
+      if (part && g2)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, true, 0, 2>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                   bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
+      else if (g2)
+        S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, false, 0, 2>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X, bias, Y,
+                   M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
+      else if (part)
         S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, true>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
                    bias, Y, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, part, BnLifEpi{});
       else
@@ -1345,12 +1408,20 @@ extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, co
                (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr, NnEx{});
   } else if (c == 8) {
     const int m_tiles = (M + 63) / 64;
-    S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
-               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+    if (nn_super_steps(Kb, (int64_t)n_tiles * m_tiles * batch))
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, false, 1, 2>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                 (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+    else
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 1, 2, 4, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                 (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
   } else if (c == 7) {
     const int m_tiles = (M + 127) / 128;
-    S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
-               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+    if (nn_super_steps(Kb, (int64_t)n_tiles * m_tiles * batch))
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, false, 1, 2>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                 (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
+    else
+      S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 4, 2, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(512), 0, s, a_pack, X,
+                 (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, Conv3{0, 0, 0}, (float*)nullptr, ep);
   } else {
     const int m_tiles = (M + 63) / 64;
     S2F_LAUNCH(true, true, (pg_conv_kernel<1, 2, 2, 2, 1, false, false, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
@@ -1518,6 +1589,11 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
   // cfg 7 = cfg 4 with 32-row steps (half the barriers and waits per MFMA): 11.7 vs 12.6 us, 19.0 vs 20.8, 32.6 vs 38.1 on the three
   // shapes above; the plain-store form only (no beta, no contraction split)
   if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : (beta == 0.f ? 7 : 4);
+  // 64-row steps (cfg 10) where cfg 7 would run and the grid is one workgroup per CU or less (144 KB of LDS): the step waits for the
+  // gradient rows loaded one step earlier, so half as many steps expose half as many round trips -- C2 step 36.58 -> 36.42 ms
+  // same-box (S2F_PG_DX_KS4=0: the A/B switch).  The 128 x 128 tile with 32-row steps (cfg 9) measured equal to cfg 3: left alone.
+  static const char* ks4 = getenv("S2F_PG_DX_KS4");
+  if (c == 7 && !(ks4 && ks4[0] == '0') && Mo >= 128 && (int64_t)n_tiles * batch * ((Ki + 63) / 64) <= 512) c = 10;
   // few output tiles and a long contraction (the decoder's 100-token products): split the contraction over gridDim.z
   int zsplit = 1;
   {
@@ -1556,22 +1632,25 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
     case 3: S2F_PGD(1, 2, 4, 2); break;          // 128 x 128 on eight wavefronts (two per SIMD)
     case 4: S2F_PGD(1, 1, 2, 4); break;          // 64 x 128 on eight wavefronts of 32 x 32
     case 5: S2F_PGD(1, 1, 1, 4); break;          // 32 x 128 on four wavefronts of 32 x 32: twice the workgroups of cfg 2
-#define S2F_PGD2(MI, NJ, WMW, WNW)                                                                                      \
+#define S2F_PGD2(MI, NJ, WMW, WNW) S2F_PGD3(MI, NJ, WMW, WNW, 2)
+#define S2F_PGD3(MI, NJ, WMW, WNW, KSV)                                                                                 \
   do {                                                                                                                 \
     S2F_REQUIRE(zsplit == 1 && beta == 0.f, S2F_EINVAL, "s2f_pgemm_dx_f32: cfg %d is the plain store form", c);           \
     const int m_tiles = (Ki + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                    \
     if (part)                                                                                                          \
-      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2, true>), dim3(n_tiles * m_tiles, batch, 1),        \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, KSV, true>), dim3(n_tiles * m_tiles, batch, 1),      \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
                  dx_batch_stride, part, TnGroups{}, BnLifEpi{});                                                                       \
     else                                                                                                               \
-      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, 2>), dim3(n_tiles * m_tiles, batch, 1),              \
+      S2F_LAUNCH(true, true, (pg_tn_f32_kernel<MI, NJ, WMW, WNW, 0, KSV>), dim3(n_tiles * m_tiles, batch, 1),            \
                  dim3(64 * WMW * WNW), 0, s, w_pack, G, DX, Mo, Ki, N, KbW, n_tiles, m_tiles, beta, g_batch_stride,      \
                  dx_batch_stride, part, TnGroups{}, BnLifEpi{});                                                                       \
   } while (0)
     case 7: S2F_PGD2(1, 1, 2, 4); break;         // cfg 4 with 32-row steps (half the barriers per MFMA)
     case 8: S2F_PGD2(1, 2, 2, 2); break;         // cfg 2 with 32-row steps
     case 9: S2F_PGD2(1, 2, 4, 2); break;         // cfg 3 with 32-row steps
+    case 10: S2F_PGD3(1, 1, 2, 4, 4); break;     // cfg 4 with 64-row steps (144 KB of LDS: one workgroup per CU)
+#undef S2F_PGD3
 #undef S2F_PGD2
     default: S2F_REQUIRE(false, S2F_EINVAL, "s2f_pgemm_dx_f32: unknown cfg %d", c);
   }
@@ -1636,6 +1715,8 @@ extern "C" int s2f_dense_gemm_bn_lif_fwd(const uint16_t* const* w_packs, int gro
     S2F_PGE(1, 1, 1, 4, 1);
   else if (wide)
     S2F_PGE(1, 2, 4, 2, 2);
+  else if (K >= 128 && (int64_t)n_tiles * batch * ((M + 63) / 64) * groups <= 512)
+    S2F_PGE(1, 1, 2, 4, 4);          // 64-row steps for the launches of one workgroup per CU or less (as s2f_pgemm_dx_f32's cfg 10)
   else
     S2F_PGE(1, 1, 2, 4, 2);
 #undef S2F_PGE

@@ -477,7 +477,7 @@ class _SpikeGemm(torch.autograd.Function):
                 _time_next("spike_gemm_dw", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, x)
                 st = side.cuda_stream if side is not None else _stream()
-                if xb and cfg.DW_PIPE and M >= 128 and K >= 128 and lib.s2f_spike_gemm_dw_pipe_ok(B, M, K, L):
+                if xb and cfg.DW_PIPE and cfg.DW_PIPE_SINGLE and M >= 128 and K >= 128 and lib.s2f_spike_gemm_dw_pipe_ok(B, M, K, L):
                     # long contractions launch on their own: the LDS-DMA pipeline where its 128 x 256 tile is filled
                     check(lib.s2f_spike_gemm_dw_pipe(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, L,
                                                      int(sink is not None), 0, 0, st), "s2f_spike_gemm_dw_pipe")

@@ -108,7 +108,7 @@ if what in ("dx", "all"):
         row = f"B{B} Mo{Mo:5d} Ki{Ki:5d} N{N:6d}  lib {tl:7.1f} ({lib_err:.1e})"
         fl = 2 * B * Mo * N * Ki
         best = 1e9
-        for cfg in (2, 3, 4, 5, 7, 9):
+        for cfg in (2, 3, 4, 5, 7, 9, 10):
             if N % 4:
                 continue
             dx = torch.full((B, Ki, N), float("nan"), device="cuda")
