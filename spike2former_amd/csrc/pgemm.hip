@@ -1229,12 +1229,15 @@ bool nn_super_steps(int Kb, int64_t workgroups) {
 int pick_cfg_nn(int M, int N, int K, int batch, int force) {
   if (force > 0) return force;
   // measured (tools/probe_pgemm.py fwd, profiles/r03_probe_pgemm.txt):
-  //   long contractions (K >= 1024): the all-DMA 64 x 128 tile on four wavefronts, two LDS stages (cfg 4);
+  //   long contractions (K >= 1024): the all-DMA 64 x 128 tile on four wavefronts, three LDS stages (cfg 2; two: cfg 4);
   //   otherwise the activation rows through registers (pg_conv_kernel<.., CONV = false>) -- 128 x 128 on eight wavefronts when
   //   that still gives every CU a workgroup (cfg 7), else 64 x 128 on four (cfg 6): 8.7 vs 10.2 us on [256x256]@[8x256x1024],
   //   12.0 vs 14.0 on [512x256], 18.9 vs 20.4 on [256x256]@[8x256x4096].  Rows of N % 8 != 0 elements only take cfg 6 / 7.
   const int64_t tiles128 = (int64_t)((N + 127) / 128) * batch * ((M + 127) / 128);
-  if (K >= 1024 && (N & 7) == 0) return 4;
+  // (round 5, in the step: THREE stages (cfg 2) 36.38 / 36.39 ms against 36.56 / 36.54 with two (cfg 4) and 36.42 on the register-staged
+  //  tile with two steps per barrier -- the isolated probe, whose operands are cache-resident, had the two-stage form ahead)
+  static const char* k1024 = getenv("S2F_PG_NN_LONGK");          // A/B switch
+  if (K >= 1024 && (N & 7) == 0) return k1024 ? atoi(k1024) : 2;
   // (cfg 8 = the 64 x 128 tile on eight wavefronts of 32 x 32: 8.1 vs 8.6 us, 11.8 vs 12.6, 19.9 vs 20.5 on the 1 024-column shapes)
   // (round 4, tools/probe_small_n.py: the eight-wavefront tile also wins on the decoder's 100-token maps -- 31.0 vs 33.4 us on
   //  [256x2048], 6.4 vs 7.1 on [256x256], 8.4 vs 8.9 on [2048x256] -- so cfg 6 is left with the outputs of fewer than 64 rows)
@@ -1402,7 +1405,11 @@ extern "C" int s2f_gemm_bn_lif_fwd(const uint16_t* a_pack, const uint16_t* X, co
   // the tile rule of the plain product (pick_cfg_nn): round 3 ran every fused launch on the four-wavefront DMA tile, 36 us on average
   // in the C2 inference step where the plain products of the same shapes take 14-21 us
   const int c = pick_cfg_nn(M, N, K, batch, 0);
-  if (c == 4) {
+  if (c == 2) {
+    const int m_tiles = (M + 63) / 64;
+    S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 3, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
+               (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr, NnEx{});
+  } else if (c == 4) {
     const int m_tiles = (M + 63) / 64;
     S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 1>), dim3(n_tiles * m_tiles, batch), dim3(256), 0, s, a_pack, X,
                (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, (int64_t)K * N, ep, (float*)nullptr, NnEx{});
@@ -1449,16 +1456,25 @@ extern "C" int s2f_conv3x3_bn_lif_fwd(const uint16_t* w_pack, const uint16_t* X,
               1.0f / (float)D};
   hipStream_t s = (hipStream_t)stream;
   const Conv3 geo{H, W, C};
+  // (the small-grid rule of the training forward, conv_launch: 64 x 128 tiles and two K steps per barrier when that is all the chip gets)
+  static const char* small_env = getenv("S2F_PG_CONV_SMALL");
+  const bool small_ok = !(small_env && small_env[0] == '0');
+  const bool narrow = small_ok && M > 64 && (int64_t)n_tiles * batch * ((M + 127) / 128) <= 256;
 #define S2F_PGCE(MI, NJ, WMW, WNW)                                                                                        \
   do {                                                                                                                   \
     const int m_tiles = (M + 32 * MI * WMW - 1) / (32 * MI * WMW);                                                       \
-    S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, false, 1>), dim3(n_tiles * m_tiles, batch),         \
-               dim3(64 * WMW * WNW), 0, s, w_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, \
-               geo, (float*)nullptr, ep);                                                                                \
+    if (small_ok && (Kb & 1) == 0 && Kb >= 4 && (int64_t)n_tiles * m_tiles * batch <= 512)                               \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, false, 1, 2>), dim3(n_tiles * m_tiles, batch),    \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, \
+                 geo, (float*)nullptr, ep);                                                                              \
+    else                                                                                                                 \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, false, 1>), dim3(n_tiles * m_tiles, batch),       \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, X, (const float*)nullptr, (float*)nullptr, M, N, K, Kb, n_tiles, m_tiles, \
+                 geo, (float*)nullptr, ep);                                                                              \
   } while (0)
   if (M <= 32)
     S2F_PGCE(1, 1, 1, 4);
-  else if (M <= 64)
+  else if (M <= 64 || narrow)
     S2F_PGCE(1, 2, 2, 2);
   else
     S2F_PGCE(1, 2, 4, 2);
@@ -1514,6 +1530,14 @@ static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, b
   // measured (tools/probe_pgemm.py conv, profiles/r03_probe_pgemm_conv.txt): rows <= 32 / <= 64 -> the 32- / 64-row tiles; otherwise
   // 128 x 128 on eight wavefronts (two per SIMD: the staging of one runs under the MFMAs of the other)
   if (c <= 0) c = M <= 32 ? 3 : M <= 64 ? 2 : 4;
+  // A launch of at most one 128 x 128 tile per CU (e.g. [128 <- 512] on 64 x 64: 256 tiles, 144 K steps each) runs its steps one
+  // exposed round trip after the other: twice as many 64 x 128 tiles on four wavefronts overlap each other's (isolated 168 vs 176 us,
+  // in the step 217 us on the large tile), and two K steps per barrier halve the round trips (S2F_PG_CONV_SMALL=0: the A/B switch)
+  static const char* small_env = getenv("S2F_PG_CONV_SMALL");
+  const bool small_ok = !(small_env && small_env[0] == '0');
+  if (cfg <= 0 && !force && small_ok && c == 4 && (int64_t)n_tiles * batch * ((M + 127) / 128) <= 256) c = 2;
+  const bool g2 = small_ok && !x_fp32 && (Kb & 1) == 0 && Kb >= 4 &&
+                  (int64_t)n_tiles * batch * ((M + (c == 4 || c == 1 ? 127 : c == 2 ? 63 : 31)) / (c == 4 || c == 1 ? 128 : c == 2 ? 64 : 32)) <= 512;
   const Conv3 geo{H, W, C};
 #define S2F_PGC(MI, NJ, WMW, WNW)                                                                                         \
   do {                                                                                                                   \
@@ -1521,6 +1545,12 @@ static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, b
     if (x_fp32)                                                                                                          \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 3>), dim3(n_tiles * m_tiles, batch), dim3(64 * WMW * WNW), 0, s, \
                  w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});                                           \
+    else if (part && g2)                                                                                                 \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, true, 0, 2>), dim3(n_tiles * m_tiles, batch),     \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});               \
+    else if (g2)                                                                                                         \
+      S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, false, 0, 2>), dim3(n_tiles * m_tiles, batch),    \
+                 dim3(64 * WMW * WNW), 0, s, w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});               \
     else if (part)                                                                                                       \
       S2F_LAUNCH(true, true, (pg_conv_kernel<MI, NJ, WMW, WNW, 1, true, true>), dim3(n_tiles * m_tiles, batch),           \
                  dim3(64 * WMW * WNW), 0, s, w_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, geo, part, BnLifEpi{});               \
