@@ -1241,7 +1241,9 @@ int pick_cfg_nn(int M, int N, int K, int batch, int force) {
   // (cfg 8 = the 64 x 128 tile on eight wavefronts of 32 x 32: 8.1 vs 8.6 us, 11.8 vs 12.6, 19.9 vs 20.5 on the 1 024-column shapes)
   // (round 4, tools/probe_small_n.py: the eight-wavefront tile also wins on the decoder's 100-token maps -- 31.0 vs 33.4 us on
   //  [256x2048], 6.4 vs 7.1 on [256x256], 8.4 vs 8.9 on [2048x256] -- so cfg 6 is left with the outputs of fewer than 64 rows)
-  return (M > 64 && tiles128 >= 256) ? 7 : ((N >= 128 || M >= 64) ? 8 : 6);
+  static const char* t7e = getenv("S2F_PG_NN_T7");          // probe: the tile-count threshold of the 128 x 128 tile
+  const int64_t t7 = t7e ? atoll(t7e) : 256;
+  return (M > 64 && tiles128 >= t7) ? 7 : ((N >= 128 || M >= 64) ? 8 : 6);
 }
 
 }  // namespace
@@ -1368,9 +1370,15 @@ extern "C" int s2f_pgemm_nn_bf16_ex(const uint16_t* a_pack, int64_t a_batch_stri
   const int Kb = (K + PK - 1) / PK, n_tiles = (N + 127) / 128, m_tiles = (M + 63) / 64;
   // 64 x 128 on four wavefronts, two LDS stages, three workgroups per CU (cfg 4 of s2f_pgemm_nn_bf16): 603 us on the C2 mask contraction
   // [700 x 1024] @ [2 x 1024 x 65536] against 834 for the round-2 kernel and 659 for the 256 x 128 eight-wavefront tile (tools/probe_mask_fwd.py)
-  S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 0, false, true>), dim3(n_tiles * m_tiles, batch), dim3(256), 0,
-             (hipStream_t)stream, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, x_batch_stride, BnLifEpi{}, nullptr,
-             NnEx{k_inner, a_batch_stride, x_outer_stride, bias_batch_stride, out_scale});
+  static const char* nst_env = getenv("S2F_PG_EX_NST");          // A/B switch: LDS stages of this launch
+  if (nst_env && nst_env[0] == '3')
+    S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 3, 0, false, true>), dim3(n_tiles * m_tiles, batch), dim3(256), 0,
+               (hipStream_t)stream, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, x_batch_stride, BnLifEpi{}, nullptr,
+               NnEx{k_inner, a_batch_stride, x_outer_stride, bias_batch_stride, out_scale});
+  else
+    S2F_LAUNCH(true, true, (pg_nn_kernel<1, 2, 2, 2, 3, 2, 0, false, true>), dim3(n_tiles * m_tiles, batch), dim3(256), 0,
+               (hipStream_t)stream, a_pack, X, bias, Y, M, N, K, Kb, n_tiles, m_tiles, x_batch_stride, BnLifEpi{}, nullptr,
+               NnEx{k_inner, a_batch_stride, x_outer_stride, bias_batch_stride, out_scale});
   return s2f_check_launch("s2f_pgemm_nn_bf16_ex");
 }
 
@@ -1618,7 +1626,9 @@ static int pgemm_dx_impl(const uint16_t* w_pack, const float* G, int64_t g_batch
   // whose staging, LDS reads and MFMAs only ever run one after the other); <= 32 output rows: 32 x 128 tiles (cfg 5)
   // cfg 7 = cfg 4 with 32-row steps (half the barriers and waits per MFMA): 11.7 vs 12.6 us, 19.0 vs 20.8, 32.6 vs 38.1 on the three
   // shapes above; the plain-store form only (no beta, no contraction split)
-  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= 192) ? 3 : (beta == 0.f ? 7 : 4);
+  static const char* t3e = getenv("S2F_PG_DX_T3");          // probe: the tile-count threshold of the 128 x 128 tile
+  const int64_t t3 = t3e ? atoll(t3e) : 192;
+  if (c <= 0) c = Ki <= 32 ? 5 : (Ki > 64 && (int64_t)n_tiles * batch * ((Ki + 127) / 128) >= t3) ? 3 : (beta == 0.f ? 7 : 4);
   // 64-row steps (cfg 10) where cfg 7 would run and the grid is one workgroup per CU or less (144 KB of LDS): the step waits for the
   // gradient rows loaded one step earlier, so half as many steps expose half as many round trips -- C2 step 36.58 -> 36.42 ms
   // same-box (S2F_PG_DX_KS4=0: the A/B switch).  The 128 x 128 tile with 32-row steps (cfg 9) measured equal to cfg 3: left alone.

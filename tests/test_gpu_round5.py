@@ -362,3 +362,47 @@ def test_predict_on_the_last_layer_alone_gives_the_logits_of_the_full_head():
         maskformer_head.PREDICT_LAST_ONLY = was
     assert outs[True].shape == outs[False].shape
     assert (outs[True] - outs[False]).abs().max().item() <= 1e-6 * outs[False].abs().max().item()
+
+
+def test_stateless_inference_fusions_run_and_match_the_unfused_path():
+    """Row f4, the fusions of the second half of round 5 at model level (plumbing widths, 256x256 images, reset neurons): the dense
+    1x1 + BatchNorm(-pair) + neuron launches (s2f_dense_gemm_bn_lif_fwd) and the sigmoid inside the final up-sampling are really
+    taken, and the segmentation logits agree with the two-kernel path (fused.EVAL_FUSION =
+    False) to fp32 round-off where no spike sits on a rounding boundary: 10^-4 of the logits' range, same arg-max on 99.9 % of the pixels."""
+    import spike2former_amd as s2f
+    from spike2former_amd import fused
+    from spike2former_amd._lib import lib
+    from spike2former_amd.init_utils import seeded_init
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1"))).cuda().eval()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(21)).cuda()
+    counts = {"s2f_dense_gemm_bn_lif_fwd": 0, "s2f_sdsa_lif_fwd_bf16_nomask": 0, "s2f_upsample2x_sigmoid_fwd": 0}
+    origs = {n: getattr(lib, n) for n in counts}
+
+    def wrap(n):
+        def f(*a):
+            counts[n] += 1
+            return origs[n](*a)
+        return f
+    for n in counts:
+        setattr(lib, n, wrap(n))
+    outs = {}
+    try:
+        for on in (True, False):
+            fused.EVAL_FUSION = on
+            s2f.reset_net(model)
+            with torch.no_grad():
+                outs[on] = model(img, mode="logits").clone()
+            if on:
+                taken = dict(counts)
+    finally:
+        fused.EVAL_FUSION = True
+        for n in counts:
+            setattr(lib, n, origs[n])
+    # (the plumbing config has 10 queries: the attention + neuron pair needs Nq % 4 == 0 and is covered by its own test above)
+    assert taken["s2f_dense_gemm_bn_lif_fwd"] >= 8 and taken["s2f_upsample2x_sigmoid_fwd"] == 1, taken
+    assert counts["s2f_dense_gemm_bn_lif_fwd"] == taken["s2f_dense_gemm_bn_lif_fwd"]          # ... and not with the switch off
+    a, b = outs[True], outs[False]
+    rng = (b.max() - b.min()).item()
+    assert (a - b).abs().max().item() <= 1e-4 * rng, ((a - b).abs().max().item(), rng)
+    assert (a.argmax(1) == b.argmax(1)).float().mean().item() >= 0.999
