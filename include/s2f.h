@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 21
+#define S2F_ABI_VERSION 22
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -85,6 +85,11 @@ int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, void* y_k
                      void* stream);
 int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const uint64_t* mask_key, const uint64_t* mask_value,
                      float* gx, int64_t n, int D, void* stream);
+/* The same with either incoming gradient optional (NULL = zero) and, in gx_key?, STE(g_key, mask_key) alone: summed over the T
+ * time steps it is the gradient with respect to `pos` (the decoder's self- / cross-attention query neurons, whose position term is
+ * the learnable query embedding: mmcv_spike/transformer.py:597-638). */
+int s2f_sum2_lif_bwd_ex(const float* g_key, const float* g_value, const uint64_t* mask_key, const uint64_t* mask_value, float* gx,
+                        float* gx_key, int64_t n, int D, void* stream);
 
 /* Layer scale folded into a BatchNorm's affine pair: w[c] = gamma[c] * s[c], b[c] = beta[c] * s[c]  (the pixel decoder's
  * `q + gamma_i * f(q)`, detr_layers.py:331-337, with f ending in a BatchNorm: u = s * BN(z) = BN_{gamma s, beta s}(z)).

@@ -259,24 +259,31 @@ __global__ __launch_bounds__(kBlock) void sum2_lif_fwd_kernel(const float* __res
 }
 
 // gx = STE_k(g_k) + STE_v(g_v)   (the gradient with respect to x; the one with respect to e is its per-channel sum)
+// gk / gv may be null (a neuron whose output nobody differentiated); gxk? receives STE_k(g_k) alone -- the gradient with respect to
+// `pos` is its sum over the T time steps (the decoder's self-attention, whose position term is the learnable query embedding)
 __global__ __launch_bounds__(kBlock) void sum2_lif_bwd_kernel(const float* __restrict__ gk, const float* __restrict__ gv,
                                                               const uint64_t* __restrict__ mk,
                                                               const uint64_t* __restrict__ mv, float* __restrict__ gx,
-                                                              int64_t n, float Df) {
+                                                              float* __restrict__ gxk, int64_t n, float Df) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t ntiles = (n + 255) >> 8;
   for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * 256 + lane * 4;
-    const Tile4 a = load4(gk, base, n, 0.f), b = load4(gv, base, n, 0.f);
-    Tile4 o;
+    Tile4 a, b, o, ok;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.a[j] = b.a[j] = 0.f;
+    if (gk) a = load4(gk, base, n, 0.f);
+    if (gv) b = load4(gv, base, n, 0.f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool bk = (mk[tile * 4 + j] >> lane) & 1ull, bv = (mv[tile * 4 + j] >> lane) & 1ull;
-      o.a[j] = (bv ? b.a[j] / Df : 0.f) + (bk ? a.a[j] / Df : 0.f);
+      ok.a[j] = bk ? a.a[j] / Df : 0.f;
+      o.a[j] = (bv ? b.a[j] / Df : 0.f) + ok.a[j];
     }
     store4(gx, base, n, o);
+    if (gxk) store4(gxk, base, n, ok);
   }
 }
 
@@ -476,8 +483,19 @@ extern "C" int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const 
   S2F_REQUIRE(s2f_aligned16(g_key) && s2f_aligned16(g_value) && s2f_aligned16(gx), S2F_EALIGN,
               "s2f_sum2_lif_bwd: tensors must be 16-byte aligned");
   S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
-             mask_key, mask_value, gx, n, (float)D);
+             mask_key, mask_value, gx, (float*)nullptr, n, (float)D);
   return s2f_check_launch("s2f_sum2_lif_bwd");
+}
+
+extern "C" int s2f_sum2_lif_bwd_ex(const float* g_key, const float* g_value, const uint64_t* mask_key,
+                                   const uint64_t* mask_value, float* gx, float* gx_key, int64_t n, int D, void* stream) {
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE((g_key || g_value) && mask_key && mask_value && gx, S2F_EINVAL, "s2f_sum2_lif_bwd_ex: null pointer");
+  S2F_REQUIRE(s2f_aligned16(g_key) && s2f_aligned16(g_value) && s2f_aligned16(gx) && s2f_aligned16(gx_key), S2F_EALIGN,
+              "s2f_sum2_lif_bwd_ex: tensors must be 16-byte aligned");
+  S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
+             mask_key, mask_value, gx, gx_key, n, (float)D);
+  return s2f_check_launch("s2f_sum2_lif_bwd_ex");
 }
 
 extern "C" int s2f_scale_affine_fwd(const float* gamma, const float* beta, const float* s, float* w, float* b, int C,

@@ -4,6 +4,7 @@ DCNv3 module (ops_dcnv3/modules/dcnv3.py:96-233), pixel-decoder MS_MLP and decod
 263-339, 417-559) and the sine positional encoding (positional_encoding.py:59-98).  Class names, kwargs and state_dict
 keys follow the reference; the bug-compatible `reshape`-instead-of-permute quirks are reproduced and flagged."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -17,6 +18,9 @@ from .registry import ConfigDict
 
 def _lif():
     return Q_IFNode(surrogate_function=Quant())
+
+
+FUSED_QUERY_NEURONS = os.environ.get("S2F_FUSED_QN", "1") != "0"          # decoder: `query + query_pos` and the neurons that read it as one launch (False: add + neurons, for A/B)
 
 
 class SepConv_Spike(nn.Module):
@@ -279,8 +283,29 @@ class MultiHeadAttentionBlock(nn.Module):
         v = self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, None if kv_spikes is None else kv_spikes[1])
         return k, v
 
+    def fused_neurons_ok(self, which, x):
+        """The input neurons `which` (of q_conv_spike / k_conv_spike / v_conv_spike) are pure functions of their input with the same
+        parameters, and x [t, b, dim, n] is a map ops.sum2_lif takes: the position add and the neurons can run as one launch."""
+        ns = [getattr(self, w + "_conv_spike") for w in which]
+        return (FUSED_QUERY_NEURONS and x.is_cuda and x.dim() == 4 and x.shape[-1] % 4 == 0 and x.dtype == torch.float32
+                and all(isinstance(n.v, float) and not n.keep_membrane and n.stats is None and not n._forward_hooks
+                        and not n._forward_pre_hooks for n in ns)
+                and len({(n.D, n.v_threshold) for n in ns}) == 1 and ops.spikes_bf16_ok(ns[0].D))
+
+    def fire_with_pos(self, x, pos):
+        """x [t, b, dim, n], pos [b, dim, n] -> (Q_IFNode(x + pos), Q_IFNode(x)) as ops.Spikes of x's shape: ONE launch forward, one
+        backward, the sum never materialised (ops.sum2_lif with a zero level embedding; fused_neurons_ok says when this is legal)."""
+        z = getattr(self, "_zero_e", None)
+        if z is None or z.device != x.device or z.shape[0] != x.shape[2]:
+            z = self._zero_e = torch.zeros(x.shape[2], dtype=torch.float32, device=x.device)
+        n0 = self.q_conv_spike
+        yk, yv = ops.sum2_lif(x.flatten(0, 1), z, pos, x.shape[1], n0.D, n0.v_threshold)
+        for m in (self.q_conv_spike, self.k_conv_spike, self.v_conv_spike):
+            m.v = 0.0
+        return yk.view(x.shape), yv.view(x.shape)
+
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None,
-                kv_projected=None, query_channel_major=False, residual_cm=None):
+                kv_projected=None, query_channel_major=False, residual_cm=None, q_spikes=None):
         """`residual_cm` (channel-major streams only): a [t,b,dim,nq] tensor added to the result inside the output BatchNorm kernel
         (the decoder layer's `query + attention(query)`, detr_layers.py:523-537) -- the add launch disappears.
         query [t,b,nq,dim]; key/value [t,b,nk,dim] as in the reference, or -- `kv_channel_major` -- [t,b,dim,nk], the
@@ -299,7 +324,7 @@ class MultiHeadAttentionBlock(nn.Module):
 
         if kv_projected is not None:
             # keys / values do not depend on the query: the head projected them for every layer ahead of the query chain
-            q = self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm)
+            q = self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm, q_spikes)
             k, v, handle = kv_projected
             ops.join(handle, (k, v))
         else:
@@ -308,7 +333,7 @@ class MultiHeadAttentionBlock(nn.Module):
             k, v, q = ops.branches([   # independent chains (the long ones first: keys / values are the 1 024 - 16 384-token maps)
                 lambda: self._proj(self.k_conv_spike, self.k_conv, self.k_spike, key, cm, fk),
                 lambda: self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, fv),
-                lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm)],
+                lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm, q_spikes)],
                 inputs=(query, key, value, fk, fv))
         o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)      # embed_dim**0.5, not head dim
         res = residual_cm.reshape(t * b, dim, nq) if (residual_cm is not None and qcm) else None
@@ -338,9 +363,15 @@ class MultiheadAttention(nn.Module):
                 key_padding_mask=None, kv_channel_major=False, kv_spikes=None, kv_projected=None, **kwargs):
         qcm = bool(kwargs.get("query_channel_major", False))
         if kv_spikes is not None or kv_projected is not None:
-            return self.attn(query=query if query_pos is None else query + query_pos, key=None, value=None,
+            q_spikes = None
+            if qcm and query_pos is not None and self.attn.fused_neurons_ok(("q",), query):
+                # query + query_pos only feeds the query neuron: add and neuron as one launch (ops.sum2_lif), the sum never written
+                q_spikes = self.attn.fire_with_pos(query, query_pos)[0]
+            elif query_pos is not None:
+                query = query + query_pos
+            return self.attn(query=query, key=None, value=None,
                              attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes,
-                             kv_projected=kv_projected, query_channel_major=qcm,
+                             kv_projected=kv_projected, query_channel_major=qcm, q_spikes=q_spikes,
                              residual_cm=kwargs.get("residual_cm") if qcm else None)[0]
         if key is None:
             key = query
@@ -427,9 +458,16 @@ class DetrTransformerDecoderLayer(nn.Module):
                              kv_spikes=kv_spikes, kv_projected=kv_projected, query_channel_major=True,
                              residual_cm=q_cm if fused else None)
         q_cm = ca if fused else q_cm + ca
-        qp = q_cm + query_pos_cm                       # query + query_pos == key + key_pos: formed once
-        q_cm = self.self_attn.attn(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True,
-                                   residual_cm=q_cm)[0]
+        sa = self.self_attn.attn
+        if sa.fused_neurons_ok(("q", "k", "v"), q_cm):
+            # query + query_pos == key + key_pos feeds the query and key neurons, the query itself the value neuron: the add and
+            # the three neurons as ONE launch (ops.sum2_lif: Q_IFNode(q + pos), Q_IFNode(q)); q and k share the first map
+            yk, yv = sa.fire_with_pos(q_cm, query_pos_cm)
+            q_cm = sa(query=q_cm, key=None, value=None, kv_spikes=(yk, yv), q_spikes=yk, query_channel_major=True,
+                      residual_cm=q_cm)[0]
+        else:
+            qp = q_cm + query_pos_cm                       # query + query_pos == key + key_pos: formed once
+            q_cm = sa(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True, residual_cm=q_cm)[0]
         q_tm = ops.transpose_last2(q_cm)
         out = self.ffn(q_tm, identity=q_tm)
         return out, (None if last else ops.transpose_last2(out))

@@ -83,6 +83,7 @@ class _Sum2LIF(torch.autograd.Function):
                                    int(bf16), _stream()), "s2f_sum2_lif_fwd")
         ctx.save_for_backward(mk, mv)
         ctx.D = D
+        ctx.tb = (TB // B, B)
         ctx.set_materialize_grads(False)
         if bf16:
             ctx.mark_non_differentiable(yk, yv)
@@ -96,15 +97,22 @@ class _Sum2LIF(torch.autograd.Function):
         mk, mv = ctx.saved_tensors
         if gk is None and gv is None:
             return (None,) * 7
-        gk = torch.zeros_like(gv) if gk is None else gk
-        gv = torch.zeros_like(gk) if gv is None else gv
-        gk, gv = gk.contiguous(), gv.contiguous()
-        gx = torch.empty_like(gk)
-        _time_next("lif_bwd", 12 * gk.numel())
-        check(lib.s2f_sum2_lif_bwd(_ptr(gk), _ptr(gv), _ptr(mk), _ptr(mv), _ptr(gx), gk.numel(), ctx.D, _stream()),
-              "s2f_sum2_lif_bwd")
+        # (either gradient may be missing -- a neuron whose spikes nobody differentiated: the kernel takes NULL for zero)
+        gk = None if gk is None else gk.contiguous()
+        gv = None if gv is None else gv.contiguous()
+        like = gk if gk is not None else gv
+        gx = torch.empty_like(like)
+        want_pos = ctx.needs_input_grad[2] and gk is not None
+        gxk = torch.empty_like(like) if want_pos else None          # STE_k(g_k) alone: its sum over the time steps is d/d(pos)
+        _time_next("lif_bwd", 12 * like.numel())
+        check(lib.s2f_sum2_lif_bwd_ex(_ptr(gk), _ptr(gv), _ptr(mk), _ptr(mv), _ptr(gx), _ptr(gxk), like.numel(), ctx.D, _stream()),
+              "s2f_sum2_lif_bwd_ex")
         ge = gx.sum((0, 2)) if ctx.needs_input_grad[1] else None
-        return gx, ge, None, None, None, None, None
+        gpos = None
+        if ctx.needs_input_grad[2]:
+            T, B = ctx.tb
+            gpos = gxk.view(T, B, *like.shape[1:]).sum(0) if want_pos else torch.zeros(B, *like.shape[1:], dtype=like.dtype, device=like.device)
+        return gx, ge, gpos, None, None, None, None
 
 
 def sum2_lif(x, e, pos, B, D=8, vth=1.0):

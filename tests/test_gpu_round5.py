@@ -406,3 +406,45 @@ def test_stateless_inference_fusions_run_and_match_the_unfused_path():
     rng = (b.max() - b.min()).item()
     assert (a - b).abs().max().item() <= 1e-4 * rng, ((a - b).abs().max().item(), rng)
     assert (a.argmax(1) == b.argmax(1)).float().mean().item() >= 0.999
+
+
+def test_decoder_layer_with_fused_query_neurons_is_the_add_and_neuron_form():
+    """head_layers.FUSED_QUERY_NEURONS: `query + query_pos` and the query (cross-attention) resp. query / key / value (self-attention)
+    neurons as one ops.sum2_lif launch.  One decoder layer on the channel-major query stream, 100 queries: outputs bit-identical to the
+    add + neuron form, gradients (query, the learnable position term, a projection weight) to fp32 round-off of their accumulation."""
+    import spike2former_amd as s2f
+    from spike2former_amd import head_layers, ops
+    from spike2former_amd.init_utils import seeded_init
+    T, B, C, Nq, L = 4, 2, 256, 100, 64
+    layer = seeded_init(head_layers.DetrTransformerDecoderLayer(
+        self_attn_cfg=dict(embed_dims=C, num_heads=8, batch_first=True), cross_attn_cfg=dict(embed_dims=C, num_heads=8, batch_first=True),
+        ffn_cfg=dict(embed_dims=C, feedforward_channels=512, num_fcs=2))).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    q0 = torch.randn(T, B, C, Nq, device="cuda", generator=g) * 2
+    pos0 = torch.randn(B, C, Nq, device="cuda", generator=g)
+    mem = torch.randn(T * B, C, L, device="cuda", generator=g) * 2
+    kpos = torch.randn(B, C, L, device="cuda", generator=g)
+    lvl = torch.randn(C, device="cuda", generator=g) * 0.1
+    wq = torch.randn(T, B, Nq, C, device="cuda", generator=g)
+    res = {}
+    was = head_layers.FUSED_QUERY_NEURONS
+    try:
+        for flag in (True, False):
+            head_layers.FUSED_QUERY_NEURONS = flag
+            s2f.reset_net(layer)                      # (also forgets the neurons' shared-launch memo of the previous pass)
+            for p in layer.parameters():
+                p.grad = None
+            q = q0.clone().requires_grad_(True)
+            pos = pos0.clone().requires_grad_(True)
+            yk, yv = ops.sum2_lif(mem, lvl, kpos, B, 8, 1.0)
+            out, _ = layer.forward_stream(q, pos, kv_spikes=(yk.view(T, B, C, L), yv.view(T, B, C, L)), last=True)
+            (out * wq).sum().backward()
+            res[flag] = (out.detach().clone(), q.grad.clone(), pos.grad.clone(), layer.self_attn.attn.q_conv[0].weight.grad.clone(),
+                         layer.cross_attn.attn.q_conv[0].weight.grad.clone())
+    finally:
+        head_layers.FUSED_QUERY_NEURONS = was
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        assert (x - y).abs().max().item() <= 2e-6 * max(y.abs().max().item(), 1e-6), (x - y).abs().max().item()
+    assert a[2].abs().max().item() > 0
