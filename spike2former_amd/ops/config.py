@@ -5,7 +5,7 @@ import os
 
 
 class Config:
-    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
     RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
 
     def __init__(self):
@@ -25,6 +25,8 @@ class Config:
         self.CONV3X3_IMPLICIT_MIN_PIXELS = int(os.environ.get("S2F_CONV3_MIN_PIXELS", 32 * 32))
         self.CONV3X3_DX_IMPLICIT = True
         self.CONV3X3_DX_MIN_PIXELS = 0
+        # 3x3 input gradients on the pipelined kernel: 0 never, 1 by the shape rule of ops/conv.py, 2 always (A/B switch)
+        self.CONV3X3_DX_PIPE = int(os.environ.get("S2F_CONV3_DX_PIPE", "1"))
         self.MASK_EINSUM_DW_GROUPED = os.environ.get("S2F_MASK_DW_GROUPED", "1") != "0"
         self.MASK_EINSUM_DE_MFMA = True
         self.MASK_FWD_PGEMM = os.environ.get("S2F_MASK_FWD_PGEMM", "1") != "0"          # folded mask contraction forward on the LDS-DMA pipeline

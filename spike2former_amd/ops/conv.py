@@ -228,7 +228,7 @@ class _ConvDense(torch.autograd.Function):
                 # measured (tools/probe_pgemm.py conv): the pipelined kernel wins for <= 64 output rows (narrow tiles: 442 vs 729 us
                 # on [32 <- 128] at 256 x 256) and for long contractions (>= 256 channels); the round-2 kernel keeps a 5-10 % edge
                 # on wide outputs over short contractions
-                if cfg.PGEMM_CONV and (C <= 64 or M >= 256):
+                if cfg.PGEMM_CONV and (cfg.CONV3X3_DX_PIPE == 2 or (cfg.CONV3X3_DX_PIPE == 1 and (C <= 64 or M >= 256))):
                     check(lib.s2f_pgemm_conv3x3_f32(_ptr(pack_weight_conv3(weight, transposed=True)), _ptr(gy), _ptr(gx), N, C, M, H,
                                                     W, 0, _stream()), "s2f_pgemm_conv3x3_f32")
                 else:
