@@ -171,14 +171,23 @@ def self_launch(args):
     torch or touched a GPU (nothing is re-exec'ed) -- relay its output (rank 0 prints the JSON line) and exit with its code."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    rc = 1
+    for attempt in range(3):
+        # a free port found by bind / close can be taken by somebody else before the launcher binds it again: the rendezvous then
+        # fails within seconds (nothing has been measured yet) and the launch is repeated on another port
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(p.stderr)
+        rc = p.returncode
+        if rc == 0 or "EADDRINUSE" not in p.stderr and "Address already in use" not in p.stderr:
+            break
+    return rc
 
 
 def main():

@@ -48,11 +48,13 @@ class Conv2d(nn.Conv2d):
     def forward(self, x, border=None):
         return self._conv(x, self.bias, border)
 
-    def forward_nobias(self, x):
-        """The convolution without its bias (the fused BatchNorm kernels add the bias on the fly)."""
-        return self._conv(x, None)
+    def forward_nobias(self, x, stats=None):
+        """The convolution without its bias (the fused BatchNorm kernels add the bias on the fly).  `stats`: whether the consumer is a
+        train-mode BatchNorm that wants the per-tile statistics out of the GEMM's epilogue (None: this module's own training flag;
+        fused.conv_bn_act passes the BatchNorm's, so that conv.train() + bn.eval() does not pay for partials nobody reads)."""
+        return self._conv(x, None, stats=stats)
 
-    def _conv(self, x, bias, border=None):
+    def _conv(self, x, bias, border=None, stats=None):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         if self.groups != 1:
@@ -66,7 +68,7 @@ class Conv2d(nn.Conv2d):
         N, C, H, W = x.shape
         M = self.out_channels
         kh, kw = self.kernel_size
-        stats = self.training and bias is None
+        stats = (self.training if stats is None else bool(stats)) and bias is None
         if kh == 1 and kw == 1 and self.stride == (1, 1) and self.padding == (0, 0):
             y = _gemm_nc(self.weight.view(M, C), x.reshape(N, C, H * W), bias, self.spike_input, stats)
             return ops.carry_stats(y, y.view(N, M, H, W))
@@ -84,11 +86,12 @@ class Conv1d(nn.Conv1d):
     def forward(self, x):
         return self._conv(x, self.bias)
 
-    def forward_nobias(self, x):
-        return self._conv(x, None)
+    def forward_nobias(self, x, stats=None):
+        return self._conv(x, None, stats=stats)
 
-    def _conv(self, x, bias):
+    def _conv(self, x, bias, stats=None):
         if x.device.type != "cuda":
             raise RuntimeError("spike2former_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
         assert self.kernel_size == (1,) and self.stride == (1,) and self.groups == 1, "only k=1 Conv1d is on the path"
-        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias, self.spike_input, self.training and bias is None)
+        return _gemm_nc(self.weight.view(self.out_channels, -1), x, bias, self.spike_input,
+                        (self.training if stats is None else bool(stats)) and bias is None)

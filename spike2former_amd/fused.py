@@ -173,7 +173,7 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
                 and _no_grad_needed(x, conv, bn, residual) and not (torch.is_grad_enabled() and scale.requires_grad)):
             bn = _scaled_eval_bn(bn, scale)
         else:
-            z = conv.forward_nobias(x)
+            z = conv.forward_nobias(x, stats=bool(bn.training or bn.running_mean is None))
             return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif, scale=scale)
     fire = next_lif if (next_lif is not None and lif is None) else lif
     if want_pre is None:
@@ -217,7 +217,7 @@ def conv_bn_act(conv, x, bn, residual=None, lif: Q_IFNode = None, want_pre=None,
     if not dense and not ((pure_conv or conv3) and eval_bn and EVAL_FUSION and ops.gemm_bn_lif_eval_ok(x, L)
                           and _no_grad_needed(x, conv, bn, residual)
                           and (fire is None or (ops.spikes_bf16_ok(fire.D) and not fire._forward_pre_hooks))):
-        z = conv.forward_nobias(x)
+        z = conv.forward_nobias(x, stats=bool(bn.training or bn.running_mean is None))
         return bn_act(z, conv.bias, bn, residual=residual, lif=lif, want_pre=want_pre, next_lif=next_lif)
     M = conv.out_channels
     v_in = None
