@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void pg_conv_kernel(const unsigned 
 bool nn_super_steps(int Kb, int64_t workgroups) {
   static const char* e = getenv("S2F_PG_NN_G");          // A/B switch: "1" keeps one step per barrier
   if (e && e[0] == '1') return false;
-  return (Kb & 1) == 0 && Kb >= 4 && workgroups <= 512;
+  static const char* mw = getenv("S2F_PG_G2_MAXWG");          // probe: the grid size up to which two steps share a barrier
+  return (Kb & 1) == 0 && Kb >= 4 && workgroups <= (mw ? atoll(mw) : 512);
 }
 
 int pick_cfg_nn(int M, int N, int K, int batch, int force) {
@@ -1544,8 +1545,8 @@ static int conv_launch(const char* who, const uint16_t* w_pack, const void* X, b
   static const char* small_env = getenv("S2F_PG_CONV_SMALL");
   const bool small_ok = !(small_env && small_env[0] == '0');
   if (cfg <= 0 && !force && small_ok && c == 4 && (int64_t)n_tiles * batch * ((M + 127) / 128) <= 256) c = 2;
-  const bool g2 = small_ok && !x_fp32 && (Kb & 1) == 0 && Kb >= 4 &&
-                  (int64_t)n_tiles * batch * ((M + (c == 4 || c == 1 ? 127 : c == 2 ? 63 : 31)) / (c == 4 || c == 1 ? 128 : c == 2 ? 64 : 32)) <= 512;
+  const bool g2 = small_ok && !x_fp32 &&
+                  nn_super_steps(Kb, (int64_t)n_tiles * batch * ((M + (c == 4 || c == 1 ? 127 : c == 2 ? 63 : 31)) / (c == 4 || c == 1 ? 128 : c == 2 ? 64 : 32)));
   const Conv3 geo{H, W, C};
 #define S2F_PGC(MI, NJ, WMW, WNW)                                                                                         \
   do {                                                                                                                   \
