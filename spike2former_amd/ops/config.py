@@ -13,7 +13,9 @@ class Config:
         self.GRAD_SINKS = None
         self.WGRAD_STREAM = None
         self.DEFER_DW = True
-        self.DEFER_DW_MAX_CONTRACTION = int(os.environ.get("S2F_DEFER_DW_MAX", "32768"))
+        # (round 5, with the pipelined grouped kernel: 131 072 -- the 128 x 128 maps' layers join the grouped launch -- 36.31 ms against
+        #  36.48 at 32 768 and 36.39-36.44 beyond, same box)
+        self.DEFER_DW_MAX_CONTRACTION = int(os.environ.get("S2F_DEFER_DW_MAX", "131072"))
         self.BRANCH_STREAMS = None
         self.LONG_STREAMS = None
         self.LONG_WHAT = ("lat", "mf", "kv")
