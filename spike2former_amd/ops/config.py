@@ -5,7 +5,7 @@ import os
 
 
 class Config:
-    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
     RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
 
     def __init__(self):
@@ -38,7 +38,10 @@ class Config:
         # deferred / grouped weight gradients on the LDS-DMA pipeline (csrc/dwp.hip) where the shape qualifies (L % 4 == 0, L >= 32)
         self.DW_PIPE = os.environ.get("S2F_DW_PIPE", "1") != "0"
         self.DW_PIPE_SINGLE = os.environ.get("S2F_DW_PIPE_SINGLE", "1") != "0"          # ... the long-contraction layers that launch on their own
-        self.DW_PIPE_CONV = os.environ.get("S2F_DW_PIPE_CONV", "1") != "0"          # ... and the implicit 3x3 weight gradients (W % 8 == 0)
+        self.DW_PIPE_CONV = os.environ.get("S2F_DW_PIPE_CONV", "1") != "0"
+        # the pipelined kernel's schedule (0: two halves in opposite phase, 1: symmetric; ragged jobs need 0) and workgroup count (0: one per CU)
+        self.DWP_SCHEDULE = int(os.environ.get("S2F_DWP_SCHEDULE", "0"))
+        self.DWP_WGS = int(os.environ.get("S2F_DWP_WGS", "0"))          # ... and the implicit 3x3 weight gradients (W % 8 == 0)
         self.SPIKE_GEMM_CHECK = False
         self.PGEMM = os.environ.get("S2F_PGEMM", "1") != "0"
         self.PGEMM_DX = os.environ.get("S2F_PGEMM_DX", "1") != "0"

@@ -258,7 +258,7 @@ class _ConvDense(torch.autograd.Function):
                     check(lib.s2f_shift1_bf16(_ptr(x), _ptr(xs), x.numel(), _stream()), "s2f_shift1_bf16")
                     gt.zero_()
                     arr = (ctypes.c_int64 * 9)(_ptr(gy), _ptr(x), _ptr(xs), _ptr(gt), N, M, C, H, W)
-                    check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, 0, 0, _stream()), "s2f_spike_conv3x3_dw_pipe")
+                    check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, cfg.DWP_SCHEDULE, cfg.DWP_WGS, _stream()), "s2f_spike_conv3x3_dw_pipe")
                 else:
                     fn = lib.s2f_spike_conv3x3_dw_bf16 if xb else lib.s2f_spike_conv3x3_dw
                     check(fn(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")

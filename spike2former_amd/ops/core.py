@@ -209,7 +209,7 @@ def wgrad_flush():
             _time_next("spike_gemm_dw", sum(4 * B * L * (K + M) for _, _, _, B, M, K, L in chunk),
                        sum(2 * B * M * L * K for _, _, _, B, M, K, L in chunk),
                        moved=sum(B * L * (2 * K + 4 * M) for _, _, _, B, M, K, L in chunk))
-            check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, len(chunk), 0, 0, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
+            check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, len(chunk), cfg.DWP_SCHEDULE, cfg.DWP_WGS, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
     for bkv, jobs in _DW_PENDING.items():
         while jobs:
             chunk, rest = jobs[:56], jobs[56:]

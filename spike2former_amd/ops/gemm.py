@@ -907,7 +907,7 @@ class _MaskEinsumFolded(torch.autograd.Function):
                         flat += [g[b].data_ptr(), S[t, b].data_ptr(), H[t, b].data_ptr(), 1, Q, C, HW]
                 arr = (ctypes.c_int64 * len(flat))(*flat)
                 if cfg.DW_PIPE and lib.s2f_spike_gemm_dw_pipe_ok(1, Q, C, HW):
-                    check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, T * B, 0, 0, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
+                    check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, T * B, cfg.DWP_SCHEDULE, cfg.DWP_WGS, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
                 else:
                     check(lib.s2f_spike_gemm_dw_grouped(arr, T * B, 64, _stream()), "s2f_spike_gemm_dw_grouped")
             else:
