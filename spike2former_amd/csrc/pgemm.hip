@@ -1242,8 +1242,10 @@ int pick_cfg_nn(int M, int N, int K, int batch, int force) {
   // (cfg 8 = the 64 x 128 tile on eight wavefronts of 32 x 32: 8.1 vs 8.6 us, 11.8 vs 12.6, 19.9 vs 20.5 on the 1 024-column shapes)
   // (round 4, tools/probe_small_n.py: the eight-wavefront tile also wins on the decoder's 100-token maps -- 31.0 vs 33.4 us on
   //  [256x2048], 6.4 vs 7.1 on [256x256], 8.4 vs 8.9 on [2048x256] -- so cfg 6 is left with the outputs of fewer than 64 rows)
-  static const char* t7e = getenv("S2F_PG_NN_T7");          // probe: the tile-count threshold of the 128 x 128 tile
-  const int64_t t7 = t7e ? atoll(t7e) : 256;
+  // (round 5, swept in the step: 512 instead of 256 -- a launch of 256 .. 511 large tiles is one to two per CU, where the 64 x 128 tile's
+  //  two workgroups per CU overlap each other's phases: C2 35.95 -> 35.85 ms, C3 -0.1, C5 82.10 -> 81.52 ms same-box; 768 .. 2 048 equal)
+  static const char* t7e = getenv("S2F_PG_NN_T7");          // A/B switch: the tile-count threshold of the 128 x 128 tile
+  const int64_t t7 = t7e ? atoll(t7e) : 512;
   return (M > 64 && tiles128 >= t7) ? 7 : ((N >= 128 || M >= 64) ? 8 : 6);
 }
 
