@@ -298,6 +298,10 @@ def main():
     eager_step()                                    # discovers which gradients arrive through a sink ...
     red.compact()                                   # ... and moves them behind the others: packing stays one batched copy
     optim = sched = None
+    if args.optimizer and args.overlap_allreduce:
+        # GraphedOverlapStep replays forward(k + 1) under all-reduce(k): no update can sit in between (one-step-stale data
+        # parallelism otherwise), and a line labelled "training iteration" must have run the optimiser
+        raise SystemExit("bench.py: --optimizer and --overlap-allreduce exclude each other (the overlapped step is benchmark-only)")
     if args.optimizer:
         # configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:137-167
         from spike2former_amd.train import FlatAdamW, LinearThenPoly

@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 22
+#define S2F_ABI_VERSION 23
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -74,6 +74,19 @@ int s2f_lif_fwd(const float* x, const float* v_in, void* y, float* v_out, uint64
 /* STE backward of one step:  gx = gv_out + (gy / D - gv_out * vth) * m   (gv_out? NULL == 0; dL/dv_in == gx). */
 int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth, int D,
                 void* stream);
+
+/* Leaky charge in front of the same firing rule -- LIFNode.neuronal_charge (neuron.py:803-814) under the fork's BaseNode.forward
+ * (:166-197: multi-level quantised firing, soft reset, y = s / D).  No Spike2Former module instantiates LIFNode; the
+ * entry points exist so that the neuron file's second node type has the same kernel-backed mirror (host: neuron.LIFNode).
+ *     decay_input != 0:  h = v + (x - v) / tau        (reference expression order, true fp32 division)
+ *     decay_input == 0:  h = v * (1 - 1/tau) + x      (factor formed in double, rounded to fp32 once, as Python's scalar multiply)
+ * then as s2f_lif_fwd.  v_in? NULL == membrane freshly reset (0.): h = x / tau resp. x.  tau > 1 (neuron.py:792).
+ * Backward: g_h = gv_out + (gy / D - gv_out * vth) * m;  decay_input: gx = g_h / tau, gv_in = g_h - g_h / tau;
+ * otherwise gx = g_h, gv_in = g_h * (1 - 1/tau).  gv_out? NULL == 0; gv_in? NULL == not wanted. */
+int s2f_lif_leaky_fwd(const float* x, const float* v_in, void* y, float* v_out, uint64_t* mask, uint64_t* stats, int64_t n, float vth,
+                      int D, float tau, int decay_input, int y_bf16, void* stream);
+int s2f_lif_leaky_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, float* gv_in, int64_t n, float vth, int D,
+                      float tau, int decay_input, void* stream);
 
 /* The decoder's value / key neurons on  a = x + e[c]  and  a + pos[b, c, l]  in one pass (x [TB, C, L] with tb = t*B + b,
  * e [C] = level_embed row, pos [B, C, L] = key positional encoding; mmdet/models/dense_heads/maskformer_head.py:535-540,
@@ -577,6 +590,17 @@ int s2f_adamw_prepare(const double* partials, int nparts, float max_norm, double
 int s2f_adamw_chunk_elems(void);
 int s2f_adamw_step(const int64_t* slots, const float* hyper, const int32_t* chunks, int nchunks, const float* g, float* m, float* v,
                    const float* state, double beta1, double beta2, float eps, void* stream);
+
+/* ---- general strided fp32 product on the vector ALUs (csrc/bmm.hip, round 6) -----------------------------------------------
+ * C[b][m][n] = sum_k A[b][m][k] B[b][k][n], every operand with explicit ELEMENT strides (a transposed or broadcast operand is a
+ * stride choice: *_sb = 0 shares one matrix over the batch); reduce_batch != 0: C[m][n] = sum_b sum_k ... (c_sb ignored) -- the
+ * weight-gradient form.  Ascending-k (then ascending-b) fp32 multiply-adds: bit-repeatable.  Any M, N, K >= 0, any alignment.
+ * Serves the shapes the matrix-core GEMM families do not take (rows that are no whole 16-byte groups, maps below one 128-column
+ * tile: the plumbing configuration C1's 4 x 4 .. 16 x 16 maps and 10-query rows) -- replaces torch.bmm (rocBLAS / hipBLASLt), i.e.
+ * the reference's nn.Conv2d / nn.Conv1d / nn.Linear and their autograd gradients on such shapes
+ * (mmseg/models/backbones/sdtv2.py:112-255; mmdet/models/layers/transformer/mmcv_spike/transformer.py:196-361, 710-784). */
+int s2f_bmm_f32(const float* a, int64_t a_sb, int64_t a_sm, int64_t a_sk, const float* b, int64_t b_sb, int64_t b_sk, int64_t b_sn,
+                float* c, int64_t c_sb, int64_t c_sm, int64_t c_sn, int B, int M, int N, int K, int reduce_batch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from .data_preprocessor import SegDataPreProcessor, SegDataSample  # noqa: F401
 from .firing import FiringRecorder  # noqa: F401
 from .loss import MaskFormerLoss, seg_to_instances  # noqa: F401
 from .maskformer_head import MaskFormerHead  # noqa: F401
-from .neuron import Q_IFNode, Quant, reset_net, set_keep_membrane  # noqa: F401
+from .neuron import LIFNode, Q_IFNode, Quant, reset_net, set_keep_membrane  # noqa: F401
 from .pixel_decoder import DCNTransformerEncoderPixelDecoder  # noqa: F401
 from .registry import HOOKS, MODELS, ConfigDict, register_upstream  # noqa: F401
 from . import reparam  # noqa: F401

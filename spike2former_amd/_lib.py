@@ -22,6 +22,8 @@ SIGNATURES = {
     "s2f_lif_mask_words": (_i64, [_i64]),
     "s2f_lif_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _i, _i, _p]),
     "s2f_lif_bwd": (_i, [_p, _p, _p, _p, _i64, _f, _i, _p]),
+    "s2f_lif_leaky_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _i, _f, _i, _i, _p]),
+    "s2f_lif_leaky_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _f, _i, _f, _i, _p]),
     "s2f_sum2_lif_fwd": (_i, [_p] * 7 + [_i64] * 4 + [_f, _i, _i, _p]),
     "s2f_sum2_lif_bwd": (_i, [_p] * 5 + [_i64, _i, _p]),
     "s2f_sum2_lif_bwd_ex": (_i, [_p] * 6 + [_i64, _i, _p]),
@@ -113,6 +115,7 @@ SIGNATURES = {
     "s2f_grad_sqnorm": (_i, [_p, _i64, _p, _p]),
     "s2f_adamw_prepare": (_i, [_p, _i, _f, ctypes.c_double, ctypes.c_double, _p, _p]),
     "s2f_adamw_chunk_elems": (_i, []),
+    "s2f_bmm_f32": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
     "s2f_adamw_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, ctypes.c_double, ctypes.c_double, _f, _p]),
 }
 

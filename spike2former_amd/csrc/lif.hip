@@ -396,6 +396,103 @@ __global__ __launch_bounds__(kBlock) void lif_seq_bwd_kernel(const float* __rest
   }
 }
 
+
+// ------------------------------------------------------------------ leaky charge (LIFNode.neuronal_charge, neuron.py:803-814)
+// No Spike2Former module instantiates LIFNode (Q_IFNode is a copy of IFNode), but the class is part of the
+// neuron file the path imports, with the fork's forward (multi-level quantised firing, soft reset, y = s / D; neuron.py:153, 197):
+//     decay_input:      h = v + (x - v) / tau          (the reference's expression order; true fp32 division)
+//     not decay_input:  h = v * (1 - 1/tau) + x        (the factor formed in double by Python, rounded to fp32 by the scalar multiply)
+// then s = rint(clamp(h, 0, D)), v' = h - s * vth, y = s / D as in lif_fwd_kernel.  Backward (autograd of the same expressions):
+//     g_h = gv' + (gy / D - gv' * vth) * m ;   decay_input: gx = g_h / tau, gv = g_h - g_h / tau ;   else: gx = g_h, gv = g_h * c.
+template <bool HAS_V, bool YB, bool DECAY_INPUT>
+__global__ __launch_bounds__(kBlock) void lif_leaky_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v_in,
+                                                               float* __restrict__ y, float* __restrict__ v_out,
+                                                               uint64_t* __restrict__ mask, unsigned long long* __restrict__ stats,
+                                                               int64_t n, float vth, float Df, float tau, float keep) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  uint32_t csum = 0, cnz = 0;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    Tile4 xv = load4(x, base, n, -1.0f);
+    Tile4 vv;
+    if (HAS_V) vv = load4(v_in, base, n, 0.0f);
+    Tile4 yv, vo;
+    bool inr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float h;
+      if (DECAY_INPUT)
+        h = HAS_V ? (vv.a[j] + (xv.a[j] - vv.a[j]) / tau) : (xv.a[j] / tau);          // v == 0.: 0. + (x - 0.) / tau
+      else
+        h = HAS_V ? (vv.a[j] * keep + xv.a[j]) : xv.a[j];                             // v == 0.: 0. * c + x
+      float s;
+      s2f_lif_update(h, Df, 1.0f, vth, s, yv.a[j], vo.a[j], inr[j]);
+      yv.a[j] = s / Df;
+      inr[j] = inr[j] && (base + j < n);
+      const uint32_t si = (uint32_t)s;
+      if (base + j < n) {
+        csum += si;
+        cnz += (si != 0);
+      }
+    }
+    if (YB)
+      store4_bf16(reinterpret_cast<unsigned short*>(y), base, n, yv);
+    else
+      store4(y, base, n, yv);
+    if (v_out != nullptr) store4(v_out, base, n, vo);
+    write_mask(mask, tile, lane, inr);
+  }
+  if (stats != nullptr) {
+    csum = wave_sum_u32(csum);
+    cnz = wave_sum_u32(cnz);
+    if (lane == 0) {
+      unsigned long long* slot = stats + 2 * (blockIdx.x % S2F_STAT_SLOTS);
+      if (csum) atomicAdd(&slot[0], (unsigned long long)csum);
+      if (cnz) atomicAdd(&slot[1], (unsigned long long)cnz);
+    }
+  }
+}
+
+template <bool HAS_GV, bool DECAY_INPUT>
+__global__ __launch_bounds__(kBlock) void lif_leaky_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gv,
+                                                               const uint64_t* __restrict__ mask, float* __restrict__ gx,
+                                                               float* __restrict__ gv_in, int64_t n, float vth, float Df, float tau,
+                                                               float keep) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + 255) >> 8;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * 256 + lane * 4;
+    Tile4 g = load4(gy, base, n, 0.0f);
+    Tile4 gvv;
+    if (HAS_GV) gvv = load4(gv, base, n, 0.0f);
+    Tile4 ox, ov;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool m = (mask[tile * 4 + j] >> lane) & 1ull;
+      const float through = g.a[j] / Df;
+      float gh;
+      if (HAS_GV)
+        gh = m ? (gvv.a[j] + (through - gvv.a[j] * vth)) : gvv.a[j];
+      else
+        gh = m ? through : 0.0f;
+      if (DECAY_INPUT) {
+        ox.a[j] = gh / tau;
+        ov.a[j] = gh - ox.a[j];
+      } else {
+        ox.a[j] = gh;
+        ov.a[j] = gh * keep;
+      }
+    }
+    store4(gx, base, n, ox);
+    if (gv_in != nullptr) store4(gv_in, base, n, ov);
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t tiles = (n + 255) >> 8;
   int64_t blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -453,6 +550,60 @@ extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t*
     S2F_LAUNCH(true, true, lif_bwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
                        (float)D);
   return s2f_check_launch("s2f_lif_bwd");
+}
+
+extern "C" int s2f_lif_leaky_fwd(const float* x, const float* v_in, void* y_out, float* v_out, uint64_t* mask, uint64_t* stats,
+                                 int64_t n, float vth, int D, float tau, int decay_input, int y_bf16, void* stream) {
+  float* y = reinterpret_cast<float*>(y_out);
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(x && y, S2F_EINVAL, "s2f_lif_leaky_fwd: null x/y");
+  S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_leaky_fwd: bad n=%lld or D=%d", (long long)n, D);
+  S2F_REQUIRE(tau > 1.0f, S2F_EINVAL, "s2f_lif_leaky_fwd: tau must exceed 1 (neuron.py:792), got %g", (double)tau);
+  S2F_REQUIRE(!y_bf16 || s2f_bf16_spikes_exact(D), S2F_EINVAL, "s2f_lif_leaky_fwd: bf16 spikes need D a power of two <= 128 (D=%d)", D);
+  S2F_REQUIRE(s2f_aligned16(x) && s2f_aligned16(y) && s2f_aligned16(v_in) && s2f_aligned16(v_out), S2F_EALIGN,
+              "s2f_lif_leaky_fwd: x/y/v must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  auto* st = reinterpret_cast<unsigned long long*>(stats);
+  const float keep = (float)(1.0 - 1.0 / (double)tau);          // Python forms 1. - 1. / tau in double; the scalar multiply rounds it to fp32
+#define S2F_LEAKY_GO(HV, YBV, DI)                                                                                                   \
+  S2F_LAUNCH(true, true, (lif_leaky_fwd_kernel<HV, YBV, DI>), dim3(grid_for(n)), dim3(kBlock), 0, s, x, v_in, y, v_out, mask, st, n, \
+             vth, (float)D, tau, keep)
+#define S2F_LEAKY_YB(HV, DI) \
+  do {                       \
+    if (y_bf16)              \
+      S2F_LEAKY_GO(HV, true, DI); \
+    else                     \
+      S2F_LEAKY_GO(HV, false, DI); \
+  } while (0)
+  if (v_in != nullptr) {
+    if (decay_input) S2F_LEAKY_YB(true, true); else S2F_LEAKY_YB(true, false);
+  } else {
+    if (decay_input) S2F_LEAKY_YB(false, true); else S2F_LEAKY_YB(false, false);
+  }
+#undef S2F_LEAKY_YB
+#undef S2F_LEAKY_GO
+  return s2f_check_launch("s2f_lif_leaky_fwd");
+}
+
+extern "C" int s2f_lif_leaky_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, float* gv_in, int64_t n,
+                                 float vth, int D, float tau, int decay_input, void* stream) {
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE(gy && mask && gx, S2F_EINVAL, "s2f_lif_leaky_bwd: null gy/mask/gx");
+  S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255 && tau > 1.0f, S2F_EINVAL, "s2f_lif_leaky_bwd: bad n, D or tau");
+  S2F_REQUIRE(s2f_aligned16(gy) && s2f_aligned16(gx) && s2f_aligned16(gv_out) && s2f_aligned16(gv_in), S2F_EALIGN,
+              "s2f_lif_leaky_bwd: gy/gx/gv must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const float keep = (float)(1.0 - 1.0 / (double)tau);
+#define S2F_LEAKY_BGO(HG, DI)                                                                                                    \
+  S2F_LAUNCH(true, true, (lif_leaky_bwd_kernel<HG, DI>), dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, gv_in, n, vth, \
+             (float)D, tau, keep)
+  if (gv_out != nullptr) {
+    if (decay_input) S2F_LEAKY_BGO(true, true); else S2F_LEAKY_BGO(true, false);
+  } else {
+    if (decay_input) S2F_LEAKY_BGO(false, true); else S2F_LEAKY_BGO(false, false);
+  }
+#undef S2F_LEAKY_BGO
+  return s2f_check_launch("s2f_lif_leaky_bwd");
 }
 
 extern "C" int s2f_sum2_lif_fwd(const float* x, const float* e, const float* pos, void* y_key_out, void* y_value_out,

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void adamw_prepare_kernel(const double* __rest
 constexpr int kChunk = 4096;          // elements per workgroup: 256 threads x 4 float4
 
 // slots  int64 [nslots][3] = {parameter pointer, offset of the slot in the flat buffers (elements), numel}
-// hyper  float [nslots][2] = {lr, weight_decay} of this iteration (the scheduler rewrites the table, not the kernel arguments)
+// hyper  float [nslots][2] = {lr, weight_decay} of this iteration (the scheduler rewrites the table, not the kernel arguments);
+//        lr < 0 marks a parameter WITHOUT a gradient: neither decayed nor moved, moments untouched (torch.optim.AdamW on grad None)
 // chunks int32 [nchunks][2] = {slot, first element inside the slot}
 __global__ __launch_bounds__(256) void adamw_step_kernel(const long long* __restrict__ slots, const float* __restrict__ hyper,
                                                          const int* __restrict__ chunks, const float* __restrict__ g,
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(const long long* __rest
   const long long off = slots[3 * slot + 1];
   const int numel = (int)slots[3 * slot + 2];
   const float lr = hyper[2 * slot], wd = hyper[2 * slot + 1];
+  if (lr < 0.f) return;          // "no gradient this iteration" (p.grad is None): torch.optim.AdamW skips such a parameter entirely
   const float clip = state[0], bc1 = state[2], bc2s = state[3];
   const float step_size = lr / bc1, decay = 1.f - lr * wd;
   const int end = min(numel, start + kChunk);

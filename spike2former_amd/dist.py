@@ -58,6 +58,7 @@ class FlatGradAllReduce:
         self.sinks = False
         self._zero = None
         self._n_dense = self._dense_elems = None
+        self.missing = []                      # see without_gradient(); refreshed by gather()
 
     @staticmethod
     def _slot(p):
@@ -122,6 +123,7 @@ class FlatGradAllReduce:
         """After backward: pack p.grad into the flat buffer (parameters without a gradient keep zeros)."""
         from . import ops
         ops.wgrad_flush()                      # deferred weight gradients (ops.DEFER_DW) go into their sinks now
+        self.missing = self.without_gradient()
         # No gradient tensor: with sinks the parameter's slice already holds the sum (or the zeros of `zero()`) and is left
         # alone -- the packing runs over the maximal runs of parameters that do have a tensor; without sinks it is a zero.
         self._need_zero()
@@ -136,19 +138,35 @@ class FlatGradAllReduce:
             return
         # not compacted, or a parameter changed sides since compact() (unused on this iteration: no tensor although it lies in the
         # dense region; a gradient tensor for a parameter placed in the sink region): one batched copy per run of gradient tensors.
-        # A slot without a tensor is left alone -- it holds the zeros of zero() or the sum a kernel added through the sink.
+        # A slot without a tensor is left alone -- it holds the zeros of zero() or the sum a kernel added through the sink.  A gradient
+        # TENSOR for a parameter of the sink region is ADDED to its slot: a kernel may have added a share through the sink in the same
+        # step (a weight used twice, once by a sinking kernel and once by an ATen op), and a copy would overwrite that share.
         run, start, off = [], 0, 0
-        for p in self.params:
-            if p.grad is not None:
+        for i, p in enumerate(self.params):
+            sunk = self._n_dense is not None and i >= self._n_dense
+            if p.grad is not None and not sunk:
                 if not run:
                     start = off
                 run += self._pieces([p])
-            elif run:
-                torch.cat(run, out=self.flat[start:off])
-                run = []
+            else:
+                if run:
+                    torch.cat(run, out=self.flat[start:off])
+                    run = []
+                if p.grad is not None:
+                    self.views[i].add_(p.grad)
             off += self._slot(p)
         if run:
             torch.cat(run, out=self.flat[start:off])
+
+    def without_gradient(self):
+        """Indices of the parameters that certainly received NO gradient in the step just packed: no tensor from autograd and no
+        sink a kernel could have added through (train.FlatAdamW skips them, as torch.optim.AdamW skips a parameter whose .grad is
+        None).  A parameter WITH a sink cannot be told apart from one whose gradient is all zeros without reading the device: it
+        is treated as having a (zero) gradient -- decayed and moment-updated, where torch would skip it if its layer never ran.
+        Every sunk weight of this path is used by every step, so the deviation is latent."""
+        from . import ops
+        sinks = ops.GRAD_SINKS if self.sinks else None
+        return [i for i, p in enumerate(self.params) if p.grad is None and not (sinks and p.data_ptr() in sinks)]
 
     def pack(self, grads):
         """Like gather(), from an explicit gradient list aligned with `self.params` (torch.autograd.grad output; None =

@@ -88,6 +88,11 @@ class GraphedStep:
         if self.optimizer is not None:
             self.optimizer.sync_hyper()
         self.graph.replay()
+        if self.optimizer is not None:
+            # the replayed update changed every weight after this replay's own re-split ran (at its START): the version-keyed
+            # conversion caches now hold the terms of the weights BEFORE the update under unchanged version counters -- an eager
+            # forward (validation, predict(), export) would multiply by one-step-stale bf16 terms.  Bump the versions.
+            self.optimizer.mark_updated()
         return self.static_loss
 
 
@@ -264,6 +269,8 @@ class GraphedHungarianStep:
         torch.cuda.current_stream().synchronize()
         self._match()
         self.graph_b.replay()
+        if self.optimizer is not None:
+            self.optimizer.mark_updated()          # see GraphedStep.__call__
         return self.losses
 
 

@@ -102,6 +102,57 @@ class Q_IFNode(nn.Module):
         return y
 
 
+class LIFNode(nn.Module):
+    """Leaky integrate-and-fire node (neuron.py:694-814) under this fork's `BaseNode.forward` (:166-197: quantised multi-level
+    firing, soft reset, output s / D) -- the neuron file's second node type.  No Spike2Former module instantiates it (SURVEY fact 3:
+    the live path's Q_IFNode has no leak); it is here so that a model which swaps the node type still runs on the HIP kernels
+    (csrc/lif.hip `lif_leaky_*`).  Charge: decay_input -> h = v + (x - v) / tau, otherwise h = v (1 - 1/tau) + x.
+    Deliberately NOT a subclass of Q_IFNode: the fused producer kernels (fused.bn_act(lif=...), prefire) implement the leak-free
+    charge and recognise their neuron by that type."""
+
+    def __init__(self, tau=2.0, decay_input=True, v_threshold=1.0, v_reset=0.0, surrogate_function=None, detach_reset=False,
+                 cupy_fp32_inference=False):
+        super().__init__()
+        assert isinstance(tau, float) and tau > 1.0                       # neuron.py:792
+        assert isinstance(v_threshold, float) and isinstance(detach_reset, bool)
+        if detach_reset:
+            raise NotImplementedError("detach_reset=True is not instantiated anywhere on the Spike2Former path")
+        if not (v_reset is None or v_reset == 0.0):
+            raise NotImplementedError("LIFNode: a non-zero v_reset changes the charge expression (neuron.py:808, 814); unused by the fork")
+        self.tau, self.decay_input = tau, decay_input
+        self.v_threshold, self.v_reset, self.detach_reset = v_threshold, v_reset, detach_reset
+        self.surrogate_function = surrogate_function if surrogate_function is not None else Quant()
+        self.D = getattr(self.surrogate_function, "D", 8)
+        self.v = 0.0
+        self.keep_membrane = True
+        self.stats = None
+        self.stats_elems = 0
+
+    def reset(self):
+        self.v = 0.0
+
+    def extra_repr(self):
+        return (f"v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}, D={self.D}, "
+                f"tau={self.tau}")
+
+    def _apply(self, fn, *a, **k):
+        if isinstance(self.v, torch.Tensor):
+            self.v = fn(self.v)
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x):
+        v_in = None if isinstance(self.v, float) else self.v
+        if self.stats is not None:
+            self.stats_elems += x.numel()
+        y, v_out = ops.lif_leaky(x, v_in, self.D, self.v_threshold, self.tau, self.decay_input, self.keep_membrane, self.stats)
+        self.v = v_out if self.keep_membrane else 0.0
+        return y
+
+    def fire(self, x, as_float=False):
+        y = self(x)
+        return y if as_float else ops.as_spikes(y)
+
+
 _PURE_MEMO = {}
 PURE_MEMO = True          # share the launch of pure neurons applied to the same tensor (57.3 vs 57.7 ms/step at C2)
 

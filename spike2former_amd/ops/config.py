@@ -5,7 +5,7 @@ import os
 
 
 class Config:
-    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "BLAS_AUTOTUNE", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
     RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
 
     def __init__(self):
@@ -19,7 +19,6 @@ class Config:
         self.BRANCH_STREAMS = None
         self.LONG_STREAMS = None
         self.LONG_WHAT = ("lat", "mf", "kv")
-        self.BLAS_AUTOTUNE = True
         self.SPIKES_BF16 = True
         self.SPIKE_GEMM_TERMS = 3
         self.SPIKE_GEMM_ENABLED = True
@@ -61,7 +60,7 @@ class Config:
 
     def snapshot(self):
         """the settings a captured hipGraph depends on (scalars only)"""
-        return {n: getattr(self, n) for n in self.FIELDS if n not in self.RUNTIME}
+        return {n: getattr(self, n) for n in self.FIELDS if n not in self.RUNTIME and n != "STRICT"}          # (STRICT selects no launch)
 
 
 cfg = Config()

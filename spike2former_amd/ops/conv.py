@@ -199,7 +199,7 @@ class _ConvDense(torch.autograd.Function):
                     check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d, transposed=True)), _ptr(cols), 0, _ptr(y), 0, N, cols.shape[1], M,
                                                L, 0.0, 0, _stream()), "s2f_pgemm_dx_f32")
             else:
-                y = bmm_tuned(w2d.unsqueeze(0).expand(N, -1, -1), cols)
+                y = bmm_small(w2d.unsqueeze(0).expand(N, -1, -1), cols)
             if bias is not None:
                 y = y + bias.view(1, -1, 1)
         ctx.save_for_backward(cols, weight)
@@ -238,7 +238,7 @@ class _ConvDense(torch.autograd.Function):
             elif M < C and stride == 1 and kh == kw and Ho == H and Wo == W:
                 wt = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(C, M * kh * kw)        # [C, M*k*k], tiny
                 gcols = im2col(gy.view(N, M, Ho, Wo), kh, kw, 1, kh - 1 - padding)
-                gx = bmm_tuned(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
+                gx = bmm_small(wt.unsqueeze(0).expand(N, -1, -1), gcols).view(N, C, H, W)
             else:
                 dcols = dx_gemm(w2d, gy)
                 gx = col2im(dcols, C, H, W, kh, kw, stride, padding)
@@ -292,8 +292,7 @@ class _ConvDense(torch.autograd.Function):
                 check(lib.s2f_gemm_dw_general(_ptr(gy), 0, _ptr(cols), 0, _ptr(gw if sink is None else sink), N, M, K, Ho * Wo,
                                               int(sink is not None), _stream()), "s2f_gemm_dw_general")
             else:
-                fallback("conv_dense dW", f"M={M} L={Ho * Wo}")
-                gw = torch.bmm(gy, cols.float().transpose(1, 2)).sum(0)
+                gw = bmm_small(gy, cols.float().transpose(1, 2), reduce_batch=True)          # ragged / tiny maps (csrc/bmm.hip)
             gw = gw.view_as(weight) if gw is not None else None
         if has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))

@@ -7,55 +7,33 @@ from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _str
 from .misc import transpose_last2
 
 
-# ------------------------------------------------------------------------------------------------ library GEMMs
-# The fp32 GEMMs of two general operands (dX of the 1x1 / k x k convolutions, non-spike 1x1 convolutions) are plain library
-# calls.  PyTorch-ROCm can route torch.bmm through rocBLAS or hipBLASLt; neither wins everywhere on gfx950 (tools/probe_blas.py,
-# us: [256x1024]@[8x1024x1024] 56 vs 41, [256x512]@[8x512x1024] 35 vs 23, [256x2048]@[8x2048x100] 32 vs 20, but
-# [256x256]@[8x256x1024] 12.6 vs 19.8, [360x360]@[8x360x1024] 23 vs 30), so the first call of every distinct (shape, stride)
-# times both and the faster one is used from then on.  Never tunes inside a graph capture (the warm-up steps have seen
-# every shape by then).
-_BLAS_CHOICE = {}
+# ------------------------------------------------------------------------------------------------ small / ragged products
+# The matrix-core GEMM families want rows of whole 16-byte groups (L % 4 == 0) and at least one 128-column tile.  Everything else --
+# the plumbing configuration's 4 x 4 .. 16 x 16 maps and 10-query rows, odd test shapes -- runs on
+# s2f_bmm_f32 (csrc/bmm.hip): a strided fp32 product on the vector ALUs, ascending-k fp32 multiply-adds, bit-repeatable.  Rounds 1-5
+# sent these to rocBLAS / hipBLASLt through torch.bmm (`bmm_tuned`, timed per shape): the last vendor GEMMs on the path, and exactly
+# the shapes of the fixtures the reference itself produced -- a parity test could not tell this build's arithmetic from the library's.
+# No vendor GEMM is called from this package any more.
 
 
-def _time_bmm(a, b, backend, reps=5):
-    torch.backends.cuda.preferred_blas_library(backend)
-    for _ in range(2):
-        torch.bmm(a, b)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        torch.bmm(a, b)
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1)
+def bmm_small(a, b, reduce_batch=False):
+    """a [B, M, K] @ b [B, K, N] -> [B, M, N] (or, `reduce_batch`, their sum over B -> [M, N]); fp32, any strides (expanded /
+    transposed views are read in place)."""
+    _need_cuda(a, b)
+    B, M, K = a.shape
+    N = b.shape[2]
+    if b.shape[0] != B or b.shape[1] != K:
+        raise RuntimeError(f"bmm_small: {tuple(a.shape)} @ {tuple(b.shape)}")
+    c = torch.empty((M, N) if reduce_batch else (B, M, N), dtype=torch.float32, device=a.device)
+    if c.numel() == 0:
+        return c
+    if K == 0 or B == 0:
+        return c.zero_()
+    check(lib.s2f_bmm_f32(_ptr(a), a.stride(0), a.stride(1), a.stride(2), _ptr(b), b.stride(0), b.stride(1), b.stride(2), _ptr(c),
+                          0 if reduce_batch else M * N, N, 1, B, M, N, K, int(bool(reduce_batch)), _stream()), "s2f_bmm_f32")
+    return c
 
 
-def bmm_tuned(a, b):
-    fallback("bmm_tuned", f"{tuple(a.shape)} @ {tuple(b.shape)}")
-    if not cfg.BLAS_AUTOTUNE or not a.is_cuda:
-        return torch.bmm(a, b)
-    key = (tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()))
-    choice = _BLAS_CHOICE.get(key)
-    prev = torch.backends.cuda.preferred_blas_library()
-    if choice is None:
-        if torch.cuda.is_current_stream_capturing():
-            return torch.bmm(a, b)
-        try:
-            with torch.no_grad():
-                t = {lib_: _time_bmm(a.detach(), b.detach(), lib_) for lib_ in ("cublas", "cublaslt")}
-            choice = min(t, key=t.get)
-        except RuntimeError:                      # a backend that cannot run this problem: stay with the default
-            choice = "default"
-        finally:
-            torch.backends.cuda.preferred_blas_library(prev)
-        _BLAS_CHOICE[key] = choice
-    if choice == "default":
-        return torch.bmm(a, b)
-    torch.backends.cuda.preferred_blas_library(choice)
-    try:
-        return torch.bmm(a, b)
-    finally:
-        torch.backends.cuda.preferred_blas_library(prev)
 
 
 class _DenseGemm(torch.autograd.Function):
@@ -104,7 +82,7 @@ class _DenseGemm(torch.autograd.Function):
         ctx.mark_non_differentiable(part)
         ctx.set_materialize_grads(False)
         wb = torch.stack(ws, 0).unsqueeze(0).expand(B, G, M, K).reshape(B * G, M, K) if G > 1 else ws[0].expand(B, M, K)
-        return bmm_tuned(wb, x.view(B * G, K, L)).view(B, G * M, L), part
+        return bmm_small(wb, x.view(B * G, K, L)).view(B, G * M, L), part
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
@@ -147,9 +125,9 @@ class _DenseGemm(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             wt = torch.stack(ws, 0).transpose(1, 2)
             wb = wt.unsqueeze(0).expand(B, G, K, M).reshape(B * G, K, M) if G > 1 else wt[0].expand(B, K, M)
-            gx = bmm_tuned(wb, gyv).view(B, G * K, L)
+            gx = bmm_small(wb, gyv).view(B, G * K, L)
         if any(ctx.needs_input_grad[2:]):
-            gw = bmm_tuned(gyv, x.view(B * G, K, L).transpose(1, 2)).view(B, G, M, K).sum(0)
+            gw = bmm_small(gyv, x.view(B * G, K, L).transpose(1, 2)).view(B, G, M, K).sum(0)
             gws = [gw[g] for g in range(G)]
         return (None, gx, *gws)
 
@@ -477,7 +455,8 @@ class _SpikeGemm(torch.autograd.Function):
                 _time_next("spike_gemm_dw", 4 * B * L * (K + M), 2 * B * M * L * K, moved=B * L * ((2 if xb else 4) * K + 4 * M))
                 side = _wgrad_stream(sink, gy, x)
                 st = side.cuda_stream if side is not None else _stream()
-                if xb and cfg.DW_PIPE and cfg.DW_PIPE_SINGLE and M >= 128 and K >= 128 and lib.s2f_spike_gemm_dw_pipe_ok(B, M, K, L):
+                if (xb and cfg.DW_PIPE and cfg.DW_PIPE_SINGLE and M >= 128 and K >= 128 and lib.s2f_spike_gemm_dw_pipe_ok(B, M, K, L)
+                        and gy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
                     # long contractions launch on their own: the LDS-DMA pipeline where its 128 x 256 tile is filled
                     check(lib.s2f_spike_gemm_dw_pipe(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, L,
                                                      int(sink is not None), 0, 0, st), "s2f_spike_gemm_dw_pipe")
@@ -488,8 +467,7 @@ class _SpikeGemm(torch.autograd.Function):
                     check(lib.s2f_spike_gemm_dw(_ptr(gy), _ptr(x), _ptr(gw if sink is None else sink), B, M, K, L,
                                                 int(sink is not None), 1, st), "s2f_spike_gemm_dw")
             else:
-                fallback("spike_gemm dW", f"M={M} L={L}")
-                gw = torch.bmm(gy, x.float().transpose(1, 2)).sum(0)
+                gw = bmm_small(gy, x.float().transpose(1, 2), reduce_batch=True)          # shapes the matrix-core kernels do not take
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = gy.sum((0, 2))
         return _grad_pair(ctx.has_tok, gx) + (gw, gb, None)
@@ -506,12 +484,7 @@ def dx_gemm(w2d, gy):
         check(lib.s2f_pgemm_dx_f32(_ptr(pack_weight(w2d)), _ptr(gy), 0, _ptr(gx), 0, B, M, K, N, 0.0, 0, _stream()),
               "s2f_pgemm_dx_f32")
         return gx
-    fallback("dx_gemm", f"N={N}")
-    if gy.shape[2] <= 128 and w2d.shape[0] <= 512 and w2d.shape[1] <= 512:
-        # rocBLAS picks a 40 us kernel for the batched [256x256]^T @ [256x100] of the decoder (tools/probe_small_dx.py);
-        # the same product through einsum's folding takes 12 us
-        return torch.einsum("mk,bml->bkl", w2d, gy)
-    return bmm_tuned(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)
+    return bmm_small(w2d.t().unsqueeze(0).expand(B, -1, -1), gy)          # N % 4 != 0 (10-query rows of the plumbing configuration)
 
 
 def gemm_bn_lif_eval_ok(x, N):
@@ -672,11 +645,10 @@ class _LinearTM(torch.autograd.Function):
 
 def _mm_tm(x2d, w_oc):
     """x2d [n, c] @ w_oc[o, c]^T -> [n, o] on s2f_gemm_dw_general (both operands contraction-contiguous; no contraction split:
-    repeats bit for bit); the library for c % 4 != 0."""
+    repeats bit for bit); ops.bmm_small for c % 4 != 0."""
     n, c = x2d.shape
     if not (cfg.LINEAR_TM and c % 4 == 0 and x2d.is_cuda and n > 0):
-        fallback("mm_tm", f"c={c}")
-        return torch.matmul(x2d, w_oc.t())
+        return bmm_small(x2d.unsqueeze(0), w_oc.t().unsqueeze(0))[0]
     y = torch.zeros(n, w_oc.shape[0], dtype=torch.float32, device=x2d.device)
     check(lib.s2f_gemm_dw_general(_ptr(x2d.contiguous()), 0, _ptr(w_oc.contiguous()), 0, _ptr(y), 1, n, w_oc.shape[0], c, 3, _stream()),
           "s2f_gemm_dw_general")
@@ -685,13 +657,13 @@ def _mm_tm(x2d, w_oc):
 
 def _mtm_tm(a2d, b2d, out=None):
     """a2d [n, o]^T @ b2d [n, c] -> [o, c]: the contraction runs over the rows of both -- the transposed packed-operand kernel with a2d
-    packed on the fly (s2f_pgemm_dx_f32, contraction split over gridDim.z); the library for c % 4 != 0.  `out`: a contiguous
+    packed on the fly (s2f_pgemm_dx_f32, contraction split over gridDim.z); ops.bmm_small for c % 4 != 0.  `out`: a contiguous
     [o, c] fp32 destination (16-byte aligned)."""
     n, o = a2d.shape
     c = b2d.shape[1]
     if not (cfg.LINEAR_TM and c % 4 == 0 and a2d.is_cuda and n > 0):
-        fallback("mtm_tm", f"c={c}")
-        return torch.matmul(a2d.t(), b2d) if out is None else torch.matmul(a2d.t(), b2d, out=out)
+        r = bmm_small(a2d.t().unsqueeze(0), b2d.unsqueeze(0))[0]
+        return r if out is None else out.copy_(r)
     ap = torch.empty(int(lib.s2f_pack_elems(n, o)), dtype=torch.int16, device=a2d.device)
     check(lib.s2f_pack_bf16x3(_ptr(a2d.contiguous()), _ptr(ap), n, o, 0, 0, _stream()), "s2f_pack_bf16x3")
     if out is None:
@@ -703,13 +675,36 @@ def _mtm_tm(a2d, b2d, out=None):
 
 
 
+class _LinearSmall(torch.autograd.Function):
+    """nn.Linear with a contraction length that is no multiple of 4 (none on the shipped configurations): the three products on
+    ops.bmm_small."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_cuda(x, w, b)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        y = bmm_small(x.unsqueeze(0), w.detach().t().unsqueeze(0))[0]
+        return y + b.detach() if b is not None else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = bmm_small(gy.unsqueeze(0), w.detach().unsqueeze(0))[0] if ctx.needs_input_grad[0] else None
+        gw = bmm_small(gy.t().unsqueeze(0), x.unsqueeze(0))[0] if ctx.needs_input_grad[1] else None
+        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
 def linear_tm(x, weight, bias=None):
-    """torch.nn.functional.linear(x, weight, bias) for x [..., c] fp32 on the GPU with c % 4 == 0 (else the library)."""
+    """torch.nn.functional.linear(x, weight, bias) for x [..., c] fp32 on the GPU: the token-major matrix-core products for
+    c % 4 == 0, ops.bmm_small otherwise."""
     c = x.shape[-1]
-    if not (cfg.LINEAR_TM and x.is_cuda and x.dtype == torch.float32 and c % 4 == 0 and x.numel() > 0):
-        fallback("linear_tm", f"c={c} dtype={x.dtype}")
+    if not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+        fallback("linear_tm", f"c={c} dtype={x.dtype} cuda={x.is_cuda}")
         return torch.nn.functional.linear(x, weight, bias)
-    return _LinearTM.apply(x.reshape(-1, c), weight, bias).view(*x.shape[:-1], weight.shape[0])
+    fn = _LinearTM if (cfg.LINEAR_TM and c % 4 == 0) else _LinearSmall
+    return fn.apply(x.reshape(-1, c), weight, bias).view(*x.shape[:-1], weight.shape[0])
 
 
 # ------------------------------------------------------------------------------------------------ mask einsum (SDME)
@@ -752,11 +747,9 @@ class _MaskEinsum(torch.autograd.Function):
                                      Q * HW, scale, B, Q, HW, T * C, (Q + 127) // 128 * 128, Kpad, _stream()),
                   "s2f_split_gemm")
         else:
-            fallback("mask_einsum", f"e_exact={bool(e_exact)} HW={HW}")
-            es = e * scale
-            out = torch.bmm(es[0], mf[0])
-            for t in range(1, T):
-                torch.baddbmm(out, es[t], mf[t], out=out)
+            # E not exact in bf16, or ragged rows: one strided product with the T slabs folded into the contraction
+            # (row (b, q) x column (t, c) against row (t, c) x column hw), ascending-k fp32 multiply-adds
+            out = bmm_small((e * scale).permute(1, 2, 0, 3).reshape(B, Q, T * C), mf.permute(1, 0, 2, 3).reshape(B, T * C, HW))
         ctx.save_for_backward(e, mf)
         ctx.scale, ctx.mfma = scale, mfma
         return out
@@ -778,9 +771,7 @@ class _MaskEinsum(torch.autograd.Function):
                         check(lib.s2f_spike_gemm_dw(_ptr(g[b]), _ptr(mf[t, b]), _ptr(ge[t, b]), 1, Q, C, HW, 1, 3, _stream()),
                               "s2f_spike_gemm_dw")
             else:
-                ge = torch.empty_like(e)
-                for t in range(T):
-                    torch.bmm(g, mf[t].transpose(1, 2), out=ge[t])
+                ge = torch.stack([bmm_small(g, mf[t].transpose(1, 2)) for t in range(T)], 0)
             ge.mul_(ctx.scale)
         if ctx.needs_input_grad[1]:
             gmf = torch.empty_like(mf)
@@ -794,7 +785,7 @@ class _MaskEinsum(torch.autograd.Function):
             else:
                 es = e * ctx.scale
                 for t in range(T):
-                    torch.bmm(es[t].transpose(1, 2), g, out=gmf[t])
+                    gmf[t].copy_(bmm_small(es[t].transpose(1, 2), g))
         return ge, gmf, None, None
 
 
@@ -887,10 +878,9 @@ class _MaskEinsumFolded(torch.autograd.Function):
                                              _ptr(G[t]), Co * HW, scale, B, Co, HW, Q, (Co + 127) // 128 * 128, Kp, _stream()),
                           "s2f_split_gemm")
             else:
-                fallback("mask_einsum_folded dS", f"e_exact={bool(e_exact)} HW={HW}")
                 es = e * scale
                 for t in range(T):
-                    torch.bmm(es[t].transpose(1, 2), g, out=G[t])
+                    G[t].copy_(bmm_small(es[t].transpose(1, 2), g))
             gs = dx_gemm(W, G.view(T * B, Co, HW))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             H = torch.empty(T, B, Q, C, dtype=torch.float32, device=dev)
@@ -906,7 +896,8 @@ class _MaskEinsumFolded(torch.autograd.Function):
                     for b in range(B):
                         flat += [g[b].data_ptr(), S[t, b].data_ptr(), H[t, b].data_ptr(), 1, Q, C, HW]
                 arr = (ctypes.c_int64 * len(flat))(*flat)
-                if cfg.DW_PIPE and lib.s2f_spike_gemm_dw_pipe_ok(1, Q, C, HW):
+                if (cfg.DW_PIPE and lib.s2f_spike_gemm_dw_pipe_ok(1, Q, C, HW) and g.data_ptr() % 16 == 0 and S.data_ptr() % 16 == 0
+                        and (Q * HW) % 4 == 0 and (C * HW) % 8 == 0 and (HW % 32 == 0 or cfg.DWP_SCHEDULE == 0)):
                     check(lib.s2f_spike_gemm_dw_pipe_grouped(arr, T * B, cfg.DWP_SCHEDULE, cfg.DWP_WGS, _stream()), "s2f_spike_gemm_dw_pipe_grouped")
                 else:
                     check(lib.s2f_spike_gemm_dw_grouped(arr, T * B, 64, _stream()), "s2f_spike_gemm_dw_grouped")
@@ -938,10 +929,15 @@ def class_mask_product(cls_score, mask_probs):
     the class scores packed on the fly) instead of the vendor GEMM the einsum lowers to.  No autograd (inference glue)."""
     B, Q, K = cls_score.shape
     h, w = mask_probs.shape[-2:]
-    if not (cfg.LINEAR_TM and cls_score.is_cuda and (h * w) % 4 == 0 and cls_score.dtype == torch.float32
-            and not (torch.is_grad_enabled() and (cls_score.requires_grad or mask_probs.requires_grad))):
-        fallback("class_mask_product", f"hw={h * w}")
+    if not cls_score.is_cuda:
+        # host tensors: the a13 callers are Python glue in the reference too and are pinned on the CPU bit for bit
+        # (tests/test_a13_callers.py); nothing of the hot path runs there
         return torch.einsum("bqc,bqhw->bchw", cls_score, mask_probs)
+    if torch.is_grad_enabled() and (cls_score.requires_grad or mask_probs.requires_grad):
+        fallback("class_mask_product", "autograd wanted through the inference post-processing")
+        return torch.einsum("bqc,bqhw->bchw", cls_score, mask_probs)
+    if not (cfg.LINEAR_TM and cls_score.is_cuda and (h * w) % 4 == 0 and cls_score.dtype == torch.float32):
+        return bmm_small(cls_score.transpose(1, 2), mask_probs.reshape(B, Q, h * w)).view(B, K, h, w)
     out = torch.empty(B, K, h, w, dtype=torch.float32, device=cls_score.device)          # every image's product lands in its slice
     for b in range(B):
         _mtm_tm(cls_score[b], mask_probs[b].reshape(Q, h * w), out=out[b].view(K, h * w))

@@ -55,6 +55,56 @@ class _LIF(torch.autograd.Function):
         return gx, (gx if ctx.has_v else None), None, None, None, None, None
 
 
+class _LIFLeaky(torch.autograd.Function):
+    """One LIFNode call: leaky charge (neuron.py:803-814) in front of the fork's quantised firing rule (s2f.h s2f_lif_leaky_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, v_in, D, vth, tau, decay_input, keep_v, stats):
+        _need_cuda(x, v_in)
+        x = x.contiguous()
+        if v_in is not None:
+            v_in = v_in.contiguous()
+        n = x.numel()
+        y = torch.empty_like(x)
+        v_out = torch.empty_like(x) if keep_v else None
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
+        check(lib.s2f_lif_leaky_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), n, vth, D, tau,
+                                    int(bool(decay_input)), 0, _stream()), "s2f_lif_leaky_fwd")
+        ctx.save_for_backward(mask)
+        ctx.cfg = (D, vth, tau, int(bool(decay_input)), v_in is not None)
+        ctx.set_materialize_grads(False)
+        if v_out is None:
+            v_out = x.new_empty(0)
+            ctx.mark_non_differentiable(v_out)
+        return y, v_out
+
+    @staticmethod
+    def backward(ctx, gy, gv):
+        (mask,) = ctx.saved_tensors
+        D, vth, tau, di, has_v = ctx.cfg
+        if gy is None and gv is None:
+            return (None,) * 8
+        if gy is None:
+            gy = torch.zeros_like(gv)
+        gy = gy.contiguous()
+        if gv is not None and gv.numel() != gy.numel():
+            gv = None
+        if gv is not None:
+            gv = gv.contiguous()
+        gx = torch.empty_like(gy)
+        gvi = torch.empty_like(gy) if has_v else None
+        check(lib.s2f_lif_leaky_bwd(_ptr(gy), _ptr(gv), _ptr(mask), _ptr(gx), _ptr(gvi), gy.numel(), vth, D, tau, di, _stream()),
+              "s2f_lif_leaky_bwd")
+        return gx, gvi, None, None, None, None, None, None
+
+
+def lif_leaky(x, v_in=None, D=8, vth=1.0, tau=2.0, decay_input=True, keep_v=True, stats=None):
+    """-> (y fp32, v_out or None): LIFNode (neuron.py:694-814) under the fork's BaseNode.forward"""
+    y, v = _LIFLeaky.apply(x, v_in, int(D), float(vth), float(tau), bool(decay_input), bool(keep_v), stats)
+    return y, (v if keep_v else None)
+
+
 def lif(x, v_in=None, D=8, vth=1.0, keep_v=True, stats=None, spikes=False):
     """-> (y, v_out or None); `spikes`: y as a Spikes pair (bf16 when cfg.SPIKES_BF16 and the size allows 8-byte stores)"""
     bf16 = bool(spikes) and spikes_bf16_ok(D) and x.numel() % 4 == 0 and x.numel() > 0

@@ -8,7 +8,7 @@ mmengine itself is not part of the reference tree (third-party, mmengine 0.8.4 p
 the `custom_keys` rule of DefaultOptimWrapperConstructor and the two schedulers are restated from its published behaviour;
 parity is pinned by the config's own values only.  The reference's optimiser is torch.optim.AdamW behind clip_grad_norm_;
 `OptimWrapper` runs exactly that (eager, one group per parameter), `FlatAdamW` is the same update as three HIP launches over
-the flat gradient buffer of the data-parallel step (csrc/optim.hip), pinned against the former in tests/test_gpu_optim.py."""
+the flat gradient buffer of the data-parallel step (csrc/optim.hip), pinned against the former in tests/test_gpu_round5.py."""
 import torch
 
 from .neuron import reset_net
@@ -93,9 +93,10 @@ class FlatAdamW:
         n = grad_buffer.flat.numel()
         self.partials = torch.zeros(int(lib.s2f_grad_sqnorm_parts(n)), dtype=torch.float64, device=dev)
         self.state = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.empty(len(self.params), 2, dtype=torch.float32)
+        self._hyper_host = [torch.empty(len(self.params), 2, dtype=torch.float32) for _ in range(2)]
         if dev.type == "cuda":
-            self._hyper_host = self._hyper_host.pin_memory()
+            self._hyper_host = [h.pin_memory() for h in self._hyper_host]
+        self._hyper_events, self._hyper_turn, self._hyper_last = [None, None], 0, None
         self.hyper = torch.zeros(len(self.params), 2, dtype=torch.float32, device=dev)
         self._build_tables()
 
@@ -114,10 +115,33 @@ class FlatAdamW:
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
 
     def sync_hyper(self):
-        """the per-parameter (lr, weight_decay) table of this iteration -> device (one small copy)"""
-        for i, g in enumerate(self.param_groups):
-            self._hyper_host[i, 0], self._hyper_host[i, 1] = g["lr"], g["weight_decay"]
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        """the per-parameter (lr, weight_decay) table of this iteration -> device.  Uploaded only when a scheduler changed a value,
+        from one of TWO pinned tables in turn: the copy reads host memory when it EXECUTES, and the host may run several replays
+        ahead -- the table a queued copy still has to read is never the one being rewritten (its event is waited for first)."""
+        import numpy as np
+        vals = np.array([(g["lr"], g["weight_decay"]) for g in self.param_groups], dtype=np.float32).reshape(-1, 2)
+        for i in getattr(self.red, "missing", ()):
+            vals[i, 0] = -1.0          # no gradient in the step just packed (p.grad is None): the kernel skips the parameter (optim.hip)
+        if self._hyper_last is not None and np.array_equal(vals, self._hyper_last):
+            return
+        self._hyper_turn ^= 1
+        host, ev = self._hyper_host[self._hyper_turn], self._hyper_events[self._hyper_turn]
+        if ev is not None:
+            ev.synchronize()
+        host.copy_(torch.from_numpy(vals))
+        self.hyper.copy_(host, non_blocking=True)
+        if self.hyper.is_cuda:
+            ev = torch.cuda.Event() if ev is None else ev
+            ev.record()
+            self._hyper_events[self._hyper_turn] = ev
+        self._hyper_last = vals
+
+    def mark_updated(self):
+        """The kernels wrote the parameters behind autograd's back: bump their version counters so that every cache keyed on a
+        weight's version (the bf16 term splits / packs of ops.gemm, the composed eval-mode BatchNorm affines of fused.py) re-converts
+        at its next eager use.  step() does it itself when it runs eagerly; a REPLAY of a hipGraph that holds the update cannot
+        (nothing of Python runs inside it): graph.GraphedStep / GraphedHungarianStep call this after every replay."""
+        torch.autograd.graph.increment_version(self.params)
 
     def step(self, sync_hyper=True):
         """Gradients: `grad_buffer.flat` as the step left it (packed, averaged).  -> the gradient norm (device scalar)."""
@@ -141,7 +165,7 @@ class FlatAdamW:
         # weight's version (the bf16 term splits / packs of ops.gemm) re-converts in eager use; a captured step re-converts inside
         # the graph anyway (ops.resplit_all)
         if not torch.cuda.is_current_stream_capturing():
-            torch.autograd.graph.increment_version(self.params)
+            self.mark_updated()
         return self.state[1]
 
     def rebuild(self):
@@ -156,6 +180,7 @@ class FlatAdamW:
         self.exp_avg, self.exp_avg_sq = m, v
         self.params = list(self.red.params)
         self.param_groups = [groups[id(p)] for p in self.params]
+        self._hyper_last = None                      # the table's row order changed with the buffer's layout: upload again
         self._build_tables()
 
     @property

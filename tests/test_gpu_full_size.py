@@ -17,20 +17,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-# the graph-mechanics tests of this file run on the shrunken C1_64 configuration (10 queries: rows of 10 elements do take library paths)
-_TINY_CONFIG_TESTS = ("test_tiny_", "test_graph_replay_follows_weight_updates", "test_overlap_step_is_the_single_graph_step",
-                      "test_hungarian_graph_step_is_the_eager_loss_step")
-
-
-@pytest.fixture(autouse=True)
-def _strict(request):
-    """S2F_STRICT for every full-size test: at the BASELINE configs no shape may leave the package's kernels for a vendor library
-    (rocBLAS / hipBLASLt through torch.bmm / matmul / einsum) or an ATen convolution -- ops.fallback raises."""
-    from spike2former_amd import ops
-    before = ops.STRICT
-    ops.STRICT = not request.node.name.startswith(_TINY_CONFIG_TESTS)
-    yield
-    ops.STRICT = before
+# Every GPU test runs under ops.STRICT (tests/conftest.py `_fallback_census`): no shape of any configuration -- BASELINE's C2-C5 or the
+# shrunken C1_64 of the graph-mechanics tests -- may leave the package's kernels for a vendor library or an ATen convolution.
 
 
 @pytest.fixture(scope="module")

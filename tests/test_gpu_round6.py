@@ -1,0 +1,119 @@
+"""Round 6: the kernels and host paths added this round, on the GPU, against the oracle / the reference's vectors / fp64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_leaky_node_kernels_vs_reference_vectors(golden):
+    """neuron.LIFNode on csrc/lif.hip `lif_leaky_*` against the reference's own LIFNode (tests/golden/lif_leaky_kat.npz): five
+    stateful calls, BPTT through the membrane chain -- spikes, final membrane and both gradients BIT-EXACT."""
+    import spike2former_amd as s2f
+    g = golden("lif_leaky_kat.npz")
+    for tag in "abcd":
+        for state in ("reset", "v0"):
+            k = f"{tag}_{state}"
+            tau, di = float(g[f"{k}_cfg"][0]), bool(g[f"{k}_cfg"][1])
+            xs = T(g[f"{k}_x"]).cuda().requires_grad_(True)
+            n = s2f.LIFNode(tau=tau, decay_input=di, surrogate_function=s2f.Quant())
+            v0 = None
+            if state == "v0":
+                v0 = T(g[f"{k}_v0"]).cuda().requires_grad_(True)
+                n.v = v0
+            ys = torch.stack([n(xs[t]) for t in range(xs.shape[0])])
+            ((ys * T(g[f"{k}_wy"]).cuda()).sum() + (n.v * T(g[f"{k}_wv"]).cuda()).sum()).backward()
+            assert torch.equal(ys.detach().cpu(), T(g[f"{k}_y"])), k
+            assert torch.equal(n.v.detach().cpu(), T(g[f"{k}_vT"])), k
+            assert torch.equal(xs.grad.cpu(), T(g[f"{k}_gx"])), k
+            if v0 is not None:
+                assert torch.equal(v0.grad.cpu(), T(g[f"{k}_gv0"])), k
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 257, 4099, 1 << 18])
+def test_leaky_node_kernels_vs_c_oracle_ragged(n):
+    """ragged sizes, both charge forms, D = 4 and 8, a stateful second call: bit-exact against oracle/lif_ref.c"""
+    from oracle import lif_ref
+    from spike2former_amd import ops
+    rng = np.random.default_rng(n + 5)
+    for di in (True, False):
+        for D, tau in ((8, 2.0), (4, 1.7)):
+            x = (rng.standard_normal((2, n)) * 3 + 1).astype(np.float32)
+            gy = rng.standard_normal((2, n)).astype(np.float32)
+            gv = rng.standard_normal(n).astype(np.float32)
+            wy, vT, _, inr = lif_ref.leaky_seq_fwd(x, None, D=D, tau=tau, decay_input=di)
+            wgx, _ = lif_ref.leaky_seq_bwd(gy, inr, gv, D=D, tau=tau, decay_input=di)
+            xs = T(x).cuda().requires_grad_(True)
+            y0, v = ops.lif_leaky(xs[0], None, D, 1.0, tau, di)
+            y1, v = ops.lif_leaky(xs[1], v, D, 1.0, tau, di)
+            if n:
+                ((y0 * T(gy[0]).cuda()).sum() + (y1 * T(gy[1]).cuda()).sum() + (v * T(gv).cuda()).sum()).backward()
+                assert torch.equal(xs.grad.cpu(), T(wgx)), (n, di, D)
+            assert torch.equal(torch.stack([y0, y1]).detach().cpu(), T(wy)) and torch.equal(v.detach().cpu(), T(vT)), (n, di, D)
+
+
+@pytest.mark.parametrize("B,M,N,K", [(1, 1, 1, 1), (3, 5, 7, 9), (2, 64, 64, 16), (2, 65, 130, 33), (8, 72, 10, 72), (4, 21, 16, 64),
+                                     (1, 300, 100, 257)])
+def test_bmm_small_vs_fp64(B, M, N, K):
+    """csrc/bmm.hip: any shape, strided / transposed / broadcast operands read in place, the batch-reduced (weight-gradient) form;
+    fp32 multiply-adds in ascending k: within 2e-6 of sum |a||b| of the fp64 product, and bit-repeatable."""
+    from spike2former_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + M)
+    a = torch.randn(B, M, K, generator=g).cuda()
+    b = torch.randn(B, K, N, generator=g).cuda()
+    want = torch.bmm(a.double().cpu(), b.double().cpu())
+    bound = 2e-6 * torch.bmm(a.abs().double().cpu(), b.abs().double().cpu()) + 1e-30
+    got = ops.bmm_small(a, b)
+    assert ((got.double().cpu() - want).abs() <= bound).all()
+    assert torch.equal(got, ops.bmm_small(a, b))
+    # transposed views and a broadcast (stride 0) operand
+    at = a.transpose(1, 2).contiguous().transpose(1, 2)
+    assert torch.equal(ops.bmm_small(at, b), got)
+    w = a[0]
+    gotw = ops.bmm_small(w.unsqueeze(0).expand(B, -1, -1), b)
+    wantw = torch.matmul(w.double().cpu(), b.double().cpu())
+    assert ((gotw.double().cpu() - wantw).abs() <= 2e-6 * torch.matmul(w.abs().double().cpu(), b.abs().double().cpu()) + 1e-30).all()
+    # batch-reduced
+    red = ops.bmm_small(a, b, reduce_batch=True)
+    assert ((red.double().cpu() - want.sum(0)).abs() <= bound.sum(0)).all()
+
+
+def test_no_vendor_gemm_on_the_plumbing_configuration():
+    """One train step of C1_64 (10-query rows, 4 x 4 .. 32 x 32 maps: every shape the matrix-core kernels refuse) under ops.STRICT:
+    no op may leave the package's kernels, and rocBLAS / hipBLASLt are never entered (torch.bmm / matmul / einsum are patched to
+    raise for the duration)."""
+    import spike2former_amd as s2f
+    from oracle import s2f_oracle as so
+    from spike2former_amd import ops
+    cfg = so.CONFIGS["C1_64"]
+    model = s2f.MODELS.build(s2f.model_cfg("C1_64"))
+    model.load_state_dict(so.make_params(cfg, requires_grad=False), strict=True)
+    model.cuda().train()
+    names = ("bmm", "matmul", "einsum", "mm", "baddbmm", "addmm")
+    saved = {k: getattr(torch, k) for k in names}
+    lin = torch.nn.functional.linear
+
+    def refuse(*a, **k):
+        raise AssertionError("a vendor GEMM entry point was called on the product path")
+    before, strict = dict(ops.FALLBACKS), ops.STRICT
+    try:
+        for k in names:
+            setattr(torch, k, refuse)
+        torch.nn.functional.linear = refuse
+        ops.STRICT = True
+        s2f.reset_net(model)
+        cls, masks = model(so.synthetic_image(cfg).cuda())
+        s2f.headline_loss(cls, masks).backward()
+        torch.cuda.synchronize()
+    finally:
+        for k, v in saved.items():
+            setattr(torch, k, v)
+        torch.nn.functional.linear = lin
+        ops.STRICT = strict
+    assert dict(ops.FALLBACKS) == before
+    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
+    assert len(grads) > 500 and all(torch.isfinite(g).all() for g in grads)

@@ -56,6 +56,26 @@ def test_lif_gradient_kats(golden):
     assert np.array_equal(gx, g["seq_gx"]) and np.array_equal(gv0, g["seq_gv0"])
 
 
+def test_leaky_node_c_restatement_vs_reference_vectors(golden):
+    """LIFNode (neuron.py:694-814) under the fork's forward: the C restatement against the reference's own outputs, bit for bit --
+    both charge forms, tau = 2 (exact reciprocal) and 3 (a rounded division), from a reset membrane and from a given one."""
+    g = golden("lif_leaky_kat.npz")
+    for tag in "abcd":
+        for state in ("reset", "v0"):
+            k = f"{tag}_{state}"
+            tau, di = float(g[f"{k}_cfg"][0]), bool(g[f"{k}_cfg"][1])
+            v0 = g[f"{k}_v0"] if state == "v0" else None
+            y, vT, c, inr = lif_ref.leaky_seq_fwd(g[f"{k}_x"], v0, tau=tau, decay_input=di)
+            assert np.array_equal(y, g[f"{k}_y"]) and np.array_equal(vT, g[f"{k}_vT"]), k
+            gx, gv0 = lif_ref.leaky_seq_bwd(g[f"{k}_wy"], inr, g[f"{k}_wv"], tau=tau, decay_input=di)
+            assert np.array_equal(gx, g[f"{k}_gx"]), k
+            if v0 is not None:
+                assert np.array_equal(gv0, g[f"{k}_gv0"]), k
+    # the leak is real: the same input through the leak-free node gives other spikes
+    y_if = lif_ref.seq_fwd(g["a_reset_x"])[0]
+    assert not np.array_equal(y_if, g["a_reset_y"])
+
+
 def test_lif_empty_and_ragged():
     c, v = so.lif_seq_numpy(np.zeros((3, 0), np.float32))
     assert c.shape == (3, 0) and v.shape == (0,)

@@ -1,6 +1,6 @@
 """Every GEMM-shaped launch of one eager C2 step (forward + backward), by entry point and shape, with its measured duration:
 our kernels through the C ABI's own launch timing (s2f_time_next_call), library GEMMs (torch.bmm / einsum behind
-ops.bmm_tuned / ops.dx_gemm) between two stream events.   python tools/gemm_census.py [workload] > gpurun_out/census.txt"""
+ops.bmm_small / ops.dx_gemm) between two stream events.   python tools/gemm_census.py [workload] > gpurun_out/census.txt"""
 import collections
 import ctypes
 import os
@@ -93,17 +93,17 @@ def torch_timed(kind, shape, flops, fn):
     return out
 
 
-_bmm = ops.bmm_tuned
+_bmm = ops.bmm_small
 
 
-def bmm_tuned(a, b):
+def bmm_small(a, b):
     Bn, M, K = a.shape
     N = b.shape[2]
     return torch_timed("lib bmm", f"B{Bn} M{M} K{K} N{N} a{tuple(a.stride())} b{tuple(b.stride())}", 2 * Bn * M * N * K,
                        lambda: _bmm(a, b))
 
 
-ops.bmm_tuned = ops.gemm.bmm_tuned = ops.conv.bmm_tuned = bmm_tuned
+ops.bmm_small = ops.gemm.bmm_small = ops.conv.bmm_small = bmm_small
 _einsum = torch.einsum
 
 

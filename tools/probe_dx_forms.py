@@ -21,9 +21,9 @@ shapes = [(8, 256, 256, 1024), (8, 512, 256, 1024), (8, 256, 512, 1024), (8, 102
           (8, 1440, 360, 1024), (8, 360, 1440, 1024), (8, 256, 256, 4096), (8, 256, 256, 16384), (8, 256, 128, 4096), (8, 512, 128, 4096), (8, 128, 512, 4096)]
 for (B, M, K, L) in shapes:
     w = torch.randn(M, K, device="cuda"); gy = torch.randn(B, M, L, device="cuda")
-    t_view = graphed(lambda: ops.bmm_tuned(w.t().unsqueeze(0).expand(B, -1, -1), gy))
+    t_view = graphed(lambda: torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gy))
     wt = w.t().contiguous()
-    t_mat = graphed(lambda: ops.bmm_tuned(wt.unsqueeze(0).expand(B, -1, -1), gy))
+    t_mat = graphed(lambda: torch.bmm(wt.unsqueeze(0).expand(B, -1, -1), gy))
     asp, Rpad, Kpad = ops._split_rows(wt, 128)           # A = W^T [K x M]
     y = torch.empty(B, K, L, device="cuda")
     Mp = (K + 127) // 128 * 128
