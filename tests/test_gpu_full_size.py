@@ -1146,3 +1146,21 @@ def test_c5_size_dcn_layer_forward_backward_vs_oracle():
     rows = _other_config_stage_rows("C5", 1, 50, 84, [
         ("decode_head.pixel_decoder.encoder.layers.0", "_enc_layer", (4, 1, 50, 84, 256))], 400)
     _assert_stage_rows(rows, 8)
+
+
+@pytest.mark.timeout(1800)
+def test_c2_stages_at_the_bench_batch_forward_backward_vs_oracle():
+    """C2 at the BENCH's own per-GPU batch (B = 2; the other C2 parity tests of this file run the oracle at B = 1).  B changes the
+    per-channel row length that selects the BatchNorm kernel form -- at the 32 x 32 stage T B H W = 8 192 elements per channel, exactly
+    the single-pass limit (B = 1: 4 096) -- and the GEMM column count (8 x 1 024).  One stage of each kind that lives on that map,
+    forward + backward against the oracle's autograd with the comparison re-seeded at every neuron (`_stage_forced`):
+    `downsample4` (3 x 3 stride 1, 256 -> 360: implicit 3 x 3 + BatchNorm over 8 192-element rows), `block3.2` and `block4.0`
+    (RepConv q | k | v chains, attention over 1 024 tokens, the MLP; 256 and 360 channels), and a pixel-decoder encoder layer
+    (SepConv_Spike + DCNv3 + MS_MLP on [4, 2, 32, 32, 256]).  Reference: configs/Spike2Former/SDTv2_maskformer_DCNpixelDecoder_ade20k.py:23-93."""
+    rows = _other_config_stage_rows("C2", 2, 32, 32, [
+        ("backbone.downsample4", "run_backbone_stage", (4, 2, 256, 32, 32)),
+        ("backbone.block3.2", "_block", (4, 2, 256, 32, 32)),
+        ("backbone.block4.0", "_block", (4, 2, 360, 32, 32)),
+        ("decode_head.pixel_decoder.encoder.layers.0", "_enc_layer", (4, 2, 32, 32, 256))], 600)
+    _assert_stage_rows(rows, 1)
+    assert rows["backbone.block3.2"]["neurons"] >= 7 and rows["decode_head.pixel_decoder.encoder.layers.0"]["neurons"] >= 8

@@ -5,8 +5,10 @@ through ATen-CPU in the reference: results agree to fp32 round-off (~1e-6 relati
 turns a round-off difference into a one-level (1/8) flip when its input sits within that distance of k + 0.5
 (SURVEY section 7 "hard parts").  So: pre-neuron quantities are compared with rtol 1e-4; spike maps are compared by the
 fraction of elements that differ (<= 2e-3) and every difference must be exactly one level; the firing table (means of
-counts) within 2e-3 absolute; final logits / gradients within 2e-2 of their max (flips propagate through the tiny
-model's few hundred spatial positions)."""
+counts) within 2e-3 absolute; final logits / gradients within 2e-2 / 5e-2 of their max (flips propagate through the tiny
+model's few hundred spatial positions) -- but ONLY for a step in which a neuron did flip: every comparison below first checks the
+exact per-neuron census and holds a flip-free step to 1e-5 on the outputs and to 10x the measured reference-vs-oracle gap on the
+gradients (see the comment above TIGHT_OUT)."""
 import numpy as np
 import pytest
 import torch
@@ -40,10 +42,12 @@ def rel(a, b):
 # round-off of 0 or 8).  Per neuron the exact integer census {sum of spike counts, non-zero counts, elements in range} is compared
 # with the reference's (tests/golden/e2e_C1_64.npz `census`, written by oracle/gen_golden.py from the reference's own hooks) or the
 # oracle's; when EVERY neuron agrees, the logits must agree to fp32 round-off (1e-5).  Gradients: this configuration (B = 1,
-# train-mode BatchNorm over a few hundred positions) is ill-conditioned -- the generator measures 2e-3 between the reference's and
-# the oracle's gradients on BIT-IDENTICAL forwards (oracle/gen_golden.py gen_e2e `worst`), so 1e-2 of a tensor's scale is what a
-# flip-free step is held to, 5e-2 one with a flip.
-TIGHT_OUT, TIGHT_GRAD, LOOSE_OUT, LOOSE_GRAD = 1e-5, 1e-2, 2e-2, 5e-2
+# train-mode BatchNorm over a few hundred positions) is ill-conditioned; the generator MEASURES the gap between the reference's and
+# the oracle's gradients on bit-identical forwards and stores it (e2e_C1_64.npz `grad_gap_ref_vs_oracle` = 1.5e-4 in the metric
+# max|d| / (max|g| + 5e-3 gradient scale); per block: blocks_C1_64.npz `<tag>_gap_ref_vs_oracle`): a flip-free step is held to 10x
+# the measured figure (floor 1e-5 where the two agreed exactly); the loose bounds apply ONLY to a step in which a neuron flipped.
+TIGHT_OUT, LOOSE_OUT, LOOSE_GRAD = 1e-5, 2e-2, 5e-2
+TIGHT_GRAD_LIVE = 2e-3          # against the LIVE oracle (no stored measurement): 10x the largest gap the generator has measured
 
 
 def spike_census(s2f, model, fwd):
@@ -94,17 +98,18 @@ def test_end_to_end_train_step_vs_reference(env, golden):
     want = {str(n): tuple(int(v) for v in c) for n, c in zip(g["lif_names"], g["census"])}
     assert set(census) == set(want)
     flipped = sorted(n for n in want if census[n] != want[n])
-    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD)
+    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, 10.0 * float(g["grad_gap_ref_vs_oracle"]))
     assert rel(cls.cpu(), torch.from_numpy(g["cls"])) <= tol_out, flipped
     assert rel(masks.cpu(), torch.from_numpy(g["masks"])) <= tol_out, flipped
     grads = dict(model.named_parameters())
-    gscale = g["grad_absmax"].max()
+    gscale = float(g["grad_scale"])
     for i, k in enumerate(g["sel_keys"]):
         ref = torch.from_numpy(g[f"sel_grad_{i}"])
         mine = grads[str(k)].grad
         mine = torch.zeros_like(ref) if mine is None else mine.cpu()      # conv bias under train-mode BN: exactly zero
         err = (mine - ref).abs().max().item()
-        assert err <= tol_grad * ref.abs().max().item() + 1e-5 * gscale, (k, err, ref.abs().max().item(), flipped)
+        # the generator's metric (oracle/gen_golden.py gen_e2e): max|d| / (max|g| + 5e-3 * gradient scale)
+        assert err <= tol_grad * (ref.abs().max().item() + 5e-3 * gscale), (k, err, ref.abs().max().item(), flipped)
     sd = model.state_dict()
     for k, ssum in zip(g["stat_keys"], g["stat_sum"]):
         assert abs(sd[str(k)].double().sum().item() - ssum) <= 1e-3 * max(1.0, abs(ssum)), k
@@ -119,15 +124,20 @@ def test_stateful_inference_firing_table_vs_reference(env, golden):
     s2f.reset_net(model)
     s2f.set_keep_membrane(model, True)
     names = list(g["lif_names"])
+    gaps = []
     with torch.no_grad(), s2f.FiringRecorder(model) as rec:
         for i, seed in enumerate(g["seeds"]):
             cls, masks = model(so.synthetic_image(cfg, seed=int(seed)).cuda())
             before = dict(rec.table)
             rec.collect()
             call = np.array([rec.table[n] - before.get(n, 0.0) for n in names])
-            assert np.abs(call - g["firing"][i]).max() <= 2e-3, f"call {i}"
-    assert rel(cls.cpu(), torch.from_numpy(g["cls_last"])) <= 2e-2
-    assert rel(masks.cpu(), torch.from_numpy(g["masks_last"])) <= 2e-2
+            gaps.append(np.abs(call - g["firing"][i]).max())
+            assert gaps[-1] <= 2e-3, f"call {i}"
+    # one flipped spike moves a neuron's rate by >= 1 / (its element count) >= 1e-5 here; rates that agree to 2e-6 in all three calls
+    # mean no neuron flipped in any of them, and then the last call's logits must agree to fp32 round-off
+    tol = 1e-5 if max(gaps) <= 2e-6 else LOOSE_OUT
+    assert rel(cls.cpu(), torch.from_numpy(g["cls_last"])) <= tol, gaps
+    assert rel(masks.cpu(), torch.from_numpy(g["masks_last"])) <= tol, gaps
     # without the carried membrane the table is a different one -> the state is really used
     s2f.reset_net(model)
     with torch.no_grad(), s2f.FiringRecorder(model) as rec2:
@@ -152,11 +162,19 @@ def test_blocks_vs_reference(env, golden):
     for tag, fn in cases.items():
         s2f.reset_net(model)
         xs = [torch.from_numpy(g[f"{tag}_x{i}"]).cuda().requires_grad_(True) for i in range(2) if f"{tag}_x{i}" in g.files]
-        y = fn(*xs)
+        y, census = spike_census(s2f, model, lambda: fn(*xs))
         y.backward(torch.from_numpy(g[f"{tag}_gy"]).cuda())
-        assert rel(y.detach().cpu(), torch.from_numpy(g[f"{tag}_y"])) <= 2e-2, tag
+        # the census rule per block: the reference's own neurons of this case (name, spike sum, non-zero count, in-range count; written
+        # by the generator's hooks in execution order) against this build's; flip-free => output 1e-5, input gradients 10x the gap the
+        # generator measured between reference and oracle on this case (floor 1e-5)
+        want = {str(n): tuple(int(v) for v in c) for n, c in zip(g[f"{tag}_census_names"], g[f"{tag}_census"])}
+        assert set(census) == set(want), (tag, set(census) ^ set(want))
+        flipped = sorted(n for n in want if census[n] != want[n])
+        gap_y, gap_g = (float(v) for v in g[f"{tag}_gap_ref_vs_oracle"])
+        tol_y, tol_g = (LOOSE_OUT, LOOSE_GRAD) if flipped else (max(TIGHT_OUT, 10 * gap_y), max(1e-5, 10 * gap_g))
+        assert rel(y.detach().cpu(), torch.from_numpy(g[f"{tag}_y"])) <= tol_y, (tag, flipped)
         for i, x in enumerate(xs):
-            assert rel(x.grad.cpu(), torch.from_numpy(g[f"{tag}_gx{i}"])) <= 5e-2, (tag, i)
+            assert rel(x.grad.cpu(), torch.from_numpy(g[f"{tag}_gx{i}"])) <= tol_g, (tag, i, flipped)
     pe = hd.decoder_pe(torch.zeros(2, 6, 5, dtype=torch.bool, device="cuda"))
     assert torch.allclose(pe.cpu(), torch.from_numpy(g["pos_embed_2x6x5"]), atol=2e-6)
 
@@ -180,14 +198,14 @@ def test_train_step_vs_oracle_on_fresh_input(env):
     s2f.headline_loss(cls, masks).backward()
     assert set(got) == set(want), set(got) ^ set(want)
     flipped = sorted(n for n in got if got[n] != want[n])
-    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD)
+    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD_LIVE)
     assert rel(cls.detach().cpu(), ocls.detach()) <= tol_out and rel(masks.detach().cpu(), omasks.detach()) <= tol_out, flipped
     gscale = max(v.grad.abs().max().item() for v in st.values() if v.grad is not None)
     worst = 0.0
     for k, p in model.named_parameters():
         ref = st[k].grad
         mine = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
-        worst = max(worst, (mine - ref).abs().max().item() / (ref.abs().max().item() + 1e-3 * gscale))
+        worst = max(worst, (mine - ref).abs().max().item() / (ref.abs().max().item() + 5e-3 * gscale))          # the generator's metric
     assert worst <= tol_grad, (worst, flipped)
 
 
@@ -394,8 +412,8 @@ def test_gradient_sinks_and_deferred_weight_gradients_equal_autograd(env):
 
 def test_c1_plumbing_config_at_its_own_size_vs_oracle():
     """BASELINE configs[0] as written: ONE 128x128 tile, T = 1, the tiny widths, 20 classes -- forward + backward against the
-    oracle on the host (the committed fixtures hold its 64x64 / T = 2 form): logits within 2e-2 of their maximum, firing
-    table (270-row order) within 2e-3, a mask-embedding gradient within 5e-2."""
+    oracle on the host (the committed fixtures hold its 64x64 / T = 2 form), judged by the per-neuron census rule: flip-free => logits
+    1e-5, firing table exact, the mask-embedding gradient 2e-3 in the generator's metric."""
     import spike2former_amd as s2f
     from oracle import s2f_oracle as so
     cfg = so.CONFIGS["C1"]
@@ -407,21 +425,32 @@ def test_c1_plumbing_config_at_its_own_size_vs_oracle():
     assert img.shape == (1, 3, 128, 128) and cfg.T == 1
     s2f.reset_net(model)
     with s2f.FiringRecorder(model) as rec:
-        cls, masks = model(img.cuda())
+        (cls, masks), got = spike_census(s2f, model, lambda: model(img.cuda()))
         rec.collect()
     s2f.headline_loss(cls, masks).backward()
     net = so.OracleNet(st, cfg, training=True)
+    want, inr = {}, {}
+    net.tap = lambda n, y: want.__setitem__(n, (int((y.detach() * 8).round().sum().item()), int((y.detach() != 0).sum().item())))
+    net.tap_in = lambda n, h: inr.__setitem__(n, int(((h >= 0) & (h <= 8)).sum().item()))
     ocls, omasks = net.forward(img)
+    net.tap = net.tap_in = None
+    want = {n: v + (inr[n],) for n, v in want.items()}
     so.headline_loss(ocls, omasks).backward()
     assert cls.shape == ocls.shape and masks.shape == omasks.shape
-    assert rel(cls.detach().cpu(), ocls.detach()) <= 2e-2 and rel(masks.detach().cpu(), omasks.detach()) <= 2e-2
+    # the census rule (see the top of this file): no neuron flipped => logits to fp32 round-off, the gradient to 10x the generator's
+    # largest measured reference-vs-oracle gap; the loose bounds explain a step WITH a flip only
+    assert set(got) == set(want), set(got) ^ set(want)
+    flipped = sorted(n for n in got if got[n] != want[n])
+    tol_out, tol_grad = (LOOSE_OUT, LOOSE_GRAD) if flipped else (TIGHT_OUT, TIGHT_GRAD_LIVE)
+    assert rel(cls.detach().cpu(), ocls.detach()) <= tol_out and rel(masks.detach().cpu(), omasks.detach()) <= tol_out, flipped
     table = rec.result()["t0"]
     assert len(table) == len(net.firing)
     for k, v in table.items():
-        assert abs(v - net.firing[k]) <= 2e-3, (k, v, net.firing[k])
+        assert abs(v - net.firing[k]) <= (2e-3 if flipped else 1e-9), (k, v, net.firing[k])
     k = "decode_head.mask_embed.fc1.weight"
     gm, go = dict(model.named_parameters())[k].grad.cpu(), st[k].grad
-    assert (gm - go).abs().max().item() <= 5e-2 * go.abs().max().item()
+    gscale = max(v.grad.abs().max().item() for v in st.values() if v.grad is not None)
+    assert (gm - go).abs().max().item() <= tol_grad * (go.abs().max().item() + 5e-3 * gscale), flipped
 
 
 def test_folded_mask_feature_convolution_does_not_change_the_step(env):

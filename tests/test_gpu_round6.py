@@ -117,3 +117,44 @@ def test_no_vendor_gemm_on_the_plumbing_configuration():
     assert dict(ops.FALLBACKS) == before
     grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
     assert len(grads) > 500 and all(torch.isfinite(g).all() for g in grads)
+
+
+def test_eager_forward_after_graphed_training_reads_the_updated_weights():
+    """ADVICE r5 (medium).  A replayed hipGraph that holds the AdamW update re-splits the weights at its START and updates them at
+    its END: after a replay the version-keyed conversion caches (bf16 terms / packs, composed eval-mode BatchNorm affines) hold the
+    weights from BEFORE the last update under unchanged version counters.  GraphedStep bumps the versions after every replay
+    (FlatAdamW.mark_updated), so an eager forward -- validation, predict() -- re-converts: it must equal a FRESH model that loads
+    the trained state_dict, in train mode (batch statistics) and in eval mode (the fused eval path with its cached affines)."""
+    import spike2former_amd as s2f
+    from spike2former_amd.dist import FlatGradAllReduce
+    from spike2former_amd.graph import GraphedStep
+    from spike2former_amd.init_utils import seeded_init
+    from spike2former_amd.train import FlatAdamW
+    w = s2f.WORKLOADS["C1_64"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C1_64"))).cuda().train()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(2, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(7)).cuda()
+    with torch.no_grad():                                    # an eager eval forward BEFORE training fills every version-keyed cache
+        model.eval(); s2f.reset_net(model); model(img); model.train()
+    red = FlatGradAllReduce(model.parameters(), 1)
+    red.install_sinks()
+    s2f.reset_net(model); red.zero()
+    s2f.headline_loss(*model(img)).backward()
+    s2f.ops.wgrad_join(); red.gather(); red.compact()
+    # a large learning rate: one stale step must be visible far above round-off
+    opt = FlatAdamW(model, red, lr=0.05, weight_decay=0.005, clip_grad=dict(max_norm=1e9))
+    gs = GraphedStep(model, s2f.headline_loss, img, grad_buffer=red, warmup=1, optimizer=opt)
+    for _ in range(3):
+        gs()
+    torch.cuda.synchronize()
+    fresh = s2f.MODELS.build(s2f.model_cfg("C1_64")).cuda()
+    fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()}, strict=True)
+    s2f.set_keep_membrane(fresh, False)
+    for mode in ("eval", "train"):
+        getattr(model, mode)(); getattr(fresh, mode)()
+        with torch.no_grad():
+            s2f.reset_net(model); got = model(img)
+            s2f.reset_net(fresh); want = fresh(img)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), (mode, (a - b).abs().max().item())
+    red.close()
