@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 23
+#define S2F_ABI_VERSION 24
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -601,6 +601,25 @@ int s2f_adamw_step(const int64_t* slots, const float* hyper, const int32_t* chun
  * (mmseg/models/backbones/sdtv2.py:112-255; mmdet/models/layers/transformer/mmcv_spike/transformer.py:196-361, 710-784). */
 int s2f_bmm_f32(const float* a, int64_t a_sb, int64_t a_sm, int64_t a_sk, const float* b, int64_t b_sb, int64_t b_sk, int64_t b_sn,
                 float* c, int64_t c_sb, int64_t c_sm, int64_t c_sn, int B, int M, int N, int K, int reduce_batch, void* stream);
+
+/* ---- reductions and fills of the step outside the neuron / BatchNorm / GEMM kernels (csrc/glue.hip, round 6) --------------------
+ * What ran as ATen reduce / fill launches inside the captured step.  Partial sums are STORED and added in index order by a second
+ * small kernel: deterministic, no atomics.
+ *   s2f_sum_all       out[0] = scale * sum_i x[i]; partials: float[s2f_sum_all_parts(n)] scratch.  The benchmark's headline loss
+ *                     (the mean of all_cls_scores / all_mask_preds, mmdet dense_heads/maskformer_head.py:498-586 outputs).
+ *   s2f_fill          p[i] = (value_ptr? ? value_ptr[0] : 1) * value -- a device scalar times a host scalar, no host round trip: the
+ *                     constant gradient of a mean, written once in the layout its consumer reads.
+ *   s2f_channel_sum   out[c] (+)= sum_n sum_l x[n][c][l], x [N][C][L], L % 4 == 0; workspace: float[C * s2f_channel_sum_slices(N, C, L)].
+ *                     The level-embedding gradient of the decoder's fused key / value neurons (maskformer_head.py:535-540), the
+ *                     mask contraction's row sums.
+ *   s2f_sum_lead      out[m] = sum_t x[t][m], x [T][M], M % 4 == 0: the query position embedding's gradient, summed over the T time
+ *                     steps (mmcv_spike/transformer.py:626-629). */
+int64_t s2f_sum_all_parts(int64_t n);
+int s2f_sum_all(const float* x, int64_t n, float scale, float* partials, float* out, void* stream);
+int s2f_fill(float* p, int64_t n, const float* value_ptr, float value, void* stream);
+int s2f_channel_sum_slices(int N, int C, int L);
+int s2f_channel_sum(const float* x, int N, int C, int L, float* workspace, float* out, int accumulate, void* stream);
+int s2f_sum_lead(const float* x, int T, int64_t M, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,11 @@ fails loudly, and every op raises when handed a non-CUDA tensor.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- FIRST: torch brings its own HIP runtime (libamdhip64 in torch/lib); libs2f_hip.so must bind to THAT copy.
+#                             Loaded before torch, the library pulls in /opt/rocm's runtime instead, the process holds two HIP runtimes
+#                             and launches through the second one fail with "no ROCm-capable device is detected" (seen when
+#                             `python __graft_entry__.py smoke` imported the package before anything had imported torch).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S2F_LIB") or os.path.join(_HERE, "libs2f_hip.so")      # S2F_LIB: another build of the same ABI (A/B runs)
 
@@ -115,6 +120,12 @@ SIGNATURES = {
     "s2f_grad_sqnorm": (_i, [_p, _i64, _p, _p]),
     "s2f_adamw_prepare": (_i, [_p, _i, _f, ctypes.c_double, ctypes.c_double, _p, _p]),
     "s2f_adamw_chunk_elems": (_i, []),
+    "s2f_sum_all_parts": (_i64, [_i64]),
+    "s2f_sum_all": (_i, [_p, _i64, _f, _p, _p, _p]),
+    "s2f_fill": (_i, [_p, _i64, _p, _f, _p]),
+    "s2f_channel_sum_slices": (_i, [_i, _i, _i]),
+    "s2f_channel_sum": (_i, [_p, _i, _i, _i, _p, _p, _i, _p]),
+    "s2f_sum_lead": (_i, [_p, _i, _i64, _p, _p]),
     "s2f_bmm_f32": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
     "s2f_adamw_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, ctypes.c_double, ctypes.c_double, _f, _p]),
 }

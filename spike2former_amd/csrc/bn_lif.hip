@@ -1009,6 +1009,15 @@ struct Bn2 {
   float eps, momentum;
 };
 
+// SHIFTED statistics of the single-pass kernels (round 6).  The sums are taken of (z + b) - pivot, pivot = the channel's first element:
+// var = E[d^2] - E[d]^2 then cancels against (mean - pivot)^2 -- of the order of the variance itself -- instead of against mean^2.  The
+// plain form E[x^2] - E[x]^2 with fp32 squares carries an absolute error of ~1e-7 mean^2: for a channel whose variance is far below
+// its squared mean (tiny maps, near-constant channels: the 4 x 4 maps of the plumbing configuration) that is a PER-CENT error in
+// rstd -- invisible forward (x - mean is tiny there) but multiplied into every input gradient of the channel (found by holding the
+// tiny-config gradients to 10x the measured reference-vs-oracle gap: 2-7 % on dcn.input_proj at C1_64).  ATen's CPU BatchNorm
+// (the reference) computes the variance in two passes; a constant channel now gives var == 0 exactly here too.
+#define S2F_BN_PIVOT const float piv = z[(int64_t)c * L] + b
+
 template <bool LIF, bool HAS_V, bool YB, bool DOUBLE = false>
 __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ stat, float* __restrict__ running_mean,
@@ -1038,19 +1047,21 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < kTpw; ++i) rvp[i] = (S2F_BN_NT & 32) ? ld4_nt(res + base[i]) : ld4(res + base[i]);
   }
+  S2F_BN_PIVOT;
   float ps = 0.f, pq = 0.f;
 #pragma unroll
   for (int i = 0; i < kTpw; ++i) {
     if (!ok[i]) continue;
-    const float a0 = zv[i].a[0] + b, a1 = zv[i].a[1] + b, a2 = zv[i].a[2] + b, a3 = zv[i].a[3] + b;
+    const float a0 = (zv[i].a[0] + b) - piv, a1 = (zv[i].a[1] + b) - piv, a2 = (zv[i].a[2] + b) - piv, a3 = (zv[i].a[3] + b) - piv;
     ps += (a0 + a1) + (a2 + a3);
     pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
   }
   double s1 = (double)ps, s2 = (double)pq;
   block_sum2(s1, s2, red, nwaves);
-  const double md = s1 * inv_count;
-  double vd = s2 * inv_count - md * md;
+  const double dm = s1 * inv_count;                       // mean of (z + b) - pivot
+  double vd = s2 * inv_count - dm * dm;
   if (vd < 0) vd = 0;
+  const double md = (double)piv + dm;
   const float mean = (float)md, var = (float)vd;
   const float rstd = 1.0f / sqrtf(var + eps);
   float g = gamma[c], be = beta[c];
@@ -1257,18 +1268,20 @@ __global__ __launch_bounds__(64) void bn_small_fwd_kernel(
       if (res) rvp[i] = ld4(res + base[i]);
     }
   }
+  S2F_BN_PIVOT;
   float ps = 0.f, pq = 0.f;
 #pragma unroll
   for (int i = 0; i < kSmallIters; ++i) {
     if (!ok[i]) continue;
-    const float a0 = zv[i].a[0] + b, a1 = zv[i].a[1] + b, a2 = zv[i].a[2] + b, a3 = zv[i].a[3] + b;
+    const float a0 = (zv[i].a[0] + b) - piv, a1 = (zv[i].a[1] + b) - piv, a2 = (zv[i].a[2] + b) - piv, a3 = (zv[i].a[3] + b) - piv;
     ps += (a0 + a1) + (a2 + a3);
     pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
   }
   const double s1 = wave_sum_f64((double)ps), s2 = wave_sum_f64((double)pq);
-  const double md = s1 * inv_count;
-  double vd = s2 * inv_count - md * md;
+  const double dm = s1 * inv_count;                       // mean of (z + b) - pivot
+  double vd = s2 * inv_count - dm * dm;
   if (vd < 0) vd = 0;
+  const double md = (double)piv + dm;
   const float mean = (float)md, var = (float)vd;
   const float rstd = 1.0f / sqrtf(var + eps);
   const float g_ = gamma[c], be = beta[c];
@@ -1439,19 +1452,21 @@ __global__ __launch_bounds__(64 * kMidWaves) void bn_mid_fwd_kernel(
       if (res) rvp[i] = ld4(res + base[i]);
     }
   }
+  S2F_BN_PIVOT;
   float ps = 0.f, pq = 0.f;
 #pragma unroll
   for (int i = 0; i < kMidIters; ++i) {
     if (!ok[i]) continue;
-    const float a0 = zv[i].a[0] + b, a1 = zv[i].a[1] + b, a2 = zv[i].a[2] + b, a3 = zv[i].a[3] + b;
+    const float a0 = (zv[i].a[0] + b) - piv, a1 = (zv[i].a[1] + b) - piv, a2 = (zv[i].a[2] + b) - piv, a3 = (zv[i].a[3] + b) - piv;
     ps += (a0 + a1) + (a2 + a3);
     pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
   }
   double s1 = (double)ps, s2 = (double)pq;
   block_sum2(s1, s2, red, W);
-  const double md = s1 * inv_count;
-  double vd = s2 * inv_count - md * md;
+  const double dm = s1 * inv_count;                       // mean of (z + b) - pivot
+  double vd = s2 * inv_count - dm * dm;
   if (vd < 0) vd = 0;
+  const double md = (double)piv + dm;
   const float mean = (float)md, var = (float)vd;
   const float rstd = 1.0f / sqrtf(var + eps);
   const float g_ = gamma[c], be = beta[c];

@@ -125,6 +125,13 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _aligned16(t):
+    """contiguous and 16-byte aligned (a row slice of a tensor whose rows are no whole 16-byte groups is neither a copy nor
+    aligned): what the 16-byte loads of the streaming kernels need"""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -4,7 +4,7 @@ import torch
 
 from .config import cfg
 from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _stream, check, lib, Spikes, ...)
-from .misc import transpose_last2
+from .misc import channel_sum, transpose_last2
 
 
 # ------------------------------------------------------------------------------------------------ small / ragged products
@@ -910,7 +910,7 @@ class _MaskEinsumFolded(torch.autograd.Function):
                         else:
                             check(lib.s2f_spike_gemm_dw(_ptr(g[b]), _ptr(S[t, b]), _ptr(H[t, b]), 1, Q, C, HW, 0, 1, _stream()),
                                   "s2f_spike_gemm_dw")
-            rs = g.sum(-1) if bias is not None else None                      # [B, Q]
+            rs = channel_sum(g.view(1, B * Q, HW)).view(B, Q) if bias is not None else None                      # [B, Q]
             if ctx.needs_input_grad[0]:
                 ge = _mm_tm(H.view(-1, C), W).view(T, B, Q, Co)                                   # H @ W^T
                 if bias is not None:

@@ -71,6 +71,82 @@ def transpose_last2(x):
     return _TransposeLast2.apply(x.reshape(-1, R, C)).view(*lead, C, R)
 
 
+# ------------------------------------------------------------------------------------------------ reductions / fills (csrc/glue.hip)
+def channel_sum(x):
+    """x [N, C, L] fp32 -> [C] = x.sum((0, 2)) on s2f_channel_sum (partials stored, added in order: bit-repeatable); ATen for rows
+    that are no whole 16-byte groups."""
+    N, C, L = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and L % 4 == 0 and x.numel() > 0 and C < 65536):
+        return x.sum((0, 2))
+    x = x.contiguous()
+    ws = torch.empty(C * int(lib.s2f_channel_sum_slices(N, C, L)), dtype=torch.float32, device=x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(lib.s2f_channel_sum(_ptr(x), N, C, L, _ptr(ws), _ptr(out), 0, _stream()), "s2f_channel_sum")
+    return out
+
+
+def sum_lead(x):
+    """x [T, ...] fp32 -> x.sum(0) on s2f_sum_lead"""
+    T = x.shape[0]
+    M = x.numel() // max(T, 1)
+    if not (x.is_cuda and x.dtype == torch.float32 and M % 4 == 0 and x.numel() > 0):
+        return x.sum(0)
+    x = x.contiguous()
+    out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+    check(lib.s2f_sum_lead(_ptr(x), T, M, _ptr(out), _stream()), "s2f_sum_lead")
+    return out
+
+
+def _dense_flat(x):
+    """x as a flat view of the memory it covers when its elements are a permutation of one dense block (any permuted view of a
+    contiguous tensor), else None"""
+    if x.numel() == 0:
+        return None
+    dims = sorted((st, sz) for st, sz in zip(x.stride(), x.shape) if sz > 1)
+    run = 1
+    for st, sz in dims:
+        if st != run:
+            return None
+        run *= sz
+    return x.as_strided((x.numel(),), (1,))
+
+
+class _MeanAll(torch.autograd.Function):
+    """x.mean() over a whole tensor (the benchmark's headline loss terms).  Forward: s2f_sum_all over the memory x covers (a permuted
+    view sums to the same value).  Backward: the constant g / n written ONCE, by s2f_fill, with x's own strides -- the gradient of
+    the permuted logits view is then a plain tensor in the contraction's layout and the consumer's .contiguous() is a no-op.  (torch's
+    formula materialises expand(g) / n in the view's layout and the consumer copies it into its own: two passes over 367 MB at C2.)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        flat = _dense_flat(x) if (x.is_cuda and x.dtype == torch.float32) else None
+        ctx.meta = (x.shape, x.stride(), flat is not None)
+        if flat is None or flat.data_ptr() % 16 != 0:
+            ctx.meta = (x.shape, x.stride(), False)
+            return x.mean()
+        n = flat.numel()
+        part = torch.empty(int(lib.s2f_sum_all_parts(n)), dtype=torch.float32, device=x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        check(lib.s2f_sum_all(_ptr(flat), n, 1.0 / n, _ptr(part), _ptr(out), _stream()), "s2f_sum_all")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, stride, ours = ctx.meta
+        n = 1
+        for d in shape:
+            n *= d
+        if not ours:
+            return (g / n).expand(shape)
+        gx = torch.empty_strided(shape, stride, dtype=torch.float32, device=g.device)
+        check(lib.s2f_fill(_ptr(gx), n, _ptr(g.contiguous()), 1.0 / n, _stream()), "s2f_fill")
+        return gx
+
+
+def mean_all(x):
+    return _MeanAll.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
 class _Up2x(torch.autograd.Function):
     @staticmethod

@@ -3,6 +3,7 @@ import torch
 
 from .config import cfg
 from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _stream, check, lib, Spikes, ...)
+from .misc import channel_sum, sum_lead
 
 
 # ------------------------------------------------------------------------------------------------ LIF
@@ -61,12 +62,12 @@ class _LIFLeaky(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v_in, D, vth, tau, decay_input, keep_v, stats):
         _need_cuda(x, v_in)
-        x = x.contiguous()
+        x = _aligned16(x)
         if v_in is not None:
-            v_in = v_in.contiguous()
+            v_in = _aligned16(v_in)
         n = x.numel()
-        y = torch.empty_like(x)
-        v_out = torch.empty_like(x) if keep_v else None
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        v_out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if keep_v else None
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         mask = torch.empty(mask_words(n), dtype=torch.int64, device=x.device) if need_grad else None
         check(lib.s2f_lif_leaky_fwd(_ptr(x), _ptr(v_in), _ptr(y), _ptr(v_out), _ptr(mask), _ptr(stats), n, vth, D, tau,
@@ -87,13 +88,13 @@ class _LIFLeaky(torch.autograd.Function):
             return (None,) * 8
         if gy is None:
             gy = torch.zeros_like(gv)
-        gy = gy.contiguous()
+        gy = _aligned16(gy)
         if gv is not None and gv.numel() != gy.numel():
             gv = None
         if gv is not None:
-            gv = gv.contiguous()
-        gx = torch.empty_like(gy)
-        gvi = torch.empty_like(gy) if has_v else None
+            gv = _aligned16(gv)
+        gx = torch.empty(gy.shape, dtype=torch.float32, device=gy.device)
+        gvi = torch.empty(gy.shape, dtype=torch.float32, device=gy.device) if has_v else None
         check(lib.s2f_lif_leaky_bwd(_ptr(gy), _ptr(gv), _ptr(mask), _ptr(gx), _ptr(gvi), gy.numel(), vth, D, tau, di, _stream()),
               "s2f_lif_leaky_bwd")
         return gx, gvi, None, None, None, None, None, None
@@ -157,11 +158,11 @@ class _Sum2LIF(torch.autograd.Function):
         _time_next("lif_bwd", 12 * like.numel())
         check(lib.s2f_sum2_lif_bwd_ex(_ptr(gk), _ptr(gv), _ptr(mk), _ptr(mv), _ptr(gx), _ptr(gxk), like.numel(), ctx.D, _stream()),
               "s2f_sum2_lif_bwd_ex")
-        ge = gx.sum((0, 2)) if ctx.needs_input_grad[1] else None
+        ge = channel_sum(gx) if ctx.needs_input_grad[1] else None
         gpos = None
         if ctx.needs_input_grad[2]:
             T, B = ctx.tb
-            gpos = gxk.view(T, B, *like.shape[1:]).sum(0) if want_pos else torch.zeros(B, *like.shape[1:], dtype=like.dtype, device=like.device)
+            gpos = sum_lead(gxk.view(T, B, *like.shape[1:])) if want_pos else torch.zeros(B, *like.shape[1:], dtype=like.dtype, device=like.device)
         return gx, ge, gpos, None, None, None, None
 
 

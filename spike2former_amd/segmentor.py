@@ -142,26 +142,7 @@ class ResetModelHook:
     before_train_iter = before_val_iter = before_test_iter = lambda self, runner, *a, **k: self._reset(runner)
 
 
-class _MeanAll(torch.autograd.Function):
-    """x.mean() whose backward hands out its constant gradient g / n as a stride-0 VIEW of the input's shape.  torch's own formula
-    materialises expand(g) / n -- one write pass over a tensor of the input's size (367 MB for the C2 mask logits) -- only for the
-    consumer's .contiguous() (the logits are a permuted view of the contraction's output) to copy it again: two passes for a
-    constant.  The consumer still materialises the gradient once, in the layout it reads."""
-
-    @staticmethod
-    def forward(ctx, x):
-        ctx.shape = x.shape
-        return x.mean()
-
-    @staticmethod
-    def backward(ctx, g):
-        n = 1
-        for d in ctx.shape:
-            n *= d
-        return (g / n).expand(ctx.shape)
-
-
 def headline_loss(all_cls_scores, all_mask_preds):
     """Scalar loss of the benchmark step: on-device, data-independent:
     all_cls_scores.float().mean() + all_mask_preds.float().mean()."""
-    return _MeanAll.apply(all_cls_scores.float()) + _MeanAll.apply(all_mask_preds.float())
+    return ops.mean_all(all_cls_scores.float()) + ops.mean_all(all_mask_preds.float())

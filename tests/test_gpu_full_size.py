@@ -1041,7 +1041,7 @@ def test_c2_batchnorm_statistics_come_from_the_gemm_epilogues(c2):
 
 
 # ------------------------------------------------------------------------------------------------ other configs, one stage each vs the oracle
-def _stage_forced(s2f, so, cfg, st0, model, mod, name, fn, x, seed):
+def _stage_forced(s2f, so, cfg, st0, model, mod, name, fn, x, seed, conditioning=False):
     """One stage forward + backward with the comparison RE-SEEDED at every neuron: this build runs first (forward hooks record the
     spike counts and the straight-through mask of every Q_IFNode of the run that is compared), then the oracle runs the stage
     emitting exactly these counts (OracleNet.force: the gradient still flows through its own quantiser) -- every neuron of the oracle
@@ -1086,11 +1086,27 @@ def _stage_forced(s2f, so, cfg, st0, model, mod, name, fn, x, seed):
     grads = {n: p.grad for n, p in mod.named_parameters() if p.grad is not None}
     ref = {n: st[pref + n].grad for n in grads if st[pref + n].grad is not None}
     p_gap, worst_p = _grad_gaps(grads, ref)
-    return dict(out=rel_l2(out.detach().cpu(), yo.detach()), gx=rel_l2(xg.grad.cpu(), xo.grad), p_gap=p_gap, worst_p=worst_p, elems=elems,
-                dspk=dspk, max_level=max_level, dmask=dmask, neurons=len(mine))
+    row = dict(out=rel_l2(out.detach().cpu(), yo.detach()), gx=rel_l2(xg.grad.cpu(), xo.grad), p_gap=p_gap, worst_p=worst_p, elems=elems,
+               dspk=dspk, max_level=max_level, dmask=dmask, neurons=len(mine))
+    if conditioning:
+        # How well conditioned is this stage's gradient in fp32?  The oracle again in fp64 (same forced spikes): `ref64` is what the
+        # fp32 ORACLE misses the fp64 result by -- the distance between two correct fp32 implementations -- and `vs64` what this build
+        # misses it by.  (Measured at C2, B = 2: the DCN encoder layer's input gradient carries 6e-4 of fp32 noise in the oracle itself
+        # and 0.9 % on dcn.input_proj's parameters -- the sampling core's offset gradient is a difference of neighbouring values.)
+        st64 = {k: (v.clone().double().requires_grad_(v.is_floating_point() and "running" not in k and k.startswith(pref))
+                    if (k.startswith(pref) and v.is_floating_point()) else v) for k, v in st0.items()}
+        net64 = so.OracleNet(st64, cfg, training=True)
+        net64.force = net.force
+        x64 = x.double().requires_grad_(True)
+        getattr(net64, fn)(name, x64).backward(gy.double())
+        ref64 = {n: st64[pref + n].grad for n in grads if st64[pref + n].grad is not None}
+        row.update(gx_vs64=rel_l2(xg.grad.cpu().double(), x64.grad), gx_ref64=rel_l2(xo.grad.double(), x64.grad),
+                   p_vs64=_grad_gaps({n: g_.double() for n, g_ in grads.items()}, ref64)[0],
+                   p_ref64=_grad_gaps({n: ref[n].double() for n in ref64 if n in ref}, ref64)[0])
+    return row
 
 
-def _other_config_stage_rows(workload, B, H16, W16, stages, seed):
+def _other_config_stage_rows(workload, B, H16, W16, stages, seed, conditioning=()):
     """Builds the modules of another BASELINE config at FULL width and runs `stages` = [(name, oracle fn, input shape)] forward +
     backward on both sides from a seeded stage input (`_stage_forced`) -- no full oracle forward is needed."""
     import spike2former_amd as s2f
@@ -1107,7 +1123,8 @@ def _other_config_stage_rows(workload, B, H16, W16, stages, seed):
         mod = model
         for part in name.split("."):
             mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
-        rows[name] = _stage_forced(s2f, so, cfg, st0, model, mod, name, fn, torch.randn(*shape, generator=g), seed + len(rows))
+        rows[name] = _stage_forced(s2f, so, cfg, st0, model, mod, name, fn, torch.randn(*shape, generator=g), seed + len(rows),
+                                   conditioning=name in conditioning)
     return rows
 
 
@@ -1118,7 +1135,10 @@ def _assert_stage_rows(rows, min_neurons):
         # the borderline flips are few and by one level; the output agrees to round-off whatever flipped (the oracle was re-seeded)
         assert r["dspk"] <= max(1e-4 * r["elems"], 4) and r["max_level"] <= 1.0 and r["dmask"] <= max(1e-4 * r["elems"], 4), (name, r)
         assert r["out"] <= 1e-5, (name, r)
-        if r["dmask"] == 0:          # no straight-through mask bit differs either: the gradients agree to round-off
+        if r["dmask"] == 0 and "gx_ref64" in r:
+            # self-calibrated: this build may miss the fp64 gradient by at most 10x what the fp32 oracle misses it by
+            assert r["gx_vs64"] <= max(1e-5, 10 * r["gx_ref64"]) and r["p_vs64"] <= max(1e-3, 10 * r["p_ref64"]), (name, r)
+        elif r["dmask"] == 0:        # no straight-through mask bit differs either: the gradients agree to round-off
             assert r["gx"] <= 1e-5 and r["p_gap"] <= 1e-3, (name, r)
         else:
             assert r["gx"] <= 5e-2 and r["p_gap"] <= 2e-1, (name, r)
@@ -1161,6 +1181,7 @@ def test_c2_stages_at_the_bench_batch_forward_backward_vs_oracle():
         ("backbone.downsample4", "run_backbone_stage", (4, 2, 256, 32, 32)),
         ("backbone.block3.2", "_block", (4, 2, 256, 32, 32)),
         ("backbone.block4.0", "_block", (4, 2, 360, 32, 32)),
-        ("decode_head.pixel_decoder.encoder.layers.0", "_enc_layer", (4, 2, 32, 32, 256))], 600)
+        ("decode_head.pixel_decoder.encoder.layers.0", "_enc_layer", (4, 2, 32, 32, 256))], 600,
+        conditioning=("decode_head.pixel_decoder.encoder.layers.0",))
     _assert_stage_rows(rows, 1)
     assert rows["backbone.block3.2"]["neurons"] >= 7 and rows["decode_head.pixel_decoder.encoder.layers.0"]["neurons"] >= 8

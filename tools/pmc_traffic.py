@@ -16,6 +16,24 @@ def _bn_bwd(n, with_spike_grad):
     return len(a) >= 2 and (a[1] == "true") == with_spike_grad
 
 
+def _short(n):
+    """`void (anonymous namespace)::bn_apply_rows_kernel<true, false, true, true>(float const*, ...)` -> the kernel with its template
+    arguments, without return type, namespace and parameter list (the names used to be cut at the first "(" -- which for every
+    kernel of an anonymous namespace is the one in "void (anonymous namespace)::": every entry read "void ")"""
+    n = n.replace("(anonymous namespace)::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    depth = 0
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return n[:i].strip()
+    return n.strip()
+
+
 FAMILIES = {          # bench.py roofline key -> predicate on the kernel name
     "bn_lif_fwd": lambda n: any(k in n for k in ("bn_apply_kernel<true", "bn_apply_rows_kernel<true", "bn_fused_fwd_kernel<true",
                                                  "bn_small_fwd_kernel<true")),
@@ -53,7 +71,7 @@ def per_family(db, counter):
         vals = [v for d, v in per.items() if pred(name[d])]
         if vals:
             out[fam] = (len(vals), sum(vals) / len(vals))
-            KERNELS[fam] |= {name[d].split("(")[0] for d in per if pred(name[d])}
+            KERNELS[fam] |= {_short(name[d]) for d in per if pred(name[d])}
     return out
 
 

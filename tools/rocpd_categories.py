@@ -25,6 +25,7 @@ def cat(name):
     if 'bn_' in name: return 'bn(+lif) fused (ours)'
     if 'lif_' in name: return 'lif (ours)'
     if 'apply_kernel' in name or 'outer_kernel' in name or 'outer_mfma' in name or 'sdsa' in name: return 'sdsa (ours)'
+    if any(k in name for k in ('sum_all_', 'fill_kernel', 'channel_sum_', 'sum_lead_kernel', 'bmm_f32_kernel')): return 'glue reductions / fills (ours, glue.hip)'
     if 's2f_zero' in name: return 'fill/memset'
     if 'depthwise' in name: return 'depthwise conv (ATen)'
     if 'batch_norm' in name: return 'batch_norm (ATen)'
@@ -62,6 +63,12 @@ def main():
     print(f"# {nsteps} steps, {len(sel)//nsteps} launches/step, kernel time {tot/nsteps/1e6:.2f} ms/step, wall span {span/nsteps/1e6:.2f} ms/step")
     for k, v in agg.most_common():
         print(f"{k:30s} {v/nsteps/1e6:8.2f} ms/step {cnt[k]//nsteps:6d} launches/step {100*v/tot:5.1f}%")
+    # kernels that are not this package's: ATen elementwise / reduce / copy launches inside the captured step (S2F_STRICT does not see
+    # them: they are not GEMMs or convolutions).  S2F_FORBID_ATEN=1 makes their presence a failure (exit 3).
+    aten = [(n, e - s) for n, s, e in sel if 'at::native' in n or n.startswith('Cijk') or 'rocclr' in n]
+    print(f"# not ours (at::native / rocclr / Tensile): {len(aten)//nsteps} launches/step, {sum(t for _, t in aten)/nsteps/1e6:.2f} ms/step")
+    if os.environ.get("S2F_FORBID_ATEN") == "1" and aten:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
