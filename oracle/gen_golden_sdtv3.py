@@ -26,6 +26,15 @@ def main():
     ref.load_state_dict(mine.state_dict(), strict=True)
     ref.train()
     img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(31))
+    # exact per-neuron census of the reference's own Multispike_norm modules, in execution order: (sum of spike counts, non-zero counts,
+    # elements with 0 <= x <= 4) -- what decides whether two fp32 implementations can be compared at round-off (tests/test_gpu_model.py)
+    Msn = importlib.import_module("mmseg.models.utils.Qtrick").Multispike_norm
+    census = []
+    for n, m in ref.named_modules():
+        if isinstance(m, Msn):
+            m.register_forward_hook(lambda mod, i, o, n=n: census.append(
+                (n, int((o.detach() * 4).round().sum().item()), int((o.detach() != 0).sum().item()),
+                 int(((i[0].detach() >= 0) & (i[0].detach() <= 4)).sum().item()))))
     outs = ref(img)
     sum((o * o).mean() for o in outs).backward()            # a plain mean of BatchNorm outputs has no gradient
     blob = {"img": img.numpy()}
@@ -34,6 +43,12 @@ def main():
     params = dict(ref.named_parameters())
     for k in GRADS:
         blob["grad__" + k] = params[k].grad.numpy()
+    blob["census_names"] = np.array([c[0] for c in census])
+    blob["census"] = np.array([c[1:] for c in census], dtype=np.int64)
+    # every parameter gradient's largest magnitude (the gradient scale of the comparison metric) and the names
+    gk = [k for k, p in params.items() if p.grad is not None]
+    blob["grad_keys"] = np.array(gk)
+    blob["grad_absmax"] = np.array([params[k].grad.abs().max().item() for k in gk], dtype=np.float64)
     blob["running_mean__block3.0.attn.q_conv.1"] = dict(ref.named_buffers())["block3.0.attn.q_conv.1.running_mean"].numpy()
     np.savez_compressed(OUT, **blob)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", [tuple(o.shape) for o in outs])

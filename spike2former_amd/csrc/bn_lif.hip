@@ -1016,7 +1016,10 @@ struct Bn2 {
 // rstd -- invisible forward (x - mean is tiny there) but multiplied into every input gradient of the channel (found by holding the
 // tiny-config gradients to 10x the measured reference-vs-oracle gap: 2-7 % on dcn.input_proj at C1_64).  ATen's CPU BatchNorm
 // (the reference) computes the variance in two passes; a constant channel now gives var == 0 exactly here too.
-#define S2F_BN_PIVOT const float piv = z[(int64_t)c * L] + b
+#ifndef S2F_BN_SHIFTED
+#define S2F_BN_SHIFTED 1          // 0: the plain E[x^2] - E[x]^2 form (A/B builds only)
+#endif
+#define S2F_BN_PIVOT const float piv = S2F_BN_SHIFTED ? z[(int64_t)c * L] + b : 0.f
 
 template <bool LIF, bool HAS_V, bool YB, bool DOUBLE = false>
 __global__ __launch_bounds__(kFusedBlock) void bn_fused_fwd_kernel(

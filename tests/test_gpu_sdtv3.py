@@ -1,7 +1,6 @@
 """E-SpikeFormer backbone on the GPU against vectors produced by the reference's own sdtv3.py
-(oracle/gen_golden_sdtv3.py -> tests/golden/sdtv3_tiny.npz).  Tolerances as for the SDT-v2 path (tests/test_gpu_model.py):
-fp32 round-off before a neuron may flip a borderline spike by one level, so feature maps are compared at 2e-2 of their
-maximum and gradients at 5e-2 of the gradient scale."""
+(oracle/gen_golden_sdtv3.py -> tests/golden/sdtv3_tiny.npz).  Tolerances as for the SDT-v2 path (tests/test_gpu_model.py): the exact
+per-neuron census decides -- a flip-free step is held to 1e-5 (feature maps) / 1e-4 (gradients); 2e-2 / 5e-2 only explain a flip."""
 import numpy as np
 import pytest
 import torch
@@ -28,19 +27,38 @@ def test_sdtv3_backbone_vs_reference_vectors(golden):
     from spike2former_amd.init_utils import seeded_init
     g = golden("sdtv3_tiny.npz")
     model = seeded_init(s2f.MODELS.build(dict(type="Spiking_vit_MetaFormerv2", **KW))).cuda().train()
+    # the census rule of tests/test_gpu_model.py: exact per-neuron {sum of spike counts, non-zero counts, elements with 0 <= x <= 4}
+    # against the reference's own Multispike_norm modules (written by the generator's hooks); no neuron differs => feature maps to
+    # 1e-5, gradients to 1e-4 of the gradient scale.  The loose bounds only explain a step in which a neuron flipped.
+    census = {}
+
+    def grab(mod, inp, out, n):
+        if n not in census:
+            u = inp[0].detach()
+            census[n] = (int((out.detach() * mod.D).round().sum().item()), int((out.detach() != 0).sum().item()),
+                         int(((u >= 0) & (u <= mod.D)).sum().item()))
+    hooks = [m.register_forward_hook(lambda m_, i_, o_, n=n: grab(m_, i_, o_, n)) for n, m in model.named_modules()
+             if isinstance(m, s2f.Multispike_norm)]
     outs = model(torch.from_numpy(g["img"]).cuda())
+    for h in hooks:
+        h.remove()
     sum((o * o).mean() for o in outs).backward()            # a plain mean of BatchNorm outputs has no gradient
+    want = {str(n): tuple(int(v) for v in c) for n, c in zip(g["census_names"], g["census"])}
+    assert set(census) == set(want), set(census) ^ set(want)
+    flipped = sorted(n for n in want if census[n] != want[n])
+    tol_out, tol_grad = (2e-2, 5e-2) if flipped else (1e-5, 1e-4)
     assert [tuple(o.shape) for o in outs] == [tuple(g[f"x{i + 1}"].shape) for i in range(4)]
     for i, o in enumerate(outs):
         ref = torch.from_numpy(g[f"x{i + 1}"])
-        assert (o.detach().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), i
+        assert (o.detach().cpu() - ref).abs().max().item() <= tol_out * ref.abs().max().item(), (i, flipped)
         assert all(torch.equal(o[0], o[t]) for t in range(1, o.shape[0]))              # reset step: T identical slices
     params = dict(model.named_parameters())
     keys = [k[6:] for k in g.files if k.startswith("grad__")]
-    gscale = max(np.abs(g["grad__" + k]).max() for k in keys)
+    gscale = float(g["grad_absmax"].max())
     for k in keys:
         ref = torch.from_numpy(g["grad__" + k])
-        assert (params[k].grad.cpu() - ref).abs().max().item() <= 5e-2 * (ref.abs().max().item() + 1e-3 * gscale), k
+        err = (params[k].grad.cpu() - ref).abs().max().item()
+        assert err <= tol_grad * (ref.abs().max().item() + 5e-3 * gscale), (k, err, ref.abs().max().item(), flipped)
     rm = dict(model.named_buffers())["block3.0.attn.q_conv.1.running_mean"].cpu()
     assert torch.allclose(rm, torch.from_numpy(g["running_mean__block3.0.attn.q_conv.1"]), rtol=1e-3, atol=1e-5)
 
