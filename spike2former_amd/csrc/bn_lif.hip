@@ -23,7 +23,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
-__device__ __forceinline__ void block_atomic_add2(double a, double b, double* dst) {
+// (a, b) = this thread's sum and sum of squares of d = x - pivot over `count` elements of the workgroup in total (round 6: shifted
+// sums, see S2F_BN_PIVOT below -- the fp32 squares are taken of the SHIFTED values, whose mean is of the order of their spread);
+// un-shifted in fp64 -- sum x = sum d + n K, sum x^2 = sum d^2 + 2 K sum d + n K^2, where the cancellation of the consumer's
+// E[x^2] - E[x]^2 costs 1e-16 mean^2 instead of the 1e-7 mean^2 of fp32 squares -- and added to dst[0], dst[1].
+__device__ __forceinline__ void block_atomic_add2(double a, double b, double* dst, double pivot = 0.0, double count = 0.0) {
   __shared__ double red[2 * kWaves];
   a = wave_sum_f64(a);
   b = wave_sum_f64(b);
@@ -39,6 +43,8 @@ __device__ __forceinline__ void block_atomic_add2(double a, double b, double* ds
       sa += red[2 * i];
       sb += red[2 * i + 1];
     }
+    sb += 2.0 * pivot * sa + count * pivot * pivot;
+    sa += count * pivot;
     atomicAdd(dst, sa);
     atomicAdd(dst + 1, sb);
   }
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
   const float b = bias ? bias[c] : 0.0f;
   const int per_row = (l1 - l0) >> 2;                    // float4 items per row (slice and L are multiples of 4)
   const int total = N * per_row;
+  const float piv = z[(int64_t)c * L + l0] + b;          // pivot of this (channel, slice): its first element (shifted sums)
   float ps = 0.f, pq = 0.f;                              // fp32 partials over <= total/256 * 4 elements per thread
   for (int it = threadIdx.x; it < total; it += kBlock * kUnroll) {
     float4 v[kUnroll];
@@ -66,17 +73,19 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
         const int n = id / per_row, q = id - n * per_row;
         v[u] = *reinterpret_cast<const float4*>(z + ((int64_t)n * C + c) * L + l0 + q * 4);
       } else {
-        v[u] = make_float4(-b, -b, -b, -b);              // contributes exactly zero after the bias add
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const float a0 = v[u].x + b, a1 = v[u].y + b, a2 = v[u].z + b, a3 = v[u].w + b;
+      const bool ok = it + u * kBlock < total;            // items past the slice contribute exactly zero
+      const float a0 = ok ? (v[u].x + b) - piv : 0.f, a1 = ok ? (v[u].y + b) - piv : 0.f, a2 = ok ? (v[u].z + b) - piv : 0.f,
+                  a3 = ok ? (v[u].w + b) - piv : 0.f;
       ps += (a0 + a1) + (a2 + a3);
       pq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
   }
-  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c, (double)piv, 4.0 * (double)total);
 }
 
 // Any row length (L % 4 != 0: rows are not 16-byte aligned): the same reduction with one element per thread and step.  Only
@@ -87,14 +96,15 @@ __global__ __launch_bounds__(kBlock) void bn_stats_any_kernel(const float* __res
   const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
   const float b = bias ? bias[c] : 0.0f;
   const int len = l1 - l0, total = N * len;
+  const float piv = total > 0 ? z[(int64_t)c * L + l0] + b : 0.f;
   float ps = 0.f, pq = 0.f;
   for (int id = threadIdx.x; id < total; id += kBlock) {
     const int n = id / len, q = id - n * len;
-    const float a = z[((int64_t)n * C + c) * L + l0 + q] + b;
+    const float a = (z[((int64_t)n * C + c) * L + l0 + q] + b) - piv;
     ps += a;
     pq += a * a;
   }
-  block_atomic_add2((double)ps, (double)pq, sums + 2 * c);
+  block_atomic_add2((double)ps, (double)pq, sums + 2 * c, (double)piv, (double)total);
 }
 
 // Per-channel statistics derived identically by every lane that needs them (deterministic: same inputs, same ops).

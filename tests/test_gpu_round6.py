@@ -158,3 +158,38 @@ def test_eager_forward_after_graphed_training_reads_the_updated_weights():
         for a, b in zip(got, want):
             assert torch.equal(a, b), (mode, (a - b).abs().max().item())
     red.close()
+
+
+@pytest.mark.parametrize("N,C,L", [(8, 32, 1024),          # bn_fused_fwd_kernel (8 192 elements per channel: the C2 bench shape)
+                                   (8, 32, 100),           # bn_small_fwd_kernel (one wavefront per channel)
+                                   (4, 32, 4200),          # bn_mid_fwd_kernel (rows that are no whole tiles)
+                                   (2, 16, 16)])           # the 4 x 4 maps of the plumbing configuration
+def test_single_pass_batchnorm_statistics_survive_a_large_mean(N, C, L):
+    """Channels whose variance is far below their squared mean (mean 50, std 1e-2 .. 1): the statistics as shifted sums (round 6,
+    S2F_BN_PIVOT) against an fp64 two-pass BatchNorm.  E[x^2] - E[x]^2 on fp32 squares carries ~1e-7 mean^2 = 2.5e-4 of absolute
+    variance error here -- larger than the variance of the quiet channels: their rstd, and with it every input gradient of the
+    channel, came out wrong by tens of per cent while the forward (x - mean is tiny) looked fine.  One channel is exactly constant."""
+    from spike2former_amd import ops
+    g = torch.Generator().manual_seed(L)
+    std = torch.logspace(-2, 0, C).view(1, C, 1)
+    z = 50.0 + std * torch.randn(N, C, L, generator=g)
+    z[:, 0] = 3.25                                                     # a constant channel: var must be 0 exactly
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    gu = torch.randn(N, C, L, generator=g)
+    zd = z.double().requires_grad_(True)
+    mean = zd.mean((0, 2), keepdim=True)
+    var = ((zd - mean) ** 2).mean((0, 2), keepdim=True)
+    u64 = (zd - mean) / torch.sqrt(var + 1e-5) * gamma.double().view(1, C, 1) + beta.double().view(1, C, 1)
+    (u64 * gu.double()).sum().backward()
+    zc = z.cuda().requires_grad_(True)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    u = ops.bn_act(zc, None, gamma.cuda(), beta.cuda(), rm, rv, nbt, True, 0.1, 1e-5, lif=False, want_pre=True)[0]
+    (u * gu.cuda()).sum().backward()
+    # x_hat = (z - mean) * rstd is O(1): an rstd off by 1 % moves u by 1e-2.  fp32 round-off of z - mean at |z| = 50 is 4e-6 absolute,
+    # i.e. up to 4e-6 / 1e-2 = 4e-4 of a quiet channel's x_hat -- the bound below leaves room for exactly that
+    assert (u.detach().cpu().double() - u64.detach()).abs().max().item() <= 2e-3
+    ref = zd.grad
+    err = (zc.grad.cpu().double() - ref).abs().amax((0, 2)) / ref.abs().amax((0, 2)).clamp_min(1e-30)
+    assert err[1:].max().item() <= 5e-3, err
+    assert abs(rv[0].item() - 0.9) <= 1e-7                              # running_var of the constant channel: 0.9 * 1 + 0.1 * 0
