@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 24
+#define S2F_ABI_VERSION 25
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -620,6 +620,19 @@ int s2f_fill(float* p, int64_t n, const float* value_ptr, float value, void* str
 int s2f_channel_sum_slices(int N, int C, int L);
 int s2f_channel_sum(const float* x, int N, int C, int L, float* workspace, float* out, int accumulate, void* stream);
 int s2f_sum_lead(const float* x, int T, int64_t M, float* out, void* stream);
+
+/* ---- masked spike-driven attention (csrc/sdsa_masked.hip, round 6) -------------------------------------------------------------
+ * The `attn_mask` branch of (Cross)MultiHeadAttentionBlock.forward (mmcv_spike/transformer.py:259-272, 343-355):
+ *     scores = q k^T * scale ; scores.masked_fill(mask, 0) ; out = scores v
+ * q, o, go, gq: fp32 [TB][heads * d][Nq]; k, v, gk, gv: fp32 [TB][heads * d][Nk] (channel-major, c = head * d + j, tb = t * B + b);
+ * mask: uint8 [B][heads][Nq][Nk], non-zero = masked, shared by the time steps (the reference reshapes attn_mask with t where its comment
+ * says bs and therefore only runs for t == b -- where it applies mask[b, h] to every t: the semantics implemented here, for any t).
+ * Explicit O(Nq Nk d) evaluation on the vector ALUs (a mask forbids the q (k^T v) association of s2f_sdsa_*); d <= 64.  The head of
+ * every shipped config passes no mask (dense_heads/maskformer_head.py:554-564). */
+int s2f_sdsa_masked_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float* o, int TB, int B, int heads, int d,
+                        int Nq, int Nk, float scale, void* stream);
+int s2f_sdsa_masked_bwd(const float* q, const float* k, const float* v, const uint8_t* mask, const float* go, float* gq, float* gk,
+                        float* gv, int TB, int B, int heads, int d, int Nq, int Nk, float scale, void* stream);
 
 #ifdef __cplusplus
 }

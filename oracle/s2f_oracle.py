@@ -558,7 +558,7 @@ class OracleNet:
         mf = self.conv2d(n + ".mask_feature", y.flatten(0, 1))
         return mf.reshape(t, bs, *mf.shape[1:]), memory, out[:3]
 
-    def _dec_attn(self, n, query, key, value):           # (Cross)MultiHeadAttentionBlock, mmcv_spike/transformer.py:196-361
+    def _dec_attn(self, n, query, key, value, attn_mask=None):   # (Cross)MultiHeadAttentionBlock, mmcv_spike/transformer.py:196-361
         t, b, nq, dim = query.shape
         nk = key.shape[2]
         nh = self.cfg.num_heads
@@ -572,6 +572,10 @@ class OracleNet:
 
         q, k, v = proj("q", query, nq), proj("k", key, nk), proj("v", value, nk)
         scores = (q @ k.transpose(3, 4)) / (dim ** 0.5)   # embed_dim**0.5, not head-dim; no softmax (:263, :346)
+        if attn_mask is not None:
+            # :266-269, :349-352 -- reshaped with querys.shape[0] = t where the comment says bs, then broadcast against
+            # [t, b, heads, nq, nk]: runs only for t == b (or b == 1), applying mask[b, h] to every time step
+            scores = scores.masked_fill(attn_mask.reshape(q.shape[0], nh, nq, nk), 0)
         o = scores @ v
         o = o.permute(0, 1, 3, 2, 4).reshape(t, b, nq, dim)
         o = self.lif(n + ".attn_spike", o).permute(0, 1, 3, 2)
@@ -586,10 +590,11 @@ class OracleNet:
         a = self.lif(n + ".fc2_spike", a)
         return self.bn(n + ".bn2", self.conv1d(n + ".fc2", a.flatten(0, 1))).reshape(t, bs, N, C)   # (:781)
 
-    def _dec_layer(self, n, query, key, query_pos, key_pos):   # DetrTransformerDecoderLayer.forward, detr_layers.py:491-559
-        ca = self._dec_attn(n + ".cross_attn.attn", query + query_pos, key + key_pos, key)
+    def _dec_layer(self, n, query, key, query_pos, key_pos, self_attn_mask=None, cross_attn_mask=None):
+        # DetrTransformerDecoderLayer.forward, detr_layers.py:491-559
+        ca = self._dec_attn(n + ".cross_attn.attn", query + query_pos, key + key_pos, key, cross_attn_mask)
         query = query + ca
-        sa = self._dec_attn(n + ".self_attn.attn", query + query_pos, query + query_pos, query)
+        sa = self._dec_attn(n + ".self_attn.attn", query + query_pos, query + query_pos, query, self_attn_mask)
         query = query + sa
         return query + self._dec_ffn(n + ".ffn", query)
 

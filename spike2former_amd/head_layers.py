@@ -314,8 +314,6 @@ class MultiHeadAttentionBlock(nn.Module):
         already formed by the caller (channel-major; the head's fused add + neuron kernel) -- key / value are then unused.
         `query_channel_major`: query is [t,b,dim,nq] and so is the result (the decoder's channel-major query stream: the
         projections and the attention core work on channel-major maps anyway, so nothing is transposed)."""
-        if attn_mask is not None:
-            raise NotImplementedError("attn_mask is always None on the MaskFormerHead path (maskformer_head.py:554-564)")
         if query_channel_major:
             t, b, dim, nq = query.shape
         else:
@@ -335,7 +333,12 @@ class MultiHeadAttentionBlock(nn.Module):
                 lambda: self._proj(self.v_conv_spike, self.v_conv, self.v_spike, value, cm, fv),
                 lambda: self._proj(self.q_conv_spike, self.q_conv, self.q_spike, query, qcm, q_spikes)],
                 inputs=(query, key, value, fk, fv))
-        o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)      # embed_dim**0.5, not head dim
+        if attn_mask is not None:
+            # scores.masked_fill(mask, 0) (transformer.py:266-269, 349-352): the explicit O(nq nk d) form (ops.sdsa_masked); never
+            # taken by the MaskFormerHead path, whose cross_attn_mask is None (dense_heads/maskformer_head.py:554-564)
+            o = self.attn_spike.fire(ops.sdsa_masked(q, k, v, attn_mask, self.num_heads, 1.0 / (self.embed_dim ** 0.5), b))
+        else:
+            o = ops.sdsa(q, k, v, self.num_heads, 1.0 / (self.embed_dim ** 0.5), lif=self.attn_spike)  # embed_dim**0.5, not head dim
         res = residual_cm.reshape(t * b, dim, nq) if (residual_cm is not None and qcm) else None
         o, _ = conv_bn_act(self.out_conv[0], o, self.out_conv[1], residual=res)
         if qcm:

@@ -113,6 +113,52 @@ class _SDSASpikes(torch.autograd.Function):
         return (None, None, None) + out + (None,) * 7
 
 
+class _SDSAMasked(torch.autograd.Function):
+    """out = (scale q k^T).masked_fill(mask, 0) v on channel-major fp32 maps (transformer.py:259-272, 343-355; s2f.h
+    s2f_sdsa_masked_fwd / _bwd).  mask: uint8 [B, heads, Nq, Nk], shared over the time steps."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads, scale):
+        _need_cuda(q, k, v)
+        q, k, v, mask = q.contiguous(), k.contiguous(), v.contiguous(), mask.contiguous()
+        TB, C, Nq = q.shape
+        Nk = k.shape[2]
+        B = mask.shape[0]
+        o = torch.empty_like(q)
+        check(lib.s2f_sdsa_masked_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(o), TB, B, heads, C // heads, Nq, Nk, scale,
+                                      _stream()), "s2f_sdsa_masked_fwd")
+        ctx.save_for_backward(q, k, v, mask)
+        ctx.cfg = (heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, mask = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        go = go.contiguous()
+        TB, C, Nq = q.shape
+        Nk = k.shape[2]
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(lib.s2f_sdsa_masked_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(go), _ptr(gq), _ptr(gk), _ptr(gv), TB, mask.shape[0],
+                                      heads, C // heads, Nq, Nk, scale, _stream()), "s2f_sdsa_masked_bwd")
+        return gq, gk, gv, None, None, None
+
+
+def sdsa_masked(q, k, v, attn_mask, heads, scale, B):
+    """The attention core with an `attn_mask` (True / non-zero = the score is replaced by 0).  q [T*B, C, Nq], k, v [T*B, C, Nk]: fp32
+    tensors or Spikes.  attn_mask: b * heads * Nq * Nk booleans in any shape -- the reference reshapes to (t, heads, nq, nk) and
+    broadcasts against (t, b, heads, nq, nk), which only runs for t == b and then applies mask[b, h] to every time step; that is the
+    semantics here, for any t.  -> fp32 [T*B, C, Nq]."""
+    TB, C, Nq = q.shape
+    Nk = k.shape[2]
+    if C // heads > 64:
+        raise NotImplementedError("sdsa_masked: head dimension > 64")
+    if attn_mask.numel() != B * heads * Nq * Nk:
+        raise RuntimeError(f"attn_mask has {attn_mask.numel()} elements; (batch {B}) x (heads {heads}) x (nq {Nq}) x (nk {Nk}) wanted")
+    m = attn_mask.reshape(B, heads, Nq, Nk).to(device=q.device, dtype=torch.uint8)
+    return _SDSAMasked.apply(spikes_float(q), spikes_float(k), spikes_float(v), m, heads, float(scale))
+
+
 def sdsa(q, k, v, heads, scale, lif=None):
     """o = scale * q (k^T v) on channel-major spike maps.  q, k, v: fp32 tensors or Spikes.  `lif`: the Q_IFNode applied to o
     (the attention's attn_spike); given, the result is its spike map (Spikes) -- from ONE fused kernel when the neuron starts

@@ -154,12 +154,24 @@ def test_blocks_vs_reference(env, golden):
     model.train()
     bb, hd = model.backbone, model.decode_head
     qp, kp = torch.from_numpy(g["dec_layer_qpos"]).cuda(), torch.from_numpy(g["dec_layer_kpos"]).cuda()
+    qp8, kp8 = torch.from_numpy(g["dec_layer_masked_qpos"]).cuda(), torch.from_numpy(g["dec_layer_masked_kpos"]).cuda()
+    sm, cm = torch.from_numpy(g["dec_layer_masked_self_mask"]).cuda(), torch.from_numpy(g["dec_layer_masked_cross_mask"]).cuda()
     cases = {
         "attn": bb.block3[1].attn, "repconv": bb.block3[2].attn.q_conv, "block3": bb.block3[3],
         "dcn": hd.pixel_decoder.encoder.layers[0].dcn, "enc_layer": hd.pixel_decoder.encoder.layers[1],
         "dec_layer": lambda a, b: hd.transformer_decoder.layers[0](query=a, key=b, value=b, query_pos=qp, key_pos=kp),
+        # attention masks (mmcv_spike/transformer.py:266-269, 349-352) in the one geometry where the reference's own reshape runs:
+        # 8 queries, 8 keys, 8 heads, T == B; the generator made the q / k / v BatchNorms of the two blocks dense (gain, bias shift)
+        "dec_layer_masked": lambda a, b: hd.transformer_decoder.layers[0](query=a, key=b, value=b, query_pos=qp8, key_pos=kp8,
+                                                                          self_attn_mask=sm, cross_attn_mask=cm),
     }
+    params = dict(model.named_parameters())
+    gain, shift = (float(v) for v in g["dec_layer_masked_bn_edit"])
     for tag, fn in cases.items():
+        if tag == "dec_layer_masked":
+            with torch.no_grad():
+                for k in g["dec_layer_masked_bn_edit_names"]:
+                    params[str(k)].mul_(gain) if str(k).endswith("weight") else params[str(k)].add_(shift)
         s2f.reset_net(model)
         xs = [torch.from_numpy(g[f"{tag}_x{i}"]).cuda().requires_grad_(True) for i in range(2) if f"{tag}_x{i}" in g.files]
         y, census = spike_census(s2f, model, lambda: fn(*xs))
@@ -175,6 +187,7 @@ def test_blocks_vs_reference(env, golden):
         assert rel(y.detach().cpu(), torch.from_numpy(g[f"{tag}_y"])) <= tol_y, (tag, flipped)
         for i, x in enumerate(xs):
             assert rel(x.grad.cpu(), torch.from_numpy(g[f"{tag}_gx{i}"])) <= tol_g, (tag, i, flipped)
+    model.load_state_dict(so.make_params(cfg, requires_grad=False), strict=True)          # undo the masked case's BatchNorm edit
     pe = hd.decoder_pe(torch.zeros(2, 6, 5, dtype=torch.bool, device="cuda"))
     assert torch.allclose(pe.cpu(), torch.from_numpy(g["pos_embed_2x6x5"]), atol=2e-6)
 

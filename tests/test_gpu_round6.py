@@ -193,3 +193,35 @@ def test_single_pass_batchnorm_statistics_survive_a_large_mean(N, C, L):
     err = (zc.grad.cpu().double() - ref).abs().amax((0, 2)) / ref.abs().amax((0, 2)).clamp_min(1e-30)
     assert err[1:].max().item() <= 5e-3, err
     assert abs(rv[0].item() - 0.9) <= 1e-7                              # running_var of the constant channel: 0.9 * 1 + 0.1 * 0
+
+
+@pytest.mark.parametrize("T,B,heads,d,Nq,Nk", [(2, 2, 8, 8, 8, 8), (4, 2, 8, 32, 100, 1000), (1, 3, 2, 45, 7, 130), (3, 1, 4, 64, 65, 64)])
+def test_masked_attention_core_vs_fp64(T, B, heads, d, Nq, Nk):
+    """ops.sdsa_masked (csrc/sdsa_masked.hip): out = (scale q k^T).masked_fill(mask, 0) v, mask [B, heads, Nq, Nk] shared over the time
+    steps, on spike operands -- every product and partial sum is exact in fp32, so the result must equal the fp64 evaluation of the
+    reference's expression (mmcv_spike/transformer.py:262-272) BIT FOR BIT, forward and all three gradients (with an integer-valued
+    output gradient); ragged token counts, head dimensions up to 64, t != b."""
+    from spike2former_amd import ops
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    C = heads * d
+    q = torch.randint(0, 9, (T * B, C, Nq), generator=g).float() / 8
+    k = torch.randint(0, 9, (T * B, C, Nk), generator=g).float() / 8
+    v = torch.randint(0, 9, (T * B, C, Nk), generator=g).float() / 8
+    mask = torch.rand(B * heads, Nq, Nk, generator=g) < 0.4
+    go = torch.randint(-4, 5, (T * B, C, Nq), generator=g).float()
+    scale = 1.0 / 16
+    qd, kd, vd = (t.double().view(T, B, heads, d, -1).transpose(3, 4).requires_grad_(True) for t in (q, k, v))          # [t, b, h, n, d]
+    scores = (qd @ kd.transpose(3, 4)) * scale
+    scores = scores.masked_fill(mask.view(1, B, heads, Nq, Nk), 0)
+    o64 = (scores @ vd).transpose(3, 4).reshape(T * B, C, Nq)
+    o64.backward(go.double())
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    o = ops.sdsa_masked(qc, kc, vc, mask.cuda(), heads, scale, B)
+    o.backward(go.cuda())
+    assert torch.equal(o.detach().cpu().double(), o64.detach())
+    for mine, ref in ((qc, qd), (kc, kd), (vc, vd)):
+        want = ref.grad.transpose(3, 4).reshape(mine.shape)
+        assert torch.equal(mine.grad.cpu().double(), want)
+    # no mask bit set: the unmasked core (q (k^T v) on the matrix cores / VALU kernels of sdsa.hip)
+    o0 = ops.sdsa_masked(qc.detach(), kc.detach(), vc.detach(), torch.zeros_like(mask).cuda(), heads, scale, B)
+    assert torch.equal(o0, ops.sdsa(qc.detach(), kc.detach(), vc.detach(), heads, scale))
