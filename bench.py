@@ -429,16 +429,19 @@ def main():
                 for f_ in ("bn_lif.hip", "lif.hip"):
                     h.update(open(os.path.join(ROOT, "spike2former_amd", "csrc", f_), "rb").read())
                 sha = h.hexdigest()[:16]
-                path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+                import glob
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))          # the newest round's profile
+                path = cands[-1] if cands else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                pname = "profiles/" + os.path.basename(path)
                 if os.path.exists(path):
                     with open(path) as f:
                         prof = json.load(f)
                     if prof.get("streaming_kernel_sources_sha16") == sha:
                         traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["kernels"].items()}
-                        traffic_src = ("profiles/r05_pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command on the "
+                        traffic_src = (pname + " (rocprofv3 --pmc passes of an earlier run of this command on the "
                                        "same kernel sources, not measured in this run)")
                     else:
-                        traffic_src = "profiles/r05_pmc_traffic.json is STALE (the streaming kernels changed since): traffic not reported"
+                        traffic_src = pname + " is STALE (the streaming kernels changed since): traffic not reported"
             except (OSError, KeyError, ValueError):
                 pass
             if args.dump_events:

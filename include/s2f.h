@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 25
+#define S2F_ABI_VERSION 26
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -620,6 +620,19 @@ int s2f_fill(float* p, int64_t n, const float* value_ptr, float value, void* str
 int s2f_channel_sum_slices(int N, int C, int L);
 int s2f_channel_sum(const float* x, int N, int C, int L, float* workspace, float* out, int accumulate, void* stream);
 int s2f_sum_lead(const float* x, int T, int64_t M, float* out, void* stream);
+/* The residual glue of a step as generic strided kernels (host: ops/glue_mode.py, a TorchDispatchMode that routes the aten calls autograd
+ * and the module code still make -- gradient accumulation where two consumers meet, scalar multiples, sigmoid, layout copies, dtype
+ * casts, small sums -- to these instead of ATen's kernels, and reports what it could not route).
+ *   s2f_ew          out[..] = f(a[..], b?[..]) over an index space of ndim <= 6 dimensions; size / sa / sb / so: extents and ELEMENT strides
+ *                   (0 = broadcast), host arrays of ndim entries.  op: 0 copy | 1 a + alpha b | 2 a b | 3 a / b | 4 sigmoid(a) |
+ *                   5 (a (1 - b)) b  [sigmoid_backward(grad = a, output = b)] | 6 a alpha + beta | 7 a / alpha | 8 a - alpha b.
+ *                   a_bf16: a is bf16 (a dtype cast); flat != 0: every operand contiguous over the same elements (16-byte accesses).
+ *   s2f_reduce_sum  out[o] = scale * sum_r a[off(o) + off(r)]: kept index space (nd_o <= 6; may be 0) and reduced index space (1 <= nd_r <= 6),
+ *                   one wavefront per output element, fixed summation order. */
+int s2f_ew(int op, const void* a, const float* b, float* out, int ndim, const int64_t* size, const int64_t* sa, const int64_t* sb,
+           const int64_t* so, float alpha, float beta, int a_bf16, int flat, void* stream);
+int s2f_reduce_sum(const float* a, float* out, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so, int nd_r,
+                   const int64_t* size_r, const int64_t* sa_r, float scale, void* stream);
 
 /* ---- masked spike-driven attention (csrc/sdsa_masked.hip, round 6) -------------------------------------------------------------
  * The `attn_mask` branch of (Cross)MultiHeadAttentionBlock.forward (mmcv_spike/transformer.py:259-272, 343-355):

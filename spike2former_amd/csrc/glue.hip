@@ -109,6 +109,109 @@ __global__ __launch_bounds__(kBlock) void sum_lead_kernel(const float* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Generic strided element-wise and reduction kernels: the residual glue of the step (autograd's gradient accumulation where two
+// consumers meet, scalar multiples, sigmoid, layout copies, dtype casts, small sums) that ops/glue_mode.py routes here instead of
+// ATen.  Index space of up to 6 dimensions, element strides per operand (0 = broadcast).  Same IEEE operations as ATen's kernels for
+// add / mul / div / copy (bit-identical results); sigmoid = 1 / (1 + expf(-x)).
+constexpr int kMaxDim = 6;
+struct EwArgs {
+  const void* a;
+  const float* b;
+  float* out;
+  long long n;
+  int ndim, op, a_bf16;
+  long long size[kMaxDim], sa[kMaxDim], sb[kMaxDim], so[kMaxDim];
+  float alpha, beta;
+};
+// ops: 0 copy a | 1 a + alpha b | 2 a * b | 3 a / b | 4 sigmoid(a) | 5 (a * (1 - b)) * b  [sigmoid_backward(grad = a, out = b)]
+//      6 a * alpha + beta | 7 a / alpha | 8 a - alpha b
+__device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha, float beta) {
+  switch (op) {
+    case 0: return a;
+    case 1: return alpha == 1.f ? a + b : a + alpha * b;
+    case 2: return a * b;
+    case 3: return a / b;
+    case 4: return 1.0f / (1.0f + expf(-a));
+    case 5: return (a * (1.0f - b)) * b;
+    case 6: return beta == 0.f ? a * alpha : a * alpha + beta;
+    case 7: return a / alpha;
+    default: return a - alpha * b;
+  }
+}
+__device__ __forceinline__ float ew_load_a(const void* a, long long i, int bf16) {
+  return bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a)[i] << 16) : reinterpret_cast<const float*>(a)[i];
+}
+
+// every operand contiguous over the same n elements (fp32): 16-byte accesses
+__global__ __launch_bounds__(kBlock) void ew_flat_kernel(EwArgs p) {
+  const long long n4 = p.n >> 2;
+  const float4* A = reinterpret_cast<const float4*>(p.a);
+  const float4* B = reinterpret_cast<const float4*>(p.b);
+  float4* O = reinterpret_cast<float4*>(p.out);
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+    const float4 a = A[i], b = p.b ? B[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    O[i] = make_float4(ew_apply(p.op, a.x, b.x, p.alpha, p.beta), ew_apply(p.op, a.y, b.y, p.alpha, p.beta),
+                       ew_apply(p.op, a.z, b.z, p.alpha, p.beta), ew_apply(p.op, a.w, b.w, p.alpha, p.beta));
+  }
+  for (long long i = 4 * n4 + (long long)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (long long)gridDim.x * kBlock)
+    p.out[i] = ew_apply(p.op, reinterpret_cast<const float*>(p.a)[i], p.b ? p.b[i] : 0.f, p.alpha, p.beta);
+}
+
+__global__ __launch_bounds__(kBlock) void ew_strided_kernel(EwArgs p) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (long long)gridDim.x * kBlock) {
+    long long r = i, ia = 0, ib = 0, io = 0;
+#pragma unroll
+    for (int d = kMaxDim - 1; d >= 0; --d) {
+      if (d < p.ndim) {
+        const long long c = r % p.size[d];
+        r /= p.size[d];
+        ia += c * p.sa[d], ib += c * p.sb[d], io += c * p.so[d];
+      }
+    }
+    p.out[io] = ew_apply(p.op, ew_load_a(p.a, ia, p.a_bf16), p.b ? p.b[ib] : 0.f, p.alpha, p.beta);
+  }
+}
+
+// out[o] = scale * sum_r a[off(o) + off(r)]: one wavefront per output element, lanes stride over the reduced index space, lane sums added
+// by the DPP tree (a fixed order: deterministic)
+struct RedArgs {
+  const float* a;
+  float* out;
+  long long n_out, n_red;
+  int nd_o, nd_r;
+  long long size_o[kMaxDim], sa_o[kMaxDim], so[kMaxDim], size_r[kMaxDim], sa_r[kMaxDim];
+  float scale;
+};
+__global__ __launch_bounds__(kBlock) void reduce_sum_kernel(RedArgs p) {
+  const int lane = threadIdx.x & 63;
+  for (long long o = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); o < p.n_out; o += (long long)gridDim.x * (kBlock / 64)) {
+    long long r = o, ia = 0, io = 0;
+#pragma unroll
+    for (int d = kMaxDim - 1; d >= 0; --d)
+      if (d < p.nd_o) {
+        const long long c = r % p.size_o[d];
+        r /= p.size_o[d];
+        ia += c * p.sa_o[d], io += c * p.so[d];
+      }
+    float acc = 0.f;
+    for (long long j = lane; j < p.n_red; j += 64) {
+      long long q = j, off = 0;
+#pragma unroll
+      for (int d = kMaxDim - 1; d >= 0; --d)
+        if (d < p.nd_r) {
+          const long long c = q % p.size_r[d];
+          q /= p.size_r[d];
+          off += c * p.sa_r[d];
+        }
+      acc += p.a[ia + off];
+    }
+    acc = s2f_wave_sum_lane63(acc);
+    if (lane == 63) p.out[io] = acc * p.scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t s2f_sum_all_parts(int64_t n) { return n <= 0 ? 0 : (n + kPerBlock - 1) / kPerBlock; }
@@ -158,4 +261,44 @@ extern "C" int s2f_sum_lead(const float* x, int T, int64_t M, float* out, void* 
   blocks = blocks > 4096 ? 4096 : blocks;
   hipLaunchKernelGGL(sum_lead_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, T, M / 4, out);
   return s2f_check_launch("s2f_sum_lead");
+}
+
+extern "C" int s2f_ew(int op, const void* a, const float* b, float* out, int ndim, const int64_t* size, const int64_t* sa, const int64_t* sb,
+                      const int64_t* so, float alpha, float beta, int a_bf16, int flat, void* stream) {
+  S2F_REQUIRE(a && out && ndim >= 0 && ndim <= kMaxDim && op >= 0 && op <= 8, S2F_EINVAL, "s2f_ew: null pointer, ndim > %d or unknown op", kMaxDim);
+  S2F_REQUIRE(b || (op == 0 || op == 4 || op == 6 || op == 7), S2F_EINVAL, "s2f_ew: op %d needs a second operand", op);
+  EwArgs p{};
+  p.a = a, p.b = b, p.out = out, p.ndim = ndim, p.op = op, p.a_bf16 = a_bf16, p.alpha = alpha, p.beta = beta;
+  long long n = 1;
+  for (int d = 0; d < ndim; ++d) {
+    S2F_REQUIRE(size[d] > 0, S2F_EINVAL, "s2f_ew: empty dimension");
+    p.size[d] = size[d], p.sa[d] = sa[d], p.sb[d] = b ? sb[d] : 0, p.so[d] = so[d];
+    n *= size[d];
+  }
+  p.n = n;
+  long long blocks = (n + kBlock * 4 - 1) / (kBlock * 4);
+  blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+  if (flat) {
+    S2F_REQUIRE(!a_bf16 && s2f_aligned16(a) && s2f_aligned16(out) && s2f_aligned16(b), S2F_EALIGN, "s2f_ew: the flat form needs fp32, 16-byte aligned operands");
+    hipLaunchKernelGGL(ew_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(ew_strided_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+  }
+  return s2f_check_launch("s2f_ew");
+}
+
+extern "C" int s2f_reduce_sum(const float* a, float* out, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so, int nd_r,
+                              const int64_t* size_r, const int64_t* sa_r, float scale, void* stream) {
+  S2F_REQUIRE(a && out && nd_o >= 0 && nd_o <= kMaxDim && nd_r >= 1 && nd_r <= kMaxDim, S2F_EINVAL, "s2f_reduce_sum: null pointer or too many dimensions");
+  RedArgs p{};
+  p.a = a, p.out = out, p.nd_o = nd_o, p.nd_r = nd_r, p.scale = scale;
+  long long no = 1, nr = 1;
+  for (int d = 0; d < nd_o; ++d) p.size_o[d] = size_o[d], p.sa_o[d] = sa_o[d], p.so[d] = so[d], no *= size_o[d];
+  for (int d = 0; d < nd_r; ++d) p.size_r[d] = size_r[d], p.sa_r[d] = sa_r[d], nr *= size_r[d];
+  S2F_REQUIRE(no > 0 && nr > 0, S2F_EINVAL, "s2f_reduce_sum: empty index space");
+  p.n_out = no, p.n_red = nr;
+  long long blocks = (no + kBlock / 64 - 1) / (kBlock / 64);
+  blocks = blocks > 16384 ? 16384 : blocks;
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+  return s2f_check_launch("s2f_reduce_sum");
 }

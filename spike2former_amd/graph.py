@@ -49,6 +49,9 @@ class GraphedStep:
         with torch.cuda.stream(side):                  # warm-up on a side stream (allocator pools, lazy inits, caches)
             for _ in range(warmup):
                 self._eager_step()
+        if ops.GLUE_MODE:                              # one more warm-up on the launch structure that is captured (ops.GlueMode)
+            with torch.cuda.stream(side), ops.glue_mode():
+                self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         ops.resplit_all(self.static_in.device)          # builds the weight-split job table the captured step replays
         torch.cuda.synchronize()
@@ -56,7 +59,9 @@ class GraphedStep:
         # keeps its (legal, uncaptured) calls from invalidating the capture; single-process runs keep the strict default.
         import torch.distributed as dist
         mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+        # ops.GLUE_MODE: the residual aten calls of the step (autograd's gradient accumulation, scalar multiples, copies, fills, small
+        # sums) are routed to csrc/glue.hip while the step is RECORDED -- the replay then consists of this package's kernels only
+        with torch.cuda.graph(self.graph, capture_error_mode=mode), ops.glue_mode():
             self.static_loss = self._eager_step()
         torch.cuda.synchronize()
         # the graph bakes in the addresses of the conversion job tables and of every cached split / pack buffer: hold them (an

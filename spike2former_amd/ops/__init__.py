@@ -7,6 +7,8 @@ import types
 
 from . import attention, bn, config, conv, core, gemm, misc, neuron
 from .config import cfg
+from . import glue_mode as glue  # noqa: F401  (the module: ops.glue.ROUTED / UNROUTED / HANDLERS)
+from .glue_mode import GlueMode, glue_mode  # noqa: F401  (ops.glue_mode(): the context manager)
 
 for _m in (core, misc, neuron, attention, bn, gemm, conv):
     for _k, _v in vars(_m).items():

@@ -5,7 +5,7 @@ import os
 
 
 class Config:
-    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "STRICT")
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "GLUE_MODE", "STRICT_GLUE", "STRICT")
     RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
 
     def __init__(self):
@@ -55,12 +55,17 @@ class Config:
         # an optimiser step multiplies by the current weights.  False: frozen weights (an inference graph) -- the conversions of capture
         # time are replayed against; a weight update then needs a new capture
         self.RESPLIT_IN_GRAPH = True
+        # GLUE_MODE: the captured steps (graph.py) run their warm-up and capture under ops.GlueMode -- the residual aten calls of a step
+        # (autograd's gradient accumulation, scalar multiples, sigmoid, copies, fills, small sums) on csrc/glue.hip instead of ATen;
+        # STRICT_GLUE: an aten call that GlueMode cannot route and that touches a CUDA tensor is an error
+        self.GLUE_MODE = os.environ.get("S2F_GLUE_MODE", "0") != "0"
+        self.STRICT_GLUE = os.environ.get("S2F_STRICT_GLUE", "0") != "0"
         # STRICT: a shape that leaves this package's kernels for a library / ATen path is an error, not a slower number
         self.STRICT = os.environ.get("S2F_STRICT", "0") != "0"
 
     def snapshot(self):
         """the settings a captured hipGraph depends on (scalars only)"""
-        return {n: getattr(self, n) for n in self.FIELDS if n not in self.RUNTIME and n != "STRICT"}          # (STRICT selects no launch)
+        return {n: getattr(self, n) for n in self.FIELDS if n not in self.RUNTIME and n not in ("STRICT", "STRICT_GLUE")}          # (STRICT selects no launch)
 
 
 cfg = Config()

@@ -225,3 +225,44 @@ def test_masked_attention_core_vs_fp64(T, B, heads, d, Nq, Nk):
     # no mask bit set: the unmasked core (q (k^T v) on the matrix cores / VALU kernels of sdsa.hip)
     o0 = ops.sdsa_masked(qc.detach(), kc.detach(), vc.detach(), torch.zeros_like(mask).cuda(), heads, scale, B)
     assert torch.equal(o0, ops.sdsa(qc.detach(), kc.detach(), vc.detach(), heads, scale))
+
+
+def test_glue_mode_routes_the_residual_aten_calls_of_a_step():
+    """ops.GlueMode on a C1_64 train step: the aten calls that the module code and autograd's engine still make (gradient accumulation
+    where two consumers meet, alpha * spikes, sigmoid, stack / cat, copies, fills, small sums) run on csrc/glue.hip.  Element-wise
+    routes are the same IEEE operations: mask logits bit-identical; the class scores pass one routed mean over T (fixed-order sum): 1e-6;
+    gradients 1e-5.  Under STRICT_GLUE nothing that touches a CUDA tensor may reach ATen."""
+    import spike2former_amd as s2f
+    from oracle import s2f_oracle as so
+    from spike2former_amd import ops
+    cfg = so.CONFIGS["C1_64"]
+    model = s2f.MODELS.build(s2f.model_cfg("C1_64"))
+    model.load_state_dict(so.make_params(cfg, requires_grad=False), strict=True)
+    model.cuda().train()
+    s2f.set_keep_membrane(model, False)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    img = so.synthetic_image(cfg, seed=9).cuda()
+    runs = []
+    strict = ops.STRICT_GLUE
+    try:
+        for on in (False, True):
+            model.load_state_dict(state)
+            s2f.reset_net(model); model.zero_grad(set_to_none=True)
+            ops.glue.reset_counts()
+            ops.STRICT_GLUE = on
+            with ops.glue_mode(force=on):
+                cls, masks = model(img)
+                s2f.headline_loss(cls, masks).backward()
+            torch.cuda.synchronize()
+            runs.append((cls.detach().clone(), masks.detach().clone(),
+                         {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        ops.STRICT_GLUE = strict
+    assert sum(ops.glue.ROUTED.values()) > 100 and not ops.glue.UNROUTED, (dict(ops.glue.ROUTED), dict(ops.glue.UNROUTED))
+    (c0, m0, g0), (c1, m1, g1) = runs
+    assert torch.equal(m0, m1)
+    assert (c0 - c1).abs().max().item() <= 1e-6 * c0.abs().max().item()
+    assert g0.keys() == g1.keys()
+    gscale = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * (g0[k].abs().max().item() + 1e-3 * gscale), k
