@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 26
+#define S2F_ABI_VERSION 27
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -628,11 +628,16 @@ int s2f_sum_lead(const float* x, int T, int64_t M, float* out, void* stream);
  *                   5 (a (1 - b)) b  [sigmoid_backward(grad = a, output = b)] | 6 a alpha + beta | 7 a / alpha | 8 a - alpha b.
  *                   a_bf16: a is bf16 (a dtype cast); flat != 0: every operand contiguous over the same elements (16-byte accesses).
  *   s2f_reduce_sum  out[o] = scale * sum_r a[off(o) + off(r)]: kept index space (nd_o <= 6; may be 0) and reduced index space (1 <= nd_r <= 6),
- *                   one wavefront per output element, fixed summation order. */
+ *                   the reduced space cut into pieces whose partial sums are stored and added in order (deterministic);
+ *                   one wavefront per (output, piece), or one lane per output when consecutive outputs are adjacent in memory. */
 int s2f_ew(int op, const void* a, const float* b, float* out, int ndim, const int64_t* size, const int64_t* sa, const int64_t* sb,
            const int64_t* so, float alpha, float beta, int a_bf16, int flat, void* stream);
-int s2f_reduce_sum(const float* a, float* out, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so, int nd_r,
-                   const int64_t* size_r, const int64_t* sa_r, float scale, void* stream);
+/* up to eight contiguous fp32 pieces (each a multiple of 4 elements, 16-byte aligned) copied back to back into dst: torch.stack / cat along
+ * the leading dimension as one launch; srcs / ns: HOST arrays of `count` entries */
+int s2f_copy_segments(float* dst, const void* const* srcs, const int64_t* ns, int count, void* stream);
+int64_t s2f_reduce_sum_workspace(int64_t n_out, int64_t n_red);          /* floats of scratch for the call below */
+int s2f_reduce_sum(const float* a, float* out, float* workspace, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so,
+                   int nd_r, const int64_t* size_r, const int64_t* sa_r, float scale, void* stream);
 
 /* ---- masked spike-driven attention (csrc/sdsa_masked.hip, round 6) -------------------------------------------------------------
  * The `attn_mask` branch of (Cross)MultiHeadAttentionBlock.forward (mmcv_spike/transformer.py:259-272, 343-355):

@@ -129,7 +129,9 @@ SIGNATURES = {
     "s2f_sdsa_masked_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "s2f_sdsa_masked_bwd": (_i, [_p] * 8 + [_i] * 6 + [_f, _p]),
     "s2f_ew": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _f, _f, _i, _i, _p]),
-    "s2f_reduce_sum": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _p, _f, _p]),
+    "s2f_copy_segments": (_i, [_p, _p, _p, _i, _p]),
+    "s2f_reduce_sum_workspace": (_i64, [_i64, _i64]),
+    "s2f_reduce_sum": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _f, _p]),
     "s2f_bmm_f32": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
     "s2f_adamw_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, ctypes.c_double, ctypes.c_double, _f, _p]),
 }

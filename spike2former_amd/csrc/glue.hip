@@ -159,6 +159,27 @@ __global__ __launch_bounds__(kBlock) void ew_flat_kernel(EwArgs p) {
     p.out[i] = ew_apply(p.op, reinterpret_cast<const float*>(p.a)[i], p.b ? p.b[i] : 0.f, p.alpha, p.beta);
 }
 
+// the same with the innermost dimension walked in 16-byte groups: size[ndim - 1] counts float4s, every operand's innermost stride is 1 (b may be
+// absent), the other strides and the base pointers are multiples of 4 elements / 16 bytes
+__global__ __launch_bounds__(kBlock) void ew_strided4_kernel(EwArgs p) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (long long)gridDim.x * kBlock) {
+    long long r = i, ia = 0, ib = 0, io = 0;
+#pragma unroll
+    for (int d = kMaxDim - 1; d >= 0; --d) {
+      if (d < p.ndim) {
+        const long long c = r % p.size[d];
+        r /= p.size[d];
+        const long long m = d == p.ndim - 1 ? 4 : 1;
+        ia += c * p.sa[d] * m, ib += c * p.sb[d] * m, io += c * p.so[d] * m;
+      }
+    }
+    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.a) + ia);
+    const float4 b = p.b ? *reinterpret_cast<const float4*>(p.b + ib) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(p.out + io) = make_float4(ew_apply(p.op, a.x, b.x, p.alpha, p.beta), ew_apply(p.op, a.y, b.y, p.alpha, p.beta),
+                                                          ew_apply(p.op, a.z, b.z, p.alpha, p.beta), ew_apply(p.op, a.w, b.w, p.alpha, p.beta));
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void ew_strided_kernel(EwArgs p) {
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (long long)gridDim.x * kBlock) {
     long long r = i, ia = 0, ib = 0, io = 0;
@@ -174,41 +195,98 @@ __global__ __launch_bounds__(kBlock) void ew_strided_kernel(EwArgs p) {
   }
 }
 
-// out[o] = scale * sum_r a[off(o) + off(r)]: one wavefront per output element, lanes stride over the reduced index space, lane sums added
-// by the DPP tree (a fixed order: deterministic)
+
+// up to eight contiguous fp32 pieces copied back to back into one destination (torch.stack / cat along the leading dimension):
+// blockIdx.y = piece; 16-byte accesses (every piece a multiple of 4 elements, 16-byte aligned)
+struct SegArgs {
+  float* dst;
+  const float* src[8];
+  long long n[8], at[8];
+};
+__global__ __launch_bounds__(kBlock) void copy_segments_kernel(SegArgs p) {
+  const int s = blockIdx.y;
+  const float4* src = reinterpret_cast<const float4*>(p.src[s]);
+  float4* dst = reinterpret_cast<float4*>(p.dst + p.at[s]);
+  const long long n4 = p.n[s] >> 2;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) dst[i] = src[i];
+}
+
+// out[o] = scale * sum_r a[off(o) + off(r)] in two levels: the reduced index space is cut into S equal pieces, partial[s][o] is STORED,
+// and a second kernel adds the S partials of every output in order (deterministic, no atomics).  Two first-level forms:
+//   rows: one wavefront per (output, piece), lanes stride over the piece (coalesced when the reduced space is contiguous), DPP lane sum;
+//   cols: one LANE per output -- 64 consecutive outputs per wavefront, coalesced when consecutive outputs are adjacent in memory (a sum
+//         over leading dimensions: bias / embedding gradients) -- each lane walking the piece serially.
 struct RedArgs {
   const float* a;
-  float* out;
-  long long n_out, n_red;
-  int nd_o, nd_r;
+  float* part;          // [S][n_out]; S == 1: the output itself (addressed through so, scaled)
+  long long n_out, n_red, chunk;
+  int nd_o, nd_r, S;
   long long size_o[kMaxDim], sa_o[kMaxDim], so[kMaxDim], size_r[kMaxDim], sa_r[kMaxDim];
   float scale;
 };
-__global__ __launch_bounds__(kBlock) void reduce_sum_kernel(RedArgs p) {
+__device__ __forceinline__ long long red_off(long long idx, int nd, const long long* size, const long long* stride) {
+  long long off = 0;
+#pragma unroll
+  for (int d = kMaxDim - 1; d >= 0; --d)
+    if (d < nd) {
+      const long long c = idx % size[d];
+      idx /= size[d];
+      off += c * stride[d];
+    }
+  return off;
+}
+__global__ __launch_bounds__(kBlock) void reduce_rows_kernel(RedArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long items = p.n_out * p.S;
+  for (long long it = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); it < items; it += (long long)gridDim.x * (kBlock / 64)) {
+    const long long o = it % p.n_out, sidx = it / p.n_out;
+    const long long ia = red_off(o, p.nd_o, p.size_o, p.sa_o);
+    const long long j0 = sidx * p.chunk, j1 = min(p.n_red, j0 + p.chunk);
+    float acc = 0.f;
+    for (long long j = j0 + lane; j < j1; j += 64) acc += p.a[ia + red_off(j, p.nd_r, p.size_r, p.sa_r)];
+    acc = s2f_wave_sum_lane63(acc);
+    if (lane == 63) {
+      if (p.S == 1)
+        p.part[red_off(o, p.nd_o, p.size_o, p.so)] = acc * p.scale;
+      else
+        p.part[sidx * p.n_out + o] = acc;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void reduce_cols_kernel(RedArgs p) {
+  const long long o = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long sidx = blockIdx.y;
+  if (o >= p.n_out) return;
+  const long long ia = red_off(o, p.nd_o, p.size_o, p.sa_o);
+  const long long j0 = sidx * p.chunk, j1 = min(p.n_red, j0 + p.chunk);
+  float acc = 0.f;
+  if (p.nd_r == 1) {
+    const long long st = p.sa_r[0];
+    for (long long j = j0; j < j1; ++j) acc += p.a[ia + j * st];
+  } else {
+    for (long long j = j0; j < j1; ++j) acc += p.a[ia + red_off(j, p.nd_r, p.size_r, p.sa_r)];
+  }
+  if (p.S == 1)
+    p.part[red_off(o, p.nd_o, p.size_o, p.so)] = acc * p.scale;
+  else
+    p.part[sidx * p.n_out + o] = acc;
+}
+struct RedFinal {
+  const float* part;
+  float* out;
+  long long n_out;
+  int S, nd_o;
+  long long size_o[kMaxDim], so[kMaxDim];
+  float scale;
+};
+// one wavefront per output: lanes stride over the S partials (a fixed assignment), DPP lane sum -- deterministic
+__global__ __launch_bounds__(kBlock) void reduce_final_kernel(RedFinal p) {
   const int lane = threadIdx.x & 63;
   for (long long o = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); o < p.n_out; o += (long long)gridDim.x * (kBlock / 64)) {
-    long long r = o, ia = 0, io = 0;
-#pragma unroll
-    for (int d = kMaxDim - 1; d >= 0; --d)
-      if (d < p.nd_o) {
-        const long long c = r % p.size_o[d];
-        r /= p.size_o[d];
-        ia += c * p.sa_o[d], io += c * p.so[d];
-      }
     float acc = 0.f;
-    for (long long j = lane; j < p.n_red; j += 64) {
-      long long q = j, off = 0;
-#pragma unroll
-      for (int d = kMaxDim - 1; d >= 0; --d)
-        if (d < p.nd_r) {
-          const long long c = q % p.size_r[d];
-          q /= p.size_r[d];
-          off += c * p.sa_r[d];
-        }
-      acc += p.a[ia + off];
-    }
+    for (int s = lane; s < p.S; s += 64) acc += p.part[(long long)s * p.n_out + o];
     acc = s2f_wave_sum_lane63(acc);
-    if (lane == 63) p.out[io] = acc * p.scale;
+    if (lane == 63) p.out[red_off(o, p.nd_o, p.size_o, p.so)] = acc * p.scale;
   }
 }
 
@@ -282,23 +360,86 @@ extern "C" int s2f_ew(int op, const void* a, const float* b, float* out, int ndi
     S2F_REQUIRE(!a_bf16 && s2f_aligned16(a) && s2f_aligned16(out) && s2f_aligned16(b), S2F_EALIGN, "s2f_ew: the flat form needs fp32, 16-byte aligned operands");
     hipLaunchKernelGGL(ew_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
   } else {
-    hipLaunchKernelGGL(ew_strided_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+    // innermost dimension in 16-byte groups when every operand walks it contiguously and everything else is 16-byte aligned
+    bool v4 = !a_bf16 && ndim >= 1 && (size[ndim - 1] & 3) == 0 && sa[ndim - 1] == 1 && so[ndim - 1] == 1 && (!b || sb[ndim - 1] == 1) &&
+              s2f_aligned16(a) && s2f_aligned16(out) && s2f_aligned16(b);
+    for (int d = 0; v4 && d < ndim - 1; ++d) v4 = (sa[d] & 3) == 0 && (so[d] & 3) == 0 && (!b || (sb[d] & 3) == 0);
+    if (v4) {
+      p.size[ndim - 1] >>= 2;
+      p.n >>= 2;
+      long long b4 = (p.n + kBlock - 1) / kBlock;
+      b4 = b4 < 1 ? 1 : (b4 > 8192 ? 8192 : b4);
+      hipLaunchKernelGGL(ew_strided4_kernel, dim3((unsigned)b4), dim3(kBlock), 0, (hipStream_t)stream, p);
+    } else {
+      hipLaunchKernelGGL(ew_strided_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+    }
   }
   return s2f_check_launch("s2f_ew");
 }
 
-extern "C" int s2f_reduce_sum(const float* a, float* out, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so, int nd_r,
-                              const int64_t* size_r, const int64_t* sa_r, float scale, void* stream) {
-  S2F_REQUIRE(a && out && nd_o >= 0 && nd_o <= kMaxDim && nd_r >= 1 && nd_r <= kMaxDim, S2F_EINVAL, "s2f_reduce_sum: null pointer or too many dimensions");
+// pieces of the reduced space: none when there are plenty of outputs already; otherwise enough (output, piece) items to fill the chip,
+// pieces of at least 64 elements (rows form) -- or of 16 (cols form, chosen by the caller of the kernel: one lane per output)
+static int64_t red_pieces(int64_t n_out, int64_t n_red, bool cols) {
+  if (n_out <= 0 || n_red <= 0) return 0;
+  if (n_out >= 16384) return 1;
+  const int64_t grain = cols ? 16 : 64;
+  int64_t S = (16384 + n_out - 1) / n_out;
+  const int64_t most = (n_red + grain - 1) / grain;
+  if (S > most) S = most;
+  if (S < 1) S = 1;
+  return S > 8192 ? 8192 : S;
+}
+extern "C" int64_t s2f_reduce_sum_workspace(int64_t n_out, int64_t n_red) {
+  const int64_t a = red_pieces(n_out, n_red, false), b = red_pieces(n_out, n_red, true);
+  return (a > b ? a : b) * (n_out > 0 ? n_out : 0);
+}
+
+extern "C" int s2f_reduce_sum(const float* a, float* out, float* workspace, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so,
+                              int nd_r, const int64_t* size_r, const int64_t* sa_r, float scale, void* stream) {
+  S2F_REQUIRE(a && out && workspace && nd_o >= 0 && nd_o <= kMaxDim && nd_r >= 1 && nd_r <= kMaxDim, S2F_EINVAL,
+              "s2f_reduce_sum: null pointer or too many dimensions");
   RedArgs p{};
-  p.a = a, p.out = out, p.nd_o = nd_o, p.nd_r = nd_r, p.scale = scale;
+  RedFinal f{};
   long long no = 1, nr = 1;
-  for (int d = 0; d < nd_o; ++d) p.size_o[d] = size_o[d], p.sa_o[d] = sa_o[d], p.so[d] = so[d], no *= size_o[d];
+  for (int d = 0; d < nd_o; ++d) p.size_o[d] = f.size_o[d] = size_o[d], p.sa_o[d] = sa_o[d], p.so[d] = f.so[d] = so[d], no *= size_o[d];
   for (int d = 0; d < nd_r; ++d) p.size_r[d] = size_r[d], p.sa_r[d] = sa_r[d], nr *= size_r[d];
   S2F_REQUIRE(no > 0 && nr > 0, S2F_EINVAL, "s2f_reduce_sum: empty index space");
-  p.n_out = no, p.n_red = nr;
-  long long blocks = (no + kBlock / 64 - 1) / (kBlock / 64);
-  blocks = blocks > 16384 ? 16384 : blocks;
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+  // consecutive outputs adjacent in memory and plenty of them: one lane per output (coalesced across the outputs)
+  const bool cols = nd_o >= 1 && sa_o[nd_o - 1] == 1 && no >= 256;
+  const long long S = red_pieces(no, nr, cols);
+  S2F_REQUIRE(S <= 65535, S2F_EINVAL, "s2f_reduce_sum: too many pieces");
+  p.a = a, p.part = S == 1 ? out : workspace, p.n_out = no, p.n_red = nr, p.nd_o = nd_o, p.nd_r = nd_r, p.S = (int)S, p.chunk = (nr + S - 1) / S;
+  p.scale = scale;
+  f.part = workspace, f.out = out, f.n_out = no, f.S = (int)S, f.nd_o = nd_o, f.scale = scale;
+  hipStream_t s = (hipStream_t)stream;
+  if (cols) {
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((no + kBlock - 1) / kBlock), (unsigned)S), dim3(kBlock), 0, s, p);
+  } else {
+    long long blocks = (no * S + kBlock / 64 - 1) / (kBlock / 64);
+    blocks = blocks > 16384 ? 16384 : blocks;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, p);
+  }
+  if (S > 1) {
+    long long blocks = (no + kBlock / 64 - 1) / (kBlock / 64);
+    blocks = blocks > 16384 ? 16384 : blocks;
+    hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, f);
+  }
   return s2f_check_launch("s2f_reduce_sum");
+}
+
+extern "C" int s2f_copy_segments(float* dst, const void* const* srcs, const int64_t* ns, int count, void* stream) {
+  S2F_REQUIRE(dst && srcs && ns && count >= 1 && count <= 8 && s2f_aligned16(dst), S2F_EINVAL, "s2f_copy_segments: 1 .. 8 pieces, 16-byte aligned destination");
+  SegArgs p{};
+  p.dst = dst;
+  long long at = 0, most = 0;
+  for (int i = 0; i < count; ++i) {
+    S2F_REQUIRE(srcs[i] && ns[i] > 0 && (ns[i] & 3) == 0 && s2f_aligned16(srcs[i]), S2F_EINVAL, "s2f_copy_segments: piece %d: null, empty, not a multiple of 4 elements or misaligned", i);
+    p.src[i] = reinterpret_cast<const float*>(srcs[i]), p.n[i] = ns[i], p.at[i] = at;
+    at += ns[i];
+    most = ns[i] > most ? ns[i] : most;
+  }
+  long long blocks = (most / 4 + kBlock - 1) / kBlock;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(kBlock), 0, (hipStream_t)stream, p);
+  return s2f_check_launch("s2f_copy_segments");
 }

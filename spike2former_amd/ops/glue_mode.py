@@ -34,6 +34,11 @@ VIEW_OPS = {"view", "_unsafe_view", "reshape", "_reshape_alias", "expand", "perm
             "diagonal", "real", "is_non_overlapping_and_dense", "is_strides_like_format", "_has_compatible_shallow_copy_type",
             "item", "prim_layout"}
 
+# aten calls that stay on ATen by decision (counted in ALLOWED, never an error): the gradient packing's batched copy of ~650 pieces into
+# the flat buffer (dist.FlatGradAllReduce.gather: ATen's CatArrayBatchedCopy does it in ~6 launches; a launch per piece would cost more),
+# and the BatchNorms' num_batches_tracked counters (one _foreach_add_ over int64 scalars)
+ALLOW = {"aten.cat.out", "aten._foreach_add_.Scalar"}
+ALLOWED = collections.Counter()
 ROUTED = collections.Counter()
 UNROUTED = collections.Counter()
 _I64x6 = ctypes.c_int64 * 6
@@ -52,20 +57,30 @@ def _arr(v):
     return _I64x6(*[int(x) for x in v])
 
 
+def _coalesce(shape, strides):
+    """merge adjacent dimensions that every operand walks contiguously (stride[i] == stride[i + 1] * size[i + 1] for all of them) and
+    drop dimensions of extent 1: fewer index divisions per element in the strided kernel"""
+    dims = [(n, tuple(st[i] for st in strides)) for i, n in enumerate(shape) if n != 1]
+    if not dims:
+        return [1], [[0] for _ in strides]
+    out = [dims[0]]
+    for n, st in dims[1:]:
+        pn, pst = out[-1]
+        if all(ps == s_ * n for ps, s_ in zip(pst, st)):
+            out[-1] = (pn * n, st)
+        else:
+            out.append((n, st))
+    return [n for n, _ in out], [[st[k] for _, st in out] for k in range(len(strides))]
+
+
 def _ew(op, a, b, out, alpha=1.0, beta=0.0, a_bf16=False):
     """out[...] = f(a, b) over out's shape; a, b already expanded to it (stride 0 = broadcast)"""
     shape = tuple(out.shape)
-    flat = (not a_bf16 and a.is_contiguous() and out.is_contiguous() and tuple(a.shape) == shape
-            and (b is None or (b.is_contiguous() and tuple(b.shape) == shape)) and a.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
-            and (b is None or b.data_ptr() % 16 == 0))
-    if flat:
-        size, sa, sb, so, nd = [out.numel()], [1], [1], [1], 1
-    else:
-        size, sa, so = list(shape), list(a.stride()), list(out.stride())
-        sb = list(b.stride()) if b is not None else [0] * len(size)
-        nd = len(size)
-        if nd == 0:
-            size, sa, sb, so, nd = [1], [0], [0], [0], 1
+    strides = [list(a.stride()), list(b.stride()) if b is not None else [0] * len(shape), list(out.stride())]
+    size, (sa, sb, so) = _coalesce(shape, strides)
+    nd = len(size)
+    flat = (nd == 1 and not a_bf16 and sa[0] == 1 and so[0] == 1 and (b is None or sb[0] == 1) and a.data_ptr() % 16 == 0
+            and out.data_ptr() % 16 == 0 and (b is None or b.data_ptr() % 16 == 0))
     check(lib.s2f_ew(op, a.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(), nd, _arr(size), _arr(sa), _arr(sb), _arr(so),
                      float(alpha), float(beta), int(a_bf16), int(flat), _stream()), "s2f_ew")
     return out
@@ -141,6 +156,13 @@ def h_neg(a):
     return _ew(6, a, None, torch.empty(a.shape, dtype=torch.float32, device=a.device), -1.0, 0.0)
 
 
+def h_addcmul(a, t1, t2, *, value=1):
+    prod = _binary(2, t1, t2)
+    if prod is NotImplemented:
+        return NotImplemented
+    return _binary(1, a, prod, value)
+
+
 def h_sigmoid(a):
     if not _ok(a):
         return NotImplemented
@@ -192,6 +214,11 @@ def _fill(t, value):
 
 
 def h_zero_(t):
+    if (torch.is_tensor(t) and t.is_cuda and t.numel() > 0 and t.is_contiguous() and t.dtype != torch.float32
+            and (t.numel() * t.element_size()) % 4 == 0 and t.data_ptr() % 4 == 0):
+        # any dtype whose zero is all-zero bytes (fp64 reduction arena, int64 counters, bf16 maps): cleared as 4-byte words
+        check(lib.s2f_fill(t.data_ptr(), t.numel() * t.element_size() // 4, 0, 0.0, _stream()), "s2f_fill")
+        return t
     return _fill(t, 0.0)
 
 
@@ -251,9 +278,9 @@ def _reduce(x, dims, keepdim, scale):
     n_red = 1
     for d in dims:
         n_red *= x.shape[d]
-    so = list(out.stride())
-    check(lib.s2f_reduce_sum(x.data_ptr(), out.data_ptr(), len(keep), _arr(out_shape), _arr([x.stride(d) for d in keep]), _arr(so),
-                             len(dims), _arr([x.shape[d] for d in dims]), _arr([x.stride(d) for d in dims]),
+    ws = torch.empty(int(lib.s2f_reduce_sum_workspace(max(out.numel(), 1), n_red)), dtype=torch.float32, device=x.device)
+    check(lib.s2f_reduce_sum(x.data_ptr(), out.data_ptr(), ws.data_ptr(), len(keep), _arr(out_shape), _arr([x.stride(d) for d in keep]),
+                             _arr(list(out.stride())), len(dims), _arr([x.shape[d] for d in dims]), _arr([x.stride(d) for d in dims]),
                              (1.0 / n_red) if scale == "mean" else 1.0, _stream()), "s2f_reduce_sum")
     if keepdim:
         shape = [1 if d in dims else x.shape[d] for d in range(nd)]
@@ -289,6 +316,22 @@ def h_mean(x, *, dtype=None):
     return _reduce(x, list(range(x.dim())), False, "mean")
 
 
+def _segments(out, pieces):
+    """contiguous pieces copied back to back into the contiguous `out`: one launch per eight pieces (s2f_copy_segments)"""
+    at = 0
+    for i in range(0, len(pieces), 8):
+        grp = pieces[i:i + 8]
+        srcs = (ctypes.c_void_p * 8)(*([t.data_ptr() for t in grp] + [0] * (8 - len(grp))))
+        ns = (ctypes.c_int64 * 8)(*([t.numel() for t in grp] + [0] * (8 - len(grp))))
+        check(lib.s2f_copy_segments(out.data_ptr() + 4 * at, srcs, ns, len(grp), _stream()), "s2f_copy_segments")
+        at += sum(t.numel() for t in grp)
+    return out
+
+
+def _seg_ok(ts):
+    return all(t.is_contiguous() and t.data_ptr() % 16 == 0 and t.numel() % 4 == 0 for t in ts)
+
+
 def h_cat(tensors, dim=0):
     ts = [t for t in tensors if not (t.dim() == 1 and t.numel() == 0)]
     if not ts or not all(_ok(t) for t in ts) or len({t.dim() for t in ts}) != 1:
@@ -298,6 +341,24 @@ def h_cat(tensors, dim=0):
     shape = list(ts[0].shape)
     shape[dim] = sum(t.shape[dim] for t in ts)
     out = torch.empty(shape, dtype=torch.float32, device=ts[0].device)
+    if dim == 0 and _seg_ok(ts):
+        return _segments(out, ts)
+    at = 0
+    for t in ts:
+        _ew(0, t, None, out.narrow(dim, at, t.shape[dim]))
+        at += t.shape[dim]
+    return out
+
+
+def h_cat_out(tensors, dim=0, *, out):
+    ts = [t for t in tensors if not (t.dim() == 1 and t.numel() == 0)]
+    if not ts or not all(_ok(t) for t in ts) or not _ok(out) or len({t.dim() for t in ts}) != 1:
+        return NotImplemented
+    dim = dim % ts[0].dim()
+    if out.dim() != ts[0].dim() or out.shape[dim] != sum(t.shape[dim] for t in ts):
+        return NotImplemented
+    if len(ts) > 64:
+        return NotImplemented          # (hundreds of pieces: one launch per piece would cost more than ATen's batched copy; see dist.gather)
     at = 0
     for t in ts:
         _ew(0, t, None, out.narrow(dim, at, t.shape[dim]))
@@ -313,6 +374,8 @@ def h_stack(tensors, dim=0):
     shape = list(ts[0].shape)
     shape.insert(dim, len(ts))
     out = torch.empty(shape, dtype=torch.float32, device=ts[0].device)
+    if dim == 0 and _seg_ok(ts):
+        return _segments(out, ts)
     for i, t in enumerate(ts):
         _ew(0, t, None, out.select(dim, i))
     return out
@@ -336,7 +399,7 @@ def h_constant_pad_nd(x, pad, value=0):
 
 
 def h_repeat(x, repeats):
-    if not _ok(x) or len(repeats) < x.dim() or 2 * len(repeats) > 6:
+    if not _ok(x) or len(repeats) < x.dim():
         return NotImplemented
     lead = len(repeats) - x.dim()
     xs = x.reshape((1,) * lead + tuple(x.shape))
@@ -347,7 +410,28 @@ def h_repeat(x, repeats):
         inter += [r, s]
     ov = out.view(inter)
     xe = xs.reshape([1 if i % 2 == 0 else inter[i] for i in range(len(inter))]).expand(inter)
+    if len(_coalesce(inter, [list(xe.stride()), [0] * len(inter), list(ov.stride())])[0]) > 6:
+        return NotImplemented
     _ew(0, xe, None, ov)
+    return out
+
+
+def h_flip(x, dims):
+    """copy through negated strides from the far corner of the flipped dimensions"""
+    if not _ok(x) or x.dim() == 0:
+        return NotImplemented
+    out = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        return out
+    sa, off = list(x.stride()), 0
+    for d in {d % x.dim() for d in dims}:
+        off += (x.shape[d] - 1) * sa[d]
+        sa[d] = -sa[d]
+    size, (ca, cb, co) = _coalesce(tuple(x.shape), [sa, [0] * x.dim(), list(out.stride())])
+    if len(size) > 6:
+        return NotImplemented
+    check(lib.s2f_ew(0, x.data_ptr() + 4 * off, 0, out.data_ptr(), len(size), _arr(size), _arr(ca), _arr(cb), _arr(co), 1.0, 0.0, 0, 0,
+                     _stream()), "s2f_ew")
     return out
 
 
@@ -364,16 +448,16 @@ HANDLERS = {
     aten.sub.Tensor: h_sub, aten.sub.Scalar: h_sub,
     aten.mul.Tensor: h_mul, aten.mul.Scalar: h_mul, aten.mul_.Tensor: h_mul_, aten.mul_.Scalar: h_mul_,
     aten.div.Tensor: h_div, aten.div.Scalar: h_div, aten.div_.Tensor: h_div_, aten.div_.Scalar: h_div_,
-    aten.neg.default: h_neg,
+    aten.neg.default: h_neg, aten.addcmul.default: h_addcmul,
     aten.sigmoid.default: h_sigmoid, aten.sigmoid_backward.default: h_sigmoid_backward,
     aten.clone.default: h_clone, aten.copy_.default: h_copy_, aten._to_copy.default: h_to_copy,
     aten.zero_.default: h_zero_, aten.fill_.Scalar: h_fill_,
     aten.zeros.default: h_zeros, aten.ones.default: h_ones, aten.full.default: h_full,
     aten.zeros_like.default: h_zeros_like, aten.ones_like.default: h_ones_like,
     aten.sum.dim_IntList: h_sum_dim, aten.sum.default: h_sum, aten.mean.dim: h_mean_dim, aten.mean.default: h_mean,
-    aten.cat.default: h_cat, aten.stack.default: h_stack,
+    aten.cat.default: h_cat, aten.cat.out: h_cat_out, aten.stack.default: h_stack,
     aten.constant_pad_nd.default: h_constant_pad_nd, aten.repeat.default: h_repeat,
-    aten.select_backward.default: h_select_backward,
+    aten.select_backward.default: h_select_backward, aten.flip.default: h_flip,
 }
 
 
@@ -401,6 +485,9 @@ class GlueMode(TorchDispatchMode):
         out = func(*args, **kwargs)
         name = func.__name__.split(".")[0]
         if name not in VIEW_OPS and _touches_cuda(args, out):
+            if str(func) in ALLOW:
+                ALLOWED[str(func)] += 1
+                return out
             UNROUTED[str(func)] += 1
             if cfg.STRICT_GLUE:
                 raise RuntimeError(f"spike2former_amd: {func} reached ATen inside a glue_mode step; S2F_STRICT_GLUE forbids that")
@@ -424,3 +511,4 @@ def glue_mode(force=None):
 def reset_counts():
     ROUTED.clear()
     UNROUTED.clear()
+    ALLOWED.clear()

@@ -25,7 +25,8 @@ def cat(name):
     if 'bn_' in name: return 'bn(+lif) fused (ours)'
     if 'lif_' in name: return 'lif (ours)'
     if 'apply_kernel' in name or 'outer_kernel' in name or 'outer_mfma' in name or 'sdsa' in name: return 'sdsa (ours)'
-    if any(k in name for k in ('sum_all_', 'fill_kernel', 'channel_sum_', 'sum_lead_kernel', 'bmm_f32_kernel')): return 'glue reductions / fills (ours, glue.hip)'
+    if any(k in name for k in ('sum_all_', 'fill_kernel', 'channel_sum_', 'sum_lead_kernel', 'bmm_f32_kernel', 'ew_flat_kernel', 'ew_strided_kernel', 'ew_strided4_kernel',
+                               'reduce_rows_kernel', 'reduce_cols_kernel', 'reduce_final_kernel', 'copy_segments_kernel')): return 'glue: element-wise / reductions / fills (ours, glue.hip)'
     if 's2f_zero' in name: return 'fill/memset'
     if 'depthwise' in name: return 'depthwise conv (ATen)'
     if 'batch_norm' in name: return 'batch_norm (ATen)'
