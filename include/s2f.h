@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 27
+#define S2F_ABI_VERSION 28
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -74,6 +74,12 @@ int s2f_lif_fwd(const float* x, const float* v_in, void* y, float* v_out, uint64
 /* STE backward of one step:  gx = gv_out + (gy / D - gv_out * vth) * m   (gv_out? NULL == 0; dL/dv_in == gx). */
 int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth, int D,
                 void* stream);
+/* The same with the gradient sums of a fan-out folded in (each NULL = absent): gy2? = the gradient a SECOND consumer of the spike
+ * map sends back, skip? = the gradient of a residual branch that read the neuron's INPUT (x + f(Q_IFNode(x)), sdtv2.py:203-219,
+ * detr_layers.py:523-556):  gx = STE((gy + gy2) / D) + skip  -- the adds autograd's engine would launch on its own.  skip needs
+ * gv_out == NULL. */
+int s2f_lif_bwd_ports(const float* gy, const float* gy2, const float* gv_out, const uint64_t* mask, const float* skip, float* gx,
+                      int64_t n, float vth, int D, void* stream);
 
 /* Leaky charge in front of the same firing rule -- LIFNode.neuronal_charge (neuron.py:803-814) under the fork's BaseNode.forward
  * (:166-197: multi-level quantised firing, soft reset, y = s / D).  No Spike2Former module instantiates LIFNode; the
@@ -103,6 +109,12 @@ int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const uint64_t* m
  * the learnable query embedding: mmcv_spike/transformer.py:597-638). */
 int s2f_sum2_lif_bwd_ex(const float* g_key, const float* g_value, const uint64_t* mask_key, const uint64_t* mask_value, float* gx,
                         float* gx_key, int64_t n, int D, void* stream);
+/* ... and with a second consumer's gradient per spike map and a residual branch's gradient on x folded in (s2f_lif_bwd_ports):
+ * the key / value spikes of one memory level are read by two decoder layers (maskformer_head.py:554-564), the decoder's
+ * query + attention(query) reads the query beside its neurons (detr_layers.py:523-537). */
+int s2f_sum2_lif_bwd_ports(const float* g_key, const float* g_key2, const float* g_value, const float* g_value2,
+                           const uint64_t* mask_key, const uint64_t* mask_value, const float* skip, float* gx, float* gx_key, int64_t n,
+                           int D, void* stream);
 
 /* Layer scale folded into a BatchNorm's affine pair: w[c] = gamma[c] * s[c], b[c] = beta[c] * s[c]  (the pixel decoder's
  * `q + gamma_i * f(q)`, detr_layers.py:331-337, with f ending in a BatchNorm: u = s * BN(z) = BN_{gamma s, beta s}(z)).

@@ -27,11 +27,13 @@ SIGNATURES = {
     "s2f_lif_mask_words": (_i64, [_i64]),
     "s2f_lif_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _i, _i, _p]),
     "s2f_lif_bwd": (_i, [_p, _p, _p, _p, _i64, _f, _i, _p]),
+    "s2f_lif_bwd_ports": (_i, [_p] * 6 + [_i64, _f, _i, _p]),
     "s2f_lif_leaky_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _i, _f, _i, _i, _p]),
     "s2f_lif_leaky_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _f, _i, _f, _i, _p]),
     "s2f_sum2_lif_fwd": (_i, [_p] * 7 + [_i64] * 4 + [_f, _i, _i, _p]),
     "s2f_sum2_lif_bwd": (_i, [_p] * 5 + [_i64, _i, _p]),
     "s2f_sum2_lif_bwd_ex": (_i, [_p] * 6 + [_i64, _i, _p]),
+    "s2f_sum2_lif_bwd_ports": (_i, [_p] * 9 + [_i64, _i, _p]),
     "s2f_mask_loss_fwd": (_i, [_p] * 4 + [_i64, _i, _i, _f, _f, _p]),
     "s2f_mask_loss_bwd": (_i, [_p] * 5 + [_i64, _i, _i, _f, _f, _p]),
     "s2f_scale_affine_fwd": (_i, [_p] * 5 + [_i, _p]),

@@ -184,10 +184,14 @@ __global__ __launch_bounds__(kBlock) void lif_fwd_kernel(const float* __restrict
   }
 }
 
+// gy2 (optional): the gradient of a SECOND consumer of the same spike map, skip (optional): the gradient of a residual branch that
+// read the neuron's input itself -- both sums the autograd engine would otherwise form with an add launch of its own
+// (ops/neuron.py: the neuron's second handle and its pass-through output); (gy + gy2) / D + skip are the same IEEE operations.
 template <bool HAS_GV>
 __global__ __launch_bounds__(kBlock) void lif_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gv,
                                                          const uint64_t* __restrict__ mask, float* __restrict__ gx,
-                                                         int64_t n, float vth, float Df) {
+                                                         int64_t n, float vth, float Df, const float* __restrict__ gy2,
+                                                         const float* __restrict__ skip) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -195,6 +199,11 @@ __global__ __launch_bounds__(kBlock) void lif_bwd_kernel(const float* __restrict
   for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * 256 + lane * 4;
     Tile4 g = load4(gy, base, n, 0.0f);
+    if (gy2) {
+      const Tile4 g2 = load4(gy2, base, n, 0.0f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g.a[j] += g2.a[j];
+    }
     Tile4 gvv;
     if (HAS_GV) gvv = load4(gv, base, n, 0.0f);
     Tile4 o;
@@ -207,6 +216,11 @@ __global__ __launch_bounds__(kBlock) void lif_bwd_kernel(const float* __restrict
         o.a[j] = m ? (gvv.a[j] + (through - gvv.a[j] * vth)) : gvv.a[j];
       else
         o.a[j] = m ? through : 0.0f;
+    }
+    if (skip) {
+      const Tile4 sk = load4(skip, base, n, 0.0f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.a[j] += sk.a[j];
     }
     store4(gx, base, n, o);
   }
@@ -261,10 +275,15 @@ __global__ __launch_bounds__(kBlock) void sum2_lif_fwd_kernel(const float* __res
 // gx = STE_k(g_k) + STE_v(g_v)   (the gradient with respect to x; the one with respect to e is its per-channel sum)
 // gk / gv may be null (a neuron whose output nobody differentiated); gxk? receives STE_k(g_k) alone -- the gradient with respect to
 // `pos` is its sum over the T time steps (the decoder's self-attention, whose position term is the learnable query embedding)
+// gk2 / gv2 / skip (optional): a second consumer's gradient of either spike map and the gradient of a residual branch on x, summed
+// here instead of by the autograd engine (see lif_bwd_kernel)
 __global__ __launch_bounds__(kBlock) void sum2_lif_bwd_kernel(const float* __restrict__ gk, const float* __restrict__ gv,
                                                               const uint64_t* __restrict__ mk,
                                                               const uint64_t* __restrict__ mv, float* __restrict__ gx,
-                                                              float* __restrict__ gxk, int64_t n, float Df) {
+                                                              float* __restrict__ gxk, int64_t n, float Df,
+                                                              const float* __restrict__ gk2,
+                                                              const float* __restrict__ gv2,
+                                                              const float* __restrict__ skip) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -276,11 +295,26 @@ __global__ __launch_bounds__(kBlock) void sum2_lif_bwd_kernel(const float* __res
     for (int j = 0; j < 4; ++j) a.a[j] = b.a[j] = 0.f;
     if (gk) a = load4(gk, base, n, 0.f);
     if (gv) b = load4(gv, base, n, 0.f);
+    if (gk2) {
+      const Tile4 t = load4(gk2, base, n, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a.a[j] = gk ? a.a[j] + t.a[j] : t.a[j];
+    }
+    if (gv2) {
+      const Tile4 t = load4(gv2, base, n, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b.a[j] = gv ? b.a[j] + t.a[j] : t.a[j];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool bk = (mk[tile * 4 + j] >> lane) & 1ull, bv = (mv[tile * 4 + j] >> lane) & 1ull;
       ok.a[j] = bk ? a.a[j] / Df : 0.f;
       o.a[j] = (bv ? b.a[j] / Df : 0.f) + ok.a[j];
+    }
+    if (skip) {
+      const Tile4 t = load4(skip, base, n, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.a[j] += t.a[j];
     }
     store4(gx, base, n, o);
     if (gxk) store4(gxk, base, n, ok);
@@ -535,21 +569,27 @@ extern "C" int s2f_lif_fwd(const float* x, const float* v_in, void* y_out, float
   return s2f_check_launch("s2f_lif_fwd");
 }
 
-extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth,
-                           int D, void* stream) {
+extern "C" int s2f_lif_bwd_ports(const float* gy, const float* gy2, const float* gv_out, const uint64_t* mask, const float* skip,
+                                 float* gx, int64_t n, float vth, int D, void* stream) {
   if (n == 0) return S2F_OK;  // empty tensors are legal (null pointers included)
   S2F_REQUIRE(gy && mask && gx, S2F_EINVAL, "s2f_lif_bwd: null gy/mask/gx");
   S2F_REQUIRE(n >= 0 && D >= 1 && D <= 255, S2F_EINVAL, "s2f_lif_bwd: bad n or D");
-  S2F_REQUIRE(s2f_aligned16(gy) && s2f_aligned16(gx) && s2f_aligned16(gv_out), S2F_EALIGN,
+  S2F_REQUIRE(!(gv_out && skip), S2F_EINVAL, "s2f_lif_bwd_ports: a pass-through gradient only for a neuron without a membrane gradient");
+  S2F_REQUIRE(s2f_aligned16(gy) && s2f_aligned16(gx) && s2f_aligned16(gv_out) && s2f_aligned16(gy2) && s2f_aligned16(skip), S2F_EALIGN,
               "s2f_lif_bwd: gy/gx/gv must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   if (gv_out != nullptr)
     S2F_LAUNCH(true, true, lif_bwd_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
-                       (float)D);
+                       (float)D, gy2, skip);
   else
     S2F_LAUNCH(true, true, lif_bwd_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, gy, gv_out, mask, gx, n, vth,
-                       (float)D);
+                       (float)D, gy2, skip);
   return s2f_check_launch("s2f_lif_bwd");
+}
+
+extern "C" int s2f_lif_bwd(const float* gy, const float* gv_out, const uint64_t* mask, float* gx, int64_t n, float vth,
+                           int D, void* stream) {
+  return s2f_lif_bwd_ports(gy, nullptr, gv_out, mask, nullptr, gx, n, vth, D, stream);
 }
 
 extern "C" int s2f_lif_leaky_fwd(const float* x, const float* v_in, void* y_out, float* v_out, uint64_t* mask, uint64_t* stats,
@@ -634,19 +674,26 @@ extern "C" int s2f_sum2_lif_bwd(const float* g_key, const float* g_value, const 
   S2F_REQUIRE(s2f_aligned16(g_key) && s2f_aligned16(g_value) && s2f_aligned16(gx), S2F_EALIGN,
               "s2f_sum2_lif_bwd: tensors must be 16-byte aligned");
   S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
-             mask_key, mask_value, gx, (float*)nullptr, n, (float)D);
+             mask_key, mask_value, gx, (float*)nullptr, n, (float)D, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   return s2f_check_launch("s2f_sum2_lif_bwd");
+}
+
+extern "C" int s2f_sum2_lif_bwd_ports(const float* g_key, const float* g_key2, const float* g_value, const float* g_value2,
+                                      const uint64_t* mask_key, const uint64_t* mask_value, const float* skip, float* gx, float* gx_key,
+                                      int64_t n, int D, void* stream) {
+  if (n == 0) return S2F_OK;
+  S2F_REQUIRE((g_key || g_value || g_key2 || g_value2) && mask_key && mask_value && gx, S2F_EINVAL, "s2f_sum2_lif_bwd_ports: null pointer");
+  S2F_REQUIRE(s2f_aligned16(g_key) && s2f_aligned16(g_value) && s2f_aligned16(g_key2) && s2f_aligned16(g_value2) && s2f_aligned16(skip) &&
+                  s2f_aligned16(gx) && s2f_aligned16(gx_key),
+              S2F_EALIGN, "s2f_sum2_lif_bwd_ports: tensors must be 16-byte aligned");
+  S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
+             mask_key, mask_value, gx, gx_key, n, (float)D, g_key2, g_value2, skip);
+  return s2f_check_launch("s2f_sum2_lif_bwd_ports");
 }
 
 extern "C" int s2f_sum2_lif_bwd_ex(const float* g_key, const float* g_value, const uint64_t* mask_key,
                                    const uint64_t* mask_value, float* gx, float* gx_key, int64_t n, int D, void* stream) {
-  if (n == 0) return S2F_OK;
-  S2F_REQUIRE((g_key || g_value) && mask_key && mask_value && gx, S2F_EINVAL, "s2f_sum2_lif_bwd_ex: null pointer");
-  S2F_REQUIRE(s2f_aligned16(g_key) && s2f_aligned16(g_value) && s2f_aligned16(gx) && s2f_aligned16(gx_key), S2F_EALIGN,
-              "s2f_sum2_lif_bwd_ex: tensors must be 16-byte aligned");
-  S2F_LAUNCH(true, true, sum2_lif_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, g_key, g_value,
-             mask_key, mask_value, gx, gx_key, n, (float)D);
-  return s2f_check_launch("s2f_sum2_lif_bwd_ex");
+  return s2f_sum2_lif_bwd_ports(g_key, nullptr, g_value, nullptr, mask_key, mask_value, nullptr, gx, gx_key, n, D, stream);
 }
 
 extern "C" int s2f_scale_affine_fwd(const float* gamma, const float* beta, const float* s, float* w, float* b, int C,

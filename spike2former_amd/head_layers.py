@@ -44,7 +44,11 @@ class SepConv_Spike(nn.Module):
         """Channel-major form: x, residual, result [T,B,C,H,W].  -> scale * SepConv(x) [+ residual]; the layer scale, the
         residual add and the next neuron on the stream are folded into the last BatchNorm kernel (fused.bn_act)."""
         T, B, C, H, W = x.shape
-        x = self.spike1.fire(x).flatten(0, 1)
+        if residual is x:          # x + scale * SepConv(x): the residual's gradient is summed inside spike1's backward kernel
+            x, residual = self.spike1.fire(x, skip=True)
+            x = x.flatten(0, 1)
+        else:
+            x = self.spike1.fire(x).flatten(0, 1)
         _, x = conv_bn_act(self.pwconv1[0], x, self.pwconv1[1], lif=self.spike2)
         _, x = conv_bn_act(self.dwconv[0], x, self.dwconv[1], lif=self.spike3)          # (eval: stencil + BatchNorm + neuron, one launch)
         x, _ = conv_bn_act(self.pwconv2[0], x, self.pwconv2[1], scale=scale, next_lif=next_lif,          # (eval: one launch)
@@ -125,13 +129,18 @@ class DCNv3_pytorch(nn.Module):
         the Cg channels of a group as one vector): one transposition in, one out, instead of the reference's permute pair
         around every sub-module."""
         T, N, C, H, W = inp.shape
+        through = [residual]
 
         def sampled_input():
             x = self.input_proj.forward_nchw(inp)
             return ops.transpose_last2(x.reshape(T * N, C, H * W)).view(T * N, H, W, C)   # NCHW -> [T*N, H, W, C]
 
         def offset_and_mask():
-            x1 = self.dw_spike.fire(inp).flatten(0, 1)
+            if residual is inp:          # inp + scale * DCN(inp): the residual's gradient joins dw_spike's backward kernel
+                x1, through[0] = self.dw_spike.fire(inp, skip=True)
+                x1 = x1.flatten(0, 1)
+            else:
+                x1 = self.dw_spike.fire(inp).flatten(0, 1)
             ops.use_here(x1)
             _, x1 = conv_bn_act(self.dw_conv[0], x1, self.dw_conv[1], lif=self.offset_spike)
             # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
@@ -147,7 +156,7 @@ class DCNv3_pytorch(nn.Module):
         y = ops.dcnv3_core(x, offset, mask, k, k, self.stride, self.stride, self.pad, self.pad,
                            self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale)
         y = ops.transpose_last2(y.reshape(T * N, H * W, C)).view(T, N, C, H, W)
-        return self.output_proj.forward_nchw(y, scale=scale, residual=residual, next_lif=next_lif)
+        return self.output_proj.forward_nchw(y, scale=scale, residual=through[0], next_lif=next_lif)
 
     def forward(self, inp):
         """The reference's interface: NHWC in, NHWC out (dcnv3.py:198-233)."""
@@ -292,17 +301,19 @@ class MultiHeadAttentionBlock(nn.Module):
                         and not n._forward_pre_hooks for n in ns)
                 and len({(n.D, n.v_threshold) for n in ns}) == 1 and ops.spikes_bf16_ok(ns[0].D))
 
-    def fire_with_pos(self, x, pos):
+    def fire_with_pos(self, x, pos, skip=False):
         """x [t, b, dim, n], pos [b, dim, n] -> (Q_IFNode(x + pos), Q_IFNode(x)) as ops.Spikes of x's shape: ONE launch forward, one
-        backward, the sum never materialised (ops.sum2_lif with a zero level embedding; fused_neurons_ok says when this is legal)."""
+        backward, the sum never materialised (ops.sum2_lif with a zero level embedding; fused_neurons_ok says when this is legal).
+        `skip`: -> (.., .., x') with x' = x for the layer's `query + attention(query)`: that branch's gradient is summed in the
+        neurons' backward kernel (ops.sum2_lif)."""
         z = getattr(self, "_zero_e", None)
         if z is None or z.device != x.device or z.shape[0] != x.shape[2]:
             z = self._zero_e = torch.zeros(x.shape[2], dtype=torch.float32, device=x.device)
         n0 = self.q_conv_spike
-        yk, yv = ops.sum2_lif(x.flatten(0, 1), z, pos, x.shape[1], n0.D, n0.v_threshold)
+        out = ops.sum2_lif(x.flatten(0, 1), z, pos, x.shape[1], n0.D, n0.v_threshold, skip=skip)
         for m in (self.q_conv_spike, self.k_conv_spike, self.v_conv_spike):
             m.v = 0.0
-        return yk.view(x.shape), yv.view(x.shape)
+        return tuple(o.view(x.shape) for o in out)
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, kv_channel_major=False, kv_spikes=None,
                 kv_projected=None, query_channel_major=False, residual_cm=None, q_spikes=None):
@@ -367,15 +378,19 @@ class MultiheadAttention(nn.Module):
         qcm = bool(kwargs.get("query_channel_major", False))
         if kv_spikes is not None or kv_projected is not None:
             q_spikes = None
+            residual_cm = kwargs.get("residual_cm") if qcm else None
             if qcm and query_pos is not None and self.attn.fused_neurons_ok(("q",), query):
                 # query + query_pos only feeds the query neuron: add and neuron as one launch (ops.sum2_lif), the sum never written
-                q_spikes = self.attn.fire_with_pos(query, query_pos)[0]
+                if residual_cm is query:
+                    q_spikes, _, residual_cm = self.attn.fire_with_pos(query, query_pos, skip=True)
+                else:
+                    q_spikes = self.attn.fire_with_pos(query, query_pos)[0]
             elif query_pos is not None:
                 query = query + query_pos
             return self.attn(query=query, key=None, value=None,
                              attn_mask=attn_mask, key_padding_mask=key_padding_mask, kv_spikes=kv_spikes,
                              kv_projected=kv_projected, query_channel_major=qcm, q_spikes=q_spikes,
-                             residual_cm=kwargs.get("residual_cm") if qcm else None)[0]
+                             residual_cm=residual_cm)[0]
         if key is None:
             key = query
         if value is None:
@@ -413,7 +428,11 @@ class MSDA_FFN(nn.Module):
         """`identity` [t,bs,N,C]: added to the result -- elementwise in memory order, so inside bn2's kernel on the reinterpreted
         buffer (detr_layers.py:556: query + ffn(query))."""
         t, bs, N, C = x.shape
-        a = self.fc1_spike.fire(x).reshape(t * bs, C, N)
+        if identity is x:          # x + ffn(x): the identity's gradient is summed inside fc1_spike's backward kernel
+            a, identity = self.fc1_spike.fire(x, skip=True)
+            a = a.reshape(t * bs, C, N)
+        else:
+            a = self.fc1_spike.fire(x).reshape(t * bs, C, N)
         _, a = conv_bn_act(self.fc1, a, self.bn1, lif=self.fc2_spike)
         res = identity.reshape(t * bs, C, N) if identity is not None else None
         a, _ = conv_bn_act(self.fc2, a, self.bn2, residual=res)
@@ -465,9 +484,10 @@ class DetrTransformerDecoderLayer(nn.Module):
         if sa.fused_neurons_ok(("q", "k", "v"), q_cm):
             # query + query_pos == key + key_pos feeds the query and key neurons, the query itself the value neuron: the add and
             # the three neurons as ONE launch (ops.sum2_lif: Q_IFNode(q + pos), Q_IFNode(q)); q and k share the first map
-            yk, yv = sa.fire_with_pos(q_cm, query_pos_cm)
-            q_cm = sa(query=q_cm, key=None, value=None, kv_spikes=(yk, yv), q_spikes=yk, query_channel_major=True,
-                      residual_cm=q_cm)[0]
+            yk, yv, through = sa.fire_with_pos(q_cm, query_pos_cm, skip=True)
+            # (q and k read the same spikes: the second reader's gradient arrives on the neurons' spare handle, ops.Spikes.second)
+            q_cm = sa(query=q_cm, key=None, value=None, kv_spikes=(yk, yv), q_spikes=yk.second(), query_channel_major=True,
+                      residual_cm=through)[0]
         else:
             qp = q_cm + query_pos_cm                       # query + query_pos == key + key_pos: formed once
             q_cm = sa(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True, residual_cm=q_cm)[0]

@@ -147,13 +147,18 @@ class MaskFormerHead(nn.Module):
         # Keys / values do not depend on the query: with ops.LONG_STREAMS set, the key / value chains of ALL layers (the 1 024 -
         # 16 384-token projections) are launched on a side stream ahead of the serial 100-query chain and overlap with it.
         kv_proj = [None] * self.num_transformer_decoder_layers
+        # (a later layer on the same level reads the level's key / value spikes through their spare handles: the neurons' backward kernel
+        # sums the two layers' gradients, ops.Spikes.second)
+        kv_of = [kv_spikes[i % nl] if (i < nl or kv_spikes[i % nl] is None) else tuple(s.second() for s in kv_spikes[i % nl])
+                 for i in range(self.num_transformer_decoder_layers)]
         if ops.LONG_STREAMS and "kv" in ops.LONG_WHAT:
             for i in range(self.num_transformer_decoder_layers):
                 lv = i % nl
                 attn = layers[i].cross_attn.attn
+                kvs = kv_of[i]
                 (k, v), handle = ops.fork(
-                    1, lambda: attn.project_kv(dec_key[lv], dec_in[lv], True, kv_spikes[lv]),
-                    inputs=(dec_key[lv], dec_in[lv], kv_spikes[lv]), what="kv")
+                    1, lambda: attn.project_kv(dec_key[lv], dec_in[lv], True, kvs),
+                    inputs=(dec_key[lv], dec_in[lv], kvs), what="kv")
                 kv_proj[i] = (k, v, handle)
         out_dec = [query_feat]
         if QUERY_STREAM_CHANNEL_MAJOR and query_feat.is_cuda:
@@ -163,7 +168,7 @@ class MaskFormerHead(nn.Module):
             n = self.num_transformer_decoder_layers
             for i in range(n):
                 lv = i % nl
-                q_tm, q_cm = layers[i].forward_stream(q_cm, pos_cm, key=dec_key[lv], value=dec_in[lv], kv_spikes=kv_spikes[lv],
+                q_tm, q_cm = layers[i].forward_stream(q_cm, pos_cm, key=dec_key[lv], value=dec_in[lv], kv_spikes=kv_of[i],
                                                       kv_projected=kv_proj[i], last=i == n - 1)
                 out_dec.append(q_tm)
         else:
@@ -171,7 +176,7 @@ class MaskFormerHead(nn.Module):
                 lv = i % nl
                 query_feat = layers[i](
                     query=query_feat, key=dec_key[lv], value=dec_in[lv], query_pos=query_embed, key_pos=None,
-                    cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_spikes[lv],
+                    cross_attn_mask=None, key_padding_mask=None, kv_channel_major=True, kv_spikes=kv_of[i],
                     kv_projected=kv_proj[i])
                 out_dec.append(query_feat)
         return torch.stack(out_dec)

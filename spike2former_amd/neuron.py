@@ -67,9 +67,32 @@ class Q_IFNode(nn.Module):
         """The reference's interface: fp32 in, fp32 spikes out."""
         return self.fire(x, as_float=True)
 
-    def fire(self, x, as_float=False):
+    def fire(self, x, as_float=False, skip=False):
         """One call of the neuron -> ops.Spikes: the spike map as the kernels of this package pass it on (bf16 data + fp32
-        autograd handle, ops.SPIKES_BF16).  `as_float`: the fp32 tensor instead (what `forward` returns)."""
+        autograd handle, ops.SPIKES_BF16).  `as_float`: the fp32 tensor instead (what `forward` returns).
+        `skip`: -> (spikes, x') where x' is x for the residual branch of `x + f(neuron(x))`: the gradient that branch sends back is
+        summed inside this neuron's backward kernel instead of by an add of the autograd engine (ops.lif; x' is x itself whenever
+        that does not apply)."""
+        if skip:
+            return self._fire_skip(x)
+        return self._fire(x, as_float)
+
+    def _fire_skip(self, x):
+        plain = (self._forward_hooks or self._forward_pre_hooks or self._prefired is not None or not isinstance(self.v, float)
+                 or not x.is_cuda or not x.is_contiguous())
+        if not plain and PURE_MEMO and not self.keep_membrane and self.stats is None:
+            plain = (x.data_ptr(), x._version, x.numel(), x.requires_grad, self.D, self.v_threshold) in _PURE_MEMO
+        if plain:
+            return self._fire(x, False), x
+        if self.stats is not None:
+            self.stats_elems += x.numel()
+        y, v_out, through = ops.lif(x, None, self.D, self.v_threshold, self.keep_membrane, self.stats, spikes=True, skip=True)
+        if PURE_MEMO and not self.keep_membrane and self.stats is None:
+            _PURE_MEMO[(x.data_ptr(), x._version, x.numel(), x.requires_grad, self.D, self.v_threshold)] = (x, y)
+        self.v = v_out if self.keep_membrane else 0.0
+        return y, through
+
+    def _fire(self, x, as_float=False):
         if not as_float and (self._forward_hooks or self._forward_pre_hooks):
             # somebody watches this neuron through nn.Module hooks (the reference's tools do): take the module call, whose
             # hooks see the fp32 spikes of the reference's interface
@@ -91,7 +114,8 @@ class Q_IFNode(nn.Module):
             key = (x.data_ptr(), x._version, x.numel(), x.requires_grad, self.D, self.v_threshold)
             hit = _PURE_MEMO.get(key)
             if hit is not None:
-                return hit[1].view(x.shape)          # both tensors are contiguous: same address + size = same layout
+                return hit[1].view(x.shape).second()          # both tensors are contiguous: same address + size = same layout; the
+                #                                               second consumer's gradient arrives on the neuron's spare handle
         y, v_out = ops.lif(x, v_in, self.D, self.v_threshold, self.keep_membrane, self.stats, spikes=not as_float)
         if pure:
             _PURE_MEMO[key] = (x, y)                      # holding x keeps its address from being reused

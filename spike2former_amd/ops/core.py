@@ -410,10 +410,13 @@ def spikes_bf16_ok(D):
 
 
 class Spikes:
-    __slots__ = ("data", "tok")
+    """A spike map as the kernels pass it on: `data` (bf16 or fp32 values) + `tok`, the fp32 autograd handle of the producing
+    neuron (None: data is its own handle).  `tok2`: a spare handle of the same neuron for a SECOND consumer (`second()`): the
+    neuron's backward kernel sums the gradients arriving on both, instead of the autograd engine adding them (cfg.FANOUT_PORTS)."""
+    __slots__ = ("data", "tok", "tok2")
 
-    def __init__(self, data, tok=None):
-        self.data, self.tok = data, tok
+    def __init__(self, data, tok=None, tok2=None):
+        self.data, self.tok, self.tok2 = data, tok, tok2
 
     shape = property(lambda self: self.data.shape)
     device = property(lambda self: self.data.device)
@@ -426,8 +429,12 @@ class Spikes:
     def dim(self):
         return self.data.dim()
 
+    def second(self):
+        """the same spikes for another consumer, on the spare handle when there is one"""
+        return self if self.tok2 is None else Spikes(self.data, self.tok2, self.tok2)
+
     def _both(self, f):
-        return Spikes(f(self.data), None if self.tok is None else f(self.tok))
+        return Spikes(f(self.data), None if self.tok is None else f(self.tok), None if self.tok2 is None else f(self.tok2))
 
     def view(self, *shape):
         return self._both(lambda t: t.view(*shape))
@@ -445,7 +452,7 @@ class Spikes:
         return self._both(lambda t: t.unflatten(dim, sizes))
 
     def contiguous(self):
-        return Spikes(self.data.contiguous(), self.tok)
+        return Spikes(self.data.contiguous(), self.tok, self.tok2)
 
     def float(self):
         """The fp32 tensor the reference would hold at this point (one conversion pass; only for consumers off the path)."""

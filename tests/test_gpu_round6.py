@@ -266,3 +266,53 @@ def test_glue_mode_routes_the_residual_aten_calls_of_a_step():
     gscale = max(v.abs().max().item() for v in g0.values())
     for k in g0:
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * (g0[k].abs().max().item() + 1e-3 * gscale), k
+
+
+def test_fanout_ports_sum_the_same_gradients_as_the_autograd_engine():
+    """cfg.FANOUT_PORTS: the residual branch of `x + f(Q_IFNode(x))` and the second reader of a spike map send their gradients to
+    extra outputs of the neuron's autograd node, and its backward kernel sums them -- (g1 + g2) / D and STE(.) + skip are the IEEE
+    operations the engine's add launches performed, so one C2 training step gives the same outputs and gradients with the ports off
+    and on: equal up to what two runs of the SAME setting differ by (the split-contraction weight gradients add partial tiles with
+    fp32 atomics), and bit-identical when that is zero."""
+    import spike2former_amd as s2f
+    from spike2former_amd import ops
+    from spike2former_amd.init_utils import seeded_init
+    w = s2f.WORKLOADS["C2"]
+    model = seeded_init(s2f.MODELS.build(s2f.model_cfg("C2"))).cuda().train()
+    s2f.set_keep_membrane(model, False)
+    img = torch.randn(1, 3, w["H"], w["W"], generator=torch.Generator().manual_seed(11)).cuda()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(on):
+        was = ops.FANOUT_PORTS
+        ops.FANOUT_PORTS = on
+        try:
+            # (the running statistics are an INPUT of a training forward: BNAndPadLayer pads with BN(0) of the updated running
+            # statistics, sdtv2.py:48-83 -- every run starts from the same buffers)
+            model.load_state_dict(state)
+            s2f.reset_net(model); model.zero_grad(set_to_none=True)
+            cls, masks = model(img)
+            s2f.headline_loss(cls, masks).backward()
+            ops.wgrad_join()
+            torch.cuda.synchronize()
+        finally:
+            ops.FANOUT_PORTS = was
+        return cls.detach().clone(), masks.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    c0, m0, g0 = run(False)
+    c0b, m0b, g0b = run(False)
+    c1, m1, g1 = run(True)
+    for a, b, r in ((c0, c1, c0b), (m0, m1, m0b)):          # (the forward does not depend on the setting at all)
+        noise = (a - r).abs().max().item()
+        assert (a - b).abs().max().item() <= 4 * noise + 1e-6 * a.abs().max().item(), ((a - b).abs().max().item(), noise)
+    assert g0.keys() == g1.keys() and len(g0) > 500
+    worst = 0.0
+    for k in g0:
+        noise = (g0[k] - g0b[k]).abs().max().item()
+        d = (g0[k] - g1[k]).abs().max().item()
+        scale = g0[k].abs().max().item() + 1e-30
+        assert d <= 4 * noise + 1e-6 * scale, (k, d, noise, scale)
+        worst = max(worst, d / scale)
+    print(f"ports on vs off: worst relative gradient difference {worst:.2e}; forward off vs off again "
+          f"{(c0 - c0b).abs().max().item():.2e} / {(m0 - m0b).abs().max().item():.2e}, off vs on {(c0 - c1).abs().max().item():.2e} / "
+          f"{(m0 - m1).abs().max().item():.2e}")
