@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 28
+#define S2F_ABI_VERSION 29
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -432,6 +432,16 @@ int s2f_pgemm_dx_f32_stats(const uint16_t* w_pack, const float* G, int64_t g_bat
                            float* bn_partials, int batch, int Mo, int Ki, int N, void* stream);
 int s2f_bn_partials_finalize(const float* partials, int64_t P, const float* conv_bias, double* sums_out, int64_t N, int64_t C,
                              int64_t L, void* stream);
+/* s2f_bn_act_bwd with a SECOND gradient of the spike map (g_y2?, NULL = absent): the neuron fused into this BatchNorm has two
+ * readers (the backbone taps feed the next stage and the pixel decoder's lateral convolution, mask2former's pixel_decoder.py:316-472;
+ * DCNv3's offset and mask convolutions share offset_spike, dcnv3.py:209-214), and g_y + g_y2 is formed where g_y is read instead of
+ * by an add launch of the autograd engine.  Only on the kernels s2f_bn_bwd_ports_ok() names (1 = supported for this shape). */
+int s2f_bn_bwd_ports_ok(int64_t N, int64_t C, int64_t L, int training, int D);
+int s2f_bn_act_bwd_ports(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
+                         const float* g_y, const float* g_y2, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
+                         float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training, float vth,
+                         int D, void* stream);
+
 /* The gradient of a GEMM-produced pre-activation as THREE bf16 PLANES hi | mid | lo (gz = hi + mid + lo to 2^-24; plane p at
  * gz_split + p * N C L): s2f_bn_act_bwd_split is s2f_bn_act_bwd writing that form instead of fp32 (6 instead of 4 bytes per
  * element), s2f_pgemm_dx_split the input-gradient product reading it (plane p of batch b at G_split + p * plane_stride +

@@ -101,6 +101,8 @@ SIGNATURES = {
     "s2f_pgemm_dx_f32_stats": (_i, [_p, _p, _i64, _p, _i64, _p] + [_i] * 4 + [_p]),
     "s2f_bn_partials_finalize": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "s2f_bn_act_bwd_split": (_i, [_p] * 13 + [_i64] * 3 + [_i, _f, _i, _p]),
+    "s2f_bn_act_bwd_ports": (_i, [_p] * 14 + [_i64] * 3 + [_i, _f, _i, _p]),
+    "s2f_bn_bwd_ports_ok": (_i, [_i64, _i64, _i64, _i, _i]),
     "s2f_mask_cost_bins": (_i, [_p, _p, _p, _i, _i, _i64, _i, _f, _f, _f, _p]),
     "s2f_mask_loss_seg_partials": (_i64, [_i] * 4),
     "s2f_mask_loss_seg_fwd": (_i, [_p] * 5 + [_i] * 4 + [_f, _f, _p]),

@@ -822,7 +822,8 @@ template <bool GU, bool GY, bool GV>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ stat,
     const float* __restrict__ g_u, const float* __restrict__ g_y, const float* __restrict__ g_v,
-    const uint64_t* __restrict__ mask, double* __restrict__ sums, int N, int C, int L, int slice, float vth, float Df) {
+    const uint64_t* __restrict__ mask, double* __restrict__ sums, int N, int C, int L, int slice, float vth, float Df,
+    const float* __restrict__ g_y2) {          // g_y2?: a second reader's gradient of the spike map, summed here (s2f_bn_act_bwd_ports)
   const int c = blockIdx.x, lane = threadIdx.x & 63, wv = wave_id_uniform();
   const int l0 = blockIdx.y * slice, l1 = min(L, l0 + slice);
   const float b = bias ? bias[c] : 0.0f, mean = stat[c], rstd = stat[C + c];
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
     const int lo_first = (int)(e0 - (int64_t)t_first * 256);          // first valid element of the first tile
     const int hi_last = (int)(e1 - (int64_t)t_last * 256);            // end of the valid elements of the last tile
     for (uint32_t t0 = t_first + (uint32_t)wv; t0 <= t_last; t0 += kWaves * kRowUnroll) {
-      Tile4 zv[kRowUnroll], a[kRowUnroll], bb[kRowUnroll], cc[kRowUnroll];
+      Tile4 zv[kRowUnroll], a[kRowUnroll], bb[kRowUnroll], b2[kRowUnroll], cc[kRowUnroll];
       uint64_t mw[kRowUnroll][4];
       bool act[kRowUnroll];
 #pragma unroll
@@ -848,6 +849,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
           zv[u] = ld4(z + base);
           if (GU) a[u] = ld4(g_u + base);
           if (GY) bb[u] = ld4(g_y + base);
+          if (GY && g_y2) b2[u] = ld4(g_y2 + base);
           if (GV) cc[u] = ld4(g_v + base);
         }
         if ((GY || GV) && live) {
@@ -861,7 +863,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_rows_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool m = (GY || GV) ? __builtin_amdgcn_inverse_ballot_w64(mw[u][j]) : false;
-          const float gu = form_gu_rows<GU, GY, GV>(GU ? a[u].a[j] : 0.f, GY ? bb[u].a[j] : 0.f, GV ? cc[u].a[j] : 0.f, m, vth, inv_d);
+          const float gyv = GY ? ((g_y2 && act[u]) ? bb[u].a[j] + b2[u].a[j] : bb[u].a[j]) : 0.f;
+          const float gu = form_gu_rows<GU, GY, GV>(GU ? a[u].a[j] : 0.f, gyv, GV ? cc[u].a[j] : 0.f, m, vth, inv_d);
           const float xhat = ((zv[u].a[j] + b) - mean) * rstd;
           if (act[u]) {
             ps += gu;
@@ -881,13 +884,13 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, const double* __restrict__ sums,
     float* __restrict__ gz, float* __restrict__ g_res, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int64_t total, uint32_t ntiles, int C, uint32_t L, uint32_t chunk, double inv_count, int training, float vth, float Df,
-    unsigned short* __restrict__ gzs) {
+    unsigned short* __restrict__ gzs, const float* __restrict__ g_y2) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWaves + (uint32_t)wave_id_uniform();
   uint32_t t = wave * chunk;
   const uint32_t t_end = min(ntiles, t + chunk);
   const uint32_t tail = (uint32_t)(total - (int64_t)(ntiles - 1) * 256);
-  Tile4 zn, an, bn, cn;
+  Tile4 zn, an, bn, b2n, cn;
   uint64_t mn[4] = {0, 0, 0, 0};
   auto request = [&](uint32_t tile) __attribute__((always_inline)) {
     if (tile < t_end) {
@@ -896,6 +899,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
         zn = (S2F_BN_NT & 2) ? ld4_nt(z + base) : ld4(z + base);
         if (GU) an = (S2F_BN_NT & 2) ? ld4_nt(g_u + base) : ld4(g_u + base);
         if (GY) bn = (S2F_BN_NT & 2) ? ld4_nt(g_y + base) : ld4(g_y + base);
+        if (GY && g_y2) b2n = (S2F_BN_NT & 2) ? ld4_nt(g_y2 + base) : ld4(g_y2 + base);
         if (GV) cn = ld4(g_v + base);
       }
       if (GY || GV) {
@@ -924,7 +928,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_rows_kernel(
   const float inv_d = 1.0f / Df;
   for (; t < t_end; ++t) {
     const int64_t base = (int64_t)t * 256 + lane * 4;
-    const Tile4 zv = zn, a = an, bb = bn, cc = cn;
+    const Tile4 zv = zn, a = an, cc = cn;
+    Tile4 bb = bn;
+    if (GY && g_y2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb.a[j] += b2n.a[j];
+    }
     const uint64_t mw[4] = {mn[0], mn[1], mn[2], mn[3]};
     request(t + 1);
     const uint32_t bnd = L - w.off;
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ g_u, const float* __restrict__ g_y,
     const float* __restrict__ g_v, const uint64_t* __restrict__ mask, float* __restrict__ gz, float* __restrict__ g_res,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int L, double inv_count, float vth, float Df,
-    unsigned short* __restrict__ gzs, Bn2Bwd bn2) {
+    unsigned short* __restrict__ gzs, Bn2Bwd bn2, const float* __restrict__ g_y2) {
   __shared__ double red[2 * kFusedWaves];
   const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = L >> 8, tiles = N * tpr;
@@ -1188,6 +1197,11 @@ __global__ __launch_bounds__(kFusedBlock) void bn_fused_bwd_kernel(
     Tile4 bb, cc;
     uint64_t word = 0;
     if (GY) bb = (S2F_BN_NT & 16) ? ld4_nt(g_y + base) : ld4(g_y + base);
+    if (GY && g_y2) {
+      const Tile4 t2 = (S2F_BN_NT & 16) ? ld4_nt(g_y2 + base) : ld4(g_y2 + base);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb.a[j] += t2.a[j];
+    }
     if (GV) cc = ld4(g_v + base);
     if (GY || GV) word = mask[(base >> 8) * 4 + (lane & 3)];
 #pragma unroll
@@ -1918,7 +1932,10 @@ extern "C" int s2f_bn2_act_fwd(const float* z, const float* conv_bias, float* st
 static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* stat, const float* gamma, const float* g_u,
                            const float* g_y, const float* g_v, const uint64_t* mask, double* sums_zeroed, float* gz,
                            float* g_residual, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t L, int training,
-                           float vth, int D, void* stream, unsigned short* gzs, Bn2Bwd bn2 = Bn2Bwd{}) {
+                           float vth, int D, void* stream, unsigned short* gzs, Bn2Bwd bn2 = Bn2Bwd{}, const float* g_y2 = nullptr) {
+  S2F_REQUIRE(!g_y2 || (g_y && s2f_aligned16(g_y2) && !(training && (mid_rows_ok(N, C, L) || small_rows_ok(N, C, L))) &&
+                        ((training && single_pass_ok(N, C, L)) || rows_ok(N, C, L, D))),
+              S2F_EINVAL, "s2f_bn_act_bwd_ports: a second spike gradient only on the single-pass and row-walking kernels (s2f_bn_bwd_ports_ok)");
   S2F_REQUIRE(!bn2.gamma || (training && single_pass_ok(N, C, L) && bn2.dgamma && bn2.dbeta && !gzs), S2F_EINVAL,
               "s2f_bn2_act_bwd: the BatchNorm pair runs on the single-pass kernels only");
   const bool single = training && (single_pass_ok(N, C, L) || small_rows_ok(N, C, L) || mid_rows_ok(N, C, L));
@@ -1973,11 +1990,11 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
     if (bn2.gamma)                                                                                                        \
       S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc, true>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0,  \
                  s, z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C,        \
-                 (int)L, 1.0 / ((double)N * (double)L), vth, (float)D, gzs, bn2);                                         \
+                 (int)L, 1.0 / ((double)N * (double)L), vth, (float)D, gzs, bn2, g_y2);                                   \
     else                                                                                                                  \
       S2F_LAUNCH(true, true, (bn_fused_bwd_kernel<A, B, Cc>), dim3((unsigned)C), dim3(single_pass_threads(N, L)), 0, s, z,  \
                  conv_bias, stat, gamma, g_u, g_y, g_v, mask, gz, g_residual, dgamma, dbeta, (int)N, (int)C, (int)L,      \
-                 1.0 / ((double)N * (double)L), vth, (float)D, gzs, bn2);                                                 \
+                 1.0 / ((double)N * (double)L), vth, (float)D, gzs, bn2, g_y2);                                           \
   } while (0)
     const int combo = (g_u ? 4 : 0) | (g_y ? 2 : 0) | (g_v ? 1 : 0);
     switch (combo) {
@@ -2004,12 +2021,12 @@ static int bn_act_bwd_impl(const float* z, const float* conv_bias, const float* 
     const int rgrid = grid_rows<bn_bwd_apply_rows_kernel<A, B, Cc, AL>>(ntiles, 0, chunk, 4);                               \
     S2F_LAUNCH(false, true, (bn_bwd_apply_rows_kernel<A, B, Cc, AL>), dim3(rgrid), dim3(kBlock), 0, s, z, conv_bias, stat, \
                gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, total, ntiles, (int)C, (uint32_t)L, \
-               chunk, inv_count, training, vth, (float)D, gzs);                                                          \
+               chunk, inv_count, training, vth, (float)D, gzs, g_y2);                                                    \
   } while (0)
 #define S2F_BN_ROWS_BWD(A, B, Cc)                                                                                        \
   do {                                                                                                                   \
     S2F_LAUNCH(true, false, (bn_bwd_reduce_rows_kernel<A, B, Cc>), dim3((unsigned)C, S), dim3(kBlock), 0, s, z, conv_bias, \
-               stat, g_u, g_y, g_v, mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D);                     \
+               stat, g_u, g_y, g_v, mask, sums_zeroed, (int)N, (int)C, (int)L, slice, vth, (float)D, g_y2);               \
     if (aligned)                                                                                                         \
       S2F_BN_ROWS_APPLY(A, B, Cc, true);                                                                                 \
     else                                                                                                                 \
@@ -2054,6 +2071,23 @@ extern "C" int s2f_bn_act_bwd(const float* z, const float* conv_bias, const floa
   S2F_REQUIRE(gz, S2F_EINVAL, "s2f_bn_act_bwd: null gz");
   return bn_act_bwd_impl(z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, N, C, L,
                          training, vth, D, stream, nullptr);
+}
+
+// 1: s2f_bn_act_bwd_ports takes a second spike gradient for this shape (the kernels that carry the large maps and the 32 x 32 stage)
+extern "C" int s2f_bn_bwd_ports_ok(int64_t N, int64_t C, int64_t L, int training, int D) {
+  if (N <= 0 || C <= 0 || L <= 0) return 0;
+  if (training && (mid_rows_ok(N, C, L) || small_rows_ok(N, C, L))) return 0;
+  if (training && single_pass_ok(N, C, L)) return 1;
+  return rows_ok(N, C, L, D) ? 1 : 0;
+}
+
+extern "C" int s2f_bn_act_bwd_ports(const float* z, const float* conv_bias, const float* stat, const float* gamma,
+                                    const float* g_u, const float* g_y, const float* g_y2, const float* g_v, const uint64_t* mask,
+                                    double* sums_zeroed, float* gz, float* g_residual, float* dgamma, float* dbeta, int64_t N,
+                                    int64_t C, int64_t L, int training, float vth, int D, void* stream) {
+  S2F_REQUIRE(gz, S2F_EINVAL, "s2f_bn_act_bwd_ports: null gz");
+  return bn_act_bwd_impl(z, conv_bias, stat, gamma, g_u, g_y, g_v, mask, sums_zeroed, gz, g_residual, dgamma, dbeta, N, C, L,
+                         training, vth, D, stream, nullptr, Bn2Bwd{}, g_y2);
 }
 
 extern "C" int s2f_bn_act_bwd_split(const float* z, const float* conv_bias, const float* stat, const float* gamma,

@@ -145,7 +145,8 @@ class DCNv3_pytorch(nn.Module):
             _, x1 = conv_bn_act(self.dw_conv[0], x1, self.dw_conv[1], lif=self.offset_spike)
             # bug-compatible: the NCHW conv outputs are *reinterpreted* as [T*N, H, W, C'] (dcnv3.py:213-214)
             offset, _ = conv_bn_act(self.offset[0], x1, self.offset[1])
-            _, mask = conv_bn_act(self.mask[0], x1, self.mask[1], lif=self.mask_spike)
+            # (the second reader of offset_spike's map: its gradient travels on the spare handle, ops.Spikes.second)
+            _, mask = conv_bn_act(self.mask[0], x1.second() if isinstance(x1, ops.Spikes) else x1, self.mask[1], lif=self.mask_spike)
             return offset.reshape(T * N, H, W, -1), mask.reshape(T * N, H, W, -1)
 
         # the two chains share only `inp`: launched side by side when ops.BRANCH_STREAMS is set.  (Forking offset / mask once

@@ -64,20 +64,29 @@ class _BNAct(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # bf16 spikes: slot 1 carries the autograd handle, slot 4 the (non-differentiable) bf16 tensor
         ydata = z.new_empty(0)
+        tok2 = z.new_empty(0)          # bf16 spikes: a second handle for a second reader of the spike map (ops.Spikes.second)
         if bf16:
             ydata, y = y, _new_tok(z)
+            if cfg.FANOUT_PORTS:
+                tok2 = _new_tok(z)
         outs = [t if t is not None else z.new_empty(0) for t in (u, y, v_out)]
         ctx.mark_non_differentiable(border, ydata, *[o for o, t in zip(outs, (u, y, v_out)) if t is None])
-        return tuple(outs) + (border, ydata)
+        if tok2.numel() == 0:
+            ctx.mark_non_differentiable(tok2)
+        return tuple(outs) + (border, ydata, tok2)
 
     @staticmethod
-    def backward(ctx, g_u, g_y, g_v, g_border, _g_ydata):
+    def backward(ctx, g_u, g_y, g_v, g_border, _g_ydata, g_y2):
         z, conv_bias, gamma, stat, mask = ctx.saved_tensors
         N, C, L, training, D, vth, has_res, has_bias = ctx.cfg
 
         def prep(g):
             return None if (g is None or g.numel() == 0) else g.contiguous()
-        g_u, g_y, g_v = prep(g_u), prep(g_y), prep(g_v)
+        g_u, g_y, g_v, g_y2 = prep(g_u), prep(g_y), prep(g_v), prep(g_y2)
+        if g_y is None:
+            g_y, g_y2 = g_y2, None
+        if g_y2 is not None and not lib.s2f_bn_bwd_ports_ok(N, C, L, int(training), D):
+            g_y, g_y2 = g_y + g_y2, None          # (a kernel form without the second port: the add the autograd engine would have made)
         if g_u is None and g_y is None and g_v is None:
             return (None,) * 20
         dev = z.device
@@ -89,9 +98,9 @@ class _BNAct(torch.autograd.Function):
         # read z + incoming grads, write gz [, g_residual]
         alg = 4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None))
         _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd", alg)
-        check(lib.s2f_bn_act_bwd(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_v),
-                                 _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
-                                 int(training), vth, D, _stream()), "s2f_bn_act_bwd")
+        check(lib.s2f_bn_act_bwd_ports(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_y2), _ptr(g_v),
+                                       _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
+                                       int(training), vth, D, _stream()), "s2f_bn_act_bwd_ports")
         g_bias = None
         if has_bias:
             # train-mode BN removes any per-channel constant: d/d(bias) == 0 exactly -> no gradient tensor at all (None, a
@@ -111,10 +120,10 @@ def bn_act(z, conv_bias, gamma, beta, running_mean, running_var, nbt, training, 
         from .gemm import stats_of
         partials = stats_of(z)
     bf16 = bool(lif) and spikes_bf16_ok(D) and z.numel() % 4 == 0          # as ops.lif: consumers read bf16 spikes in 8-byte groups
-    u, y, v, border, ydata = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
-                                          momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16, partials)
+    u, y, v, border, ydata, tok2 = _BNAct.apply(z, conv_bias, gamma, beta, residual, v_in, running_mean, running_var, nbt, training,
+                                                momentum, eps, lif, want_pre, keep_v, D, vth, stats, bf16, partials)
     if lif:
-        y = Spikes(ydata, y) if bf16 else Spikes(y, None)
+        y = Spikes(ydata, y, tok2 if tok2.numel() else None) if bf16 else Spikes(y, None)
     out = (u if want_pre else None), (y if lif else None), (v if (lif and keep_v) else None)
     return out + (border,) if want_border else out
 

@@ -981,12 +981,12 @@ def test_bn_backward_presplit_planes_are_the_fp32_gradient(ops, monkeypatch, N, 
     r = torch.randn(N, C, L, generator=g).cuda().requires_grad_(True) if res else None
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")
     seen = {}
-    orig = lib.s2f_bn_act_bwd
+    orig = lib.s2f_bn_act_bwd_ports          # (what ops.bn_act's backward calls: s2f_bn_act_bwd + the second spike-gradient port)
 
     def both(*a):
         planes = torch.empty(3, N, C, L, dtype=torch.bfloat16, device="cuda")
-        a2 = list(a)
-        gz_ptr, dg_ptr, db_ptr = a2[9], a2[11], a2[12]
+        assert not a[6]                        # one reader here: no second gradient
+        a2 = list(a[:6] + a[7:])               # the argument list of s2f_bn_act_bwd / _split
         tmp = [torch.empty(C, device="cuda") for _ in range(2)]
         gres2 = torch.empty(N, C, L, device="cuda") if a2[10] else None
         ws = a2[8]
@@ -996,7 +996,7 @@ def test_bn_backward_presplit_planes_are_the_fp32_gradient(ops, monkeypatch, N, 
         check(lib.s2f_bn_act_bwd_split(*a2), "split")
         seen["planes"], seen["dg"], seen["db"], seen["gres"] = planes, tmp[0], tmp[1], gres2
         return orig(*a)
-    monkeypatch.setattr(lib, "s2f_bn_act_bwd", both)
+    monkeypatch.setattr(lib, "s2f_bn_act_bwd_ports", both)
     u, y, _ = ops.bn_act(z, None, gamma, beta, rm, rv, nbt if training else None, training, 0.1, 1e-5, residual=r, lif=lif,
                          want_pre=True)
     loss = (u * torch.randn(u.shape, generator=g).cuda()).sum()

@@ -316,3 +316,65 @@ def test_fanout_ports_sum_the_same_gradients_as_the_autograd_engine():
     print(f"ports on vs off: worst relative gradient difference {worst:.2e}; forward off vs off again "
           f"{(c0 - c0b).abs().max().item():.2e} / {(m0 - m0b).abs().max().item():.2e}, off vs on {(c0 - c1).abs().max().item():.2e} / "
           f"{(m0 - m1).abs().max().item():.2e}")
+
+
+@pytest.mark.parametrize("N,C,L", [(8, 16, 1024), (2, 32, 65536), (8, 3, 16800), (8, 8, 100), (2, 7, 1052)])
+def test_batchnorm_neuron_second_reader_port_is_the_engine_sum(N, C, L):
+    """Two readers of the spike map of a fused BatchNorm + neuron: with cfg.FANOUT_PORTS the second reader's gradient reaches the
+    backward kernels on the spare handle and is summed where g_y is read (single-pass and row-walking kernels; the other forms add on
+    the host) -- bit-identical to the autograd engine's own add, for z, gamma, beta and the residual."""
+    from spike2former_amd import ops
+    out = []
+    for on in (False, True):
+        was = ops.FANOUT_PORTS
+        ops.FANOUT_PORTS = on
+        try:
+            g = torch.Generator().manual_seed(N + C + L)
+            z = (torch.randn(N, C, L, generator=g) * 2 + 0.5).cuda().requires_grad_(True)
+            gamma = (torch.rand(C, generator=g) + 0.5).cuda().requires_grad_(True)
+            beta = torch.randn(C, generator=g).cuda().requires_grad_(True)
+            r = torch.randn(N, C, L, generator=g).cuda().requires_grad_(True)
+            rm, rv, nbt = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.zeros((), dtype=torch.int64, device="cuda")
+            u, y, _ = ops.bn_act(z, None, gamma, beta, rm, rv, nbt, True, 0.1, 1e-5, residual=r, lif=True, want_pre=True)
+            w0, w1, w2 = (torch.randn(u.shape, generator=g).cuda() for _ in range(3))
+            y2 = y.second()
+            assert (y2.tok is not y.tok) == (on and y.tok2 is not None)
+            ((u * w0).sum() + (y.float() * w1).sum() + (y2.float() * w2).sum()).backward()
+            out.append((z.grad.clone(), gamma.grad.clone(), beta.grad.clone(), r.grad.clone()))
+        finally:
+            ops.FANOUT_PORTS = was
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [1024, 4100, 1 << 20])
+def test_neuron_ports_are_the_engine_sums(n):
+    """ops.lif / ops.sum2_lif with a second reader and a residual branch on the input: ports on == ports off, bit for bit."""
+    from spike2former_amd import ops
+    out = []
+    for on in (False, True):
+        was = ops.FANOUT_PORTS
+        ops.FANOUT_PORTS = on
+        try:
+            g = torch.Generator().manual_seed(n)
+            x = (torch.randn(n, generator=g) * 3 + 1).cuda().requires_grad_(True)
+            w1, w2, w3 = (torch.randn(n, generator=g).cuda() for _ in range(3))
+            y, _, xs = ops.lif(x, None, 8, 1.0, False, None, spikes=True, skip=True)
+            ((y.float() * w1).sum() + (y.second().float() * w2).sum() + (xs * w3).sum()).backward()
+            res = [x.grad.clone()]
+            if n % 4 == 0:
+                B, C, L = 2, 4, n // 32
+                x3 = (torch.randn(4 * B, C, L, generator=g) * 3 + 1).cuda().requires_grad_(True)
+                pos = torch.randn(B, C, L, generator=g).cuda().requires_grad_(True)
+                e = torch.zeros(C).cuda()
+                ws = [torch.randn(4 * B, C, L, generator=g).cuda() for _ in range(5)]
+                yk, yv, xs3 = ops.sum2_lif(x3, e, pos, B, 8, 1.0, skip=True)
+                ((yk.float() * ws[0]).sum() + (yk.second().float() * ws[1]).sum() + (yv.float() * ws[2]).sum()
+                 + (yv.second().float() * ws[3]).sum() + (xs3 * ws[4]).sum()).backward()
+                res += [x3.grad.clone(), pos.grad.clone()]
+            out.append(res)
+        finally:
+            ops.FANOUT_PORTS = was
+    assert len(out[0]) == len(out[1])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
