@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 29
+#define S2F_ABI_VERSION 30
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -478,6 +478,10 @@ int s2f_upsample2x_fwd(const float* x, float* y, int64_t planes, int h, int w, v
  * where the masks are predicted at half the image resolution (every Spike2Former config).  No adjoint: inference only. */
 int s2f_upsample2x_sigmoid_fwd(const float* x, float* y, int64_t planes, int h, int w, void* stream);
 int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream);
+/* gx = adjoint(gy) + add  (add? [planes, h, w], NULL = absent): the pixel decoder's level map feeds the next level's up-sampling
+ * AND the transformer decoder (pixel_decoder.py:437-449, 466-471); the gradient the second reader sends back is summed here instead
+ * of by an add launch of the autograd engine. */
+int s2f_upsample2x_bwd_add(const float* gy, const float* add, float* gx, int64_t planes, int h, int w, void* stream);
 
 /* ---- batched transposition of the last two dimensions: x [B, R, C] -> y [B, C, R] (fp32) -----------------------------------
  * Replaces the `.permute(0, 1, 3, 4, 2)` / `.permute(0, 1, 4, 2, 3)` copies around the DCNv3 sampling core

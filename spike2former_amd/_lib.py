@@ -60,6 +60,7 @@ SIGNATURES = {
     "s2f_upsample2x_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_upsample2x_sigmoid_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_upsample2x_bwd": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "s2f_upsample2x_bwd_add": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_last2": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_scale_add_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_scale_add_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),

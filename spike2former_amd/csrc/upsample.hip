@@ -144,8 +144,9 @@ __device__ __forceinline__ float wgt(int o, int i, int in_size) {     // d out[o
   return r;
 }
 
+// (add?: the gradient a second reader of the up-sampling's INPUT sends back -- s2f_upsample2x_bwd_add -- summed into the result)
 __global__ __launch_bounds__(256) void up2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t planes,
-                                                       int h, int w) {
+                                                       int h, int w, const float* __restrict__ add) {
   const int W = 2 * w, H = 2 * h;
   const int64_t total = planes * h * w;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(const float* __restrict__
       }
       acc += wy * s;
     }
-    gx[idx] = acc;
+    gx[idx] = add ? acc + add[idx] : acc;
   }
 }
 
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(const float* __restrict__
 // where at the plane's first / last index the missing outer tap's weight moves to the inner one (the clamped source index
 // of the forward: out[0] = in[0], out[2w-1] = in[w-1]).
 __global__ __launch_bounds__(256) void up2x_bwd_block_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                             int64_t planes, int h, int w) {
+                                                             int64_t planes, int h, int w, const float* __restrict__ add) {
   const int W = 2 * w, H = 2 * h;
   const int qw = w / 4, qh = h / 2;
   const uint32_t cells = (uint32_t)qh * (uint32_t)qw;                 // grid (ceil(cells / 256), plane groups), as the forward
@@ -215,6 +216,12 @@ __global__ __launch_bounds__(256) void up2x_bwd_block_kernel(const float* __rest
       }
     }
     float* o = gx + (p * h + iy) * w + ix0;
+    if (add) {
+      const float* q = add + (p * h + iy) * w + ix0;
+      const float4 a0 = *reinterpret_cast<const float4*>(q), a1 = *reinterpret_cast<const float4*>(q + w);
+      acc0[0] += a0.x, acc0[1] += a0.y, acc0[2] += a0.z, acc0[3] += a0.w;
+      acc1[0] += a1.x, acc1[1] += a1.y, acc1[2] += a1.z, acc1[3] += a1.w;
+    }
     *reinterpret_cast<float4*>(o) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
     *reinterpret_cast<float4*>(o + w) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
   }
@@ -369,15 +376,19 @@ extern "C" int s2f_upsample2x_sigmoid_fwd(const float* x, float* y, int64_t plan
   return s2f_check_launch("s2f_upsample2x_sigmoid_fwd");
 }
 
-extern "C" int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream) {
+extern "C" int s2f_upsample2x_bwd_add(const float* gy, const float* add, float* gx, int64_t planes, int h, int w, void* stream) {
   S2F_REQUIRE(gy && gx, S2F_EINVAL, "s2f_upsample2x_bwd: null pointer");
   S2F_REQUIRE(planes > 0 && h > 0 && w > 0, S2F_EINVAL, "s2f_upsample2x_bwd: bad shape");
-  if ((w & 3) == 0 && (h & 1) == 0 && s2f_aligned16(gy) && s2f_aligned16(gx))
+  if ((w & 3) == 0 && (h & 1) == 0 && s2f_aligned16(gy) && s2f_aligned16(gx) && s2f_aligned16(add))
     hipLaunchKernelGGL(up2x_bwd_block_kernel, plane_grid((int64_t)(h / 2) * (w / 4), planes), dim3(256), 0, (hipStream_t)stream,
-                       gy, gx, planes, h, w);
+                       gy, gx, planes, h, w, add);
   else
-    hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, (hipStream_t)stream, gy, gx, planes, h, w);
+    hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, (hipStream_t)stream, gy, gx, planes, h, w, add);
   return s2f_check_launch("s2f_upsample2x_bwd");
+}
+
+extern "C" int s2f_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int h, int w, void* stream) {
+  return s2f_upsample2x_bwd_add(gy, nullptr, gx, planes, h, w, stream);
 }
 
 extern "C" int s2f_mask_loss_fwd(const float* pred, const uint8_t* tgt, const int64_t* gt_index, float* sums, int64_t P, int h,

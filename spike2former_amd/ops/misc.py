@@ -149,28 +149,48 @@ def mean_all(x):
 
 # ------------------------------------------------------------------------------------------------ 2x bilinear up-sampling
 class _Up2x(torch.autograd.Function):
+    """-> (up-sampled map, pass-through of x or an empty stand-in): the pass-through serves a second reader of x; the gradient it
+    sends back is summed inside the adjoint kernel (s2f_upsample2x_bwd_add) instead of by an add of the autograd engine."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip):
         _need_cuda(x)
+        x_in = x
         x = x.contiguous()
         N, C, h, w = x.shape
         y = torch.empty(N, C, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
         check(lib.s2f_upsample2x_fwd(_ptr(x), _ptr(y), N * C, h, w, _stream()), "s2f_upsample2x_fwd")
         ctx.shape = (N, C, h, w)
-        return y
+        ctx.set_materialize_grads(False)
+        if skip:
+            return y, x_in
+        aux = x.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return y, aux
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip):
         N, C, h, w = ctx.shape
+        if gy is None:
+            return gskip, None
         gy = gy.contiguous()
+        if gskip is not None:
+            gskip = gskip.contiguous()
         gx = torch.empty(N, C, h, w, dtype=torch.float32, device=gy.device)
-        check(lib.s2f_upsample2x_bwd(_ptr(gy), _ptr(gx), N * C, h, w, _stream()), "s2f_upsample2x_bwd")
-        return gx
+        check(lib.s2f_upsample2x_bwd_add(_ptr(gy), _ptr(gskip), _ptr(gx), N * C, h, w, _stream()), "s2f_upsample2x_bwd_add")
+        return gx, None
 
 
-def upsample_bilinear(x, size, sigmoid=False):
+def upsample_bilinear(x, size, sigmoid=False, skip=False):
     """F.interpolate(x, size, mode='bilinear', align_corners=False); the exact-2x case runs the HIP kernel.  `sigmoid`: followed by
-    .sigmoid() -- inside the same pass where no gradient is wanted (the inference post-processing)."""
+    .sigmoid() -- inside the same pass where no gradient is wanted (the inference post-processing).
+    `skip`: -> (y, x') with x' = x for a second reader of x, whose gradient the adjoint kernel then sums (cfg.FANOUT_PORTS; x' is x
+    itself where that does not apply)."""
+    if skip:
+        h, w = x.shape[-2:]
+        if cfg.FANOUT_PORTS and tuple(size) == (2 * h, 2 * w) and w % 2 == 0 and x.dim() == 4 and x.is_cuda and not sigmoid:
+            return _Up2x.apply(x, True)
+        return upsample_bilinear(x, size, sigmoid), x
     h, w = x.shape[-2:]
     if tuple(size) == (2 * h, 2 * w) and w % 2 == 0:
         if sigmoid and w % 4 == 0 and x.dim() == 4 and not (torch.is_grad_enabled() and x.requires_grad):
@@ -180,7 +200,7 @@ def upsample_bilinear(x, size, sigmoid=False):
             y = torch.empty(N, C, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
             check(lib.s2f_upsample2x_sigmoid_fwd(_ptr(x), _ptr(y), N * C, h, w, _stream()), "s2f_upsample2x_sigmoid_fwd")
             return y
-        y = _Up2x.apply(x)
+        y = _Up2x.apply(x, False)[0]
         return y.sigmoid() if sigmoid else y
     fallback("upsample_bilinear", f"{(h, w)} -> {tuple(size)}")
     y = torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)

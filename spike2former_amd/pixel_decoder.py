@@ -97,10 +97,15 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
         memory = self.encoder.forward_nchw(y)          # == encoder(query=y.permute(0,1,3,4,2)).permute(0,1,4,2,3)
         memory = self.encoder_out_proj_spike.fire(memory)
         y = conv_bn(self.encoder_out_proj, memory.flatten(0, 1))[0]
-        out = [y.reshape(t, bs, E, h, w)]
+        out = []
 
-        def level(i, y):
-            up = ops.upsample_bilinear(y, feats[i].shape[-2:])
+        # A level map y has two readers: the next (finer) level's up-sampling and the transformer decoder (`out`).  The decoder reads
+        # the pass-through the up-sampling hands back (ops.upsample_bilinear skip=True): its gradient is summed inside the up-sampling's
+        # adjoint kernel instead of by an add launch of the autograd engine over the [T*B, C, H, W] map.
+        def level(i, y, keep=None):
+            up, through = ops.upsample_bilinear(y, feats[i].shape[-2:], skip=True)
+            if keep is not None:
+                keep.append(through.reshape(t, bs, *through.shape[1:]))
             if lat_eval:
                 x = self.lateral_convs_spike[i].fire(feats[i]).flatten(0, 1)
                 _, s = conv_bn_act(self.lateral_convs[i][0], x, self.lateral_convs[i][1], residual=up, lif=self.output_convs_spike[i])
@@ -114,8 +119,7 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
             return conv_bn(self.output_convs[i], s, next_lif=self.mask_feature_spike if i == 0 else None)[0]
 
         for i in range(self.num_inputs - 2, 0, -1):
-            y = level(i, y)
-            out.append(y.reshape(t, bs, *y.shape[1:]))
+            y = level(i, y, out)          # (appends the map that entered this level)
 
         # The H/2 level and the mask_feature convolution (the largest maps of the head) feed only the mask einsum at the very
         # end: as a branch on the side stream they overlap with the transformer decoder; the head joins it (mask_feature_handle).
@@ -124,7 +128,7 @@ class DCNTransformerEncoderPixelDecoder(nn.Module):
                 and mfc.in_channels % 32 == 0 and not self.mask_feature_spike._forward_hooks)
 
         def finest(y=y):
-            y0 = level(0, y)
+            y0 = level(0, y, out)          # (the pass-through is a view of y: nothing of it is computed on the side stream)
             s0 = self.mask_feature_spike.fire(y0)
             if fold and isinstance(s0, ops.Spikes) and s0.tok is not None and (s0.shape[-1] * s0.shape[-2]) % 8 == 0:
                 return s0
