@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 30
+#define S2F_ABI_VERSION 31
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -308,6 +308,9 @@ int s2f_pgemm_nn_bf16_ex(const uint16_t* a_pack, int64_t a_batch_stride, const u
                          int M, int N, int K, void* stream);
 int s2f_spike_gemm_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int K, int L, int accumulate,
                            void* stream);
+/* Implicit 3x3 weight gradient (stride 1, padding 1).  accumulate: bit 0 = add into dW (otherwise dW is zeroed first); bit 1 = dW in
+ * the WEIGHT's layout [M][C][3][3] instead of the tap-major [M][3][3][C] the kernel contracts in -- with both bits the gradient goes
+ * straight into the parameter's slot of the flat gradient buffer (no zeroed staging tensor, no permuted add). */
 int s2f_spike_conv3x3_dw_bf16(const float* dY, const uint16_t* X, float* dW, int batch, int M, int C, int H, int W,
                               int accumulate, void* stream);
 /* MANY weight gradients in one launch.  jobs: HOST array of njobs (<= 56) records {dY, X, dW (device pointers), batch, M, K,
@@ -336,7 +339,8 @@ int s2f_spike_gemm_dw_pipe_grouped(const int64_t* jobs, int njobs, int cfg, int 
  * reads the horizontal taps from Xs, a copy of the activation shifted by one element behind an 8-element front pad (s2f_shift1_bf16:
  * Xs holds n + 16 elements, Xs[8 + i] = X[i + 1] for i = -1 .. n - 2, zeros elsewhere; n % 8 == 0),
  * and zeroes in the fragments what the zero padding would have supplied.  jobs (HOST array): njobs x {dY, X, Xs, dW (pointers),
- * batch, M, C, H, W} as int64; every dW is accumulated into.  Needs C % 32 == 0, W % 8 == 0, W >= 32, H W % 32 == 0, B C H W 2 < 2^31
+ * batch, M, C, H, W} as int64; every dW is accumulated into; cfg bit 0 = the probe schedule of s2f_spike_gemm_dw_pipe, bit 1 = dW in
+ * the weight's layout [M][C][3][3] (as s2f_spike_conv3x3_dw_bf16's accumulate bit 1).  Needs C % 32 == 0, W % 8 == 0, W >= 32, H W % 32 == 0, B C H W 2 < 2^31
  * (s2f_spike_conv3x3_dw_pipe_ok).  Replaces the autograd weight gradient of MS_ConvBlock's dense 3x3 convolutions and of the stride-1
  * down-sampling (mmseg/models/backbones/sdtv2.py:183-219, 540-548). */
 int s2f_spike_conv3x3_dw_pipe_ok(int batch, int M, int C, int H, int W);

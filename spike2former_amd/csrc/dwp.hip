@@ -83,6 +83,7 @@ struct DwpConv {
   const unsigned short* Xs;
   int C, H, W;
   unsigned x_bytes;          // bytes of X (= of Xs): B C H W 2 < 2^31
+  int wl;                    // 1: dW in the weight's layout [M][C][3][3] (column (tap, c) of the tap-major product -> c * 9 + tap)
 };
 // RAG ("ragged"): L % 32 != 0 (L % 4 == 0) -- the 100-token layers of the decoder, the 50 x 84 maps of C5.  The last step of a batch
 // element runs past the end of the rows: the copies are range-checked against the whole tensors (B M L < 2^30, B K L < 2^31: the
@@ -370,10 +371,15 @@ __device__ __forceinline__ void dwp_body(const float* __restrict__ dY, const uns
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = k0 + wn * 64 + j * 32 + (lane & 31);
+      int colw = col;
+      if (CONV && cv.wl) {
+        const int tap = col / cv.C;
+        colw = (col - tap * cv.C) * 9 + tap;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
+        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + colw, acc[i][j][r]);
       }
     }
 }
@@ -581,8 +587,8 @@ extern "C" int s2f_shift1_bf16(const uint16_t* X, uint16_t* Xs, int64_t n, void*
 }
 
 // Implicit 3x3 weight gradients (stride 1, padding 1) on the pipelined kernel, many convolutions per launch: jobs (HOST array):
-// njobs x {dY, X, Xs, dW (pointers), batch, M, C, H, W}; dW [M][3][3][C] tap-major (as s2f_spike_conv3x3_dw_bf16), accumulated
-// into.  Xs = s2f_shift1_bf16(X).  Replaces the autograd weight gradient of MS_ConvBlock's dense 3x3 convolutions
+// njobs x {dY, X, Xs, dW (pointers), batch, M, C, H, W}; dW [M][3][3][C] tap-major (as s2f_spike_conv3x3_dw_bf16) or -- cfg & 2 --
+// [M][C][3][3], the weight's own layout (straight into the parameter's gradient slot), accumulated into.  Xs = s2f_shift1_bf16(X).  Replaces the autograd weight gradient of MS_ConvBlock's dense 3x3 convolutions
 // (mmseg/models/backbones/sdtv2.py:183-219) and of the stride-1 down-sampling (sdtv2.py:540-548).
 extern "C" int s2f_spike_conv3x3_dw_pipe(const int64_t* jobs, int njobs, int cfg, int target_wgs, void* stream) {
   S2F_REQUIRE(jobs && njobs > 0 && njobs <= kMaxConvJobs, S2F_EINVAL, "s2f_spike_conv3x3_dw_pipe: 1 .. %d jobs", kMaxConvJobs);
@@ -604,6 +610,7 @@ extern "C" int s2f_spike_conv3x3_dw_pipe(const int64_t* jobs, int njobs, int cfg
                 "s2f_spike_conv3x3_dw_pipe: job %d misaligned", i);
     cj.j.K = 9 * C, cj.j.L = H * W, cj.j.steps = B * (cj.j.L >> 5);
     cj.cv.C = C, cj.cv.H = H, cj.cv.W = W, cj.cv.x_bytes = (unsigned)((int64_t)B * C * H * W * 2);
+    cj.cv.wl = (cfg & 2) ? 1 : 0;
     cj.j.k_tiles = (cj.j.K + TK - 1) / TK;
     cj.j.first_work = (int)work;
     work += (int64_t)((cj.j.M + TM - 1) / TM) * cj.j.k_tiles * cj.j.steps;
@@ -615,7 +622,7 @@ extern "C" int s2f_spike_conv3x3_dw_pipe(const int64_t* jobs, int njobs, int cfg
   const int wgs = (int)((work + quota - 1) / quota);
   tab.work = (int)work, tab.quota = quota;
   hipStream_t s = (hipStream_t)stream;
-  if (cfg == 1)
+  if (cfg & 1)
     S2F_LAUNCH(true, true, (dwp_conv_kernel<true>), dim3((unsigned)wgs), dim3(512), 0, s, tab);
   else
     S2F_LAUNCH(true, true, (dwp_conv_kernel<false>), dim3((unsigned)wgs), dim3(512), 0, s, tab);

@@ -444,10 +444,16 @@ __device__ __forceinline__ void dw_tile_body(const float* __restrict__ dY, const
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = k0 + wn * (NJ * 32) + j * 32 + (lane & 31);
+      // CONV, plane < 0: dW in the WEIGHT's layout [M][C][3][3] -- column (tap, c) of the tap-major product goes to c * 9 + tap
+      int colw = col;
+      if (CONV && plane < 0) {
+        const int tap = col / geo.C;
+        colw = (col - tap * geo.C) * 9 + tap;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + col, acc[i][j][r]);
+        if (row < M && col < K) atomicAdd(dW + (int64_t)row * K + colw, acc[i][j][r]);
       }
     }
 }
@@ -608,8 +614,9 @@ int dw_launch(const float* dY, const uint16_t* X, float* dW, int batch, int M, i
   S2F_REQUIRE(s2f_aligned16(dY) && (reinterpret_cast<uintptr_t>(X) & 7u) == 0, S2F_EALIGN,
               "s2f_spike_gemm_dw_bf16: dY must be 16-byte, X 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, s) != S2F_OK)
+  if (!(accumulate & 1) && s2f_zero_async(dW, sizeof(float) * (size_t)M * K, s) != S2F_OK)
     return s2f_check_launch("s2f_spike_gemm_dw_bf16 memset");
+  if (conv && (accumulate & 2)) plane = -1;          // the implicit 3x3 form writing the weight's own layout (see the kernel's epilogue)
   // tile / step / split choice: the measured model of gemm.hip's spike_dw_launch
   int tm = M <= 32 ? 32 : M <= 64 ? 64 : 128;
   if (tm == 128 && (int64_t)batch * L <= 16384 && (int64_t)M * K > 65536) tm = 64;

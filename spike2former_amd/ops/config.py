@@ -5,7 +5,7 @@ import os
 
 
 class Config:
-    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "FANOUT_PORTS", "GLUE_MODE", "STRICT_GLUE", "STRICT")
+    FIELDS = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "DEFER_DW", "DEFER_DW_MAX_CONTRACTION", "BRANCH_STREAMS", "LONG_STREAMS", "LONG_WHAT", "SPIKES_BF16", "SPIKE_GEMM_TERMS", "SPIKE_GEMM_ENABLED", "CONV3X3_IMPLICIT", "CONV3X3_IMPLICIT_MIN_PIXELS", "CONV3X3_DX_IMPLICIT", "CONV3X3_DX_MIN_PIXELS", "CONV3X3_DX_PIPE", "MASK_EINSUM_DW_GROUPED", "MASK_EINSUM_DE_MFMA", "MASK_FWD_PGEMM", "MASK_BWD_FOLDED", "SPIKE_GEMM_DW", "DW_PIPE", "DW_PIPE_SINGLE", "DW_PIPE_CONV", "DWP_SCHEDULE", "DWP_WGS", "SPIKE_GEMM_CHECK", "PGEMM", "PGEMM_DX", "PGEMM_MIN_N", "PGEMM_CONV", "BN_PARTIALS", "BN_PARTIALS_SINGLE", "BN2_FUSED", "LINEAR_TM", "DENSE_GROUPED", "RESPLIT_IN_GRAPH", "FANOUT_PORTS", "CONV_DW_DIRECT", "GLUE_MODE", "STRICT_GLUE", "STRICT")
     RUNTIME = ("KERNEL_EVENTS", "GRAD_SINKS", "WGRAD_STREAM", "BRANCH_STREAMS", "LONG_STREAMS")          # objects, not settings
 
     def __init__(self):
@@ -59,6 +59,10 @@ class Config:
         # for a residual branch; its backward kernel sums the gradients that arrive on them (otherwise the autograd engine launches an
         # add per fan-out: 75 per C2 step, 209 M elements)
         self.FANOUT_PORTS = os.environ.get("S2F_FANOUT_PORTS", "1") != "0"
+        # 1: the implicit 3x3 weight-gradient kernels store in the weight's layout, straight into the gradient slot, instead of a tap-major
+        # staging tensor + zero fill + permuted add (18 launches per C2 step).  MEASURED SLOWER and off: the partial tiles' atomics then
+        # hit addresses 36 bytes apart -- 39.07 / 39.09 vs 36.52 / 36.46 ms per step, same box (profiles/r06_ab_conv_dw_direct.txt)
+        self.CONV_DW_DIRECT = os.environ.get("S2F_CONV_DW_DIRECT", "0") != "0"
         # GLUE_MODE: the captured steps (graph.py) run their warm-up and capture under ops.GlueMode -- the residual aten calls of a step
         # (autograd's gradient accumulation, scalar multiples, sigmoid, copies, fills, small sums) on csrc/glue.hip instead of ATen;
         # STRICT_GLUE: an aten call that GlueMode cannot route and that touches a CUDA tensor is an error

@@ -246,7 +246,14 @@ class _ConvDense(torch.autograd.Function):
             K = w2d.shape[1]
             if ctx.implicit:
                 x = cols                                                  # the saved tensor is the activation itself
-                gt = torch.empty(M, 3, 3, C, dtype=torch.float32, device=gy.device)        # tap-major, as the kernel contracts
+                # bf16 spikes: the kernels store the gradient in the weight's own layout [M, C, 3, 3] (they contract tap-major) and add
+                # into the parameter's slot of the flat gradient buffer when there is one -- no zeroed staging tensor, no permuted add
+                sink = _sink_for(weight)
+                direct = xb and cfg.CONV_DW_DIRECT
+                if direct:
+                    gt = sink if sink is not None else torch.zeros(M, C, 3, 3, dtype=torch.float32, device=gy.device)
+                else:
+                    gt = torch.empty(M, 3, 3, C, dtype=torch.float32, device=gy.device)    # tap-major, as the kernel contracts
                 _time_next("spike_gemm_dw", 4 * N * H * W * (C + M), 2 * N * M * H * W * K,
                            moved=N * H * W * ((2 if xb else 4) * C + 4 * M))
                 if xb and cfg.DW_PIPE_CONV and M >= 128 and C >= 64 and lib.s2f_spike_conv3x3_dw_pipe_ok(N, M, C, H, W):
@@ -256,14 +263,19 @@ class _ConvDense(torch.autograd.Function):
                     import ctypes
                     xs = torch.empty(x.numel() + 16, dtype=x.dtype, device=x.device)
                     check(lib.s2f_shift1_bf16(_ptr(x), _ptr(xs), x.numel(), _stream()), "s2f_shift1_bf16")
-                    gt.zero_()
                     arr = (ctypes.c_int64 * 9)(_ptr(gy), _ptr(x), _ptr(xs), _ptr(gt), N, M, C, H, W)
-                    check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, cfg.DWP_SCHEDULE, cfg.DWP_WGS, _stream()), "s2f_spike_conv3x3_dw_pipe")
+                    if not direct:
+                        gt.zero_()
+                    check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, (cfg.DWP_SCHEDULE & 1) | (2 if direct else 0), cfg.DWP_WGS, _stream()),
+                          "s2f_spike_conv3x3_dw_pipe")
+                elif xb:
+                    check(lib.s2f_spike_conv3x3_dw_bf16(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 3 if direct else 0, _stream()),
+                          "s2f_spike_conv3x3_dw_bf16")
                 else:
-                    fn = lib.s2f_spike_conv3x3_dw_bf16 if xb else lib.s2f_spike_conv3x3_dw
-                    check(fn(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")
-                sink = _sink_for(weight)
-                if sink is not None:
+                    check(lib.s2f_spike_conv3x3_dw(_ptr(gy), _ptr(x), _ptr(gt), N, M, C, H, W, 0, _stream()), "s2f_spike_conv3x3_dw")
+                if direct:
+                    gw = None if sink is not None else gt
+                elif sink is not None:
                     sink.view(M, C, 3, 3).add_(gt.permute(0, 3, 1, 2))
                     gw = None
                 else:

@@ -378,3 +378,36 @@ def test_neuron_ports_are_the_engine_sums(n):
     assert len(out[0]) == len(out[1])
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,M,C,H,W", [(2, 128, 64, 8, 64), (1, 256, 32, 20, 168), (3, 130, 64, 4, 56), (2, 32, 128, 16, 16), (2, 64, 32, 8, 84)])
+def test_conv3x3_weight_gradient_in_the_weights_layout(B, M, C, H, W):
+    """Both implicit 3x3 weight-gradient kernels with the weight-layout option (dW [M, C, 3, 3], added into its destination): the same
+    value as the tap-major product permuted -- same products, same sums per element up to the order of the partial tiles' atomics --
+    against fp64 conv2d; accumulates onto what the destination holds."""
+    import ctypes
+    import torch.nn.functional as F
+    from spike2former_amd._lib import check, lib
+    from spike2former_amd.ops.core import _stream
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C)
+    x = (torch.randint(0, 9, (B, C, H, W), device="cuda", generator=g).float() / 8).to(torch.bfloat16)
+    gy = torch.randn(B, M, H, W, device="cuda", generator=g)
+    w = torch.zeros(M, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(gy.double())
+    wabs = torch.zeros(M, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wabs, None, 1, 1).backward(gy.abs().double())
+    scale = wabs.grad.clamp_min(1e-30)
+    base = torch.randn(M, C, 3, 3, device="cuda", generator=g)
+    out = base.clone()
+    check(lib.s2f_spike_conv3x3_dw_bf16(gy.data_ptr(), x.data_ptr(), out.data_ptr(), B, M, C, H, W, 3, _stream()), "conv3x3_dw_bf16")
+    assert (((out - base).double() - w.grad).abs() / scale).max().item() <= 4e-6
+    tap = torch.empty(M, 3, 3, C, device="cuda")
+    check(lib.s2f_spike_conv3x3_dw_bf16(gy.data_ptr(), x.data_ptr(), tap.data_ptr(), B, M, C, H, W, 0, _stream()), "conv3x3_dw_bf16")
+    assert ((tap.permute(0, 3, 1, 2).double() - w.grad).abs() / scale).max().item() <= 2e-6
+    if lib.s2f_spike_conv3x3_dw_pipe_ok(B, M, C, H, W):
+        xs = torch.empty(x.numel() + 16, dtype=x.dtype, device=x.device)
+        check(lib.s2f_shift1_bf16(x.data_ptr(), xs.data_ptr(), x.numel(), _stream()), "shift1")
+        out = base.clone()
+        arr = (ctypes.c_int64 * 9)(gy.data_ptr(), x.data_ptr(), xs.data_ptr(), out.data_ptr(), B, M, C, H, W)
+        check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, 2, 0, _stream()), "conv3x3_dw_pipe")
+        assert (((out - base).double() - w.grad).abs() / scale).max().item() <= 4e-6
