@@ -97,7 +97,7 @@ class _BNAct(torch.autograd.Function):
         ws = None if (training and lib.s2f_bn_single_pass(N, C, L)) else _take_zeroed(2 * C, dev)
         # read z + incoming grads, write gz [, g_residual]
         alg = 4 * z.numel() * (2 + (g_u is not None) + (g_y is not None) + (g_res is not None))
-        _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd", alg)
+        _time_next("bn_lif_bwd" if g_y is not None else "bn_bwd", alg, moved=alg + 4 * z.numel() * (g_y2 is not None))
         check(lib.s2f_bn_act_bwd_ports(_ptr(z), _ptr(conv_bias), _ptr(stat), _ptr(gamma), _ptr(g_u), _ptr(g_y), _ptr(g_y2), _ptr(g_v),
                                        _ptr(mask), _ptr(ws), _ptr(gz), _ptr(g_res), _ptr(dgamma), _ptr(dbeta), N, C, L,
                                        int(training), vth, D, _stream()), "s2f_bn_act_bwd_ports")

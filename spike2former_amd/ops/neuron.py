@@ -62,7 +62,7 @@ class _LIF(torch.autograd.Function):
         if gskip is not None:
             gskip = gskip.contiguous()
         gx = torch.empty_like(gy)
-        _time_next("lif_bwd", 12 * gy.numel())
+        _time_next("lif_bwd", 12 * gy.numel(), moved=(12 + 4 * (gy2 is not None) + 4 * bool(fold)) * gy.numel())
         check(lib.s2f_lif_bwd_ports(_ptr(gy), _ptr(gy2), _ptr(gv), _ptr(mask), _ptr(gskip) if fold else 0, _ptr(gx), gy.numel(), ctx.vth,
                                     ctx.D, _stream()), "s2f_lif_bwd_ports")
         gx_in = gx if (gskip is None or fold) else gx + gskip.view(gx.shape)
@@ -187,7 +187,7 @@ class _Sum2LIF(torch.autograd.Function):
         fold = gskip is not None and not ctx.needs_input_grad[1]
         if gskip is not None:
             gskip = gskip.contiguous()
-        _time_next("lif_bwd", 12 * like.numel())
+        _time_next("lif_bwd", 12 * like.numel(), moved=(12 + 4 * (gk2 is not None) + 4 * (gv2 is not None) + 4 * bool(fold)) * like.numel())
         check(lib.s2f_sum2_lif_bwd_ports(_ptr(gk), _ptr(gk2), _ptr(gv), _ptr(gv2), _ptr(mk), _ptr(mv), _ptr(gskip) if fold else 0,
                                          _ptr(gx), _ptr(gxk), like.numel(), ctx.D, _stream()), "s2f_sum2_lif_bwd_ports")
         ge = channel_sum(gx) if ctx.needs_input_grad[1] else None
