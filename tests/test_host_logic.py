@@ -203,3 +203,21 @@ def test_register_upstream_fills_the_reference_registries(monkeypatch):
         monkeypatch.setitem(sys.modules, pkg, None)
         monkeypatch.setitem(sys.modules, pkg + ".registry", None)
     assert s2f.register_upstream() == []
+
+
+def test_spike_map_handles_for_a_second_reader():
+    """ops.Spikes: `second()` hands out the producing neuron's spare autograd handle (cfg.FANOUT_PORTS: the backward kernel sums the
+    two readers' gradients) and keeps handing out that one to later readers; views carry both handles; without a spare handle the map
+    itself is returned (the autograd engine then adds, as before)."""
+    import torch
+    from spike2former_amd import ops
+    data = torch.zeros(2, 4, 8, dtype=torch.bfloat16)
+    tok, tok2 = torch.zeros(()).expand(2, 4, 8), torch.ones(()).expand(2, 4, 8)
+    s = ops.Spikes(data, tok, tok2)
+    assert s.second().tok is tok2 and s.second().second().tok is tok2 and s.second().data is data
+    v = s.view(8, 8)
+    assert v.tok.shape == (8, 8) and v.tok2.shape == (8, 8) and v.second().tok.shape == (8, 8)
+    assert float(v.second().tok.sum()) == 64.0 and float(v.tok.sum()) == 0.0
+    plain = ops.Spikes(data, tok)
+    assert plain.second() is plain and plain.flatten(0, 1).tok2 is None
+    assert ops.Spikes(data).second().tok is None
