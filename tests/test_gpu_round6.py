@@ -265,7 +265,9 @@ def test_glue_mode_routes_the_residual_aten_calls_of_a_step():
     assert g0.keys() == g1.keys()
     gscale = max(v.abs().max().item() for v in g0.values())
     for k in g0:
-        assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * (g0[k].abs().max().item() + 1e-3 * gscale), k
+        # the generators' metric (oracle/gen_golden.py): gradients that are mathematically zero (a bias in front of a BatchNorm) are pure
+        # rounding noise of size 1e-8 x the largest gradient, and the split-contraction atomics reorder it from run to run
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * (g0[k].abs().max().item() + 5e-3 * gscale), k
 
 
 def test_fanout_ports_sum_the_same_gradients_as_the_autograd_engine():
