@@ -29,7 +29,7 @@ extern "C" {
 #define S2F_EALIGN (-2)   /* pointer not aligned as required */
 #define S2F_ELAUNCH (-3)  /* hipLaunch / runtime error */
 
-#define S2F_ABI_VERSION 31
+#define S2F_ABI_VERSION 32
 #define S2F_STAT_SLOTS 256
 
 int s2f_version(void);
@@ -491,6 +491,10 @@ int s2f_upsample2x_bwd_add(const float* gy, const float* add, float* gx, int64_t
  * Replaces the `.permute(0, 1, 3, 4, 2)` / `.permute(0, 1, 4, 2, 3)` copies around the DCNv3 sampling core
  * (ops_dcnv3/modules/dcnv3.py:198-233; mmdet/models/layers/detr_layers.py:331-337).  x != y; B < 65536. */
 int s2f_transpose_last2(const float* x, float* y, int64_t B, int R, int C, void* stream);
+/* y = x^T + add  (add? of y's shape [B, C, R], NULL = absent): as the adjoint of a transposition whose SOURCE has a second reader --
+ * the decoder layer's result goes to the prediction stack and, transposed, to the next layer (detr_layers.py:556, maskformer_head.py:554-566)
+ * -- the second reader's gradient is summed here instead of by an add launch of the autograd engine. */
+int s2f_transpose_last2_add(const float* x, const float* add, float* y, int64_t B, int R, int C, void* stream);
 /* y[b][c][r] = q[b][c][r] + g[c] * x[b][r][c]  (x [B, R, C] token-major, q / y [B, C, R] channel-major, g [C]): the pixel decoder's
  * `query + gamma3 * ffn(query)` (detr_layers.py:336-337) with the FFN output's reinterpretation (mmcv_spike/transformer.py:829) as
  * one pass.  Backward: gx[b][r][c] = g[c] gy[b][c][r], gg[c] += sum gy[b][c][r] x[b][r][c] (gg zeroed by the caller; d/dq = gy).
@@ -665,6 +669,10 @@ int s2f_ew(int op, const void* a, const float* b, float* out, int ndim, const in
 /* up to eight contiguous fp32 pieces (each a multiple of 4 elements, 16-byte aligned) copied back to back into dst: torch.stack / cat along
  * the leading dimension as one launch; srcs / ns: HOST arrays of `count` entries */
 int s2f_copy_segments(float* dst, const void* const* srcs, const int64_t* ns, int count, void* stream);
+/* out = ((srcs[0] + srcs[1]) + srcs[2]) + ...  over n fp32 elements, 1 .. 16 addends (HOST array of device pointers), in the order given:
+ * the gradient of a tensor with MANY readers (the decoder's query position embedding: twelve neurons per step,
+ * mmcv_spike/transformer.py:597-638) in one launch and in the order the autograd engine would have accumulated it. */
+int s2f_sum_n(const void* const* srcs, int count, float* out, int64_t n, void* stream);
 int64_t s2f_reduce_sum_workspace(int64_t n_out, int64_t n_red);          /* floats of scratch for the call below */
 int s2f_reduce_sum(const float* a, float* out, float* workspace, int nd_o, const int64_t* size_o, const int64_t* sa_o, const int64_t* so,
                    int nd_r, const int64_t* size_r, const int64_t* sa_r, float scale, void* stream);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "s2f_upsample2x_bwd": (_i, [_p, _p, _i64, _i, _i, _p]),
     "s2f_upsample2x_bwd_add": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_last2": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "s2f_transpose_last2_add": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
+    "s2f_sum_n": (_i, [_p, _i, _p, _i64, _p]),
     "s2f_transpose_scale_add_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
     "s2f_transpose_scale_add_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),
     "s2f_spike_conv3x3_fwd": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p]),

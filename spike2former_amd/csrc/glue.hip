@@ -427,6 +427,37 @@ extern "C" int s2f_reduce_sum(const float* a, float* out, float* workspace, int 
   return s2f_check_launch("s2f_reduce_sum");
 }
 
+// out = ((src[0] + src[1]) + src[2]) + ...   (up to 16 equal-sized fp32 tensors, summed in the order given: the order in which the
+// autograd engine would have accumulated them, so the bits are the engine's)
+struct SumNArgs {
+  const float* src[16];
+  float* out;
+  long long n;
+  int count;
+};
+__global__ __launch_bounds__(kBlock) void sum_n_kernel(SumNArgs p) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (long long)gridDim.x * kBlock) {
+    float a = p.src[0][i];
+    for (int k = 1; k < p.count; ++k) a += p.src[k][i];
+    p.out[i] = a;
+  }
+}
+
+extern "C" int s2f_sum_n(const void* const* srcs, int count, float* out, int64_t n, void* stream) {
+  S2F_REQUIRE(srcs && out && count >= 1 && count <= 16 && n >= 0, S2F_EINVAL, "s2f_sum_n: 1 .. 16 addends");
+  if (n == 0) return S2F_OK;
+  SumNArgs p{};
+  for (int i = 0; i < count; ++i) {
+    S2F_REQUIRE(srcs[i], S2F_EINVAL, "s2f_sum_n: null addend %d", i);
+    p.src[i] = reinterpret_cast<const float*>(srcs[i]);
+  }
+  p.out = out, p.n = n, p.count = count;
+  long long blocks = (n + kBlock - 1) / kBlock;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(sum_n_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p);
+  return s2f_check_launch("s2f_sum_n");
+}
+
 extern "C" int s2f_copy_segments(float* dst, const void* const* srcs, const int64_t* ns, int count, void* stream) {
   S2F_REQUIRE(dst && srcs && ns && count >= 1 && count <= 8 && s2f_aligned16(dst), S2F_EINVAL, "s2f_copy_segments: 1 .. 8 pieces, 16-byte aligned destination");
   SegArgs p{};

@@ -11,13 +11,16 @@ namespace {
 
 constexpr int kT = 64;
 
+// add?: a tensor of y's shape summed into the result (s2f_transpose_last2_add: the gradient of a second reader of the transposed
+// tensor's source, ops.transpose_last2 skip=True)
 __global__ __launch_bounds__(256) void transpose_tiles_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C,
-                                                              int vec) {
+                                                              int vec, const float* __restrict__ add) {
   __shared__ float s[kT][kT + 1];
   const int64_t b = blockIdx.z;
   const int r0 = blockIdx.y * kT, c0 = blockIdx.x * kT;
   const float* xb = x + b * (int64_t)R * C;
   float* yb = y + b * (int64_t)R * C;
+  const float* ab = add ? add + b * (int64_t)R * C : nullptr;
   // load: thread -> (row i, 4 columns from j4)
   for (int e = threadIdx.x; e < kT * (kT / 4); e += 256) {
     const int i = e >> 4, j4 = (e & 15) * 4;
@@ -39,11 +42,16 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const float* __res
     const int c = c0 + j, r = r0 + i4;
     if (c >= C) continue;
     if (vec && r + 3 < R) {
-      *reinterpret_cast<float4*>(yb + (int64_t)c * R + r) = make_float4(s[i4][j], s[i4 + 1][j], s[i4 + 2][j], s[i4 + 3][j]);
+      float4 o = make_float4(s[i4][j], s[i4 + 1][j], s[i4 + 2][j], s[i4 + 3][j]);
+      if (ab) {
+        const float4 a = *reinterpret_cast<const float4*>(ab + (int64_t)c * R + r);
+        o.x += a.x, o.y += a.y, o.z += a.z, o.w += a.w;
+      }
+      *reinterpret_cast<float4*>(yb + (int64_t)c * R + r) = o;
     } else {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (r + u < R) yb[(int64_t)c * R + r + u] = s[i4 + u][j];
+        if (r + u < R) yb[(int64_t)c * R + r + u] = ab ? s[i4 + u][j] + ab[(int64_t)c * R + r + u] : s[i4 + u][j];
     }
   }
 }
@@ -138,13 +146,17 @@ extern "C" int s2f_transpose_scale_add_bwd(const float* gy, const float* x, cons
   return s2f_check_launch("s2f_transpose_scale_add_bwd");
 }
 
-extern "C" int s2f_transpose_last2(const float* x, float* y, int64_t B, int R, int C, void* stream) {
+extern "C" int s2f_transpose_last2_add(const float* x, const float* add, float* y, int64_t B, int R, int C, void* stream) {
   if (B == 0 || R == 0 || C == 0) return S2F_OK;
-  S2F_REQUIRE(x && y && x != y, S2F_EINVAL, "s2f_transpose_last2: null or aliased pointers");
+  S2F_REQUIRE(x && y && x != y && add != y, S2F_EINVAL, "s2f_transpose_last2: null or aliased pointers");
   S2F_REQUIRE(B > 0 && B < 65536 && R > 0 && C > 0, S2F_EINVAL, "s2f_transpose_last2: bad shape B=%lld R=%d C=%d",
               (long long)B, R, C);
-  const int vec = (R % 4 == 0) && (C % 4 == 0) && s2f_aligned16(x) && s2f_aligned16(y);
+  const int vec = (R % 4 == 0) && (C % 4 == 0) && s2f_aligned16(x) && s2f_aligned16(y) && s2f_aligned16(add);
   hipLaunchKernelGGL(transpose_tiles_kernel, dim3((C + kT - 1) / kT, (R + kT - 1) / kT, (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, x, y, R, C, vec);
+                     (hipStream_t)stream, x, y, R, C, vec, add);
   return s2f_check_launch("s2f_transpose_last2");
+}
+
+extern "C" int s2f_transpose_last2(const float* x, float* y, int64_t B, int R, int C, void* stream) {
+  return s2f_transpose_last2_add(x, nullptr, y, B, R, C, stream);
 }

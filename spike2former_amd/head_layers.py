@@ -477,7 +477,10 @@ class DetrTransformerDecoderLayer(nn.Module):
         (transformer.py:777,:781) needs the other layout -- one transposition in, one out."""
         # the three residual adds of the layer run inside the last BatchNorm kernel of each branch (residual=)
         fused = kv_spikes is not None or kv_projected is not None
-        ca = self.cross_attn(query=q_cm, key=key, value=value, query_pos=query_pos_cm, kv_channel_major=True,
+        # (query_pos_cm may come as a pair: one alias per reader -- cross-attention, self-attention -- of ops.fan_out, whose backward
+        # sums the position embedding's twelve gradients of a step in one launch)
+        pos_ca, query_pos_cm = query_pos_cm if isinstance(query_pos_cm, (tuple, list)) else (query_pos_cm, query_pos_cm)
+        ca = self.cross_attn(query=q_cm, key=key, value=value, query_pos=pos_ca, kv_channel_major=True,
                              kv_spikes=kv_spikes, kv_projected=kv_projected, query_channel_major=True,
                              residual_cm=q_cm if fused else None)
         q_cm = ca if fused else q_cm + ca
@@ -494,7 +497,12 @@ class DetrTransformerDecoderLayer(nn.Module):
             q_cm = sa(query=qp, key=qp, value=q_cm, kv_channel_major=True, query_channel_major=True, residual_cm=q_cm)[0]
         q_tm = ops.transpose_last2(q_cm)
         out = self.ffn(q_tm, identity=q_tm)
-        return out, (None if last else ops.transpose_last2(out))
+        if last:
+            return out, None
+        # `out` goes to the prediction stack AND, transposed, to the next layer: the stack reads the pass-through, whose gradient the
+        # transposition's adjoint sums (ops.transpose_last2 skip=True)
+        q_next, out = ops.transpose_last2(out, skip=True)
+        return out, q_next
 
 
 class DetrTransformerDecoder(nn.Module):

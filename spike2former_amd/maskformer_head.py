@@ -166,9 +166,10 @@ class MaskFormerHead(nn.Module):
             q_cm = query_feat.transpose(2, 3).contiguous()
             pos_cm = query_embed.transpose(1, 2).contiguous()
             n = self.num_transformer_decoder_layers
+            pos_of = ops.fan_out(pos_cm, 2 * n)          # one alias per reader (two per layer): their gradients are summed by one launch
             for i in range(n):
                 lv = i % nl
-                q_tm, q_cm = layers[i].forward_stream(q_cm, pos_cm, key=dec_key[lv], value=dec_in[lv], kv_spikes=kv_of[i],
+                q_tm, q_cm = layers[i].forward_stream(q_cm, (pos_of[2 * i], pos_of[2 * i + 1]), key=dec_key[lv], value=dec_in[lv], kv_spikes=kv_of[i],
                                                       kv_projected=kv_proj[i], last=i == n - 1)
                 out_dec.append(q_tm)
         else:

@@ -6,25 +6,77 @@ from .core import *          # noqa: F401,F403  (the shared plumbing: _ptr, _str
 
 
 # ------------------------------------------------------------------------------------------------ transposition
+import os as _os
+_SMALL_PORTS = _os.environ.get("S2F_FANOUT_SMALL", "1") != "0"          # A/B switch of the two ports on small decoder tensors
+
+
 class _TransposeLast2(torch.autograd.Function):
-    """x [B, R, C] -> [B, C, R], contiguous (the adjoint is the same kernel the other way round)."""
+    """x [B, R, C] -> [B, C, R], contiguous (the adjoint is the same kernel the other way round).  -> (x^T, pass-through of x or an
+    empty stand-in): the pass-through serves a second reader of x, whose gradient the adjoint sums (s2f_transpose_last2_add)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip):
         _need_cuda(x)
+        x_in = x
         x = x.contiguous()
         B, R, C = x.shape
         y = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
         check(lib.s2f_transpose_last2(_ptr(x), _ptr(y), B, R, C, _stream()), "s2f_transpose_last2")
-        return y
+        ctx.set_materialize_grads(False)
+        if skip:
+            return y, x_in
+        aux = x.new_empty(0)
+        ctx.mark_non_differentiable(aux)
+        return y, aux
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip):
+        if gy is None:
+            return gskip, None
         gy = gy.contiguous()
         B, C, R = gy.shape
         gx = torch.empty(B, R, C, dtype=torch.float32, device=gy.device)
-        check(lib.s2f_transpose_last2(_ptr(gy), _ptr(gx), B, C, R, _stream()), "s2f_transpose_last2")
-        return gx
+        if gskip is not None:
+            gskip = gskip.contiguous()
+        check(lib.s2f_transpose_last2_add(_ptr(gy), _ptr(gskip), _ptr(gx), B, C, R, _stream()), "s2f_transpose_last2_add")
+        return gx, None
+
+
+class _FanOut(torch.autograd.Function):
+    """x -> n aliases of x, one per reader; backward: the readers' gradients summed by ONE launch (s2f_sum_n) in the order the autograd
+    engine would have accumulated them (last reader first) -- instead of n - 1 add launches (cfg.FANOUT_PORTS; the decoder's query
+    position embedding has twelve readers per step)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g.contiguous() for g in reversed(gs) if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        import ctypes
+        out = torch.empty_like(live[0])
+        while len(live) > 1:          # (16 addends per launch)
+            part = live[:16]
+            arr = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
+            check(lib.s2f_sum_n(arr, len(part), _ptr(out), out.numel(), _stream()), "s2f_sum_n")
+            live = [out] + live[16:]
+            if len(live) > 1:
+                out = torch.empty_like(out)
+        return live[0], None
+
+
+def fan_out(x, n):
+    """-> n tensors that are x, for n readers whose gradients one launch sums (float32 CUDA tensors with cfg.FANOUT_PORTS; otherwise
+    x itself n times: the autograd engine adds)"""
+    if n > 1 and cfg.FANOUT_PORTS and _SMALL_PORTS and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled():
+        return list(_FanOut.apply(x, n))
+    return [x] * n
 
 
 class _TransposeScaleAdd(torch.autograd.Function):
@@ -61,14 +113,20 @@ def transpose_scale_add(x, q, g):
     return torch.addcmul(q, transpose_last2(x).view(q.shape), g.view(*([1] * (q.dim() - 2)), C, 1))
 
 
-def transpose_last2(x):
+def transpose_last2(x, skip=False):
     """x [..., R, C] (fp32, CUDA) -> contiguous [..., C, R]: the `.permute(...).contiguous()` copies around the DCNv3 sampling
-    core as one tiled kernel (s2f_transpose_last2)."""
+    core as one tiled kernel (s2f_transpose_last2).  `skip`: -> (x^T, x') with x' = x for a second reader of x, whose gradient the
+    adjoint kernel sums (cfg.FANOUT_PORTS; x' is x itself where that does not apply)."""
     lead = x.shape[:-2]
     R, C = x.shape[-2:]
     if x.dtype != torch.float32 or x.numel() == 0:
-        return x.transpose(-1, -2).contiguous()
-    return _TransposeLast2.apply(x.reshape(-1, R, C)).view(*lead, C, R)
+        y = x.transpose(-1, -2).contiguous()
+        return (y, x) if skip else y
+    if skip and cfg.FANOUT_PORTS and _SMALL_PORTS and x.is_cuda:
+        y, through = _TransposeLast2.apply(x.reshape(-1, R, C), True)
+        return y.view(*lead, C, R), through.view(x.shape)
+    y = _TransposeLast2.apply(x.reshape(-1, R, C), False)[0].view(*lead, C, R)
+    return (y, x) if skip else y
 
 
 # ------------------------------------------------------------------------------------------------ reductions / fills (csrc/glue.hip)

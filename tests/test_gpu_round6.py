@@ -413,3 +413,32 @@ def test_conv3x3_weight_gradient_in_the_weights_layout(B, M, C, H, W):
         arr = (ctypes.c_int64 * 9)(gy.data_ptr(), x.data_ptr(), xs.data_ptr(), out.data_ptr(), B, M, C, H, W)
         check(lib.s2f_spike_conv3x3_dw_pipe(arr, 1, 2, 0, _stream()), "conv3x3_dw_pipe")
         assert (((out - base).double() - w.grad).abs() / scale).max().item() <= 4e-6
+
+
+def test_transpose_pass_through_and_fan_out_are_the_engine_sums():
+    """ops.transpose_last2(skip=True) and ops.fan_out: the second reader's gradient summed inside the transposition's adjoint, the
+    gradients of n readers summed by one launch in the engine's accumulation order -- ports on == ports off, bit for bit."""
+    from spike2former_amd import ops
+    out = []
+    for on in (False, True):
+        was = ops.FANOUT_PORTS
+        ops.FANOUT_PORTS = on
+        try:
+            g = torch.Generator().manual_seed(3)
+            x = torch.randn(8, 100, 256, generator=g).cuda().requires_grad_(True)
+            w1, w2 = torch.randn(8, 256, 100, generator=g).cuda(), torch.randn(8, 100, 256, generator=g).cuda()
+            y, xs = ops.transpose_last2(x, skip=True)
+            ((y * w1).sum() + (xs * w2).sum()).backward()
+            p = torch.randn(2, 256, 100, generator=g).cuda().requires_grad_(True)
+            ws = [torch.randn(2, 256, 100, generator=g).cuda() for _ in range(12)]
+            fans = ops.fan_out(p, 12)
+            assert len(fans) == 12 and all(torch.equal(f, p) for f in fans)
+            loss = 0
+            for f, w in zip(fans, ws):          # readers in forward order: the engine accumulates their gradients last reader first
+                loss = loss + (f * w).sum()
+            loss.backward()
+            out.append((x.grad.clone(), p.grad.clone()))
+        finally:
+            ops.FANOUT_PORTS = was
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
